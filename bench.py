@@ -1,0 +1,210 @@
+#!/usr/bin/env python3
+"""bench.py -- iLQR iterations/sec on the keypoint-iLQR hot path (BASELINE.json metric).
+
+One "step" = one whole GPU-side iLQR iteration for every trajectory of the batch:
+    fd_difference (a2) -> interpolate (a4) -> cost_derivs (a6) -> backward pass (a7, one pass at a
+    valid lambda) -> linearised forward pass over the 6 line-search alphas (a8)
+with all inputs (host FD results, residuals and their Jacobians, nominal controls) already resident
+in HBM when the timed region starts.  Workload (N=1 and per rank for N>1, weak scaling): Franka Panda
+7-DoF reaching, T=3000, set-interval key-points every 5 steps, batch=1024 independent trajectories
+(BASELINE configs[3]; configs[1] is the same problem at batch=1: `--batch 1`).
+
+    python bench.py --gpus N --steps K --warmup W
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...
+
+Rank 0 prints ONE JSON line.  Extra objects: "roofline" (dominant kernel = backward pass, HIP-event
+timed on the launch stream) and "cpu_baseline" (the CPU oracle = line-faithful port of the
+reference, timed on this box's host cores; rank 0, N=1 only).
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+
+HBM_PEAK_GBS = 8000.0   # MI355X HBM3E spec peak (/opt/skills/guides/MI355X_MICROARCH.md)
+
+
+def algorithmic_bytes(dof, m, nr, T, Kp, n_alpha):
+    """compulsory FP64 stage I/O per trajectory-iteration."""
+    n = 2 * dof
+    return dict(
+        fd_difference=8 * Kp * ((2 * dof + m) * 2 * n + (n * n + n * m)),
+        interpolate=8 * (Kp * (n * n + n * m) + T * (n * n + n * m)),
+        cost_derivs=8 * ((T + 1) * nr * (1 + n + m) + T * (n + n * n + m + m * m)),
+        backward=8 * T * ((n * n + n * m + n + n * n + m + m * m) + (m * n + m)),
+        forward=8 * T * (n * n + n * m + m * n + m + n + n * n + m + m * m) + 8 * n_alpha,
+    )
+
+
+def cpu_baseline(task, T, min_N, n_traj_per_core=8):
+    """Times the CPU oracle (oracle/kpilqr_oracle.c, -O3 -march=native) on this host: the same five
+    stages, independent trajectories spread over all host cores with a thread pool (the C calls
+    release the GIL), mirroring the reference's hardware_concurrency() pools."""
+    from concurrent.futures import ThreadPoolExecutor
+    from oracle import oracle as orc
+    from oracle import pipeline
+    from trajoptkp_amd import synth
+    import tempfile
+    path = orc.build(native=True, out_dir=tempfile.mkdtemp(prefix="kpilqr_oracle_"))
+    orc._LIB = orc.lib(path)
+    cores = os.cpu_count() or 1
+    try:
+        cores = len(os.sched_getaffinity(0))
+    except Exception:
+        pass
+    uniq = 4
+    p = synth.make_problem(task=task, T=T, batch=uniq, min_N=min_N)
+    pipeline.run_trajectory(p, 0)                      # warm-up
+    t0 = time.perf_counter(); pipeline.run_trajectory(p, 1); t_single = time.perf_counter() - t0
+    n_traj = max(16, n_traj_per_core * cores)
+    t0 = time.perf_counter()
+    with ThreadPoolExecutor(cores) as ex:
+        list(ex.map(lambda i: pipeline.run_trajectory(p, i % uniq)["status"], range(n_traj)))
+    wall = time.perf_counter() - t0
+    return {"value": n_traj / wall, "unit": "trajectory-iterations/s", "cores": cores, "kind": "port",
+            "sample": f"{n_traj} trajectory-iterations ({task}, T={T}, key-points every {min_N}), {cores} threads; "
+                      f"single-thread: {1.0 / t_single:.2f} it/s",
+            "single_thread_value": 1.0 / t_single}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--batch", type=int, default=1024, help="trajectories per GPU")
+    ap.add_argument("--T", type=int, default=3000)
+    ap.add_argument("--min-N", type=int, default=5)
+    ap.add_argument("--task", default="panda_reaching")
+    ap.add_argument("--unique", type=int, default=8, help="distinct seeded trajectories, tiled to --batch")
+    ap.add_argument("--generic", action="store_true", help="force the generic (non-MFMA) kernels")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    args = ap.parse_args()
+
+    import torch
+    from trajoptkp_amd import Engine, synth
+
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs an MI355X: no HIP device visible (there is no CPU fallback)")
+    torch.cuda.set_device(local_rank)
+    dist = None
+    if world > 1:
+        import torch.distributed as dist
+        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+
+    B, T = args.batch, args.T
+    uniq = min(args.unique, B)
+    reps = (B + uniq - 1) // uniq
+    p = synth.make_problem(task=args.task, T=T, batch=uniq, min_N=args.min_N, first_b=rank * uniq)
+    if reps > 1:
+        p = synth.tile_problem(p, reps)
+    B = p["batch"]
+    stream = torch.cuda.current_stream()
+    eng = Engine(p["dof"], p["m"], T, p["nr"], batch=B, device=local_rank, stream=stream.cuda_stream,
+                 generic=args.generic)
+    synth.upload(eng, p)
+    lam = np.full(B, p["lam"])
+    alphas = np.array([(i / 6.0) ** 2 for i in range(1, 7)])
+    eng.backward(lam, 100, fetch=False)               # uploads lambda / alphas once
+    eng.forward_linear(alphas, fetch=False)
+    eng.sync()
+    Kp = len(p["kp_times"])
+    ab = algorithmic_bytes(p["dof"], p["m"], p["nr"], T, Kp, 6)
+
+    # line-search cost reduction across GPUs: [sum_b J_pred(alpha_1..6), sum_b delta_J, #valid] (8 doubles)
+    red = torch.zeros(8, dtype=torch.float64, device="cuda")
+    cost_view = torch.as_tensor(eng.device_array(9, (B, 6)), device="cuda")       # KPILQR_BUF_COST_PRED
+    dJ_view = torch.as_tensor(eng.device_array(10, (B,)), device="cuda")          # KPILQR_BUF_DELTA_J
+    st_view = torch.as_tensor(eng.device_array(11, (B,), "<i4"), device="cuda")   # KPILQR_BUF_STATUS
+
+    stages = ("fd_difference", "interpolate", "cost_derivs", "backward", "forward")
+
+    def one_step(events=None):
+        for i, name in enumerate(stages):
+            if events is not None:
+                events[i][0].record(stream)
+            if name == "fd_difference": eng.fd_difference()
+            elif name == "interpolate": eng.interpolate()
+            elif name == "cost_derivs": eng.cost_derivs()
+            elif name == "backward": eng.backward(None, 100, fetch=False)      # lambda stays resident
+            else: eng.forward_linear(None, fetch=False)                       # alphas stay resident
+            if events is not None:
+                events[i][1].record(stream)
+        if world > 1:
+            red[:6] = cost_view.sum(0); red[6] = dJ_view.sum(); red[7] = (st_view == 0).sum()
+            dist.all_reduce(red)
+
+    for _ in range(args.warmup):
+        one_step()
+    torch.cuda.synchronize()
+    if world > 1:
+        dist.barrier()
+    torch.cuda.synchronize()
+    evs = [[(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in stages]
+           for _ in range(args.steps)]
+    t0 = time.perf_counter()
+    for s in range(args.steps):
+        one_step(evs[s])
+    torch.cuda.synchronize()
+    if world > 1:
+        dist.barrier()
+    torch.cuda.synchronize()
+    elapsed = time.perf_counter() - t0
+    if world > 1:
+        tt = torch.tensor([elapsed], dtype=torch.float64, device="cuda")
+        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+        elapsed = float(tt.item())
+
+    stage_ms = {name: float(np.mean([evs[s][i][0].elapsed_time(evs[s][i][1]) for s in range(args.steps)]))
+                for i, name in enumerate(stages)}
+    res = eng.results()
+    n_ok = int((res["status"] == 0).sum())
+
+    if rank == 0:
+        total_traj = B * world
+        value = total_traj * args.steps / elapsed
+        dom = "backward"
+        achieved = ab[dom] * B / (stage_ms[dom] * 1e-3) / 1e9
+        out = {
+            "metric": "iLQR iterations/sec (Panda 7-DoF, T=3000)" if args.task == "panda_reaching" and T == 3000
+                      else f"iLQR iterations/sec ({args.task}, T={T})",
+            "value": value, "unit": "trajectory-iterations/s", "n_gpus": world, "steps": args.steps,
+            "warmup": args.warmup, "ms_per_step": 1e3 * elapsed / args.steps, "higher_is_better": True,
+            "scaling": "weak", "vs_baseline": None, "dtype": "f64", "data": "synthetic",
+            "config": {"workload": f"{args.task} T={T} set_interval({args.min_N}) keypoints={Kp} "
+                                   f"batch={B}/GPU ({uniq} distinct seeds tiled), 6 alphas, lambda={p['lam']}",
+                       "batch_per_gpu": B, "global_batch": total_traj, "horizon": T,
+                       "kernels": {"backward": eng.backward_variant, "forward": eng.forward_variant},
+                       "valid_backward_passes": n_ok, "parallelism": f"traj-shard x{world}"},
+            "batch_iterations_per_s": args.steps / elapsed,
+            "stage_ms": stage_ms,
+            "stage_algorithmic_GBps": {k: ab[k] * B / (stage_ms[k] * 1e-3) / 1e9 for k in stages},
+            "pipeline_algorithmic_GBps": sum(ab.values()) * B / (elapsed / args.steps) / 1e9,
+            "roofline": {"bound": "hbm", "kernel": f"backward ({eng.backward_variant})", "achieved": achieved,
+                         "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS, "traffic": None,
+                         "algorithmic_bytes_per_launch": ab[dom] * B, "avg_launch_ms": stage_ms[dom]},
+        }
+        if world == 1 and not args.no_cpu_baseline:
+            try:
+                out["cpu_baseline"] = cpu_baseline(args.task, T, args.min_N)
+                out["gpu_over_cpu"] = value / out["cpu_baseline"]["value"]
+            except Exception as ex:   # the baseline is reporting only; never hide the GPU number
+                out["cpu_baseline"] = {"error": repr(ex)}
+        print(json.dumps(out), flush=True)
+    eng.close()
+    if world > 1:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

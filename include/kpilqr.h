@@ -1,0 +1,169 @@
+/*
+ * kpilqr.h -- C ABI of libkpilqr.so: the MI355X (gfx950) engine for the numerical hot path of
+ * keypoint-interpolated iLQR.  It is the drop-in boundary for the reference DMackRus/TrajOptKP:
+ * a C++ `Optimiser` subclass (see INTEGRATION.md, and trajoptkp_amd/host/ for the one shipped
+ * here) forwards STEP 1b/1c/2/3 of iLQR::Iteration (src/Optimiser/iLQR.cpp:412-531) to these
+ * entry points; MuJoCo and the ModelTranslator stay on the host.
+ *
+ * The reference has no FFI of its own (its plugin surface is three C++ classes wired with
+ * shared_ptr in src/main.cpp:39-47,114-147); each entry point below names the reference
+ * function it replaces.  Paths are relative to the reference repository root.
+ *
+ * Conventions
+ *  - plain C, no torch / Eigen / HIP types in any signature; `stream` is a hipStream_t passed as
+ *    void* (NULL = the library creates its own non-blocking stream).
+ *  - all floating point data is FP64.  Host-side matrices use the reference's Eigen layout:
+ *    COLUMN-MAJOR per matrix, one matrix per time-step, time-major then batch-major:
+ *    A[b][t] at A + ((b*T + t)*n*n), element (r,c) at r + c*n.   n = 2*dof, m = num_ctrl.
+ *  - device buffers are owned by the context (internal layout: DESIGN.md section 3).
+ *  - every call returns int: 0 = ok, <0 = error (kpilqr_strerror), >0 = numerical status.
+ *    Calls that launch kernels are asynchronous on the context's stream; host output buffers
+ *    are valid after kpilqr_sync().  One context per (GPU, host thread); not re-entrant.
+ *  - the library FAILS LOUDLY (negative code) when no HIP device is present: there is no CPU
+ *    fallback inside it.
+ */
+#ifndef KPILQR_H
+#define KPILQR_H
+
+#include <stddef.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define KPILQR_VERSION 100   /* 0.1.0 */
+
+typedef struct kpilqr_ctx kpilqr_ctx;
+
+typedef struct {
+    int dof;       /* position DoFs of the optimiser's state vector (stateVectorList::dof)      */
+    int m;         /* num_ctrl                                                                  */
+    int T;         /* horizon_length                                                            */
+    int nr;        /* residual_list.size()                                                      */
+    int batch;     /* independent trajectories resident in this context                         */
+    int n_alpha;   /* num_parallel_rollouts, include/Optimiser/Optimiser.h:259 (6)              */
+    int device;    /* HIP device ordinal                                                        */
+    int flags;     /* KPILQR_FLAG_*                                                             */
+} kpilqr_dims;
+
+#define KPILQR_FLAG_GENERIC_KERNELS 1   /* force the dimension-generic LDS kernels (no MFMA path) */
+
+enum {
+    KPILQR_OK = 0,
+    KPILQR_ERR_ARG = -1,       /* bad argument / size mismatch (reference: setters return false) */
+    KPILQR_ERR_NO_DEVICE = -2, /* no HIP device / runtime failure at create                      */
+    KPILQR_ERR_HIP = -3,       /* a HIP call failed; see kpilqr_strerror                          */
+    KPILQR_ERR_ALLOC = -4,
+    KPILQR_ERR_STATE = -5      /* call order violated (e.g. interpolate before set_keypoints)     */
+};
+
+/* which device buffer kpilqr_device_ptr returns */
+enum {
+    KPILQR_BUF_STEP_RECORDS = 0, /* [batch][T][rec] : A|B|l_xx|l_x|l_uu|l_u per step  */
+    KPILQR_BUF_K = 1,            /* [batch][T][n][m]  (column-major m x n, as Eigen)             */
+    KPILQR_BUF_k = 2,            /* [batch][T][m]                                                */
+    KPILQR_BUF_RESIDUALS = 3,    /* [batch][T+1][nr]                                             */
+    KPILQR_BUF_R_X = 4,          /* [batch][T+1][nr][n]                                          */
+    KPILQR_BUF_R_U = 5,          /* [batch][T+1][nr][m]                                          */
+    KPILQR_BUF_U_NOM = 6,        /* [batch][T][m]                                                */
+    KPILQR_BUF_FD_XPLUS = 7,     /* [jobs][n]                                                    */
+    KPILQR_BUF_FD_XMINUS = 8,    /* [jobs][n]                                                    */
+    KPILQR_BUF_COST_PRED = 9,    /* [batch][n_alpha]                                             */
+    KPILQR_BUF_DELTA_J = 10,     /* [batch]                                                      */
+    KPILQR_BUF_STATUS = 11       /* [batch] int32                                                */
+};
+
+/* ---- lifetime --------------------------------------------------------------------------
+ * Replaces iLQR::iLQR / iLQR::Resize allocation of A,B,l_*,K,k (src/Optimiser/iLQR.cpp:4-200). */
+int  kpilqr_create(const kpilqr_dims *dims, void *stream, kpilqr_ctx **out);
+void kpilqr_destroy(kpilqr_ctx *ctx);
+int  kpilqr_version(void);
+const char *kpilqr_strerror(kpilqr_ctx *ctx);       /* last error text of this context (or global) */
+int  kpilqr_get_dims(kpilqr_ctx *ctx, kpilqr_dims *out);
+
+/* Pinned host staging memory (the "one pinned hipMemcpyAsync" of the design). */
+int  kpilqr_host_alloc(kpilqr_ctx *ctx, size_t bytes, void **pinned);
+int  kpilqr_host_free(kpilqr_ctx *ctx, void *pinned);
+
+int  kpilqr_sync(kpilqr_ctx *ctx);
+int  kpilqr_device_ptr(kpilqr_ctx *ctx, int which, void **dptr, size_t *bytes);
+
+/* ---- STEP 1b: dynamics derivatives -------------------------------------------------------
+ * Key-points per DoF: kp_times[kp_offsets[b*dof+i] .. kp_offsets[b*dof+i+1]) = sorted time
+ * indices at which DoF i of trajectory b is finite-differenced (the transpose of the reference's
+ * std::vector<std::vector<int>> keypoints, include/KeyPointGenerator.h:85-100).  */
+int  kpilqr_set_keypoints(kpilqr_ctx *ctx, const int *kp_offsets, const int *kp_times);
+
+/* Host FD results, one job per perturbed column (Differentiator::DynamicsDerivatives,
+ * src/Differentiator/Differentiator.cpp:81-428 stays on the host and fills these):
+ *   job_b[j], job_t[j]   trajectory and time index of the key-point
+ *   job_col[j]           0..n-1 -> column of A (i: d/dqpos_i, i+dof: d/dqvel_i); n..n+m-1 -> column of B
+ *   job_mode[j]          0 central (x+ - x-)/(2 eps), 1 forward (x+ - xnom)/eps, 2 backward (xnom - x-)/eps
+ *   job_nom[j]           row of xnom holding the unperturbed next state (modes 1,2)
+ *   xplus, xminus        [njobs][n] tangent-space next states; xnom [nnom][n]
+ * One hipMemcpyAsync per array; host arrays should come from kpilqr_host_alloc. */
+int  kpilqr_upload_fd(kpilqr_ctx *ctx, int njobs, const int *job_b, const int *job_t,
+                      const int *job_col, const unsigned char *job_mode, const int *job_nom,
+                      const double *xplus, const double *xminus,
+                      int nnom, const double *xnom, double eps);
+/* Differencing tail of Differentiator::DynamicsDerivatives (:166-222,286-321,386-423,441-457):
+ * writes the key-point columns of A and B. */
+int  kpilqr_fd_difference(kpilqr_ctx *ctx);
+/* KeypointGenerator::InterpolateDerivatives (src/KeyPointGenerator/KeyPointGenerator.cpp:840-954). */
+int  kpilqr_interpolate(kpilqr_ctx *ctx);
+
+/* ---- STEP 1c: cost derivatives -----------------------------------------------------------
+ * Residuals and their host-side FD Jacobians (Differentiator::ResidualDerivatives stays on the
+ * host): r [batch][T+1][nr], r_x [batch][T+1][nr][n], r_u [batch][T+1][nr][m]; residual weights
+ * w_run / w_term [nr] (struct residual, include/StdInclude.h:82-88).  Any pointer may be NULL to
+ * keep what is already resident. */
+int  kpilqr_upload_residuals(kpilqr_ctx *ctx, const double *r, const double *r_x, const double *r_u,
+                             const double *w_run, const double *w_term);
+/* ModelTranslator::CostDerivativesFromResiduals (src/ModelTranslator/ModelTranslator.cpp:552-583)
+ * over the loop of Optimiser::ComputeCostDerivatives (src/Optimiser/Optimiser.cpp:202-211),
+ * including the terminal-weight re-write of t = T-1. */
+int  kpilqr_cost_derivs(kpilqr_ctx *ctx);
+/* ModelTranslator::CostFunction (:314-327) summed over the horizon as RolloutTrajectory does
+ * (src/Optimiser/iLQR.cpp:202-254): cost[b] = sum_{t<T-1} w_run.r_t^2 + w_term.r_{T-1}^2. */
+int  kpilqr_trajectory_cost(kpilqr_ctx *ctx, double *cost /*[batch]*/);
+
+/* ---- STEP 2: backward pass ----------------------------------------------------------------
+ * iLQR::BackwardsPassQuuRegularisation + CheckMatrixPD (src/Optimiser/iLQR.cpp:535-670).
+ * lambda [batch]; pd_check_stride = 100 in the reference.  status[b] = 0 ok, t+1 = first step
+ * whose Q_uu + lambda I failed the Cholesky test; delta_J [batch].  status / delta_J may be NULL
+ * (results stay on the device, KPILQR_BUF_STATUS / KPILQR_BUF_DELTA_J). */
+int  kpilqr_backward(kpilqr_ctx *ctx, const double *lambda, int pd_check_stride,
+                     int *status, double *delta_J);
+/* K [batch][T][n][m] (column-major m x n), k [batch][T][m]; either may be NULL. */
+int  kpilqr_download_gains(kpilqr_ctx *ctx, double *K, double *k);
+
+/* ---- STEP 3: forward pass over the line-search alphas ----------------------------------------
+ * Nominal controls U_old [batch][T][m] and ModelTranslator::ReturnControlLimits [2*m] = lo,hi pairs. */
+int  kpilqr_upload_nominal(kpilqr_ctx *ctx, const double *u_nom, const double *ctrl_lim);
+/* Control law + clamp of iLQR::ForwardsPassParallel (src/Optimiser/iLQR.cpp:876-890) on the
+ * linearised model, scored with the quadratic cost model (declared semantic change, DESIGN.md
+ * section 2).  alphas [n_alpha]; cost_pred [batch][n_alpha] = predicted cost CHANGE;
+ * U_alpha [batch][n_alpha][T][m] or NULL. */
+int  kpilqr_forward_linear(kpilqr_ctx *ctx, const double *alphas, double *cost_pred, double *U_alpha);
+
+/* ---- one whole iteration (STEP 1b + 1c + 2 + 3) enqueued back to back ------------------------ */
+int  kpilqr_iterate(kpilqr_ctx *ctx, const double *lambda, int pd_check_stride, const double *alphas);
+
+/* ---- debug / oracle hooks: inject or read the intermediates in the reference's layout -------
+ * (the reference exposes A, B, l_x ... as public members, include/Optimiser/Optimiser.h:194-211,
+ * and GenTestingData dumps them, src/GenTestingData.cpp:795-797).  NULL pointers are skipped. */
+int  kpilqr_set_AB(kpilqr_ctx *ctx, const double *A, const double *B);
+int  kpilqr_get_AB(kpilqr_ctx *ctx, double *A, double *B);
+int  kpilqr_set_cost_derivs(kpilqr_ctx *ctx, const double *l_x, const double *l_xx,
+                            const double *l_u, const double *l_uu);
+int  kpilqr_get_cost_derivs(kpilqr_ctx *ctx, double *l_x, double *l_xx, double *l_u, double *l_uu);
+
+/* Name of the kernel variant the backward / forward pass will launch for these dims
+ * ("mfma_f64_t1", "generic_lds", ...): for logs, tests and the bench's roofline line. */
+const char *kpilqr_backward_variant(kpilqr_ctx *ctx);
+const char *kpilqr_forward_variant(kpilqr_ctx *ctx);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

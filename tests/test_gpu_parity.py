@@ -1,0 +1,299 @@
+"""GPU parity tests: the HIP engine (through the C ABI, via trajoptkp_amd.Engine) against the CPU
+oracle on identical seeded inputs.
+
+Bars (BASELINE.json north_star / task brief):
+  * fd_difference, interpolate, cost_derivs, and the generic (reference-order) backward / forward
+    kernels: BIT-EXACT against the oracle (they are compiled with -ffp-contract=off and written in
+    the reference's operation order; src/tests/Keypoints_Test.cpp:273-289 pins a4 bitwise).
+  * MFMA backward pass: feedback gains K within 1e-6 relative (north_star); we assert 1e-9.
+  * MFMA forward pass: predicted costs within 1e-9 relative, controls within 1e-9.
+"""
+import numpy as np
+import pytest
+
+from oracle import oracle as orc
+from oracle import pipeline
+from trajoptkp_amd import Engine, synth
+
+pytestmark = pytest.mark.gpu
+
+K_RTOL = 1e-6          # north_star tolerance for the gains
+K_RTOL_TIGHT = 1e-9    # what we actually hold the MFMA kernel to
+
+
+def relerr(a, b):
+    return float(np.max(np.abs(a - b)) / max(float(np.max(np.abs(b))), 1e-300))
+
+
+def run_engine(p, generic=False, pd_stride=100, lam=None, want_U=True):
+    lam = p["lam"] if lam is None else lam
+    with Engine(p["dof"], p["m"], p["T"], p["nr"], batch=p["batch"], generic=generic) as e:
+        synth.upload(e, p)
+        e.fd_difference()
+        e.sync()
+        A_kp, B_kp = e.get_AB()
+        e.interpolate()
+        A, B = e.get_AB()
+        e.cost_derivs()
+        l_x, l_xx, l_u, l_uu = e.get_cost_derivs()
+        status, dJ = e.backward(lam, pd_stride)
+        K, k = e.gains()
+        cost, U = e.forward_linear(orc.alphas(6), want_U=True)
+        return dict(A_kp=A_kp, B_kp=B_kp, A=A, B=B, l_x=l_x, l_xx=l_xx, l_u=l_u, l_uu=l_uu, status=status,
+                    delta_J=dJ, K=K, k=k, cost_pred=cost, U_alpha=U,
+                    variants=(e.backward_variant, e.forward_variant))
+
+
+PROBLEMS = {
+    "panda_T64": dict(task="panda_reaching", T=64, batch=2, min_N=5, config_id=2, dense_residuals=True, one_sided_frac=0.15),
+    "acrobot_T100": dict(task="acrobot", T=100, batch=1, min_N=5, config_id=1, dense_residuals=True),
+    "pushing_T48": dict(task="panda_pushing", T=48, batch=1, min_N=4, config_id=3, dense_residuals=True),
+    "panda_T300_b3": dict(task="panda_reaching", T=300, batch=3, min_N=5, config_id=2),
+}
+
+
+@pytest.fixture(scope="module", params=list(PROBLEMS))
+def case(request):
+    p = synth.make_problem(**PROBLEMS[request.param])
+    ref = [pipeline.run_trajectory(p, b, want_U=True) for b in range(p["batch"])]
+    return request.param, p, ref
+
+
+def test_elementwise_stages_bit_exact(case):
+    name, p, ref = case
+    g = run_engine(p, generic=True)
+    for b, o in enumerate(ref):
+        for key in ("A", "B", "l_x", "l_xx", "l_u", "l_uu"):
+            assert np.array_equal(g[key][b], o[key]), f"{name} b{b} {key} not bit-exact"
+        # key-point columns right after fd_difference
+        kp_t = p["kp_times"]
+        assert np.array_equal(g["A_kp"][b][kp_t], o["A_kp"][kp_t])
+        assert np.array_equal(g["B_kp"][b][kp_t], o["B_kp"][kp_t])
+
+
+def test_generic_backward_forward_bit_exact(case):
+    name, p, ref = case
+    g = run_engine(p, generic=True)
+    assert g["variants"] == ("generic_lds", "generic_lds")
+    for b, o in enumerate(ref):
+        assert g["status"][b] == o["status"] == 0
+        assert np.array_equal(g["K"][b], o["K"]), f"{name} b{b}: generic K differs: {relerr(g['K'][b], o['K'])}"
+        assert np.array_equal(g["k"][b], o["k"])
+        assert g["delta_J"][b] == o["delta_J"]
+        assert np.array_equal(g["cost_pred"][b], o["cost_pred"])
+        assert np.array_equal(g["U_alpha"][b], o["U_alpha"])
+
+
+def test_mfma_backward_gains_within_tolerance(case):
+    name, p, ref = case
+    g = run_engine(p, generic=False)
+    if p["dof"] * 2 + 1 > 16:
+        assert g["variants"][0] == "generic_lds"
+    else:
+        assert g["variants"][0] == "mfma_f64_t1", g["variants"]
+    for b, o in enumerate(ref):
+        assert g["status"][b] == 0
+        eK, ek = relerr(g["K"][b], o["K"]), relerr(g["k"][b], o["k"])
+        assert eK < K_RTOL and ek < K_RTOL, (name, b, eK, ek)
+        assert eK < K_RTOL_TIGHT and ek < K_RTOL_TIGHT, (name, b, eK, ek)
+        assert abs(g["delta_J"][b] - o["delta_J"]) <= 1e-9 * abs(o["delta_J"]) + 1e-300
+
+
+def test_mfma_forward_within_tolerance(case):
+    name, p, ref = case
+    g = run_engine(p, generic=False)
+    for b, o in enumerate(ref):
+        scale = np.max(np.abs(o["cost_pred"]))
+        assert np.max(np.abs(g["cost_pred"][b] - o["cost_pred"])) <= 1e-9 * scale, (name, b, g["cost_pred"][b], o["cost_pred"])
+        assert relerr(g["U_alpha"][b], o["U_alpha"]) < 1e-9
+
+
+def test_golden_fixtures(golden_dir):
+    from oracle.crosscheck import GOLDEN
+    for name, kw in GOLDEN.items():
+        gold = np.load(f"{golden_dir}/{name}.npz")
+        p = synth.make_problem(**kw)
+        g = run_engine(p, generic=False)
+        ge = run_engine(p, generic=True)
+        for b in range(p["batch"]):
+            for key in ("A", "B", "l_x", "l_xx", "l_u", "l_uu"):
+                assert np.array_equal(g[key][b], gold[f"b{b}_{key}"]), (name, key)
+            assert np.array_equal(ge["K"][b], gold[f"b{b}_K"])
+            assert relerr(g["K"][b], gold[f"b{b}_K"]) < K_RTOL_TIGHT
+            assert relerr(g["k"][b], gold[f"b{b}_k"]) < K_RTOL_TIGHT
+            assert relerr(g["cost_pred"][b], gold[f"b{b}_cost_pred"]) < 1e-9
+
+
+def test_full_size_panda_T3000(golden_dir):
+    """BASELINE configs[1]: Panda reaching, T=3000, set-interval 5, batch 1 -- against the committed
+    checksums and the oracle run here."""
+    from oracle.crosscheck import GOLDEN_BIG
+    kw = GOLDEN_BIG["panda_T3000"]
+    gold = np.load(f"{golden_dir}/panda_T3000.npz")
+    p = synth.make_problem(**kw)
+    o = pipeline.run_trajectory(p, 0)
+    g = run_engine(p, generic=False)
+    assert g["status"][0] == 0
+    for key in ("A", "B", "l_xx"):
+        assert np.sum(g[key][0]) == float(gold[f"sum_{key}"])
+        assert np.sum(np.abs(g[key][0])) == float(gold[f"abssum_{key}"])
+    assert relerr(g["K"][0], o["K"]) < K_RTOL_TIGHT
+    assert relerr(g["K"][0][0], gold["K_first"]) < K_RTOL_TIGHT
+    assert relerr(g["K"][0][1500], gold["K_mid"]) < K_RTOL_TIGHT
+    assert relerr(g["k"][0], o["k"]) < K_RTOL_TIGHT
+    assert abs(g["delta_J"][0] - float(gold["delta_J"])) < 1e-9 * abs(float(gold["delta_J"]))
+    assert relerr(g["cost_pred"][0], gold["cost_pred"]) < 1e-9
+    # the generic kernel at full size: bit-exact with the oracle
+    ge = run_engine(p, generic=True)
+    assert np.array_equal(ge["K"][0], o["K"])
+
+
+def test_batch_independence_and_sharding():
+    """Trajectories are independent units: a batch of replicas gives identical results per replica,
+    and results do not depend on which other trajectories share the batch (multi-GPU sharding)."""
+    p1 = synth.make_problem(task="panda_reaching", T=200, batch=2, min_N=5)
+    g1 = run_engine(p1)
+    pt = synth.tile_problem(p1, 5)
+    gt = run_engine(pt)
+    for rep in range(5):
+        for b in range(2):
+            assert np.array_equal(gt["K"][rep * 2 + b], g1["K"][b])
+            assert np.array_equal(gt["cost_pred"][rep * 2 + b], g1["cost_pred"][b])
+    # shard: trajectory 1 alone
+    p_single = synth.make_problem(task="panda_reaching", T=200, batch=1, min_N=5, first_b=1)
+    gs = run_engine(p_single)
+    assert np.array_equal(gs["K"][0], g1["K"][1])
+
+
+def test_interpolation_known_answer_relation():
+    """Interpolate.basic_interpolation (src/tests/Keypoints_Test.cpp:204-308): set_interval min_N=3,
+    T=100: A[1] == A[0] + (A[3]-A[0])/3 bitwise; A[98] ~= A[96] + 2 (A[99]-A[96])/3."""
+    p = synth.make_problem(task="acrobot", T=100, batch=1, min_N=3, config_id=1)
+    with Engine(p["dof"], p["m"], p["T"], p["nr"], batch=1) as e:
+        synth.upload(e, p)
+        e.fd_difference(); e.interpolate()
+        A, B = e.get_AB()
+    A, B = A[0], B[0]
+    for M in (A, B):
+        diff = (M[3] - M[0]) / 3.0
+        assert np.array_equal(M[1], M[0] + diff)
+        d2 = (M[99] - M[96]) / 3.0
+        assert np.allclose(M[98], M[96] + d2 + d2, rtol=0, atol=1e-6)
+
+
+def test_ragged_keypoints_per_dof():
+    """adaptive-jerk style key-points: every DoF has its own key-point times."""
+    T, dof = 120, 7
+    p = synth.make_problem(task="panda_reaching", T=T, batch=2, min_N=1, dense_residuals=True)   # FD at every step
+    rng = np.random.default_rng(7)
+    rows = []
+    for b in range(2):
+        offs = np.zeros(T + 1, np.int32); cols = []
+        for t in range(T):
+            offs[t] = len(cols)
+            if t == 0 or t == T - 1:
+                cols.extend(range(dof))
+            else:
+                cols.extend([i for i in range(dof) if rng.uniform() < 0.25])
+        offs[T] = len(cols)
+        rows.append((offs, np.asarray(cols, np.int32)))
+    p["kp_rows"] = rows
+    g = run_engine(p, generic=False)
+    for b in range(2):
+        o = pipeline.run_trajectory(p, b, want_U=True)
+        assert np.array_equal(g["A"][b], o["A"]) and np.array_equal(g["B"][b], o["B"])
+        assert relerr(g["K"][b], o["K"]) < K_RTOL_TIGHT
+
+
+def test_pd_failure_status_and_lambda_retry():
+    """Non-PD Q_uu + lambda I: status = t+1 at the first CHECKED step (every pd_stride-th), exactly
+    where the reference's CheckMatrixPD (iLQR.cpp:587-595) would return false; raising lambda fixes it."""
+    p = synth.make_problem(task="panda_reaching", T=64, batch=2, min_N=5, dense_residuals=True)
+    with Engine(p["dof"], p["m"], p["T"], p["nr"], batch=2) as e, \
+            Engine(p["dof"], p["m"], p["T"], p["nr"], batch=2, generic=True) as eg:
+        for eng in (e, eg):
+            synth.upload(eng, p)
+            eng.fd_difference(); eng.interpolate(); eng.cost_derivs()
+        l_x, l_xx, l_u, l_uu = e.get_cost_derivs()
+        l_uu[1] -= 5.0 * np.eye(p["m"])[None]          # make trajectory 1 indefinite in u
+        for eng in (e, eg):
+            eng.set_cost_derivs(l_uu=l_uu)
+        A, B = e.get_AB()
+        for stride in (1, 10):
+            st_o = [orc.backward(p["n"], p["m"], p["T"], A[b], B[b], l_x[b], l_xx[b], l_u[b], l_uu[b], 0.1, stride)[0]
+                    for b in range(2)]
+            assert st_o[0] == 0 and st_o[1] > 0
+            for eng in (e, eg):
+                st, _ = eng.backward(0.1, stride)
+                assert list(st) == st_o, (stride, eng.backward_variant, st, st_o)
+        # unchecked indefinite steps (stride larger than T): follows Eigen's pivoted LDLT
+        o = orc.backward(p["n"], p["m"], p["T"], A[1], B[1], l_x[1], l_xx[1], l_u[1], l_uu[1], 0.1, 1000)
+        st, _ = e.backward(0.1, 1000)
+        K, k = e.gains()
+        assert st[1] == 0 and o[0] == 0
+        assert relerr(K[1], o[1]) < 1e-6
+        # lambda retry (iLQR.cpp:435-442): a larger lambda makes it PD again
+        st, _ = e.backward(10.0, 1)
+        assert list(st) == [0, 0]
+
+
+def test_per_trajectory_lambda():
+    p = synth.make_problem(task="panda_reaching", T=80, batch=3, min_N=5)
+    lams = np.array([0.1, 1.0, 1e-4])
+    with Engine(p["dof"], p["m"], p["T"], p["nr"], batch=3) as e:
+        synth.upload(e, p)
+        e.fd_difference(); e.interpolate(); e.cost_derivs()
+        e.backward(lams)
+        K, _ = e.gains()
+    for b in range(3):
+        o = pipeline.run_trajectory(p, b, lam=float(lams[b]), stages=("fd", "interp", "cost", "bwd"))
+        assert relerr(K[b], o["K"]) < K_RTOL_TIGHT
+
+
+def test_clamp_active_in_forward():
+    """Tight control limits so that the clamp of iLQR.cpp:883-889 is active."""
+    p = synth.make_problem(task="panda_reaching", T=100, batch=1, min_N=5)
+    p["ctrl_lim"] = np.stack([p["u_nom"][0].min(0) - 1e-3, p["u_nom"][0].max(0) + 1e-3], axis=1).reshape(-1)
+    o = pipeline.run_trajectory(p, 0, want_U=True)
+    g = run_engine(p)
+    lim = p["ctrl_lim"]
+    assert np.any(o["U_alpha"] == lim[1::2][None, None, :]) or np.any(o["U_alpha"] == lim[0::2][None, None, :])
+    assert relerr(g["U_alpha"][0], o["U_alpha"]) < 1e-9
+    assert relerr(g["cost_pred"][0], o["cost_pred"]) < 1e-9
+
+
+def test_iterate_equals_staged_calls():
+    p = synth.make_problem(task="panda_reaching", T=150, batch=4, min_N=5)
+    g = run_engine(p)
+    with Engine(p["dof"], p["m"], p["T"], p["nr"], batch=4) as e:
+        synth.upload(e, p)
+        e.iterate(p["lam"], 100, orc.alphas(6))
+        res = e.results()
+        K, k = e.gains()
+    assert np.array_equal(K, g["K"]) and np.array_equal(res["cost_pred"], g["cost_pred"])
+    assert np.array_equal(res["delta_J"], g["delta_J"]) and np.all(res["status"] == 0)
+
+
+def test_trajectory_cost_matches_cost_function():
+    p = synth.make_problem(task="panda_reaching", T=90, batch=2, min_N=5)
+    with Engine(p["dof"], p["m"], p["T"], p["nr"], batch=2) as e:
+        synth.upload(e, p)
+        c = e.trajectory_cost()
+    for b in range(2):
+        ref = 0.0
+        for t in range(p["T"]):
+            ref += orc.cost_function(p["r"][b, t], p["w_term"] if t == p["T"] - 1 else p["w_run"])
+        assert c[b] == ref
+
+
+def test_bad_arguments_fail_loudly():
+    from trajoptkp_amd import KpilqrError
+    with pytest.raises(KpilqrError):
+        Engine(0, 7, 10, 14)
+    with Engine(7, 7, 20, 14) as e:
+        with pytest.raises(KpilqrError):
+            e.interpolate()                                      # before set_keypoints
+        with pytest.raises(KpilqrError):
+            e.upload_fd([0], [25], [0], [0], np.zeros((1, 14)), np.zeros((1, 14)))   # t out of range
+        with pytest.raises(KpilqrError):
+            e.upload_fd([0], [5], [0], [1], np.zeros((1, 14)), np.zeros((1, 14)))    # one-sided, no nominal

@@ -1,0 +1,87 @@
+"""ctypes binding of libkpilqr.so -- the C ABI declared in include/kpilqr.h.
+
+This is the only way Python reaches the engine: there is no Python/torch compute fallback.  If the
+shared library is missing it is built in-tree with hipcc (trajoptkp_amd/csrc/Makefile); if that
+fails, importing the engine raises.
+"""
+import ctypes as C
+import os
+import subprocess
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "lib", "libkpilqr.so")
+CSRC = os.path.join(_HERE, "csrc")
+
+# every symbol include/kpilqr.h declares (tests check the .so exports exactly these)
+SYMBOLS = [
+    "kpilqr_create", "kpilqr_destroy", "kpilqr_version", "kpilqr_strerror", "kpilqr_get_dims",
+    "kpilqr_host_alloc", "kpilqr_host_free", "kpilqr_sync", "kpilqr_device_ptr",
+    "kpilqr_set_keypoints", "kpilqr_upload_fd", "kpilqr_fd_difference", "kpilqr_interpolate",
+    "kpilqr_upload_residuals", "kpilqr_cost_derivs", "kpilqr_trajectory_cost",
+    "kpilqr_backward", "kpilqr_download_gains", "kpilqr_upload_nominal", "kpilqr_forward_linear",
+    "kpilqr_iterate", "kpilqr_set_AB", "kpilqr_get_AB", "kpilqr_set_cost_derivs",
+    "kpilqr_get_cost_derivs", "kpilqr_backward_variant", "kpilqr_forward_variant",
+]
+
+
+class Dims(C.Structure):
+    _fields_ = [("dof", C.c_int), ("m", C.c_int), ("T", C.c_int), ("nr", C.c_int),
+                ("batch", C.c_int), ("n_alpha", C.c_int), ("device", C.c_int), ("flags", C.c_int)]
+
+
+FLAG_GENERIC_KERNELS = 1
+
+BUF_STEP_RECORDS, BUF_K, BUF_k, BUF_RESIDUALS, BUF_R_X, BUF_R_U, BUF_U_NOM, BUF_FD_XPLUS, \
+    BUF_FD_XMINUS, BUF_COST_PRED, BUF_DELTA_J, BUF_STATUS = range(12)
+
+ERR_ARG, ERR_NO_DEVICE, ERR_HIP, ERR_ALLOC, ERR_STATE = -1, -2, -3, -4, -5
+
+_lib = None
+
+
+def build(force=False):
+    """Compile libkpilqr.so for gfx950 with hipcc (cross-compiles without a GPU)."""
+    if force or not os.path.exists(LIB_PATH):
+        subprocess.check_call(["make", "-C", CSRC, "-j4"] + (["-B"] if force else []))
+    return LIB_PATH
+
+
+def load():
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        build()
+    L = C.CDLL(LIB_PATH)
+    vp, ip, dp = C.c_void_p, C.POINTER(C.c_int), C.POINTER(C.c_double)
+    L.kpilqr_create.argtypes = [C.POINTER(Dims), vp, C.POINTER(vp)]
+    L.kpilqr_destroy.argtypes = [vp]; L.kpilqr_destroy.restype = None
+    L.kpilqr_version.argtypes = []
+    L.kpilqr_strerror.argtypes = [vp]; L.kpilqr_strerror.restype = C.c_char_p
+    L.kpilqr_get_dims.argtypes = [vp, C.POINTER(Dims)]
+    L.kpilqr_host_alloc.argtypes = [vp, C.c_size_t, C.POINTER(vp)]
+    L.kpilqr_host_free.argtypes = [vp, vp]
+    L.kpilqr_sync.argtypes = [vp]
+    L.kpilqr_device_ptr.argtypes = [vp, C.c_int, C.POINTER(vp), C.POINTER(C.c_size_t)]
+    L.kpilqr_set_keypoints.argtypes = [vp, vp, vp]
+    L.kpilqr_upload_fd.argtypes = [vp, C.c_int, vp, vp, vp, vp, vp, vp, vp, C.c_int, vp, C.c_double]
+    L.kpilqr_fd_difference.argtypes = [vp]
+    L.kpilqr_interpolate.argtypes = [vp]
+    L.kpilqr_upload_residuals.argtypes = [vp, vp, vp, vp, vp, vp]
+    L.kpilqr_cost_derivs.argtypes = [vp]
+    L.kpilqr_trajectory_cost.argtypes = [vp, vp]
+    L.kpilqr_backward.argtypes = [vp, vp, C.c_int, vp, vp]
+    L.kpilqr_download_gains.argtypes = [vp, vp, vp]
+    L.kpilqr_upload_nominal.argtypes = [vp, vp, vp]
+    L.kpilqr_forward_linear.argtypes = [vp, vp, vp, vp]
+    L.kpilqr_iterate.argtypes = [vp, vp, C.c_int, vp]
+    L.kpilqr_set_AB.argtypes = [vp, vp, vp]
+    L.kpilqr_get_AB.argtypes = [vp, vp, vp]
+    L.kpilqr_set_cost_derivs.argtypes = [vp, vp, vp, vp, vp]
+    L.kpilqr_get_cost_derivs.argtypes = [vp, vp, vp, vp, vp]
+    L.kpilqr_backward_variant.argtypes = [vp]; L.kpilqr_backward_variant.restype = C.c_char_p
+    L.kpilqr_forward_variant.argtypes = [vp]; L.kpilqr_forward_variant.restype = C.c_char_p
+    for s in SYMBOLS:
+        getattr(L, s)          # raises AttributeError if the .so lacks a declared symbol
+    _lib = L
+    return L

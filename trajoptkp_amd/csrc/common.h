@@ -1,0 +1,115 @@
+// common.h -- internal declarations shared by the translation units of libkpilqr.so.
+// Not part of the public surface (that is include/kpilqr.h).
+#pragma once
+
+#include <hip/hip_runtime.h>
+#include <stddef.h>
+#include <stdint.h>
+#include <string>
+
+#include "../../include/kpilqr.h"
+
+namespace kpilqr {
+
+// ---- device layout of one "step record" (all FP64), one per (trajectory b, time t) ----------
+// [ A (n x n) | B (n x m) | l_xx (n x n) | l_x (n) | l_uu (m x m) | l_u (m) ], every matrix
+// ROW-major so that the MFMA kernels' D-layout loads (lane -> one column, 4 consecutive rows per
+// instruction) read contiguous 4-row slabs.  Record stride is padded to 16 doubles (128 B).
+struct RecLayout {
+    int n, m;
+    int off_A, off_B, off_lxx, off_lx, off_luu, off_lu;
+    int rec;      // used doubles
+    int stride;   // padded stride in doubles
+    __host__ __device__ RecLayout() {}
+    __host__ __device__ RecLayout(int n_, int m_) : n(n_), m(m_) {
+        off_A = 0;
+        off_B = off_A + n * n;
+        off_lxx = off_B + n * m;
+        off_lx = off_lxx + n * n;
+        off_luu = off_lx + n;
+        off_lu = off_luu + m * m;
+        rec = off_lu + m;
+        stride = (rec + 15) & ~15;
+    }
+};
+
+struct Ctx {
+    kpilqr_dims d{};
+    int n = 0;
+    RecLayout L;
+    hipStream_t stream = nullptr;
+    bool own_stream = false;
+    std::string err;
+
+    // device buffers
+    double *rec = nullptr;        // [batch][T][stride]
+    double *K = nullptr;          // [batch][T][n*m]
+    double *k = nullptr;          // [batch][T][m]
+    double *r = nullptr;          // [batch][T+1][nr]
+    double *r_x = nullptr;        // [batch][T+1][nr][n]
+    double *r_u = nullptr;        // [batch][T+1][nr][m]
+    double *w_run = nullptr, *w_term = nullptr;   // [nr]
+    double *u_nom = nullptr;      // [batch][T][m]
+    double *ctrl_lim = nullptr;   // [2m]
+    double *lambda = nullptr;     // [batch]
+    double *alphas = nullptr;     // [n_alpha]
+    double *cost_pred = nullptr;  // [batch][n_alpha]
+    double *delta_J = nullptr;    // [batch]
+    double *traj_cost = nullptr;  // [batch]
+    int *status = nullptr;        // [batch]
+    int2 *segmap = nullptr;       // [batch][dof][T]: (start,end) key-points around t, or (-1,-1)
+    int *kp_offsets = nullptr;    // [batch*dof+1]
+    int *kp_times = nullptr;      // [kp_total]
+    size_t kp_cap = 0;            // capacity of kp_times (ints)
+    bool have_kp = false;
+
+    // FD job buffers (grow on demand)
+    int njobs = 0, nnom = 0;
+    size_t job_cap = 0, nom_cap = 0;
+    int *job_b = nullptr, *job_t = nullptr, *job_col = nullptr, *job_nom = nullptr;
+    unsigned char *job_mode = nullptr;
+    double *xplus = nullptr, *xminus = nullptr, *xnom = nullptr;
+    double eps = 1e-6;
+
+    // staging for debug hooks / U_alpha
+    double *stage = nullptr;
+    size_t stage_cap = 0;   // bytes
+
+    const char *bwd_variant = "";
+    const char *fwd_variant = "";
+};
+
+#define KP_HIP(ctx, call)                                                        \
+    do {                                                                         \
+        hipError_t e_ = (call);                                                  \
+        if (e_ != hipSuccess) {                                                  \
+            (ctx)->err = std::string(#call) + ": " + hipGetErrorString(e_);      \
+            return KPILQR_ERR_HIP;                                               \
+        }                                                                        \
+    } while (0)
+
+// ---- launchers (defined in the .hip files) --------------------------------------------------
+// elementwise.hip
+hipError_t launch_fd_difference(Ctx *c);
+hipError_t launch_build_segmap(Ctx *c);
+hipError_t launch_interpolate(Ctx *c);
+hipError_t launch_cost_derivs(Ctx *c);
+hipError_t launch_trajectory_cost(Ctx *c);
+// pack/unpack between the reference layout (column-major, separate arrays) and step records
+hipError_t launch_pack_AB(Ctx *c, const double *A, const double *B);      // device staging -> records
+hipError_t launch_unpack_AB(Ctx *c, double *A, double *B);
+hipError_t launch_pack_cost(Ctx *c, const double *lx, const double *lxx, const double *lu, const double *luu);
+hipError_t launch_unpack_cost(Ctx *c, double *lx, double *lxx, double *lu, double *luu);
+
+// riccati_generic.hip / forward_generic.hip: any (n, m); LDS-resident, op order of the reference.
+hipError_t launch_backward_generic(Ctx *c, int pd_stride);
+hipError_t launch_forward_generic(Ctx *c, double *U_alpha_dev);
+size_t backward_generic_lds_bytes(int n, int m);
+
+// riccati_mfma.hip / forward_mfma.hip: n+1 <= 16 and m <= 15 (one 16x16 f64 MFMA tile per block).
+bool backward_mfma_supported(int n, int m);
+hipError_t launch_backward_mfma(Ctx *c, int pd_stride);
+bool forward_mfma_supported(int n, int m, int n_alpha);
+hipError_t launch_forward_mfma(Ctx *c, double *U_alpha_dev);
+
+}  // namespace kpilqr

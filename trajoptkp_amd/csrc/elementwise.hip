@@ -1,0 +1,328 @@
+// elementwise.hip -- the HBM-bound, embarrassingly parallel stages of one iLQR iteration:
+//   fd_difference  (a2)  Differentiator::DynamicsDerivatives tail, src/Differentiator/Differentiator.cpp:166-222,286-321,386-423,441-457
+//   interpolate    (a4)  KeypointGenerator::InterpolateDerivatives, src/KeyPointGenerator/KeyPointGenerator.cpp:840-954
+//   cost_derivs    (a6)  ModelTranslator::CostDerivativesFromResiduals, src/ModelTranslator/ModelTranslator.cpp:552-583
+//   trajectory_cost      ModelTranslator::CostFunction, src/ModelTranslator/ModelTranslator.cpp:314-327
+// plus the pack/unpack kernels behind the debug hooks.
+//
+// This file is compiled with -ffp-contract=off: every expression is written in the reference's
+// operation order and must not be fused, because the reference's own test pins the interpolation
+// bitwise (src/tests/Keypoints_Test.cpp:273-289) and the parity tests compare these stages
+// bit-for-bit with the CPU oracle.
+#include "common.h"
+
+namespace kpilqr {
+
+// ---------------------------------------------------------------------------------------------
+// a2.  One thread per (row, job); jobs vary fastest so that the columns of one key-point land in
+// consecutive addresses of the row-major record.
+__global__ void __launch_bounds__(256)
+k_fd_difference(RecLayout L, int T, int njobs,
+                const int *__restrict__ job_b, const int *__restrict__ job_t,
+                const int *__restrict__ job_col, const unsigned char *__restrict__ job_mode,
+                const int *__restrict__ job_nom,
+                const double *__restrict__ xplus, const double *__restrict__ xminus,
+                const double *__restrict__ xnom, double eps, double *__restrict__ rec)
+{
+    const int n = L.n, m = L.m;
+    const long long total = (long long)njobs * n;
+    for (long long idx = (long long)blockIdx.x * blockDim.x + threadIdx.x; idx < total;
+         idx += (long long)gridDim.x * blockDim.x) {
+        const int job = (int)(idx % njobs);
+        const int row = (int)(idx / njobs);
+        const int mode = job_mode[job];
+        const double xp = xplus[(size_t)job * n + row];
+        const double xm = xminus[(size_t)job * n + row];
+        double v;
+        if (mode == 0) {
+            v = (xp - xm) / (2 * eps);
+        } else {
+            const double x0 = xnom[(size_t)job_nom[job] * n + row];
+            v = (mode == 1) ? (xp - x0) / (eps) : (x0 - xm) / (eps);
+        }
+        const int col = job_col[job];
+        double *R = rec + ((size_t)job_b[job] * T + job_t[job]) * L.stride;
+        if (col < n) R[L.off_A + row * n + col] = v;
+        else         R[L.off_B + row * m + (col - n)] = v;
+    }
+}
+
+hipError_t launch_fd_difference(Ctx *c)
+{
+    if (c->njobs == 0) return hipSuccess;
+    const long long total = (long long)c->njobs * c->n;
+    int blocks = (int)((total + 255) / 256);
+    if (blocks > 256 * 32) blocks = 256 * 32;
+    hipLaunchKernelGGL(k_fd_difference, dim3(blocks), dim3(256), 0, c->stream, c->L, c->d.T, c->njobs,
+                       c->job_b, c->job_t, c->job_col, c->job_mode, c->job_nom, c->xplus, c->xminus,
+                       c->xnom, c->eps, c->rec);
+    return hipGetLastError();
+}
+
+// ---------------------------------------------------------------------------------------------
+// Key-point CSR (per trajectory, per DoF: sorted times) -> dense (start,end) map per (b, dof, t):
+// the pair of consecutive key-points strictly around t, or (-1,-1) when t is itself a key-point
+// of that DoF or lies outside the DoF's first/last key-point (the reference leaves those alone).
+__global__ void __launch_bounds__(256)
+k_build_segmap(int batch, int dof, int T, const int *__restrict__ offs, const int *__restrict__ times,
+               int2 *__restrict__ segmap)
+{
+    const long long total = (long long)batch * dof * T;
+    for (long long idx = (long long)blockIdx.x * blockDim.x + threadIdx.x; idx < total;
+         idx += (long long)gridDim.x * blockDim.x) {
+        const int t = (int)(idx % T);
+        const int bi = (int)(idx / T);
+        const int lo0 = offs[bi], hi0 = offs[bi + 1];
+        // upper_bound(t) - 1
+        int lo = lo0, hi = hi0;
+        while (lo < hi) {
+            const int mid = (lo + hi) >> 1;
+            if (times[mid] <= t) lo = mid + 1; else hi = mid;
+        }
+        const int p = lo - 1;
+        int2 r = make_int2(-1, -1);
+        if (p >= lo0 && p + 1 < hi0) {
+            const int s = times[p], e = times[p + 1];
+            if (s != t) r = make_int2(s, e);
+        }
+        segmap[idx] = r;
+    }
+}
+
+hipError_t launch_build_segmap(Ctx *c)
+{
+    const long long total = (long long)c->d.batch * c->d.dof * c->d.T;
+    int blocks = (int)((total + 255) / 256);
+    if (blocks > 256 * 32) blocks = 256 * 32;
+    hipLaunchKernelGGL(k_build_segmap, dim3(blocks), dim3(256), 0, c->stream, c->d.batch, c->d.dof,
+                       c->d.T, c->kp_offsets, c->kp_times, c->segmap);
+    return hipGetLastError();
+}
+
+// ---------------------------------------------------------------------------------------------
+// a4.  Each block owns TT consecutive time-steps of one trajectory; one thread per element of the
+// contiguous [A|B] part of the record.  value = start + (t - s) * ((end - start) / (e - s)) in
+// exactly this order (KeyPointGenerator.cpp:900,934).
+#define INTERP_TT 8
+__global__ void __launch_bounds__(256)
+k_interpolate(RecLayout L, int dof, int T, const int2 *__restrict__ segmap, double *__restrict__ rec)
+{
+    const int n = L.n, m = L.m;
+    const int ne = n * n + n * m;
+    const int b = blockIdx.y;
+    const int t0 = blockIdx.x * INTERP_TT;
+    double *R = rec + (size_t)b * T * L.stride;
+    const int2 *sm = segmap + (size_t)b * dof * T;
+    for (int w = threadIdx.x; w < INTERP_TT * ne; w += blockDim.x) {
+        const int tt = w / ne, e = w - tt * ne;
+        const int t = t0 + tt;
+        if (t >= T) break;
+        int i;
+        if (e < n * n) { const int col = e % n; i = col < dof ? col : col - dof; }
+        else           { const int col = (e - n * n) % m; i = col; if (i >= dof) continue; }
+        const int2 se = sm[(size_t)i * T + t];
+        if (se.x < 0) continue;
+        const double vs = R[(size_t)se.x * L.stride + e];
+        const double ve = R[(size_t)se.y * L.stride + e];
+        const double add = (ve - vs) / (double)(se.y - se.x);
+        R[(size_t)t * L.stride + e] = vs + ((double)(t - se.x) * add);
+    }
+}
+
+hipError_t launch_interpolate(Ctx *c)
+{
+    dim3 grid((c->d.T + INTERP_TT - 1) / INTERP_TT, c->d.batch);
+    hipLaunchKernelGGL(k_interpolate, grid, dim3(256), 0, c->stream, c->L, c->d.dof, c->d.T, c->segmap, c->rec);
+    return hipGetLastError();
+}
+
+// ---------------------------------------------------------------------------------------------
+// a6.  Each block owns TT consecutive time-steps of one trajectory: residuals and their Jacobians
+// are staged in LDS, then one thread per output element accumulates over the residuals in index
+// order: l_x += (w*2*r_i) r_x[i];  l_xx += (w*2*r_x[i]) r_x[i]'; same for u  (ModelTranslator.cpp:570-581).
+#define COST_TT 4
+__global__ void __launch_bounds__(256)
+k_cost_derivs(RecLayout L, int nr, int T,
+              const double *__restrict__ r, const double *__restrict__ r_x, const double *__restrict__ r_u,
+              const double *__restrict__ w_run, const double *__restrict__ w_term, double *__restrict__ rec)
+{
+    extern __shared__ __attribute__((aligned(16))) double sh[];
+    const int n = L.n, m = L.m;
+    const int per = nr * (1 + n + m);
+    const int b = blockIdx.y;
+    const int t0 = blockIdx.x * COST_TT;
+    const int nt = min(COST_TT, T - t0);
+    // stage: [tt][ r(nr) | r_x(nr*n) | r_u(nr*m) ]
+    for (int w = threadIdx.x; w < nt * per; w += blockDim.x) {
+        const int tt = w / per, e = w - tt * per;
+        const size_t bt = (size_t)b * (T + 1) + (t0 + tt);
+        double v;
+        if (e < nr) v = r[bt * nr + e];
+        else if (e < nr + nr * n) v = r_x[bt * nr * n + (e - nr)];
+        else v = r_u[bt * nr * m + (e - nr - nr * n)];
+        sh[w] = v;
+    }
+    __syncthreads();
+    const int nout = n * n + n + m * m + m;
+    for (int w = threadIdx.x; w < nt * nout; w += blockDim.x) {
+        const int tt = w / nout, o = w - tt * nout;
+        const int t = t0 + tt;
+        const double *wt = (t == T - 1) ? w_term : w_run;   // Optimiser.cpp:208-211
+        const double *sr = sh + tt * per, *srx = sr + nr, *sru = srx + nr * n;
+        double acc = 0.0;
+        int dst;
+        if (o < n * n) {                       // l_xx(a,b), stored row-major
+            const int a = o / n, bb = o - a * n;
+            for (int i = 0; i < nr; i++) acc += ((wt[i] * 2) * srx[i * n + a]) * srx[i * n + bb];
+            dst = L.off_lxx + o;
+        } else if (o < n * n + n) {            // l_x(a)
+            const int a = o - n * n;
+            for (int i = 0; i < nr; i++) acc += ((wt[i] * 2) * sr[i]) * srx[i * n + a];
+            dst = L.off_lx + a;
+        } else if (o < n * n + n + m * m) {    // l_uu(a,b)
+            const int q = o - n * n - n;
+            const int a = q / m, bb = q - a * m;
+            for (int i = 0; i < nr; i++) acc += ((wt[i] * 2) * sru[i * m + a]) * sru[i * m + bb];
+            dst = L.off_luu + q;
+        } else {                               // l_u(a)
+            const int a = o - n * n - n - m * m;
+            for (int i = 0; i < nr; i++) acc += ((wt[i] * 2) * sr[i]) * sru[i * m + a];
+            dst = L.off_lu + a;
+        }
+        rec[((size_t)b * T + t) * L.stride + dst] = acc;
+    }
+}
+
+hipError_t launch_cost_derivs(Ctx *c)
+{
+    dim3 grid((c->d.T + COST_TT - 1) / COST_TT, c->d.batch);
+    const size_t lds = sizeof(double) * COST_TT * c->d.nr * (1 + c->n + c->d.m);
+    hipLaunchKernelGGL(k_cost_derivs, grid, dim3(256), lds, c->stream, c->L, c->d.nr, c->d.T, c->r, c->r_x,
+                       c->r_u, c->w_run, c->w_term, c->rec);
+    return hipGetLastError();
+}
+
+// ---------------------------------------------------------------------------------------------
+// Trajectory cost as RolloutTrajectory sums it (iLQR.cpp:219-247): sequential over t, terminal
+// weights at t = T-1.  One thread per trajectory: strictly ordered sum, not a hot kernel.
+__global__ void k_trajectory_cost(int batch, int nr, int T, const double *__restrict__ r,
+                                  const double *__restrict__ w_run, const double *__restrict__ w_term,
+                                  double *__restrict__ cost)
+{
+    const int b = blockIdx.x * blockDim.x + threadIdx.x;
+    if (b >= batch) return;
+    double total = 0.0;
+    for (int t = 0; t < T; t++) {
+        const double *rt = r + ((size_t)b * (T + 1) + t) * nr;
+        const double *w = (t == T - 1) ? w_term : w_run;
+        double c = 0.0;
+        for (int i = 0; i < nr; i++) c += w[i] * (rt[i] * rt[i]);
+        total += c;
+    }
+    cost[b] = total;
+}
+
+hipError_t launch_trajectory_cost(Ctx *c)
+{
+    hipLaunchKernelGGL(k_trajectory_cost, dim3((c->d.batch + 63) / 64), dim3(64), 0, c->stream, c->d.batch,
+                       c->d.nr, c->d.T, c->r, c->w_run, c->w_term, c->traj_cost);
+    return hipGetLastError();
+}
+
+// ---------------------------------------------------------------------------------------------
+// Debug hooks: reference layout (column-major, separate arrays) <-> step records.
+__global__ void __launch_bounds__(256)
+k_pack_AB(RecLayout L, long long nbt, const double *__restrict__ A, const double *__restrict__ B,
+          double *__restrict__ rec, int to_rec)
+{
+    const int n = L.n, m = L.m, ne = n * n + n * m;
+    const long long total = nbt * ne;
+    for (long long idx = (long long)blockIdx.x * blockDim.x + threadIdx.x; idx < total;
+         idx += (long long)gridDim.x * blockDim.x) {
+        const long long bt = idx / ne;
+        const int e = (int)(idx - bt * ne);
+        double *R = rec + (size_t)bt * L.stride;
+        if (e < n * n) {
+            if (!A) continue;
+            const int row = e / n, col = e - row * n;
+            double *a = const_cast<double *>(A) + (size_t)bt * n * n + row + (size_t)col * n;
+            if (to_rec) R[L.off_A + e] = *a; else *a = R[L.off_A + e];
+        } else {
+            if (!B) continue;
+            const int q = e - n * n, row = q / m, col = q - row * m;
+            double *p = const_cast<double *>(B) + (size_t)bt * n * m + row + (size_t)col * n;
+            if (to_rec) R[L.off_B + q] = *p; else *p = R[L.off_B + q];
+        }
+    }
+}
+
+static int grid_for(long long total) {
+    long long b = (total + 255) / 256;
+    return (int)(b > 256 * 32 ? 256 * 32 : (b < 1 ? 1 : b));
+}
+
+hipError_t launch_pack_AB(Ctx *c, const double *A, const double *B)
+{
+    const long long nbt = (long long)c->d.batch * c->d.T;
+    hipLaunchKernelGGL(k_pack_AB, dim3(grid_for(nbt * (c->n * c->n + c->n * c->d.m))), dim3(256), 0, c->stream,
+                       c->L, nbt, A, B, c->rec, 1);
+    return hipGetLastError();
+}
+hipError_t launch_unpack_AB(Ctx *c, double *A, double *B)
+{
+    const long long nbt = (long long)c->d.batch * c->d.T;
+    hipLaunchKernelGGL(k_pack_AB, dim3(grid_for(nbt * (c->n * c->n + c->n * c->d.m))), dim3(256), 0, c->stream,
+                       c->L, nbt, A, B, c->rec, 0);
+    return hipGetLastError();
+}
+
+__global__ void __launch_bounds__(256)
+k_pack_cost(RecLayout L, long long nbt, const double *__restrict__ lx, const double *__restrict__ lxx,
+            const double *__restrict__ lu, const double *__restrict__ luu, double *__restrict__ rec, int to_rec)
+{
+    const int n = L.n, m = L.m, ne = n * n + n + m * m + m;
+    const long long total = nbt * ne;
+    for (long long idx = (long long)blockIdx.x * blockDim.x + threadIdx.x; idx < total;
+         idx += (long long)gridDim.x * blockDim.x) {
+        const long long bt = idx / ne;
+        const int e = (int)(idx - bt * ne);
+        double *R = rec + (size_t)bt * L.stride;
+        double *h; int dst;
+        if (e < n * n) {
+            if (!lxx) continue;
+            const int row = e / n, col = e - row * n;
+            h = const_cast<double *>(lxx) + (size_t)bt * n * n + row + (size_t)col * n; dst = L.off_lxx + e;
+        } else if (e < n * n + n) {
+            if (!lx) continue;
+            h = const_cast<double *>(lx) + (size_t)bt * n + (e - n * n); dst = L.off_lx + (e - n * n);
+        } else if (e < n * n + n + m * m) {
+            if (!luu) continue;
+            const int q = e - n * n - n, row = q / m, col = q - row * m;
+            h = const_cast<double *>(luu) + (size_t)bt * m * m + row + (size_t)col * m; dst = L.off_luu + q;
+        } else {
+            if (!lu) continue;
+            const int q = e - n * n - n - m * m;
+            h = const_cast<double *>(lu) + (size_t)bt * m + q; dst = L.off_lu + q;
+        }
+        if (to_rec) R[dst] = *h; else *h = R[dst];
+    }
+}
+
+hipError_t launch_pack_cost(Ctx *c, const double *lx, const double *lxx, const double *lu, const double *luu)
+{
+    const long long nbt = (long long)c->d.batch * c->d.T;
+    const int ne = c->n * c->n + c->n + c->d.m * c->d.m + c->d.m;
+    hipLaunchKernelGGL(k_pack_cost, dim3(grid_for(nbt * ne)), dim3(256), 0, c->stream, c->L, nbt, lx, lxx, lu, luu,
+                       c->rec, 1);
+    return hipGetLastError();
+}
+hipError_t launch_unpack_cost(Ctx *c, double *lx, double *lxx, double *lu, double *luu)
+{
+    const long long nbt = (long long)c->d.batch * c->d.T;
+    const int ne = c->n * c->n + c->n + c->d.m * c->d.m + c->d.m;
+    hipLaunchKernelGGL(k_pack_cost, dim3(grid_for(nbt * ne)), dim3(256), 0, c->stream, c->L, nbt, lx, lxx, lu, luu,
+                       c->rec, 0);
+    return hipGetLastError();
+}
+
+}  // namespace kpilqr

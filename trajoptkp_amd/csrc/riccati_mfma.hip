@@ -1,0 +1,349 @@
+// riccati_mfma.hip -- backward pass (a7) for n+1 <= 16: ONE wavefront per trajectory, the value
+// function resident in registers, every per-step product on the FP64 matrix core
+// (v_mfma_f64_16x16x4_f64), the small Q_uu solve on the VALU with its operands broadcast through LDS.
+//
+// Reference: iLQR::BackwardsPassQuuRegularisation + CheckMatrixPD, src/Optimiser/iLQR.cpp:535-670.
+//
+// Formulation.  With z = [dx; 1] the first-order terms ride in row/column n of
+// 16x16 tiles:
+//     V' = [V_xx V_x; V_x' 0]   Fz = [A 0; 0 1]   Fu = [B; 0]   Lzz = [l_xx l_x; l_x' 0]   Luz = [0 l_u]
+//     Tz = V' Fz,  Tu = V' Fu
+//     Qzz = Lzz + Fz' Tz        (= [Q_xx Q_x; Q_x' *])
+//     Quz = Luz + Fu' Tz        (= [Q_ux Q_u])
+//     Quu = l_uu + Fu' Tu
+//     K'  = -(Quu + lambda I)^-1 Quz          (= [K k])
+//     V'  = Qzz + K''(Quu K' + Quz) + Quz' K'  (iLQR.cpp:606-607, both lines at once), then (V'+V'')/2
+//     delta_J += [K''(Quu K' + Quz)]_(n,n)     (= k'Q_uu k + k'Q_u, iLQR.cpp:612-613)
+// Tiles live in the MFMA accumulator ("D") layout: lane (c = lane&15, q = lane>>4), register r holds
+// element (row 4r+q, col c).  In that layout a tile is directly the B operand of the next MFMA (k-chunk
+// r = register r) and, used as the A operand, it is its own transpose.  So the single primitive is
+//     P(Y, X) = Y' X      (sum over the shared ROW index, 4 rows per MFMA)
+// and the whole recursion chains without any cross-lane movement except one LDS transpose per step
+// for the symmetrisation.  V' and Quu are symmetric up to rounding, which is what lets V' Fz be
+// computed as P(V', Fz).
+//
+// The association order differs from the reference's ((A'V)A vs A'(VA)) and the 7x7 system is solved
+// by an unpivoted LDL' per lane instead of Eigen's pivoted LDLT + explicit inverse; both change K by
+// O(1e-14) relative for the PD, lambda-regularised systems the algorithm accepts.  When a pivot is
+// not positive (Q_uu + lambda I indefinite between two PD checks) the kernel falls back to a
+// line-for-line port of Eigen's pivoted LDLT so that even that case follows the reference.
+#include "common.h"
+
+namespace kpilqr {
+
+typedef double d4 __attribute__((ext_vector_type(4)));
+
+#define MFMA(a, b, c) __builtin_amdgcn_mfma_f64_16x16x4f64((a), (b), (c), 0, 0, 0)
+
+// acc + Y' X over NC row-chunks (rows 0 .. 4*NC-1 of Y and X).
+template <int NC>
+__device__ __forceinline__ d4 P(const d4 &Y, const d4 &X, d4 acc)
+{
+    acc = MFMA(Y.x, X.x, acc);
+    if (NC > 1) acc = MFMA(Y.y, X.y, acc);
+    if (NC > 2) acc = MFMA(Y.z, X.z, acc);
+    if (NC > 3) acc = MFMA(Y.w, X.w, acc);
+    return acc;
+}
+
+__device__ __forceinline__ double ld_or_zero(const double *R, int off)
+{
+    const double v = R[off < 0 ? 0 : off];
+    return off < 0 ? 0.0 : v;
+}
+
+struct TileOffs { int fz[4], fu[4], lzz[4], luz[4], luu[4]; double one[4]; };
+
+struct StepTiles { d4 Fz, Fu, Lzz, Luz, Luu; };
+
+__device__ __forceinline__ void load_step(const double *R, const TileOffs &o, StepTiles &s)
+{
+    s.Fz.x = ld_or_zero(R, o.fz[0]) + o.one[0]; s.Fz.y = ld_or_zero(R, o.fz[1]) + o.one[1];
+    s.Fz.z = ld_or_zero(R, o.fz[2]) + o.one[2]; s.Fz.w = ld_or_zero(R, o.fz[3]) + o.one[3];
+    s.Fu.x = ld_or_zero(R, o.fu[0]); s.Fu.y = ld_or_zero(R, o.fu[1]);
+    s.Fu.z = ld_or_zero(R, o.fu[2]); s.Fu.w = ld_or_zero(R, o.fu[3]);
+    s.Lzz.x = ld_or_zero(R, o.lzz[0]); s.Lzz.y = ld_or_zero(R, o.lzz[1]);
+    s.Lzz.z = ld_or_zero(R, o.lzz[2]); s.Lzz.w = ld_or_zero(R, o.lzz[3]);
+    s.Luz.x = ld_or_zero(R, o.luz[0]); s.Luz.y = ld_or_zero(R, o.luz[1]);
+    s.Luz.z = ld_or_zero(R, o.luz[2]); s.Luz.w = ld_or_zero(R, o.luz[3]);
+    s.Luu.x = ld_or_zero(R, o.luu[0]); s.Luu.y = ld_or_zero(R, o.luu[1]);
+    s.Luu.z = ld_or_zero(R, o.luu[2]); s.Luu.w = ld_or_zero(R, o.luu[3]);
+}
+
+// Eigen's pivoted LDLT + solve(I) (slow path; identical to generic.hip's dev_ldlt_inverse).
+__device__ static void slow_ldlt_inverse(int m, const double *M, int ms, double *a, double *x, double *temp, int *tr)
+{
+#define AA(i, j) a[(i) + (j) * m]
+#define XX(i, j) x[(i) + (j) * m]
+    for (int j = 0; j < m; j++) for (int i = 0; i < m; i++) AA(i, j) = M[i * ms + j];
+    for (int k = 0; k < m; k++) {
+        int big = k; double bv = fabs(AA(k, k));
+        for (int i = k + 1; i < m; i++) if (fabs(AA(i, i)) > bv) { bv = fabs(AA(i, i)); big = i; }
+        tr[k] = big;
+        if (big != k) {
+            for (int j = 0; j < k; j++) { double t = AA(k, j); AA(k, j) = AA(big, j); AA(big, j) = t; }
+            for (int i = big + 1; i < m; i++) { double t = AA(i, k); AA(i, k) = AA(i, big); AA(i, big) = t; }
+            { double t = AA(k, k); AA(k, k) = AA(big, big); AA(big, big) = t; }
+            for (int i = k + 1; i < big; i++) { double t = AA(i, k); AA(i, k) = AA(big, i); AA(big, i) = t; }
+        }
+        if (k > 0) {
+            for (int j = 0; j < k; j++) temp[j] = AA(j, j) * AA(k, j);
+            double dot = 0.0;
+            for (int j = 0; j < k; j++) dot += AA(k, j) * temp[j];
+            AA(k, k) -= dot;
+            for (int i = k + 1; i < m; i++) {
+                double d2 = 0.0;
+                for (int j = 0; j < k; j++) d2 += AA(i, j) * temp[j];
+                AA(i, k) -= d2;
+            }
+        }
+        const double akk = AA(k, k);
+        const bool valid = fabs(akk) > 0.0;
+        if (k == 0 && !valid) { for (int j = 0; j < m; j++) tr[j] = j; break; }
+        if (valid) for (int i = k + 1; i < m; i++) AA(i, k) /= akk;
+    }
+    for (int c = 0; c < m; c++) for (int r = 0; r < m; r++) XX(r, c) = (r == c) ? 1.0 : 0.0;
+    for (int k = 0; k < m; k++)
+        if (tr[k] != k) for (int c = 0; c < m; c++) { double t = XX(k, c); XX(k, c) = XX(tr[k], c); XX(tr[k], c) = t; }
+    for (int c = 0; c < m; c++)
+        for (int k = 0; k < m; k++) {
+            const double b = XX(k, c);
+            for (int i = k + 1; i < m; i++) XX(i, c) -= b * AA(i, k);
+        }
+    for (int i = 0; i < m; i++) {
+        const double d = AA(i, i);
+        for (int c = 0; c < m; c++) {
+            if (fabs(d) > 2.2250738585072014e-308) XX(i, c) /= d; else XX(i, c) = 0.0;
+        }
+    }
+    for (int c = 0; c < m; c++)
+        for (int k = m - 1; k >= 0; k--) {
+            const double b = XX(k, c);
+            for (int i = 0; i < k; i++) XX(i, c) -= b * AA(k, i);
+        }
+    for (int k = m - 1; k >= 0; k--)
+        if (tr[k] != k) for (int c = 0; c < m; c++) { double t = XX(k, c); XX(k, c) = XX(tr[k], c); XX(tr[k], c) = t; }
+#undef AA
+#undef XX
+}
+
+// LDS map (doubles).  MS: row stride of the Quu image; MZ: column stride of the Quz image (odd ->
+// conflict-free column reads); VS: row stride of the transpose image.
+#define MS 16
+#define MZ 17
+#define VS 17
+#define LDS_Q 0
+#define LDS_Z (LDS_Q + 16 * MS)
+#define LDS_V (LDS_Z + 16 * MZ)
+#define LDS_SLOW (LDS_V + 16 * VS)
+#define LDS_TOTAL (LDS_SLOW + 2 * 256 + 16 + 16)
+
+template <int M, int NCZ, int NCU>
+__global__ void __launch_bounds__(64)
+k_backward_mfma(RecLayout L, int T, const double *__restrict__ rec, const double *__restrict__ lambda,
+                int pd_stride, double *__restrict__ Kout, double *__restrict__ kout,
+                double *__restrict__ delta_J, int *__restrict__ status)
+{
+    __shared__ __attribute__((aligned(16))) double sh[LDS_TOTAL];
+    const int n = L.n, m = M;
+    const int lane = threadIdx.x, c = lane & 15, q = lane >> 4;
+    const int b = blockIdx.x;
+    const double lam = lambda[b];
+
+    TileOffs o;
+#pragma unroll
+    for (int r = 0; r < 4; r++) {
+        const int row = 4 * r + q;
+        o.fz[r] = (row < n && c < n) ? L.off_A + row * n + c : -1;
+        o.one[r] = (row == n && c == n) ? 1.0 : 0.0;
+        o.fu[r] = (row < n && c < m) ? L.off_B + row * m + c : -1;
+        o.lzz[r] = (row < n && c < n) ? L.off_lxx + row * n + c
+                 : (c == n && row < n) ? L.off_lx + row
+                 : (row == n && c < n) ? L.off_lx + c : -1;
+        o.luz[r] = (row < m && c == n) ? L.off_lu + row : -1;
+        o.luu[r] = (row < m && c < m) ? L.off_luu + row * m + c : -1;
+    }
+    // where element (n,n) of a tile lives
+    const bool lane_nn = (c == n) && (q == (n & 3));
+    const int reg_nn = n >> 2;
+
+    const double *R0 = rec + (size_t)b * T * L.stride;
+    StepTiles cur, nxt;
+    load_step(R0 + (size_t)(T - 1) * L.stride, o, cur);
+    d4 V = cur.Lzz;                         // V_x = l_x[T-1]; V_xx = l_xx[T-1]   (iLQR.cpp:537-539)
+    nxt = cur;
+
+    int pd_counter = 0;
+    double dJ = 0.0;
+    int fail = 0;
+    const d4 zero = {0.0, 0.0, 0.0, 0.0};
+
+    for (int t = T - 1; t >= 0; t--) {
+        if (t > 0) load_step(R0 + (size_t)(t - 1) * L.stride, o, nxt);   // prefetch one step ahead
+        pd_counter++;
+        const bool check_pd = pd_counter >= pd_stride;
+
+        // ---- Tu = V' Fu ; Quu = l_uu + Fu' Tu --------------------------------------- :577
+        d4 Tu = P<NCZ>(V, cur.Fu, zero);
+        d4 Quu = P<NCZ>(cur.Fu, Tu, cur.Luu);
+        // Quu + lambda I -> LDS image (row-major, stride MS)
+        if (c < m) {
+            { const int row = q;      if (row < m) sh[LDS_Q + row * MS + c] = Quu.x + (row == c ? lam : 0.0); }
+            if (NCU > 1) { const int row = 4 + q;  if (row < m) sh[LDS_Q + row * MS + c] = Quu.y + (row == c ? lam : 0.0); }
+            if (NCU > 2) { const int row = 8 + q;  if (row < m) sh[LDS_Q + row * MS + c] = Quu.z + (row == c ? lam : 0.0); }
+            if (NCU > 3) { const int row = 12 + q; if (row < m) sh[LDS_Q + row * MS + c] = Quu.w + (row == c ? lam : 0.0); }
+        }
+        // ---- independent of the factorisation: Tz, Quz, Qzz --------------------------- :570-579
+        d4 Tz = P<NCZ>(V, cur.Fz, zero);
+        d4 Quz = P<NCZ>(cur.Fu, Tz, cur.Luz);
+        d4 Qzz = P<NCZ>(cur.Fz, Tz, cur.Lzz);
+        __syncthreads();
+
+        // ---- unpivoted LDL' of Quu + lambda I, redundantly in every lane (lower triangle) ----
+        double Lm[M][M], dd[M], rd[M];
+        bool pos = true;
+#pragma unroll
+        for (int j = 0; j < M; j++) {
+            double w[M];
+            double dj = sh[LDS_Q + j * MS + j];
+#pragma unroll
+            for (int kk = 0; kk < j; kk++) { w[kk] = Lm[j][kk] * dd[kk]; dj -= Lm[j][kk] * w[kk]; }
+            dd[j] = dj;
+            pos = pos && (dj > 0.0);
+            const double rj = 1.0 / dj;
+            rd[j] = rj;
+#pragma unroll
+            for (int i = j + 1; i < M; i++) {
+                double v = sh[LDS_Q + i * MS + j];
+#pragma unroll
+                for (int kk = 0; kk < j; kk++) v -= Lm[i][kk] * w[kk];
+                Lm[i][j] = v * rj;
+            }
+        }
+        if (check_pd) {                       // CheckMatrixPD every pd_stride steps   :587-595
+            if (!pos) { fail = t + 1; break; }
+            pd_counter = 0;
+        }
+
+        // ---- Quz -> LDS (column image), then every lane solves its own column ------------------
+        {
+            { const int row = q;      sh[LDS_Z + c * MZ + row] = Quz.x; }
+            if (NCU > 1) { const int row = 4 + q;  sh[LDS_Z + c * MZ + row] = Quz.y; }
+            if (NCU > 2) { const int row = 8 + q;  sh[LDS_Z + c * MZ + row] = Quz.z; }
+            if (NCU > 3) { const int row = 12 + q; sh[LDS_Z + c * MZ + row] = Quz.w; }
+        }
+        __syncthreads();
+        double x[M];
+        if (pos) {
+#pragma unroll
+            for (int i = 0; i < M; i++) x[i] = sh[LDS_Z + c * MZ + i];
+#pragma unroll
+            for (int j = 0; j < M; j++) {            // L y = z
+#pragma unroll
+                for (int i = j + 1; i < M; i++) x[i] -= Lm[i][j] * x[j];
+            }
+#pragma unroll
+            for (int i = 0; i < M; i++) x[i] *= rd[i];   // D
+#pragma unroll
+            for (int j = M - 1; j >= 0; j--) {       // L' x = y
+#pragma unroll
+                for (int i = 0; i < j; i++) x[i] -= Lm[j][i] * x[j];
+            }
+#pragma unroll
+            for (int i = 0; i < M; i++) x[i] = -x[i];
+        } else {
+            // Q_uu + lambda I is not PD and this is not a checked step: follow Eigen's pivoted
+            // LDLT + explicit inverse exactly (iLQR.cpp:597-604).
+            double *wa = sh + LDS_SLOW, *wx = wa + 256, *wt = wx + 256;
+            int *tr = (int *)(wt + 16);
+            if (lane == 0) slow_ldlt_inverse(m, sh + LDS_Q, MS, wa, wx, wt, tr);
+            __syncthreads();
+#pragma unroll
+            for (int i = 0; i < M; i++) {
+                double s = 0.0;
+#pragma unroll
+                for (int p = 0; p < M; p++) s += (-wx[i + p * m]) * sh[LDS_Z + c * MZ + p];
+                x[i] = s;
+            }
+            __syncthreads();
+        }
+        // K' tile in D layout: register r of lane (c,q) = K'[4r+q][c]
+        d4 Kp = zero;
+        const bool colok = (c <= n);
+#pragma unroll
+        for (int i = 0; i < M; i++) {
+            const double xi = colok ? x[i] : 0.0;
+            if ((i & 3) == 0) { if (q == 0) { if (i / 4 == 0) Kp.x = xi; else if (i / 4 == 1) Kp.y = xi; else if (i / 4 == 2) Kp.z = xi; else Kp.w = xi; } }
+            if ((i & 3) == 1) { if (q == 1) { if (i / 4 == 0) Kp.x = xi; else if (i / 4 == 1) Kp.y = xi; else if (i / 4 == 2) Kp.z = xi; else Kp.w = xi; } }
+            if ((i & 3) == 2) { if (q == 2) { if (i / 4 == 0) Kp.x = xi; else if (i / 4 == 1) Kp.y = xi; else if (i / 4 == 2) Kp.z = xi; else Kp.w = xi; } }
+            if ((i & 3) == 3) { if (q == 3) { if (i / 4 == 0) Kp.x = xi; else if (i / 4 == 1) Kp.y = xi; else if (i / 4 == 2) Kp.z = xi; else Kp.w = xi; } }
+        }
+        // K (m x n column-major) and k out: lane (c,q) owns rows q, 4+q, ... of column c
+        {
+            double *Kt = Kout + ((size_t)b * T + t) * m * n;
+            double *kt = kout + ((size_t)b * T + t) * m;
+            const double kv[4] = {Kp.x, Kp.y, Kp.z, Kp.w};
+#pragma unroll
+            for (int r = 0; r < NCU; r++) {
+                const int row = 4 * r + q;
+                if (row < m) {
+                    if (c < n) Kt[row + c * m] = kv[r];
+                    else if (c == n) kt[row] = kv[r];
+                }
+            }
+        }
+
+        // ---- V' = Qzz + K''(Quu K' + Quz) + Quz' K'   (:606-607), delta_J (:612-613) ---------------
+        d4 W = P<NCU>(Quu, Kp, Quz);               // Quu' K' + Quz  (Quu symmetric up to rounding)
+        d4 acc = P<NCU>(Kp, W, Qzz);
+        {
+            const double a_nn = reg_nn == 0 ? acc.x : reg_nn == 1 ? acc.y : reg_nn == 2 ? acc.z : acc.w;
+            const double q_nn = reg_nn == 0 ? Qzz.x : reg_nn == 1 ? Qzz.y : reg_nn == 2 ? Qzz.z : Qzz.w;
+            if (lane_nn) dJ += a_nn - q_nn;         // q_nn == 0 exactly: element (n,n) is kept at zero
+        }
+        acc = P<NCU>(Quz, Kp, acc);
+
+        // ---- V' = (V' + V'')/2 through an LDS transpose   (:610) -----------------------------------
+        sh[LDS_V + (q) * VS + c] = acc.x;
+        sh[LDS_V + (4 + q) * VS + c] = acc.y;
+        sh[LDS_V + (8 + q) * VS + c] = acc.z;
+        sh[LDS_V + (12 + q) * VS + c] = acc.w;
+        __syncthreads();
+        V.x = 0.5 * (acc.x + sh[LDS_V + c * VS + q]);
+        V.y = 0.5 * (acc.y + sh[LDS_V + c * VS + 4 + q]);
+        V.z = 0.5 * (acc.z + sh[LDS_V + c * VS + 8 + q]);
+        V.w = 0.5 * (acc.w + sh[LDS_V + c * VS + 12 + q]);
+        if (lane_nn) { if (reg_nn == 0) V.x = 0.0; else if (reg_nn == 1) V.y = 0.0; else if (reg_nn == 2) V.z = 0.0; else V.w = 0.0; }
+        __syncthreads();
+        cur = nxt;
+    }
+    // delta_J lives in lane_nn; status is uniform
+    if (lane_nn) delta_J[b] = dJ;
+    if (lane == 0) status[b] = fail;
+}
+
+bool backward_mfma_supported(int n, int m)
+{
+    return (n + 1 <= 16) && (m == 7 || m == 1) && n >= 2;
+}
+
+hipError_t launch_backward_mfma(Ctx *c, int pd_stride)
+{
+    const int n = c->n, m = c->d.m;
+    const int ncz = (n + 1 + 3) / 4;
+    dim3 grid(c->d.batch), block(64);
+#define LAUNCH(MM, NCZ, NCU)                                                                              \
+    hipLaunchKernelGGL((k_backward_mfma<MM, NCZ, NCU>), grid, block, 0, c->stream, c->L, c->d.T, c->rec,  \
+                       c->lambda, pd_stride, c->K, c->k, c->delta_J, c->status)
+    if (m == 7) {
+        if (ncz <= 2) LAUNCH(7, 2, 2); else if (ncz == 3) LAUNCH(7, 3, 2); else LAUNCH(7, 4, 2);
+    } else if (m == 1) {
+        if (ncz <= 2) LAUNCH(1, 2, 1); else if (ncz == 3) LAUNCH(1, 3, 1); else LAUNCH(1, 4, 1);
+    } else {
+        return hipErrorInvalidValue;
+    }
+#undef LAUNCH
+    return hipGetLastError();
+}
+
+}  // namespace kpilqr

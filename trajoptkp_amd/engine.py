@@ -1,0 +1,251 @@
+"""Python host-side mirror of the C ABI: one `Engine` = one kpilqr_ctx.
+
+Array conventions are those of include/kpilqr.h (the reference's Eigen layout): numpy float64,
+C-contiguous, one COLUMN-MAJOR matrix per step, i.e. shapes
+    A [B,T,n,n] (A[b,t,c,r] = A(r,c)),  B [B,T,m,n],  l_xx [B,T,n,n],  l_uu [B,T,m,m],
+    K [B,T,n,m] (K[b,t,c,r] = K(r,c), K is m x n),  k [B,T,m],  r [B,T+1,nr],  r_x [B,T+1,nr,n] ...
+Nothing here computes: every method forwards to libkpilqr.so and raises if it reports an error.
+"""
+import ctypes as C
+
+import numpy as np
+
+from . import _lib
+
+
+class KpilqrError(RuntimeError):
+    def __init__(self, code, msg):
+        super().__init__(f"kpilqr error {code}: {msg}")
+        self.code = code
+
+
+def _f64(a, shape=None):
+    a = np.ascontiguousarray(a, dtype=np.float64)
+    if shape is not None and tuple(a.shape) != tuple(shape):
+        raise ValueError(f"expected shape {tuple(shape)}, got {tuple(a.shape)}")
+    return a
+
+
+def _ptr(a):
+    return None if a is None else a.ctypes.data_as(C.c_void_p)
+
+
+class _DeviceArray:
+    """Zero-copy view of a context-owned device buffer (for torch.as_tensor(..., device='cuda'))."""
+
+    def __init__(self, ptr, shape, typestr, owner):
+        self.__cuda_array_interface__ = {"shape": tuple(shape), "typestr": typestr, "data": (ptr, False),
+                                         "version": 2, "strides": None}
+        self._owner = owner
+
+
+class Engine:
+    def __init__(self, dof, m, T, nr, batch=1, n_alpha=6, device=0, stream=None, generic=False):
+        self._L = _lib.load()
+        self.dof, self.n, self.m, self.T, self.nr = dof, 2 * dof, m, T, nr
+        self.batch, self.n_alpha, self.device = batch, n_alpha, device
+        d = _lib.Dims(dof, m, T, nr, batch, n_alpha, device, _lib.FLAG_GENERIC_KERNELS if generic else 0)
+        h = C.c_void_p()
+        rc = self._L.kpilqr_create(C.byref(d), C.c_void_p(stream) if stream else None, C.byref(h))
+        if rc != 0:
+            raise KpilqrError(rc, (self._L.kpilqr_strerror(None) or b"").decode())
+        self._h = h
+        self._keep = []
+
+    # -- plumbing -------------------------------------------------------------------------------
+    def _ck(self, rc):
+        if rc < 0:
+            raise KpilqrError(rc, (self._L.kpilqr_strerror(self._h) or b"").decode())
+        return rc
+
+    def close(self):
+        if getattr(self, "_h", None):
+            self._L.kpilqr_destroy(self._h)
+            self._h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def __enter__(self):
+        return self
+
+    def __exit__(self, *a):
+        self.close()
+
+    def sync(self):
+        self._ck(self._L.kpilqr_sync(self._h))
+        self._keep.clear()
+
+    @property
+    def backward_variant(self):
+        return self._L.kpilqr_backward_variant(self._h).decode()
+
+    @property
+    def forward_variant(self):
+        return self._L.kpilqr_forward_variant(self._h).decode()
+
+    def device_array(self, which, shape, typestr="<f8"):
+        p, sz = C.c_void_p(), C.c_size_t()
+        self._ck(self._L.kpilqr_device_ptr(self._h, which, C.byref(p), C.byref(sz)))
+        item = int(typestr[2:])
+        if int(np.prod(shape)) * item > sz.value:
+            raise ValueError("requested view larger than the device buffer")
+        return _DeviceArray(p.value, shape, typestr, self)
+
+    # -- STEP 1b --------------------------------------------------------------------------------
+    def set_keypoints(self, kp_offsets, kp_times):
+        """Per-DoF CSR: kp_times[kp_offsets[b*dof+i]:kp_offsets[b*dof+i+1]] sorted time indices."""
+        o = np.ascontiguousarray(kp_offsets, dtype=np.int32)
+        t = np.ascontiguousarray(kp_times, dtype=np.int32)
+        if o.shape != (self.batch * self.dof + 1,):
+            raise ValueError("kp_offsets must have batch*dof+1 entries")
+        if t.shape != (int(o[-1]),):
+            raise ValueError("kp_times length must equal kp_offsets[-1]")
+        self._ck(self._L.kpilqr_set_keypoints(self._h, _ptr(o), _ptr(t if len(t) else np.zeros(1, np.int32))))
+
+    def set_keypoints_rows(self, per_traj):
+        """per_traj: list over b of (offs[T+1], cols) -- the reference's keypoints[t] lists."""
+        offs, times = rows_to_dof_csr(per_traj, self.dof, self.T)
+        self.set_keypoints(offs, times)
+
+    def upload_fd(self, job_b, job_t, job_col, job_mode, xplus, xminus, job_nom=None, xnom=None, eps=1e-6):
+        nj = len(job_t)
+        jb = np.ascontiguousarray(job_b, np.int32); jt = np.ascontiguousarray(job_t, np.int32)
+        jc = np.ascontiguousarray(job_col, np.int32); jm = np.ascontiguousarray(job_mode, np.uint8)
+        xp = _f64(xplus, (nj, self.n)); xm = _f64(xminus, (nj, self.n))
+        jn = None if job_nom is None else np.ascontiguousarray(job_nom, np.int32)
+        xn = None if xnom is None else _f64(xnom)
+        nnom = 0 if xn is None else xn.shape[0]
+        self._keep += [jb, jt, jc, jm, xp, xm, jn, xn]
+        self._ck(self._L.kpilqr_upload_fd(self._h, nj, _ptr(jb), _ptr(jt), _ptr(jc), _ptr(jm), _ptr(jn),
+                                          _ptr(xp), _ptr(xm), nnom, _ptr(xn), float(eps)))
+
+    def fd_difference(self):
+        self._ck(self._L.kpilqr_fd_difference(self._h))
+
+    def interpolate(self):
+        self._ck(self._L.kpilqr_interpolate(self._h))
+
+    # -- STEP 1c --------------------------------------------------------------------------------
+    def upload_residuals(self, r=None, r_x=None, r_u=None, w_run=None, w_term=None):
+        B, T1, n, m, nr = self.batch, self.T + 1, self.n, self.m, self.nr
+        r = None if r is None else _f64(r, (B, T1, nr))
+        r_x = None if r_x is None else _f64(r_x, (B, T1, nr, n))
+        r_u = None if r_u is None else _f64(r_u, (B, T1, nr, m))
+        w_run = None if w_run is None else _f64(w_run, (nr,))
+        w_term = None if w_term is None else _f64(w_term, (nr,))
+        self._keep += [r, r_x, r_u, w_run, w_term]
+        self._ck(self._L.kpilqr_upload_residuals(self._h, _ptr(r), _ptr(r_x), _ptr(r_u), _ptr(w_run), _ptr(w_term)))
+
+    def cost_derivs(self):
+        self._ck(self._L.kpilqr_cost_derivs(self._h))
+
+    def trajectory_cost(self):
+        out = np.zeros(self.batch)
+        self._ck(self._L.kpilqr_trajectory_cost(self._h, _ptr(out)))
+        self.sync()
+        return out
+
+    # -- STEP 2 ---------------------------------------------------------------------------------
+    def backward(self, lam, pd_stride=100, fetch=True):
+        if lam is not None:         # None: keep the lambdas already resident on the device
+            lam = _f64(np.broadcast_to(np.asarray(lam, dtype=np.float64), (self.batch,)))
+            self._keep.append(lam)
+        if not fetch:
+            self._ck(self._L.kpilqr_backward(self._h, _ptr(lam), pd_stride, None, None))
+            return None
+        status = np.zeros(self.batch, np.int32); dJ = np.zeros(self.batch)
+        self._ck(self._L.kpilqr_backward(self._h, _ptr(lam), pd_stride, _ptr(status), _ptr(dJ)))
+        self.sync()
+        return status, dJ
+
+    def gains(self):
+        K = np.zeros((self.batch, self.T, self.n, self.m)); k = np.zeros((self.batch, self.T, self.m))
+        self._ck(self._L.kpilqr_download_gains(self._h, _ptr(K), _ptr(k)))
+        self.sync()
+        return K, k
+
+    # -- STEP 3 ---------------------------------------------------------------------------------
+    def upload_nominal(self, u_nom=None, ctrl_lim=None):
+        u = None if u_nom is None else _f64(u_nom, (self.batch, self.T, self.m))
+        cl = None if ctrl_lim is None else _f64(ctrl_lim, (2 * self.m,))
+        self._keep += [u, cl]
+        self._ck(self._L.kpilqr_upload_nominal(self._h, _ptr(u), _ptr(cl)))
+
+    def forward_linear(self, alphas, want_U=False, fetch=True):
+        a = None if alphas is None else _f64(alphas, (self.n_alpha,))   # None: keep resident alphas
+        self._keep.append(a)
+        if not fetch:
+            self._ck(self._L.kpilqr_forward_linear(self._h, _ptr(a), None, None))
+            return None
+        cost = np.zeros((self.batch, self.n_alpha))
+        U = np.zeros((self.batch, self.n_alpha, self.T, self.m)) if want_U else None
+        self._ck(self._L.kpilqr_forward_linear(self._h, _ptr(a), _ptr(cost), _ptr(U)))
+        self.sync()
+        return (cost, U) if want_U else cost
+
+    def iterate(self, lam=None, pd_stride=100, alphas=None):
+        """Enqueue STEP 1b + 1c + 2 + 3 back to back (asynchronous)."""
+        lam = None if lam is None else _f64(np.broadcast_to(np.asarray(lam, dtype=np.float64), (self.batch,)))
+        a = None if alphas is None else _f64(alphas, (self.n_alpha,))
+        self._keep += [lam, a]
+        self._ck(self._L.kpilqr_iterate(self._h, _ptr(lam), pd_stride, _ptr(a)))
+
+    def results(self):
+        """Device-resident outputs of the last backward/forward: status, delta_J, cost_pred."""
+        import ctypes
+        out = {}
+        self.sync()
+        for name, which, shape, dt in (("status", _lib.BUF_STATUS, (self.batch,), np.int32),
+                                       ("delta_J", _lib.BUF_DELTA_J, (self.batch,), np.float64),
+                                       ("cost_pred", _lib.BUF_COST_PRED, (self.batch, self.n_alpha), np.float64)):
+            out[name] = self._d2h(which, shape, dt)
+        return out
+
+    def _d2h(self, which, shape, dt):
+        import torch
+        t = torch.as_tensor(self.device_array(which, shape, "<i4" if dt == np.int32 else "<f8"),
+                            device=f"cuda:{self.device}")
+        return t.cpu().numpy().copy()
+
+    # -- debug / oracle hooks ---------------------------------------------------------------------
+    def set_AB(self, A=None, B=None):
+        Bt, T, n, m = self.batch, self.T, self.n, self.m
+        A = None if A is None else _f64(A, (Bt, T, n, n)); B = None if B is None else _f64(B, (Bt, T, m, n))
+        self._ck(self._L.kpilqr_set_AB(self._h, _ptr(A), _ptr(B)))
+
+    def get_AB(self):
+        Bt, T, n, m = self.batch, self.T, self.n, self.m
+        A = np.zeros((Bt, T, n, n)); B = np.zeros((Bt, T, m, n))
+        self._ck(self._L.kpilqr_get_AB(self._h, _ptr(A), _ptr(B)))
+        return A, B
+
+    def set_cost_derivs(self, l_x=None, l_xx=None, l_u=None, l_uu=None):
+        Bt, T, n, m = self.batch, self.T, self.n, self.m
+        l_x = None if l_x is None else _f64(l_x, (Bt, T, n)); l_xx = None if l_xx is None else _f64(l_xx, (Bt, T, n, n))
+        l_u = None if l_u is None else _f64(l_u, (Bt, T, m)); l_uu = None if l_uu is None else _f64(l_uu, (Bt, T, m, m))
+        self._ck(self._L.kpilqr_set_cost_derivs(self._h, _ptr(l_x), _ptr(l_xx), _ptr(l_u), _ptr(l_uu)))
+
+    def get_cost_derivs(self):
+        Bt, T, n, m = self.batch, self.T, self.n, self.m
+        l_x = np.zeros((Bt, T, n)); l_xx = np.zeros((Bt, T, n, n)); l_u = np.zeros((Bt, T, m)); l_uu = np.zeros((Bt, T, m, m))
+        self._ck(self._L.kpilqr_get_cost_derivs(self._h, _ptr(l_x), _ptr(l_xx), _ptr(l_u), _ptr(l_uu)))
+        return l_x, l_xx, l_u, l_uu
+
+
+def rows_to_dof_csr(per_traj, dof, T):
+    """Reference key-point rows (CSR over time, one (offs, cols) pair per trajectory) -> the C ABI's
+    per-DoF CSR of sorted, de-duplicated time indices (offsets [B*dof+1], times)."""
+    offs = [0]
+    times = []
+    for (o, c) in per_traj:
+        o = np.asarray(o); c = np.asarray(c)
+        t_of = np.repeat(np.arange(T), np.diff(o))
+        for i in range(dof):
+            ti = np.unique(t_of[c == i])
+            times.append(ti.astype(np.int32))
+            offs.append(offs[-1] + len(ti))
+    return np.asarray(offs, np.int32), (np.concatenate(times) if times else np.zeros(0, np.int32))
