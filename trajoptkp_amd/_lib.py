@@ -52,6 +52,15 @@ def load():
         return _lib
     if not os.path.exists(LIB_PATH):
         build()
+    # One HIP runtime per process: PyTorch-ROCm bundles its own libamdhip64.so.7 / libhsa-runtime64
+    # (torch/lib).  If libkpilqr.so were loaded first it would pull /opt/rocm's copy and a later
+    # `import torch` would bring a SECOND runtime that finds no GPU.  Importing torch first makes the
+    # loader resolve our DT_NEEDED libamdhip64.so.7 to the copy torch already mapped.  torch is only
+    # plumbing here (streams, events, torch.distributed); C/C++ hosts link the system runtime.
+    try:
+        import torch  # noqa: F401
+    except ImportError:
+        pass
     L = C.CDLL(LIB_PATH)
     vp, ip, dp = C.c_void_p, C.POINTER(C.c_int), C.POINTER(C.c_double)
     L.kpilqr_create.argtypes = [C.POINTER(Dims), vp, C.POINTER(vp)]
