@@ -59,6 +59,7 @@ def cpu_baseline(task, T, min_N, n_traj_per_core=8):
         cores = len(os.sched_getaffinity(0))
     except Exception:
         pass
+    cores = min(cores, int(os.environ.get("KPILQR_CPU_THREADS", "16")))   # a 1-GPU box's CPU share is 16 cores
     uniq = 4
     p = synth.make_problem(task=task, T=T, batch=uniq, min_N=min_N)
     pipeline.run_trajectory(p, 0)                      # warm-up
@@ -109,7 +110,10 @@ def main():
     if reps > 1:
         p = synth.tile_problem(p, reps)
     B = p["batch"]
-    stream = torch.cuda.current_stream()
+    # a dedicated (non-null) HIP stream shared by torch and the engine: kernels, HIP events and the
+    # RCCL all-reduce are all ordered on it
+    stream = torch.cuda.Stream()
+    torch.cuda.set_stream(stream)
     eng = Engine(p["dof"], p["m"], T, p["nr"], batch=B, device=local_rank, stream=stream.cuda_stream,
                  generic=args.generic)
     synth.upload(eng, p)
