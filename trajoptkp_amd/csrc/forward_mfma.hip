@@ -10,8 +10,8 @@
 // Tiles in the MFMA "D" layout (lane (c,q), register r <-> element (4r+q, c)); primitive
 // P(Y,X) = Y'X as in riccati_mfma.hip.  State tile Z: rows 0..n-1 = dx, row n = alpha, row n+1 = 1,
 // column a = line-search candidate a.  Then with
-//     Yk = [K' ; k' ; u_nom']  (rows = state index / alpha / one, cols = control index)
-//     U  = P(Yk, Z) = K dx + alpha k + u_nom            (:879, association differs by rounding)
+//     Yk = [K' ; k']  (rows = state index / alpha, cols = control index)
+//     U  = u_nom + P(Yk, Z) = u_nom + K dx + alpha k    (:879, association differs by rounding)
 //     dU = clamp(U) - u_nom                              (:883-889)
 //     Z+ = P(Ya, Z) + P(Yb, dU),  Ya = [A' 0 0; 0 1 0; 0 0 1], Yb = B'
 //     cost: lane-local  sum_r Z_r * P(Lc, Z)_r / 2 + dU_r * (P(Luu, dU)_r / 2 + l_u)   with
@@ -34,10 +34,17 @@ __device__ __forceinline__ d4 PF(const d4 &Y, const d4 &X, d4 acc)
     return acc;
 }
 
-__device__ __forceinline__ double ldz(const double *R, int off)
+// Bounds-checked buffer loads: a lane whose tile element is a structural zero carries an out-of-range
+// offset and gets 0 from the hardware (no select on the loaded value -> the loads of step t+1 stay in
+// flight behind the whole of step t; see riccati_mfma.hip).
+#define OOB 0x7ffffff0
+__device__ __forceinline__ double bld(__amdgpu_buffer_rsrc_t r, int byte_off)
 {
-    const double v = R[off < 0 ? 0 : off];
-    return off < 0 ? 0.0 : v;
+    return __builtin_bit_cast(double, __builtin_amdgcn_raw_buffer_load_b64(r, byte_off, 0, 0));
+}
+__device__ __forceinline__ __amdgpu_buffer_rsrc_t rsrc(const double *p, int bytes)
+{
+    return __builtin_amdgcn_make_buffer_rsrc((void *)p, 0, bytes, 0x00020000);
 }
 
 template <int NCZ, int NCU>
@@ -52,24 +59,23 @@ k_forward_mfma(RecLayout L, int T, int n_alpha, const double *__restrict__ rec,
     const int lane = threadIdx.x, c = lane & 15, q = lane >> 4;
     const int b = blockIdx.x;
 
-    // per-lane source offsets (doubles); -1 = structural zero
-    int oK[4], ok_[4], oun[4], oA[4], oB[4], oLc[4], oLuu[4], olu[4], oub[4];
+    // per-lane source BYTE offsets; OOB = structural zero
+    int oK[4], ok_[4], oA[4], oB[4], oLc[4], oLuu[4], olu[4], oub[4];
     double oneA[4], lo[4], hi[4];
 #pragma unroll
     for (int r = 0; r < 4; r++) {
         const int row = 4 * r + q;
-        oK[r] = (row < n && c < m) ? row * m + c : -1;            // K(i=c, p=row) at c + row*m
-        ok_[r] = (row == n && c < m) ? c : -1;                     // k(i=c)
-        oun[r] = (row == n + 1 && c < m) ? c : -1;                 // u_nom(i=c)
-        oA[r] = (row < n && c < n) ? L.off_A + c * n + row : -1;   // A(i=c, p=row)
+        oK[r] = (row < n && c < m) ? 8 * (row * m + c) : OOB;            // K(i=c, p=row) at c + row*m
+        ok_[r] = (row == n && c < m) ? 8 * c : OOB;                      // k(i=c)
+        oA[r] = (row < n && c < n) ? 8 * (L.off_A + c * n + row) : OOB;  // A(i=c, p=row)
         oneA[r] = ((row == n && c == n) || (row == n + 1 && c == n + 1)) ? 1.0 : 0.0;
-        oB[r] = (row < m && c < n) ? L.off_B + c * m + row : -1;   // B(i=c, p=row)
-        oLc[r] = (row < n && c < n) ? L.off_lxx + row * n + c
-               : (row == n + 1 && c < n) ? L.off_lx + c
-               : (c == n + 1 && row < n) ? L.off_lx + row : -1;
-        oLuu[r] = (row < m && c < m) ? L.off_luu + row * m + c : -1;
-        olu[r] = (row < m) ? L.off_lu + row : -1;
-        oub[r] = (row < m) ? row : -1;
+        oB[r] = (row < m && c < n) ? 8 * (L.off_B + c * m + row) : OOB;  // B(i=c, p=row)
+        oLc[r] = (row < n && c < n) ? 8 * (L.off_lxx + row * n + c)
+               : (row == n + 1 && c < n) ? 8 * (L.off_lx + c)
+               : (c == n + 1 && row < n) ? 8 * (L.off_lx + row) : OOB;
+        oLuu[r] = (row < m && c < m) ? 8 * (L.off_luu + row * m + c) : OOB;
+        olu[r] = (row < m) ? 8 * (L.off_lu + row) : OOB;
+        oub[r] = (row < m) ? 8 * row : OOB;
         lo[r] = (row < m) ? ctrl_lim[2 * row] : -1.0e300;
         hi[r] = (row < m) ? ctrl_lim[2 * row + 1] : 1.0e300;
     }
@@ -87,34 +93,41 @@ k_forward_mfma(RecLayout L, int T, int n_alpha, const double *__restrict__ rec,
     const d4 zero = {0.0, 0.0, 0.0, 0.0};
     double partial = 0.0;
 
-    struct Tiles { d4 Yk, Ya, Yb, Lc, Luu, lu, ub; };
+    struct Tiles { d4 YkK, Ykk, Ya, Yb, Lc, Luu, lu, ub; };
+    const int rec_bytes = L.rec * 8;
     auto load_tiles = [&](int t, Tiles &s) {
-        const double *R = rec + ((size_t)b * T + t) * L.stride;
-        const double *Kt = Kin + ((size_t)b * T + t) * m * n;
-        const double *kt = kin + ((size_t)b * T + t) * m;
-        const double *un = u_nom + ((size_t)b * T + t) * m;
-        s.Yk.x = ldz(Kt, oK[0]) + ldz(kt, ok_[0]) + ldz(un, oun[0]);
-        s.Yk.y = ldz(Kt, oK[1]) + ldz(kt, ok_[1]) + ldz(un, oun[1]);
-        s.Yk.z = ldz(Kt, oK[2]) + ldz(kt, ok_[2]) + ldz(un, oun[2]);
-        s.Yk.w = ldz(Kt, oK[3]) + ldz(kt, ok_[3]) + ldz(un, oun[3]);
-        s.Ya.x = ldz(R, oA[0]) + oneA[0]; s.Ya.y = ldz(R, oA[1]) + oneA[1];
-        s.Ya.z = ldz(R, oA[2]) + oneA[2]; s.Ya.w = ldz(R, oA[3]) + oneA[3];
-        s.Yb.x = ldz(R, oB[0]); s.Yb.y = ldz(R, oB[1]); s.Yb.z = ldz(R, oB[2]); s.Yb.w = ldz(R, oB[3]);
-        s.Lc.x = ldz(R, oLc[0]); s.Lc.y = ldz(R, oLc[1]); s.Lc.z = ldz(R, oLc[2]); s.Lc.w = ldz(R, oLc[3]);
-        s.Luu.x = ldz(R, oLuu[0]); s.Luu.y = ldz(R, oLuu[1]); s.Luu.z = ldz(R, oLuu[2]); s.Luu.w = ldz(R, oLuu[3]);
-        s.lu.x = ldz(R, olu[0]); s.lu.y = ldz(R, olu[1]); s.lu.z = ldz(R, olu[2]); s.lu.w = ldz(R, olu[3]);
-        s.ub.x = ldz(un, oub[0]); s.ub.y = ldz(un, oub[1]); s.ub.z = ldz(un, oub[2]); s.ub.w = ldz(un, oub[3]);
+        __amdgpu_buffer_rsrc_t rR = rsrc(rec + ((size_t)b * T + t) * L.stride, rec_bytes);
+        __amdgpu_buffer_rsrc_t rK = rsrc(Kin + ((size_t)b * T + t) * m * n, m * n * 8);
+        __amdgpu_buffer_rsrc_t rk = rsrc(kin + ((size_t)b * T + t) * m, m * 8);
+        __amdgpu_buffer_rsrc_t ru = rsrc(u_nom + ((size_t)b * T + t) * m, m * 8);
+        s.YkK.x = bld(rK, oK[0]); s.YkK.y = bld(rK, oK[1]); s.YkK.z = bld(rK, oK[2]); s.YkK.w = bld(rK, oK[3]);
+        s.Ykk.x = bld(rk, ok_[0]); s.Ykk.y = bld(rk, ok_[1]); s.Ykk.z = bld(rk, ok_[2]); s.Ykk.w = bld(rk, ok_[3]);
+        s.Ya.x = bld(rR, oA[0]); s.Ya.y = bld(rR, oA[1]); s.Ya.z = bld(rR, oA[2]); s.Ya.w = bld(rR, oA[3]);
+        s.Yb.x = bld(rR, oB[0]); s.Yb.y = NCU > 1 ? bld(rR, oB[1]) : 0.0;
+        s.Yb.z = NCU > 2 ? bld(rR, oB[2]) : 0.0; s.Yb.w = NCU > 3 ? bld(rR, oB[3]) : 0.0;
+        s.Lc.x = bld(rR, oLc[0]); s.Lc.y = bld(rR, oLc[1]); s.Lc.z = bld(rR, oLc[2]); s.Lc.w = bld(rR, oLc[3]);
+        s.Luu.x = bld(rR, oLuu[0]); s.Luu.y = NCU > 1 ? bld(rR, oLuu[1]) : 0.0;
+        s.Luu.z = NCU > 2 ? bld(rR, oLuu[2]) : 0.0; s.Luu.w = NCU > 3 ? bld(rR, oLuu[3]) : 0.0;
+        s.lu.x = bld(rR, olu[0]); s.lu.y = NCU > 1 ? bld(rR, olu[1]) : 0.0;
+        s.lu.z = NCU > 2 ? bld(rR, olu[2]) : 0.0; s.lu.w = NCU > 3 ? bld(rR, olu[3]) : 0.0;
+        s.ub.x = bld(ru, oub[0]); s.ub.y = NCU > 1 ? bld(ru, oub[1]) : 0.0;
+        s.ub.z = NCU > 2 ? bld(ru, oub[2]) : 0.0; s.ub.w = NCU > 3 ? bld(ru, oub[3]) : 0.0;
     };
-    Tiles cur, nxt;
-    load_tiles(0, cur);
-    nxt = cur;
+    Tiles nxt;
+    load_tiles(0, nxt);
 
     for (int t = 0; t < T; t++) {
-        if (t + 1 < T) load_tiles(t + 1, nxt);      // prefetch one step ahead
-        const d4 Yk = cur.Yk, Ya = cur.Ya, Yb = cur.Yb, Lc = cur.Lc, Luu = cur.Luu, lu = cur.lu, ub = cur.ub;
+        // consume the loads issued one step ago, then request the next step's at once
+        const Tiles cur = nxt;
+        const d4 Yk = cur.YkK + cur.Ykk;
+        d4 Ya = cur.Ya;
+        Ya.x += oneA[0]; Ya.y += oneA[1]; Ya.z += oneA[2]; Ya.w += oneA[3];
+        const d4 Yb = cur.Yb, Lc = cur.Lc, Luu = cur.Luu, lu = cur.lu, ub = cur.ub;
+        if (t + 1 < T) load_tiles(t + 1, nxt);
+        __builtin_amdgcn_sched_barrier(0);     // keep the prefetch AHEAD of this step's compute
 
         // control law + clamp
-        d4 U = PF<NCZ>(Yk, Z, zero);
+        d4 U = PF<NCZ>(Yk, Z, ub);        // u_nom + K dx + alpha k
         d4 dU;
         {
             double u;
@@ -139,7 +152,6 @@ k_forward_mfma(RecLayout L, int T, int n_alpha, const double *__restrict__ rec,
         d4 Zn = PF<NCZ>(Ya, Z, zero);
         Zn = PF<NCU>(Yb, dU, Zn);
         Z = Zn;
-        cur = nxt;
     }
     // column sums: lanes c, c+16, c+32, c+48
     partial += __shfl_xor(partial, 16);

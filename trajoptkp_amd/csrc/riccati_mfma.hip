@@ -46,32 +46,47 @@ __device__ __forceinline__ d4 P(const d4 &Y, const d4 &X, d4 acc)
     return acc;
 }
 
-__device__ __forceinline__ double ld_or_zero(const double *R, int off)
+// Step-record loads go through a buffer descriptor that covers exactly ONE record: lanes whose tile
+// element is a structural zero carry an out-of-range offset and the hardware returns 0 for them
+// without touching memory.  No select on the loaded value means nothing consumes it until the MFMA
+// that needs it, so the loads of step t-1 stay in flight behind the whole of step t.
+typedef unsigned int u32x2 __attribute__((ext_vector_type(2)));
+#define OOB 0x7ffffff0
+
+__device__ __forceinline__ double bld(__amdgpu_buffer_rsrc_t r, int byte_off)
 {
-    const double v = R[off < 0 ? 0 : off];
-    return off < 0 ? 0.0 : v;
+    return __builtin_bit_cast(double, __builtin_amdgcn_raw_buffer_load_b64(r, byte_off, 0, 0));
 }
 
-struct TileOffs { int fz[4], fu[4], lzz[4], luz[4], luu[4]; double one[4]; };
+// 1/x to ~1 ulp: v_rcp_f64 seed + two Newton steps (the pivots are O(lambda)..O(1): no scaling needed;
+// a non-positive or non-finite pivot is caught by the `pos` test and takes the slow path).
+__device__ __forceinline__ double fast_rcp(double x)
+{
+    double r = __builtin_amdgcn_rcp(x);
+    r = __builtin_fma(__builtin_fma(-x, r, 1.0), r, r);
+    r = __builtin_fma(__builtin_fma(-x, r, 1.0), r, r);
+    return r;
+}
+
+struct TileOffs { int fz[4], fu[4], lzz[4], luz[4], luu[4]; };
 
 struct StepTiles { d4 Fz, Fu, Lzz, Luz, Luu; };
 
-__device__ __forceinline__ void load_step(const double *R, const TileOffs &o, StepTiles &s)
+template <int NCU>
+__device__ __forceinline__ void load_step(const double *R, int rec_bytes, const TileOffs &o, StepTiles &s)
 {
-    s.Fz.x = ld_or_zero(R, o.fz[0]) + o.one[0]; s.Fz.y = ld_or_zero(R, o.fz[1]) + o.one[1];
-    s.Fz.z = ld_or_zero(R, o.fz[2]) + o.one[2]; s.Fz.w = ld_or_zero(R, o.fz[3]) + o.one[3];
-    s.Fu.x = ld_or_zero(R, o.fu[0]); s.Fu.y = ld_or_zero(R, o.fu[1]);
-    s.Fu.z = ld_or_zero(R, o.fu[2]); s.Fu.w = ld_or_zero(R, o.fu[3]);
-    s.Lzz.x = ld_or_zero(R, o.lzz[0]); s.Lzz.y = ld_or_zero(R, o.lzz[1]);
-    s.Lzz.z = ld_or_zero(R, o.lzz[2]); s.Lzz.w = ld_or_zero(R, o.lzz[3]);
-    s.Luz.x = ld_or_zero(R, o.luz[0]); s.Luz.y = ld_or_zero(R, o.luz[1]);
-    s.Luz.z = ld_or_zero(R, o.luz[2]); s.Luz.w = ld_or_zero(R, o.luz[3]);
-    s.Luu.x = ld_or_zero(R, o.luu[0]); s.Luu.y = ld_or_zero(R, o.luu[1]);
-    s.Luu.z = ld_or_zero(R, o.luu[2]); s.Luu.w = ld_or_zero(R, o.luu[3]);
+    __amdgpu_buffer_rsrc_t r = __builtin_amdgcn_make_buffer_rsrc((void *)R, 0, rec_bytes, 0x00020000);
+    s.Fz.x = bld(r, o.fz[0]); s.Fz.y = bld(r, o.fz[1]); s.Fz.z = bld(r, o.fz[2]); s.Fz.w = bld(r, o.fz[3]);
+    s.Fu.x = bld(r, o.fu[0]); s.Fu.y = bld(r, o.fu[1]); s.Fu.z = bld(r, o.fu[2]); s.Fu.w = bld(r, o.fu[3]);
+    s.Lzz.x = bld(r, o.lzz[0]); s.Lzz.y = bld(r, o.lzz[1]); s.Lzz.z = bld(r, o.lzz[2]); s.Lzz.w = bld(r, o.lzz[3]);
+    s.Luz.x = bld(r, o.luz[0]); s.Luu.x = bld(r, o.luu[0]);
+    s.Luz.y = NCU > 1 ? bld(r, o.luz[1]) : 0.0; s.Luu.y = NCU > 1 ? bld(r, o.luu[1]) : 0.0;
+    s.Luz.z = NCU > 2 ? bld(r, o.luz[2]) : 0.0; s.Luu.z = NCU > 2 ? bld(r, o.luu[2]) : 0.0;
+    s.Luz.w = NCU > 3 ? bld(r, o.luz[3]) : 0.0; s.Luu.w = NCU > 3 ? bld(r, o.luu[3]) : 0.0;
 }
 
 // Eigen's pivoted LDLT + solve(I) (slow path; identical to generic.hip's dev_ldlt_inverse).
-__device__ static void slow_ldlt_inverse(int m, const double *M, int ms, double *a, double *x, double *temp, int *tr)
+__device__ static __attribute__((noinline)) void slow_ldlt_inverse(int m, const double *M, int ms, double *a, double *x, double *temp, int *tr)
 {
 #define AA(i, j) a[(i) + (j) * m]
 #define XX(i, j) x[(i) + (j) * m]
@@ -138,7 +153,10 @@ __device__ static void slow_ldlt_inverse(int m, const double *M, int ms, double 
 #define LDS_SLOW (LDS_V + 16 * VS)
 #define LDS_TOTAL (LDS_SLOW + 2 * 256 + 16 + 16)
 
-template <int M, int NCZ, int NCU>
+// ABL: ablation switches for tools/ablate_backward.cpp only (0 in the product): 1 = always load the
+// same record (no HBM streaming), 2 = skip the LDL' solve, 4 = skip the K/k stores, 8 = skip the
+// symmetrisation transpose.
+template <int M, int NCZ, int NCU, int ABL = 0>
 __global__ void __launch_bounds__(64)
 k_backward_mfma(RecLayout L, int T, const double *__restrict__ rec, const double *__restrict__ lambda,
                 int pd_stride, double *__restrict__ Kout, double *__restrict__ kout,
@@ -151,27 +169,28 @@ k_backward_mfma(RecLayout L, int T, const double *__restrict__ rec, const double
     const double lam = lambda[b];
 
     TileOffs o;
+    double one[4];
 #pragma unroll
     for (int r = 0; r < 4; r++) {
         const int row = 4 * r + q;
-        o.fz[r] = (row < n && c < n) ? L.off_A + row * n + c : -1;
-        o.one[r] = (row == n && c == n) ? 1.0 : 0.0;
-        o.fu[r] = (row < n && c < m) ? L.off_B + row * m + c : -1;
-        o.lzz[r] = (row < n && c < n) ? L.off_lxx + row * n + c
-                 : (c == n && row < n) ? L.off_lx + row
-                 : (row == n && c < n) ? L.off_lx + c : -1;
-        o.luz[r] = (row < m && c == n) ? L.off_lu + row : -1;
-        o.luu[r] = (row < m && c < m) ? L.off_luu + row * m + c : -1;
+        o.fz[r] = (row < n && c < n) ? 8 * (L.off_A + row * n + c) : OOB;
+        one[r] = (row == n && c == n) ? 1.0 : 0.0;
+        o.fu[r] = (row < n && c < m) ? 8 * (L.off_B + row * m + c) : OOB;
+        o.lzz[r] = (row < n && c < n) ? 8 * (L.off_lxx + row * n + c)
+                 : (c == n && row < n) ? 8 * (L.off_lx + row)
+                 : (row == n && c < n) ? 8 * (L.off_lx + c) : OOB;
+        o.luz[r] = (row < m && c == n) ? 8 * (L.off_lu + row) : OOB;
+        o.luu[r] = (row < m && c < m) ? 8 * (L.off_luu + row * m + c) : OOB;
     }
+    const int rec_bytes = L.rec * 8;
     // where element (n,n) of a tile lives
     const bool lane_nn = (c == n) && (q == (n & 3));
     const int reg_nn = n >> 2;
 
     const double *R0 = rec + (size_t)b * T * L.stride;
     StepTiles cur, nxt;
-    load_step(R0 + (size_t)(T - 1) * L.stride, o, cur);
-    d4 V = cur.Lzz;                         // V_x = l_x[T-1]; V_xx = l_xx[T-1]   (iLQR.cpp:537-539)
-    nxt = cur;
+    load_step<NCU>(R0 + (size_t)(T - 1) * L.stride, rec_bytes, o, nxt);
+    d4 V = nxt.Lzz;                         // V_x = l_x[T-1]; V_xx = l_xx[T-1]   (iLQR.cpp:537-539)
 
     int pd_counter = 0;
     double dJ = 0.0;
@@ -179,7 +198,11 @@ k_backward_mfma(RecLayout L, int T, const double *__restrict__ rec, const double
     const d4 zero = {0.0, 0.0, 0.0, 0.0};
 
     for (int t = T - 1; t >= 0; t--) {
-        if (t > 0) load_step(R0 + (size_t)(t - 1) * L.stride, o, nxt);   // prefetch one step ahead
+        // the loads issued one step ago are consumed here; then the next record is requested at once
+        cur = nxt;
+        cur.Fz.x += one[0]; cur.Fz.y += one[1]; cur.Fz.z += one[2]; cur.Fz.w += one[3];
+        if (t > 0) load_step<NCU>(R0 + (size_t)((ABL & 1) ? T - 1 : t - 1) * L.stride, rec_bytes, o, nxt);
+        __builtin_amdgcn_sched_barrier(0);     // keep the prefetch AHEAD of this step's compute
         pd_counter++;
         const bool check_pd = pd_counter >= pd_stride;
 
@@ -203,14 +226,14 @@ k_backward_mfma(RecLayout L, int T, const double *__restrict__ rec, const double
         double Lm[M][M], dd[M], rd[M];
         bool pos = true;
 #pragma unroll
-        for (int j = 0; j < M; j++) {
+        for (int j = 0; j < ((ABL & 2) ? 0 : M); j++) {
             double w[M];
             double dj = sh[LDS_Q + j * MS + j];
 #pragma unroll
             for (int kk = 0; kk < j; kk++) { w[kk] = Lm[j][kk] * dd[kk]; dj -= Lm[j][kk] * w[kk]; }
             dd[j] = dj;
             pos = pos && (dj > 0.0);
-            const double rj = 1.0 / dj;
+            const double rj = fast_rcp(dj);
             rd[j] = rj;
 #pragma unroll
             for (int i = j + 1; i < M; i++) {
@@ -234,7 +257,10 @@ k_backward_mfma(RecLayout L, int T, const double *__restrict__ rec, const double
         }
         __syncthreads();
         double x[M];
-        if (pos) {
+        if (ABL & 2) {
+#pragma unroll
+            for (int i = 0; i < M; i++) x[i] = -1e-3 * sh[LDS_Z + c * MZ + i];
+        } else if (pos) {
 #pragma unroll
             for (int i = 0; i < M; i++) x[i] = sh[LDS_Z + c * MZ + i];
 #pragma unroll
@@ -256,7 +282,7 @@ k_backward_mfma(RecLayout L, int T, const double *__restrict__ rec, const double
             // LDLT + explicit inverse exactly (iLQR.cpp:597-604).
             double *wa = sh + LDS_SLOW, *wx = wa + 256, *wt = wx + 256;
             int *tr = (int *)(wt + 16);
-            if (lane == 0) slow_ldlt_inverse(m, sh + LDS_Q, MS, wa, wx, wt, tr);
+            if (lane == 0) slow_ldlt_inverse(L.m, sh + LDS_Q, MS, wa, wx, wt, tr);
             __syncthreads();
 #pragma unroll
             for (int i = 0; i < M; i++) {
@@ -279,7 +305,7 @@ k_backward_mfma(RecLayout L, int T, const double *__restrict__ rec, const double
             if ((i & 3) == 3) { if (q == 3) { if (i / 4 == 0) Kp.x = xi; else if (i / 4 == 1) Kp.y = xi; else if (i / 4 == 2) Kp.z = xi; else Kp.w = xi; } }
         }
         // K (m x n column-major) and k out: lane (c,q) owns rows q, 4+q, ... of column c
-        {
+        if (!(ABL & 4)) {
             double *Kt = Kout + ((size_t)b * T + t) * m * n;
             double *kt = kout + ((size_t)b * T + t) * m;
             const double kv[4] = {Kp.x, Kp.y, Kp.z, Kp.w};
@@ -304,6 +330,7 @@ k_backward_mfma(RecLayout L, int T, const double *__restrict__ rec, const double
         acc = P<NCU>(Quz, Kp, acc);
 
         // ---- V' = (V' + V'')/2 through an LDS transpose   (:610) -----------------------------------
+        if (ABL & 8) { V = acc; continue; }
         sh[LDS_V + (q) * VS + c] = acc.x;
         sh[LDS_V + (4 + q) * VS + c] = acc.y;
         sh[LDS_V + (8 + q) * VS + c] = acc.z;
@@ -315,7 +342,6 @@ k_backward_mfma(RecLayout L, int T, const double *__restrict__ rec, const double
         V.w = 0.5 * (acc.w + sh[LDS_V + c * VS + 12 + q]);
         if (lane_nn) { if (reg_nn == 0) V.x = 0.0; else if (reg_nn == 1) V.y = 0.0; else if (reg_nn == 2) V.z = 0.0; else V.w = 0.0; }
         __syncthreads();
-        cur = nxt;
     }
     // delta_J lives in lane_nn; status is uniform
     if (lane_nn) delta_J[b] = dJ;
