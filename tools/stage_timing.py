@@ -31,23 +31,3 @@ for k, fn in st.items():
 print("bwd after cost:", end=" "); e.cost_derivs(); print(f"{timeit(st['bwd'], 1):8.3f} ms")
 print("bwd after bwd :", end=" "); print(f"{timeit(st['bwd'], 1):8.3f} ms")
 res = e.results(); print("status ok:", int((res['status'] == 0).sum()), "dJ0", res['delta_J'][0])
-import time as _t
-big = torch.empty(1 << 30, dtype=torch.uint8, device="cuda"); big2 = torch.empty_like(big)
-def after(name, pre):
-    pre(); print(f"bwd after {name:12s}: {timeit(st['bwd'], 1):8.3f} ms")
-after("interp", st["interp"]); after("fwd", st["fwd"]); after("fd", st["fd"])
-after("idle 50ms", lambda: (e.sync(), _t.sleep(0.05)))
-after("torch copy", lambda: big2.copy_(big))
-after("bwd", st["bwd"])
-after("2x bwd", lambda: (st["bwd"](), st["bwd"]()))
-print("fwd after cost:", end=" "); e.cost_derivs(); print(f"{timeit(st['fwd'], 1):8.3f} ms")
-print("fwd after fwd :", end=" "); print(f"{timeit(st['fwd'], 1):8.3f} ms")
-recv = torch.as_tensor(e.device_array(0, (B * T * 560,)), device="cuda")
-def copies():
-    for _ in range(12): big2.copy_(big)
-after("12 copies", copies)
-after("rec.sum()", lambda: recv.sum())
-after("rec.mul_(1)", lambda: recv.mul_(1.0))
-kv = torch.as_tensor(e.device_array(1, (B * T * 98,)), device="cuda")
-after("K.zero_()", lambda: kv.zero_())
-after("interp+copies", lambda: (st["interp"](), copies()))

@@ -64,7 +64,9 @@ struct Ctx {
     bool have_kp = false;
 
     // FD job buffers (grow on demand)
-    int njobs = 0, nnom = 0;
+    int njobs = 0, nnom = 0, nslots = 0;   // slot = run of consecutive jobs with one (b, t)
+    int *slot_start = nullptr;             // [nslots+1] (device)
+    size_t slot_cap = 0;
     size_t job_cap = 0, nom_cap = 0;
     int *job_b = nullptr, *job_t = nullptr, *job_col = nullptr, *job_nom = nullptr;
     unsigned char *job_mode = nullptr;

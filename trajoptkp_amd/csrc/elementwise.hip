@@ -14,22 +14,34 @@
 namespace kpilqr {
 
 // ---------------------------------------------------------------------------------------------
-// a2.  One thread per (row, job); jobs vary fastest so that the columns of one key-point land in
-// consecutive addresses of the row-major record.
-__global__ void __launch_bounds__(256)
-k_fd_difference(RecLayout L, int T, int njobs,
+// a2.  Jobs arrive grouped by key-point: a "slot" is a maximal run of consecutive jobs with the same
+// (trajectory, time).  One wavefront per slot: phase 1 streams the slot's x+/x- rows (contiguous in
+// job order) and parks the differenced columns in LDS; phase 2 streams them out in the row-major
+// order of the record's [A|B] block, so both the HBM reads and the HBM writes are coalesced.
+// Columns the slot does not hold are left untouched (ragged key-points).
+#define FD_WAVES 4
+__global__ void __launch_bounds__(64 * FD_WAVES)
+k_fd_difference(RecLayout L, int T, int nslots, const int *__restrict__ slot_start,
                 const int *__restrict__ job_b, const int *__restrict__ job_t,
                 const int *__restrict__ job_col, const unsigned char *__restrict__ job_mode,
                 const int *__restrict__ job_nom,
                 const double *__restrict__ xplus, const double *__restrict__ xminus,
                 const double *__restrict__ xnom, double eps, double *__restrict__ rec)
 {
-    const int n = L.n, m = L.m;
-    const long long total = (long long)njobs * n;
-    for (long long idx = (long long)blockIdx.x * blockDim.x + threadIdx.x; idx < total;
-         idx += (long long)gridDim.x * blockDim.x) {
-        const int job = (int)(idx % njobs);
-        const int row = (int)(idx / njobs);
+    extern __shared__ __attribute__((aligned(16))) double sh[];
+    const int n = L.n, m = L.m, ncol = n + m, ne = n * n + n * m;
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    const int slot = blockIdx.x * FD_WAVES + wave;
+    double *sv = sh + wave * (ncol * n + ncol);          // [col][row] values, then per-column job id + 1
+    int *present = (int *)(sv + ncol * n);
+    const bool live = slot < nslots;
+    int j0 = 0, nj = 0;
+    if (live) { j0 = slot_start[slot]; nj = slot_start[slot + 1] - j0; }
+    for (int cidx = lane; cidx < ncol; cidx += 64) present[cidx] = 0;
+    __syncthreads();
+    for (int w = lane; w < nj * n; w += 64) {
+        const int j = w / n, row = w - j * n;
+        const int job = j0 + j;
         const int mode = job_mode[job];
         const double xp = xplus[(size_t)job * n + row];
         const double xm = xminus[(size_t)job * n + row];
@@ -41,21 +53,30 @@ k_fd_difference(RecLayout L, int T, int njobs,
             v = (mode == 1) ? (xp - x0) / (eps) : (x0 - xm) / (eps);
         }
         const int col = job_col[job];
-        double *R = rec + ((size_t)job_b[job] * T + job_t[job]) * L.stride;
-        if (col < n) R[L.off_A + row * n + col] = v;
-        else         R[L.off_B + row * m + (col - n)] = v;
+        sv[col * n + row] = v;
+        if (row == 0) present[col] = 1;
+    }
+    __syncthreads();
+    if (live) {
+        double *R = rec + ((size_t)job_b[j0] * T + job_t[j0]) * L.stride;
+        for (int e = lane; e < ne; e += 64) {
+            int row, col;
+            if (e < n * n) { row = e / n; col = e - row * n; }
+            else { const int q = e - n * n; row = q / m; col = n + (q - row * m); }
+            if (present[col]) R[e] = sv[col * n + row];
+        }
     }
 }
 
 hipError_t launch_fd_difference(Ctx *c)
 {
-    if (c->njobs == 0) return hipSuccess;
-    const long long total = (long long)c->njobs * c->n;
-    int blocks = (int)((total + 255) / 256);
-    if (blocks > 256 * 32) blocks = 256 * 32;
-    hipLaunchKernelGGL(k_fd_difference, dim3(blocks), dim3(256), 0, c->stream, c->L, c->d.T, c->njobs,
-                       c->job_b, c->job_t, c->job_col, c->job_mode, c->job_nom, c->xplus, c->xminus,
-                       c->xnom, c->eps, c->rec);
+    if (c->njobs == 0 || c->nslots == 0) return hipSuccess;
+    const int ncol = c->n + c->d.m;
+    const size_t lds = sizeof(double) * FD_WAVES * (ncol * c->n + ncol);
+    const int blocks = (c->nslots + FD_WAVES - 1) / FD_WAVES;
+    hipLaunchKernelGGL(k_fd_difference, dim3(blocks), dim3(64 * FD_WAVES), lds, c->stream, c->L, c->d.T, c->nslots,
+                       c->slot_start, c->job_b, c->job_t, c->job_col, c->job_mode, c->job_nom, c->xplus,
+                       c->xminus, c->xnom, c->eps, c->rec);
     return hipGetLastError();
 }
 
@@ -100,39 +121,49 @@ hipError_t launch_build_segmap(Ctx *c)
 }
 
 // ---------------------------------------------------------------------------------------------
-// a4.  Each block owns TT consecutive time-steps of one trajectory; one thread per element of the
-// contiguous [A|B] part of the record.  value = start + (t - s) * ((end - start) / (e - s)) in
-// exactly this order (KeyPointGenerator.cpp:900,934).
-#define INTERP_TT 8
-__global__ void __launch_bounds__(256)
+// a4.  Each block owns INTERP_TT consecutive time-steps of one trajectory, one thread per element of the
+// contiguous [A|B] part of the record; the thread walks the time-steps and keeps the two key-point
+// values of its current interval in registers, so each interval costs two loads however many steps
+// it spans.  value = start + (t - s) * ((end - start) / (e - s)) in exactly this order
+// (KeyPointGenerator.cpp:900,934) -- compiled without FMA contraction.
+#define INTERP_TT 16
+__global__ void __launch_bounds__(320)
 k_interpolate(RecLayout L, int dof, int T, const int2 *__restrict__ segmap, double *__restrict__ rec)
 {
     const int n = L.n, m = L.m;
     const int ne = n * n + n * m;
     const int b = blockIdx.y;
     const int t0 = blockIdx.x * INTERP_TT;
+    const int t1 = min(T, t0 + INTERP_TT);
     double *R = rec + (size_t)b * T * L.stride;
     const int2 *sm = segmap + (size_t)b * dof * T;
-    for (int w = threadIdx.x; w < INTERP_TT * ne; w += blockDim.x) {
-        const int tt = w / ne, e = w - tt * ne;
-        const int t = t0 + tt;
-        if (t >= T) break;
+    for (int e = threadIdx.x; e < ne; e += blockDim.x) {
         int i;
         if (e < n * n) { const int col = e % n; i = col < dof ? col : col - dof; }
         else           { const int col = (e - n * n) % m; i = col; if (i >= dof) continue; }
-        const int2 se = sm[(size_t)i * T + t];
-        if (se.x < 0) continue;
-        const double vs = R[(size_t)se.x * L.stride + e];
-        const double ve = R[(size_t)se.y * L.stride + e];
-        const double add = (ve - vs) / (double)(se.y - se.x);
-        R[(size_t)t * L.stride + e] = vs + ((double)(t - se.x) * add);
+        const int2 *smi = sm + (size_t)i * T;
+        int cs = -2, ce = -2;
+        double vs = 0.0, add = 0.0;
+        for (int t = t0; t < t1; t++) {
+            const int2 se = smi[t];
+            if (se.x < 0) continue;
+            if (se.x != cs || se.y != ce) {
+                cs = se.x; ce = se.y;
+                vs = R[(size_t)cs * L.stride + e];
+                const double ve = R[(size_t)ce * L.stride + e];
+                add = (ve - vs) / (double)(ce - cs);
+            }
+            R[(size_t)t * L.stride + e] = vs + ((double)(t - cs) * add);
+        }
     }
 }
 
 hipError_t launch_interpolate(Ctx *c)
 {
     dim3 grid((c->d.T + INTERP_TT - 1) / INTERP_TT, c->d.batch);
-    hipLaunchKernelGGL(k_interpolate, grid, dim3(256), 0, c->stream, c->L, c->d.dof, c->d.T, c->segmap, c->rec);
+    const int ne = c->n * c->n + c->n * c->d.m;
+    const int threads = ne >= 320 ? 320 : ((ne + 63) / 64) * 64;
+    hipLaunchKernelGGL(k_interpolate, grid, dim3(threads), 0, c->stream, c->L, c->d.dof, c->d.T, c->segmap, c->rec);
     return hipGetLastError();
 }
 
@@ -193,8 +224,90 @@ k_cost_derivs(RecLayout L, int nr, int T,
     }
 }
 
+// Register-blocked form for compile-time (N, M): one thread per output ROW.  Threads 0..N-1 of a
+// time-step own row a of l_xx (N accumulators) plus l_x[a]; threads N..N+M-1 own row a of l_uu plus
+// l_u[a].  Same accumulation order and association as the generic kernel above (bit-identical).
+template <int N, int M>
+__global__ void __launch_bounds__(256)
+k_cost_derivs_rows(RecLayout L, int nr, int T,
+                   const double *__restrict__ r, const double *__restrict__ r_x, const double *__restrict__ r_u,
+                   const double *__restrict__ w_run, const double *__restrict__ w_term, double *__restrict__ rec)
+{
+    extern __shared__ __attribute__((aligned(16))) double sh[];
+    constexpr int ROWS = N + M;
+    constexpr int TT = 256 / ROWS;                 // time-steps per block
+    const int per = nr * (1 + N + M);
+    const int b = blockIdx.y;
+    const int t0 = blockIdx.x * TT;
+    const int nt = min(TT, T - t0);
+    double *sw = sh + TT * per;                    // [2][nr]: running, terminal weights
+    for (int w = threadIdx.x; w < 2 * nr; w += blockDim.x) sw[w] = (w < nr) ? w_run[w] : w_term[w - nr];
+    {   // stage r | r_x | r_u of nt consecutive steps: three contiguous global ranges
+        const size_t bt0 = (size_t)b * (T + 1) + t0;
+        for (int w = threadIdx.x; w < nt * nr; w += blockDim.x) { const int tt = w / nr, e = w - tt * nr; sh[tt * per + e] = r[bt0 * nr + w]; }
+        for (int w = threadIdx.x; w < nt * nr * N; w += blockDim.x) { const int tt = w / (nr * N), e = w - tt * nr * N; sh[tt * per + nr + e] = r_x[bt0 * nr * N + w]; }
+        for (int w = threadIdx.x; w < nt * nr * M; w += blockDim.x) { const int tt = w / (nr * M), e = w - tt * nr * M; sh[tt * per + nr + nr * N + e] = r_u[bt0 * nr * M + w]; }
+    }
+    __syncthreads();
+    const int tt = threadIdx.x / ROWS, j = threadIdx.x - tt * ROWS;
+    if (tt >= nt) return;
+    const int t = t0 + tt;
+    const double *wt = sw + ((t == T - 1) ? nr : 0);          // Optimiser.cpp:208-211
+    const double *sr = sh + tt * per, *srx = sr + nr, *sru = srx + nr * N;
+    double *R = rec + ((size_t)b * T + t) * L.stride;
+    if (j < N) {
+        double acc[N], lx = 0.0;
+#pragma unroll
+        for (int q = 0; q < N; q++) acc[q] = 0.0;
+        for (int i = 0; i < nr; i++) {
+            const double w2 = wt[i] * 2;
+            const double xa = srx[i * N + j];
+            const double va = w2 * xa;
+            lx += (w2 * sr[i]) * xa;
+#pragma unroll
+            for (int q = 0; q < N; q++) acc[q] += va * srx[i * N + q];
+        }
+#pragma unroll
+        for (int q = 0; q < N; q++) R[L.off_lxx + j * N + q] = acc[q];
+        R[L.off_lx + j] = lx;
+    } else {
+        const int a = j - N;
+        double acc[M], lu = 0.0;
+#pragma unroll
+        for (int q = 0; q < M; q++) acc[q] = 0.0;
+        for (int i = 0; i < nr; i++) {
+            const double w2 = wt[i] * 2;
+            const double ua = sru[i * M + a];
+            const double va = w2 * ua;
+            lu += (w2 * sr[i]) * ua;
+#pragma unroll
+            for (int q = 0; q < M; q++) acc[q] += va * sru[i * M + q];
+        }
+#pragma unroll
+        for (int q = 0; q < M; q++) R[L.off_luu + a * M + q] = acc[q];
+        R[L.off_lu + a] = lu;
+    }
+}
+
+template <int N, int M>
+static hipError_t launch_cost_rows(Ctx *c)
+{
+    constexpr int TT = 256 / (N + M);
+    dim3 grid((c->d.T + TT - 1) / TT, c->d.batch);
+    const size_t lds = sizeof(double) * (TT * c->d.nr * (1 + N + M) + 2 * c->d.nr);
+    hipLaunchKernelGGL((k_cost_derivs_rows<N, M>), grid, dim3(256), lds, c->stream, c->L, c->d.nr, c->d.T, c->r,
+                       c->r_x, c->r_u, c->w_run, c->w_term, c->rec);
+    return hipGetLastError();
+}
+
 hipError_t launch_cost_derivs(Ctx *c)
 {
+    const size_t lds_rows = sizeof(double) * ((256 / (c->n + c->d.m)) * c->d.nr * (1 + c->n + c->d.m) + 2 * c->d.nr);
+    if (lds_rows <= 64 * 1024) {
+        if (c->n == 14 && c->d.m == 7) return launch_cost_rows<14, 7>(c);
+        if (c->n == 4 && c->d.m == 1) return launch_cost_rows<4, 1>(c);
+        if (c->n == 20 && c->d.m == 7) return launch_cost_rows<20, 7>(c);
+    }
     dim3 grid((c->d.T + COST_TT - 1) / COST_TT, c->d.batch);
     const size_t lds = sizeof(double) * COST_TT * c->d.nr * (1 + c->n + c->d.m);
     hipLaunchKernelGGL(k_cost_derivs, grid, dim3(256), lds, c->stream, c->L, c->d.nr, c->d.T, c->r, c->r_x,

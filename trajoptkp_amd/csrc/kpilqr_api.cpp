@@ -5,6 +5,7 @@
 #include <cstdlib>
 #include <cstring>
 #include <new>
+#include <vector>
 
 #include "common.h"
 
@@ -101,11 +102,11 @@ int kpilqr_create(const kpilqr_dims *dims, void *stream, kpilqr_ctx **out)
         return set_err(nullptr, KPILQR_ERR_ALLOC, msg);
     }
     // records start zeroed so that padding / never-written columns are defined
-    hipMemsetAsync(c->rec, 0, B * T * c->L.stride * sizeof(double), c->stream);
-    hipMemsetAsync(c->K, 0, B * T * n * m * sizeof(double), c->stream);
-    hipMemsetAsync(c->k, 0, B * T * m * sizeof(double), c->stream);
-    hipMemsetAsync(c->r_u, 0, B * (T + 1) * nr * m * sizeof(double), c->stream);
-    hipMemsetAsync(c->status, 0, B * sizeof(int), c->stream);
+    (void)hipMemsetAsync(c->rec, 0, B * T * c->L.stride * sizeof(double), c->stream);
+    (void)hipMemsetAsync(c->K, 0, B * T * n * m * sizeof(double), c->stream);
+    (void)hipMemsetAsync(c->k, 0, B * T * m * sizeof(double), c->stream);
+    (void)hipMemsetAsync(c->r_u, 0, B * (T + 1) * nr * m * sizeof(double), c->stream);
+    (void)hipMemsetAsync(c->status, 0, B * sizeof(int), c->stream);
 
     const bool generic = (dims->flags & KPILQR_FLAG_GENERIC_KERNELS) != 0;
     c->bwd_variant = (!generic && backward_mfma_supported(c->n, dims->m)) ? "mfma_f64_t1" : "generic_lds";
@@ -121,13 +122,13 @@ int kpilqr_create(const kpilqr_dims *dims, void *stream, kpilqr_ctx **out)
 void kpilqr_destroy(kpilqr_ctx *c)
 {
     if (!c) return;
-    hipStreamSynchronize(c->stream);
+    (void)hipStreamSynchronize(c->stream);
     void *ptrs[] = {c->rec, c->K, c->k, c->r, c->r_x, c->r_u, c->w_run, c->w_term, c->u_nom, c->ctrl_lim,
                     c->lambda, c->alphas, c->cost_pred, c->delta_J, c->traj_cost, c->status, c->segmap,
                     c->kp_offsets, c->kp_times, c->job_b, c->job_t, c->job_col, c->job_nom, c->job_mode,
-                    c->xplus, c->xminus, c->xnom, c->stage};
-    for (void *p : ptrs) if (p) hipFree(p);
-    if (c->own_stream) hipStreamDestroy(c->stream);
+                    c->xplus, c->xminus, c->xnom, c->stage, c->slot_start};
+    for (void *p : ptrs) if (p) (void)hipFree(p);
+    if (c->own_stream) (void)hipStreamDestroy(c->stream);
     delete c;
 }
 
@@ -243,6 +244,23 @@ int kpilqr_upload_fd(kpilqr_ctx *c, int njobs, const int *job_b, const int *job_
         if ((rc = regrow(c, &c->xnom, cap * n))) return rc;
         c->nom_cap = cap;
     }
+    // slot table: maximal runs of consecutive jobs with the same (trajectory, time)
+    std::vector<int> slots;
+    slots.reserve((size_t)njobs / 8 + 2);
+    for (int j = 0; j < njobs; j++)
+        if (j == 0 || job_b[j] != job_b[j - 1] || job_t[j] != job_t[j - 1]) slots.push_back(j);
+    const int nslots = (int)slots.size();
+    slots.push_back(njobs);
+    if ((size_t)nslots + 1 > c->slot_cap) {
+        KP_HIP(c, hipStreamSynchronize(c->stream));
+        const size_t cap = (size_t)nslots + (size_t)nslots / 8 + 64;
+        int rc = regrow(c, &c->slot_start, cap + 1);
+        if (rc) return rc;
+        c->slot_cap = cap + 1;
+    }
+    KP_HIP(c, hipMemcpyAsync(c->slot_start, slots.data(), ((size_t)nslots + 1) * sizeof(int), hipMemcpyHostToDevice, c->stream));
+    KP_HIP(c, hipStreamSynchronize(c->stream));      // `slots` is a local, pageable vector
+    c->nslots = nslots;
     const size_t J = njobs;
     if (njobs) {
         KP_HIP(c, hipMemcpyAsync(c->job_b, job_b, J * sizeof(int), hipMemcpyHostToDevice, c->stream));

@@ -68,6 +68,31 @@ __device__ __forceinline__ double fast_rcp(double x)
     return r;
 }
 
+// Pull one whole step record into this XCD's L2 a few steps before its tile loads are issued: one
+// LDS-DMA dword per 64-byte sector (the data lands in a scratch LDS row nobody reads).  It costs no
+// VGPR, and it takes the page-table walk and the HBM fetch of that record off the critical path --
+// with records freshly written by the elementwise stages the translations are cold and a walk per
+// step was worth ~3 ms per launch (B=1024, T=3000).
+typedef __attribute__((address_space(3))) void lds_void_t;
+typedef __attribute__((address_space(1))) const void glb_void_t;
+// Issued through inline asm on purpose: hipcc treats a builtin LDS-DMA as a pending LDS write and
+// drains vmcnt(0) before the step's next LDS access, which would expose the latency of the tile loads
+// just issued.  The scratch row is never read, so no wait is needed; loads hidden from the compiler
+// only make its counted vmcnt waits more conservative (the counter is in order).
+__device__ __forceinline__ void glds_dword(const void *gaddr, unsigned lds_byte_addr)
+{
+    asm volatile("s_mov_b32 m0, %1\n\ts_nop 0\n\tglobal_load_lds_dword %0, off" ::"v"(gaddr), "s"(lds_byte_addr));
+}
+__device__ __forceinline__ void l2_prefetch_record(const double *R, int rec_bytes, int lane, double *lds_scratch)
+{
+    const unsigned lds_addr = (unsigned)(size_t)(lds_void_t *)lds_scratch;
+    const int o0 = lane * 64;
+    const int o1 = (64 + lane) * 64;
+    glds_dword((const char *)R + (o0 < rec_bytes ? o0 : rec_bytes - 8), lds_addr);
+    if (o1 < rec_bytes) glds_dword((const char *)R + o1, lds_addr);
+}
+#define PF_DIST 3
+
 struct TileOffs { int fz[4], fu[4], lzz[4], luz[4], luu[4]; };
 
 struct StepTiles { d4 Fz, Fu, Lzz, Luz, Luu; };
@@ -151,7 +176,8 @@ __device__ static __attribute__((noinline)) void slow_ldlt_inverse(int m, const 
 #define LDS_Z (LDS_Q + 16 * MS)
 #define LDS_V (LDS_Z + 16 * MZ)
 #define LDS_SLOW (LDS_V + 16 * VS)
-#define LDS_TOTAL (LDS_SLOW + 2 * 256 + 16 + 16)
+#define LDS_PF (LDS_SLOW + 2 * 256 + 16 + 16)
+#define LDS_TOTAL (LDS_PF + 32)
 
 // ABL: ablation switches for tools/ablate_backward.cpp only (0 in the product): 1 = always load the
 // same record (no HBM streaming), 2 = skip the LDL' solve, 4 = skip the K/k stores, 8 = skip the
@@ -183,6 +209,13 @@ k_backward_mfma(RecLayout L, int T, const double *__restrict__ rec, const double
         o.luu[r] = (row < m && c < m) ? 8 * (L.off_luu + row * m + c) : OOB;
     }
     const int rec_bytes = L.rec * 8;
+    int oKst[4], okst[4];      // byte offsets of this lane's K / k elements, OOB where it owns none
+#pragma unroll
+    for (int r = 0; r < 4; r++) {
+        const int row = 4 * r + q;
+        oKst[r] = (row < m && c < n) ? 8 * (row + c * m) : OOB;
+        okst[r] = (row < m && c == n) ? 8 * row : OOB;
+    }
     // where element (n,n) of a tile lives
     const bool lane_nn = (c == n) && (q == (n & 3));
     const int reg_nn = n >> 2;
@@ -191,6 +224,9 @@ k_backward_mfma(RecLayout L, int T, const double *__restrict__ rec, const double
     StepTiles cur, nxt;
     load_step<NCU>(R0 + (size_t)(T - 1) * L.stride, rec_bytes, o, nxt);
     d4 V = nxt.Lzz;                         // V_x = l_x[T-1]; V_xx = l_xx[T-1]   (iLQR.cpp:537-539)
+
+    for (int d = 1; d <= PF_DIST; d++)
+        if (T - 1 - d >= 0) l2_prefetch_record(R0 + (size_t)(T - 1 - d) * L.stride, rec_bytes, lane, sh + LDS_PF);
 
     int pd_counter = 0;
     double dJ = 0.0;
@@ -202,6 +238,8 @@ k_backward_mfma(RecLayout L, int T, const double *__restrict__ rec, const double
         cur = nxt;
         cur.Fz.x += one[0]; cur.Fz.y += one[1]; cur.Fz.z += one[2]; cur.Fz.w += one[3];
         if (t > 0) load_step<NCU>(R0 + (size_t)((ABL & 1) ? T - 1 : t - 1) * L.stride, rec_bytes, o, nxt);
+        if (!(ABL & 1) && t - 1 - PF_DIST >= 0)
+            l2_prefetch_record(R0 + (size_t)(t - 1 - PF_DIST) * L.stride, rec_bytes, lane, sh + LDS_PF);
         __builtin_amdgcn_sched_barrier(0);     // keep the prefetch AHEAD of this step's compute
         pd_counter++;
         const bool check_pd = pd_counter >= pd_stride;
@@ -209,13 +247,11 @@ k_backward_mfma(RecLayout L, int T, const double *__restrict__ rec, const double
         // ---- Tu = V' Fu ; Quu = l_uu + Fu' Tu --------------------------------------- :577
         d4 Tu = P<NCZ>(V, cur.Fu, zero);
         d4 Quu = P<NCZ>(cur.Fu, Tu, cur.Luu);
-        // Quu + lambda I -> LDS image (row-major, stride MS)
-        if (c < m) {
-            { const int row = q;      if (row < m) sh[LDS_Q + row * MS + c] = Quu.x + (row == c ? lam : 0.0); }
-            if (NCU > 1) { const int row = 4 + q;  if (row < m) sh[LDS_Q + row * MS + c] = Quu.y + (row == c ? lam : 0.0); }
-            if (NCU > 2) { const int row = 8 + q;  if (row < m) sh[LDS_Q + row * MS + c] = Quu.z + (row == c ? lam : 0.0); }
-            if (NCU > 3) { const int row = 12 + q; if (row < m) sh[LDS_Q + row * MS + c] = Quu.w + (row == c ? lam : 0.0); }
-        }
+        // Quu + lambda I -> LDS image (row-major, stride MS); every lane stores (columns >= m hold zeros)
+        sh[LDS_Q + q * MS + c] = Quu.x + (q == c ? lam : 0.0);
+        if (NCU > 1) sh[LDS_Q + (4 + q) * MS + c] = Quu.y + (4 + q == c ? lam : 0.0);
+        if (NCU > 2) sh[LDS_Q + (8 + q) * MS + c] = Quu.z + (8 + q == c ? lam : 0.0);
+        if (NCU > 3) sh[LDS_Q + (12 + q) * MS + c] = Quu.w + (12 + q == c ? lam : 0.0);
         // ---- independent of the factorisation: Tz, Quz, Qzz --------------------------- :570-579
         d4 Tz = P<NCZ>(V, cur.Fz, zero);
         d4 Quz = P<NCZ>(cur.Fu, Tz, cur.Luz);
@@ -304,18 +340,17 @@ k_backward_mfma(RecLayout L, int T, const double *__restrict__ rec, const double
             if ((i & 3) == 2) { if (q == 2) { if (i / 4 == 0) Kp.x = xi; else if (i / 4 == 1) Kp.y = xi; else if (i / 4 == 2) Kp.z = xi; else Kp.w = xi; } }
             if ((i & 3) == 3) { if (q == 3) { if (i / 4 == 0) Kp.x = xi; else if (i / 4 == 1) Kp.y = xi; else if (i / 4 == 2) Kp.z = xi; else Kp.w = xi; } }
         }
-        // K (m x n column-major) and k out: lane (c,q) owns rows q, 4+q, ... of column c
+        // K (m x n column-major) and k out: lane (c,q) owns rows q, 4+q, ... of column c.  Bounds-checked
+        // buffer stores (out-of-range lanes are dropped by the hardware): straight-line code, so the
+        // compiler can keep COUNTED vmcnt waits for the prefetched tiles behind these stores.
         if (!(ABL & 4)) {
-            double *Kt = Kout + ((size_t)b * T + t) * m * n;
-            double *kt = kout + ((size_t)b * T + t) * m;
+            __amdgpu_buffer_rsrc_t rK = __builtin_amdgcn_make_buffer_rsrc((void *)(Kout + ((size_t)b * T + t) * m * n), 0, m * n * 8, 0x00020000);
+            __amdgpu_buffer_rsrc_t rk = __builtin_amdgcn_make_buffer_rsrc((void *)(kout + ((size_t)b * T + t) * m), 0, m * 8, 0x00020000);
             const double kv[4] = {Kp.x, Kp.y, Kp.z, Kp.w};
 #pragma unroll
             for (int r = 0; r < NCU; r++) {
-                const int row = 4 * r + q;
-                if (row < m) {
-                    if (c < n) Kt[row + c * m] = kv[r];
-                    else if (c == n) kt[row] = kv[r];
-                }
+                __builtin_amdgcn_raw_buffer_store_b64(__builtin_bit_cast(u32x2, kv[r]), rK, oKst[r], 0, 0);
+                __builtin_amdgcn_raw_buffer_store_b64(__builtin_bit_cast(u32x2, kv[r]), rk, okst[r], 0, 0);
             }
         }
 
