@@ -127,33 +127,61 @@ hipError_t launch_build_segmap(Ctx *c)
 // it spans.  value = start + (t - s) * ((end - start) / (e - s)) in exactly this order
 // (KeyPointGenerator.cpp:900,934) -- compiled without FMA contraction.
 #define INTERP_TT 16
-__global__ void __launch_bounds__(320)
+__global__ void __launch_bounds__(256)
 k_interpolate(RecLayout L, int dof, int T, const int2 *__restrict__ segmap, double *__restrict__ rec)
 {
+    extern __shared__ __attribute__((aligned(16))) int2 ssm[];      // [dof][INTERP_TT]
     const int n = L.n, m = L.m;
-    const int ne = n * n + n * m;
+    const int ne = n * n + n * m;               // even: n = 2*dof
     const int b = blockIdx.y;
     const int t0 = blockIdx.x * INTERP_TT;
-    const int t1 = min(T, t0 + INTERP_TT);
+    const int nt = min(INTERP_TT, T - t0);
     double *R = rec + (size_t)b * T * L.stride;
     const int2 *sm = segmap + (size_t)b * dof * T;
-    for (int e = threadIdx.x; e < ne; e += blockDim.x) {
-        int i;
-        if (e < n * n) { const int col = e % n; i = col < dof ? col : col - dof; }
-        else           { const int col = (e - n * n) % m; i = col; if (i >= dof) continue; }
-        const int2 *smi = sm + (size_t)i * T;
-        int cs = -2, ce = -2;
-        double vs = 0.0, add = 0.0;
-        for (int t = t0; t < t1; t++) {
-            const int2 se = smi[t];
-            if (se.x < 0) continue;
-            if (se.x != cs || se.y != ce) {
-                cs = se.x; ce = se.y;
-                vs = R[(size_t)cs * L.stride + e];
-                const double ve = R[(size_t)ce * L.stride + e];
-                add = (ve - vs) / (double)(ce - cs);
+    for (int w = threadIdx.x; w < dof * INTERP_TT; w += blockDim.x) {
+        const int i = w / INTERP_TT, tt = w - i * INTERP_TT;
+        ssm[w] = (tt < nt) ? sm[(size_t)i * T + t0 + tt] : make_int2(-1, -1);
+    }
+    __syncthreads();
+    // each thread owns two consecutive elements (16-byte stores); they belong to different DoFs
+    for (int e = 2 * threadIdx.x; e < ne; e += 2 * blockDim.x) {
+        int i0, i1;
+        {
+            const int ea = e, eb = e + 1;
+            if (ea < n * n) { const int col = ea % n; i0 = col < dof ? col : col - dof; }
+            else            { const int col = (ea - n * n) % m; i0 = col < dof ? col : -1; }
+            if (eb < n * n) { const int col = eb % n; i1 = col < dof ? col : col - dof; }
+            else            { const int col = (eb - n * n) % m; i1 = col < dof ? col : -1; }
+        }
+        int cs0 = -2, ce0 = -2, cs1 = -2, ce1 = -2;
+        double vs0 = 0.0, add0 = 0.0, vs1 = 0.0, add1 = 0.0;
+        for (int tt = 0; tt < nt; tt++) {
+            const int t = t0 + tt;
+            const int2 s0 = i0 >= 0 ? ssm[i0 * INTERP_TT + tt] : make_int2(-1, -1);
+            const int2 s1 = i1 >= 0 ? ssm[i1 * INTERP_TT + tt] : make_int2(-1, -1);
+            if (s0.x >= 0 && (s0.x != cs0 || s0.y != ce0)) {
+                cs0 = s0.x; ce0 = s0.y;
+                vs0 = R[(size_t)cs0 * L.stride + e];
+                const double ve = R[(size_t)ce0 * L.stride + e];
+                add0 = (ve - vs0) / (double)(ce0 - cs0);
             }
-            R[(size_t)t * L.stride + e] = vs + ((double)(t - cs) * add);
+            if (s1.x >= 0 && (s1.x != cs1 || s1.y != ce1)) {
+                cs1 = s1.x; ce1 = s1.y;
+                vs1 = R[(size_t)cs1 * L.stride + e + 1];
+                const double ve = R[(size_t)ce1 * L.stride + e + 1];
+                add1 = (ve - vs1) / (double)(ce1 - cs1);
+            }
+            double *dst = R + (size_t)t * L.stride + e;
+            if (s0.x >= 0 && s1.x >= 0) {
+                double2 v;
+                v.x = vs0 + ((double)(t - cs0) * add0);
+                v.y = vs1 + ((double)(t - cs1) * add1);
+                *reinterpret_cast<double2 *>(dst) = v;          // record stride and e are even: 16-B aligned
+            } else if (s0.x >= 0) {
+                dst[0] = vs0 + ((double)(t - cs0) * add0);
+            } else if (s1.x >= 0) {
+                dst[1] = vs1 + ((double)(t - cs1) * add1);
+            }
         }
     }
 }
@@ -162,8 +190,10 @@ hipError_t launch_interpolate(Ctx *c)
 {
     dim3 grid((c->d.T + INTERP_TT - 1) / INTERP_TT, c->d.batch);
     const int ne = c->n * c->n + c->n * c->d.m;
-    const int threads = ne >= 320 ? 320 : ((ne + 63) / 64) * 64;
-    hipLaunchKernelGGL(k_interpolate, grid, dim3(threads), 0, c->stream, c->L, c->d.dof, c->d.T, c->segmap, c->rec);
+    int threads = ((ne / 2 + 63) / 64) * 64;
+    if (threads > 256) threads = 256;
+    const size_t lds = sizeof(int2) * c->d.dof * INTERP_TT;
+    hipLaunchKernelGGL(k_interpolate, grid, dim3(threads), lds, c->stream, c->L, c->d.dof, c->d.T, c->segmap, c->rec);
     return hipGetLastError();
 }
 
@@ -240,7 +270,9 @@ k_cost_derivs_rows(RecLayout L, int nr, int T,
     const int b = blockIdx.y;
     const int t0 = blockIdx.x * TT;
     const int nt = min(TT, T - t0);
-    double *sw = sh + TT * per;                    // [2][nr]: running, terminal weights
+    constexpr int NOUT_ = N * N + N + M * M + M;
+    const int area = TT * (per > NOUT_ ? per : NOUT_);   // inputs first, outputs later, in the same LDS area
+    double *sw = sh + area;                        // [2][nr]: running, terminal weights
     for (int w = threadIdx.x; w < 2 * nr; w += blockDim.x) sw[w] = (w < nr) ? w_run[w] : w_term[w - nr];
     {   // stage r | r_x | r_u of nt consecutive steps: three contiguous global ranges
         const size_t bt0 = (size_t)b * (T + 1) + t0;
@@ -249,43 +281,68 @@ k_cost_derivs_rows(RecLayout L, int nr, int T,
         for (int w = threadIdx.x; w < nt * nr * M; w += blockDim.x) { const int tt = w / (nr * M), e = w - tt * nr * M; sh[tt * per + nr + nr * N + e] = r_u[bt0 * nr * M + w]; }
     }
     __syncthreads();
-    const int tt = threadIdx.x / ROWS, j = threadIdx.x - tt * ROWS;
-    if (tt >= nt) return;
+    const int ttr = threadIdx.x / ROWS;                        // threads beyond TT*ROWS idle in the compute phase
+    const int tt = min(ttr, TT - 1), j = threadIdx.x - ttr * ROWS;
     const int t = t0 + tt;
     const double *wt = sw + ((t == T - 1) ? nr : 0);          // Optimiser.cpp:208-211
     const double *sr = sh + tt * per, *srx = sr + nr, *sru = srx + nr * N;
-    double *R = rec + ((size_t)b * T + t) * L.stride;
-    if (j < N) {
-        double acc[N], lx = 0.0;
+    constexpr int NOUT = N * N + N + M * M + M;        // l_xx | l_x | l_uu | l_u, contiguous in the record
+    double acc[N > M ? N : M], lv = 0.0;
+    const bool active = ttr < nt;
+    if (active) {
+        if (j < N) {
 #pragma unroll
-        for (int q = 0; q < N; q++) acc[q] = 0.0;
-        for (int i = 0; i < nr; i++) {
-            const double w2 = wt[i] * 2;
-            const double xa = srx[i * N + j];
-            const double va = w2 * xa;
-            lx += (w2 * sr[i]) * xa;
+            for (int q = 0; q < N; q++) acc[q] = 0.0;
+            for (int i = 0; i < nr; i++) {
+                const double w2 = wt[i] * 2;
+                const double xa = srx[i * N + j];
+                const double va = w2 * xa;
+                lv += (w2 * sr[i]) * xa;
 #pragma unroll
-            for (int q = 0; q < N; q++) acc[q] += va * srx[i * N + q];
+                for (int q = 0; q < N; q++) acc[q] += va * srx[i * N + q];
+            }
+        } else {
+            const int a = j - N;
+#pragma unroll
+            for (int q = 0; q < M; q++) acc[q] = 0.0;
+            for (int i = 0; i < nr; i++) {
+                const double w2 = wt[i] * 2;
+                const double ua = sru[i * M + a];
+                const double va = w2 * ua;
+                lv += (w2 * sr[i]) * ua;
+#pragma unroll
+                for (int q = 0; q < M; q++) acc[q] += va * sru[i * M + q];
+            }
         }
+    }
+    __syncthreads();                 // everyone is done reading the staged inputs: reuse the LDS for outputs
+    double *so = sh + tt * NOUT;
+    if (active) {
+        if (j < N) {
 #pragma unroll
-        for (int q = 0; q < N; q++) R[L.off_lxx + j * N + q] = acc[q];
-        R[L.off_lx + j] = lx;
+            for (int q = 0; q < N; q++) so[j * N + q] = acc[q];
+            so[N * N + j] = lv;
+        } else {
+            const int a = j - N;
+#pragma unroll
+            for (int q = 0; q < M; q++) so[N * N + N + a * M + q] = acc[q];
+            so[N * N + N + M * M + a] = lv;
+        }
+    }
+    __syncthreads();
+    // coalesced write-out: NOUT contiguous doubles per step, starting at off_lxx of each record
+    double *Rb = rec + ((size_t)b * T + t0) * L.stride + L.off_lxx;
+    if ((NOUT & 1) == 0 && (L.off_lxx & 1) == 0 && (L.stride & 1) == 0) {
+        for (int w = threadIdx.x; w < nt * (NOUT / 2); w += blockDim.x) {
+            const int t2 = w / (NOUT / 2), e2 = w - t2 * (NOUT / 2);
+            *reinterpret_cast<double2 *>(Rb + (size_t)t2 * L.stride + 2 * e2) =
+                *reinterpret_cast<const double2 *>(sh + t2 * NOUT + 2 * e2);
+        }
     } else {
-        const int a = j - N;
-        double acc[M], lu = 0.0;
-#pragma unroll
-        for (int q = 0; q < M; q++) acc[q] = 0.0;
-        for (int i = 0; i < nr; i++) {
-            const double w2 = wt[i] * 2;
-            const double ua = sru[i * M + a];
-            const double va = w2 * ua;
-            lu += (w2 * sr[i]) * ua;
-#pragma unroll
-            for (int q = 0; q < M; q++) acc[q] += va * sru[i * M + q];
+        for (int w = threadIdx.x; w < nt * NOUT; w += blockDim.x) {
+            const int t2 = w / NOUT, e2 = w - t2 * NOUT;
+            Rb[(size_t)t2 * L.stride + e2] = sh[t2 * NOUT + e2];
         }
-#pragma unroll
-        for (int q = 0; q < M; q++) R[L.off_luu + a * M + q] = acc[q];
-        R[L.off_lu + a] = lu;
     }
 }
 
@@ -294,7 +351,8 @@ static hipError_t launch_cost_rows(Ctx *c)
 {
     constexpr int TT = 256 / (N + M);
     dim3 grid((c->d.T + TT - 1) / TT, c->d.batch);
-    const size_t lds = sizeof(double) * (TT * c->d.nr * (1 + N + M) + 2 * c->d.nr);
+    const int per = c->d.nr * (1 + N + M), nout = N * N + N + M * M + M;
+    const size_t lds = sizeof(double) * (TT * (per > nout ? per : nout) + 2 * c->d.nr);
     hipLaunchKernelGGL((k_cost_derivs_rows<N, M>), grid, dim3(256), lds, c->stream, c->L, c->d.nr, c->d.T, c->r,
                        c->r_x, c->r_u, c->w_run, c->w_term, c->rec);
     return hipGetLastError();
@@ -302,7 +360,8 @@ static hipError_t launch_cost_rows(Ctx *c)
 
 hipError_t launch_cost_derivs(Ctx *c)
 {
-    const size_t lds_rows = sizeof(double) * ((256 / (c->n + c->d.m)) * c->d.nr * (1 + c->n + c->d.m) + 2 * c->d.nr);
+    const int per_ = c->d.nr * (1 + c->n + c->d.m), nout_ = c->n * c->n + c->n + c->d.m * c->d.m + c->d.m;
+    const size_t lds_rows = sizeof(double) * ((256 / (c->n + c->d.m)) * (per_ > nout_ ? per_ : nout_) + 2 * c->d.nr);
     if (lds_rows <= 64 * 1024) {
         if (c->n == 14 && c->d.m == 7) return launch_cost_rows<14, 7>(c);
         if (c->n == 4 && c->d.m == 1) return launch_cost_rows<4, 1>(c);
