@@ -182,14 +182,18 @@ __device__ static __attribute__((noinline)) void slow_ldlt_inverse(int m, const 
 // ABL: ablation switches for tools/ablate_backward.cpp only (0 in the product): 1 = always load the
 // same record (no HBM streaming), 2 = skip the LDL' solve, 4 = skip the K/k stores, 8 = skip the
 // symmetrisation transpose.
-template <int M, int NCZ, int NCU, int ABL = 0>
+template <int R> __device__ __forceinline__ void set_reg(d4 &v, double x) { if (R == 0) v.x = x; else if (R == 1) v.y = x; else if (R == 2) v.z = x; else v.w = x; }
+
+template <int N, int M, int ABL = 0>
 __global__ void __launch_bounds__(64)
 k_backward_mfma(RecLayout L, int T, const double *__restrict__ rec, const double *__restrict__ lambda,
                 int pd_stride, double *__restrict__ Kout, double *__restrict__ kout,
                 double *__restrict__ delta_J, int *__restrict__ status)
 {
+    constexpr int NCZ = (N + 1 + 3) / 4;      // row chunks covering z = [dx; 1]
+    constexpr int NCU = (M + 3) / 4;          // row chunks covering u
+    constexpr int n = N, m = M;
     __shared__ __attribute__((aligned(16))) double sh[LDS_TOTAL];
-    const int n = L.n, m = M;
     const int lane = threadIdx.x, c = lane & 15, q = lane >> 4;
     const int b = blockIdx.x;
     const double lam = lambda[b];
@@ -210,21 +214,22 @@ k_backward_mfma(RecLayout L, int T, const double *__restrict__ rec, const double
     }
     const int rec_bytes = L.rec * 8;
     int oKst[4], okst[4];      // byte offsets of this lane's K / k elements, OOB where it owns none
+    double lam2d[4];           // 2*lambda on the diagonal of the u-block
 #pragma unroll
     for (int r = 0; r < 4; r++) {
         const int row = 4 * r + q;
         oKst[r] = (row < m && c < n) ? 8 * (row + c * m) : OOB;
         okst[r] = (row < m && c == n) ? 8 * row : OOB;
+        lam2d[r] = (row == c && row < m) ? 2.0 * lam : 0.0;
     }
-    // where element (n,n) of a tile lives
+    // element (n,n) of a tile lives in lane (c = n, q = n & 3), register n >> 2
     const bool lane_nn = (c == n) && (q == (n & 3));
-    const int reg_nn = n >> 2;
+    constexpr int REG_NN = n >> 2;
 
     const double *R0 = rec + (size_t)b * T * L.stride;
     StepTiles cur, nxt;
     load_step<NCU>(R0 + (size_t)(T - 1) * L.stride, rec_bytes, o, nxt);
     d4 V = nxt.Lzz;                         // V_x = l_x[T-1]; V_xx = l_xx[T-1]   (iLQR.cpp:537-539)
-
     for (int d = 1; d <= PF_DIST; d++)
         if (T - 1 - d >= 0) l2_prefetch_record(R0 + (size_t)(T - 1 - d) * L.stride, rec_bytes, lane, sh + LDS_PF);
 
@@ -248,14 +253,18 @@ k_backward_mfma(RecLayout L, int T, const double *__restrict__ rec, const double
         d4 Tu = P<NCZ>(V, cur.Fu, zero);
         d4 Quu = P<NCZ>(cur.Fu, Tu, cur.Luu);
         // Quu + lambda I -> LDS image (row-major, stride MS); every lane stores (columns >= m hold zeros)
-        sh[LDS_Q + q * MS + c] = Quu.x + (q == c ? lam : 0.0);
-        if (NCU > 1) sh[LDS_Q + (4 + q) * MS + c] = Quu.y + (4 + q == c ? lam : 0.0);
-        if (NCU > 2) sh[LDS_Q + (8 + q) * MS + c] = Quu.z + (8 + q == c ? lam : 0.0);
-        if (NCU > 3) sh[LDS_Q + (12 + q) * MS + c] = Quu.w + (12 + q == c ? lam : 0.0);
-        // ---- independent of the factorisation: Tz, Quz, Qzz --------------------------- :570-579
+        sh[LDS_Q + q * MS + c] = Quu.x + 0.5 * lam2d[0];
+        if (NCU > 1) sh[LDS_Q + (4 + q) * MS + c] = Quu.y + 0.5 * lam2d[1];
+        if (NCU > 2) sh[LDS_Q + (8 + q) * MS + c] = Quu.z + 0.5 * lam2d[2];
+        if (NCU > 3) sh[LDS_Q + (12 + q) * MS + c] = Quu.w + 0.5 * lam2d[3];
+        // ---- Tz, Quz, Qzz --------------------------------------------------------------- :570-579
         d4 Tz = P<NCZ>(V, cur.Fz, zero);
         d4 Quz = P<NCZ>(cur.Fu, Tz, cur.Luz);
         d4 Qzz = P<NCZ>(cur.Fz, Tz, cur.Lzz);
+        sh[LDS_Z + c * MZ + q] = Quz.x;
+        if (NCU > 1) sh[LDS_Z + c * MZ + 4 + q] = Quz.y;
+        if (NCU > 2) sh[LDS_Z + c * MZ + 8 + q] = Quz.z;
+        if (NCU > 3) sh[LDS_Z + c * MZ + 12 + q] = Quz.w;
         __syncthreads();
 
         // ---- unpivoted LDL' of Quu + lambda I, redundantly in every lane (lower triangle) ----
@@ -284,18 +293,11 @@ k_backward_mfma(RecLayout L, int T, const double *__restrict__ rec, const double
             pd_counter = 0;
         }
 
-        // ---- Quz -> LDS (column image), then every lane solves its own column ------------------
-        {
-            { const int row = q;      sh[LDS_Z + c * MZ + row] = Quz.x; }
-            if (NCU > 1) { const int row = 4 + q;  sh[LDS_Z + c * MZ + row] = Quz.y; }
-            if (NCU > 2) { const int row = 8 + q;  sh[LDS_Z + c * MZ + row] = Quz.z; }
-            if (NCU > 3) { const int row = 12 + q; sh[LDS_Z + c * MZ + row] = Quz.w; }
-        }
-        __syncthreads();
+        // ---- every lane solves (Quu + lambda I) x = Quz[:, c] for its own column c --------------
         double x[M];
         if (ABL & 2) {
 #pragma unroll
-            for (int i = 0; i < M; i++) x[i] = -1e-3 * sh[LDS_Z + c * MZ + i];
+            for (int i = 0; i < M; i++) x[i] = 1e-3 * sh[LDS_Z + c * MZ + i];
         } else if (pos) {
 #pragma unroll
             for (int i = 0; i < M; i++) x[i] = sh[LDS_Z + c * MZ + i];
@@ -311,8 +313,6 @@ k_backward_mfma(RecLayout L, int T, const double *__restrict__ rec, const double
 #pragma unroll
                 for (int i = 0; i < j; i++) x[i] -= Lm[j][i] * x[j];
             }
-#pragma unroll
-            for (int i = 0; i < M; i++) x[i] = -x[i];
         } else {
             // Q_uu + lambda I is not PD and this is not a checked step: follow Eigen's pivoted
             // LDLT + explicit inverse exactly (iLQR.cpp:597-604).
@@ -322,28 +322,26 @@ k_backward_mfma(RecLayout L, int T, const double *__restrict__ rec, const double
             __syncthreads();
 #pragma unroll
             for (int i = 0; i < M; i++) {
-                double s = 0.0;
+                double sacc = 0.0;
 #pragma unroll
-                for (int p = 0; p < M; p++) s += (-wx[i + p * m]) * sh[LDS_Z + c * MZ + p];
-                x[i] = s;
+                for (int p = 0; p < M; p++) sacc += (-wx[i + p * m]) * sh[LDS_Z + c * MZ + p];
+                x[i] = -sacc;
             }
             __syncthreads();
         }
-        // K' tile in D layout: register r of lane (c,q) = K'[4r+q][c]
-        d4 Kp = zero;
-        const bool colok = (c <= n);
+        // X = (Quu + lambda I)^-1 Quz and K' = -X as tiles in D layout: register r of lane (c,q) = X[4r+q][c]
+        d4 Xp = zero;
+        {
+            double xr[4] = {0.0, 0.0, 0.0, 0.0};
 #pragma unroll
-        for (int i = 0; i < M; i++) {
-            const double xi = colok ? x[i] : 0.0;
-            if ((i & 3) == 0) { if (q == 0) { if (i / 4 == 0) Kp.x = xi; else if (i / 4 == 1) Kp.y = xi; else if (i / 4 == 2) Kp.z = xi; else Kp.w = xi; } }
-            if ((i & 3) == 1) { if (q == 1) { if (i / 4 == 0) Kp.x = xi; else if (i / 4 == 1) Kp.y = xi; else if (i / 4 == 2) Kp.z = xi; else Kp.w = xi; } }
-            if ((i & 3) == 2) { if (q == 2) { if (i / 4 == 0) Kp.x = xi; else if (i / 4 == 1) Kp.y = xi; else if (i / 4 == 2) Kp.z = xi; else Kp.w = xi; } }
-            if ((i & 3) == 3) { if (q == 3) { if (i / 4 == 0) Kp.x = xi; else if (i / 4 == 1) Kp.y = xi; else if (i / 4 == 2) Kp.z = xi; else Kp.w = xi; } }
+            for (int i = 0; i < M; i++)
+                if (q == (i & 3)) xr[i >> 2] = x[i];
+            Xp.x = xr[0]; Xp.y = xr[1]; Xp.z = xr[2]; Xp.w = xr[3];
         }
-        // K (m x n column-major) and k out: lane (c,q) owns rows q, 4+q, ... of column c.  Bounds-checked
-        // buffer stores (out-of-range lanes are dropped by the hardware): straight-line code, so the
-        // compiler can keep COUNTED vmcnt waits for the prefetched tiles behind these stores.
+        const d4 Kp = -Xp;
         if (!(ABL & 4)) {
+            // K (m x n column-major) and k out through bounds-checked buffer stores (lanes that own no
+            // element carry an out-of-range offset and are dropped): straight-line code.
             __amdgpu_buffer_rsrc_t rK = __builtin_amdgcn_make_buffer_rsrc((void *)(Kout + ((size_t)b * T + t) * m * n), 0, m * n * 8, 0x00020000);
             __amdgpu_buffer_rsrc_t rk = __builtin_amdgcn_make_buffer_rsrc((void *)(kout + ((size_t)b * T + t) * m), 0, m * 8, 0x00020000);
             const double kv[4] = {Kp.x, Kp.y, Kp.z, Kp.w};
@@ -353,16 +351,20 @@ k_backward_mfma(RecLayout L, int T, const double *__restrict__ rec, const double
                 __builtin_amdgcn_raw_buffer_store_b64(__builtin_bit_cast(u32x2, kv[r]), rk, okst[r], 0, 0);
             }
         }
-
-        // ---- V' = Qzz + K''(Quu K' + Quz) + Quz' K'   (:606-607), delta_J (:612-613) ---------------
-        d4 W = P<NCU>(Quu, Kp, Quz);               // Quu' K' + Quz  (Quu symmetric up to rounding)
-        d4 acc = P<NCU>(Kp, W, Qzz);
+        // ---- delta_J += k'Q_u + k'Q_uu k  (:612-613).  With (Q_uu + lambda I) k = -Q_u this is
+        //      k'(Q_uu k + Q_u) = -lambda k'k, evaluated in that cancellation-free form (lane of column n).
         {
-            const double a_nn = reg_nn == 0 ? acc.x : reg_nn == 1 ? acc.y : reg_nn == 2 ? acc.z : acc.w;
-            const double q_nn = reg_nn == 0 ? Qzz.x : reg_nn == 1 ? Qzz.y : reg_nn == 2 ? Qzz.z : Qzz.w;
-            if (lane_nn) dJ += a_nn - q_nn;         // q_nn == 0 exactly: element (n,n) is kept at zero
+            double kk = 0.0;
+#pragma unroll
+            for (int i = 0; i < M; i++) kk += x[i] * x[i];
+            if (lane_nn) dJ -= lam * kk;
         }
-        acc = P<NCU>(Quz, Kp, acc);
+        // ---- V' = Qzz + K''Quu K' + K''Quz + Quz'K'   (:606-607).  Substituting Quz = -(Quu + lambda I) K'
+        //      gives V' = Qzz - K''(Quu + 2 lambda I) K' = Qzz + X'[(Quu + 2 lambda I) K']: two products.
+        d4 Quu2 = Quu;
+        Quu2.x += lam2d[0]; Quu2.y += lam2d[1]; Quu2.z += lam2d[2]; Quu2.w += lam2d[3];
+        d4 G = P<NCU>(Quu2, Kp, zero);             // (Quu + 2 lambda I) K'  (Quu symmetric up to rounding)
+        d4 acc = P<NCU>(Xp, G, Qzz);
 
         // ---- V' = (V' + V'')/2 through an LDS transpose   (:610) -----------------------------------
         if (ABL & 8) { V = acc; continue; }
@@ -375,7 +377,7 @@ k_backward_mfma(RecLayout L, int T, const double *__restrict__ rec, const double
         V.y = 0.5 * (acc.y + sh[LDS_V + c * VS + 4 + q]);
         V.z = 0.5 * (acc.z + sh[LDS_V + c * VS + 8 + q]);
         V.w = 0.5 * (acc.w + sh[LDS_V + c * VS + 12 + q]);
-        if (lane_nn) { if (reg_nn == 0) V.x = 0.0; else if (reg_nn == 1) V.y = 0.0; else if (reg_nn == 2) V.z = 0.0; else V.w = 0.0; }
+        if (lane_nn) set_reg<REG_NN>(V, 0.0);      // element (n,n) carries nothing: keep it at zero
         __syncthreads();
     }
     // delta_J lives in lane_nn; status is uniform
@@ -385,24 +387,19 @@ k_backward_mfma(RecLayout L, int T, const double *__restrict__ rec, const double
 
 bool backward_mfma_supported(int n, int m)
 {
-    return (n + 1 <= 16) && (m == 7 || m == 1) && n >= 2;
+    return (n == 14 && m == 7) || (n == 4 && m == 1);
 }
 
 hipError_t launch_backward_mfma(Ctx *c, int pd_stride)
 {
     const int n = c->n, m = c->d.m;
-    const int ncz = (n + 1 + 3) / 4;
     dim3 grid(c->d.batch), block(64);
-#define LAUNCH(MM, NCZ, NCU)                                                                              \
-    hipLaunchKernelGGL((k_backward_mfma<MM, NCZ, NCU>), grid, block, 0, c->stream, c->L, c->d.T, c->rec,  \
+#define LAUNCH(NN, MM)                                                                              \
+    hipLaunchKernelGGL((k_backward_mfma<NN, MM>), grid, block, 0, c->stream, c->L, c->d.T, c->rec,  \
                        c->lambda, pd_stride, c->K, c->k, c->delta_J, c->status)
-    if (m == 7) {
-        if (ncz <= 2) LAUNCH(7, 2, 2); else if (ncz == 3) LAUNCH(7, 3, 2); else LAUNCH(7, 4, 2);
-    } else if (m == 1) {
-        if (ncz <= 2) LAUNCH(1, 2, 1); else if (ncz == 3) LAUNCH(1, 3, 1); else LAUNCH(1, 4, 1);
-    } else {
-        return hipErrorInvalidValue;
-    }
+    if (n == 14 && m == 7) LAUNCH(14, 7);
+    else if (n == 4 && m == 1) LAUNCH(4, 1);
+    else return hipErrorInvalidValue;
 #undef LAUNCH
     return hipGetLastError();
 }
