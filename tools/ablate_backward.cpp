@@ -53,11 +53,11 @@ template <int ABL>
 static float run(RecLayout L, int B, int T, double *rec, double *lam, double *K, double *k, double *dJ, int *st, int reps)
 {
     hipEvent_t e0, e1; CK(hipEventCreate(&e0)); CK(hipEventCreate(&e1));
-    hipLaunchKernelGGL((k_backward_mfma<14, 7, ABL>), dim3(B), dim3(64), 0, 0, L, T, rec, lam, 100, K, k, dJ, st);
+    hipLaunchKernelGGL((k_backward_mfma_excl<14, 7, ABL>), dim3(B), dim3(64), 0, 0, L, T, rec, lam, 100, K, k, dJ, st);
     CK(hipDeviceSynchronize());
     CK(hipEventRecord(e0));
     for (int i = 0; i < reps; i++)
-        hipLaunchKernelGGL((k_backward_mfma<14, 7, ABL>), dim3(B), dim3(64), 0, 0, L, T, rec, lam, 100, K, k, dJ, st);
+        hipLaunchKernelGGL((k_backward_mfma_excl<14, 7, ABL>), dim3(B), dim3(64), 0, 0, L, T, rec, lam, 100, K, k, dJ, st);
     CK(hipEventRecord(e1)); CK(hipEventSynchronize(e1));
     float ms; CK(hipEventElapsedTime(&ms, e0, e1));
     int s0; double d0; CK(hipMemcpy(&s0, st, 4, hipMemcpyDeviceToHost)); CK(hipMemcpy(&d0, dJ, 8, hipMemcpyDeviceToHost));

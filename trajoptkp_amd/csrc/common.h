@@ -38,6 +38,7 @@ struct Ctx {
     int n = 0;
     RecLayout L;
     hipStream_t stream = nullptr;
+    int n_simd = 1024;             // SIMDs on the device (CUs x 4)
     bool own_stream = false;
     std::string err;
 

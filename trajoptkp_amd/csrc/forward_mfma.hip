@@ -48,8 +48,7 @@ __device__ __forceinline__ __amdgpu_buffer_rsrc_t rsrc(const double *p, int byte
 }
 
 template <int NCZ, int NCU>
-__global__ void __launch_bounds__(64)
-k_forward_mfma(RecLayout L, int T, int n_alpha, const double *__restrict__ rec,
+__device__ __forceinline__ void forward_body(RecLayout L, int T, int n_alpha, const double *__restrict__ rec,
                const double *__restrict__ Kin, const double *__restrict__ kin,
                const double *__restrict__ u_nom, const double *__restrict__ ctrl_lim,
                const double *__restrict__ alphas, double *__restrict__ cost_pred,
@@ -159,6 +158,24 @@ k_forward_mfma(RecLayout L, int T, int n_alpha, const double *__restrict__ rec,
     if (q == 0 && c < n_alpha) cost_pred[(size_t)b * n_alpha + c] = partial;
 }
 
+// Shared / exclusive-SIMD entry points (see riccati_mfma.hip: one wave per SIMD when the batch fits).
+template <int NCZ, int NCU>
+__global__ void __launch_bounds__(64)
+k_forward_mfma(RecLayout L, int T, int n_alpha, const double *__restrict__ rec, const double *__restrict__ Kin,
+               const double *__restrict__ kin, const double *__restrict__ u_nom, const double *__restrict__ ctrl_lim,
+               const double *__restrict__ alphas, double *__restrict__ cost_pred, double *__restrict__ U_alpha)
+{
+    forward_body<NCZ, NCU>(L, T, n_alpha, rec, Kin, kin, u_nom, ctrl_lim, alphas, cost_pred, U_alpha);
+}
+template <int NCZ, int NCU>
+__global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(1, 1)))
+k_forward_mfma_excl(RecLayout L, int T, int n_alpha, const double *__restrict__ rec, const double *__restrict__ Kin,
+                    const double *__restrict__ kin, const double *__restrict__ u_nom, const double *__restrict__ ctrl_lim,
+                    const double *__restrict__ alphas, double *__restrict__ cost_pred, double *__restrict__ U_alpha)
+{
+    forward_body<NCZ, NCU>(L, T, n_alpha, rec, Kin, kin, u_nom, ctrl_lim, alphas, cost_pred, U_alpha);
+}
+
 bool forward_mfma_supported(int n, int m, int n_alpha)
 {
     return (n + 2 <= 16) && (m <= 8) && (n_alpha <= 16) && n >= 2;
@@ -169,9 +186,18 @@ hipError_t launch_forward_mfma(Ctx *c, double *U_alpha_dev)
     const int n = c->n, m = c->d.m;
     const int ncz = (n + 2 + 3) / 4, ncu = (m + 3) / 4;
     dim3 grid(c->d.batch), block(64);
-#define LAUNCH(NCZ, NCU)                                                                               \
-    hipLaunchKernelGGL((k_forward_mfma<NCZ, NCU>), grid, block, 0, c->stream, c->L, c->d.T, c->d.n_alpha, \
-                       c->rec, c->K, c->k, c->u_nom, c->ctrl_lim, c->alphas, c->cost_pred, U_alpha_dev)
+    const bool excl = c->d.batch <= c->n_simd;
+#define LAUNCH(NCZ, NCU)                                                                                         \
+    do {                                                                                                         \
+        if (excl)                                                                                                \
+            hipLaunchKernelGGL((k_forward_mfma_excl<NCZ, NCU>), grid, block, 0, c->stream, c->L, c->d.T,         \
+                               c->d.n_alpha, c->rec, c->K, c->k, c->u_nom, c->ctrl_lim, c->alphas, c->cost_pred, \
+                               U_alpha_dev);                                                                     \
+        else                                                                                                     \
+            hipLaunchKernelGGL((k_forward_mfma<NCZ, NCU>), grid, block, 0, c->stream, c->L, c->d.T,              \
+                               c->d.n_alpha, c->rec, c->K, c->k, c->u_nom, c->ctrl_lim, c->alphas, c->cost_pred, \
+                               U_alpha_dev);                                                                     \
+    } while (0)
     if (ncu <= 1) { if (ncz <= 2) LAUNCH(2, 1); else if (ncz == 3) LAUNCH(3, 1); else LAUNCH(4, 1); }
     else          { if (ncz <= 2) LAUNCH(2, 2); else if (ncz == 3) LAUNCH(3, 2); else LAUNCH(4, 2); }
 #undef LAUNCH

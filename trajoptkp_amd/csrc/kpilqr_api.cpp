@@ -65,6 +65,11 @@ int kpilqr_create(const kpilqr_dims *dims, void *stream, kpilqr_ctx **out)
     c->d = *dims;
     c->n = 2 * dims->dof;
     c->L = RecLayout(c->n, dims->m);
+    {
+        hipDeviceProp_t prop;
+        if (hipGetDeviceProperties(&prop, dims->device) == hipSuccess && prop.multiProcessorCount > 0)
+            c->n_simd = prop.multiProcessorCount * 4;
+    }
 
     if (stream) { c->stream = (hipStream_t)stream; c->own_stream = false; }
     else {
