@@ -91,7 +91,7 @@ __device__ __forceinline__ void l2_prefetch_record(const double *R, int rec_byte
     glds_dword((const char *)R + (o0 < rec_bytes ? o0 : rec_bytes - 8), lds_addr);
     if (o1 < rec_bytes) glds_dword((const char *)R + o1, lds_addr);
 }
-#define PF_DIST 3
+#define PF_DIST 0
 
 struct TileOffs { int fz[4], fu[4], lzz[4], luz[4], luu[4]; };
 
@@ -242,7 +242,7 @@ __device__ __forceinline__ void backward_body(RecLayout L, int T, const double *
         cur = nxt;
         cur.Fz.x += one[0]; cur.Fz.y += one[1]; cur.Fz.z += one[2]; cur.Fz.w += one[3];
         if (t > 0) load_step<NCU>(R0 + (size_t)((ABL & 1) ? T - 1 : t - 1) * L.stride, rec_bytes, o, nxt);
-        if (!(ABL & 1) && t - 1 - PF_DIST >= 0)
+        if (PF_DIST > 0 && !(ABL & 1) && t - 1 - PF_DIST >= 0)
             l2_prefetch_record(R0 + (size_t)(t - 1 - PF_DIST) * L.stride, rec_bytes, lane, sh + LDS_PF);
         __builtin_amdgcn_sched_barrier(0);     // keep the prefetch AHEAD of this step's compute
         pd_counter++;
