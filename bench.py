@@ -126,7 +126,7 @@ def main():
     ab = algorithmic_bytes(p["dof"], p["m"], p["nr"], T, Kp, 6)
 
     # line-search cost reduction across GPUs: [sum_b J_pred(alpha_1..6), sum_b delta_J, #valid] (8 doubles)
-    red = torch.zeros(8, dtype=torch.float64, device="cuda")
+    from trajoptkp_amd import distributed as kd
     cost_view = torch.as_tensor(eng.device_array(9, (B, 6)), device="cuda")       # KPILQR_BUF_COST_PRED
     dJ_view = torch.as_tensor(eng.device_array(10, (B,)), device="cuda")          # KPILQR_BUF_DELTA_J
     st_view = torch.as_tensor(eng.device_array(11, (B,), "<i4"), device="cuda")   # KPILQR_BUF_STATUS
@@ -145,8 +145,7 @@ def main():
             if events is not None:
                 events[i][1].record(stream)
         if world > 1:
-            red[:6] = cost_view.sum(0); red[6] = dJ_view.sum(); red[7] = (st_view == 0).sum()
-            dist.all_reduce(red)
+            kd.allreduce_linesearch(kd.pack_linesearch(cost_view, dJ_view, st_view))
 
     for _ in range(args.warmup):
         one_step()

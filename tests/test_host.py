@@ -1,0 +1,78 @@
+"""Host-side C++ classes (trajoptkp_amd/host/): key-point generators against the CPU oracle (CPU), and
+the Optimiser-shaped iLQR_GPU end to end on the acrobot plumbing configuration (GPU)."""
+import numpy as np
+import pytest
+
+from oracle import oracle as orc
+from trajoptkp_amd import host
+
+
+def _states(rng, dof, T, dt=0.01):
+    t = np.arange(T) * dt
+    q = np.stack([rng.uniform(0.2, 1.0) * np.cos(rng.uniform(1, 8) * t + rng.uniform(0, 3)) for _ in range(dof)], 1)
+    v = np.stack([rng.uniform(0.5, 3.0) * np.sin(rng.uniform(1, 9) * t + rng.uniform(0, 3)) for _ in range(dof)], 1)
+    v += 0.05 * rng.standard_normal(v.shape)
+    return np.concatenate([q, v], 1)
+
+
+@pytest.mark.parametrize("dof,T,min_N", [(2, 100, 2), (2, 100, 3), (7, 3000, 5), (7, 64, 1)])
+def test_set_interval_matches_oracle(dof, T, min_N):
+    o, c, pct = host.keypoints("set_interval", dof, T, min_N)
+    oo, oc = orc.kp_set_interval(dof, T, min_N)
+    assert np.array_equal(o, oo) and np.array_equal(c, oc)
+    assert np.allclose(pct, orc.kp_percentages(dof, T, oo, oc))
+
+
+@pytest.mark.parametrize("seed", range(6))
+def test_adaptive_jerk_matches_oracle(seed):
+    rng = np.random.default_rng(seed)
+    dof, T = int(rng.integers(1, 8)), int(rng.integers(20, 300))
+    X = _states(rng, dof, T)
+    thr = rng.uniform(1.0, 400.0, dof)
+    min_N, max_N = int(rng.integers(1, 4)), int(rng.integers(4, 30))
+    o, c, _ = host.keypoints("adaptive_jerk", dof, T, min_N, max_N, thr, dt=0.01, X=X)
+    oo, oc = orc.kp_adaptive_jerk(dof, T, min_N, max_N, thr, 0.01, X)
+    assert np.array_equal(o, oo) and np.array_equal(c, oc)
+
+
+@pytest.mark.parametrize("seed", range(6))
+def test_velocity_change_matches_oracle(seed):
+    rng = np.random.default_rng(100 + seed)
+    dof, T = int(rng.integers(1, 8)), int(rng.integers(20, 300))
+    X = _states(rng, dof, T)
+    thr = rng.uniform(0.5, 10.0, dof)
+    min_N, max_N = int(rng.integers(1, 4)), int(rng.integers(4, 30))
+    o, c, _ = host.keypoints("velocity_change", dof, T, min_N, max_N, thr, X=X)
+    oo, oc = orc.kp_velocity_change(dof, T, min_N, max_N, thr, X)
+    assert np.array_equal(o, oo) and np.array_equal(c, oc)
+
+
+@pytest.mark.parametrize("seed", range(4))
+def test_iterative_error_matches_oracle(seed):
+    rng = np.random.default_rng(200 + seed)
+    dof, T = int(rng.integers(1, 5)), int(rng.integers(30, 200))
+    n = 2 * dof
+    A = np.cumsum(0.01 * rng.standard_normal((T, n, n)), axis=0)
+    A[T // 3:, :, :] += 0.3 * rng.standard_normal((n, n))            # a kink forces refinement
+    thr = 10.0 ** rng.uniform(-5, -2)
+    min_N = int(rng.integers(1, 4))
+    o, c, pct = host.keypoints("iterative_error", dof, T, min_N, iterative_error_threshold=thr, A=A)
+    oo, oc = orc.kp_iterative_error(dof, T, min_N, thr, A)
+    assert np.array_equal(o, oo) and np.array_equal(c, oc)
+    assert np.allclose(pct, orc.kp_percentages(dof, T, oo, oc))
+
+
+@pytest.mark.gpu
+def test_acrobot_plumbing_optimise_on_gpu():
+    """BASELINE configs[0] end to end through the reference-shaped C++ surface: acrobot swing-up, T=100,
+    set_interval 5: RolloutTrajectory -> Iteration (host FD -> GPU fd/interp/cost/backward/forward ->
+    confirming rollout).  The cost must decrease and never increase across accepted iterations."""
+    res = host.run_acrobot(T=100, min_N=5, max_iter=6, min_iter=2)
+    h = res["cost_history"]
+    assert res["iterations"] >= 1 and len(h) >= 2
+    assert np.all(np.diff(h) <= 1e-12), h
+    assert h[-1] < 0.9 * h[0], h
+    assert np.all(np.isfinite(res["U"])) and np.all(np.abs(res["U"]) <= 100.0 + 1e-9)
+    # key-point method that interleaves FD with placement
+    res2 = host.run_acrobot(T=100, min_N=2, max_iter=3, min_iter=1, method="iterative_error")
+    assert res2["cost_history"][-1] < res2["cost_history"][0]

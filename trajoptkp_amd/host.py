@@ -1,0 +1,64 @@
+"""ctypes access to libkpilqr_host.so: the C++ host classes (KeypointGenerator, Differentiator,
+iLQR_GPU -- trajoptkp_amd/host/) through the small C entry points of host_capi.cpp."""
+import ctypes as C
+import os
+import subprocess
+
+import numpy as np
+
+from . import _lib
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+HOST_LIB_PATH = os.path.join(_HERE, "lib", "libkpilqr_host.so")
+_host = None
+
+
+def build_host():
+    subprocess.check_call(["make", "-C", os.path.join(_HERE, "host")])
+    return HOST_LIB_PATH
+
+
+def load_host():
+    global _host
+    if _host is not None:
+        return _host
+    _lib.load()                       # libkpilqr.so (and torch's HIP runtime) first
+    if not os.path.exists(HOST_LIB_PATH):
+        build_host()
+    H = C.CDLL(HOST_LIB_PATH)
+    vp = C.c_void_p
+    H.kpilqr_host_keypoints.argtypes = [C.c_char_p, C.c_int, C.c_int, C.c_int, C.c_int, vp, C.c_double, C.c_double,
+                                        vp, vp, vp, vp, vp]
+    H.kpilqr_host_keypoints.restype = C.c_int
+    H.kpilqr_host_run_acrobot.argtypes = [C.c_int, C.c_int, C.c_int, C.c_int, C.c_char_p, vp, C.c_int, vp, vp, vp]
+    H.kpilqr_host_run_acrobot.restype = C.c_int
+    _host = H
+    return H
+
+
+def _p(a):
+    return None if a is None else a.ctypes.data_as(C.c_void_p)
+
+
+def keypoints(method, dof, T, min_N, max_N=1, thresholds=None, iterative_error_threshold=0.0, dt=0.01, X=None, A=None):
+    """KeypointGenerator::GenerateKeyPoints -> (offs[T+1], cols, percentages), CSR over time."""
+    H = load_host()
+    offs = np.zeros(T + 1, np.int32)
+    cols = np.zeros(2 * T * dof + dof, np.int32)
+    pct = np.zeros(dof)
+    th = None if thresholds is None else np.ascontiguousarray(thresholds, np.float64)
+    Xc = None if X is None else np.ascontiguousarray(X, np.float64)
+    Ac = None if A is None else np.ascontiguousarray(A, np.float64)
+    cnt = H.kpilqr_host_keypoints(method.encode(), dof, T, min_N, max_N, _p(th), iterative_error_threshold, dt,
+                                  _p(Xc), _p(Ac), _p(offs), _p(cols), _p(pct))
+    return offs, cols[:cnt].copy(), pct
+
+
+def run_acrobot(T=100, min_N=5, max_iter=5, min_iter=2, method="set_interval"):
+    H = load_host()
+    hist = np.zeros(max_iter + 2); U = np.zeros(T); K0 = np.zeros(4); tm = np.zeros(4)
+    it = H.kpilqr_host_run_acrobot(T, min_N, max_iter, min_iter, method.encode(), _p(hist), len(hist), _p(U), _p(K0), _p(tm))
+    if it < 0:
+        raise RuntimeError(f"kpilqr_host_run_acrobot failed: {it}")
+    return dict(iterations=it, cost_history=hist[:it + 1].copy(), U=U, K0=K0,
+                timings_ms=dict(derivs=tm[0], backward=tm[1], forward=tm[2], total=tm[3]))

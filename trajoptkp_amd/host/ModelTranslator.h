@@ -1,0 +1,40 @@
+// ModelTranslator.h -- task plugin surface used by the iLQR path, names as in
+// include/ModelTranslator/ModelTranslator.h:39-458.  Only what Optimiser/Differentiator call.
+#pragma once
+#include <memory>
+#include <vector>
+#include "PhysicsSimulator.h"
+#include "StdInclude.h"
+
+class ModelTranslator {
+public:
+    virtual ~ModelTranslator() {}
+    // Residuals of the task at state d  (ModelTranslator.h:91; e.g. Reaching.cpp:28-60)
+    virtual void Residuals(SimData *d, MatrixXd &residuals) = 0;
+    // sum_i w_i r_i^2   (src/ModelTranslator/ModelTranslator.cpp:314-327)
+    virtual double CostFunction(const MatrixXd &residuals, const stateVectorList &state_vector, bool terminal)
+    {
+        (void)state_vector;
+        double cost = 0.0;
+        for (size_t i = 0; i < residual_list.size(); i++) {
+            const double w = terminal ? residual_list[i].weight_terminal : residual_list[i].weight;
+            cost += w * (residuals((int)i) * residuals((int)i));
+        }
+        return cost;
+    }
+    virtual MatrixXd ReturnStateVector(SimData *d, const stateVectorList &sv) = 0;       // [q; qdot], 2*dof x 1
+    virtual bool SetStateVector(const MatrixXd &x, SimData *d, const stateVectorList &sv) = 0;
+    virtual MatrixXd ReturnControlVector(SimData *d, const stateVectorList &sv) = 0;
+    virtual bool SetControlVector(const MatrixXd &u, SimData *d, const stateVectorList &sv) = 0;
+    virtual MatrixXd ReturnControlLimits(const stateVectorList &sv) = 0;                // [lo0,hi0,lo1,hi1,...]
+
+    std::shared_ptr<PhysicsSimulator> MuJoCo_helper;
+    stateVectorList current_state_vector, full_state_vector;
+    std::vector<residual> residual_list;
+    // key-point settings read from the task YAML in the reference (FileHandler.cpp:21-289)
+    std::string keypoint_method = "set_interval";
+    int min_N = 1, max_N = 1;
+    std::vector<double> jerk_thresholds, velocity_change_thresholds;
+    double iterative_error_threshold = 0.0;
+    bool auto_adjust = false;
+};

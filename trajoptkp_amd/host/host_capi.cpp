@@ -1,0 +1,65 @@
+// host_capi.cpp -- small C entry points over the C++ host classes so that the Python tests can drive
+// them (key-point generators against the oracle; the acrobot plumbing optimisation end to end).
+#include <cstring>
+#include <memory>
+
+#include "AcrobotModel.h"
+#include "iLQR_GPU.h"
+
+extern "C" {
+
+// Key-points of `method` for a trajectory X [T][2*dof]; A (optional, [T][n*n] column-major) feeds
+// iterative_error.  Returns the number of entries written to cols; offs has T+1 entries.
+int kpilqr_host_keypoints(const char *method, int dof, int T, int min_N, int max_N, const double *thresholds,
+                          double iterative_error_threshold, double dt, const double *X, const double *A,
+                          int *offs, int *cols, double *percentages)
+{
+    const int n = 2 * dof;
+    KeypointGenerator gen(dof, T);
+    keypoint_method km;
+    km.name = method; km.min_N = min_N; km.max_N = max_N;
+    if (thresholds) { km.jerk_thresholds.assign(thresholds, thresholds + dof); km.velocity_change_thresholds = km.jerk_thresholds; }
+    km.iterative_error_threshold = iterative_error_threshold;
+    gen.SetKeypointMethod(km);
+    std::vector<MatrixXd> states(T, MatrixXd(n, 1));
+    if (X) for (int t = 0; t < T; t++) std::memcpy(states[t].data(), X + (size_t)t * n, sizeof(double) * n);
+    KeypointGenerator::ColumnFD fd;
+    if (A) fd = [&](int t, int i, double *cp, double *cv) {
+        std::memcpy(cp, A + (size_t)t * n * n + (size_t)i * n, sizeof(double) * n);
+        std::memcpy(cv, A + (size_t)t * n * n + (size_t)(i + dof) * n, sizeof(double) * n);
+    };
+    gen.GenerateKeyPoints(states, dt, fd);
+    int cnt = 0;
+    for (int t = 0; t < T; t++) { offs[t] = cnt; for (int i : gen.keypoints[t]) cols[cnt++] = i; }
+    offs[T] = cnt;
+    if (percentages) for (int i = 0; i < dof; i++) percentages[i] = gen.last_percentages[i];
+    return cnt;
+}
+
+// Acrobot swing-up, BASELINE configs[0]: T steps, set_interval(min_N) key-points, zero initial controls
+// from the hanging-ish start [3.1415, 0.3] (acrobot.yaml:16).  Runs Optimise(max_iter, min_iter) on the
+// GPU engine; writes cost_history (initial cost first) and the final controls.  Returns iterations run,
+// or <0 on error.
+int kpilqr_host_run_acrobot(int T, int min_N, int max_iter, int min_iter, const char *keypoint_method_name,
+                            double *cost_history, int cost_cap, double *U_out, double *K0_out, double *timings_ms)
+{
+    auto sim = std::make_shared<AcrobotSimulator>(0.01, 8);
+    auto mt = std::make_shared<AcrobotTranslator>(sim);
+    mt->min_N = min_N;
+    if (keypoint_method_name) mt->keypoint_method = keypoint_method_name;
+    sim->main_data->q[0] = 3.1415; sim->main_data->q[1] = 0.3;
+    *sim->master_reset_data = *sim->main_data;
+    auto diff = std::make_shared<Differentiator>(mt, sim);
+    iLQR_GPU opt(mt, sim, diff, T);
+    if (!opt.ok()) return -2;
+    std::vector<MatrixXd> U0(T, MatrixXd(1, 1));
+    std::vector<MatrixXd> U = opt.Optimise(sim->main_data, U0, max_iter, min_iter, T);
+    const int nh = (int)opt.cost_history.size();
+    for (int i = 0; i < nh && i < cost_cap; i++) cost_history[i] = opt.cost_history[i];
+    if (U_out) for (int t = 0; t < T; t++) U_out[t] = U[t](0);
+    if (K0_out) for (int c = 0; c < 4; c++) K0_out[c] = opt.K[0](0, c);
+    if (timings_ms) { timings_ms[0] = opt.avg_time_get_derivs_ms; timings_ms[1] = opt.avg_time_backwards_pass_ms; timings_ms[2] = opt.avg_time_forwards_pass_ms; timings_ms[3] = opt.opt_time_ms; }
+    return opt.num_iterations;
+}
+
+}  // extern "C"

@@ -1,0 +1,280 @@
+// iLQR_GPU.cpp -- host control flow of one optimisation, line-cited against src/Optimiser/iLQR.cpp.
+#include "iLQR_GPU.h"
+
+#include <algorithm>
+#include <chrono>
+#include <cstdio>
+#include <cstdlib>
+
+using clk = std::chrono::high_resolution_clock;
+static double ms_since(clk::time_point t0) { return std::chrono::duration<double, std::milli>(clk::now() - t0).count(); }
+
+void iLQR_GPU::fatal(const char *what, int rc)
+{
+    // fatal configuration / runtime errors end the program in the reference too (std::cerr + exit(1))
+    std::fprintf(stderr, "iLQR_GPU: %s failed (%d): %s\n", what, rc, kpilqr_strerror(ctx));
+    std::exit(1);
+}
+
+iLQR_GPU::iLQR_GPU(std::shared_ptr<ModelTranslator> mt, std::shared_ptr<PhysicsSimulator> sim,
+                   std::shared_ptr<Differentiator> diff, int horizon, int device_)
+    : Optimiser(mt, sim, diff), device(device_)
+{
+    // saved state list with horizon+1 entries (iLQR.cpp:9-26)
+    for (int i = 0; i <= horizon; i++)
+        if (!MuJoCo_helper->CheckIfDataIndexExists(i)) MuJoCo_helper->AppendSystemStateToEnd(MuJoCo_helper->main_data);
+    for (int i = 1; i <= num_parallel_rollouts; i++) { const double l = (double)i / num_parallel_rollouts; alphas.push_back(l * l); }   // :466-470
+    Resize(mt->current_state_vector.dof, mt->current_state_vector.num_ctrl, horizon);
+}
+
+iLQR_GPU::~iLQR_GPU() { if (ctx) kpilqr_destroy(ctx); }
+
+void iLQR_GPU::Resize(int new_num_dofs, int new_num_ctrl, int new_horizon)
+{
+    if (new_num_dofs == dof && new_num_ctrl == num_ctrl && new_horizon == horizon_length && ctx) return;
+    dof = new_num_dofs; num_ctrl = new_num_ctrl; horizon_length = new_horizon;
+    const int n = 2 * dof, m = num_ctrl, T = horizon_length, nr = (int)activeModelTranslator->residual_list.size();
+    if (ctx) { kpilqr_destroy(ctx); ctx = nullptr; }
+    kpilqr_dims d = {dof, m, T, nr, 1, num_parallel_rollouts, device, 0};
+    const int rc = kpilqr_create(&d, nullptr, &ctx);
+    if (rc != KPILQR_OK) { last_error = kpilqr_strerror(nullptr); ctx = nullptr; std::fprintf(stderr, "iLQR_GPU: %s\n", last_error.c_str()); std::exit(1); }
+    U_old.assign(T, MatrixXd(m, 1)); X_old.assign(T + 1, MatrixXd(n, 1)); X_new.assign(T + 1, MatrixXd(n, 1));
+    residuals.assign(T + 1, MatrixXd(nr, 1));
+    K.assign(T, MatrixXd(m, n)); k.assign(T, MatrixXd(m, 1));
+    host_r.assign((size_t)(T + 1) * nr, 0.0); host_rx.assign((size_t)(T + 1) * nr * n, 0.0); host_ru.assign((size_t)(T + 1) * nr * m, 0.0);
+    host_unom.assign((size_t)T * m, 0.0); host_K.assign((size_t)T * n * m, 0.0); host_k.assign((size_t)T * m, 0.0);
+    w_run.clear(); w_term.clear();
+    for (const residual &r : activeModelTranslator->residual_list) { w_run.push_back(r.weight); w_term.push_back(r.weight_terminal); }
+    const MatrixXd lim = activeModelTranslator->ReturnControlLimits(activeModelTranslator->current_state_vector);
+    ctrl_lim.assign(lim.data(), lim.data() + 2 * m);
+    keypoint_generator->Resize(dof, m, T);
+    while ((int)MuJoCo_helper->saved_systems_state_list.size() <= T) MuJoCo_helper->AppendSystemStateToEnd(MuJoCo_helper->main_data);
+}
+
+// iLQR.cpp:202-254
+double iLQR_GPU::RolloutTrajectory(SimData *d, bool save_states, std::vector<MatrixXd> initial_controls)
+{
+    const stateVectorList &sv = activeModelTranslator->full_state_vector;
+    double cost = 0.0;
+    MuJoCo_helper->CopySystemState(MuJoCo_helper->main_data, d);
+    X_old[0] = activeModelTranslator->ReturnStateVector(MuJoCo_helper->main_data, sv);
+    MuJoCo_helper->CopySystemState(MuJoCo_helper->saved_systems_state_list[0], MuJoCo_helper->main_data);
+    for (int i = 0; i < horizon_length; i++) {
+        activeModelTranslator->SetControlVector(initial_controls[i], MuJoCo_helper->main_data, sv);
+        MuJoCo_helper->ForwardSimulator(MuJoCo_helper->main_data);
+        activeModelTranslator->Residuals(MuJoCo_helper->main_data, residuals[i]);
+        cost += activeModelTranslator->CostFunction(residuals[i], sv, i == horizon_length - 1);
+        if (save_states) {
+            X_old[i + 1] = activeModelTranslator->ReturnStateVector(MuJoCo_helper->main_data, sv);
+            U_old[i] = activeModelTranslator->ReturnControlVector(MuJoCo_helper->main_data, sv);
+            MuJoCo_helper->CopySystemState(MuJoCo_helper->saved_systems_state_list[i + 1], MuJoCo_helper->main_data);
+        }
+    }
+    initial_cost = cost;
+    cost_history.push_back(cost);
+    return cost;
+}
+
+// iLQR.cpp:269-410
+std::vector<MatrixXd> iLQR_GPU::Optimise(SimData *d, std::vector<MatrixXd> initial_controls, int max_iterations,
+                                         int min_iterations, int horizon)
+{
+    const auto opt_start = clk::now();
+    Resize(activeModelTranslator->current_state_vector.dof, activeModelTranslator->current_state_vector.num_ctrl, horizon);
+    cost_history.clear(); time_get_derivs_ms.clear(); time_backwards_pass_ms.clear(); time_forwardsPass_ms.clear();
+    percentage_derivs_per_iteration.clear();
+    num_iterations = 0;
+    old_cost = RolloutTrajectory(d, true, initial_controls);
+    initial_cost = old_cost; new_cost = old_cost;
+    MuJoCo_helper->CopySystemState(MuJoCo_helper->main_data, MuJoCo_helper->saved_systems_state_list[0]);
+    cost_reduced_last_iter = true;
+    for (int i = 0; i < max_iterations; i++) {
+        num_iterations++;
+        bool lambda_exit = false, converged = false;
+        Iteration(i, converged, lambda_exit);
+        if (converged && (i >= min_iterations)) break;
+        if (lambda_exit) break;
+    }
+    cost_reduction = 1 - (new_cost / initial_cost);
+    opt_time_ms = ms_since(opt_start);
+    auto mean = [](const std::vector<double> &v) { double s = 0; for (double x : v) s += x; return v.empty() ? 0.0 : s / v.size(); };
+    avg_time_get_derivs_ms = mean(time_get_derivs_ms); avg_time_backwards_pass_ms = mean(time_backwards_pass_ms);
+    avg_time_forwards_pass_ms = mean(time_forwardsPass_ms); avg_percent_derivs = mean(percentage_derivs_per_iteration);
+    MuJoCo_helper->CopySystemState(MuJoCo_helper->main_data, MuJoCo_helper->saved_systems_state_list[0]);
+    return U_old;
+}
+
+// Optimiser::GenerateDerivatives (Optimiser.cpp:80-169): key-points, FD at key-points (host) -> GPU
+// differencing + interpolation; residual FD (host) -> GPU Gauss-Newton cost derivatives.
+void iLQR_GPU::GenerateDerivatives()
+{
+    const stateVectorList &sv = activeModelTranslator->current_state_vector;
+    const int n = 2 * dof, m = num_ctrl, T = horizon_length, nr = (int)w_run.size();
+    const double eps = 1e-6;                                     // Optimiser.cpp:319-321
+    keypoint_generator->ResetCache();
+    KeypointGenerator::ColumnFD col_fd = [&](int t, int i, double *cp, double *cv) {
+        FDJobs one;
+        activeDifferentiator->DynamicsDerivatives(one, 0, std::vector<int>(1, i), t, 0, true, eps);
+        for (int j = 0; j < one.njobs(); j++) {
+            double *dst = one.job_col[j] == i ? cp : one.job_col[j] == i + dof ? cv : nullptr;
+            if (dst) for (int r = 0; r < n; r++) dst[r] = (one.xplus[(size_t)j * n + r] - one.xminus[(size_t)j * n + r]) / (2 * eps);
+        }
+    };
+    std::vector<MatrixXd> Xk(X_old.begin(), X_old.begin() + T);
+    keypoint_generator->GenerateKeyPoints(Xk, MuJoCo_helper->ReturnModelTimeStep(), col_fd);
+    std::vector<int> offs, times;
+    keypoint_generator->PerDofCSR(offs, times);
+    int rc = kpilqr_set_keypoints(ctx, offs.data(), times.data());
+    if (rc) fatal("kpilqr_set_keypoints", rc);
+    jobs.clear();
+    activeDifferentiator->DynamicsDerivativesAtKeypoints(jobs, 0, keypoint_generator->keypoints, eps);
+    rc = kpilqr_upload_fd(ctx, jobs.njobs(), jobs.job_b.data(), jobs.job_t.data(), jobs.job_col.data(), jobs.job_mode.data(),
+                          jobs.job_nom.data(), jobs.xplus.data(), jobs.xminus.data(), jobs.nnom(n), jobs.xnom.data(), eps);
+    if (rc) fatal("kpilqr_upload_fd", rc);
+    if ((rc = kpilqr_fd_difference(ctx))) fatal("kpilqr_fd_difference", rc);
+    if ((rc = kpilqr_interpolate(ctx))) fatal("kpilqr_interpolate", rc);
+    // residuals and their FD Jacobians at every step (Optimiser::ComputeResidualDerivatives, :217-236)
+    for (int t = 0; t <= T; t++) {
+        for (int i = 0; i < nr; i++) host_r[(size_t)t * nr + i] = residuals[t](i);
+        activeDifferentiator->ResidualDerivatives(&host_rx[(size_t)t * nr * n], &host_ru[(size_t)t * nr * m], std::min(t, T), 0, eps);
+    }
+    rc = kpilqr_upload_residuals(ctx, host_r.data(), host_rx.data(), host_ru.data(), w_run.data(), w_term.data());
+    if (rc) fatal("kpilqr_upload_residuals", rc);
+    if ((rc = kpilqr_cost_derivs(ctx))) fatal("kpilqr_cost_derivs", rc);
+    double pct = 0.0;
+    for (int i = 0; i < sv.dof; i++) pct += keypoint_generator->last_percentages[i];
+    percentage_derivs_per_iteration.push_back(pct / sv.dof);
+}
+
+// iLQR.cpp:535-634 on the GPU; false = Q_uu + lambda I failed the PD test
+bool iLQR_GPU::BackwardsPassQuuRegularisation()
+{
+    int status = 0;
+    int rc = kpilqr_backward(ctx, &lambda, 100, &status, &delta_J);
+    if (rc < 0) fatal("kpilqr_backward", rc);
+    if ((rc = kpilqr_sync(ctx))) fatal("kpilqr_sync", rc);
+    return status == 0;
+}
+
+// iLQR.cpp:636-657
+bool iLQR_GPU::UpdateLambda(bool valid_backwards_pass)
+{
+    bool lambda_exit = false;
+    if (!valid_backwards_pass) lambda *= lambda_factor; else lambda /= lambda_factor;
+    if (lambda > max_lambda) { lambda = max_lambda; lambda_exit = true; }
+    if (lambda < min_lambda) lambda = min_lambda;
+    return lambda_exit;
+}
+
+// One closed-loop simulator rollout with the chosen alpha: the reference's ForwardsPassParallel
+// (iLQR.cpp:824-934) for ONE alpha, used to confirm the GPU's prediction.
+double iLQR_GPU::ForwardsPassConfirm(double alpha, std::vector<MatrixXd> &U_out, std::vector<MatrixXd> &X_out)
+{
+    const stateVectorList &sv = activeModelTranslator->current_state_vector;
+    const int n = 2 * dof, m = num_ctrl;
+    SimData *d = MuJoCo_helper->fd_data[0];
+    MuJoCo_helper->CopySystemState(d, MuJoCo_helper->saved_systems_state_list[0]);
+    double cost = 0.0;
+    MatrixXd r((int)w_run.size(), 1);
+    X_out[0] = activeModelTranslator->ReturnStateVector(d, sv);
+    for (int t = 0; t < horizon_length; t++) {
+        const MatrixXd x = activeModelTranslator->ReturnStateVector(d, sv);
+        MatrixXd u(m, 1);
+        for (int i = 0; i < m; i++) {
+            double fb = 0.0;
+            for (int p = 0; p < n; p++) fb += K[t](i, p) * (x(p) - X_old[t](p));       // :853,876
+            double v = U_old[t](i) + (alpha * k[t](i)) + fb;                            // :879
+            if (v > ctrl_lim[2 * i + 1]) v = ctrl_lim[2 * i + 1];                       // :883-889
+            if (v < ctrl_lim[2 * i]) v = ctrl_lim[2 * i];
+            u(i) = v;
+        }
+        activeModelTranslator->SetControlVector(u, d, sv);
+        activeModelTranslator->Residuals(d, r);
+        cost += activeModelTranslator->CostFunction(r, sv, t == horizon_length - 1);
+        U_out[t] = u;
+        MuJoCo_helper->ForwardSimulator(d);
+        X_out[t + 1] = activeModelTranslator->ReturnStateVector(d, sv);
+    }
+    return cost;
+}
+
+// iLQR.cpp:412-531
+void iLQR_GPU::Iteration(int iteration_num, bool &converged, bool &lambda_exit)
+{
+    (void)iteration_num;
+    const int n = 2 * dof, m = num_ctrl, T = horizon_length;
+    auto t0 = clk::now();
+    if (cost_reduced_last_iter) GenerateDerivatives();                                  // STEP 1 (:419)
+    time_get_derivs_ms.push_back(ms_since(t0));
+
+    t0 = clk::now();
+    bool valid = false;                                                                 // STEP 2 (:435-442)
+    while (!valid) {
+        valid = BackwardsPassQuuRegularisation();
+        lambda_exit = UpdateLambda(valid);
+        if (lambda_exit) break;
+    }
+    time_backwards_pass_ms.push_back(ms_since(t0));
+    if (lambda_exit) return;
+
+    t0 = clk::now();                                                                    // STEP 3
+    for (int t = 0; t < T; t++) for (int i = 0; i < m; i++) host_unom[(size_t)t * m + i] = U_old[t](i);
+    int rc = kpilqr_upload_nominal(ctx, host_unom.data(), ctrl_lim.data());
+    if (rc) fatal("kpilqr_upload_nominal", rc);
+    std::vector<double> pred(alphas.size());
+    if ((rc = kpilqr_forward_linear(ctx, alphas.data(), pred.data(), nullptr))) fatal("kpilqr_forward_linear", rc);
+    if ((rc = kpilqr_download_gains(ctx, host_K.data(), host_k.data()))) fatal("kpilqr_download_gains", rc);
+    if ((rc = kpilqr_sync(ctx))) fatal("kpilqr_sync", rc);
+    for (int t = 0; t < T; t++) {
+        for (int c = 0; c < n; c++) for (int r = 0; r < m; r++) K[t](r, c) = host_K[((size_t)t * n + c) * m + r];
+        for (int r = 0; r < m; r++) k[t](r) = host_k[(size_t)t * m + r];
+    }
+    // candidates in order of predicted cost; each is confirmed with one simulator rollout until one
+    // improves the true cost (the reference rolls all six out in parallel and takes the best, :478-502)
+    std::vector<int> order(alphas.size());
+    for (size_t i = 0; i < order.size(); i++) order[i] = (int)i;
+    std::sort(order.begin(), order.end(), [&](int a, int b) { return pred[a] < pred[b]; });
+    std::vector<MatrixXd> U_try(T, MatrixXd(m, 1)), X_try(T + 1, MatrixXd(n, 1));
+    new_cost = old_cost;
+    for (int idx : order) {
+        const double c = ForwardsPassConfirm(alphas[idx], U_try, X_try);
+        if (c < old_cost) { new_cost = c; break; }
+    }
+    time_forwardsPass_ms.push_back(ms_since(t0));
+
+    converged = CheckForConvergence(old_cost, new_cost);                                // STEP 4 (:515)
+    if (new_cost < old_cost) {
+        // UpdateNominal (:936-948) from the confirming rollout
+        const stateVectorList &sv = activeModelTranslator->current_state_vector;
+        SimData *d = MuJoCo_helper->main_data;
+        MuJoCo_helper->CopySystemState(d, MuJoCo_helper->saved_systems_state_list[0]);
+        for (int t = 0; t < T; t++) {
+            U_old[t] = U_try[t];
+            activeModelTranslator->SetControlVector(U_old[t], d, sv);
+            MuJoCo_helper->ForwardSimulator(d);
+            activeModelTranslator->Residuals(d, residuals[t]);
+            X_old[t + 1] = activeModelTranslator->ReturnStateVector(d, sv);
+            MuJoCo_helper->CopySystemState(MuJoCo_helper->saved_systems_state_list[t + 1], d);
+        }
+        old_cost = new_cost;
+        cost_reduced_last_iter = true;
+    } else {
+        cost_reduced_last_iter = false;
+        lambda *= lambda_factor; lambda *= lambda_factor;                               // :525-527
+        if (lambda > max_lambda) lambda = max_lambda;
+    }
+    cost_history.push_back(new_cost);
+}
+
+void iLQR_GPU::DownloadDerivatives(std::vector<MatrixXd> &A, std::vector<MatrixXd> &B)
+{
+    const int n = 2 * dof, m = num_ctrl, T = horizon_length;
+    std::vector<double> a((size_t)T * n * n), b((size_t)T * n * m);
+    const int rc = kpilqr_get_AB(ctx, a.data(), b.data());
+    if (rc) fatal("kpilqr_get_AB", rc);
+    A.assign(T, MatrixXd(n, n)); B.assign(T, MatrixXd(n, m));
+    for (int t = 0; t < T; t++) {
+        std::copy(a.begin() + (size_t)t * n * n, a.begin() + (size_t)(t + 1) * n * n, A[t].data());
+        std::copy(b.begin() + (size_t)t * n * m, b.begin() + (size_t)(t + 1) * n * m, B[t].data());
+    }
+}

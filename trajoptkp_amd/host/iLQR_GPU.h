@@ -1,0 +1,42 @@
+// iLQR_GPU.h -- the reference's iLQR optimiser (include/Optimiser/iLQR.h, src/Optimiser/iLQR.cpp) with
+// STEP 1b/1c/2/3 of Iteration() forwarded to libkpilqr.so through the C ABI of include/kpilqr.h.
+// Selected like the reference's optimisers by name ("iLQR_GPU", src/main.cpp:134-165).
+#pragma once
+#include "Optimiser.h"
+#include "../../include/kpilqr.h"
+
+class iLQR_GPU : public Optimiser {
+public:
+    iLQR_GPU(std::shared_ptr<ModelTranslator> _modelTranslator, std::shared_ptr<PhysicsSimulator> MuJoCo_helper,
+             std::shared_ptr<Differentiator> _differentiator, int horizon, int device = 0);
+    ~iLQR_GPU() override;
+
+    double RolloutTrajectory(SimData *d, bool save_states, std::vector<MatrixXd> initial_controls) override;
+    std::vector<MatrixXd> Optimise(SimData *d, std::vector<MatrixXd> initial_controls, int max_iterations,
+                                   int min_iterations, int horizon_length) override;
+    std::string ReturnName() override { return "iLQR_GPU"; }
+    void Resize(int new_num_dofs, int new_num_ctrl, int new_horizon) override;
+
+    // gains of the last backward pass, reference layout (K[t] is m x n, k[t] is m x 1)
+    std::vector<MatrixXd> K, k;
+    double delta_J = 0.0;
+    // A, B, l_* of the last GenerateDerivatives as the reference exposes them (debug hook of the ABI)
+    void DownloadDerivatives(std::vector<MatrixXd> &A, std::vector<MatrixXd> &B);
+    bool ok() const { return ctx != nullptr; }
+    std::string last_error;
+
+private:
+    void Iteration(int iteration_num, bool &converged, bool &lambda_exit);
+    void GenerateDerivatives();
+    bool BackwardsPassQuuRegularisation();
+    bool UpdateLambda(bool valid_backwards_pass);
+    double ForwardsPassConfirm(double alpha, std::vector<MatrixXd> &U_out, std::vector<MatrixXd> &X_out);
+    void fatal(const char *what, int rc);
+
+    kpilqr_ctx *ctx = nullptr;
+    int device = 0;
+    bool cost_reduced_last_iter = true;
+    std::vector<double> alphas, w_run, w_term, ctrl_lim;
+    std::vector<double> host_r, host_rx, host_ru, host_unom, host_K, host_k;
+    FDJobs jobs;
+};

@@ -31,7 +31,7 @@ def seed_for(config_id, b):
 
 def keypoint_rows_set_interval(dof, T, min_N):
     """KeypointGenerator::GenerateKeyPointsSetInterval (KeyPointGenerator.cpp:319-339), numpy twin
-    of the oracle's orc_kp_set_interval (used only to build inputs)."""
+    of the test oracle's set-interval routine (used only to build inputs)."""
     offs = np.zeros(T + 1, np.int32)
     cols = []
     for t in range(T):
