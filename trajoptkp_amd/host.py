@@ -30,7 +30,7 @@ def load_host():
     H.kpilqr_host_keypoints.argtypes = [C.c_char_p, C.c_int, C.c_int, C.c_int, C.c_int, vp, C.c_double, C.c_double,
                                         vp, vp, vp, vp, vp]
     H.kpilqr_host_keypoints.restype = C.c_int
-    H.kpilqr_host_run_acrobot.argtypes = [C.c_int, C.c_int, C.c_int, C.c_int, C.c_char_p, vp, C.c_int, vp, vp, vp]
+    H.kpilqr_host_run_acrobot.argtypes = [C.c_int, C.c_int, C.c_int, C.c_int, C.c_char_p, C.c_double, vp, C.c_int, vp, vp, vp]
     H.kpilqr_host_run_acrobot.restype = C.c_int
     _host = H
     return H
@@ -54,10 +54,10 @@ def keypoints(method, dof, T, min_N, max_N=1, thresholds=None, iterative_error_t
     return offs, cols[:cnt].copy(), pct
 
 
-def run_acrobot(T=100, min_N=5, max_iter=5, min_iter=2, method="set_interval"):
+def run_acrobot(T=100, min_N=5, max_iter=5, min_iter=2, method="set_interval", torque_weight=-1.0):
     H = load_host()
     hist = np.zeros(max_iter + 2); U = np.zeros(T); K0 = np.zeros(4); tm = np.zeros(4)
-    it = H.kpilqr_host_run_acrobot(T, min_N, max_iter, min_iter, method.encode(), _p(hist), len(hist), _p(U), _p(K0), _p(tm))
+    it = H.kpilqr_host_run_acrobot(T, min_N, max_iter, min_iter, method.encode(), float(torque_weight), _p(hist), len(hist), _p(U), _p(K0), _p(tm))
     if it < 0:
         raise RuntimeError(f"kpilqr_host_run_acrobot failed: {it}")
     return dict(iterations=it, cost_history=hist[:it + 1].copy(), U=U, K0=K0,

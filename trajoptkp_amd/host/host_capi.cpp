@@ -41,11 +41,13 @@ int kpilqr_host_keypoints(const char *method, int dof, int T, int min_N, int max
 // GPU engine; writes cost_history (initial cost first) and the final controls.  Returns iterations run,
 // or <0 on error.
 int kpilqr_host_run_acrobot(int T, int min_N, int max_iter, int min_iter, const char *keypoint_method_name,
+                            double torque_weight /* <0: task default 100 */,
                             double *cost_history, int cost_cap, double *U_out, double *K0_out, double *timings_ms)
 {
     auto sim = std::make_shared<AcrobotSimulator>(0.01, 8);
     auto mt = std::make_shared<AcrobotTranslator>(sim);
     mt->min_N = min_N;
+    if (torque_weight >= 0) { mt->residual_list[4].weight = torque_weight; mt->residual_list[4].weight_terminal = torque_weight; }
     if (keypoint_method_name) mt->keypoint_method = keypoint_method_name;
     sim->main_data->q[0] = 3.1415; sim->main_data->q[1] = 0.3;
     *sim->master_reset_data = *sim->main_data;
