@@ -177,6 +177,16 @@ def main():
         total_traj = B * world
         value = total_traj * args.steps / elapsed
         dom = "backward"
+        # HBM bytes of the dominant kernel from the PMC passes (profiles/r01_pmc_traffic.json: separate
+        # rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE runs, gfx950 x2 read correction) -- same workload only
+        traffic = None
+        try:
+            pmc = json.load(open(os.path.join(ROOT, "profiles", "r01_pmc_traffic.json")))
+            wl = pmc["workload"]
+            if wl["task"] == args.task and wl["T"] == T and wl["batch"] == B and not args.generic:
+                traffic = pmc["kernels"][dom]["traffic_bytes"]
+        except Exception:
+            traffic = None
         achieved = ab[dom] * B / (stage_ms[dom] * 1e-3) / 1e9
         out = {
             "metric": "iLQR iterations/sec (Panda 7-DoF, T=3000)" if args.task == "panda_reaching" and T == 3000
@@ -194,7 +204,7 @@ def main():
             "stage_algorithmic_GBps": {k: ab[k] * B / (stage_ms[k] * 1e-3) / 1e9 for k in stages},
             "pipeline_algorithmic_GBps": sum(ab.values()) * B / (elapsed / args.steps) / 1e9,
             "roofline": {"bound": "hbm", "kernel": f"backward ({eng.backward_variant})", "achieved": achieved,
-                         "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS, "traffic": None,
+                         "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
                          "algorithmic_bytes_per_launch": ab[dom] * B, "avg_launch_ms": stage_ms[dom]},
         }
         if world == 1 and not args.no_cpu_baseline:
