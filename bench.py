@@ -43,15 +43,14 @@ def algorithmic_bytes(dof, m, nr, T, Kp, n_alpha):
     )
 
 
-def cpu_baseline(task, T, min_N, n_traj_per_core=8):
-    """Times the CPU oracle (oracle/kpilqr_oracle.c, -O3 -march=native) on this host: the same five
-    stages, independent trajectories spread over all host cores with a thread pool (the C calls
-    release the GIL), mirroring the reference's hardware_concurrency() pools."""
-    from concurrent.futures import ThreadPoolExecutor
-    from oracle import oracle as orc
-    from oracle import pipeline
-    from trajoptkp_amd import synth
+def cpu_baseline(task, T, min_N, reps_per_thread=10):
+    """Times the CPU oracle (oracle/kpilqr_oracle.c = line-faithful port of the reference, built here with
+    -O3 -march=native) on this host: whole trajectory-iterations (the same five stages) run by a pthread
+    pool inside the C library, one independent trajectory per thread at a time -- the batch analogue of
+    the reference's hardware_concurrency() thread pools.  Thread count = the 1-GPU box's CPU share (16)."""
     import tempfile
+    from oracle import oracle as orc
+    from trajoptkp_amd import synth
     path = orc.build(native=True, out_dir=tempfile.mkdtemp(prefix="kpilqr_oracle_"))
     orc._LIB = orc.lib(path)
     cores = os.cpu_count() or 1
@@ -60,18 +59,14 @@ def cpu_baseline(task, T, min_N, n_traj_per_core=8):
     except Exception:
         pass
     cores = min(cores, int(os.environ.get("KPILQR_CPU_THREADS", "16")))   # a 1-GPU box's CPU share is 16 cores
-    uniq = 4
-    p = synth.make_problem(task=task, T=T, batch=uniq, min_N=min_N)
-    pipeline.run_trajectory(p, 0)                      # warm-up
-    t0 = time.perf_counter(); pipeline.run_trajectory(p, 1); t_single = time.perf_counter() - t0
-    n_traj = max(16, n_traj_per_core * cores)
-    t0 = time.perf_counter()
-    with ThreadPoolExecutor(cores) as ex:
-        list(ex.map(lambda i: pipeline.run_trajectory(p, i % uniq)["status"], range(n_traj)))
-    wall = time.perf_counter() - t0
+    p = synth.make_problem(task=task, T=T, batch=1, min_N=min_N)
+    orc.iteration_batch_seconds(p, 0, 1, 1)                                # warm-up
+    t_single = orc.iteration_batch_seconds(p, 0, 1, 5) / 5
+    wall = orc.iteration_batch_seconds(p, 0, cores, reps_per_thread)
+    n_traj = cores * reps_per_thread
     return {"value": n_traj / wall, "unit": "trajectory-iterations/s", "cores": cores, "kind": "port",
-            "sample": f"{n_traj} trajectory-iterations ({task}, T={T}, key-points every {min_N}), {cores} threads; "
-                      f"single-thread: {1.0 / t_single:.2f} it/s",
+            "sample": f"{n_traj} trajectory-iterations ({task}, T={T}, key-points every {min_N}) on {cores} pthreads "
+                      f"({wall:.1f} s wall); single thread: {1.0 / t_single:.2f} it/s",
             "single_thread_value": 1.0 / t_single}
 
 

@@ -11,7 +11,10 @@
  */
 #include "kpilqr_oracle.h"
 
+#define _POSIX_C_SOURCE 200809L
 #include <float.h>
+#include <pthread.h>
+#include <time.h>
 #include <math.h>
 #include <stdlib.h>
 #include <string.h>
@@ -600,4 +603,55 @@ int orc_linesearch_accept(int n_alpha, const double *costs, double old_cost,
         if (*lambda > max_lambda) *lambda = max_lambda;
     }
     return best;
+}
+
+/* ------------------------------------------------------------------------------------ */
+/* whole iteration for one trajectory + pthread batch driver                               */
+int orc_iteration(const orc_problem *p, double *K, double *k, double *delta_J, double *cost_pred)
+{
+    const int n = 2 * p->dof, m = p->m, T = p->T;
+    const size_t nn = (size_t)n * n, nm = (size_t)n * m, mm_ = (size_t)m * m;
+    double *A = (double *)calloc((size_t)T * nn, sizeof(double)), *B = (double *)calloc((size_t)T * nm, sizeof(double));
+    double *l_x = (double *)malloc(sizeof(double) * T * n), *l_xx = (double *)malloc(sizeof(double) * T * nn);
+    double *l_u = (double *)malloc(sizeof(double) * T * m), *l_uu = (double *)malloc(sizeof(double) * T * mm_);
+    double alphas[16];
+    orc_fd_difference(n, m, p->njobs, p->job_t, p->job_col, p->job_mode, p->job_nom, p->xplus, p->xminus, p->xnom,
+                      p->eps, A, B);
+    orc_interpolate(p->dof, m, T, p->kp_offs, p->kp_cols, A, B);
+    orc_cost_derivs(n, m, p->nr, T, p->r, p->r_x, p->r_u, p->w_run, p->w_term, l_x, l_xx, l_u, l_uu);
+    const int st = orc_backward(n, m, T, A, B, l_x, l_xx, l_u, l_uu, p->lambda, p->pd_stride, K, k, delta_J);
+    if (st == 0) {
+        orc_alphas(p->n_alpha, alphas);
+        orc_forward_linear(n, m, T, p->n_alpha, alphas, A, B, K, k, l_x, l_xx, l_u, l_uu, p->u_nom, p->ctrl_lim,
+                           cost_pred, 0);
+    }
+    free(A); free(B); free(l_x); free(l_xx); free(l_u); free(l_uu);
+    return st;
+}
+
+typedef struct { const orc_problem *p; int reps; } orc_worker_arg;
+
+static void *orc_worker(void *arg_)
+{
+    const orc_worker_arg *arg = (const orc_worker_arg *)arg_;
+    const orc_problem *p = arg->p;
+    const int n = 2 * p->dof;
+    double *K = (double *)malloc(sizeof(double) * (size_t)p->T * n * p->m), *k = (double *)malloc(sizeof(double) * (size_t)p->T * p->m);
+    double dJ, cost[16];
+    for (int i = 0; i < arg->reps; i++) orc_iteration(p, K, k, &dJ, cost);
+    free(K); free(k);
+    return 0;
+}
+
+double orc_iteration_batch(const orc_problem *p, int nthreads, int reps)
+{
+    pthread_t *th = (pthread_t *)malloc(sizeof(pthread_t) * nthreads);
+    orc_worker_arg arg = { p, reps };
+    struct timespec t0, t1;
+    clock_gettime(CLOCK_MONOTONIC, &t0);
+    for (int i = 0; i < nthreads; i++) pthread_create(&th[i], 0, orc_worker, &arg);
+    for (int i = 0; i < nthreads; i++) pthread_join(th[i], 0);
+    clock_gettime(CLOCK_MONOTONIC, &t1);
+    free(th);
+    return (double)(t1.tv_sec - t0.tv_sec) + 1e-9 * (double)(t1.tv_nsec - t0.tv_nsec);
 }

@@ -113,6 +113,24 @@ int orc_linesearch_accept(int n_alpha, const double *costs, double old_cost,
                           double *new_cost, int *accepted,
                           double *lambda, double lambda_factor, double max_lambda);
 
+/* ---- whole iteration (a2 + a4 + a6 + a7 + a8) for ONE trajectory, and a pthread driver that runs
+ * independent trajectory-iterations on `nthreads` host threads (the reference's own parallelism is a
+ * std::thread pool over key-points, src/Optimiser/Optimiser.cpp:227,280; over a batch the natural
+ * unit is the trajectory).  Used for cross-checks and as bench.py's cpu_baseline ("port"). */
+typedef struct {
+    int dof, m, nr, T, njobs, pd_stride, n_alpha;
+    double eps, lambda;
+    const int *job_t, *job_col, *job_nom;
+    const unsigned char *job_mode;
+    const double *xplus, *xminus, *xnom;
+    const int *kp_offs, *kp_cols;               /* CSR over time */
+    const double *r, *r_x, *r_u, *w_run, *w_term, *u_nom, *ctrl_lim;
+} orc_problem;
+/* K [T][m*n], k [T][m], cost_pred [n_alpha]; returns the backward-pass status. */
+int orc_iteration(const orc_problem *p, double *K, double *k, double *delta_J, double *cost_pred);
+/* Runs nthreads x reps iterations (each thread on private work buffers); returns wall seconds. */
+double orc_iteration_batch(const orc_problem *p, int nthreads, int reps);
+
 #ifdef __cplusplus
 }
 #endif

@@ -29,7 +29,7 @@ def build(native=False, out_dir=None):
     src = os.path.join(_HERE, "kpilqr_oracle.c")
     march = "native" if native else "x86-64-v3"
     cmd = ["gcc", "-O3", f"-march={march}", "-ffp-contract=off", "-fPIC", "-std=c99",
-           "-shared", "-o", out, src, "-lm"]
+           "-shared", "-o", out, src, "-lm", "-lpthread"]
     subprocess.check_call(cmd)
     return out
 
@@ -80,9 +80,51 @@ def lib(path=None):
                                         C.POINTER(C.c_int), C.POINTER(C.c_double),
                                         C.c_double, C.c_double]
     L.orc_linesearch_accept.restype = C.c_int
+    L.orc_iteration.argtypes = [C.POINTER(Problem), _d, _d, C.POINTER(C.c_double), _d]
+    L.orc_iteration.restype = C.c_int
+    L.orc_iteration_batch.argtypes = [C.POINTER(Problem), C.c_int, C.c_int]
+    L.orc_iteration_batch.restype = C.c_double
     if path is None:
         _LIB = L
     return L
+
+
+class Problem(C.Structure):
+    """struct orc_problem (kpilqr_oracle.h)."""
+    _fields_ = [("dof", C.c_int), ("m", C.c_int), ("nr", C.c_int), ("T", C.c_int), ("njobs", C.c_int),
+                ("pd_stride", C.c_int), ("n_alpha", C.c_int), ("eps", C.c_double), ("lam", C.c_double),
+                ("job_t", C.c_void_p), ("job_col", C.c_void_p), ("job_nom", C.c_void_p), ("job_mode", C.c_void_p),
+                ("xplus", C.c_void_p), ("xminus", C.c_void_p), ("xnom", C.c_void_p),
+                ("kp_offs", C.c_void_p), ("kp_cols", C.c_void_p),
+                ("r", C.c_void_p), ("r_x", C.c_void_p), ("r_u", C.c_void_p), ("w_run", C.c_void_p),
+                ("w_term", C.c_void_p), ("u_nom", C.c_void_p), ("ctrl_lim", C.c_void_p)]
+
+
+def make_c_problem(p, b, lam=None, pd_stride=100, n_alpha=6):
+    """orc_problem for trajectory b of a synth problem dict; returns (struct, keep-alive list)."""
+    sel = p["job_b"] == b
+    arrs = dict(job_t=_c(p["job_t"][sel], np.int32), job_col=_c(p["job_col"][sel], np.int32),
+                job_nom=_c(p["job_nom"][sel], np.int32), job_mode=_c(p["job_mode"][sel], np.uint8),
+                xplus=_c(p["xplus"][sel]), xminus=_c(p["xminus"][sel]), xnom=_c(p["xnom"]),
+                kp_offs=_c(p["kp_rows"][b][0], np.int32), kp_cols=_c(p["kp_rows"][b][1], np.int32),
+                r=_c(p["r"][b]), r_x=_c(p["r_x"][b]), r_u=_c(p["r_u"][b]), w_run=_c(p["w_run"]), w_term=_c(p["w_term"]),
+                u_nom=_c(p["u_nom"][b]), ctrl_lim=_c(p["ctrl_lim"]))
+    s = Problem(p["dof"], p["m"], p["nr"], p["T"], int(sel.sum()), pd_stride, n_alpha, p["eps"],
+                p["lam"] if lam is None else lam, **{k: v.ctypes.data for k, v in arrs.items()})
+    return s, arrs
+
+
+def iteration(p, b, **kw):
+    s, keep = make_c_problem(p, b, **kw)
+    n, m, T = p["n"], p["m"], p["T"]
+    K = np.zeros((T, n, m)); k = np.zeros((T, m)); dJ = C.c_double(0.0); cost = np.zeros(16)
+    st = lib().orc_iteration(C.byref(s), K, k, C.byref(dJ), cost)
+    return st, K, k, dJ.value, cost[:s.n_alpha].copy()
+
+
+def iteration_batch_seconds(p, b, nthreads, reps, **kw):
+    s, keep = make_c_problem(p, b, **kw)
+    return lib().orc_iteration_batch(C.byref(s), nthreads, reps)
 
 
 def _c(a, dt=np.float64):
