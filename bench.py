@@ -43,7 +43,7 @@ def algorithmic_bytes(dof, m, nr, T, Kp, n_alpha):
     )
 
 
-def cpu_baseline(task, T, min_N, reps_per_thread=10):
+def cpu_baseline(task, T, min_N, reps_per_thread=60):
     """Times the CPU oracle (oracle/kpilqr_oracle.c = line-faithful port of the reference, built here with
     -O3 -march=native) on this host: whole trajectory-iterations (the same five stages) run by a pthread
     pool inside the C library, one independent trajectory per thread at a time -- the batch analogue of
@@ -92,11 +92,17 @@ def main():
     world = int(os.environ.get("WORLD_SIZE", "1"))
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs an MI355X: no HIP device visible (there is no CPU fallback)")
+    # one rank per GPU; the modulo only matters when rehearsing N>1 ranks on a 1-GPU box (gloo backend)
+    local_rank = local_rank % torch.cuda.device_count()
     torch.cuda.set_device(local_rank)
     dist = None
     if world > 1:
         import torch.distributed as dist
-        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+        backend = os.environ.get("KPILQR_DIST_BACKEND", "nccl")        # "nccl" is RCCL on ROCm
+        if backend == "nccl":
+            dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+        else:
+            dist.init_process_group(backend)
 
     B, T = args.batch, args.T
     uniq = min(args.unique, B)
