@@ -274,18 +274,28 @@ k_cost_derivs_rows(RecLayout L, int nr, int T,
     const int area = TT * (per > NOUT_ ? per : NOUT_);   // inputs first, outputs later, in the same LDS area
     double *sw = sh + area;                        // [2][nr]: running, terminal weights
     for (int w = threadIdx.x; w < 2 * nr; w += blockDim.x) sw[w] = (w < nr) ? w_run[w] : w_term[w - nr];
-    {   // stage r | r_x | r_u of nt consecutive steps: three contiguous global ranges
+    // stage r | r_x | r_u of nt consecutive steps: each is ONE contiguous global range, copied linearly
+    // (no index arithmetic per element) into its own LDS region, 16 bytes per lane where alignment allows
+    double *sr_all = sh, *srx_all = sh + TT * nr, *sru_all = srx_all + TT * nr * N;
+    {
         const size_t bt0 = (size_t)b * (T + 1) + t0;
-        for (int w = threadIdx.x; w < nt * nr; w += blockDim.x) { const int tt = w / nr, e = w - tt * nr; sh[tt * per + e] = r[bt0 * nr + w]; }
-        for (int w = threadIdx.x; w < nt * nr * N; w += blockDim.x) { const int tt = w / (nr * N), e = w - tt * nr * N; sh[tt * per + nr + e] = r_x[bt0 * nr * N + w]; }
-        for (int w = threadIdx.x; w < nt * nr * M; w += blockDim.x) { const int tt = w / (nr * M), e = w - tt * nr * M; sh[tt * per + nr + nr * N + e] = r_u[bt0 * nr * M + w]; }
+        const double *gr = r + bt0 * nr, *grx = r_x + bt0 * nr * N, *gru = r_u + bt0 * nr * M;
+        for (int w = threadIdx.x; w < nt * nr; w += blockDim.x) sr_all[w] = gr[w];
+        const int cx = nt * nr * N, cu = nt * nr * M;
+        if (((nr * N) & 1) == 0 && ((TT * nr) & 1) == 0) {
+            for (int w = threadIdx.x; w < cx / 2; w += blockDim.x)
+                reinterpret_cast<double2 *>(srx_all)[w] = reinterpret_cast<const double2 *>(grx)[w];
+        } else {
+            for (int w = threadIdx.x; w < cx; w += blockDim.x) srx_all[w] = grx[w];
+        }
+        for (int w = threadIdx.x; w < cu; w += blockDim.x) sru_all[w] = gru[w];
     }
     __syncthreads();
     const int ttr = threadIdx.x / ROWS;                        // threads beyond TT*ROWS idle in the compute phase
     const int tt = min(ttr, TT - 1), j = threadIdx.x - ttr * ROWS;
     const int t = t0 + tt;
     const double *wt = sw + ((t == T - 1) ? nr : 0);          // Optimiser.cpp:208-211
-    const double *sr = sh + tt * per, *srx = sr + nr, *sru = srx + nr * N;
+    const double *sr = sr_all + tt * nr, *srx = srx_all + tt * nr * N, *sru = sru_all + tt * nr * M;
     constexpr int NOUT = N * N + N + M * M + M;        // l_xx | l_x | l_uu | l_u, contiguous in the record
     double acc[N > M ? N : M], lv = 0.0;
     const bool active = ttr < nt;
