@@ -297,3 +297,61 @@ def test_bad_arguments_fail_loudly():
             e.upload_fd([0], [25], [0], [0], np.zeros((1, 14)), np.zeros((1, 14)))   # t out of range
         with pytest.raises(KpilqrError):
             e.upload_fd([0], [5], [0], [1], np.zeros((1, 14)), np.zeros((1, 14)))    # one-sided, no nominal
+
+
+@pytest.mark.parametrize("T", [2, 3, 7])
+def test_tiny_horizons(T):
+    """Smallest horizons the reference's loops admit (T >= 2: rows 0 and T-1 are always key-points)."""
+    p = synth.make_problem(task="panda_reaching", T=T, batch=2, min_N=5, dense_residuals=True)
+    g = run_engine(p)
+    ge = run_engine(p, generic=True)
+    for b in range(2):
+        o = pipeline.run_trajectory(p, b, want_U=True)
+        assert np.array_equal(g["A"][b], o["A"]) and np.array_equal(g["l_xx"][b], o["l_xx"])
+        assert np.array_equal(ge["K"][b], o["K"])
+        assert relerr(g["K"][b], o["K"]) < K_RTOL_TIGHT
+        assert relerr(g["cost_pred"][b], o["cost_pred"]) < 1e-9
+
+
+def test_three_alphas_and_U_alpha_output():
+    """n_alpha other than the reference's 6 (iLQR_SVR uses a different alpha set, iLQR_SVR.cpp:469-471)."""
+    p = synth.make_problem(task="panda_reaching", T=50, batch=2, min_N=5, dense_residuals=True)
+    alphas = np.array([1.0, 0.5, 0.1])
+    with Engine(p["dof"], p["m"], p["T"], p["nr"], batch=2, n_alpha=3) as e:
+        synth.upload(e, p)
+        e.fd_difference(); e.interpolate(); e.cost_derivs(); e.backward(p["lam"])
+        cost, U = e.forward_linear(alphas, want_U=True)
+    for b in range(2):
+        o = pipeline.run_trajectory(p, b, stages=("fd", "interp", "cost", "bwd"))
+        c, Uo = orc.forward_linear(p["n"], p["m"], p["T"], alphas, o["A"], o["B"], o["K"], o["k"], o["l_x"], o["l_xx"],
+                                   o["l_u"], o["l_uu"], p["u_nom"][b], p["ctrl_lim"], want_U=True)
+        assert relerr(cost[b], c) < 1e-9 and relerr(U[b], Uo) < 1e-9
+
+
+def test_empty_fd_upload_and_rerun_is_idempotent():
+    """Re-running a stage on unchanged inputs gives identical bytes; an empty FD upload is legal and
+    leaves the records alone."""
+    p = synth.make_problem(task="panda_reaching", T=40, batch=1, min_N=5)
+    with Engine(p["dof"], p["m"], p["T"], p["nr"], batch=1) as e:
+        synth.upload(e, p)
+        e.iterate(p["lam"], 100, orc.alphas(6)); K1, k1 = e.gains(); A1, B1 = e.get_AB()
+        e.iterate(); K2, k2 = e.gains(); A2, B2 = e.get_AB()
+        assert np.array_equal(K1, K2) and np.array_equal(A1, A2) and np.array_equal(B1, B2)
+        e.upload_fd([], [], [], [], np.zeros((0, p["n"])), np.zeros((0, p["n"])))
+        e.fd_difference(); e.sync()
+        A3, B3 = e.get_AB()
+        assert np.array_equal(A1, A3)
+
+
+def test_set_AB_and_cost_derivs_hooks_roundtrip():
+    rng = np.random.default_rng(5)
+    with Engine(3, 2, 9, 4, batch=2) as e:      # odd sizes: n=6, m=2 (generic kernels)
+        A = rng.standard_normal((2, 9, 6, 6)); B = rng.standard_normal((2, 9, 2, 6))
+        lx = rng.standard_normal((2, 9, 6)); lxx = rng.standard_normal((2, 9, 6, 6))
+        lu = rng.standard_normal((2, 9, 2)); luu = rng.standard_normal((2, 9, 2, 2))
+        e.set_AB(A, B); e.set_cost_derivs(lx, lxx, lu, luu)
+        A2, B2 = e.get_AB(); g = e.get_cost_derivs()
+        assert np.array_equal(A, A2) and np.array_equal(B, B2)
+        for x, y in zip((lx, lxx, lu, luu), g):
+            assert np.array_equal(x, y)
+        assert e.backward_variant == "generic_lds"

@@ -12,8 +12,10 @@
 //     Quz = Luz + Fu' Tz        (= [Q_ux Q_u])
 //     Quu = l_uu + Fu' Tu
 //     K'  = -(Quu + lambda I)^-1 Quz          (= [K k])
-//     V'  = Qzz + K''(Quu K' + Quz) + Quz' K'  (iLQR.cpp:606-607, both lines at once), then (V'+V'')/2
-//     delta_J += [K''(Quu K' + Quz)]_(n,n)     (= k'Q_uu k + k'Q_u, iLQR.cpp:612-613)
+//     V'  = Qzz - K''(Quu + 2 lambda I) K'     (= Qzz + K''Quu K' + K''Quz + Quz'K' of iLQR.cpp:606-607, both
+//                                               lines at once, after substituting Quz = -(Quu + lambda I) K'),
+//                                               then (V'+V'')/2
+//     delta_J -= lambda k'k                    (= k'Q_uu k + k'Q_u of iLQR.cpp:612-613, same substitution)
 // Tiles live in the MFMA accumulator ("D") layout: lane (c = lane&15, q = lane>>4), register r holds
 // element (row 4r+q, col c).  In that layout a tile is directly the B operand of the next MFMA (k-chunk
 // r = register r) and, used as the A operand, it is its own transpose.  So the single primitive is
