@@ -47,6 +47,7 @@ typedef struct {
 } kpilqr_dims;
 
 #define KPILQR_FLAG_GENERIC_KERNELS 1   /* force the dimension-generic LDS kernels (no MFMA path) */
+#define KPILQR_FLAG_TILED_KERNELS   2   /* prefer the LDS-tiled MFMA kernels even when one tile would do */
 
 enum {
     KPILQR_OK = 0,

@@ -88,7 +88,7 @@ def test_mfma_backward_gains_within_tolerance(case):
     name, p, ref = case
     g = run_engine(p, generic=False)
     if p["dof"] * 2 + 1 > 16:
-        assert g["variants"][0] == "generic_lds"
+        assert g["variants"][0] == "mfma_f64_tiled", g["variants"]
     else:
         assert g["variants"][0] == "mfma_f64_t1", g["variants"]
     for b, o in enumerate(ref):
@@ -355,3 +355,21 @@ def test_set_AB_and_cost_derivs_hooks_roundtrip():
         for x, y in zip((lx, lxx, lu, luu), g):
             assert np.array_equal(x, y)
         assert e.backward_variant == "generic_lds"
+
+
+@pytest.mark.parametrize("task,T,batch", [("panda_pushing", 60, 2), ("high_dof_push", 24, 2)])
+def test_tiled_mfma_large_state(task, T, batch):
+    """n = 20 (2x2 tiles) and n = 62 (4x4 tiles): tiled MFMA backward pass against the oracle, and the
+    generic kernel bit-exact beside it."""
+    p = synth.make_problem(task=task, T=T, batch=batch, min_N=4, dense_residuals=True, one_sided_frac=0.1)
+    g = run_engine(p)
+    ge = run_engine(p, generic=True)
+    assert g["variants"][0] == "mfma_f64_tiled"
+    for b in range(batch):
+        o = pipeline.run_trajectory(p, b, want_U=True)
+        assert g["status"][b] == 0
+        assert np.array_equal(ge["K"][b], o["K"])
+        assert relerr(g["K"][b], o["K"]) < K_RTOL_TIGHT, relerr(g["K"][b], o["K"])
+        assert relerr(g["k"][b], o["k"]) < K_RTOL_TIGHT
+        assert abs(g["delta_J"][b] - o["delta_J"]) <= 1e-9 * abs(o["delta_J"])
+        assert relerr(g["cost_pred"][b], o["cost_pred"]) < 1e-9

@@ -115,4 +115,9 @@ hipError_t launch_backward_mfma(Ctx *c, int pd_stride);
 bool forward_mfma_supported(int n, int m, int n_alpha);
 hipError_t launch_forward_mfma(Ctx *c, double *U_alpha_dev);
 
+// tiled_mfma.hip: n+2 <= 64 (NT x NT grids of 16x16 tiles in LDS), m in {1,7}
+bool backward_tiled_supported(int n, int m);
+hipError_t launch_backward_tiled(Ctx *c, int pd_stride);
+size_t backward_tiled_lds_bytes(int nt);
+
 }  // namespace kpilqr

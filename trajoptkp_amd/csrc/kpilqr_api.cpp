@@ -114,7 +114,9 @@ int kpilqr_create(const kpilqr_dims *dims, void *stream, kpilqr_ctx **out)
     (void)hipMemsetAsync(c->status, 0, B * sizeof(int), c->stream);
 
     const bool generic = (dims->flags & KPILQR_FLAG_GENERIC_KERNELS) != 0;
-    c->bwd_variant = (!generic && backward_mfma_supported(c->n, dims->m)) ? "mfma_f64_t1" : "generic_lds";
+    const bool force_tiled = (dims->flags & KPILQR_FLAG_TILED_KERNELS) != 0;
+    c->bwd_variant = (!generic && !force_tiled && backward_mfma_supported(c->n, dims->m)) ? "mfma_f64_t1"
+                   : (!generic && backward_tiled_supported(c->n, dims->m)) ? "mfma_f64_tiled" : "generic_lds";
     c->fwd_variant = (!generic && forward_mfma_supported(c->n, dims->m, dims->n_alpha)) ? "mfma_f64_t1" : "generic_lds";
     if (strcmp(c->bwd_variant, "generic_lds") == 0 && backward_generic_lds_bytes(c->n, dims->m) > 160 * 1024) {
         kpilqr_destroy(c);
@@ -330,6 +332,7 @@ int kpilqr_trajectory_cost(kpilqr_ctx *c, double *cost)
 static int run_backward(kpilqr_ctx *c, int pd_stride)
 {
     if (strcmp(c->bwd_variant, "mfma_f64_t1") == 0) KP_HIP(c, launch_backward_mfma(c, pd_stride));
+    else if (strcmp(c->bwd_variant, "mfma_f64_tiled") == 0) KP_HIP(c, launch_backward_tiled(c, pd_stride));
     else KP_HIP(c, launch_backward_generic(c, pd_stride));
     return KPILQR_OK;
 }

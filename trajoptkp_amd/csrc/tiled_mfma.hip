@@ -1,0 +1,454 @@
+// tiled_mfma.hip -- backward (a7) and forward (a8) passes for state dimensions beyond one MFMA tile:
+// n+2 <= 16*NT, NT = 2..4 (Panda pushing n=20, low/moderate/heavy clutter n=38..62), m <= 8.
+// Same formulation as riccati_mfma.hip / forward_mfma.hip (homogeneous coordinate, P(Y,X) = Y'X on
+// v_mfma_f64_16x16x4_f64, tiles in the accumulator layout), but the matrices are NT x NT grids of
+// 16x16 tiles that live in LDS (one wavefront per trajectory, up to 143 KB of the CU's 160 KB at NT=4),
+// and products loop over tiles.  This is where the per-step A'V_xxA is a real contraction
+// (62^3 at the high-DoF configuration): the FP64 matrix core does 1024 FMAs per ~80-cycle issue.
+//
+// Reference: iLQR::BackwardsPassQuuRegularisation + CheckMatrixPD, src/Optimiser/iLQR.cpp:535-670;
+// control law / clamp of iLQR::ForwardsPassParallel, src/Optimiser/iLQR.cpp:876-890.
+//
+// LDS tile image: 256 doubles, register r of lane l at [r*64 + l]  (element (4r + (l>>4), l&15)).
+// A workgroup is exactly one wavefront, so LDS traffic needs no s_barrier; __syncthreads() is kept as
+// the compiler-level ordering point (it lowers to nothing for a 64-thread workgroup).
+#include <cstdlib>
+#include "common.h"
+
+namespace kpilqr {
+
+typedef double d4 __attribute__((ext_vector_type(4)));
+typedef unsigned int u32x2t __attribute__((ext_vector_type(2)));
+#define MFMA(a, b, c) __builtin_amdgcn_mfma_f64_16x16x4f64((a), (b), (c), 0, 0, 0)
+#define OOBT 0x7ffffff0
+#define TILE 256
+
+__device__ __forceinline__ double tbld(__amdgpu_buffer_rsrc_t r, int byte_off)
+{
+    return __builtin_bit_cast(double, __builtin_amdgcn_raw_buffer_load_b64(r, byte_off, 0, 0));
+}
+__device__ __forceinline__ d4 lds_tile(const double *t, int lane)
+{
+    d4 v; v.x = t[lane]; v.y = t[64 + lane]; v.z = t[128 + lane]; v.w = t[192 + lane];
+    return v;
+}
+__device__ __forceinline__ void lds_store(double *t, int lane, const d4 &v)
+{
+    t[lane] = v.x; t[64 + lane] = v.y; t[128 + lane] = v.z; t[192 + lane] = v.w;
+}
+// acc += Y'X over `nc` 4-row chunks (nc is wave-uniform)
+__device__ __forceinline__ d4 Pn(const d4 &Y, const d4 &X, d4 acc, int nc)
+{
+    acc = MFMA(Y.x, X.x, acc);
+    if (nc > 1) acc = MFMA(Y.y, X.y, acc);
+    if (nc > 2) acc = MFMA(Y.z, X.z, acc);
+    if (nc > 3) acc = MFMA(Y.w, X.w, acc);
+    return acc;
+}
+__device__ __forceinline__ double trcp(double x)
+{
+    double r = __builtin_amdgcn_rcp(x);
+    r = __builtin_fma(__builtin_fma(-x, r, 1.0), r, r);
+    r = __builtin_fma(__builtin_fma(-x, r, 1.0), r, r);
+    return r;
+}
+
+// Eigen's pivoted LDLT + solve(I) on a row-major m x m image (slow path, see riccati_mfma.hip)
+__device__ static __attribute__((noinline)) void tslow_ldlt_inverse(int m, const double *M, double *a, double *x, double *temp, int *tr)
+{
+#define AA(i, j) a[(i) + (j) * m]
+#define XX(i, j) x[(i) + (j) * m]
+    for (int j = 0; j < m; j++) for (int i = 0; i < m; i++) AA(i, j) = M[i * 16 + j];
+    for (int k = 0; k < m; k++) {
+        int big = k; double bv = fabs(AA(k, k));
+        for (int i = k + 1; i < m; i++) if (fabs(AA(i, i)) > bv) { bv = fabs(AA(i, i)); big = i; }
+        tr[k] = big;
+        if (big != k) {
+            for (int j = 0; j < k; j++) { double t = AA(k, j); AA(k, j) = AA(big, j); AA(big, j) = t; }
+            for (int i = big + 1; i < m; i++) { double t = AA(i, k); AA(i, k) = AA(i, big); AA(i, big) = t; }
+            { double t = AA(k, k); AA(k, k) = AA(big, big); AA(big, big) = t; }
+            for (int i = k + 1; i < big; i++) { double t = AA(i, k); AA(i, k) = AA(big, i); AA(big, i) = t; }
+        }
+        if (k > 0) {
+            for (int j = 0; j < k; j++) temp[j] = AA(j, j) * AA(k, j);
+            double dot = 0.0;
+            for (int j = 0; j < k; j++) dot += AA(k, j) * temp[j];
+            AA(k, k) -= dot;
+            for (int i = k + 1; i < m; i++) {
+                double d2 = 0.0;
+                for (int j = 0; j < k; j++) d2 += AA(i, j) * temp[j];
+                AA(i, k) -= d2;
+            }
+        }
+        const double akk = AA(k, k);
+        const bool valid = fabs(akk) > 0.0;
+        if (k == 0 && !valid) { for (int j = 0; j < m; j++) tr[j] = j; break; }
+        if (valid) for (int i = k + 1; i < m; i++) AA(i, k) /= akk;
+    }
+    for (int c = 0; c < m; c++) for (int r = 0; r < m; r++) XX(r, c) = (r == c) ? 1.0 : 0.0;
+    for (int k = 0; k < m; k++)
+        if (tr[k] != k) for (int c = 0; c < m; c++) { double t = XX(k, c); XX(k, c) = XX(tr[k], c); XX(tr[k], c) = t; }
+    for (int c = 0; c < m; c++)
+        for (int k = 0; k < m; k++) {
+            const double b = XX(k, c);
+            for (int i = k + 1; i < m; i++) XX(i, c) -= b * AA(i, k);
+        }
+    for (int i = 0; i < m; i++) {
+        const double d = AA(i, i);
+        for (int c = 0; c < m; c++) {
+            if (fabs(d) > 2.2250738585072014e-308) XX(i, c) /= d; else XX(i, c) = 0.0;
+        }
+    }
+    for (int c = 0; c < m; c++)
+        for (int k = m - 1; k >= 0; k--) {
+            const double b = XX(k, c);
+            for (int i = 0; i < k; i++) XX(i, c) -= b * AA(k, i);
+        }
+    for (int k = m - 1; k >= 0; k--)
+        if (tr[k] != k) for (int c = 0; c < m; c++) { double t = XX(k, c); XX(k, c) = XX(tr[k], c); XX(tr[k], c) = t; }
+#undef AA
+#undef XX
+}
+
+// ---------------------------------------------------------------------------------------------
+// Backward pass.  z = [dx; 1] has nz = n+1 entries covered by NT row tiles.
+template <int M, int NT>
+__global__ void __launch_bounds__(64)
+k_backward_tiled(RecLayout L, int T, const double *__restrict__ rec, const double *__restrict__ lambda,
+                 int pd_stride, double *__restrict__ Kout, double *__restrict__ kout,
+                 double *__restrict__ delta_J, int *__restrict__ status)
+{
+    extern __shared__ __attribute__((aligned(16))) double sh[];
+    constexpr int NCU = (M + 3) / 4;
+    const int n = L.n, m = M, nz = n + 1;
+    const int lane = threadIdx.x, c = lane & 15, q = lane >> 4;
+    const int b = blockIdx.x;
+    const double lam = lambda[b];
+    // LDS map
+    double *bufV = sh;                              // NT*NT tiles: V', later Qzz and the new V'
+    double *bufF = bufV + NT * NT * TILE;           // Fz
+    double *bufT = bufF + NT * NT * TILE;           // Tz
+    double *bufFu = bufT + NT * NT * TILE;          // NT tiles
+    double *bufTu = bufFu + NT * TILE;              // NT tiles
+    double *bufQuz = bufTu + NT * TILE;             // NT tiles (row tile 0, column tile j)
+    double *bufX = bufQuz + NT * TILE;              // NT tiles: X = (Quu + lambda I)^-1 Quz
+    double *bufG = bufX + NT * TILE;                // NT tiles
+    double *sQ = bufG + NT * TILE;                  // one tile: Quu + lambda I in D layout
+    double *sRow = sQ + TILE;                       // 16x16 row-major scratch + slow-path work area (3*256+32)
+    // MFMA k-chunks (4 rows each) of row tile kt that hold rows < nz; empty tiles still issue one (zero) chunk
+    auto nchunk = [&](int kt) { const int rows = nz - 16 * kt; return rows >= 16 ? 4 : (rows + 3) / 4; };
+
+#ifdef KP_DEBUG_DUMP
+    // diagnostic build only (tools/tiled_debug.cpp): NT x NT (or 1 x NT) tile grids of step KP_DEBUG_T
+    auto dump = [&](int slot, const double *buf, int rows_t, int t) {
+        if (b != 0 || t != T - 1 - KP_DEBUG_STEP) return;
+        double *dst = delta_J + 16 + (size_t)slot * 64 * 64;
+        for (int i = 0; i < rows_t; i++) for (int j = 0; j < NT; j++) {
+            const d4 v = lds_tile(buf + (i * NT + j) * TILE, lane);
+            const double vv[4] = {v.x, v.y, v.z, v.w};
+            for (int r = 0; r < 4; r++) dst[(16 * i + 4 * r + q) * 64 + 16 * j + c] = vv[r];
+        }
+    };
+#define DUMP(slot, buf, rows_t) dump(slot, buf, rows_t, t)
+#else
+#define DUMP(slot, buf, rows_t)
+#endif
+    const double *R0 = rec + (size_t)b * T * L.stride;
+    const int rec_bytes = L.rec * 8;
+    const d4 zero = {0.0, 0.0, 0.0, 0.0};
+
+    // tile loaders (bounds-checked: structural zeros come back as 0 from out-of-range offsets)
+    auto load_Lzz = [&](__amdgpu_buffer_rsrc_t rs, int ti, int tj) -> d4 {
+        double v[4];
+#pragma unroll
+        for (int r = 0; r < 4; r++) {
+            const int row = 16 * ti + 4 * r + q, col = 16 * tj + c;
+            const int off = (row < n && col < n) ? 8 * (L.off_lxx + row * n + col)
+                          : (col == n && row < n) ? 8 * (L.off_lx + row)
+                          : (row == n && col < n) ? 8 * (L.off_lx + col) : OOBT;
+            v[r] = tbld(rs, off);
+        }
+        d4 o = {v[0], v[1], v[2], v[3]};
+        return o;
+    };
+    auto load_Fz = [&](__amdgpu_buffer_rsrc_t rs, int ti, int tj) -> d4 {
+        double v[4];
+#pragma unroll
+        for (int r = 0; r < 4; r++) {
+            const int row = 16 * ti + 4 * r + q, col = 16 * tj + c;
+            v[r] = tbld(rs, (row < n && col < n) ? 8 * (L.off_A + row * n + col) : OOBT) + ((row == n && col == n) ? 1.0 : 0.0);
+        }
+        d4 o = {v[0], v[1], v[2], v[3]};
+        return o;
+    };
+    auto load_Fu = [&](__amdgpu_buffer_rsrc_t rs, int ti) -> d4 {
+        double v[4];
+#pragma unroll
+        for (int r = 0; r < 4; r++) {
+            const int row = 16 * ti + 4 * r + q;
+            v[r] = tbld(rs, (row < n && c < m) ? 8 * (L.off_B + row * m + c) : OOBT);
+        }
+        d4 o = {v[0], v[1], v[2], v[3]};
+        return o;
+    };
+    auto load_Luz = [&](__amdgpu_buffer_rsrc_t rs, int tj) -> d4 {     // [0 l_u]: column n of the u x z block
+        double v[4];
+#pragma unroll
+        for (int r = 0; r < 4; r++) {
+            const int row = 4 * r + q, col = 16 * tj + c;
+            v[r] = tbld(rs, (row < m && col == n) ? 8 * (L.off_lu + row) : OOBT);
+        }
+        d4 o = {v[0], v[1], v[2], v[3]};
+        return o;
+    };
+    auto load_Luu = [&](__amdgpu_buffer_rsrc_t rs) -> d4 {
+        double v[4];
+#pragma unroll
+        for (int r = 0; r < 4; r++) {
+            const int row = 4 * r + q;
+            v[r] = tbld(rs, (row < m && c < m) ? 8 * (L.off_luu + row * m + c) : OOBT);
+        }
+        d4 o = {v[0], v[1], v[2], v[3]};
+        return o;
+    };
+
+    // V_x = l_x[T-1]; V_xx = l_xx[T-1]   (iLQR.cpp:537-539)
+    {
+        __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc((void *)(R0 + (size_t)(T - 1) * L.stride), 0, rec_bytes, 0x00020000);
+        for (int i = 0; i < NT; i++) for (int j = 0; j < NT; j++) lds_store(bufV + (i * NT + j) * TILE, lane, load_Lzz(rs, i, j));
+    }
+    __syncthreads();
+
+    // element (n,n): tile (tn,tn), lane (c = n&15, q = (n&15)&3), register (n&15)>>2
+    const int tn = n >> 4, cn = n & 15;
+    const bool lane_nn = (c == cn) && (q == (cn & 3));
+    const int reg_nn = cn >> 2;
+    d4 nn_keep;
+    nn_keep.x = (lane_nn && reg_nn == 0) ? 0.0 : 1.0; nn_keep.y = (lane_nn && reg_nn == 1) ? 0.0 : 1.0;
+    nn_keep.z = (lane_nn && reg_nn == 2) ? 0.0 : 1.0; nn_keep.w = (lane_nn && reg_nn == 3) ? 0.0 : 1.0;
+    double lam2d[4];
+#pragma unroll
+    for (int r = 0; r < 4; r++) lam2d[r] = (4 * r + q == c && c < m) ? 2.0 * lam : 0.0;
+
+    int pd_counter = 0, fail = 0;
+    double dJ = 0.0;
+    for (int t = T - 1; t >= 0; t--) {
+        __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc((void *)(R0 + (size_t)t * L.stride), 0, rec_bytes, 0x00020000);
+        pd_counter++;
+        const bool check_pd = pd_counter >= pd_stride;
+        // ---- stage Fz, Fu --------------------------------------------------------------------------
+        for (int i = 0; i < NT; i++) {
+            for (int j = 0; j < NT; j++) lds_store(bufF + (i * NT + j) * TILE, lane, load_Fz(rs, i, j));
+            lds_store(bufFu + i * TILE, lane, load_Fu(rs, i));
+        }
+        __syncthreads();
+        // ---- Tz = V' Fz,  Tu = V' Fu   (V' symmetric: tile (k,i) as Y gives V'[i][k]) -------------------
+        for (int i = 0; i < NT; i++) {
+            for (int j = 0; j < NT; j++) {
+                d4 acc = zero;
+                for (int k = 0; k < NT; k++)
+                    acc = Pn(lds_tile(bufV + (k * NT + i) * TILE, lane), lds_tile(bufF + (k * NT + j) * TILE, lane), acc, nchunk(k));
+                lds_store(bufT + (i * NT + j) * TILE, lane, acc);
+            }
+            d4 acc = zero;
+            for (int k = 0; k < NT; k++)
+                acc = Pn(lds_tile(bufV + (k * NT + i) * TILE, lane), lds_tile(bufFu + k * TILE, lane), acc, nchunk(k));
+            lds_store(bufTu + i * TILE, lane, acc);
+        }
+        __syncthreads();
+        DUMP(0, bufV, NT); DUMP(1, bufT, NT); DUMP(2, bufF, NT);
+        // ---- Quu = l_uu + Fu' Tu ; Quz = Luz + Fu' Tz ; Qzz = Lzz + Fz' Tz (into bufV: V' is dead) ---------
+        d4 Quu = load_Luu(rs);
+        for (int k = 0; k < NT; k++)
+            Quu = Pn(lds_tile(bufFu + k * TILE, lane), lds_tile(bufTu + k * TILE, lane), Quu, nchunk(k));
+        {
+            d4 Qr = Quu;
+            Qr.x += 0.5 * lam2d[0]; Qr.y += 0.5 * lam2d[1]; Qr.z += 0.5 * lam2d[2]; Qr.w += 0.5 * lam2d[3];
+            lds_store(sQ, lane, Qr);
+        }
+        for (int j = 0; j < NT; j++) {
+            d4 acc = load_Luz(rs, j);
+            for (int k = 0; k < NT; k++)
+                acc = Pn(lds_tile(bufFu + k * TILE, lane), lds_tile(bufT + (k * NT + j) * TILE, lane), acc, nchunk(k));
+            lds_store(bufQuz + j * TILE, lane, acc);
+        }
+        for (int i = 0; i < NT; i++)
+            for (int j = 0; j < NT; j++) {
+                d4 acc = load_Lzz(rs, i, j);
+                for (int k = 0; k < NT; k++)
+                    acc = Pn(lds_tile(bufF + (k * NT + i) * TILE, lane), lds_tile(bufT + (k * NT + j) * TILE, lane), acc, nchunk(k));
+                lds_store(bufV + (i * NT + j) * TILE, lane, acc);
+            }
+        __syncthreads();
+        DUMP(3, bufV, NT); DUMP(4, bufQuz, 1);
+        // ---- unpivoted LDL' of Quu + lambda I, redundantly per lane (element (i,j) of the D-layout image) ---
+        auto qel = [&](int i, int j) { return sQ[(i >> 2) * 64 + j + 16 * (i & 3)]; };
+        double Lm[M][M], dd[M], rd[M];
+        bool pos = true;
+#pragma unroll
+        for (int j = 0; j < M; j++) {
+            double w[M];
+            double dj = qel(j, j);
+#pragma unroll
+            for (int kk = 0; kk < j; kk++) { w[kk] = Lm[j][kk] * dd[kk]; dj -= Lm[j][kk] * w[kk]; }
+            dd[j] = dj;
+            pos = pos && (dj > 0.0);
+            const double rj = trcp(dj);
+            rd[j] = rj;
+#pragma unroll
+            for (int i = j + 1; i < M; i++) {
+                double v = qel(i, j);
+#pragma unroll
+                for (int kk = 0; kk < j; kk++) v -= Lm[i][kk] * w[kk];
+                Lm[i][j] = v * rj;
+            }
+        }
+        if (check_pd) {                       // CheckMatrixPD every pd_stride steps   :587-595
+            if (!pos) { fail = t + 1; break; }
+            pd_counter = 0;
+        }
+        double *winv = sRow + 256 + 256;      // explicit inverse of the slow path (column-major m x m)
+        if (!pos) {
+            // indefinite on an unchecked step: Eigen's pivoted LDLT + explicit inverse (iLQR.cpp:597-604)
+            if (lane == 0) {
+                for (int i = 0; i < m; i++) for (int j = 0; j < m; j++) sRow[i * 16 + j] = qel(i, j);
+                tslow_ldlt_inverse(m, sRow, sRow + 256, winv, sRow + 768, (int *)(sRow + 784));
+            }
+            __syncthreads();
+        }
+        // ---- X = (Quu + lambda I)^-1 Quz, column by column; K' = -X out; delta_J -= lambda k'k -----------
+        for (int j = 0; j < NT; j++) {
+            const double *zt = bufQuz + j * TILE;
+            double x[M];
+#pragma unroll
+            for (int i = 0; i < M; i++) x[i] = zt[(i >> 2) * 64 + c + 16 * (i & 3)];
+            if (pos) {
+#pragma unroll
+                for (int jj = 0; jj < M; jj++) {
+#pragma unroll
+                    for (int i = jj + 1; i < M; i++) x[i] -= Lm[i][jj] * x[jj];
+                }
+#pragma unroll
+                for (int i = 0; i < M; i++) x[i] *= rd[i];
+#pragma unroll
+                for (int jj = M - 1; jj >= 0; jj--) {
+#pragma unroll
+                    for (int i = 0; i < jj; i++) x[i] -= Lm[jj][i] * x[jj];
+                }
+            } else {
+                double y[M];
+#pragma unroll
+                for (int i = 0; i < M; i++) {
+                    double sacc = 0.0;
+#pragma unroll
+                    for (int p = 0; p < M; p++) sacc += (-winv[i + p * m]) * x[p];
+                    y[i] = -sacc;
+                }
+#pragma unroll
+                for (int i = 0; i < M; i++) x[i] = y[i];
+            }
+            const int col = 16 * j + c;
+            double xr[4] = {0.0, 0.0, 0.0, 0.0};
+#pragma unroll
+            for (int i = 0; i < M; i++)
+                if (q == (i & 3)) xr[i >> 2] = (col <= n) ? x[i] : 0.0;
+            d4 X = {xr[0], xr[1], xr[2], xr[3]};
+            lds_store(bufX + j * TILE, lane, X);
+            // K (m x n column-major) / k through bounds-checked stores
+            __amdgpu_buffer_rsrc_t rK = __builtin_amdgcn_make_buffer_rsrc((void *)(Kout + ((size_t)b * T + t) * m * n), 0, m * n * 8, 0x00020000);
+            __amdgpu_buffer_rsrc_t rk = __builtin_amdgcn_make_buffer_rsrc((void *)(kout + ((size_t)b * T + t) * m), 0, m * 8, 0x00020000);
+#pragma unroll
+            for (int r = 0; r < NCU; r++) {
+                const int row = 4 * r + q;
+                const double kv = -xr[r];
+                __builtin_amdgcn_raw_buffer_store_b64(__builtin_bit_cast(u32x2t, kv), rK, (row < m && col < n) ? 8 * (row + col * m) : OOBT, 0, 0);
+                __builtin_amdgcn_raw_buffer_store_b64(__builtin_bit_cast(u32x2t, kv), rk, (row < m && col == n) ? 8 * row : OOBT, 0, 0);
+            }
+            if (j == tn) {
+                double kk = 0.0;
+#pragma unroll
+                for (int i = 0; i < M; i++) kk += x[i] * x[i];
+                if (lane_nn) dJ -= lam * kk;      // = k'Q_u + k'Q_uu k  (:612-613), cancellation-free form
+            }
+        }
+        __syncthreads();
+        // ---- G = (Quu + 2 lambda I) K' ;  V' = Qzz + X'G   (= Qzz - K''(Quu + 2 lambda I)K', :606-607) ---------
+        d4 Quu2 = Quu;
+        Quu2.x += lam2d[0]; Quu2.y += lam2d[1]; Quu2.z += lam2d[2]; Quu2.w += lam2d[3];
+        for (int j = 0; j < NT; j++) {
+            const d4 X = lds_tile(bufX + j * TILE, lane);
+            lds_store(bufG + j * TILE, lane, Pn(Quu2, -X, zero, NCU));
+        }
+        __syncthreads();
+        DUMP(5, bufX, 1); DUMP(6, bufG, 1);
+        for (int i = 0; i < NT; i++) {
+            const d4 Xi = lds_tile(bufX + i * TILE, lane);
+            for (int j = 0; j < NT; j++) {
+                double *vt = bufV + (i * NT + j) * TILE;
+                lds_store(vt, lane, Pn(Xi, lds_tile(bufG + j * TILE, lane), lds_tile(vt, lane), NCU));
+            }
+        }
+        __syncthreads();
+        DUMP(7, bufV, NT);
+        // ---- V' = (V' + V'')/2   (:610): tile (i,j) against the transpose of tile (j,i), transposed through
+        //      a padded row-major scratch image (stride 17: conflict-free column reads) -----------------------
+        for (int i = 0; i < NT; i++)
+            for (int j = i; j < NT; j++) {
+                double *tij = bufV + (i * NT + j) * TILE, *tji = bufV + (j * NT + i) * TILE;
+                const d4 a = lds_tile(tij, lane), bb = lds_tile(tji, lane);
+                double *s0 = sRow, *s1 = sRow + 272;
+                s0[(q) * 17 + c] = a.x;  s0[(4 + q) * 17 + c] = a.y;  s0[(8 + q) * 17 + c] = a.z;  s0[(12 + q) * 17 + c] = a.w;
+                s1[(q) * 17 + c] = bb.x; s1[(4 + q) * 17 + c] = bb.y; s1[(8 + q) * 17 + c] = bb.z; s1[(12 + q) * 17 + c] = bb.w;
+                __syncthreads();
+                d4 at, bt;       // at = (tile ji)', bt = (tile ij)'
+                at.x = s1[c * 17 + q]; at.y = s1[c * 17 + 4 + q]; at.z = s1[c * 17 + 8 + q]; at.w = s1[c * 17 + 12 + q];
+                bt.x = s0[c * 17 + q]; bt.y = s0[c * 17 + 4 + q]; bt.z = s0[c * 17 + 8 + q]; bt.w = s0[c * 17 + 12 + q];
+                d4 na = 0.5 * (a + at), nb = 0.5 * (bb + bt);
+                if (i == tn && j == tn) na = na * nn_keep;      // V'(n,n) is a constant nobody reads: keep it 0
+                lds_store(tij, lane, na);
+                if (j != i) lds_store(tji, lane, nb);
+                __syncthreads();
+            }
+        DUMP(8, bufV, NT);
+    }
+    if (lane_nn) delta_J[b] = dJ;
+    if (lane == 0) status[b] = fail;
+}
+
+size_t backward_tiled_lds_bytes(int nt) { return sizeof(double) * ((size_t)(3 * nt * nt + 5 * nt + 1) * TILE + 3 * 256 + 64); }
+
+static int tiled_nt(int n)
+{
+    int nt = (n + 1 + 15) / 16;
+    if (nt < 2) nt = 2;
+    const char *e = getenv("KPILQR_TILED_NT_MIN");      // diagnostic: run with more tiles than needed
+    if (e && atoi(e) > nt) nt = atoi(e);
+    return nt;
+}
+
+bool backward_tiled_supported(int n, int m)
+{
+    const int nt = tiled_nt(n);
+    return nt >= 2 && nt <= 4 && (m == 7 || m == 1) && backward_tiled_lds_bytes(nt) <= 160 * 1024;
+}
+
+template <int M, int NT>
+static hipError_t launch_bt(Ctx *c, int pd_stride)
+{
+    const size_t lds = backward_tiled_lds_bytes(NT);
+    hipError_t e = hipFuncSetAttribute((const void *)k_backward_tiled<M, NT>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    if (e != hipSuccess) return e;
+    hipLaunchKernelGGL((k_backward_tiled<M, NT>), dim3(c->d.batch), dim3(64), lds, c->stream, c->L, c->d.T, c->rec, c->lambda,
+                       pd_stride, c->K, c->k, c->delta_J, c->status);
+    return hipGetLastError();
+}
+
+hipError_t launch_backward_tiled(Ctx *c, int pd_stride)
+{
+    const int nt = tiled_nt(c->n), m = c->d.m;
+    if (m == 7) { if (nt == 2) return launch_bt<7, 2>(c, pd_stride); if (nt == 3) return launch_bt<7, 3>(c, pd_stride); if (nt == 4) return launch_bt<7, 4>(c, pd_stride); }
+    if (m == 1) { if (nt == 2) return launch_bt<1, 2>(c, pd_stride); if (nt == 3) return launch_bt<1, 3>(c, pd_stride); if (nt == 4) return launch_bt<1, 4>(c, pd_stride); }
+    return hipErrorInvalidValue;
+}
+
+}  // namespace kpilqr
