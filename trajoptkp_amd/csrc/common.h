@@ -119,5 +119,7 @@ hipError_t launch_forward_mfma(Ctx *c, double *U_alpha_dev);
 bool backward_tiled_supported(int n, int m);
 hipError_t launch_backward_tiled(Ctx *c, int pd_stride);
 size_t backward_tiled_lds_bytes(int nt);
+bool forward_tiled_supported(int n, int m, int n_alpha);
+hipError_t launch_forward_tiled(Ctx *c, double *U_alpha_dev);
 
 }  // namespace kpilqr

@@ -117,7 +117,8 @@ int kpilqr_create(const kpilqr_dims *dims, void *stream, kpilqr_ctx **out)
     const bool force_tiled = (dims->flags & KPILQR_FLAG_TILED_KERNELS) != 0;
     c->bwd_variant = (!generic && !force_tiled && backward_mfma_supported(c->n, dims->m)) ? "mfma_f64_t1"
                    : (!generic && backward_tiled_supported(c->n, dims->m)) ? "mfma_f64_tiled" : "generic_lds";
-    c->fwd_variant = (!generic && forward_mfma_supported(c->n, dims->m, dims->n_alpha)) ? "mfma_f64_t1" : "generic_lds";
+    c->fwd_variant = (!generic && !force_tiled && forward_mfma_supported(c->n, dims->m, dims->n_alpha)) ? "mfma_f64_t1"
+                   : (!generic && forward_tiled_supported(c->n, dims->m, dims->n_alpha)) ? "mfma_f64_tiled" : "generic_lds";
     if (strcmp(c->bwd_variant, "generic_lds") == 0 && backward_generic_lds_bytes(c->n, dims->m) > 160 * 1024) {
         kpilqr_destroy(c);
         return set_err(nullptr, KPILQR_ERR_ARG, "state dimension too large for the generic backward kernel (LDS)");
@@ -382,6 +383,7 @@ static int ensure_stage(kpilqr_ctx *c, size_t bytes)
 static int run_forward(kpilqr_ctx *c, double *U_dev)
 {
     if (strcmp(c->fwd_variant, "mfma_f64_t1") == 0) KP_HIP(c, launch_forward_mfma(c, U_dev));
+    else if (strcmp(c->fwd_variant, "mfma_f64_tiled") == 0) KP_HIP(c, launch_forward_tiled(c, U_dev));
     else KP_HIP(c, launch_forward_generic(c, U_dev));
     return KPILQR_OK;
 }

@@ -451,4 +451,164 @@ hipError_t launch_backward_tiled(Ctx *c, int pd_stride)
     return hipErrorInvalidValue;
 }
 
+// ---------------------------------------------------------------------------------------------
+// Forward pass (a8).  Z = [dx; alpha; 1] (n+2 rows) x 16 alpha columns is NT row tiles.  One workgroup of
+// NT wavefronts per trajectory: wave i owns row tile i of Z+ and of Lc Z (its column of Ya / Lc tiles goes
+// global -> registers, prefetched one step ahead), every wave forms the (cheap) control law itself, and the
+// Z tiles are exchanged through a double-buffered LDS image with ONE s_barrier per time-step.
+template <int NT>
+__global__ void __launch_bounds__(64 * NT)
+k_forward_tiled(RecLayout L, int T, int n_alpha, const double *__restrict__ rec, const double *__restrict__ Kin,
+                const double *__restrict__ kin, const double *__restrict__ u_nom, const double *__restrict__ ctrl_lim,
+                const double *__restrict__ alphas, double *__restrict__ cost_pred, double *__restrict__ U_alpha)
+{
+    __shared__ __attribute__((aligned(16))) double zbuf[2][NT * TILE];
+    __shared__ double red[NT * 64];
+    const int n = L.n, m = L.m, nz2 = n + 2;
+    const int lane = threadIdx.x & 63, c = lane & 15, q = lane >> 4;
+    const int wi = threadIdx.x >> 6;                 // this wave's row tile
+    const int b = blockIdx.x;
+    const int ncu = (m + 3) >> 2;
+    auto nchunk = [&](int kt) { const int rows = nz2 - 16 * kt; return rows >= 16 ? 4 : (rows + 3) / 4; };
+
+    // per-lane source byte offsets (OOBT = structural zero); p = contraction (state) index, o = output index
+    int oK[NT][4], ok_[NT][4], oA[NT][4], oLc[NT][4], oB[4], oLuu[4], olu[4], oub[4];
+    double oneA[NT][4], lo[4], hi[4];
+    const int o = 16 * wi + c;
+#pragma unroll
+    for (int k = 0; k < NT; k++)
+#pragma unroll
+        for (int r = 0; r < 4; r++) {
+            const int pp = 16 * k + 4 * r + q;
+            oK[k][r] = (pp < n && c < m) ? 8 * (pp * m + c) : OOBT;
+            ok_[k][r] = (pp == n && c < m) ? 8 * c : OOBT;
+            oA[k][r] = (pp < n && o < n) ? 8 * (L.off_A + o * n + pp) : OOBT;
+            oneA[k][r] = ((pp == n && o == n) || (pp == n + 1 && o == n + 1)) ? 1.0 : 0.0;
+            oLc[k][r] = (pp < n && o < n) ? 8 * (L.off_lxx + pp * n + o)
+                      : (pp == n + 1 && o < n) ? 8 * (L.off_lx + o)
+                      : (o == n + 1 && pp < n) ? 8 * (L.off_lx + pp) : OOBT;
+        }
+#pragma unroll
+    for (int r = 0; r < 4; r++) {
+        const int row = 4 * r + q;
+        oB[r] = (row < m && o < n) ? 8 * (L.off_B + o * m + row) : OOBT;
+        oLuu[r] = (row < m && c < m) ? 8 * (L.off_luu + row * m + c) : OOBT;
+        olu[r] = (row < m) ? 8 * (L.off_lu + row) : OOBT;
+        oub[r] = (row < m) ? 8 * row : OOBT;
+        lo[r] = (row < m) ? ctrl_lim[2 * row] : -1.0e300;
+        hi[r] = (row < m) ? ctrl_lim[2 * row + 1] : 1.0e300;
+    }
+    const double my_alpha = (c < n_alpha) ? alphas[c] : 0.0;
+    {
+        double zr[4];
+#pragma unroll
+        for (int r = 0; r < 4; r++) {
+            const int row = 16 * wi + 4 * r + q;
+            zr[r] = (row == n) ? my_alpha : (row == n + 1) ? 1.0 : 0.0;
+        }
+        d4 Z0 = {zr[0], zr[1], zr[2], zr[3]};
+        lds_store(zbuf[0] + wi * TILE, lane, Z0);
+    }
+    const d4 zero = {0.0, 0.0, 0.0, 0.0};
+    double partial = 0.0;
+
+    struct Tiles { d4 YkK[NT], Ykk[NT], Ya[NT], Lc[NT], Yb, Luu, lu, ub; };
+    const int rec_bytes = L.rec * 8;
+    auto ld4 = [&](__amdgpu_buffer_rsrc_t rs, const int *off) -> d4 {
+        d4 v; v.x = tbld(rs, off[0]); v.y = tbld(rs, off[1]); v.z = tbld(rs, off[2]); v.w = tbld(rs, off[3]);
+        return v;
+    };
+    auto load_tiles = [&](int t, Tiles &s) {
+        __amdgpu_buffer_rsrc_t rR = __builtin_amdgcn_make_buffer_rsrc((void *)(rec + ((size_t)b * T + t) * L.stride), 0, rec_bytes, 0x00020000);
+        __amdgpu_buffer_rsrc_t rK = __builtin_amdgcn_make_buffer_rsrc((void *)(Kin + ((size_t)b * T + t) * m * n), 0, m * n * 8, 0x00020000);
+        __amdgpu_buffer_rsrc_t rk = __builtin_amdgcn_make_buffer_rsrc((void *)(kin + ((size_t)b * T + t) * m), 0, m * 8, 0x00020000);
+        __amdgpu_buffer_rsrc_t ru = __builtin_amdgcn_make_buffer_rsrc((void *)(u_nom + ((size_t)b * T + t) * m), 0, m * 8, 0x00020000);
+#pragma unroll
+        for (int k = 0; k < NT; k++) {
+            s.YkK[k] = ld4(rK, oK[k]); s.Ykk[k] = ld4(rk, ok_[k]);
+            s.Ya[k] = ld4(rR, oA[k]);  s.Lc[k] = ld4(rR, oLc[k]);
+        }
+        s.Yb = ld4(rR, oB); s.Luu = ld4(rR, oLuu); s.lu = ld4(rR, olu); s.ub = ld4(ru, oub);
+    };
+    Tiles nxt;
+    load_tiles(0, nxt);
+    __syncthreads();
+
+    for (int t = 0; t < T; t++) {
+        const Tiles cur = nxt;
+        if (t + 1 < T) load_tiles(t + 1, nxt);
+        __builtin_amdgcn_sched_barrier(0);     // keep the prefetch AHEAD of this step's compute
+        const double *zc = zbuf[t & 1];
+        double *zn = zbuf[(t + 1) & 1];
+        d4 Zk[NT];
+#pragma unroll
+        for (int k = 0; k < NT; k++) Zk[k] = lds_tile(zc + k * TILE, lane);
+        const d4 Zi = lds_tile(zc + wi * TILE, lane);
+        // control law + clamp (every wave; :876-890)
+        d4 U = cur.ub;
+#pragma unroll
+        for (int k = 0; k < NT; k++) U = Pn(cur.YkK[k] + cur.Ykk[k], Zk[k], U, nchunk(k));
+        d4 dU;
+        {
+            double u;
+            u = U.x; if (u > hi[0]) u = hi[0]; if (u < lo[0]) u = lo[0]; U.x = u; dU.x = u - cur.ub.x;
+            u = U.y; if (u > hi[1]) u = hi[1]; if (u < lo[1]) u = lo[1]; U.y = u; dU.y = u - cur.ub.y;
+            u = U.z; if (u > hi[2]) u = hi[2]; if (u < lo[2]) u = lo[2]; U.z = u; dU.z = u - cur.ub.z;
+            u = U.w; if (u > hi[3]) u = hi[3]; if (u < lo[3]) u = lo[3]; U.w = u; dU.w = u - cur.ub.w;
+        }
+        if (wi == 0) {
+            if (U_alpha && c < n_alpha) {
+                double *Ua = U_alpha + (((size_t)b * n_alpha + c) * T + t) * m;
+                const double uv[4] = {U.x, U.y, U.z, U.w};
+#pragma unroll
+                for (int r = 0; r < 4; r++) { const int row = 4 * r + q; if (row < m) Ua[row] = uv[r]; }
+            }
+            const d4 Wu = Pn(cur.Luu, dU, zero, ncu);
+            partial += dU.x * (0.5 * Wu.x + cur.lu.x) + dU.y * (0.5 * Wu.y + cur.lu.y)
+                     + dU.z * (0.5 * Wu.z + cur.lu.z) + dU.w * (0.5 * Wu.w + cur.lu.w);
+        }
+        // state cost rows of this tile, then the linearised dynamics for this tile
+        d4 Wz = zero, Zn = zero;
+#pragma unroll
+        for (int k = 0; k < NT; k++) Wz = Pn(cur.Lc[k], Zk[k], Wz, nchunk(k));
+        partial += 0.5 * (Zi.x * Wz.x + Zi.y * Wz.y + Zi.z * Wz.z + Zi.w * Wz.w);
+#pragma unroll
+        for (int k = 0; k < NT; k++) {
+            d4 Ya = cur.Ya[k];
+            Ya.x += oneA[k][0]; Ya.y += oneA[k][1]; Ya.z += oneA[k][2]; Ya.w += oneA[k][3];
+            Zn = Pn(Ya, Zk[k], Zn, nchunk(k));
+        }
+        Zn = Pn(cur.Yb, dU, Zn, ncu);
+        lds_store(zn + wi * TILE, lane, Zn);
+        __syncthreads();
+    }
+    // column sums: over the q lane groups, then over the waves (fixed order: reproducible)
+    partial += __shfl_xor(partial, 16);
+    partial += __shfl_xor(partial, 32);
+    red[wi * 64 + lane] = partial;
+    __syncthreads();
+    if (wi == 0 && q == 0 && c < n_alpha) {
+        double sum = 0.0;
+        for (int w = 0; w < NT; w++) sum += red[w * 64 + lane];
+        cost_pred[(size_t)b * n_alpha + c] = sum;
+    }
+}
+
+bool forward_tiled_supported(int n, int m, int n_alpha)
+{
+    const int nt = tiled_nt(n);
+    return nt >= 2 && nt <= 4 && m <= 16 && n_alpha <= 16;
+}
+
+hipError_t launch_forward_tiled(Ctx *c, double *U_alpha_dev)
+{
+    const int nt = tiled_nt(c->n);
+#define LAUNCH_FT(NT)                                                                                               \
+    hipLaunchKernelGGL((k_forward_tiled<NT>), dim3(c->d.batch), dim3(64 * NT), 0, c->stream, c->L, c->d.T,        \
+                       c->d.n_alpha, c->rec, c->K, c->k, c->u_nom, c->ctrl_lim, c->alphas, c->cost_pred, U_alpha_dev)
+    if (nt == 2) LAUNCH_FT(2); else if (nt == 3) LAUNCH_FT(3); else if (nt == 4) LAUNCH_FT(4); else return hipErrorInvalidValue;
+#undef LAUNCH_FT
+    return hipGetLastError();
+}
+
 }  // namespace kpilqr
