@@ -415,6 +415,330 @@ k_backward_tiled(RecLayout L, int T, const double *__restrict__ rec, const doubl
     if (lane == 0) status[b] = fail;
 }
 
+
+// ---------------------------------------------------------------------------------------------
+// Backward pass, W wavefronts per trajectory (small batches: one trajectory spreads over the SIMDs of a CU).
+// Same algebra and LDS images as k_backward_tiled; every phase's OUTPUT TILES are dealt round-robin to the
+// waves (item e -> wave e % W, register slot e / W) and the phases are separated by s_barrier:
+//   A  prefetched Fz/Fu tiles of step t: registers -> LDS                               | barrier
+//   B  Tz(i,j) = sum_k V'(k,i)' Fz(k,j),  Tu(i)                                          | barrier
+//   C  Quu, Quz(j), Qzz(i,j) (Qzz stays in the owner's registers); issue step t-1 loads  | barrier
+//   D  LDL' of Quu + lambda I in every wave (redundant, keeps the PD verdict block-uniform),
+//      solve + K/k stores + G(j) by the owner of column tile j                           | barrier
+//   E  acc(i,j) = Qzz(i,j) + X_i' G_j -> bufT (Tz is dead)                               | barrier
+//   F  V'(i,j) = (acc(i,j) + acc(j,i)')/2 -> bufV   (transposed LDS read of the partner tile)
+struct TileSrc { int n, m; int off_A, off_B, off_lxx, off_lx, off_luu, off_lu; };
+
+__device__ __forceinline__ d4 ld_Lzz(__amdgpu_buffer_rsrc_t rs, const TileSrc &S, int ti, int tj, int q, int c)
+{
+    double v[4];
+#pragma unroll
+    for (int r = 0; r < 4; r++) {
+        const int row = 16 * ti + 4 * r + q, col = 16 * tj + c, n = S.n;
+        const int off = (row < n && col < n) ? 8 * (S.off_lxx + row * n + col)
+                      : (col == n && row < n) ? 8 * (S.off_lx + row)
+                      : (row == n && col < n) ? 8 * (S.off_lx + col) : OOBT;
+        v[r] = tbld(rs, off);
+    }
+    d4 o = {v[0], v[1], v[2], v[3]};
+    return o;
+}
+__device__ __forceinline__ d4 ld_Fz(__amdgpu_buffer_rsrc_t rs, const TileSrc &S, int ti, int tj, int q, int c)
+{
+    double v[4];
+#pragma unroll
+    for (int r = 0; r < 4; r++) {
+        const int row = 16 * ti + 4 * r + q, col = 16 * tj + c, n = S.n;
+        v[r] = tbld(rs, (row < n && col < n) ? 8 * (S.off_A + row * n + col) : OOBT);
+    }
+    d4 o = {v[0], v[1], v[2], v[3]};
+    return o;
+}
+__device__ __forceinline__ d4 ld_Fu(__amdgpu_buffer_rsrc_t rs, const TileSrc &S, int ti, int q, int c)
+{
+    double v[4];
+#pragma unroll
+    for (int r = 0; r < 4; r++) {
+        const int row = 16 * ti + 4 * r + q;
+        v[r] = tbld(rs, (row < S.n && c < S.m) ? 8 * (S.off_B + row * S.m + c) : OOBT);
+    }
+    d4 o = {v[0], v[1], v[2], v[3]};
+    return o;
+}
+__device__ __forceinline__ d4 ld_Luz(__amdgpu_buffer_rsrc_t rs, const TileSrc &S, int tj, int q, int c)
+{
+    double v[4];
+#pragma unroll
+    for (int r = 0; r < 4; r++) {
+        const int row = 4 * r + q, col = 16 * tj + c;
+        v[r] = tbld(rs, (row < S.m && col == S.n) ? 8 * (S.off_lu + row) : OOBT);
+    }
+    d4 o = {v[0], v[1], v[2], v[3]};
+    return o;
+}
+__device__ __forceinline__ d4 ld_Luu(__amdgpu_buffer_rsrc_t rs, const TileSrc &S, int q, int c)
+{
+    double v[4];
+#pragma unroll
+    for (int r = 0; r < 4; r++) {
+        const int row = 4 * r + q;
+        v[r] = tbld(rs, (row < S.m && c < S.m) ? 8 * (S.off_luu + row * S.m + c) : OOBT);
+    }
+    d4 o = {v[0], v[1], v[2], v[3]};
+    return o;
+}
+
+template <int M, int NT, int W>
+__global__ void __launch_bounds__(64 * W)
+k_backward_tiled_mw(RecLayout L, int T, const double *__restrict__ rec, const double *__restrict__ lambda,
+                    int pd_stride, double *__restrict__ Kout, double *__restrict__ kout,
+                    double *__restrict__ delta_J, int *__restrict__ status)
+{
+    extern __shared__ __attribute__((aligned(16))) double sh[];
+    constexpr int NCU = (M + 3) / 4;
+    constexpr int NZZ = NT * NT;                     // Fz / Tz / Qzz items
+    constexpr int SL = (NZZ + W - 1) / W;            // register slots per wave for the NT x NT item families
+    constexpr int SN = (NT + W - 1) / W;             // slots for the NT item families (deal starts at wave 0)
+    const int n = L.n, m = M, nz = n + 1;
+    const int lane = threadIdx.x & 63, c = lane & 15, q = lane >> 4;
+    const int w = threadIdx.x >> 6;
+    const int b = blockIdx.x;
+    const double lam = lambda[b];
+    double *bufV = sh;
+    double *bufF = bufV + NZZ * TILE;
+    double *bufT = bufF + NZZ * TILE;
+    double *bufFu = bufT + NZZ * TILE;
+    double *bufTu = bufFu + NT * TILE;
+    double *bufQuz = bufTu + NT * TILE;
+    double *bufX = bufQuz + NT * TILE;
+    double *bufG = bufX + NT * TILE;
+    double *sQ = bufG + NT * TILE;
+    double *sRow = sQ + TILE;
+    auto nchunk = [&](int kt) { const int rows = nz - 16 * kt; return rows >= 16 ? 4 : (rows + 3) / 4; };
+    TileSrc S = {n, m, L.off_A, L.off_B, L.off_lxx, L.off_lx, L.off_luu, L.off_lu};
+
+    const double *R0 = rec + (size_t)b * T * L.stride;
+    const int rec_bytes = L.rec * 8;
+    const d4 zero = {0.0, 0.0, 0.0, 0.0};
+    const int tn = n >> 4, cn = n & 15;
+    const bool lane_nn = (c == cn) && (q == (cn & 3));
+    const int reg_nn = cn >> 2;
+    d4 nn_keep;
+    nn_keep.x = (lane_nn && reg_nn == 0) ? 0.0 : 1.0; nn_keep.y = (lane_nn && reg_nn == 1) ? 0.0 : 1.0;
+    nn_keep.z = (lane_nn && reg_nn == 2) ? 0.0 : 1.0; nn_keep.w = (lane_nn && reg_nn == 3) ? 0.0 : 1.0;
+    double lam2d[4];
+#pragma unroll
+    for (int r = 0; r < 4; r++) lam2d[r] = (4 * r + q == c && c < m) ? 2.0 * lam : 0.0;
+    // owners of the single / NT-family items
+    constexpr int W_QUU = NT % W;                    // Quu after the NT Quz items
+    // prefetched source tiles of one step
+    d4 pF[SL], pL[SL], pFu[SN], pLuz[SN], pLuu;
+    auto prefetch = [&](int t) {
+        __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc((void *)(R0 + (size_t)t * L.stride), 0, rec_bytes, 0x00020000);
+#pragma unroll
+        for (int e = 0; e < NZZ; e++)
+            if (e % W == w) { pF[e / W] = ld_Fz(rs, S, e / NT, e % NT, q, c); pL[e / W] = ld_Lzz(rs, S, e / NT, e % NT, q, c); }
+#pragma unroll
+        for (int e = 0; e < NT; e++)
+            if (e % W == w) { pFu[e / W] = ld_Fu(rs, S, e, q, c); pLuz[e / W] = ld_Luz(rs, S, e, q, c); }
+        if (w == W_QUU) pLuu = ld_Luu(rs, S, q, c);
+    };
+
+    // V' <- Lzz(T-1)   (iLQR.cpp:537-539); then the tiles of step T-1 itself
+    prefetch(T - 1);
+#pragma unroll
+    for (int e = 0; e < NZZ; e++)
+        if (e % W == w) lds_store(bufV + e * TILE, lane, pL[e / W]);
+
+    int pd_counter = 0, fail = 0;
+    double dJ = 0.0;
+    for (int t = T - 1; t >= 0; t--) {
+        pd_counter++;
+        const bool check_pd = pd_counter >= pd_stride;
+        // ---- A: stage Fz (+ the homogeneous 1), Fu ---------------------------------------------------------
+#pragma unroll
+        for (int e = 0; e < NZZ; e++)
+            if (e % W == w) {
+                d4 f = pF[e / W];
+                if (e / NT == e % NT && e / NT == tn) f = f + (1.0 - nn_keep);       // Fz(n,n) = 1
+                lds_store(bufF + e * TILE, lane, f);
+            }
+#pragma unroll
+        for (int e = 0; e < NT; e++)
+            if (e % W == w) lds_store(bufFu + e * TILE, lane, pFu[e / W]);
+        __syncthreads();
+        // ---- B: Tz = V' Fz, Tu = V' Fu ------------------------------------------------------------------
+#pragma unroll
+        for (int e = 0; e < NZZ; e++)
+            if (e % W == w) {
+                const int i = e / NT, j = e % NT;
+                d4 acc = zero;
+#pragma unroll
+                for (int k = 0; k < NT; k++)
+                    acc = Pn(lds_tile(bufV + (k * NT + i) * TILE, lane), lds_tile(bufF + (k * NT + j) * TILE, lane), acc, nchunk(k));
+                lds_store(bufT + e * TILE, lane, acc);
+            }
+#pragma unroll
+        for (int e = 0; e < NT; e++)
+            if ((NZZ + e) % W == w) {
+                d4 acc = zero;
+#pragma unroll
+                for (int k = 0; k < NT; k++)
+                    acc = Pn(lds_tile(bufV + (k * NT + e) * TILE, lane), lds_tile(bufFu + k * TILE, lane), acc, nchunk(k));
+                lds_store(bufTu + e * TILE, lane, acc);
+            }
+        __syncthreads();
+        // ---- C: Quu, Quz, Qzz -----------------------------------------------------------------------------
+        if (w == W_QUU) {
+            d4 Quu = pLuu;
+#pragma unroll
+            for (int k = 0; k < NT; k++)
+                Quu = Pn(lds_tile(bufFu + k * TILE, lane), lds_tile(bufTu + k * TILE, lane), Quu, nchunk(k));
+            Quu.x += 0.5 * lam2d[0]; Quu.y += 0.5 * lam2d[1]; Quu.z += 0.5 * lam2d[2]; Quu.w += 0.5 * lam2d[3];
+            lds_store(sQ, lane, Quu);                 // Quu + lambda I
+        }
+#pragma unroll
+        for (int e = 0; e < NT; e++)
+            if (e % W == w) {
+                d4 acc = pLuz[e / W];
+#pragma unroll
+                for (int k = 0; k < NT; k++)
+                    acc = Pn(lds_tile(bufFu + k * TILE, lane), lds_tile(bufT + (k * NT + e) * TILE, lane), acc, nchunk(k));
+                lds_store(bufQuz + e * TILE, lane, acc);
+            }
+        d4 Qzz[SL];
+#pragma unroll
+        for (int e = 0; e < NZZ; e++)
+            if (e % W == w) {
+                const int i = e / NT, j = e % NT;
+                d4 acc = pL[e / W];
+#pragma unroll
+                for (int k = 0; k < NT; k++)
+                    acc = Pn(lds_tile(bufF + (k * NT + i) * TILE, lane), lds_tile(bufT + (k * NT + j) * TILE, lane), acc, nchunk(k));
+                Qzz[e / W] = acc;
+            }
+        if (t > 0) prefetch(t - 1);                   // in flight behind phases D-F
+        __syncthreads();
+        // ---- D: LDL' (every wave), solve / K / G (owner of column tile j) ------------------------------------
+        auto qel = [&](int i, int j) { return sQ[(i >> 2) * 64 + j + 16 * (i & 3)]; };
+        double Lm[M][M], dd[M], rd[M];
+        bool pos = true;
+#pragma unroll
+        for (int j = 0; j < M; j++) {
+            double ww[M];
+            double dj = qel(j, j);
+#pragma unroll
+            for (int kk = 0; kk < j; kk++) { ww[kk] = Lm[j][kk] * dd[kk]; dj -= Lm[j][kk] * ww[kk]; }
+            dd[j] = dj;
+            pos = pos && (dj > 0.0);
+            const double rj = trcp(dj);
+            rd[j] = rj;
+#pragma unroll
+            for (int i = j + 1; i < M; i++) {
+                double v = qel(i, j);
+#pragma unroll
+                for (int kk = 0; kk < j; kk++) v -= Lm[i][kk] * ww[kk];
+                Lm[i][j] = v * rj;
+            }
+        }
+        if (check_pd) {                       // CheckMatrixPD every pd_stride steps   :587-595
+            if (!pos) { fail = t + 1; break; }          // block-uniform: every wave factored the same Quu
+            pd_counter = 0;
+        }
+        double *winv = sRow + 256 + 256;
+        if (!pos) {
+            if (threadIdx.x == 0) {
+                for (int i = 0; i < m; i++) for (int j = 0; j < m; j++) sRow[i * 16 + j] = qel(i, j);
+                tslow_ldlt_inverse(m, sRow, sRow + 256, winv, sRow + 768, (int *)(sRow + 784));
+            }
+            __syncthreads();
+        }
+        d4 Quu2 = lds_tile(sQ, lane);
+        Quu2.x += 0.5 * lam2d[0]; Quu2.y += 0.5 * lam2d[1]; Quu2.z += 0.5 * lam2d[2]; Quu2.w += 0.5 * lam2d[3];
+#pragma unroll
+        for (int j = 0; j < NT; j++)
+            if (j % W == w) {
+                const double *zt = bufQuz + j * TILE;
+                double x[M];
+#pragma unroll
+                for (int i = 0; i < M; i++) x[i] = zt[(i >> 2) * 64 + c + 16 * (i & 3)];
+                if (pos) {
+#pragma unroll
+                    for (int jj = 0; jj < M; jj++) {
+#pragma unroll
+                        for (int i = jj + 1; i < M; i++) x[i] -= Lm[i][jj] * x[jj];
+                    }
+#pragma unroll
+                    for (int i = 0; i < M; i++) x[i] *= rd[i];
+#pragma unroll
+                    for (int jj = M - 1; jj >= 0; jj--) {
+#pragma unroll
+                        for (int i = 0; i < jj; i++) x[i] -= Lm[jj][i] * x[jj];
+                    }
+                } else {
+                    double y[M];
+#pragma unroll
+                    for (int i = 0; i < M; i++) {
+                        double sacc = 0.0;
+#pragma unroll
+                        for (int pp = 0; pp < M; pp++) sacc += (-winv[i + pp * m]) * x[pp];
+                        y[i] = -sacc;
+                    }
+#pragma unroll
+                    for (int i = 0; i < M; i++) x[i] = y[i];
+                }
+                const int col = 16 * j + c;
+                double xr[4] = {0.0, 0.0, 0.0, 0.0};
+#pragma unroll
+                for (int i = 0; i < M; i++)
+                    if (q == (i & 3)) xr[i >> 2] = (col <= n) ? x[i] : 0.0;
+                d4 X = {xr[0], xr[1], xr[2], xr[3]};
+                lds_store(bufX + j * TILE, lane, X);
+                __amdgpu_buffer_rsrc_t rK = __builtin_amdgcn_make_buffer_rsrc((void *)(Kout + ((size_t)b * T + t) * m * n), 0, m * n * 8, 0x00020000);
+                __amdgpu_buffer_rsrc_t rk = __builtin_amdgcn_make_buffer_rsrc((void *)(kout + ((size_t)b * T + t) * m), 0, m * 8, 0x00020000);
+#pragma unroll
+                for (int r = 0; r < NCU; r++) {
+                    const int row = 4 * r + q;
+                    const double kv = -xr[r];
+                    __builtin_amdgcn_raw_buffer_store_b64(__builtin_bit_cast(u32x2t, kv), rK, (row < m && col < n) ? 8 * (row + col * m) : OOBT, 0, 0);
+                    __builtin_amdgcn_raw_buffer_store_b64(__builtin_bit_cast(u32x2t, kv), rk, (row < m && col == n) ? 8 * row : OOBT, 0, 0);
+                }
+                if (j == tn) {
+                    double kk = 0.0;
+#pragma unroll
+                    for (int i = 0; i < M; i++) kk += x[i] * x[i];
+                    if (lane_nn) dJ -= lam * kk;
+                }
+                lds_store(bufG + j * TILE, lane, Pn(Quu2, -X, zero, NCU));   // G = (Quu + 2 lambda I) K'
+            }
+        __syncthreads();
+        // ---- E: acc = Qzz + X'G -> bufT ---------------------------------------------------------------------
+#pragma unroll
+        for (int e = 0; e < NZZ; e++)
+            if (e % W == w) {
+                const int i = e / NT, j = e % NT;
+                Qzz[e / W] = Pn(lds_tile(bufX + i * TILE, lane), lds_tile(bufG + j * TILE, lane), Qzz[e / W], NCU);
+                lds_store(bufT + e * TILE, lane, Qzz[e / W]);
+            }
+        __syncthreads();
+        // ---- F: V'(i,j) = (acc(i,j) + acc(j,i)')/2   (:610) --------------------------------------------------
+#pragma unroll
+        for (int e = 0; e < NZZ; e++)
+            if (e % W == w) {
+                const int i = e / NT, j = e % NT;
+                const double *pt = bufT + (j * NT + i) * TILE + (c >> 2) * 64 + (c & 3) * 16 + q;   // (tile ji)'
+                d4 at;
+                at.x = pt[0]; at.y = pt[4]; at.z = pt[8]; at.w = pt[12];
+                d4 na = 0.5 * (Qzz[e / W] + at);
+                if (i == tn && j == tn) na = na * nn_keep;
+                lds_store(bufV + e * TILE, lane, na);
+            }
+        // (the barrier after the next step's phase A orders these stores before phase B reads them)
+    }
+    if (w == tn % W && lane_nn) delta_J[b] = dJ;
+    if (threadIdx.x == 0) status[b] = fail;
+}
+
 size_t backward_tiled_lds_bytes(int nt) { return sizeof(double) * ((size_t)(3 * nt * nt + 5 * nt + 1) * TILE + 3 * 256 + 64); }
 
 static int tiled_nt(int n)
@@ -432,10 +756,26 @@ bool backward_tiled_supported(int n, int m)
     return nt >= 2 && nt <= 4 && (m == 7 || m == 1) && backward_tiled_lds_bytes(nt) <= 160 * 1024;
 }
 
+// Below this many trajectories per SIMD-quad the multi-wave kernel (4 waves per trajectory) is used.
+static bool use_multiwave(const Ctx *c)
+{
+    const char *e = getenv("KPILQR_TILED_WAVES");       // diagnostic: 1 = force single-wave, 4 = force multi-wave
+    if (e && atoi(e) == 1) return false;
+    if (e && atoi(e) == 4) return true;
+    return c->d.batch * 4 <= c->n_simd;
+}
+
 template <int M, int NT>
 static hipError_t launch_bt(Ctx *c, int pd_stride)
 {
     const size_t lds = backward_tiled_lds_bytes(NT);
+    if (use_multiwave(c)) {
+        hipError_t e = hipFuncSetAttribute((const void *)k_backward_tiled_mw<M, NT, 4>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        if (e != hipSuccess) return e;
+        hipLaunchKernelGGL((k_backward_tiled_mw<M, NT, 4>), dim3(c->d.batch), dim3(256), lds, c->stream, c->L, c->d.T, c->rec,
+                           c->lambda, pd_stride, c->K, c->k, c->delta_J, c->status);
+        return hipGetLastError();
+    }
     hipError_t e = hipFuncSetAttribute((const void *)k_backward_tiled<M, NT>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     if (e != hipSuccess) return e;
     hipLaunchKernelGGL((k_backward_tiled<M, NT>), dim3(c->d.batch), dim3(64), lds, c->stream, c->L, c->d.T, c->rec, c->lambda,
