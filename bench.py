@@ -81,6 +81,8 @@ def main():
     ap.add_argument("--task", default="panda_reaching")
     ap.add_argument("--unique", type=int, default=8, help="distinct seeded trajectories, tiled to --batch")
     ap.add_argument("--generic", action="store_true", help="force the generic (non-MFMA) kernels")
+    ap.add_argument("--fused", action="store_true",
+                    help="KPILQR_FLAG_FUSED: interpolation (a4) and cost derivatives (a6) evaluated inside the sweeps")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     args = ap.parse_args()
 
@@ -116,15 +118,24 @@ def main():
     stream = torch.cuda.Stream()
     torch.cuda.set_stream(stream)
     eng = Engine(p["dof"], p["m"], T, p["nr"], batch=B, device=local_rank, stream=stream.cuda_stream,
-                 generic=args.generic)
+                 generic=args.generic, fused=args.fused)
+    fused = "fused" in eng.backward_variant
     synth.upload(eng, p)
     lam = np.full(B, p["lam"])
     alphas = np.array([(i / 6.0) ** 2 for i in range(1, 7)])
+    eng.fd_difference()
     eng.backward(lam, 100, fetch=False)               # uploads lambda / alphas once
     eng.forward_linear(alphas, fetch=False)
     eng.sync()
     Kp = len(p["kp_times"])
     ab = algorithmic_bytes(p["dof"], p["m"], p["nr"], T, Kp, 6)
+    if fused:
+        # compulsory I/O of the fused sweeps: key-point columns + residuals/Jacobians in, gains out (backward);
+        # the same plus gains and nominal controls in (forward)
+        n_, m_, nr_ = p["n"], p["m"], p["nr"]
+        src = 8 * (Kp * (n_ * n_ + n_ * m_) + T * nr_ * (1 + n_ + m_))
+        ab_fused = dict(fd_difference=ab["fd_difference"], backward=src + 8 * T * (m_ * n_ + m_),
+                        forward=src + 8 * T * (m_ * n_ + m_ + m_) + 8 * 6)
 
     # line-search cost reduction across GPUs: [sum_b J_pred(alpha_1..6), sum_b delta_J, #valid] (8 doubles)
     from trajoptkp_amd import distributed as kd
@@ -132,7 +143,8 @@ def main():
     dJ_view = torch.as_tensor(eng.device_array(10, (B,)), device="cuda")          # KPILQR_BUF_DELTA_J
     st_view = torch.as_tensor(eng.device_array(11, (B,), "<i4"), device="cuda")   # KPILQR_BUF_STATUS
 
-    stages = ("fd_difference", "interpolate", "cost_derivs", "backward", "forward")
+    stages = ("fd_difference", "backward", "forward") if fused else \
+             ("fd_difference", "interpolate", "cost_derivs", "backward", "forward")
 
     def one_step(events=None):
         for i, name in enumerate(stages):
@@ -185,10 +197,11 @@ def main():
             pmc = json.load(open(os.path.join(ROOT, "profiles", "r01_pmc_traffic.json")))
             wl = pmc["workload"]
             if wl["task"] == args.task and wl["T"] == T and wl["batch"] == B and not args.generic:
-                traffic = pmc["kernels"][dom]["traffic_bytes"]
+                traffic = pmc["kernels"]["backward_fused" if fused else dom]["traffic_bytes"]
         except Exception:
             traffic = None
-        achieved = ab[dom] * B / (stage_ms[dom] * 1e-3) / 1e9
+        kb = ab_fused if fused else ab          # bytes each launched kernel must move
+        achieved = kb[dom] * B / (stage_ms[dom] * 1e-3) / 1e9
         out = {
             "metric": "iLQR iterations/sec (Panda 7-DoF, T=3000)" if args.task == "panda_reaching" and T == 3000
                       else f"iLQR iterations/sec ({args.task}, T={T})",
@@ -196,17 +209,18 @@ def main():
             "warmup": args.warmup, "ms_per_step": 1e3 * elapsed / args.steps, "higher_is_better": True,
             "scaling": "weak", "vs_baseline": None, "dtype": "f64", "data": "synthetic",
             "config": {"workload": f"{args.task} T={T} set_interval({args.min_N}) keypoints={Kp} "
-                                   f"batch={B}/GPU ({uniq} distinct seeds tiled), 6 alphas, lambda={p['lam']}",
+                                   f"batch={B}/GPU ({uniq} distinct seeds tiled), 6 alphas, lambda={p['lam']}"
+                                   + (", fused sweeps (a4+a6 inside a7/a8)" if fused else ""),
                        "batch_per_gpu": B, "global_batch": total_traj, "horizon": T,
                        "kernels": {"backward": eng.backward_variant, "forward": eng.forward_variant},
                        "valid_backward_passes": n_ok, "parallelism": f"traj-shard x{world}"},
             "batch_iterations_per_s": args.steps / elapsed,
             "stage_ms": stage_ms,
-            "stage_algorithmic_GBps": {k: ab[k] * B / (stage_ms[k] * 1e-3) / 1e9 for k in stages},
+            "stage_algorithmic_GBps": {k: kb[k] * B / (stage_ms[k] * 1e-3) / 1e9 for k in stages},
             "pipeline_algorithmic_GBps": sum(ab.values()) * B / (elapsed / args.steps) / 1e9,
             "roofline": {"bound": "hbm", "kernel": f"backward ({eng.backward_variant})", "achieved": achieved,
                          "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
-                         "algorithmic_bytes_per_launch": ab[dom] * B, "avg_launch_ms": stage_ms[dom]},
+                         "algorithmic_bytes_per_launch": kb[dom] * B, "avg_launch_ms": stage_ms[dom]},
         }
         if world == 1 and not args.no_cpu_baseline:
             try:

@@ -48,6 +48,13 @@ typedef struct {
 
 #define KPILQR_FLAG_GENERIC_KERNELS 1   /* force the dimension-generic LDS kernels (no MFMA path) */
 #define KPILQR_FLAG_TILED_KERNELS   2   /* prefer the LDS-tiled MFMA kernels even when one tile would do */
+#define KPILQR_FLAG_FUSED           4   /* n+2 <= 16 only: kpilqr_backward / kpilqr_forward_linear / kpilqr_iterate
+                                           evaluate the interpolation (a4) and the cost derivatives (a6) inside the
+                                           sweeps, from the key-point columns written by kpilqr_fd_difference and the
+                                           uploaded residuals; A, B, l_* are then NOT materialised for every step
+                                           (kpilqr_interpolate / kpilqr_cost_derivs still do that on request, and the
+                                           set_AB / set_cost_derivs hooks do not feed the fused sweeps).  Needs
+                                           canonical key-points: per DoF strictly increasing, first 0, last T-1. */
 
 enum {
     KPILQR_OK = 0,

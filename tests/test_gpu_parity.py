@@ -376,3 +376,108 @@ def test_tiled_mfma_large_state(task, T, batch, waves, monkeypatch):
         assert relerr(g["k"][b], o["k"]) < K_RTOL_TIGHT
         assert abs(g["delta_J"][b] - o["delta_J"]) <= 1e-9 * abs(o["delta_J"])
         assert relerr(g["cost_pred"][b], o["cost_pred"]) < 1e-9
+
+
+# ---- fused sweeps (KPILQR_FLAG_FUSED): a4 + a6 evaluated inside the backward / forward kernels --------------
+def run_fused(p, pd_stride=100, lam=None, n_alpha=6, use_iterate=False):
+    lam = p["lam"] if lam is None else lam
+    with Engine(p["dof"], p["m"], p["T"], p["nr"], batch=p["batch"], n_alpha=n_alpha, fused=True) as e:
+        assert (e.backward_variant, e.forward_variant) == ("mfma_f64_t1_fused", "mfma_f64_t1_fused")
+        synth.upload(e, p)
+        if use_iterate:
+            e.iterate(lam, pd_stride, orc.alphas(n_alpha))
+            res = e.results()
+            status, dJ, cost = res["status"], res["delta_J"], res["cost_pred"]
+            K, k = e.gains()
+            U = None
+        else:
+            e.fd_difference()
+            status, dJ = e.backward(lam, pd_stride)
+            K, k = e.gains()
+            cost, U = e.forward_linear(orc.alphas(n_alpha), want_U=True)
+        return dict(status=status, delta_J=dJ, K=K, k=k, cost_pred=cost, U_alpha=U)
+
+
+def check_fused(g, p, ref=None):
+    for b in range(p["batch"]):
+        o = ref[b] if ref is not None else pipeline.run_trajectory(p, b, want_U=True)
+        assert g["status"][b] == 0
+        assert relerr(g["K"][b], o["K"]) < K_RTOL_TIGHT, relerr(g["K"][b], o["K"])
+        assert relerr(g["k"][b], o["k"]) < K_RTOL_TIGHT, relerr(g["k"][b], o["k"])
+        assert abs(g["delta_J"][b] - o["delta_J"]) <= 1e-9 * abs(o["delta_J"]) + 1e-300
+        scale = np.max(np.abs(o["cost_pred"]))
+        assert np.max(np.abs(g["cost_pred"][b] - o["cost_pred"])) <= 1e-9 * scale, (g["cost_pred"][b], o["cost_pred"])
+        if g["U_alpha"] is not None:
+            assert relerr(g["U_alpha"][b], o["U_alpha"]) < 1e-9
+
+
+def test_fused_sweeps_match_oracle(case):
+    name, p, ref = case
+    if p["dof"] * 2 + 2 > 16:
+        with Engine(p["dof"], p["m"], p["T"], p["nr"], batch=p["batch"], fused=True) as e:
+            assert "fused" not in e.backward_variant          # unsupported shape: the flag is ignored
+        return
+    check_fused(run_fused(p), p, ref)
+    check_fused(run_fused(p, use_iterate=True), p, ref)
+
+
+def test_fused_ragged_keypoints_and_dense_keypoints():
+    """Per-DoF key-point lists (every lane walks its own list), and key-points at EVERY step."""
+    T, dof = 120, 7
+    p = synth.make_problem(task="panda_reaching", T=T, batch=2, min_N=1, dense_residuals=True)
+    check_fused(run_fused(p), p)                                 # dense: a segment per step
+    rng = np.random.default_rng(11)
+    rows = []
+    for b in range(2):
+        offs = np.zeros(T + 1, np.int32); cols = []
+        for t in range(T):
+            offs[t] = len(cols)
+            if t == 0 or t == T - 1:
+                cols.extend(range(dof))
+            else:
+                cols.extend([i for i in range(dof) if rng.uniform() < (0.6 if b == 0 else 0.08)])
+        offs[T] = len(cols)
+        rows.append((offs, np.asarray(cols, np.int32)))
+    p["kp_rows"] = rows
+    check_fused(run_fused(p), p)
+
+
+@pytest.mark.parametrize("T", [1, 2, 3, 7])
+def test_fused_tiny_horizons(T):
+    if T == 1:
+        pytest.skip("the reference's key-point generators need T >= 2")
+    p = synth.make_problem(task="panda_reaching", T=T, batch=2, min_N=5, dense_residuals=True)
+    check_fused(run_fused(p), p)
+
+
+def test_fused_full_size_panda_T3000():
+    p = synth.make_problem(task="panda_reaching", T=3000, batch=2, min_N=5)
+    g = run_fused(p)
+    gu = run_engine(p)
+    for b in range(2):
+        # against the unfused MFMA path on the device (same inputs, A/B/l_* materialised) ...
+        assert relerr(g["K"][b], gu["K"][b]) < K_RTOL_TIGHT
+        assert relerr(g["cost_pred"][b], gu["cost_pred"][b]) < 1e-9
+    check_fused(g, p)                                            # ... and against the oracle
+
+
+def test_fused_pd_failure_and_noncanonical_keypoints():
+    p = synth.make_problem(task="panda_reaching", T=64, batch=2, min_N=5, dense_residuals=True)
+    p["w_run"] = p["w_run"].copy(); p["w_term"] = p["w_term"].copy()
+    # negative control-residual weights make l_uu (hence Q_uu + lambda I) indefinite
+    if np.any(p["r_u"] != 0):
+        p["w_run"][:] = -np.abs(p["w_run"]) - 1.0
+        with Engine(p["dof"], p["m"], p["T"], p["nr"], batch=2, fused=True) as e:
+            synth.upload(e, p)
+            e.fd_difference()
+            st, _ = e.backward(1e-4, 1)
+        o = [pipeline.run_trajectory(p, b, lam=1e-4, pd_stride=1, stages=("fd", "interp", "cost", "bwd"))["status"] for b in range(2)]
+        assert list(st) == o and all(s > 0 for s in o)
+    # key-point lists that do not start at 0 / end at T-1 are refused loudly by the fused sweeps
+    from trajoptkp_amd.engine import KpilqrError
+    with Engine(p["dof"], p["m"], p["T"], p["nr"], batch=2, fused=True) as e:
+        offs = np.arange(0, 2 * p["dof"] + 1, dtype=np.int32) * 2
+        times = np.tile(np.array([1, p["T"] - 1], np.int32), 2 * p["dof"])
+        e.set_keypoints(offs, times)
+        with pytest.raises(KpilqrError):
+            e.backward(0.1)

@@ -31,6 +31,7 @@ class Dims(C.Structure):
 
 FLAG_GENERIC_KERNELS = 1
 FLAG_TILED_KERNELS = 2
+FLAG_FUSED = 4
 
 BUF_STEP_RECORDS, BUF_K, BUF_k, BUF_RESIDUALS, BUF_R_X, BUF_R_U, BUF_U_NOM, BUF_FD_XPLUS, \
     BUF_FD_XMINUS, BUF_COST_PRED, BUF_DELTA_J, BUF_STATUS = range(12)

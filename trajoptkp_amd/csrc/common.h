@@ -63,6 +63,8 @@ struct Ctx {
     int *kp_times = nullptr;      // [kp_total]
     size_t kp_cap = 0;            // capacity of kp_times (ints)
     bool have_kp = false;
+    bool kp_canonical = false;   // every DoF list strictly increasing, first 0, last T-1 (what the fused sweeps walk)
+    bool fused = false;          // KPILQR_FLAG_FUSED and a supported shape
 
     // FD job buffers (grow on demand)
     int njobs = 0, nnom = 0, nslots = 0;   // slot = run of consecutive jobs with one (b, t)
@@ -121,5 +123,9 @@ hipError_t launch_backward_tiled(Ctx *c, int pd_stride);
 size_t backward_tiled_lds_bytes(int nt);
 bool forward_tiled_supported(int n, int m, int n_alpha);
 hipError_t launch_forward_tiled(Ctx *c, double *U_alpha_dev);
+// fused_mfma.hip: a4 + a6 evaluated inside the sweeps (n+2 <= 16)
+bool fused_supported(int n, int m, int nr, int dof, int T, int stride, int n_alpha);
+hipError_t launch_backward_fused(Ctx *c, int pd_stride);
+hipError_t launch_forward_fused(Ctx *c, double *U_alpha_dev);
 
 }  // namespace kpilqr

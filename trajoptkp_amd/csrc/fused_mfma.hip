@@ -1,0 +1,724 @@
+// fused_mfma.hip -- the "never materialise A, B, l_*" form of the backward (a7) and forward (a8) passes
+// for n+2 <= 16: the interpolation of the dynamics Jacobians (a4) and the
+// Gauss-Newton cost derivatives (a6) are evaluated INSIDE the two sweeps, from the key-point columns that
+// k_fd_difference left in the step records and from the residuals / residual Jacobians.
+//
+//   * a4 (KeypointGenerator::InterpolateDerivatives, src/KeyPointGenerator/KeyPointGenerator.cpp:840-954):
+//     in the MFMA "D" layout lane (c,q) holds rows 4r+q of COLUMN c of A (and of B), and the reference
+//     interpolates column-wise with one key-point list per DoF -- so each lane walks the key-point list of
+//     its own DoF and keeps (value at segment start, slope) in registers:
+//         A_t[:,c] = A_s[:,c] + (t-s) * ((A_e[:,c] - A_s[:,c]) / (e-s))          (:898-905, :933-948)
+//     same operation order as k_interpolate (no FMA contraction, correctly rounded division), so the
+//     interpolated values are the ones the materialising kernel would have written.  Key-point columns of
+//     the next segment are fetched one segment ahead (time indices two ahead).
+//   * a6 (ModelTranslator::CostDerivativesFromResiduals, src/ModelTranslator/ModelTranslator.cpp:552-583):
+//     with Rz = [r_x | r] (nr x (n+1)) and W = diag(2w):  Lzz = [l_xx l_x; l_x' *] = Rz' W Rz is ONE
+//     P(Rz, W Rz); l_uu and l_u come out of P(Ru, W [Ru | r]) (columns < m and column n).  The reference
+//     has no l_ux term, so the cross product r_u' W r_x is never formed.  Terminal weights at t = T-1
+//     (Optimiser::ComputeCostDerivatives, src/Optimiser/Optimiser.cpp:202-211).
+//     The forward pass scores a candidate with the same model written on the residuals:
+//         l_x'dx + dx'l_xx dx/2 = sum_k w_k Jx_k (2 r_k + Jx_k),   Jx = r_x dx      (likewise for du).
+//
+// Everything else (homogeneous form, LDL' solve, slow path, stores) is riccati_mfma.hip / forward_mfma.hip.
+// Per launch the kernels read Kp*(n^2+nm) + T*nr*(1+n+m) doubles instead of T*(2n^2+nm+n+m^2+m).
+#include "common.h"
+
+namespace kpilqr {
+
+typedef double d4 __attribute__((ext_vector_type(4)));
+typedef unsigned int u32x2f __attribute__((ext_vector_type(2)));
+typedef unsigned long long u64;
+#define MFMA(a, b, c) __builtin_amdgcn_mfma_f64_16x16x4f64((a), (b), (c), 0, 0, 0)
+#define OOBF 0x7ffffff0
+#define BIGT 0x3fffffff
+
+template <int NC>
+__device__ __forceinline__ d4 PS(const d4 &Y, const d4 &X, d4 acc)
+{
+    acc = MFMA(Y.x, X.x, acc);
+    if (NC > 1) acc = MFMA(Y.y, X.y, acc);
+    if (NC > 2) acc = MFMA(Y.z, X.z, acc);
+    if (NC > 3) acc = MFMA(Y.w, X.w, acc);
+    return acc;
+}
+__device__ __forceinline__ d4 PR(const d4 &Y, const d4 &X, d4 acc, int nc)      // nc wave-uniform
+{
+    acc = MFMA(Y.x, X.x, acc);
+    if (nc > 1) acc = MFMA(Y.y, X.y, acc);
+    if (nc > 2) acc = MFMA(Y.z, X.z, acc);
+    if (nc > 3) acc = MFMA(Y.w, X.w, acc);
+    return acc;
+}
+__device__ __forceinline__ double fbld(__amdgpu_buffer_rsrc_t r, int byte_off)
+{
+    return __builtin_bit_cast(double, __builtin_amdgcn_raw_buffer_load_b64(r, byte_off, 0, 0));
+}
+__device__ __forceinline__ __amdgpu_buffer_rsrc_t frsrc(const void *p, int bytes)
+{
+    return __builtin_amdgcn_make_buffer_rsrc((void *)p, 0, bytes, 0x00020000);
+}
+__device__ __forceinline__ double frcp(double x)
+{
+    double r = __builtin_amdgcn_rcp(x);
+    r = __builtin_fma(__builtin_fma(-x, r, 1.0), r, r);
+    r = __builtin_fma(__builtin_fma(-x, r, 1.0), r, r);
+    return r;
+}
+// correctly rounded a/den for a normal-range quotient: one residual correction on top of a ~1 ulp reciprocal
+// (the hardware division expansion without its scaling / fix-up tail; den is a small positive integer)
+__device__ __forceinline__ double fdiv(double a, double den, double rinv)
+{
+    const double q0 = a * rinv;
+    const double rr = __builtin_fma(-den, q0, a);
+    return __builtin_fma(rr, rinv, q0);
+}
+__device__ __forceinline__ double bits_or(double a, double b)
+{
+    return __builtin_bit_cast(double, __builtin_bit_cast(u64, a) | __builtin_bit_cast(u64, b));
+}
+__device__ __forceinline__ double bits_and(double a, u64 mask)
+{
+    return __builtin_bit_cast(double, __builtin_bit_cast(u64, a) & mask);
+}
+// start + dt*slope, never contracted (k_interpolate's operation order)
+__device__ __forceinline__ double lerp_nc(double sv, double dt, double av)
+{
+#pragma clang fp contract(off)
+    const double p = dt * av;
+    return sv + p;
+}
+
+// Eigen's pivoted LDLT + solve(I) (slow path; identical to riccati_mfma.hip's)
+__device__ static __attribute__((noinline)) void fslow_ldlt_inverse(int m, const double *M, int ms, double *a, double *x, double *temp, int *tr)
+{
+#define AA(i, j) a[(i) + (j) * m]
+#define XX(i, j) x[(i) + (j) * m]
+    for (int j = 0; j < m; j++) for (int i = 0; i < m; i++) AA(i, j) = M[i * ms + j];
+    for (int k = 0; k < m; k++) {
+        int big = k; double bv = fabs(AA(k, k));
+        for (int i = k + 1; i < m; i++) if (fabs(AA(i, i)) > bv) { bv = fabs(AA(i, i)); big = i; }
+        tr[k] = big;
+        if (big != k) {
+            for (int j = 0; j < k; j++) { double t = AA(k, j); AA(k, j) = AA(big, j); AA(big, j) = t; }
+            for (int i = big + 1; i < m; i++) { double t = AA(i, k); AA(i, k) = AA(i, big); AA(i, big) = t; }
+            { double t = AA(k, k); AA(k, k) = AA(big, big); AA(big, big) = t; }
+            for (int i = k + 1; i < big; i++) { double t = AA(i, k); AA(i, k) = AA(big, i); AA(big, i) = t; }
+        }
+        if (k > 0) {
+            for (int j = 0; j < k; j++) temp[j] = AA(j, j) * AA(k, j);
+            double dot = 0.0;
+            for (int j = 0; j < k; j++) dot += AA(k, j) * temp[j];
+            AA(k, k) -= dot;
+            for (int i = k + 1; i < m; i++) {
+                double d2 = 0.0;
+                for (int j = 0; j < k; j++) d2 += AA(i, j) * temp[j];
+                AA(i, k) -= d2;
+            }
+        }
+        const double akk = AA(k, k);
+        const bool valid = fabs(akk) > 0.0;
+        if (k == 0 && !valid) { for (int j = 0; j < m; j++) tr[j] = j; break; }
+        if (valid) for (int i = k + 1; i < m; i++) AA(i, k) /= akk;
+    }
+    for (int c = 0; c < m; c++) for (int r = 0; r < m; r++) XX(r, c) = (r == c) ? 1.0 : 0.0;
+    for (int k = 0; k < m; k++)
+        if (tr[k] != k) for (int c = 0; c < m; c++) { double t = XX(k, c); XX(k, c) = XX(tr[k], c); XX(tr[k], c) = t; }
+    for (int c = 0; c < m; c++)
+        for (int k = 0; k < m; k++) {
+            const double b = XX(k, c);
+            for (int i = k + 1; i < m; i++) XX(i, c) -= b * AA(i, k);
+        }
+    for (int i = 0; i < m; i++) {
+        const double d = AA(i, i);
+        for (int c = 0; c < m; c++) {
+            if (fabs(d) > 2.2250738585072014e-308) XX(i, c) /= d; else XX(i, c) = 0.0;
+        }
+    }
+    for (int c = 0; c < m; c++)
+        for (int k = m - 1; k >= 0; k--) {
+            const double b = XX(k, c);
+            for (int i = 0; i < k; i++) XX(i, c) -= b * AA(k, i);
+        }
+    for (int k = m - 1; k >= 0; k--)
+        if (tr[k] != k) for (int c = 0; c < m; c++) { double t = XX(k, c); XX(k, c) = XX(tr[k], c); XX(tr[k], c) = t; }
+#undef AA
+#undef XX
+}
+
+struct FusedArgs {
+    const int *kp_offsets, *kp_times;              // per (b, dof) CSR of key-point time indices
+    const double *r, *r_x, *r_u, *w_run, *w_term;  // [b][T+1][nr], [..][nr][n], [..][nr][m], [nr], [nr]
+    int dof, nr;
+};
+
+// ---- column tracker: lane (c,q) interpolates rows 4r+q of column c of A and of B ------------------------
+// col[0..3] = A(4r+q, c), col[4..7] = B(4r+q, c) (c < m).  The whole trajectory's records sit behind one
+// buffer descriptor; a lane with nothing to load carries an out-of-range offset and reads 0.
+struct ColOffs { int a[4], b[4]; };
+
+__device__ __forceinline__ void load_col(__amdgpu_buffer_rsrc_t rT, const ColOffs &o, int tk, int T, int strideB, double *col)
+{
+    const bool ok = (unsigned)tk < (unsigned)T;
+    const int base = ok ? tk * strideB : 0;
+#pragma unroll
+    for (int r = 0; r < 4; r++) {
+        col[r] = fbld(rT, (ok && o.a[r] != OOBF) ? base + o.a[r] : OOBF);
+        col[4 + r] = fbld(rT, (ok && o.b[r] != OOBF) ? base + o.b[r] : OOBF);
+    }
+}
+
+// LDS map of the backward kernel (doubles) -- as riccati_mfma.hip
+#define FMS 16
+#define FMZ 17
+#define FVS 17
+#define FLDS_Q 0
+#define FLDS_Z (FLDS_Q + 16 * FMS)
+#define FLDS_V (FLDS_Z + 16 * FMZ)
+#define FLDS_SLOW (FLDS_V + 16 * FVS)
+#define FLDS_TOTAL (FLDS_SLOW + 2 * 256 + 16 + 16)
+
+template <int R> __device__ __forceinline__ void fset_reg(d4 &v, double x) { if (R == 0) v.x = x; else if (R == 1) v.y = x; else if (R == 2) v.z = x; else v.w = x; }
+
+template <int N, int M>
+__device__ __forceinline__ void backward_fused_body(RecLayout L, FusedArgs F, int T, const double *__restrict__ rec,
+                const double *__restrict__ lambda, int pd_stride, double *__restrict__ Kout, double *__restrict__ kout,
+                double *__restrict__ delta_J, int *__restrict__ status)
+{
+    constexpr int NCZ = (N + 1 + 3) / 4;
+    constexpr int NCU = (M + 3) / 4;
+    constexpr int n = N, m = M;
+    __shared__ __attribute__((aligned(16))) double sh[FLDS_TOTAL];
+    const int lane = threadIdx.x, c = lane & 15, q = lane >> 4;
+    const int b = blockIdx.x;
+    const double lam = lambda[b];
+    const int nr = F.nr, ncr = (nr + 3) >> 2;
+    const int strideB = L.stride * 8;
+
+    ColOffs co;
+    double w2run[4], w2term[4], lam2d[4];
+    int oRx[4], oR1[4], oRu[4], oKst[4], okst[4];
+#pragma unroll
+    for (int r = 0; r < 4; r++) {
+        const int row = 4 * r + q;
+        co.a[r] = (row < n && c < n) ? 8 * (L.off_A + row * n + c) : OOBF;
+        co.b[r] = (row < n && c < m) ? 8 * (L.off_B + row * m + c) : OOBF;
+        oRx[r] = (row < nr && c < n) ? 8 * (row * n + c) : OOBF;      // Rz(k=row, c) = r_x[k][c]
+        oR1[r] = (row < nr && c == n) ? 8 * row : OOBF;               //            ... | r[k] in column n
+        oRu[r] = (row < nr && c < m) ? 8 * (row * m + c) : OOBF;      // Ru(k=row, c) = r_u[k][c]
+        w2run[r] = (row < nr) ? 2.0 * F.w_run[row] : 0.0;
+        w2term[r] = (row < nr) ? 2.0 * F.w_term[row] : 0.0;
+        oKst[r] = (row < m && c < n) ? 8 * (row + c * m) : OOBF;
+        okst[r] = (row < m && c == n) ? 8 * row : OOBF;
+        lam2d[r] = (row == c && row < m) ? 2.0 * lam : 0.0;
+    }
+    const u64 mask_n = (c == n) ? ~0ull : 0ull, mask_u = (c < m) ? ~0ull : 0ull;
+    const bool lane_nn = (c == n) && (q == (n & 3));
+    constexpr int REG_NN = n >> 2;
+
+    const double *R0 = rec + (size_t)b * T * L.stride;
+    __amdgpu_buffer_rsrc_t rT = frsrc(R0, T * strideB);
+    const double *rb = F.r + (size_t)b * (T + 1) * nr;
+    const double *rxb = F.r_x + (size_t)b * (T + 1) * nr * n;
+    const double *rub = F.r_u + (size_t)b * (T + 1) * nr * m;
+
+    struct ResTiles { d4 Rx, R1, Ru; };
+    auto load_res = [&](int t, ResTiles &s) {
+        __amdgpu_buffer_rsrc_t rRx = frsrc(rxb + (size_t)t * nr * n, nr * n * 8);
+        __amdgpu_buffer_rsrc_t rR = frsrc(rb + (size_t)t * nr, nr * 8);
+        __amdgpu_buffer_rsrc_t rRu = frsrc(rub + (size_t)t * nr * m, nr * m * 8);
+        s.Rx.x = fbld(rRx, oRx[0]); s.Rx.y = fbld(rRx, oRx[1]); s.Rx.z = fbld(rRx, oRx[2]); s.Rx.w = fbld(rRx, oRx[3]);
+        s.R1.x = fbld(rR, oR1[0]); s.R1.y = fbld(rR, oR1[1]); s.R1.z = fbld(rR, oR1[2]); s.R1.w = fbld(rR, oR1[3]);
+        s.Ru.x = fbld(rRu, oRu[0]); s.Ru.y = fbld(rRu, oRu[1]); s.Ru.z = fbld(rRu, oRu[2]); s.Ru.w = fbld(rRu, oRu[3]);
+    };
+
+    // ---- column tracker, walking DOWN in time ----------------------------------------------------------
+    const int kd = (c < F.dof) ? c : c - F.dof;
+    const bool has = c < n;
+    const int lo = has ? F.kp_offsets[(size_t)b * F.dof + kd] : 0;
+    const int hi = has ? F.kp_offsets[(size_t)b * F.dof + kd + 1] : 0;
+    int idx = hi - 1;
+    int s = has ? F.kp_times[idx] : -1;                       // == T-1 for canonical key-points
+    int nb = (has && idx - 1 >= lo) ? F.kp_times[idx - 1] : -1;
+    int nb2 = (has && idx - 2 >= lo) ? F.kp_times[idx - 2] : -1;
+    double sv[8], av[8], pv[8];
+    load_col(rT, co, s, T, strideB, sv);
+    load_col(rT, co, nb, T, strideB, pv);
+#pragma unroll
+    for (int i = 0; i < 8; i++) av[i] = 0.0;
+    // Fz(n,n) = 1: lane c == n walks no list (never crosses), so its constant start value carries the 1
+#pragma unroll
+    for (int r = 0; r < 4; r++) if (c == n && 4 * r + q == n) sv[r] = 1.0;
+
+    // single-buffered: the residual tiles are consumed by the first MFMAs of a step and re-requested for the
+    // next step right behind them (a whole step of latency cover, no register copies)
+    ResTiles cur;
+    load_res(T - 1, cur);
+    const d4 zero = {0.0, 0.0, 0.0, 0.0};
+    d4 V = zero;
+    d4 W2 = {w2term[0], w2term[1], w2term[2], w2term[3]};     // terminal weights at t = T-1, running after
+    int pd_counter = 0, fail = 0;
+    double dJ = 0.0;
+
+    for (int t = T - 1; t >= 0; t--) {
+        // ---- a4: this step's A and B columns --------------------------------------------------------------
+        if (t < s) {                                   // per lane: crossed the start of the current segment
+            const double den = (double)(s - nb);
+            const double rinv = frcp(den);
+#pragma unroll
+            for (int i = 0; i < 8; i++) {
+                const double ev = sv[i];
+                sv[i] = pv[i];
+                av[i] = fdiv(ev - sv[i], den, rinv);
+            }
+            s = nb; idx--;
+            nb = nb2;
+            nb2 = (idx - 2 >= lo) ? F.kp_times[idx - 2] : -1;
+            load_col(rT, co, nb, T, strideB, pv);
+        }
+        const double dt = (double)(t - s);
+        d4 Fz, Fu;
+        Fz.x = lerp_nc(sv[0], dt, av[0]); Fz.y = lerp_nc(sv[1], dt, av[1]);
+        Fz.z = lerp_nc(sv[2], dt, av[2]); Fz.w = lerp_nc(sv[3], dt, av[3]);
+        Fu.x = lerp_nc(sv[4], dt, av[4]); Fu.y = lerp_nc(sv[5], dt, av[5]);
+        Fu.z = lerp_nc(sv[6], dt, av[6]); Fu.w = lerp_nc(sv[7], dt, av[7]);
+        // ---- a6: Lzz, l_uu, l_u from the residuals --------------------------------------------------------
+        const bool term = (t == T - 1);
+        d4 Rz, Rur;
+        Rz.x = bits_or(cur.Rx.x, cur.R1.x); Rz.y = bits_or(cur.Rx.y, cur.R1.y);
+        Rz.z = bits_or(cur.Rx.z, cur.R1.z); Rz.w = bits_or(cur.Rx.w, cur.R1.w);
+        Rur.x = bits_or(cur.Ru.x, cur.R1.x); Rur.y = bits_or(cur.Ru.y, cur.R1.y);
+        Rur.z = bits_or(cur.Ru.z, cur.R1.z); Rur.w = bits_or(cur.Ru.w, cur.R1.w);
+        const d4 Lzz = PR(Rz, Rz * W2, zero, ncr);
+        const d4 LU = PR(cur.Ru, Rur * W2, zero, ncr);
+        __builtin_amdgcn_sched_barrier(0);
+        if (t > 0) load_res(t - 1, cur);
+        __builtin_amdgcn_sched_barrier(0);
+        d4 Luu, Luz;
+        Luu.x = bits_and(LU.x, mask_u); Luu.y = bits_and(LU.y, mask_u); Luu.z = bits_and(LU.z, mask_u); Luu.w = bits_and(LU.w, mask_u);
+        Luz.x = bits_and(LU.x, mask_n); Luz.y = bits_and(LU.y, mask_n); Luz.z = bits_and(LU.z, mask_n); Luz.w = bits_and(LU.w, mask_n);
+        if (term) {                                     // V_x = l_x[T-1]; V_xx = l_xx[T-1]   (iLQR.cpp:537-539)
+            V = Lzz;
+            W2.x = w2run[0]; W2.y = w2run[1]; W2.z = w2run[2]; W2.w = w2run[3];
+        }
+        pd_counter++;
+        const bool check_pd = pd_counter >= pd_stride;
+
+        // ---- Tu = V' Fu ; Quu = l_uu + Fu' Tu --------------------------------------- :577
+        d4 Tu = PS<NCZ>(V, Fu, zero);
+        d4 Quu = PS<NCZ>(Fu, Tu, Luu);
+        sh[FLDS_Q + q * FMS + c] = Quu.x + 0.5 * lam2d[0];
+        if (NCU > 1) sh[FLDS_Q + (4 + q) * FMS + c] = Quu.y + 0.5 * lam2d[1];
+        if (NCU > 2) sh[FLDS_Q + (8 + q) * FMS + c] = Quu.z + 0.5 * lam2d[2];
+        if (NCU > 3) sh[FLDS_Q + (12 + q) * FMS + c] = Quu.w + 0.5 * lam2d[3];
+        // ---- Tz, Quz, Qzz --------------------------------------------------------------- :570-579
+        d4 Tz = PS<NCZ>(V, Fz, zero);
+        d4 Quz = PS<NCZ>(Fu, Tz, Luz);
+        d4 Qzz = PS<NCZ>(Fz, Tz, Lzz);
+        sh[FLDS_Z + c * FMZ + q] = Quz.x;
+        if (NCU > 1) sh[FLDS_Z + c * FMZ + 4 + q] = Quz.y;
+        if (NCU > 2) sh[FLDS_Z + c * FMZ + 8 + q] = Quz.z;
+        if (NCU > 3) sh[FLDS_Z + c * FMZ + 12 + q] = Quz.w;
+        __syncthreads();
+
+        // ---- unpivoted LDL' of Quu + lambda I, redundantly in every lane ----
+        double Lm[M][M], dd[M], rd[M];
+        bool pos = true;
+#pragma unroll
+        for (int j = 0; j < M; j++) {
+            double w[M];
+            double dj = sh[FLDS_Q + j * FMS + j];
+#pragma unroll
+            for (int kk = 0; kk < j; kk++) { w[kk] = Lm[j][kk] * dd[kk]; dj -= Lm[j][kk] * w[kk]; }
+            dd[j] = dj;
+            pos = pos && (dj > 0.0);
+            const double rj = frcp(dj);
+            rd[j] = rj;
+#pragma unroll
+            for (int i = j + 1; i < M; i++) {
+                double v = sh[FLDS_Q + i * FMS + j];
+#pragma unroll
+                for (int kk = 0; kk < j; kk++) v -= Lm[i][kk] * w[kk];
+                Lm[i][j] = v * rj;
+            }
+        }
+        if (check_pd) {                       // CheckMatrixPD every pd_stride steps   :587-595
+            if (!pos) { fail = t + 1; break; }
+            pd_counter = 0;
+        }
+        double x[M];
+        if (pos) {
+#pragma unroll
+            for (int i = 0; i < M; i++) x[i] = sh[FLDS_Z + c * FMZ + i];
+#pragma unroll
+            for (int j = 0; j < M; j++) {
+#pragma unroll
+                for (int i = j + 1; i < M; i++) x[i] -= Lm[i][j] * x[j];
+            }
+#pragma unroll
+            for (int i = 0; i < M; i++) x[i] *= rd[i];
+#pragma unroll
+            for (int j = M - 1; j >= 0; j--) {
+#pragma unroll
+                for (int i = 0; i < j; i++) x[i] -= Lm[j][i] * x[j];
+            }
+        } else {
+            double *wa = sh + FLDS_SLOW, *wx = wa + 256, *wt = wx + 256;
+            int *tr = (int *)(wt + 16);
+            if (lane == 0) fslow_ldlt_inverse(L.m, sh + FLDS_Q, FMS, wa, wx, wt, tr);
+            __syncthreads();
+#pragma unroll
+            for (int i = 0; i < M; i++) {
+                double sacc = 0.0;
+#pragma unroll
+                for (int p = 0; p < M; p++) sacc += (-wx[i + p * m]) * sh[FLDS_Z + c * FMZ + p];
+                x[i] = -sacc;
+            }
+            __syncthreads();
+        }
+        d4 Xp = zero;
+        {
+            double xr[4] = {0.0, 0.0, 0.0, 0.0};
+#pragma unroll
+            for (int i = 0; i < M; i++)
+                if (q == (i & 3)) xr[i >> 2] = x[i];
+            Xp.x = xr[0]; Xp.y = xr[1]; Xp.z = xr[2]; Xp.w = xr[3];
+        }
+        const d4 Kp = -Xp;
+        {
+            __amdgpu_buffer_rsrc_t rK = frsrc(Kout + ((size_t)b * T + t) * m * n, m * n * 8);
+            __amdgpu_buffer_rsrc_t rk = frsrc(kout + ((size_t)b * T + t) * m, m * 8);
+            const double kv[4] = {Kp.x, Kp.y, Kp.z, Kp.w};
+#pragma unroll
+            for (int r = 0; r < NCU; r++) {
+                __builtin_amdgcn_raw_buffer_store_b64(__builtin_bit_cast(u32x2f, kv[r]), rK, oKst[r], 0, 0);
+                __builtin_amdgcn_raw_buffer_store_b64(__builtin_bit_cast(u32x2f, kv[r]), rk, okst[r], 0, 0);
+            }
+        }
+        {
+            double kk = 0.0;
+#pragma unroll
+            for (int i = 0; i < M; i++) kk += x[i] * x[i];
+            if (lane_nn) dJ -= lam * kk;
+        }
+        d4 Quu2 = Quu;
+        Quu2.x += lam2d[0]; Quu2.y += lam2d[1]; Quu2.z += lam2d[2]; Quu2.w += lam2d[3];
+        d4 G = PS<NCU>(Quu2, Kp, zero);
+        d4 acc = PS<NCU>(Xp, G, Qzz);
+        sh[FLDS_V + (q) * FVS + c] = acc.x;
+        sh[FLDS_V + (4 + q) * FVS + c] = acc.y;
+        sh[FLDS_V + (8 + q) * FVS + c] = acc.z;
+        sh[FLDS_V + (12 + q) * FVS + c] = acc.w;
+        __syncthreads();
+        V.x = 0.5 * (acc.x + sh[FLDS_V + c * FVS + q]);
+        V.y = 0.5 * (acc.y + sh[FLDS_V + c * FVS + 4 + q]);
+        V.z = 0.5 * (acc.z + sh[FLDS_V + c * FVS + 8 + q]);
+        V.w = 0.5 * (acc.w + sh[FLDS_V + c * FVS + 12 + q]);
+        if (lane_nn) fset_reg<REG_NN>(V, 0.0);
+        __syncthreads();
+    }
+    if (lane_nn) delta_J[b] = dJ;
+    if (lane == 0) status[b] = fail;
+}
+
+template <int N, int M>
+__global__ void __launch_bounds__(64)
+k_backward_fused(RecLayout L, FusedArgs F, int T, const double *__restrict__ rec, const double *__restrict__ lambda,
+                 int pd_stride, double *__restrict__ Kout, double *__restrict__ kout,
+                 double *__restrict__ delta_J, int *__restrict__ status)
+{
+    backward_fused_body<N, M>(L, F, T, rec, lambda, pd_stride, Kout, kout, delta_J, status);
+}
+template <int N, int M>
+__global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(1, 1)))
+k_backward_fused_excl(RecLayout L, FusedArgs F, int T, const double *__restrict__ rec, const double *__restrict__ lambda,
+                      int pd_stride, double *__restrict__ Kout, double *__restrict__ kout,
+                      double *__restrict__ delta_J, int *__restrict__ status)
+{
+    backward_fused_body<N, M>(L, F, T, rec, lambda, pd_stride, Kout, kout, delta_J, status);
+}
+
+// ---------------------------------------------------------------------------------------------------------
+// Forward pass.  The column tracker walks UP in time; its tiles (row = A row, col = A column) are turned into
+// the Y operands (row = contraction index) through a padded LDS transpose, off the Z dependency chain.
+template <int NCZ, int NCU>
+__device__ __forceinline__ void forward_fused_body(RecLayout L, FusedArgs F, int T, int n_alpha, const double *__restrict__ rec,
+               const double *__restrict__ Kin, const double *__restrict__ kin,
+               const double *__restrict__ u_nom, const double *__restrict__ ctrl_lim,
+               const double *__restrict__ alphas, double *__restrict__ cost_pred, double *__restrict__ U_alpha)
+{
+    __shared__ __attribute__((aligned(16))) double shA[16 * 17], shB[16 * 17];
+    const int n = L.n, m = L.m;
+    const int lane = threadIdx.x, c = lane & 15, q = lane >> 4;
+    const int b = blockIdx.x;
+    const int nr = F.nr;
+    const int strideB = L.stride * 8;
+    const int ncx = (n + 3) >> 2;
+
+    ColOffs co;
+    int oK[4], ok_[4], oRxT[4], oRuT[4], oR[4], oub[4];
+    double lo[NCU], hi[NCU], wcur[4];
+#pragma unroll
+    for (int r = 0; r < 4; r++) {
+        const int row = 4 * r + q;
+        co.a[r] = (row < n && c < n) ? 8 * (L.off_A + row * n + c) : OOBF;
+        co.b[r] = (row < n && c < m) ? 8 * (L.off_B + row * m + c) : OOBF;
+        oK[r] = (row < n && c < m) ? 8 * (row * m + c) : OOBF;
+        ok_[r] = (row == n && c < m) ? 8 * c : OOBF;
+        oRxT[r] = (row < n && c < nr) ? 8 * (c * n + row) : OOBF;     // RxT(p=row, k=c) = r_x[k][p]
+        oRuT[r] = (row < m && c < nr) ? 8 * (c * m + row) : OOBF;     // RuT(p=row, k=c) = r_u[k][p]
+        oR[r] = (row < nr) ? 8 * row : OOBF;                          // r[k=row] (rows of Jx / Ju)
+        oub[r] = (row < m) ? 8 * row : OOBF;
+        if (r < NCU) {
+            lo[r] = (row < m) ? ctrl_lim[2 * row] : -1.0e300;
+            hi[r] = (row < m) ? ctrl_lim[2 * row + 1] : 1.0e300;
+        }
+        wcur[r] = (row < nr) ? F.w_run[row] : 0.0;
+    }
+    const double my_alpha = (c < n_alpha) ? alphas[c] : 0.0;
+    d4 Z;
+    {
+        double zr[4];
+#pragma unroll
+        for (int r = 0; r < 4; r++) {
+            const int row = 4 * r + q;
+            zr[r] = (row == n) ? my_alpha : (row == n + 1) ? 1.0 : 0.0;
+        }
+        Z.x = zr[0]; Z.y = zr[1]; Z.z = zr[2]; Z.w = zr[3];
+    }
+    const d4 zero = {0.0, 0.0, 0.0, 0.0};
+    double partial = 0.0;
+
+    const double *R0 = rec + (size_t)b * T * L.stride;
+    __amdgpu_buffer_rsrc_t rT = frsrc(R0, T * strideB);
+    const double *rb = F.r + (size_t)b * (T + 1) * nr;
+    const double *rxb = F.r_x + (size_t)b * (T + 1) * nr * n;
+    const double *rub = F.r_u + (size_t)b * (T + 1) * nr * m;
+
+    struct Tiles { d4 YkK, Ykk, RxT, RuT, rv, ub; };
+    auto load_tiles = [&](int t, Tiles &s) {
+        __amdgpu_buffer_rsrc_t rK = frsrc(Kin + ((size_t)b * T + t) * m * n, m * n * 8);
+        __amdgpu_buffer_rsrc_t rk = frsrc(kin + ((size_t)b * T + t) * m, m * 8);
+        __amdgpu_buffer_rsrc_t ru = frsrc(u_nom + ((size_t)b * T + t) * m, m * 8);
+        __amdgpu_buffer_rsrc_t rRx = frsrc(rxb + (size_t)t * nr * n, nr * n * 8);
+        __amdgpu_buffer_rsrc_t rRu = frsrc(rub + (size_t)t * nr * m, nr * m * 8);
+        __amdgpu_buffer_rsrc_t rR = frsrc(rb + (size_t)t * nr, nr * 8);
+        s.YkK.x = fbld(rK, oK[0]); s.YkK.y = fbld(rK, oK[1]); s.YkK.z = fbld(rK, oK[2]); s.YkK.w = fbld(rK, oK[3]);
+        s.Ykk.x = fbld(rk, ok_[0]); s.Ykk.y = fbld(rk, ok_[1]); s.Ykk.z = fbld(rk, ok_[2]); s.Ykk.w = fbld(rk, ok_[3]);
+        s.RxT.x = fbld(rRx, oRxT[0]); s.RxT.y = fbld(rRx, oRxT[1]); s.RxT.z = fbld(rRx, oRxT[2]); s.RxT.w = fbld(rRx, oRxT[3]);
+        s.RuT.x = fbld(rRu, oRuT[0]); s.RuT.y = NCU > 1 ? fbld(rRu, oRuT[1]) : 0.0;
+        s.RuT.z = NCU > 2 ? fbld(rRu, oRuT[2]) : 0.0; s.RuT.w = NCU > 3 ? fbld(rRu, oRuT[3]) : 0.0;
+        s.rv.x = fbld(rR, oR[0]); s.rv.y = fbld(rR, oR[1]); s.rv.z = fbld(rR, oR[2]); s.rv.w = fbld(rR, oR[3]);
+        s.ub.x = fbld(ru, oub[0]); s.ub.y = NCU > 1 ? fbld(ru, oub[1]) : 0.0;
+        s.ub.z = NCU > 2 ? fbld(ru, oub[2]) : 0.0; s.ub.w = NCU > 3 ? fbld(ru, oub[3]) : 0.0;
+    };
+
+    // ---- column tracker, walking UP in time --------------------------------------------------------------
+    const int kd = (c < F.dof) ? c : c - F.dof;
+    const bool has = c < n;
+    const int klo = has ? F.kp_offsets[(size_t)b * F.dof + kd] : 0;
+    const int khi = has ? F.kp_offsets[(size_t)b * F.dof + kd + 1] : 0;
+    int idx = klo;
+    int s = has ? F.kp_times[idx] : 0;                                  // == 0 for canonical key-points
+    int e = (has && idx + 1 < khi) ? F.kp_times[idx + 1] : BIGT;
+    int nb = (has && idx + 2 < khi) ? F.kp_times[idx + 2] : BIGT;
+    // Walking up, a segment is entered at its START key-point, where the stored value is exact and the slope is
+    // not needed yet: the end column is requested at the crossing and the slope formed one step later
+    // (`pend`), so no second prefetch buffer is held.
+    double sv[8], ev[8], av[8];
+    load_col(rT, co, has ? s : BIGT, T, strideB, sv);
+    load_col(rT, co, e, T, strideB, ev);
+    bool pend = true;
+#pragma unroll
+    for (int i = 0; i < 8; i++) av[i] = 0.0;
+    // the identity rows of Ya (alpha and the homogeneous 1 carry over): lanes c >= n walk no list
+#pragma unroll
+    for (int r = 0; r < 4; r++) if ((c == n || c == n + 1) && 4 * r + q == c) sv[r] = 1.0;
+
+    Tiles nxt;
+    load_tiles(0, nxt);          // step 0
+
+    // One wavefront per workgroup: LDS accesses of the wave execute in order, so the write -> transposed read
+    // pairs below need no barrier.  The Y operands of step t+1 are produced during step t (off the Z chain).
+    auto stage_cols = [&](int t) {            // a4 in the column layout -> LDS
+        const double dt = (double)(t - s);
+        shA[(q) * 17 + c] = lerp_nc(sv[0], dt, av[0]);      shA[(4 + q) * 17 + c] = lerp_nc(sv[1], dt, av[1]);
+        shA[(8 + q) * 17 + c] = lerp_nc(sv[2], dt, av[2]);  shA[(12 + q) * 17 + c] = lerp_nc(sv[3], dt, av[3]);
+        shB[(q) * 17 + c] = lerp_nc(sv[4], dt, av[4]);      shB[(4 + q) * 17 + c] = lerp_nc(sv[5], dt, av[5]);
+        shB[(8 + q) * 17 + c] = lerp_nc(sv[6], dt, av[6]);  shB[(12 + q) * 17 + c] = lerp_nc(sv[7], dt, av[7]);
+    };
+    auto fetch_Y = [&](d4 &Ya, d4 &Yb) {      // Ya(p, o) = A(o, p);  Yb(p, o) = B(o, p)
+        Ya.x = shA[c * 17 + q];      Ya.y = shA[c * 17 + 4 + q];
+        Ya.z = shA[c * 17 + 8 + q];  Ya.w = shA[c * 17 + 12 + q];
+        Yb.x = shB[c * 17 + q];                Yb.y = NCU > 1 ? shB[c * 17 + 4 + q] : 0.0;
+        Yb.z = NCU > 2 ? shB[c * 17 + 8 + q] : 0.0; Yb.w = NCU > 3 ? shB[c * 17 + 12 + q] : 0.0;
+    };
+    auto advance = [&](int t) {
+        if (pend) {                           // slope of the segment entered one step ago (its end column has landed)
+            const double den = (double)(e - s);
+            const double rinv = frcp(den);
+#pragma unroll
+            for (int i = 0; i < 8; i++) av[i] = (e != BIGT) ? fdiv(ev[i] - sv[i], den, rinv) : 0.0;
+            pend = false;
+        }
+        if (t >= e) {                         // per lane: reached the end key-point of the segment
+#pragma unroll
+            for (int i = 0; i < 8; i++) { sv[i] = ev[i]; av[i] = 0.0; }
+            s = e; e = nb; idx++;
+            load_col(rT, co, e, T, strideB, ev);
+            nb = (idx + 2 < khi) ? F.kp_times[idx + 2] : BIGT;
+            pend = true;
+        }
+    };
+    d4 Ya, Yb;
+    stage_cols(0);
+    fetch_Y(Ya, Yb);
+
+    // single-buffered tiles: each is re-requested for step t+1 right behind its last use in step t
+    Tiles cur = nxt;
+    const __amdgpu_buffer_rsrc_t rNone = frsrc(Kin, 0);
+    for (int t = 0; t < T; t++) {
+        const bool more = t + 1 < T;
+        __amdgpu_buffer_rsrc_t rK = more ? frsrc(Kin + ((size_t)b * T + t + 1) * m * n, m * n * 8) : rNone;
+        __amdgpu_buffer_rsrc_t rk = more ? frsrc(kin + ((size_t)b * T + t + 1) * m, m * 8) : rNone;
+        __amdgpu_buffer_rsrc_t ru = more ? frsrc(u_nom + ((size_t)b * T + t + 1) * m, m * 8) : rNone;
+        __amdgpu_buffer_rsrc_t rRx = more ? frsrc(rxb + (size_t)(t + 1) * nr * n, nr * n * 8) : rNone;
+        __amdgpu_buffer_rsrc_t rRu = more ? frsrc(rub + (size_t)(t + 1) * nr * m, nr * m * 8) : rNone;
+        __amdgpu_buffer_rsrc_t rR = more ? frsrc(rb + (size_t)(t + 1) * nr, nr * 8) : rNone;
+        // control law + clamp
+        const d4 Yk = cur.YkK + cur.Ykk;
+        const d4 ub = cur.ub;
+        d4 U = PS<NCZ>(Yk, Z, ub);
+        __builtin_amdgcn_sched_barrier(0);
+        cur.YkK.x = fbld(rK, oK[0]); cur.YkK.y = fbld(rK, oK[1]); cur.YkK.z = fbld(rK, oK[2]); cur.YkK.w = fbld(rK, oK[3]);
+        cur.Ykk.x = fbld(rk, ok_[0]); cur.Ykk.y = fbld(rk, ok_[1]); cur.Ykk.z = fbld(rk, ok_[2]); cur.Ykk.w = fbld(rk, ok_[3]);
+        __builtin_amdgcn_sched_barrier(0);
+        d4 dU;
+        {
+            double u;
+            // rows >= 4*NCU of U hold no control (exact zeros): only the first NCU registers are clamped
+            dU = zero;
+            u = U.x; if (u > hi[0]) u = hi[0]; if (u < lo[0]) u = lo[0]; U.x = u; dU.x = u - ub.x;
+            if (NCU > 1) { u = U.y; if (u > hi[1]) u = hi[1]; if (u < lo[1]) u = lo[1]; U.y = u; dU.y = u - ub.y; }
+            if (NCU > 2) { u = U.z; if (u > hi[2]) u = hi[2]; if (u < lo[2]) u = lo[2]; U.z = u; dU.z = u - ub.z; }
+            if (NCU > 3) { u = U.w; if (u > hi[3]) u = hi[3]; if (u < lo[3]) u = lo[3]; U.w = u; dU.w = u - ub.w; }
+        }
+        __builtin_amdgcn_sched_barrier(0);
+        cur.ub.x = fbld(ru, oub[0]); cur.ub.y = NCU > 1 ? fbld(ru, oub[1]) : 0.0;
+        cur.ub.z = NCU > 2 ? fbld(ru, oub[2]) : 0.0; cur.ub.w = NCU > 3 ? fbld(ru, oub[3]) : 0.0;
+        __builtin_amdgcn_sched_barrier(0);
+        if (U_alpha && c < n_alpha) {
+            double *Ua = U_alpha + (((size_t)b * n_alpha + c) * T + t) * m;
+            const double uv[4] = {U.x, U.y, U.z, U.w};
+#pragma unroll
+            for (int r = 0; r < NCU; r++) { const int row = 4 * r + q; if (row < m) Ua[row] = uv[r]; }
+        }
+        // a4 for step t+1 (column layout -> LDS), off the Z chain
+        if (more) { advance(t + 1); stage_cols(t + 1); }
+        // quadratic cost model on the residuals: sum_k w_k [Jx_k (2 r_k + Jx_k) + Ju_k (2 r_k + Ju_k)]
+        const d4 Jx = PR(cur.RxT, Z, zero, ncx);
+        const d4 Ju = PS<NCU>(cur.RuT, dU, zero);
+        __builtin_amdgcn_sched_barrier(0);
+        cur.RxT.x = fbld(rRx, oRxT[0]); cur.RxT.y = fbld(rRx, oRxT[1]); cur.RxT.z = fbld(rRx, oRxT[2]); cur.RxT.w = fbld(rRx, oRxT[3]);
+        cur.RuT.x = fbld(rRu, oRuT[0]); cur.RuT.y = NCU > 1 ? fbld(rRu, oRuT[1]) : 0.0;
+        cur.RuT.z = NCU > 2 ? fbld(rRu, oRuT[2]) : 0.0; cur.RuT.w = NCU > 3 ? fbld(rRu, oRuT[3]) : 0.0;
+        __builtin_amdgcn_sched_barrier(0);
+        if (t == T - 1) {                     // terminal weights at the last step (Optimiser.cpp:209-211)
+#pragma unroll
+            for (int r = 0; r < 4; r++) wcur[r] = (4 * r + q < nr) ? F.w_term[4 * r + q] : 0.0;
+        }
+        const d4 r2 = cur.rv + cur.rv;
+        partial += wcur[0] * (Jx.x * (r2.x + Jx.x) + Ju.x * (r2.x + Ju.x))
+                 + wcur[1] * (Jx.y * (r2.y + Jx.y) + Ju.y * (r2.y + Ju.y))
+                 + wcur[2] * (Jx.z * (r2.z + Jx.z) + Ju.z * (r2.z + Ju.z))
+                 + wcur[3] * (Jx.w * (r2.w + Jx.w) + Ju.w * (r2.w + Ju.w));
+        __builtin_amdgcn_sched_barrier(0);
+        cur.rv.x = fbld(rR, oR[0]); cur.rv.y = fbld(rR, oR[1]); cur.rv.z = fbld(rR, oR[2]); cur.rv.w = fbld(rR, oR[3]);
+        __builtin_amdgcn_sched_barrier(0);
+        // linearised dynamics, then the Y operands of step t+1 come back from LDS behind the MFMAs
+        d4 Zn = PS<NCZ>(Ya, Z, zero);
+        Zn = PS<NCU>(Yb, dU, Zn);
+        Z = Zn;
+        __builtin_amdgcn_sched_barrier(0);
+        if (more) fetch_Y(Ya, Yb);
+    }
+    partial += __shfl_xor(partial, 16);
+    partial += __shfl_xor(partial, 32);
+    if (q == 0 && c < n_alpha) cost_pred[(size_t)b * n_alpha + c] = partial;
+}
+
+template <int NCZ, int NCU>
+__global__ void __launch_bounds__(64)
+k_forward_fused(RecLayout L, FusedArgs F, int T, int n_alpha, const double *__restrict__ rec, const double *__restrict__ Kin,
+                const double *__restrict__ kin, const double *__restrict__ u_nom, const double *__restrict__ ctrl_lim,
+                const double *__restrict__ alphas, double *__restrict__ cost_pred, double *__restrict__ U_alpha)
+{
+    forward_fused_body<NCZ, NCU>(L, F, T, n_alpha, rec, Kin, kin, u_nom, ctrl_lim, alphas, cost_pred, U_alpha);
+}
+template <int NCZ, int NCU>
+__global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(1, 1)))
+k_forward_fused_excl(RecLayout L, FusedArgs F, int T, int n_alpha, const double *__restrict__ rec, const double *__restrict__ Kin,
+                     const double *__restrict__ kin, const double *__restrict__ u_nom, const double *__restrict__ ctrl_lim,
+                     const double *__restrict__ alphas, double *__restrict__ cost_pred, double *__restrict__ U_alpha)
+{
+    forward_fused_body<NCZ, NCU>(L, F, T, n_alpha, rec, Kin, kin, u_nom, ctrl_lim, alphas, cost_pred, U_alpha);
+}
+
+bool fused_supported(int n, int m, int nr, int dof, int T, int stride, int n_alpha)
+{
+    const bool shape = (n == 14 && m == 7) || (n == 4 && m == 1);
+    return shape && nr >= 1 && nr <= 16 && m <= dof && n_alpha <= 16 && (long long)T * stride * 8 < 0x7ffffff0LL;
+}
+
+static FusedArgs fused_args(const Ctx *c)
+{
+    FusedArgs F = {c->kp_offsets, c->kp_times, c->r, c->r_x, c->r_u, c->w_run, c->w_term, c->d.dof, c->d.nr};
+    return F;
+}
+
+hipError_t launch_backward_fused(Ctx *c, int pd_stride)
+{
+    const int n = c->n, m = c->d.m;
+    dim3 grid(c->d.batch), block(64);
+    const bool excl = c->d.batch <= c->n_simd;
+    const FusedArgs F = fused_args(c);
+#define LAUNCH(NN, MM)                                                                                       \
+    do {                                                                                                     \
+        if (excl)                                                                                            \
+            hipLaunchKernelGGL((k_backward_fused_excl<NN, MM>), grid, block, 0, c->stream, c->L, F, c->d.T,  \
+                               c->rec, c->lambda, pd_stride, c->K, c->k, c->delta_J, c->status);             \
+        else                                                                                                 \
+            hipLaunchKernelGGL((k_backward_fused<NN, MM>), grid, block, 0, c->stream, c->L, F, c->d.T,       \
+                               c->rec, c->lambda, pd_stride, c->K, c->k, c->delta_J, c->status);             \
+    } while (0)
+    if (n == 14 && m == 7) LAUNCH(14, 7);
+    else if (n == 4 && m == 1) LAUNCH(4, 1);
+    else return hipErrorInvalidValue;
+#undef LAUNCH
+    return hipGetLastError();
+}
+
+hipError_t launch_forward_fused(Ctx *c, double *U_alpha_dev)
+{
+    const int n = c->n, m = c->d.m;
+    dim3 grid(c->d.batch), block(64);
+    const bool excl = c->d.batch <= c->n_simd;
+    const FusedArgs F = fused_args(c);
+#define LAUNCH(NCZ, NCU)                                                                                          \
+    do {                                                                                                          \
+        if (excl)                                                                                                 \
+            hipLaunchKernelGGL((k_forward_fused_excl<NCZ, NCU>), grid, block, 0, c->stream, c->L, F, c->d.T,      \
+                               c->d.n_alpha, c->rec, c->K, c->k, c->u_nom, c->ctrl_lim, c->alphas, c->cost_pred,  \
+                               U_alpha_dev);                                                                      \
+        else                                                                                                      \
+            hipLaunchKernelGGL((k_forward_fused<NCZ, NCU>), grid, block, 0, c->stream, c->L, F, c->d.T,           \
+                               c->d.n_alpha, c->rec, c->K, c->k, c->u_nom, c->ctrl_lim, c->alphas, c->cost_pred,  \
+                               U_alpha_dev);                                                                      \
+    } while (0)
+    if (n == 14 && m == 7) LAUNCH(4, 2);
+    else if (n == 4 && m == 1) LAUNCH(2, 1);
+    else return hipErrorInvalidValue;
+#undef LAUNCH
+    return hipGetLastError();
+}
+
+}  // namespace kpilqr

@@ -119,6 +119,11 @@ int kpilqr_create(const kpilqr_dims *dims, void *stream, kpilqr_ctx **out)
                    : (!generic && backward_tiled_supported(c->n, dims->m)) ? "mfma_f64_tiled" : "generic_lds";
     c->fwd_variant = (!generic && !force_tiled && forward_mfma_supported(c->n, dims->m, dims->n_alpha)) ? "mfma_f64_t1"
                    : (!generic && forward_tiled_supported(c->n, dims->m, dims->n_alpha)) ? "mfma_f64_tiled" : "generic_lds";
+    if ((dims->flags & KPILQR_FLAG_FUSED) && !generic && !force_tiled &&
+        fused_supported(c->n, dims->m, dims->nr, dims->dof, dims->T, c->L.stride, dims->n_alpha)) {
+        c->fused = true;
+        c->bwd_variant = c->fwd_variant = "mfma_f64_t1_fused";
+    }
     if (strcmp(c->bwd_variant, "generic_lds") == 0 && backward_generic_lds_bytes(c->n, dims->m) > 160 * 1024) {
         kpilqr_destroy(c);
         return set_err(nullptr, KPILQR_ERR_ARG, "state dimension too large for the generic backward kernel (LDS)");
@@ -204,6 +209,13 @@ int kpilqr_set_keypoints(kpilqr_ctx *c, const int *kp_offsets, const int *kp_tim
         if (kp_offsets[i + 1] < kp_offsets[i]) return set_err(c, KPILQR_ERR_ARG, "kp_offsets not monotone");
     for (int i = 0; i < total; i++)
         if (kp_times[i] < 0 || kp_times[i] >= c->d.T) return set_err(c, KPILQR_ERR_ARG, "kp_times out of [0,T)");
+    bool canonical = true;
+    for (size_t i = 0; i < nlists && canonical; i++) {
+        const int a = kp_offsets[i], e = kp_offsets[i + 1];
+        if (e <= a || kp_times[a] != 0 || kp_times[e - 1] != c->d.T - 1) { canonical = false; break; }
+        for (int j = a + 1; j < e; j++) if (kp_times[j] <= kp_times[j - 1]) { canonical = false; break; }
+    }
+    c->kp_canonical = canonical;
     if ((size_t)total > c->kp_cap) {
         if (c->kp_times) { KP_HIP(c, hipStreamSynchronize(c->stream)); KP_HIP(c, hipFree(c->kp_times)); c->kp_times = nullptr; }
         c->kp_cap = (size_t)total + (size_t)total / 4 + 64;
@@ -330,8 +342,22 @@ int kpilqr_trajectory_cost(kpilqr_ctx *c, double *cost)
 }
 
 // ---- STEP 2 -------------------------------------------------------------------------------------
+static int check_fused(kpilqr_ctx *c)
+{
+    if (!c->have_kp) return set_err(c, KPILQR_ERR_STATE, "fused sweeps need kpilqr_set_keypoints first");
+    if (!c->kp_canonical)
+        return set_err(c, KPILQR_ERR_STATE, "fused sweeps need canonical key-points (per DoF: strictly increasing, first 0, last T-1)");
+    return KPILQR_OK;
+}
+
 static int run_backward(kpilqr_ctx *c, int pd_stride)
 {
+    if (c->fused) {
+        int rc = check_fused(c);
+        if (rc) return rc;
+        KP_HIP(c, launch_backward_fused(c, pd_stride));
+        return KPILQR_OK;
+    }
     if (strcmp(c->bwd_variant, "mfma_f64_t1") == 0) KP_HIP(c, launch_backward_mfma(c, pd_stride));
     else if (strcmp(c->bwd_variant, "mfma_f64_tiled") == 0) KP_HIP(c, launch_backward_tiled(c, pd_stride));
     else KP_HIP(c, launch_backward_generic(c, pd_stride));
@@ -382,6 +408,12 @@ static int ensure_stage(kpilqr_ctx *c, size_t bytes)
 
 static int run_forward(kpilqr_ctx *c, double *U_dev)
 {
+    if (c->fused) {
+        int rc = check_fused(c);
+        if (rc) return rc;
+        KP_HIP(c, launch_forward_fused(c, U_dev));
+        return KPILQR_OK;
+    }
     if (strcmp(c->fwd_variant, "mfma_f64_t1") == 0) KP_HIP(c, launch_forward_mfma(c, U_dev));
     else if (strcmp(c->fwd_variant, "mfma_f64_tiled") == 0) KP_HIP(c, launch_forward_tiled(c, U_dev));
     else KP_HIP(c, launch_forward_generic(c, U_dev));
@@ -415,8 +447,10 @@ int kpilqr_iterate(kpilqr_ctx *c, const double *lambda, int pd_check_stride, con
     if (lambda) KP_HIP(c, hipMemcpyAsync(c->lambda, lambda, (size_t)c->d.batch * 8, hipMemcpyHostToDevice, c->stream));
     if (alphas) KP_HIP(c, hipMemcpyAsync(c->alphas, alphas, (size_t)c->d.n_alpha * 8, hipMemcpyHostToDevice, c->stream));
     KP_HIP(c, launch_fd_difference(c));
-    KP_HIP(c, launch_interpolate(c));
-    KP_HIP(c, launch_cost_derivs(c));
+    if (!c->fused) {              // the fused sweeps interpolate A,B and form l_* themselves
+        KP_HIP(c, launch_interpolate(c));
+        KP_HIP(c, launch_cost_derivs(c));
+    }
     int rc = run_backward(c, pd_check_stride);
     if (rc) return rc;
     return run_forward(c, nullptr);

@@ -40,11 +40,11 @@ class _DeviceArray:
 
 
 class Engine:
-    def __init__(self, dof, m, T, nr, batch=1, n_alpha=6, device=0, stream=None, generic=False, tiled=False):
+    def __init__(self, dof, m, T, nr, batch=1, n_alpha=6, device=0, stream=None, generic=False, tiled=False, fused=False):
         self._L = _lib.load()
         self.dof, self.n, self.m, self.T, self.nr = dof, 2 * dof, m, T, nr
         self.batch, self.n_alpha, self.device = batch, n_alpha, device
-        d = _lib.Dims(dof, m, T, nr, batch, n_alpha, device, (_lib.FLAG_GENERIC_KERNELS if generic else 0) | (_lib.FLAG_TILED_KERNELS if tiled else 0))
+        d = _lib.Dims(dof, m, T, nr, batch, n_alpha, device, (_lib.FLAG_GENERIC_KERNELS if generic else 0) | (_lib.FLAG_TILED_KERNELS if tiled else 0) | (_lib.FLAG_FUSED if fused else 0))
         h = C.c_void_p()
         rc = self._L.kpilqr_create(C.byref(d), C.c_void_p(stream) if stream else None, C.byref(h))
         if rc != 0:
