@@ -4,7 +4,10 @@
 One "step" = one whole GPU-side iLQR iteration for every trajectory of the batch:
     fd_difference (a2) -> interpolate (a4) -> cost_derivs (a6) -> backward pass (a7, one pass at a
     valid lambda) -> linearised forward pass over the 6 line-search alphas (a8)
-with all inputs (host FD results, residuals and their Jacobians, nominal controls) already resident
+By default a4 and a6 run INSIDE the two sweeps (KPILQR_FLAG_FUSED, trajoptkp_amd/csrc/fused_mfma.hip:
+three launches per iteration, A/B/l_* never written to HBM); `--unfused` times the materialising
+five-kernel pipeline instead, and at N=1 the default run reports it beside the headline number
+("materialising_pipeline").  All inputs (host FD results, residuals and their Jacobians, nominal controls) already resident
 in HBM when the timed region starts.  Workload (N=1 and per rank for N>1, weak scaling): Franka Panda
 7-DoF reaching, T=3000, set-interval key-points every 5 steps, batch=1024 independent trajectories
 (BASELINE configs[3]; configs[1] is the same problem at batch=1: `--batch 1`).
@@ -81,8 +84,10 @@ def main():
     ap.add_argument("--task", default="panda_reaching")
     ap.add_argument("--unique", type=int, default=8, help="distinct seeded trajectories, tiled to --batch")
     ap.add_argument("--generic", action="store_true", help="force the generic (non-MFMA) kernels")
-    ap.add_argument("--fused", action="store_true",
-                    help="KPILQR_FLAG_FUSED: interpolation (a4) and cost derivatives (a6) evaluated inside the sweeps")
+    ap.add_argument("--unfused", action="store_true",
+                    help="materialise A,B (interpolate) and l_* (cost_derivs) with their own kernels instead of "
+                         "evaluating them inside the sweeps (KPILQR_FLAG_FUSED)")
+    ap.add_argument("--no-secondary", action="store_true", help="skip the materialising-pipeline side measurement")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     args = ap.parse_args()
 
@@ -118,7 +123,7 @@ def main():
     stream = torch.cuda.Stream()
     torch.cuda.set_stream(stream)
     eng = Engine(p["dof"], p["m"], T, p["nr"], batch=B, device=local_rank, stream=stream.cuda_stream,
-                 generic=args.generic, fused=args.fused)
+                 generic=args.generic, fused=not args.unfused and not args.generic)
     fused = "fused" in eng.backward_variant
     synth.upload(eng, p)
     lam = np.full(B, p["lam"])
@@ -185,6 +190,35 @@ def main():
                 for i, name in enumerate(stages)}
     res = eng.results()
     n_ok = int((res["status"] == 0).sum())
+    variants = {"backward": eng.backward_variant, "forward": eng.forward_variant}
+
+    # side measurement (N=1 only, outside the timed region above): the materialising five-kernel pipeline
+    secondary = None
+    if fused and world == 1 and not args.no_secondary:
+        eng.close()
+        eng = Engine(p["dof"], p["m"], T, p["nr"], batch=B, device=local_rank, stream=stream.cuda_stream, fused=False)
+        synth.upload(eng, p)
+        eng.fd_difference(); eng.interpolate(); eng.cost_derivs()
+        eng.backward(lam, 100, fetch=False); eng.forward_linear(alphas, fetch=False); eng.sync()
+        st2 = ("fd_difference", "interpolate", "cost_derivs", "backward", "forward")
+        calls = {"fd_difference": eng.fd_difference, "interpolate": eng.interpolate, "cost_derivs": eng.cost_derivs,
+                 "backward": lambda: eng.backward(None, 100, fetch=False), "forward": lambda: eng.forward_linear(None, fetch=False)}
+        k2 = max(3, min(args.steps, 10))
+        for _ in range(2):
+            for nm in st2: calls[nm]()
+        torch.cuda.synchronize()
+        ev2 = [[(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in st2] for _ in range(k2)]
+        t1 = time.perf_counter()
+        for s_ in range(k2):
+            for i, nm in enumerate(st2):
+                ev2[s_][i][0].record(stream); calls[nm](); ev2[s_][i][1].record(stream)
+        torch.cuda.synchronize()
+        el2 = time.perf_counter() - t1
+        ms2 = {nm: float(np.mean([ev2[s_][i][0].elapsed_time(ev2[s_][i][1]) for s_ in range(k2)])) for i, nm in enumerate(st2)}
+        secondary = {"value": B * k2 / el2, "unit": "trajectory-iterations/s", "steps": k2, "ms_per_step": 1e3 * el2 / k2,
+                     "kernels": {"backward": eng.backward_variant, "forward": eng.forward_variant}, "stage_ms": ms2,
+                     "stage_algorithmic_GBps": {k: ab[k] * B / (ms2[k] * 1e-3) / 1e9 for k in st2},
+                     "backward_roofline_frac": ab["backward"] * B / (ms2["backward"] * 1e-3) / 1e9 / HBM_PEAK_GBS}
 
     if rank == 0:
         total_traj = B * world
@@ -201,7 +235,9 @@ def main():
         except Exception:
             traffic = None
         kb = ab_fused if fused else ab          # bytes each launched kernel must move
-        achieved = kb[dom] * B / (stage_ms[dom] * 1e-3) / 1e9
+        # roofline numerator: SURVEY.md 8(d)'s riccati_bwd figure (A,B,l_* in, K,k out) in both modes, so the
+        # fraction stays comparable; the fused kernel's own compulsory HBM I/O is reported beside it
+        achieved = ab[dom] * B / (stage_ms[dom] * 1e-3) / 1e9
         out = {
             "metric": "iLQR iterations/sec (Panda 7-DoF, T=3000)" if args.task == "panda_reaching" and T == 3000
                       else f"iLQR iterations/sec ({args.task}, T={T})",
@@ -212,16 +248,21 @@ def main():
                                    f"batch={B}/GPU ({uniq} distinct seeds tiled), 6 alphas, lambda={p['lam']}"
                                    + (", fused sweeps (a4+a6 inside a7/a8)" if fused else ""),
                        "batch_per_gpu": B, "global_batch": total_traj, "horizon": T,
-                       "kernels": {"backward": eng.backward_variant, "forward": eng.forward_variant},
+                       "kernels": variants,
                        "valid_backward_passes": n_ok, "parallelism": f"traj-shard x{world}"},
             "batch_iterations_per_s": args.steps / elapsed,
             "stage_ms": stage_ms,
             "stage_algorithmic_GBps": {k: kb[k] * B / (stage_ms[k] * 1e-3) / 1e9 for k in stages},
             "pipeline_algorithmic_GBps": sum(ab.values()) * B / (elapsed / args.steps) / 1e9,
-            "roofline": {"bound": "hbm", "kernel": f"backward ({eng.backward_variant})", "achieved": achieved,
+            "roofline": {"bound": "hbm", "kernel": f"backward ({variants['backward']})", "achieved": achieved,
                          "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
-                         "algorithmic_bytes_per_launch": kb[dom] * B, "avg_launch_ms": stage_ms[dom]},
+                         "algorithmic_bytes_per_launch": ab[dom] * B, "avg_launch_ms": stage_ms[dom],
+                         "kernel_compulsory_bytes_per_launch": kb[dom] * B,
+                         "iteration_algorithmic_GBps": sum(ab.values()) * B / (elapsed / args.steps) / 1e9,
+                         "iteration_frac_of_hbm_peak": sum(ab.values()) * B / (elapsed / args.steps) / 1e9 / HBM_PEAK_GBS},
         }
+        if secondary is not None:
+            out["materialising_pipeline"] = secondary
         if world == 1 and not args.no_cpu_baseline:
             try:
                 out["cpu_baseline"] = cpu_baseline(args.task, T, args.min_N)
