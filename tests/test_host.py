@@ -82,3 +82,29 @@ def test_acrobot_plumbing_optimise_on_gpu():
     for method in ("iterative_error", "adaptive_jerk", "velocity_change"):
         r2 = host.run_acrobot(T=100, min_N=2, max_iter=3, min_iter=1, method=method, torque_weight=1e-3)
         assert r2["cost_history"][1] < r2["cost_history"][0], (method, r2["cost_history"])
+
+
+def test_fd_harness_pool_matches_spawn_per_call_and_is_deterministic():
+    """the persistent-pool FD harness produces exactly the job set of the reference-shaped
+    spawn-per-call path (bit for bit, order-independent checksum) in an order that does not depend on thread
+    scheduling.  CPU only (the acrobot stand-in simulator)."""
+    a = host.fd_bench(T=400, reps=2, mode=0, fd_threads=8)
+    b = host.fd_bench(T=400, reps=2, mode=1, fd_threads=8)
+    c = host.fd_bench(T=400, reps=3, mode=1, fd_threads=3)
+    assert a["columns"] == b["columns"] == 2 * 400 * 5            # (ctrl + vel + pos) + (vel + pos) per step
+    assert a["checksum_set"] == b["checksum_set"] == c["checksum_set"]
+    assert b["checksum_order"] == c["checksum_order"]             # in-place slices: order fixed by key-point time
+    assert b["pool"] >= 1
+
+
+@pytest.mark.gpu
+def test_acrobot_fused_unfused_and_analytic_residual_jacobians_agree():
+    """The optimiser shim on the fused sweeps (default), on the materialising pipeline, and with closed-form
+    residual Jacobians: same accepted cost sequence to FD accuracy."""
+    base = host.run_acrobot(T=100, min_N=5, max_iter=6, min_iter=2, torque_weight=1e-3)
+    unf = host.run_acrobot(T=100, min_N=5, max_iter=6, min_iter=2, method="set_interval+unfused", torque_weight=1e-3)
+    ana = host.run_acrobot(T=100, min_N=5, max_iter=6, min_iter=2, method="set_interval+analytic", torque_weight=1e-3)
+    assert base["iterations"] == unf["iterations"] == ana["iterations"]
+    assert np.allclose(base["cost_history"], unf["cost_history"], rtol=1e-7)
+    assert np.allclose(base["cost_history"], ana["cost_history"], rtol=1e-5)
+    assert np.allclose(base["K0"], unf["K0"], rtol=1e-6, atol=1e-9)

@@ -32,6 +32,8 @@ def load_host():
     H.kpilqr_host_keypoints.restype = C.c_int
     H.kpilqr_host_run_acrobot.argtypes = [C.c_int, C.c_int, C.c_int, C.c_int, C.c_char_p, C.c_double, vp, C.c_int, vp, vp, vp]
     H.kpilqr_host_run_acrobot.restype = C.c_int
+    H.kpilqr_host_fd_bench.argtypes = [C.c_int, C.c_int, C.c_int, C.c_int, vp, vp, vp]
+    H.kpilqr_host_fd_bench.restype = C.c_int
     _host = H
     return H
 
@@ -62,3 +64,13 @@ def run_acrobot(T=100, min_N=5, max_iter=5, min_iter=2, method="set_interval", t
         raise RuntimeError(f"kpilqr_host_run_acrobot failed: {it}")
     return dict(iterations=it, cost_history=hist[:it + 1].copy(), U=U, K0=K0,
                 timings_ms=dict(derivs=tm[0], backward=tm[1], forward=tm[2], total=tm[3]))
+
+
+def fd_bench(T=3000, reps=5, mode=1, fd_threads=16):
+    """Host FD harness microbenchmark (no GPU): mode 0 = threads spawned per call + merge (the reference's
+    shape), mode 1 = persistent pool writing in place.  Returns dict(seconds, columns, columns_per_s, pool, checksums)."""
+    H = load_host()
+    sec = C.c_double(0.0); cols = C.c_long(0); chk = np.zeros(2)
+    pool = H.kpilqr_host_fd_bench(T, reps, mode, fd_threads, C.byref(sec), C.byref(cols), _p(chk))
+    return dict(seconds=sec.value, columns=cols.value, columns_per_s=cols.value / max(sec.value, 1e-12), pool=pool,
+                checksum_set=chk[0], checksum_order=chk[1])

@@ -63,6 +63,16 @@ void AcrobotTranslator::Residuals(SimData *d, MatrixXd &r)     // Acrobot.cpp:26
     r(0) = d->q[0]; r(1) = d->q[1]; r(2) = d->v[0]; r(3) = d->v[1]; r(4) = d->u[0];
 }
 
+bool AcrobotTranslator::ResidualJacobians(SimData *, double *r_x, double *r_u)
+{
+    if (!analytic_residual_jacobians) return false;
+    for (int j = 0; j < 5; j++) {
+        for (int i = 0; i < 4; i++) r_x[j * 4 + i] = (j == i) ? 1.0 : 0.0;
+        r_u[j] = (j == 4) ? 1.0 : 0.0;
+    }
+    return true;
+}
+
 MatrixXd AcrobotTranslator::ReturnStateVector(SimData *d, const stateVectorList &)
 {
     MatrixXd x(4, 1);

@@ -33,5 +33,9 @@ public:
     MatrixXd ReturnControlVector(SimData *d, const stateVectorList &) override;
     bool SetControlVector(const MatrixXd &u, SimData *d, const stateVectorList &) override;
     MatrixXd ReturnControlLimits(const stateVectorList &) override;
+    // r = [q, qdot, u] is linear: r_x = [I4; 0], r_u = e5 (used only when analytic_residual_jacobians is set;
+    // off by default so that the plumbing run differences Residuals() exactly as the reference does)
+    bool ResidualJacobians(SimData *d, double *r_x, double *r_u) override;
+    bool analytic_residual_jacobians = false;
     double torque_limit = 100.0;
 };

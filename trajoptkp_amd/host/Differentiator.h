@@ -4,9 +4,12 @@
 // after it -- subtract, scale, scatter into A and B (:166-222,286-321,386-423,441-457) -- is the GPU's
 // fd_difference stage, so this class only FILLS the job arrays of kpilqr_upload_fd.
 #pragma once
+#include <atomic>
+#include <functional>
 #include <memory>
 #include <vector>
 #include "ModelTranslator.h"
+#include "ThreadPool.h"
 
 // One batch of FD jobs in the layout of kpilqr_upload_fd (include/kpilqr.h).
 struct FDJobs {
@@ -16,6 +19,24 @@ struct FDJobs {
     int njobs() const { return (int)job_t.size(); }
     int nnom(int n) const { return n ? (int)(xnom.size() / n) : 0; }
     void clear() { job_b.clear(); job_t.clear(); job_col.clear(); job_nom.clear(); job_mode.clear(); xplus.clear(); xminus.clear(); xnom.clear(); }
+};
+
+// The same job arrays as raw, reusable buffers that the FD workers fill IN PLACE, each key-point writing its
+// own slice -- no per-thread vectors, no merge, and the order (ascending key-point time, then the reference's
+// column order) does not depend on thread scheduling.  With `alloc`/`release` bound to kpilqr_host_alloc /
+// kpilqr_host_free the buffers are pinned and kpilqr_upload_fd is one DMA per array (north star: "residuals
+// shipped in one pinned hipMemcpyAsync").
+struct FDStaging {
+    std::function<void *(size_t)> alloc;          // default: malloc
+    std::function<void(void *)> release;          // default: free
+    int *job_b = nullptr, *job_t = nullptr, *job_col = nullptr, *job_nom = nullptr;
+    unsigned char *job_mode = nullptr;
+    double *xplus = nullptr, *xminus = nullptr, *xnom = nullptr;
+    int njobs = 0, nnom = 0, n = 0;
+    size_t cap_jobs = 0, cap_nom = 0;
+    ~FDStaging() { free_all(); }
+    void reserve(size_t jobs, size_t noms, int n_);
+    void free_all();
 };
 
 class Differentiator {
@@ -34,8 +55,18 @@ public:
     // r_x [nr][n], r_u [nr][m] at saved state `data_index` by central differences of Residuals()
     void ResidualDerivatives(double *r_x, double *r_u, int data_index, int tid, double eps);
 
-    int count_integrations = 0;
+    // All key-points of one trajectory into `st` (appended after what is already there when `append`), on the
+    // persistent pool.  Jobs of one key-point are contiguous; key-points in ascending time.
+    void DynamicsDerivativesBatch(FDStaging &st, int b, const std::vector<std::vector<int>> &keypoints, double eps,
+                                  bool append = false);
+    // Residual Jacobians of the saved states 0..T into r_x [T+1][nr][n], r_u [T+1][nr][m] on the pool; a task
+    // that knows them in closed form (ModelTranslator::ResidualJacobians) skips the differencing altogether.
+    void ResidualDerivativesAll(double *r_x, double *r_u, int T, double eps);
+
+    std::atomic<long> count_integrations{0};
+    ThreadPool &pool();
 private:
+    std::unique_ptr<ThreadPool> pool_;
     std::shared_ptr<ModelTranslator> model_translator;
     std::shared_ptr<PhysicsSimulator> MuJoCo_helper;
 };

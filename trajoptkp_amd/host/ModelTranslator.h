@@ -22,6 +22,11 @@ public:
         }
         return cost;
     }
+    // Optional closed-form residual Jacobians at state d: r_x [nr][n], r_u [nr][m] (row-major).  Return true
+    // when filled; the default (false) makes the Differentiator finite-difference Residuals() as the
+    // reference does (src/Differentiator/Differentiator.cpp:464-663).  Tasks like reaching
+    // (src/ModelTranslator/Reaching.cpp:43-54: r = [q - q*, qdot]) have constant selector Jacobians.
+    virtual bool ResidualJacobians(SimData *d, double *r_x, double *r_u) { (void)d; (void)r_x; (void)r_u; return false; }
     virtual MatrixXd ReturnStateVector(SimData *d, const stateVectorList &sv) = 0;       // [q; qdot], 2*dof x 1
     virtual bool SetStateVector(const MatrixXd &x, SimData *d, const stateVectorList &sv) = 0;
     virtual MatrixXd ReturnControlVector(SimData *d, const stateVectorList &sv) = 0;

@@ -1,5 +1,6 @@
 // host_capi.cpp -- small C entry points over the C++ host classes so that the Python tests can drive
 // them (key-point generators against the oracle; the acrobot plumbing optimisation end to end).
+#include <chrono>
 #include <cstring>
 #include <memory>
 
@@ -44,8 +45,14 @@ int kpilqr_host_run_acrobot(int T, int min_N, int max_iter, int min_iter, const 
                             double torque_weight /* <0: task default 100 */,
                             double *cost_history, int cost_cap, double *U_out, double *K0_out, double *timings_ms)
 {
+    // keypoint_method_name may carry options after a '+': "set_interval+unfused", "set_interval+analytic"
+    std::string spec = keypoint_method_name ? keypoint_method_name : "";
+    const bool unfused = spec.find("+unfused") != std::string::npos, analytic = spec.find("+analytic") != std::string::npos;
+    if (spec.find('+') != std::string::npos) spec = spec.substr(0, spec.find('+'));
+    keypoint_method_name = spec.empty() ? nullptr : spec.c_str();
     auto sim = std::make_shared<AcrobotSimulator>(0.01, 8);
     auto mt = std::make_shared<AcrobotTranslator>(sim);
+    mt->analytic_residual_jacobians = analytic;
     mt->min_N = min_N;
     if (torque_weight >= 0) { mt->residual_list[4].weight = torque_weight; mt->residual_list[4].weight_terminal = torque_weight; }
     if (keypoint_method_name) mt->keypoint_method = keypoint_method_name;
@@ -54,6 +61,7 @@ int kpilqr_host_run_acrobot(int T, int min_N, int max_iter, int min_iter, const 
     auto diff = std::make_shared<Differentiator>(mt, sim);
     iLQR_GPU opt(mt, sim, diff, T);
     if (!opt.ok()) return -2;
+    if (unfused) opt.SetFused(false);
     std::vector<MatrixXd> U0(T, MatrixXd(1, 1));
     std::vector<MatrixXd> U = opt.Optimise(sim->main_data, U0, max_iter, min_iter, T);
     const int nh = (int)opt.cost_history.size();
@@ -62,6 +70,54 @@ int kpilqr_host_run_acrobot(int T, int min_N, int max_iter, int min_iter, const 
     if (K0_out) for (int c = 0; c < 4; c++) K0_out[c] = opt.K[0](0, c);
     if (timings_ms) { timings_ms[0] = opt.avg_time_get_derivs_ms; timings_ms[1] = opt.avg_time_backwards_pass_ms; timings_ms[2] = opt.avg_time_forwards_pass_ms; timings_ms[3] = opt.opt_time_ms; }
     return opt.num_iterations;
+}
+
+// Host FD-harness microbenchmark (no GPU involved): Acrobot, T saved states, every DoF
+// a key-point at every step, `reps` derivative calls.  mode 0 = the reference's shape (threads created and
+// joined per call, per-thread vectors merged); mode 1 = persistent pool writing in place into the staging
+// arrays.  seconds = wall time of the reps; columns = FD columns produced; checksum[0] is order-independent
+// (both modes must agree bit for bit), checksum[1] depends on the job order (mode 1 must reproduce it).
+int kpilqr_host_fd_bench(int T, int reps, int mode, int fd_threads, double *seconds, long *columns, double *checksum)
+{
+    auto sim = std::make_shared<AcrobotSimulator>(0.01, fd_threads);
+    auto mt = std::make_shared<AcrobotTranslator>(sim);
+    sim->main_data->q[0] = 3.1415; sim->main_data->q[1] = 0.3;
+    for (int t = 0; t < T; t++) {
+        sim->main_data->u[0] = 0.5 * ((t % 7) - 3);
+        sim->AppendSystemStateToEnd(sim->main_data);
+        sim->ForwardSimulator(sim->main_data);
+    }
+    Differentiator diff(mt, sim);
+    std::vector<std::vector<int>> keypoints(T, std::vector<int>{0, 1});
+    const int n = 4;
+    FDJobs jobs;
+    FDStaging st;
+    diff.pool();                                         // pool construction is not part of a call
+    const auto t0 = std::chrono::high_resolution_clock::now();
+    for (int r = 0; r < reps; r++) {
+        if (mode == 0) { jobs.clear(); diff.DynamicsDerivativesAtKeypoints(jobs, 0, keypoints, 1e-6); }
+        else diff.DynamicsDerivativesBatch(st, 0, keypoints, 1e-6);
+    }
+    *seconds = std::chrono::duration<double>(std::chrono::high_resolution_clock::now() - t0).count();
+    const int nj = mode == 0 ? jobs.njobs() : st.njobs;
+    *columns = (long)nj * reps;
+    unsigned long long h0 = 0;       // wrap-around integer sum of the bit patterns: exact and order-independent
+    double c1 = 0.0;
+    for (int j = 0; j < nj; j++) {
+        const int t = mode == 0 ? jobs.job_t[j] : st.job_t[j], col = mode == 0 ? jobs.job_col[j] : st.job_col[j];
+        const double *xp = mode == 0 ? &jobs.xplus[(size_t)j * n] : st.xplus + (size_t)j * n;
+        const double *xm = mode == 0 ? &jobs.xminus[(size_t)j * n] : st.xminus + (size_t)j * n;
+        double sj = 0.0;
+        for (int i = 0; i < n; i++) {
+            unsigned long long bp, bm;
+            std::memcpy(&bp, &xp[i], 8); std::memcpy(&bm, &xm[i], 8);
+            h0 += (bp * (unsigned long long)(i + 1) + bm * (unsigned long long)(i + 7)) * (unsigned long long)(1 + t * 31 + col);
+            sj += (i + 1) * xp[i] - (i + 2) * xm[i];
+        }
+        c1 = c1 * 0.999 + sj * (j % 13 + 1);
+    }
+    if (checksum) { checksum[0] = (double)(h0 & ((1ull << 52) - 1)); checksum[1] = c1; }
+    return diff.pool().size();
 }
 
 }  // extern "C"

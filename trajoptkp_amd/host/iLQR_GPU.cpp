@@ -27,22 +27,38 @@ iLQR_GPU::iLQR_GPU(std::shared_ptr<ModelTranslator> mt, std::shared_ptr<PhysicsS
     Resize(mt->current_state_vector.dof, mt->current_state_vector.num_ctrl, horizon);
 }
 
-iLQR_GPU::~iLQR_GPU() { if (ctx) kpilqr_destroy(ctx); }
+void iLQR_GPU::free_pinned()
+{
+    staging.free_all();
+    double **all[] = {&host_r, &host_rx, &host_ru, &host_unom, &host_K, &host_k};
+    for (double **p : all) { if (*p && ctx) kpilqr_host_free(ctx, *p); *p = nullptr; }
+}
+
+iLQR_GPU::~iLQR_GPU()
+{
+    if (ctx) { kpilqr_sync(ctx); free_pinned(); kpilqr_destroy(ctx); }
+}
 
 void iLQR_GPU::Resize(int new_num_dofs, int new_num_ctrl, int new_horizon)
 {
-    if (new_num_dofs == dof && new_num_ctrl == num_ctrl && new_horizon == horizon_length && ctx) return;
+    if (new_num_dofs == dof && new_num_ctrl == num_ctrl && new_horizon == horizon_length && ctx && !recreate_ctx) return;
+    recreate_ctx = false;
     dof = new_num_dofs; num_ctrl = new_num_ctrl; horizon_length = new_horizon;
     const int n = 2 * dof, m = num_ctrl, T = horizon_length, nr = (int)activeModelTranslator->residual_list.size();
-    if (ctx) { kpilqr_destroy(ctx); ctx = nullptr; }
-    kpilqr_dims d = {dof, m, T, nr, 1, num_parallel_rollouts, device, 0};
+    if (ctx) { kpilqr_sync(ctx); free_pinned(); kpilqr_destroy(ctx); ctx = nullptr; }
+    kpilqr_dims d = {dof, m, T, nr, 1, num_parallel_rollouts, device, use_fused ? KPILQR_FLAG_FUSED : 0};
     const int rc = kpilqr_create(&d, nullptr, &ctx);
     if (rc != KPILQR_OK) { last_error = kpilqr_strerror(nullptr); ctx = nullptr; std::fprintf(stderr, "iLQR_GPU: %s\n", last_error.c_str()); std::exit(1); }
+    fused_active = std::string(kpilqr_backward_variant(ctx)).find("fused") != std::string::npos;
+    // every host <-> device payload lives in pinned memory owned by the context
+    staging.alloc = [this](size_t bytes) { void *p = nullptr; if (kpilqr_host_alloc(ctx, bytes, &p)) fatal("kpilqr_host_alloc", -4); return p; };
+    staging.release = [this](void *p) { if (ctx) kpilqr_host_free(ctx, p); };
+    auto pinned = [&](size_t count) { void *p = nullptr; if (kpilqr_host_alloc(ctx, std::max<size_t>(count, 1) * sizeof(double), &p)) fatal("kpilqr_host_alloc", -4); std::fill((double *)p, (double *)p + count, 0.0); return (double *)p; };
+    host_r = pinned((size_t)(T + 1) * nr); host_rx = pinned((size_t)(T + 1) * nr * n); host_ru = pinned((size_t)(T + 1) * nr * m);
+    host_unom = pinned((size_t)T * m); host_K = pinned((size_t)T * n * m); host_k = pinned((size_t)T * m);
     U_old.assign(T, MatrixXd(m, 1)); X_old.assign(T + 1, MatrixXd(n, 1)); X_new.assign(T + 1, MatrixXd(n, 1));
     residuals.assign(T + 1, MatrixXd(nr, 1));
     K.assign(T, MatrixXd(m, n)); k.assign(T, MatrixXd(m, 1));
-    host_r.assign((size_t)(T + 1) * nr, 0.0); host_rx.assign((size_t)(T + 1) * nr * n, 0.0); host_ru.assign((size_t)(T + 1) * nr * m, 0.0);
-    host_unom.assign((size_t)T * m, 0.0); host_K.assign((size_t)T * n * m, 0.0); host_k.assign((size_t)T * m, 0.0);
     w_run.clear(); w_term.clear();
     for (const residual &r : activeModelTranslator->residual_list) { w_run.push_back(r.weight); w_term.push_back(r.weight_terminal); }
     const MatrixXd lim = activeModelTranslator->ReturnControlLimits(activeModelTranslator->current_state_vector);
@@ -109,7 +125,7 @@ std::vector<MatrixXd> iLQR_GPU::Optimise(SimData *d, std::vector<MatrixXd> initi
 void iLQR_GPU::GenerateDerivatives()
 {
     const stateVectorList &sv = activeModelTranslator->current_state_vector;
-    const int n = 2 * dof, m = num_ctrl, T = horizon_length, nr = (int)w_run.size();
+    const int n = 2 * dof, T = horizon_length, nr = (int)w_run.size();
     const double eps = 1e-6;                                     // Optimiser.cpp:319-321
     keypoint_generator->ResetCache();
     KeypointGenerator::ColumnFD col_fd = [&](int t, int i, double *cp, double *cv) {
@@ -126,21 +142,21 @@ void iLQR_GPU::GenerateDerivatives()
     keypoint_generator->PerDofCSR(offs, times);
     int rc = kpilqr_set_keypoints(ctx, offs.data(), times.data());
     if (rc) fatal("kpilqr_set_keypoints", rc);
-    jobs.clear();
-    activeDifferentiator->DynamicsDerivativesAtKeypoints(jobs, 0, keypoint_generator->keypoints, eps);
-    rc = kpilqr_upload_fd(ctx, jobs.njobs(), jobs.job_b.data(), jobs.job_t.data(), jobs.job_col.data(), jobs.job_mode.data(),
-                          jobs.job_nom.data(), jobs.xplus.data(), jobs.xminus.data(), jobs.nnom(n), jobs.xnom.data(), eps);
+    // FD at the key-points on the persistent pool, straight into the pinned job arrays (one DMA per array)
+    if ((rc = kpilqr_sync(ctx))) fatal("kpilqr_sync", rc);        // the previous upload has left the staging buffers
+    activeDifferentiator->DynamicsDerivativesBatch(staging, 0, keypoint_generator->keypoints, eps);
+    rc = kpilqr_upload_fd(ctx, staging.njobs, staging.job_b, staging.job_t, staging.job_col, staging.job_mode,
+                          staging.job_nom, staging.xplus, staging.xminus, staging.nnom, staging.xnom, eps);
     if (rc) fatal("kpilqr_upload_fd", rc);
     if ((rc = kpilqr_fd_difference(ctx))) fatal("kpilqr_fd_difference", rc);
-    if ((rc = kpilqr_interpolate(ctx))) fatal("kpilqr_interpolate", rc);
-    // residuals and their FD Jacobians at every step (Optimiser::ComputeResidualDerivatives, :217-236)
-    for (int t = 0; t <= T; t++) {
+    if (!fused_active && (rc = kpilqr_interpolate(ctx))) fatal("kpilqr_interpolate", rc);
+    // residuals and their Jacobians at every step (Optimiser::ComputeResidualDerivatives, :217-236)
+    for (int t = 0; t <= T; t++)
         for (int i = 0; i < nr; i++) host_r[(size_t)t * nr + i] = residuals[t](i);
-        activeDifferentiator->ResidualDerivatives(&host_rx[(size_t)t * nr * n], &host_ru[(size_t)t * nr * m], std::min(t, T), 0, eps);
-    }
-    rc = kpilqr_upload_residuals(ctx, host_r.data(), host_rx.data(), host_ru.data(), w_run.data(), w_term.data());
+    activeDifferentiator->ResidualDerivativesAll(host_rx, host_ru, T, eps);
+    rc = kpilqr_upload_residuals(ctx, host_r, host_rx, host_ru, w_run.data(), w_term.data());
     if (rc) fatal("kpilqr_upload_residuals", rc);
-    if ((rc = kpilqr_cost_derivs(ctx))) fatal("kpilqr_cost_derivs", rc);
+    if (!fused_active && (rc = kpilqr_cost_derivs(ctx))) fatal("kpilqr_cost_derivs", rc);
     double pct = 0.0;
     for (int i = 0; i < sv.dof; i++) pct += keypoint_generator->last_percentages[i];
     percentage_derivs_per_iteration.push_back(pct / sv.dof);
@@ -219,11 +235,11 @@ void iLQR_GPU::Iteration(int iteration_num, bool &converged, bool &lambda_exit)
 
     t0 = clk::now();                                                                    // STEP 3
     for (int t = 0; t < T; t++) for (int i = 0; i < m; i++) host_unom[(size_t)t * m + i] = U_old[t](i);
-    int rc = kpilqr_upload_nominal(ctx, host_unom.data(), ctrl_lim.data());
+    int rc = kpilqr_upload_nominal(ctx, host_unom, ctrl_lim.data());
     if (rc) fatal("kpilqr_upload_nominal", rc);
     std::vector<double> pred(alphas.size());
     if ((rc = kpilqr_forward_linear(ctx, alphas.data(), pred.data(), nullptr))) fatal("kpilqr_forward_linear", rc);
-    if ((rc = kpilqr_download_gains(ctx, host_K.data(), host_k.data()))) fatal("kpilqr_download_gains", rc);
+    if ((rc = kpilqr_download_gains(ctx, host_K, host_k))) fatal("kpilqr_download_gains", rc);
     if ((rc = kpilqr_sync(ctx))) fatal("kpilqr_sync", rc);
     for (int t = 0; t < T; t++) {
         for (int c = 0; c < n; c++) for (int r = 0; r < m; r++) K[t](r, c) = host_K[((size_t)t * n + c) * m + r];
@@ -270,8 +286,11 @@ void iLQR_GPU::DownloadDerivatives(std::vector<MatrixXd> &A, std::vector<MatrixX
 {
     const int n = 2 * dof, m = num_ctrl, T = horizon_length;
     std::vector<double> a((size_t)T * n * n), b((size_t)T * n * m);
-    const int rc = kpilqr_get_AB(ctx, a.data(), b.data());
+    int rc = fused_active ? kpilqr_interpolate(ctx) : 0;          // the fused sweeps do not materialise A, B
+    if (rc) fatal("kpilqr_interpolate", rc);
+    rc = kpilqr_get_AB(ctx, a.data(), b.data());
     if (rc) fatal("kpilqr_get_AB", rc);
+    if ((rc = kpilqr_sync(ctx))) fatal("kpilqr_sync", rc);
     A.assign(T, MatrixXd(n, n)); B.assign(T, MatrixXd(n, m));
     for (int t = 0; t < T; t++) {
         std::copy(a.begin() + (size_t)t * n * n, a.begin() + (size_t)(t + 1) * n * n, A[t].data());

@@ -24,6 +24,10 @@ public:
     void DownloadDerivatives(std::vector<MatrixXd> &A, std::vector<MatrixXd> &B);
     bool ok() const { return ctx != nullptr; }
     std::string last_error;
+    // KPILQR_FLAG_FUSED when the shape allows it (n+2 <= 16): interpolation and cost derivatives inside the sweeps
+    bool use_fused = true;
+    void SetFused(bool on) { if (on != use_fused) { use_fused = on; recreate_ctx = true; Resize(dof, num_ctrl, horizon_length); } }
+    std::string BackwardVariant() const { return ctx ? kpilqr_backward_variant(ctx) : ""; }
 
 private:
     void Iteration(int iteration_num, bool &converged, bool &lambda_exit);
@@ -37,6 +41,9 @@ private:
     int device = 0;
     bool cost_reduced_last_iter = true;
     std::vector<double> alphas, w_run, w_term, ctrl_lim;
-    std::vector<double> host_r, host_rx, host_ru, host_unom, host_K, host_k;
-    FDJobs jobs;
+    // pinned staging (kpilqr_host_alloc): FD jobs, residuals + Jacobians, nominal controls, gains
+    FDStaging staging;
+    double *host_r = nullptr, *host_rx = nullptr, *host_ru = nullptr, *host_unom = nullptr, *host_K = nullptr, *host_k = nullptr;
+    void free_pinned();
+    bool fused_active = false, recreate_ctx = false;
 };
