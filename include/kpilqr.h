@@ -102,6 +102,20 @@ int  kpilqr_device_ptr(kpilqr_ctx *ctx, int which, void **dptr, size_t *bytes);
  * std::vector<std::vector<int>> keypoints, include/KeyPointGenerator.h:85-100).  */
 int  kpilqr_set_keypoints(kpilqr_ctx *ctx, const int *kp_offsets, const int *kp_times);
 
+/* Key-point placement on the device for the whole batch (optional).
+ * X [batch][T][n]: the nominal trajectory states (positions then velocities), as Optimiser::X_old. */
+int  kpilqr_upload_states(kpilqr_ctx *ctx, const double *X);
+/* KeypointGenerator::GenerateKeyPoints (src/KeyPointGenerator/KeyPointGenerator.cpp:76-135) for method
+ * "set_interval" (:319-339), "adaptive_jerk" (:730-770 + :341-382) or "velocity_change" (:797-808 + :642-728)
+ * on every trajectory; the lists become the context's key-points exactly as if given to
+ * kpilqr_set_keypoints.  thresholds [dof] (jerk or velocity-change thresholds; NULL for set_interval), dt =
+ * model time-step.  "iterative_error" interleaves host finite differences and stays on the host. */
+int  kpilqr_generate_keypoints(kpilqr_ctx *ctx, const char *method, int min_N, int max_N,
+                               const double *thresholds, double dt);
+/* Reads the current per-DoF lists back (the host FD loop needs them): kp_offsets [batch*dof+1]; kp_times may be
+ * NULL to query the size.  Returns the total number of entries (>= 0) or an error (< 0).  Synchronous. */
+int  kpilqr_get_keypoints(kpilqr_ctx *ctx, int *kp_offsets, int *kp_times, int times_capacity);
+
 /* Host FD results, one job per perturbed column (Differentiator::DynamicsDerivatives,
  * src/Differentiator/Differentiator.cpp:81-428 stays on the host and fills these):
  *   job_b[j], job_t[j]   trajectory and time index of the key-point

@@ -481,3 +481,66 @@ def test_fused_pd_failure_and_noncanonical_keypoints():
         e.set_keypoints(offs, times)
         with pytest.raises(KpilqrError):
             e.backward(0.1)
+
+
+# ---- key-point placement on the device -----------------------------------------------------
+def _kp_states(rng, dof, T):
+    """Smooth-ish joint trajectories with a few velocity kinks (what makes the adaptive methods fire)."""
+    t = np.arange(T)[:, None] * 0.01
+    q = np.cumsum(rng.standard_normal((T, dof)) * 0.02, axis=0) + np.sin(t * rng.uniform(1, 9, dof))
+    v = np.gradient(q, 0.01, axis=0)
+    for _ in range(3):
+        v[int(rng.integers(2, T - 2)):, int(rng.integers(0, dof))] += rng.uniform(-2, 2)
+    return np.concatenate([q, v], axis=1)
+
+
+@pytest.mark.parametrize("method", ["set_interval", "adaptive_jerk", "velocity_change"])
+@pytest.mark.parametrize("shape", [(7, 300, 3), (2, 100, 2), (10, 65, 2), (31, 129, 1), (7, 2, 2), (7, 3000, 2)])
+def test_device_keypoint_generation_matches_oracle(method, shape):
+    from trajoptkp_amd.engine import rows_to_dof_csr
+    dof, T, B = shape
+    rng = np.random.default_rng(dof * 1000 + T)
+    X = np.stack([_kp_states(rng, dof, T) if T > 8 else rng.standard_normal((T, 2 * dof)) for _ in range(B)])
+    min_N, max_N = int(rng.integers(1, 5)), int(rng.integers(5, 40))
+    thr = rng.uniform(50.0, 4000.0, dof) if method == "adaptive_jerk" else rng.uniform(0.5, 20.0, dof)
+    rows = []
+    for b in range(B):
+        if method == "set_interval":
+            rows.append(orc.kp_set_interval(dof, T, min_N))
+        elif method == "adaptive_jerk":
+            rows.append(orc.kp_adaptive_jerk(dof, T, min_N, max_N, thr, 0.01, X[b]))
+        else:
+            rows.append(orc.kp_velocity_change(dof, T, min_N, max_N, thr, X[b]))
+    o_ref, t_ref = rows_to_dof_csr(rows, dof, T)
+    with Engine(dof, min(dof, 7), T, 3, batch=B, generic=(2 * dof + 2 > 64)) as e:
+        e.upload_states(X)
+        e.generate_keypoints(method, min_N, max_N, None if method == "set_interval" else thr, 0.01)
+        o_dev, t_dev = e.get_keypoints()
+    assert np.array_equal(o_dev, o_ref), (method, shape)
+    assert np.array_equal(t_dev, t_ref), (method, shape)
+
+
+def test_device_keypoints_feed_the_pipeline():
+    """Lists generated on the device drive interpolate and the fused sweeps exactly like uploaded ones."""
+    p = synth.make_problem(task="panda_reaching", T=120, batch=2, min_N=1, dense_residuals=True)     # FD columns everywhere
+    rng = np.random.default_rng(5)
+    X = np.stack([_kp_states(rng, p["dof"], p["T"]) for _ in range(2)])
+    thr = np.full(p["dof"], 2.0)
+    rows = [orc.kp_velocity_change(p["dof"], p["T"], 2, 15, thr, X[b]) for b in range(2)]
+    p["kp_rows"] = rows
+    ref = [pipeline.run_trajectory(p, b, want_U=True) for b in range(2)]
+    for fused in (False, True):
+        with Engine(p["dof"], p["m"], p["T"], p["nr"], batch=2, fused=fused) as e:
+            synth.upload(e, p, keypoints=False)
+            e.upload_states(X)
+            e.generate_keypoints("velocity_change", 2, 15, thr, 0.01)
+            e.iterate(p["lam"], 100, orc.alphas(6))
+            K, k = e.gains()
+            res = e.results()
+            if not fused:
+                A, B = e.get_AB()
+        for b in range(2):
+            assert relerr(K[b], ref[b]["K"]) < K_RTOL_TIGHT
+            assert np.max(np.abs(res["cost_pred"][b] - ref[b]["cost_pred"])) <= 1e-9 * np.max(np.abs(ref[b]["cost_pred"]))
+            if not fused:
+                assert np.array_equal(A[b], ref[b]["A"]) and np.array_equal(B[b], ref[b]["B"])

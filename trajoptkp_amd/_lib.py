@@ -21,6 +21,7 @@ SYMBOLS = [
     "kpilqr_backward", "kpilqr_download_gains", "kpilqr_upload_nominal", "kpilqr_forward_linear",
     "kpilqr_iterate", "kpilqr_set_AB", "kpilqr_get_AB", "kpilqr_set_cost_derivs",
     "kpilqr_get_cost_derivs", "kpilqr_backward_variant", "kpilqr_forward_variant",
+    "kpilqr_upload_states", "kpilqr_generate_keypoints", "kpilqr_get_keypoints",
 ]
 
 
@@ -92,6 +93,9 @@ def load():
     L.kpilqr_get_cost_derivs.argtypes = [vp, vp, vp, vp, vp]
     L.kpilqr_backward_variant.argtypes = [vp]; L.kpilqr_backward_variant.restype = C.c_char_p
     L.kpilqr_forward_variant.argtypes = [vp]; L.kpilqr_forward_variant.restype = C.c_char_p
+    L.kpilqr_upload_states.argtypes = [vp, vp]
+    L.kpilqr_generate_keypoints.argtypes = [vp, C.c_char_p, C.c_int, C.c_int, vp, C.c_double]
+    L.kpilqr_get_keypoints.argtypes = [vp, vp, vp, C.c_int]
     for s in SYMBOLS:
         getattr(L, s)          # raises AttributeError if the .so lacks a declared symbol
     _lib = L

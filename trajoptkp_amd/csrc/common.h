@@ -66,6 +66,13 @@ struct Ctx {
     bool kp_canonical = false;   // every DoF list strictly increasing, first 0, last T-1 (what the fused sweeps walk)
     bool fused = false;          // KPILQR_FLAG_FUSED and a supported shape
 
+    // nominal states for on-device key-point placement (kpilqr_upload_states), allocated on first use
+    double *X_states = nullptr;   // [batch][T][n]
+    double *kp_thr = nullptr;     // [dof]
+    unsigned long long *kp_mask = nullptr;   // [batch*dof][ceil(T/64)]
+    int *kp_count = nullptr;      // [batch*dof]
+    bool have_states = false;
+
     // FD job buffers (grow on demand)
     int njobs = 0, nnom = 0, nslots = 0;   // slot = run of consecutive jobs with one (b, t)
     int *slot_start = nullptr;             // [nslots+1] (device)
@@ -97,6 +104,9 @@ struct Ctx {
 // elementwise.hip
 hipError_t launch_fd_difference(Ctx *c);
 hipError_t launch_build_segmap(Ctx *c);
+// keypoints.hip
+hipError_t launch_generate_keypoints(Ctx *c, int method, int min_N, int max_N, double dt, const double *thr_dev,
+                                     const double *X_dev, unsigned long long *mask_dev, int *count_dev);
 hipError_t launch_interpolate(Ctx *c);
 hipError_t launch_cost_derivs(Ctx *c);
 hipError_t launch_trajectory_cost(Ctx *c);

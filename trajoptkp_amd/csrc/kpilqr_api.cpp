@@ -138,7 +138,7 @@ void kpilqr_destroy(kpilqr_ctx *c)
     (void)hipStreamSynchronize(c->stream);
     void *ptrs[] = {c->rec, c->K, c->k, c->r, c->r_x, c->r_u, c->w_run, c->w_term, c->u_nom, c->ctrl_lim,
                     c->lambda, c->alphas, c->cost_pred, c->delta_J, c->traj_cost, c->status, c->segmap,
-                    c->kp_offsets, c->kp_times, c->job_b, c->job_t, c->job_col, c->job_nom, c->job_mode,
+                    c->kp_offsets, c->kp_times, c->X_states, c->kp_thr, c->kp_mask, c->kp_count, c->job_b, c->job_t, c->job_col, c->job_nom, c->job_mode,
                     c->xplus, c->xminus, c->xnom, c->stage, c->slot_start};
     for (void *p : ptrs) if (p) (void)hipFree(p);
     if (c->own_stream) (void)hipStreamDestroy(c->stream);
@@ -228,6 +228,69 @@ int kpilqr_set_keypoints(kpilqr_ctx *c, const int *kp_offsets, const int *kp_tim
     KP_HIP(c, hipStreamSynchronize(c->stream));
     c->have_kp = true;
     return KPILQR_OK;
+}
+
+// ---- key-point placement on the device ----------------------------------------------------------------
+int kpilqr_upload_states(kpilqr_ctx *c, const double *X)
+{
+    if (!c || !X) return KPILQR_ERR_ARG;
+    const size_t count = (size_t)c->d.batch * c->d.T * c->n;
+    if (!c->X_states) KP_HIP(c, hipMalloc((void **)&c->X_states, count * sizeof(double)));
+    KP_HIP(c, hipMemcpyAsync(c->X_states, X, count * sizeof(double), hipMemcpyHostToDevice, c->stream));
+    c->have_states = true;
+    return KPILQR_OK;
+}
+
+int kpilqr_generate_keypoints(kpilqr_ctx *c, const char *method, int min_N, int max_N, const double *thresholds, double dt)
+{
+    if (!c || !method) return KPILQR_ERR_ARG;
+    int mth = -1;
+    if (strcmp(method, "set_interval") == 0) mth = 0;
+    else if (strcmp(method, "adaptive_jerk") == 0) mth = 1;
+    else if (strcmp(method, "velocity_change") == 0) mth = 2;
+    else return set_err(c, KPILQR_ERR_ARG, "kpilqr_generate_keypoints: method must be set_interval, adaptive_jerk or velocity_change "
+                                           "(iterative_error interleaves host finite differences and stays on the host)");
+    if (min_N < 1 || max_N < 1) return set_err(c, KPILQR_ERR_ARG, "min_N and max_N must be >= 1");
+    if (c->d.dof > 64) return set_err(c, KPILQR_ERR_ARG, "on-device key-point placement supports dof <= 64");
+    if (mth != 0 && (!thresholds || !(dt > 0.0))) return set_err(c, KPILQR_ERR_ARG, "thresholds and a positive dt are required");
+    if (mth != 0 && !c->have_states) return set_err(c, KPILQR_ERR_STATE, "kpilqr_generate_keypoints before kpilqr_upload_states");
+    const size_t nlists = (size_t)c->d.batch * c->d.dof, T = c->d.T, nchunks = (T + 63) / 64;
+    if (!c->kp_thr) KP_HIP(c, hipMalloc((void **)&c->kp_thr, sizeof(double) * c->d.dof));
+    if (!c->kp_mask) KP_HIP(c, hipMalloc((void **)&c->kp_mask, sizeof(unsigned long long) * nlists * nchunks));
+    if (!c->kp_count) KP_HIP(c, hipMalloc((void **)&c->kp_count, sizeof(int) * nlists));
+    if (!c->X_states) KP_HIP(c, hipMalloc((void **)&c->X_states, sizeof(double) * c->d.batch * T * c->n));   // set_interval never reads it
+    if (nlists * T > c->kp_cap) {            // worst case: every step a key-point
+        KP_HIP(c, hipStreamSynchronize(c->stream));
+        if (c->kp_times) KP_HIP(c, hipFree(c->kp_times));
+        c->kp_times = nullptr; c->kp_cap = 0;
+        KP_HIP(c, dalloc(&c->kp_times, nlists * T));
+        c->kp_cap = nlists * T;
+    }
+    if (thresholds) {
+        KP_HIP(c, hipMemcpyAsync(c->kp_thr, thresholds, sizeof(double) * c->d.dof, hipMemcpyHostToDevice, c->stream));
+        KP_HIP(c, hipStreamSynchronize(c->stream));       // the host array may be pageable
+    }
+    KP_HIP(c, launch_generate_keypoints(c, mth, min_N, max_N, dt, thresholds ? c->kp_thr : nullptr, c->X_states, c->kp_mask, c->kp_count));
+    KP_HIP(c, launch_build_segmap(c));
+    c->have_kp = true;
+    c->kp_canonical = true;      // rows 0 and T-1 are always full and the lists are strictly increasing by construction
+    return KPILQR_OK;
+}
+
+int kpilqr_get_keypoints(kpilqr_ctx *c, int *kp_offsets, int *kp_times, int times_capacity)
+{
+    if (!c || !kp_offsets) return KPILQR_ERR_ARG;
+    if (!c->have_kp) return set_err(c, KPILQR_ERR_STATE, "no key-points set");
+    const size_t nlists = (size_t)c->d.batch * c->d.dof;
+    KP_HIP(c, hipMemcpyAsync(kp_offsets, c->kp_offsets, (nlists + 1) * sizeof(int), hipMemcpyDeviceToHost, c->stream));
+    KP_HIP(c, hipStreamSynchronize(c->stream));
+    const int total = kp_offsets[nlists];
+    if (kp_times) {
+        if (total > times_capacity) return set_err(c, KPILQR_ERR_ARG, "kp_times capacity too small");
+        KP_HIP(c, hipMemcpyAsync(kp_times, c->kp_times, (size_t)total * sizeof(int), hipMemcpyDeviceToHost, c->stream));
+        KP_HIP(c, hipStreamSynchronize(c->stream));
+    }
+    return total;
 }
 
 int kpilqr_upload_fd(kpilqr_ctx *c, int njobs, const int *job_b, const int *job_t, const int *job_col,

@@ -111,6 +111,24 @@ class Engine:
         offs, times = rows_to_dof_csr(per_traj, self.dof, self.T)
         self.set_keypoints(offs, times)
 
+    # -- key-point placement on the device ----------------------------------------------
+    def upload_states(self, X):
+        X = _f64(X, (self.batch, self.T, self.n))
+        self._keep.append(X)
+        self._ck(self._L.kpilqr_upload_states(self._h, _ptr(X)))
+
+    def generate_keypoints(self, method, min_N, max_N=1, thresholds=None, dt=0.0):
+        th = None if thresholds is None else _f64(thresholds, (self.dof,))
+        self._ck(self._L.kpilqr_generate_keypoints(self._h, method.encode(), int(min_N), int(max_N), _ptr(th), float(dt)))
+
+    def get_keypoints(self):
+        """-> (offsets [batch*dof+1], times) per-DoF CSR currently held by the context."""
+        offs = np.zeros(self.batch * self.dof + 1, np.int32)
+        total = self._ck(self._L.kpilqr_get_keypoints(self._h, _ptr(offs), None, 0))
+        times = np.zeros(max(total, 1), np.int32)
+        self._ck(self._L.kpilqr_get_keypoints(self._h, _ptr(offs), _ptr(times), len(times)))
+        return offs, times[:total]
+
     def upload_fd(self, job_b, job_t, job_col, job_mode, xplus, xminus, job_nom=None, xnom=None, eps=1e-6):
         nj = len(job_t)
         jb = np.ascontiguousarray(job_b, np.int32); jt = np.ascontiguousarray(job_t, np.int32)
