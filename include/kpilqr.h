@@ -134,6 +134,13 @@ int  kpilqr_fd_difference(kpilqr_ctx *ctx);
 /* KeypointGenerator::InterpolateDerivatives (src/KeyPointGenerator/KeyPointGenerator.cpp:840-954). */
 int  kpilqr_interpolate(kpilqr_ctx *ctx);
 
+/* Optimiser::FilterDynamicsMatrices (src/Optimiser/Optimiser.cpp:340-406, run from GenerateDerivatives :105-107 when
+ * the task sets `filtering`): rows dof..2dof-1 of every A[t], filtered along time in place, after
+ * kpilqr_interpolate.  method "low_pass" (coefs[0] = lowPassACoefficient, Optimiser.h:219) or "FIR"
+ * (coefficients, Optimiser.h:220; at most 16).  Not available on a KPILQR_FLAG_FUSED context (the fused sweeps
+ * re-interpolate from the key-point columns). */
+int  kpilqr_filter_dynamics(kpilqr_ctx *ctx, const char *method, const double *coefs, int ncoef);
+
 /* ---- STEP 1c: cost derivatives -----------------------------------------------------------
  * Residuals and their host-side FD Jacobians (Differentiator::ResidualDerivatives stays on the
  * host): r [batch][T+1][nr], r_x [batch][T+1][nr][n], r_u [batch][T+1][nr][m]; residual weights
@@ -158,6 +165,12 @@ int  kpilqr_backward(kpilqr_ctx *ctx, const double *lambda, int pd_check_stride,
                      int *status, double *delta_J);
 /* K [batch][T][n][m] (column-major m x n), k [batch][T][m]; either may be NULL. */
 int  kpilqr_download_gains(kpilqr_ctx *ctx, double *K, double *k);
+
+/* iLQR_SVR::LeastImportantDofs, "sampling and summing" branch (src/Optimiser/iLQR_SVR.cpp:952-968), on the gains of
+ * the last backward pass: sums [batch][dof] = (sum over t = 0, s, 2s, ... and controls j of
+ * |K[t](j,i)| + |K[t](j,i+dof)|) / T.  The SVD branch (:902-950) and the state-vector resize it triggers stay on
+ * the host (a resize is kpilqr_destroy + kpilqr_create with the new dof). */
+int  kpilqr_dof_importance(kpilqr_ctx *ctx, int sampling_k_interval, double *sums);
 
 /* ---- STEP 3: forward pass over the line-search alphas ----------------------------------------
  * Nominal controls U_old [batch][T][m] and ModelTranslator::ReturnControlLimits [2*m] = lo,hi pairs. */

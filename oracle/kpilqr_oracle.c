@@ -590,6 +590,59 @@ int orc_check_convergence(double old_cost, double new_cost, double eps_converge)
     return g < eps_converge;
 }
 
+/* ------------------------------------------------------------------------------------ */
+/* optional pieces either side of the hot path */
+
+/* Optimiser::FilterDynamicsMatrices (src/Optimiser/Optimiser.cpp:340-406): rows dof..2dof-1 of A, every column,
+ * filtered along time.  method 0 = low_pass (FilterIndValLowPass :372-388, coefs[0] = lowPassACoefficient),
+ * method 1 = FIR (FilterIndValFIRFilter :390-406).  A: [T][n*n] column-major. */
+void orc_filter_dynamics(int dof, int T, int method, const double *coefs, int ncoef, double *A)
+{
+    const int n = 2 * dof;
+    double *u = (double *)malloc(sizeof(double) * (size_t)T), *f = (double *)malloc(sizeof(double) * (size_t)T);
+    for (int i = dof; i < 2 * dof; i++)
+        for (int j = 0; j < n; j++) {
+            for (int k = 0; k < T; k++) u[k] = A[(size_t)k * n * n + i + (size_t)j * n];
+            if (method == 0) {
+                const double a = coefs[0];
+                double yn1 = u[0], xn1 = u[0];
+                for (int k = 0; k < T; k++) {
+                    double xn = u[k];
+                    double yn = ((1 - a) * yn1) + a * ((xn + xn1) / 2);       /* :380 */
+                    xn1 = xn; yn1 = yn;
+                    f[k] = yn;
+                }
+            } else {
+                for (int k = 0; k < T; k++) f[k] = 0;
+                for (int k = 0; k < T; k++)
+                    for (int c = 0; c < ncoef; c++)
+                        if (k - c >= 0) f[k] += u[k - c] * coefs[c];          /* :398-402 */
+            }
+            for (int k = 0; k < T; k++) A[(size_t)k * n * n + i + (size_t)j * n] = f[k];
+        }
+    free(u); free(f);
+}
+
+/* iLQR_SVR::LeastImportantDofs, "sampling and summing" branch (src/Optimiser/iLQR_SVR.cpp:952-968):
+ * sums[i] = (sum over t = 0, s, 2s, ... and controls j of |K[t](j,i)| + |K[t](j,i+dof)|) / T.  K: [T][m*n]. */
+void orc_dof_importance(int dof, int m, int T, int sampling, const double *K, double *sums)
+{
+    for (int i = 0; i < dof; i++) sums[i] = 0.0;
+    for (int t = 0; t < T; t += sampling)
+        for (int i = 0; i < dof; i++)
+            for (int j = 0; j < m; j++) {
+                sums[i] += fabs(K[(size_t)t * m * 2 * dof + j + (size_t)i * m]);
+                sums[i] += fabs(K[(size_t)t * m * 2 * dof + j + (size_t)(i + dof) * m]);
+            }
+    for (int i = 0; i < dof; i++) sums[i] /= T;
+}
+
+/* iLQR_SVR line-search set (src/Optimiser/iLQR_SVR.cpp:469-471): 1 - i/n, i = 0..n-1 */
+void orc_alphas_svr(int n_alpha, double *alphas)
+{
+    for (int i = 0; i < n_alpha; i++) alphas[i] = 1.0 - (double)i / n_alpha;
+}
+
 int orc_linesearch_accept(int n_alpha, const double *costs, double old_cost,
                           double *new_cost, int *accepted,
                           double *lambda, double lambda_factor, double max_lambda)

@@ -113,6 +113,14 @@ int orc_linesearch_accept(int n_alpha, const double *costs, double old_cost,
                           double *new_cost, int *accepted,
                           double *lambda, double lambda_factor, double max_lambda);
 
+/* ---- optional pieces either side of the path (parity unpinned: the reference has no test for them) */
+/* Optimiser::FilterDynamicsMatrices (src/Optimiser/Optimiser.cpp:340-406); method 0 low_pass (coefs[0] = a), 1 FIR */
+void orc_filter_dynamics(int dof, int T, int method, const double *coefs, int ncoef, double *A);
+/* iLQR_SVR::LeastImportantDofs, summing branch (src/Optimiser/iLQR_SVR.cpp:952-968) */
+void orc_dof_importance(int dof, int m, int T, int sampling, const double *K, double *sums);
+/* iLQR_SVR alphas 1 - i/n (src/Optimiser/iLQR_SVR.cpp:469-471) */
+void orc_alphas_svr(int n_alpha, double *alphas);
+
 /* ---- whole iteration (a2 + a4 + a6 + a7 + a8) for ONE trajectory, and a pthread driver that runs
  * independent trajectory-iterations on `nthreads` host threads (the reference's own parallelism is a
  * std::thread pool over key-points, src/Optimiser/Optimiser.cpp:227,280; over a batch the natural

@@ -80,6 +80,12 @@ def lib(path=None):
                                         C.POINTER(C.c_int), C.POINTER(C.c_double),
                                         C.c_double, C.c_double]
     L.orc_linesearch_accept.restype = C.c_int
+    L.orc_filter_dynamics.argtypes = [C.c_int, C.c_int, C.c_int, _d, C.c_int, _d]
+    L.orc_filter_dynamics.restype = None
+    L.orc_dof_importance.argtypes = [C.c_int, C.c_int, C.c_int, C.c_int, _d, _d]
+    L.orc_dof_importance.restype = None
+    L.orc_alphas_svr.argtypes = [C.c_int, _d]
+    L.orc_alphas_svr.restype = None
     L.orc_iteration.argtypes = [C.POINTER(Problem), _d, _d, C.POINTER(C.c_double), _d]
     L.orc_iteration.restype = C.c_int
     L.orc_iteration_batch.argtypes = [C.POINTER(Problem), C.c_int, C.c_int]
@@ -228,6 +234,26 @@ def forward_linear(n, m, T, alphas_, A, B, K, k, l_x, l_xx, l_u, l_uu, u_nom, ct
                              _c(l_u), _c(l_uu), _c(u_nom), _c(ctrl_lim), cost,
                              U.ctypes.data_as(C.c_void_p) if want_U else None)
     return (cost, U) if want_U else cost
+
+
+def alphas_svr(n_alpha=6):
+    a = np.zeros(n_alpha)
+    lib().orc_alphas_svr(n_alpha, a)
+    return a
+
+
+def filter_dynamics(dof, T, method, coefs, A):
+    """A: [T][n][n] in the reference layout of this module (see interpolate); returns the filtered copy."""
+    Ac = np.ascontiguousarray(A, np.float64).copy()
+    co = np.ascontiguousarray(coefs, np.float64)
+    lib().orc_filter_dynamics(dof, T, {"low_pass": 0, "FIR": 1}[method], co, len(co), Ac)
+    return Ac
+
+
+def dof_importance(dof, m, T, sampling, K):
+    sums = np.zeros(dof)
+    lib().orc_dof_importance(dof, m, T, sampling, np.ascontiguousarray(K, np.float64), sums)
+    return sums
 
 
 def update_lambda(lam, valid, factor=10.0, min_lambda=1e-4, max_lambda=10.0):

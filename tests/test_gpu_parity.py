@@ -544,3 +544,43 @@ def test_device_keypoints_feed_the_pipeline():
             assert np.max(np.abs(res["cost_pred"][b] - ref[b]["cost_pred"])) <= 1e-9 * np.max(np.abs(ref[b]["cost_pred"]))
             if not fused:
                 assert np.array_equal(A[b], ref[b]["A"]) and np.array_equal(B[b], ref[b]["B"])
+
+
+# ---- A-matrix filters, iLQR_SVR DoF importance and alpha set -----------------------------
+@pytest.mark.parametrize("method,coefs", [("low_pass", [0.25]), ("FIR", [0.1, 0.15, 0.5, 0.15, 0.1]), ("FIR", [1.0])])
+def test_filter_dynamics_bit_exact(method, coefs):
+    p = synth.make_problem(task="panda_reaching", T=150, batch=2, min_N=5)
+    with Engine(p["dof"], p["m"], p["T"], p["nr"], batch=2) as e:
+        synth.upload(e, p)
+        e.fd_difference(); e.interpolate()
+        A0, B0 = e.get_AB()
+        e.filter_dynamics(method, coefs)
+        A1, B1 = e.get_AB()
+    for b in range(2):
+        assert np.array_equal(A1[b], orc.filter_dynamics(p["dof"], p["T"], method, coefs, A0[b])), method
+        assert np.array_equal(B1[b], B0[b])
+    from trajoptkp_amd.engine import KpilqrError
+    with Engine(p["dof"], p["m"], p["T"], p["nr"], batch=2, fused=True) as e:
+        with pytest.raises(KpilqrError):
+            e.filter_dynamics(method, coefs)
+
+
+def test_svr_dof_importance_and_alphas():
+    p = synth.make_problem(task="panda_reaching", T=200, batch=3, min_N=5)
+    with Engine(p["dof"], p["m"], p["T"], p["nr"], batch=3, fused=True) as e:
+        synth.upload(e, p)
+        e.fd_difference()
+        e.backward(p["lam"])
+        K, k = e.gains()
+        for s in (1, 5):
+            imp = e.dof_importance(s)
+            for b in range(3):
+                assert np.array_equal(imp[b], orc.dof_importance(p["dof"], p["m"], p["T"], s, K[b])), s
+        # iLQR_SVR's line-search set 1 - i/6 through the same forward kernel
+        cost, U = e.forward_linear(orc.alphas_svr(6), want_U=True)
+    for b in range(3):
+        o = pipeline.run_trajectory(p, b, stages=("fd", "interp", "cost", "bwd"))
+        c_ref, U_ref = orc.forward_linear(p["n"], p["m"], p["T"], orc.alphas_svr(6), o["A"], o["B"], o["K"], o["k"], o["l_x"], o["l_xx"],
+                                          o["l_u"], o["l_uu"], p["u_nom"][b], p["ctrl_lim"], want_U=True)
+        assert np.max(np.abs(cost[b] - c_ref)) <= 1e-9 * np.max(np.abs(c_ref))
+        assert relerr(U[b], U_ref) < 1e-9

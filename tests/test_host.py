@@ -108,3 +108,55 @@ def test_acrobot_fused_unfused_and_analytic_residual_jacobians_agree():
     assert np.allclose(base["cost_history"], unf["cost_history"], rtol=1e-7)
     assert np.allclose(base["cost_history"], ana["cost_history"], rtol=1e-5)
     assert np.allclose(base["K0"], unf["K0"], rtol=1e-6, atol=1e-9)
+    # a filtering task (Optimiser::FilterDynamicsMatrices) runs on the materialising pipeline and still optimises
+    for f in ("low_pass", "FIR"):
+        r = host.run_acrobot(T=100, min_N=5, max_iter=6, min_iter=2, method=f"set_interval+{f}", torque_weight=1e-3)
+        assert np.all(np.diff(r["cost_history"]) <= 1e-12) and r["cost_history"][1] < r["cost_history"][0], (f, r["cost_history"])
+
+
+def test_on_disk_formats_match_the_reference_writers(tmp_path):
+    """SURVEY 8f.4: the CSV dumps are what FileHandler::SaveTrajecInformation / SaveKeypointsToFile / SaveTaskToFile
+    and GenTestingData write: row-major matrices, horizon-1 lines, 6 significant digits, a comma after EVERY
+    value, int-accumulated timing columns."""
+    rng = np.random.default_rng(1)
+    T, dof, m = 6, 2, 1
+    n = 2 * dof
+    A = rng.standard_normal((T, n, n)) * 10.0 ** rng.integers(-8, 8, (T, n, n))       # A[t, col, row]
+    B = rng.standard_normal((T, m, n))
+    X = rng.standard_normal((T, n)); U = rng.standard_normal((T, m))
+    root = str(tmp_path / "savedTrajecInfo" / "acrobot" / "0")
+    assert host.save_trajec(root, A, B, X, U) == 0
+    g = lambda v: "%g" % v                                    # default-formatted ostream << double
+
+    def lines(name):
+        return open(f"{root}/{name}").read().split("\n")
+    la = lines("A_matrices.csv")
+    assert la[-1] == "" and len(la) - 1 == T - 1                # steps 0 .. horizon-2
+    for t in range(T - 1):
+        assert la[t] == "".join(g(A[t, k, j]) + "," for j in range(n) for k in range(n))
+    lb = lines("B_matrices.csv")
+    for t in range(T - 1):
+        assert lb[t] == "".join(g(B[t, k, j]) + "," for j in range(n) for k in range(m))
+    assert lines("states.csv")[2] == "".join(g(v) + "," for v in X[2])
+    assert lines("controls.csv")[T - 2] == "".join(g(v) + "," for v in U[T - 2])
+    # key-points: one line per DoF
+    offs, cols = orc.kp_set_interval(dof, 12, 5)
+    assert host.save_keypoints(root, offs, cols) == 0
+    assert lines("keypoints.csv")[:dof] == ["0,5,10,11,"] * dof
+    # task rows round trip through the loader; a size mismatch is refused
+    task = str(tmp_path / "TestTasks" / "acrobot" / "3.csv")
+    start, targets = np.array([3.1415, 0.3]), np.array([0.0, 0.0, 1.5e-7])
+    assert host.save_task(task, start, targets) == 0
+    assert open(task).read() == "3.1415,0.3,0,0,1.5e-07,\n"
+    s, t_ = host.load_task(task, 2, 3)
+    assert np.array_equal(s, start) and np.array_equal(t_, targets)
+    assert host.load_task(task, 2, 2) is None and host.load_task(task + ".missing", 2, 3) is None
+    # summary.csv: header, and the "Average time" columns are int-accumulated totals
+    summ = str(tmp_path / "summary.csv")
+    rows = np.array([[0.912345678, 41.25, 5, 7.0, 20.5]])
+    tim = np.array([[[1.6, 2.7, 0.9], [0.4, 0.4, 0.4], [10.2, 3.9, 0.5]]])
+    assert host.save_summary(summ, rows, tim) == 0
+    txt = open(summ).read().split("\n")
+    assert txt[0] == ("Cost reduction,Optimisation time (ms),Number iterations,Average num dofs,Average percent derivs,"
+                      "Average time derivs (ms),Average time BP (ms),Average time FP (ms)")
+    assert txt[1] == "0.912346,41.25,5,7,20.5,3,0,13"        # int(int(0+1.6)+2.7)=3 -> 3; 0; int(10.2)=10,13,13

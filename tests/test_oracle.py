@@ -205,3 +205,43 @@ def test_lambda_schedule_and_convergence():
     best, new_cost, acc, lam = orc.linesearch_accept(np.array([5.0, 4.0, 4.5]), 3.5, 0.5)
     assert not acc and new_cost == 3.5 and lam == 10.0     # x100, clamped (iLQR.cpp:525-527)
     assert np.allclose(orc.alphas(6), [(i / 6) ** 2 for i in range(1, 7)])
+
+
+def test_filters_and_svr_pieces_against_numpy():
+    """SURVEY 8f helpers of the oracle against independent numpy statements of the same reference lines."""
+    rng = np.random.default_rng(3)
+    dof, m, T = 3, 2, 40
+    n = 2 * dof
+    A = rng.standard_normal((T, n, n))
+    a = 0.25
+    lp = orc.filter_dynamics(dof, T, "low_pass", [a], A)
+    fir_c = [0.1, 0.15, 0.5, 0.15, 0.1]
+    fir = orc.filter_dynamics(dof, T, "FIR", fir_c, A)
+    # memory layout is column-major per matrix: element (row i, col j) of A[t] is A[t, j, i]
+    for i in range(n):
+        for j in range(n):
+            x = A[:, j, i]
+            if i < dof:
+                assert np.array_equal(lp[:, j, i], x) and np.array_equal(fir[:, j, i], x)       # position rows untouched
+                continue
+            y = np.zeros(T); yn1 = xn1 = x[0]
+            for k in range(T):
+                yn = ((1 - a) * yn1) + a * ((x[k] + xn1) / 2)
+                xn1, yn1 = x[k], yn
+                y[k] = yn
+            assert np.array_equal(lp[:, j, i], y)
+            f = np.zeros(T)
+            for k in range(T):
+                for c, co in enumerate(fir_c):
+                    if k - c >= 0:
+                        f[k] += x[k - c] * co
+            assert np.array_equal(fir[:, j, i], f)
+    K = rng.standard_normal((T, n, m))                        # column-major m x n per step
+    s = orc.dof_importance(dof, m, T, 3, K)
+    ref = np.zeros(dof)
+    for t in range(0, T, 3):
+        for i in range(dof):
+            for j in range(m):
+                ref[i] += abs(K[t, i, j]); ref[i] += abs(K[t, i + dof, j])
+    assert np.array_equal(s, ref / T)
+    assert np.array_equal(orc.alphas_svr(6), 1.0 - np.arange(6) / 6)

@@ -22,6 +22,7 @@ SYMBOLS = [
     "kpilqr_iterate", "kpilqr_set_AB", "kpilqr_get_AB", "kpilqr_set_cost_derivs",
     "kpilqr_get_cost_derivs", "kpilqr_backward_variant", "kpilqr_forward_variant",
     "kpilqr_upload_states", "kpilqr_generate_keypoints", "kpilqr_get_keypoints",
+    "kpilqr_filter_dynamics", "kpilqr_dof_importance",
 ]
 
 
@@ -96,6 +97,8 @@ def load():
     L.kpilqr_upload_states.argtypes = [vp, vp]
     L.kpilqr_generate_keypoints.argtypes = [vp, C.c_char_p, C.c_int, C.c_int, vp, C.c_double]
     L.kpilqr_get_keypoints.argtypes = [vp, vp, vp, C.c_int]
+    L.kpilqr_filter_dynamics.argtypes = [vp, C.c_char_p, vp, C.c_int]
+    L.kpilqr_dof_importance.argtypes = [vp, C.c_int, vp]
     for s in SYMBOLS:
         getattr(L, s)          # raises AttributeError if the .so lacks a declared symbol
     _lib = L

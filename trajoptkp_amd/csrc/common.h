@@ -108,6 +108,8 @@ hipError_t launch_build_segmap(Ctx *c);
 hipError_t launch_generate_keypoints(Ctx *c, int method, int min_N, int max_N, double dt, const double *thr_dev,
                                      const double *X_dev, unsigned long long *mask_dev, int *count_dev);
 hipError_t launch_interpolate(Ctx *c);
+hipError_t launch_filter_dynamics(Ctx *c, int method, const double *coefs_dev, int ncoef);
+hipError_t launch_dof_importance(Ctx *c, int sampling, double *sums_dev);
 hipError_t launch_cost_derivs(Ctx *c);
 hipError_t launch_trajectory_cost(Ctx *c);
 // pack/unpack between the reference layout (column-major, separate arrays) and step records

@@ -412,6 +412,86 @@ hipError_t launch_trajectory_cost(Ctx *c)
 }
 
 // ---------------------------------------------------------------------------------------------
+// Optimiser::FilterDynamicsMatrices (src/Optimiser/Optimiser.cpp:340-406): the velocity rows (dof..2dof-1) of A,
+// every column, filtered along time, in place.  One thread per matrix element walks the horizon (the rows form
+// one contiguous run of dof*n doubles per record, so a wavefront's loads and stores are coalesced); the
+// recurrences are the reference's, operation for operation (no contraction in this file).
+//   method 0: low-pass  y_k = ((1-a) y_{k-1}) + a ((x_k + x_{k-1})/2),  y_-1 = x_-1 = x_0        (:372-388)
+//   method 1: FIR       y_k = sum_c x_{k-c} coef_c over k-c >= 0, accumulated from 0 in c order    (:390-406)
+#define FIR_MAX 16
+__global__ void __launch_bounds__(128)
+k_filter_dynamics(RecLayout L, int dof, int T, int method, const double *__restrict__ coefs, int ncoef, double *__restrict__ rec)
+{
+    const int n = L.n, ne = dof * n;
+    const int b = blockIdx.y;
+    const int e = blockIdx.x * blockDim.x + threadIdx.x;
+    if (e >= ne) return;
+    double *p = rec + (size_t)b * T * L.stride + L.off_A + dof * n + e;
+    if (method == 0) {
+        const double a = coefs[0];
+        double yn1 = p[0], xn1 = yn1;
+        for (int k = 0; k < T; k++) {
+            const double xn = p[(size_t)k * L.stride];
+            const double yn = ((1 - a) * yn1) + a * ((xn + xn1) / 2);
+            xn1 = xn; yn1 = yn;
+            p[(size_t)k * L.stride] = yn;
+        }
+    } else {
+        double co[FIR_MAX], hist[FIR_MAX];     // hist[c] = x_{k-c}
+#pragma unroll
+        for (int c = 0; c < FIR_MAX; c++) { co[c] = c < ncoef ? coefs[c] : 0.0; hist[c] = 0.0; }
+        for (int k = 0; k < T; k++) {
+#pragma unroll
+            for (int c = FIR_MAX - 1; c > 0; c--) hist[c] = hist[c - 1];
+            hist[0] = p[(size_t)k * L.stride];
+            double y = 0;
+#pragma unroll
+            for (int c = 0; c < FIR_MAX; c++)
+                if (c < ncoef && k - c >= 0) y += hist[c] * co[c];
+            p[(size_t)k * L.stride] = y;
+        }
+    }
+}
+
+hipError_t launch_filter_dynamics(Ctx *c, int method, const double *coefs_dev, int ncoef)
+{
+    const int ne = c->d.dof * c->n;
+    hipLaunchKernelGGL(k_filter_dynamics, dim3((ne + 127) / 128, c->d.batch), dim3(128), 0, c->stream, c->L, c->d.dof,
+                       c->d.T, method, coefs_dev, ncoef, c->rec);
+    return hipGetLastError();
+}
+
+// iLQR_SVR::LeastImportantDofs, summing branch (src/Optimiser/iLQR_SVR.cpp:952-968): one thread per
+// (trajectory, DoF) accumulates in the reference's order (t, then control j, position column then velocity
+// column), so the sums are bit-identical with the host loop.  K is [b][t] column-major m x n.
+__global__ void __launch_bounds__(64)
+k_dof_importance(int batch, int dof, int m, int T, int sampling, const double *__restrict__ K, double *__restrict__ sums)
+{
+    const int idx = blockIdx.x * blockDim.x + threadIdx.x;
+    if (idx >= batch * dof) return;
+    const int b = idx / dof, i = idx - b * dof;
+    const int n = 2 * dof;
+    const double *Kb = K + (size_t)b * T * n * m;
+    double s = 0.0;
+    for (int t = 0; t < T; t += sampling) {
+        const double *Kt = Kb + (size_t)t * n * m;
+        for (int j = 0; j < m; j++) {
+            s += fabs(Kt[j + (size_t)i * m]);
+            s += fabs(Kt[j + (size_t)(i + dof) * m]);
+        }
+    }
+    sums[idx] = s / T;
+}
+
+hipError_t launch_dof_importance(Ctx *c, int sampling, double *sums_dev)
+{
+    const int total = c->d.batch * c->d.dof;
+    hipLaunchKernelGGL(k_dof_importance, dim3((total + 63) / 64), dim3(64), 0, c->stream, c->d.batch, c->d.dof, c->d.m,
+                       c->d.T, sampling, c->K, sums_dev);
+    return hipGetLastError();
+}
+
+// ---------------------------------------------------------------------------------------------
 // Debug hooks: reference layout (column-major, separate arrays) <-> step records.
 __global__ void __launch_bounds__(256)
 k_pack_AB(RecLayout L, long long nbt, const double *__restrict__ A, const double *__restrict__ B,

@@ -230,6 +230,8 @@ int kpilqr_set_keypoints(kpilqr_ctx *c, const int *kp_offsets, const int *kp_tim
     return KPILQR_OK;
 }
 
+static int ensure_stage(kpilqr_ctx *c, size_t bytes);
+
 // ---- key-point placement on the device ----------------------------------------------------------------
 int kpilqr_upload_states(kpilqr_ctx *c, const double *X)
 {
@@ -375,6 +377,23 @@ int kpilqr_interpolate(kpilqr_ctx *c)
     return KPILQR_OK;
 }
 
+// Optimiser::FilterDynamicsMatrices (Optimiser.cpp:340-406) on the materialised A sequence
+int kpilqr_filter_dynamics(kpilqr_ctx *c, const char *method, const double *coefs, int ncoef)
+{
+    if (!c || !method || !coefs) return KPILQR_ERR_ARG;
+    int mth = strcmp(method, "low_pass") == 0 ? 0 : strcmp(method, "FIR") == 0 ? 1 : -1;
+    if (mth < 0) return set_err(c, KPILQR_ERR_ARG, "Filtering method not recognised (low_pass, FIR)");
+    if (ncoef < 1 || ncoef > 16) return set_err(c, KPILQR_ERR_ARG, "1..16 filter coefficients");
+    if (c->fused)
+        return set_err(c, KPILQR_ERR_STATE, "the A filters act on the materialised sequence: create the context without KPILQR_FLAG_FUSED");
+    int rc = ensure_stage(c, 16 * sizeof(double));
+    if (rc) return rc;
+    KP_HIP(c, hipMemcpyAsync(c->stage, coefs, sizeof(double) * ncoef, hipMemcpyHostToDevice, c->stream));
+    KP_HIP(c, hipStreamSynchronize(c->stream));
+    KP_HIP(c, launch_filter_dynamics(c, mth, c->stage, ncoef));
+    return KPILQR_OK;
+}
+
 // ---- STEP 1c ------------------------------------------------------------------------------------
 int kpilqr_upload_residuals(kpilqr_ctx *c, const double *r, const double *r_x, const double *r_u,
                             const double *w_run, const double *w_term)
@@ -445,6 +464,19 @@ int kpilqr_download_gains(kpilqr_ctx *c, double *K, double *k)
     const size_t B = c->d.batch, T = c->d.T, n = c->n, m = c->d.m;
     if (K) KP_HIP(c, hipMemcpyAsync(K, c->K, B * T * n * m * 8, hipMemcpyDeviceToHost, c->stream));
     if (k) KP_HIP(c, hipMemcpyAsync(k, c->k, B * T * m * 8, hipMemcpyDeviceToHost, c->stream));
+    return KPILQR_OK;
+}
+
+// iLQR_SVR::LeastImportantDofs, summing branch (iLQR_SVR.cpp:952-968), over the gains of the last backward pass
+int kpilqr_dof_importance(kpilqr_ctx *c, int sampling_k_interval, double *sums)
+{
+    if (!c || !sums) return KPILQR_ERR_ARG;
+    if (sampling_k_interval < 1) return set_err(c, KPILQR_ERR_ARG, "sampling_k_interval must be >= 1");
+    const size_t bytes = (size_t)c->d.batch * c->d.dof * sizeof(double);
+    int rc = ensure_stage(c, bytes);
+    if (rc) return rc;
+    KP_HIP(c, launch_dof_importance(c, sampling_k_interval, c->stage));
+    KP_HIP(c, hipMemcpyAsync(sums, c->stage, bytes, hipMemcpyDeviceToHost, c->stream));
     return KPILQR_OK;
 }
 

@@ -147,6 +147,18 @@ class Engine:
     def interpolate(self):
         self._ck(self._L.kpilqr_interpolate(self._h))
 
+    def filter_dynamics(self, method, coefs):
+        """Optimiser::FilterDynamicsMatrices on the materialised A (after interpolate)."""
+        co = _f64(coefs)
+        self._ck(self._L.kpilqr_filter_dynamics(self._h, method.encode(), _ptr(co), len(co)))
+
+    def dof_importance(self, sampling_k_interval=1):
+        """iLQR_SVR::LeastImportantDofs (summing branch) over the last gains -> [batch][dof]."""
+        out = np.zeros((self.batch, self.dof))
+        self._ck(self._L.kpilqr_dof_importance(self._h, int(sampling_k_interval), _ptr(out)))
+        self.sync()
+        return out
+
     # -- STEP 1c --------------------------------------------------------------------------------
     def upload_residuals(self, r=None, r_x=None, r_u=None, w_run=None, w_term=None):
         B, T1, n, m, nr = self.batch, self.T + 1, self.n, self.m, self.nr

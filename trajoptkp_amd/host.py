@@ -34,6 +34,10 @@ def load_host():
     H.kpilqr_host_run_acrobot.restype = C.c_int
     H.kpilqr_host_fd_bench.argtypes = [C.c_int, C.c_int, C.c_int, C.c_int, vp, vp, vp]
     H.kpilqr_host_fd_bench.restype = C.c_int
+    H.kpilqr_host_save_trajec.argtypes = [C.c_char_p, C.c_int, C.c_int, C.c_int, vp, vp, vp, vp]
+    H.kpilqr_host_save_keypoints.argtypes = [C.c_char_p, C.c_int, vp, vp]
+    H.kpilqr_host_task_file.argtypes = [C.c_char_p, C.c_int, C.c_int, C.c_int, vp, vp]
+    H.kpilqr_host_save_summary.argtypes = [C.c_char_p, C.c_int, C.c_int, vp, vp]
     _host = H
     return H
 
@@ -74,3 +78,37 @@ def fd_bench(T=3000, reps=5, mode=1, fd_threads=16):
     pool = H.kpilqr_host_fd_bench(T, reps, mode, fd_threads, C.byref(sec), C.byref(cols), _p(chk))
     return dict(seconds=sec.value, columns=cols.value, columns_per_s=cols.value / max(sec.value, 1e-12), pool=pool,
                 checksum_set=chk[0], checksum_order=chk[1])
+
+
+def save_trajec(root_dir, A, B, X, U):
+    """FileHandler::SaveTrajecInformation.  A [T][n][n], B [T][m][n] in the ABI's column-major-per-matrix layout
+    (i.e. A[t, col, row]), X [T][n], U [T][m]."""
+    H = load_host()
+    T, n = X.shape; m = U.shape[1]
+    a, b, x, u = (np.ascontiguousarray(v, np.float64) for v in (A, B, X, U))
+    return H.kpilqr_host_save_trajec(root_dir.encode(), T, n // 2, m, _p(a), _p(b), _p(x), _p(u))
+
+
+def save_keypoints(root_dir, offs, cols):
+    H = load_host()
+    o = np.ascontiguousarray(offs, np.int32); c = np.ascontiguousarray(cols, np.int32)
+    return H.kpilqr_host_save_keypoints(root_dir.encode(), len(o) - 1, _p(o), _p(c))
+
+
+def save_task(filename, start, targets):
+    H = load_host()
+    s = np.ascontiguousarray(start, np.float64); g = np.ascontiguousarray(targets, np.float64)
+    return H.kpilqr_host_task_file(filename.encode(), 1, len(s), len(g), _p(s), _p(g))
+
+
+def load_task(filename, n_start, n_targets):
+    H = load_host()
+    s = np.zeros(n_start); g = np.zeros(n_targets)
+    rc = H.kpilqr_host_task_file(filename.encode(), 0, n_start, n_targets, _p(s), _p(g))
+    return (s, g) if rc == 0 else None
+
+
+def save_summary(filename, rows, timings):
+    H = load_host()
+    r = np.ascontiguousarray(rows, np.float64); t = np.ascontiguousarray(timings, np.float64)
+    return H.kpilqr_host_save_summary(filename.encode(), r.shape[0], t.shape[2], _p(r), _p(t))

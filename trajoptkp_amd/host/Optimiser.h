@@ -54,6 +54,12 @@ public:
     std::vector<MatrixXd> U_old, X_old, X_new;
     std::vector<MatrixXd> residuals;
 
+    // optional smoothing of the velocity rows of A along time (Optimiser.h:149-151,173,219-220; Optimiser.cpp:105-107)
+    std::string filteringMethod = "none";              // "none" | "low_pass" | "FIR"
+    double lowPassACoefficient = 0.25;
+    std::vector<double> FIRCoefficients = {0.1, 0.15, 0.5, 0.15, 0.1};
+    void setFIRFilter(std::vector<double> _FIRCoefficients) { FIRCoefficients = std::move(_FIRCoefficients); }
+
     // regularisation (Optimiser.h:239-242), line search (:259), convergence (:303)
     double lambda = 0.1, max_lambda = 10.0, min_lambda = 0.0001, lambda_factor = 10;
     int num_parallel_rollouts = 6;

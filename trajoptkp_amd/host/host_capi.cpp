@@ -5,6 +5,7 @@
 #include <memory>
 
 #include "AcrobotModel.h"
+#include "FileHandler.h"
 #include "iLQR_GPU.h"
 
 extern "C" {
@@ -48,6 +49,7 @@ int kpilqr_host_run_acrobot(int T, int min_N, int max_iter, int min_iter, const 
     // keypoint_method_name may carry options after a '+': "set_interval+unfused", "set_interval+analytic"
     std::string spec = keypoint_method_name ? keypoint_method_name : "";
     const bool unfused = spec.find("+unfused") != std::string::npos, analytic = spec.find("+analytic") != std::string::npos;
+    const bool lowpass = spec.find("+low_pass") != std::string::npos, fir = spec.find("+FIR") != std::string::npos;
     if (spec.find('+') != std::string::npos) spec = spec.substr(0, spec.find('+'));
     keypoint_method_name = spec.empty() ? nullptr : spec.c_str();
     auto sim = std::make_shared<AcrobotSimulator>(0.01, 8);
@@ -62,6 +64,7 @@ int kpilqr_host_run_acrobot(int T, int min_N, int max_iter, int min_iter, const 
     iLQR_GPU opt(mt, sim, diff, T);
     if (!opt.ok()) return -2;
     if (unfused) opt.SetFused(false);
+    if (lowpass || fir) { opt.filteringMethod = lowpass ? "low_pass" : "FIR"; opt.SetFused(false); }
     std::vector<MatrixXd> U0(T, MatrixXd(1, 1));
     std::vector<MatrixXd> U = opt.Optimise(sim->main_data, U0, max_iter, min_iter, T);
     const int nh = (int)opt.cost_history.size();
@@ -118,6 +121,55 @@ int kpilqr_host_fd_bench(int T, int reps, int mode, int fd_threads, double *seco
     }
     if (checksum) { checksum[0] = (double)(h0 & ((1ull << 52) - 1)); checksum[1] = c1; }
     return diff.pool().size();
+}
+
+// ---- on-disk formats (FileHandler): thin entry points for the tests ----------------------------------------
+// A [T][n*n], B [T][n*m] column-major per matrix (the ABI's host layout), X [T][n], U [T][m]
+int kpilqr_host_save_trajec(const char *root_dir, int T, int dof, int m, const double *A, const double *B, const double *X, const double *U)
+{
+    const int n = 2 * dof;
+    std::vector<MatrixXd> Am(T, MatrixXd(n, n)), Bm(T, MatrixXd(n, m)), Xm(T, MatrixXd(n, 1)), Um(T, MatrixXd(m, 1));
+    for (int t = 0; t < T; t++) {
+        std::memcpy(Am[t].data(), A + (size_t)t * n * n, sizeof(double) * n * n);
+        std::memcpy(Bm[t].data(), B + (size_t)t * n * m, sizeof(double) * n * m);
+        std::memcpy(Xm[t].data(), X + (size_t)t * n, sizeof(double) * n);
+        std::memcpy(Um[t].data(), U + (size_t)t * m, sizeof(double) * m);
+    }
+    return FileHandler::SaveTrajecInformation(Am, Bm, Xm, Um, root_dir) ? 0 : -1;
+}
+
+int kpilqr_host_save_keypoints(const char *root_dir, int T, const int *offs, const int *cols)
+{
+    std::vector<std::vector<int>> kp(T);
+    for (int t = 0; t < T; t++) kp[t].assign(cols + offs[t], cols + offs[t + 1]);
+    return FileHandler::SaveKeypointsToFile(root_dir, kp) ? 0 : -1;
+}
+
+int kpilqr_host_task_file(const char *filename, int save, int n_start, int n_targets, double *start, double *targets)
+{
+    if (save) {
+        return FileHandler::SaveTaskToFile(filename, std::vector<double>(start, start + n_start),
+                                           std::vector<double>(targets, targets + n_targets)) ? 0 : -1;
+    }
+    std::vector<double> s, g;
+    if (!FileHandler::LoadTaskFromFile(filename, n_start, n_targets, s, g)) return -1;
+    std::memcpy(start, s.data(), sizeof(double) * n_start);
+    std::memcpy(targets, g.data(), sizeof(double) * n_targets);
+    return 0;
+}
+
+// rows: [nrows][5] = cost_reduction, opt_time_ms, num_iterations, avg_num_dofs, avg_percent_derivs; timings
+// [nrows][3][niter] = per-iteration derivs / BP / FP times
+int kpilqr_host_save_summary(const char *filename, int nrows, int niter, const double *rows, const double *timings)
+{
+    std::vector<FileHandler::SummaryRow> v(nrows);
+    for (int i = 0; i < nrows; i++) {
+        v[i].cost_reduction = rows[i * 5]; v[i].optimisation_time_ms = rows[i * 5 + 1]; v[i].num_iterations = (int)rows[i * 5 + 2];
+        v[i].avg_num_dofs = rows[i * 5 + 3]; v[i].avg_percent_derivs = rows[i * 5 + 4];
+        const double *t = timings + (size_t)i * 3 * niter;
+        v[i].time_derivs_ms.assign(t, t + niter); v[i].time_bp_ms.assign(t + niter, t + 2 * niter); v[i].time_fp_ms.assign(t + 2 * niter, t + 3 * niter);
+    }
+    return FileHandler::SaveSummary(filename, v) ? 0 : -1;
 }
 
 }  // extern "C"

@@ -46,7 +46,8 @@ void iLQR_GPU::Resize(int new_num_dofs, int new_num_ctrl, int new_horizon)
     dof = new_num_dofs; num_ctrl = new_num_ctrl; horizon_length = new_horizon;
     const int n = 2 * dof, m = num_ctrl, T = horizon_length, nr = (int)activeModelTranslator->residual_list.size();
     if (ctx) { kpilqr_sync(ctx); free_pinned(); kpilqr_destroy(ctx); ctx = nullptr; }
-    kpilqr_dims d = {dof, m, T, nr, 1, num_parallel_rollouts, device, use_fused ? KPILQR_FLAG_FUSED : 0};
+    // the A filters act on the materialised sequence, so a filtering task runs the materialising pipeline
+    kpilqr_dims d = {dof, m, T, nr, 1, num_parallel_rollouts, device, (use_fused && filteringMethod == "none") ? KPILQR_FLAG_FUSED : 0};
     const int rc = kpilqr_create(&d, nullptr, &ctx);
     if (rc != KPILQR_OK) { last_error = kpilqr_strerror(nullptr); ctx = nullptr; std::fprintf(stderr, "iLQR_GPU: %s\n", last_error.c_str()); std::exit(1); }
     fused_active = std::string(kpilqr_backward_variant(ctx)).find("fused") != std::string::npos;
@@ -150,6 +151,12 @@ void iLQR_GPU::GenerateDerivatives()
     if (rc) fatal("kpilqr_upload_fd", rc);
     if ((rc = kpilqr_fd_difference(ctx))) fatal("kpilqr_fd_difference", rc);
     if (!fused_active && (rc = kpilqr_interpolate(ctx))) fatal("kpilqr_interpolate", rc);
+    if (filteringMethod != "none") {                              // Optimiser.cpp:105-107
+        if (fused_active) { recreate_ctx = true; std::fprintf(stderr, "iLQR_GPU: filtering set after the context was created; call Resize first\n"); std::exit(1); }
+        const bool lp = filteringMethod == "low_pass";
+        rc = kpilqr_filter_dynamics(ctx, filteringMethod.c_str(), lp ? &lowPassACoefficient : FIRCoefficients.data(), lp ? 1 : (int)FIRCoefficients.size());
+        if (rc) fatal("kpilqr_filter_dynamics", rc);
+    }
     // residuals and their Jacobians at every step (Optimiser::ComputeResidualDerivatives, :217-236)
     for (int t = 0; t <= T; t++)
         for (int i = 0; i < nr; i++) host_r[(size_t)t * nr + i] = residuals[t](i);
