@@ -99,9 +99,9 @@ def test_fd_harness_pool_matches_spawn_per_call_and_is_deterministic():
 
 @pytest.mark.gpu
 def test_acrobot_fused_unfused_and_analytic_residual_jacobians_agree():
-    """The optimiser shim on the fused sweeps (default), on the materialising pipeline, and with closed-form
+    """The optimiser shim on the fused sweeps, on the materialising pipeline (default at batch 1), and with closed-form
     residual Jacobians: same accepted cost sequence to FD accuracy."""
-    base = host.run_acrobot(T=100, min_N=5, max_iter=6, min_iter=2, torque_weight=1e-3)
+    base = host.run_acrobot(T=100, min_N=5, max_iter=6, min_iter=2, method="set_interval+fused", torque_weight=1e-3)
     unf = host.run_acrobot(T=100, min_N=5, max_iter=6, min_iter=2, method="set_interval+unfused", torque_weight=1e-3)
     ana = host.run_acrobot(T=100, min_N=5, max_iter=6, min_iter=2, method="set_interval+analytic", torque_weight=1e-3)
     assert base["iterations"] == unf["iterations"] == ana["iterations"]

@@ -48,7 +48,7 @@ int kpilqr_host_run_acrobot(int T, int min_N, int max_iter, int min_iter, const 
 {
     // keypoint_method_name may carry options after a '+': "set_interval+unfused", "set_interval+analytic"
     std::string spec = keypoint_method_name ? keypoint_method_name : "";
-    const bool unfused = spec.find("+unfused") != std::string::npos, analytic = spec.find("+analytic") != std::string::npos;
+    const bool unfused = spec.find("+unfused") != std::string::npos, fused = spec.find("+fused") != std::string::npos, analytic = spec.find("+analytic") != std::string::npos;
     const bool lowpass = spec.find("+low_pass") != std::string::npos, fir = spec.find("+FIR") != std::string::npos;
     if (spec.find('+') != std::string::npos) spec = spec.substr(0, spec.find('+'));
     keypoint_method_name = spec.empty() ? nullptr : spec.c_str();
@@ -64,6 +64,7 @@ int kpilqr_host_run_acrobot(int T, int min_N, int max_iter, int min_iter, const 
     iLQR_GPU opt(mt, sim, diff, T);
     if (!opt.ok()) return -2;
     if (unfused) opt.SetFused(false);
+    if (fused) opt.SetFused(true);
     if (lowpass || fir) { opt.filteringMethod = lowpass ? "low_pass" : "FIR"; opt.SetFused(false); }
     std::vector<MatrixXd> U0(T, MatrixXd(1, 1));
     std::vector<MatrixXd> U = opt.Optimise(sim->main_data, U0, max_iter, min_iter, T);
