@@ -870,14 +870,20 @@ k_forward_tiled(RecLayout L, int T, int n_alpha, const double *__restrict__ rec,
         }
         s.Yb = ld4(rR, oB); s.Luu = ld4(rR, oLuu); s.lu = ld4(rR, olu); s.ub = ld4(ru, oub);
     };
-    Tiles nxt;
-    load_tiles(0, nxt);
+    // Single-buffered tiles: each group is re-requested for step t+1 right behind its last use in step t (a whole
+    // step of latency cover, half the registers of a double buffer and no copies).  The identity entries of Ya
+    // (alpha and the homogeneous 1 carry over) are patched in after the load.
+    Tiles cur;
+    load_tiles(0, cur);
     __syncthreads();
+    const __amdgpu_buffer_rsrc_t rNone = __builtin_amdgcn_make_buffer_rsrc((void *)Kin, 0, 0, 0x00020000);
 
     for (int t = 0; t < T; t++) {
-        const Tiles cur = nxt;
-        if (t + 1 < T) load_tiles(t + 1, nxt);
-        __builtin_amdgcn_sched_barrier(0);     // keep the prefetch AHEAD of this step's compute
+        const bool more = t + 1 < T;
+        const __amdgpu_buffer_rsrc_t rR = more ? __builtin_amdgcn_make_buffer_rsrc((void *)(rec + ((size_t)b * T + t + 1) * L.stride), 0, rec_bytes, 0x00020000) : rNone;
+        const __amdgpu_buffer_rsrc_t rK = more ? __builtin_amdgcn_make_buffer_rsrc((void *)(Kin + ((size_t)b * T + t + 1) * m * n), 0, m * n * 8, 0x00020000) : rNone;
+        const __amdgpu_buffer_rsrc_t rk = more ? __builtin_amdgcn_make_buffer_rsrc((void *)(kin + ((size_t)b * T + t + 1) * m), 0, m * 8, 0x00020000) : rNone;
+        const __amdgpu_buffer_rsrc_t ru = more ? __builtin_amdgcn_make_buffer_rsrc((void *)(u_nom + ((size_t)b * T + t + 1) * m), 0, m * 8, 0x00020000) : rNone;
         const double *zc = zbuf[t & 1];
         double *zn = zbuf[(t + 1) & 1];
         d4 Zk[NT];
@@ -885,16 +891,22 @@ k_forward_tiled(RecLayout L, int T, int n_alpha, const double *__restrict__ rec,
         for (int k = 0; k < NT; k++) Zk[k] = lds_tile(zc + k * TILE, lane);
         const d4 Zi = lds_tile(zc + wi * TILE, lane);
         // control law + clamp (every wave; :876-890)
-        d4 U = cur.ub;
+        const d4 ub = cur.ub;
+        d4 U = ub;
 #pragma unroll
         for (int k = 0; k < NT; k++) U = Pn(cur.YkK[k] + cur.Ykk[k], Zk[k], U, nchunk(k));
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int k = 0; k < NT; k++) { cur.YkK[k] = ld4(rK, oK[k]); cur.Ykk[k] = ld4(rk, ok_[k]); }
+        cur.ub = ld4(ru, oub);
+        __builtin_amdgcn_sched_barrier(0);
         d4 dU;
         {
             double u;
-            u = U.x; if (u > hi[0]) u = hi[0]; if (u < lo[0]) u = lo[0]; U.x = u; dU.x = u - cur.ub.x;
-            u = U.y; if (u > hi[1]) u = hi[1]; if (u < lo[1]) u = lo[1]; U.y = u; dU.y = u - cur.ub.y;
-            u = U.z; if (u > hi[2]) u = hi[2]; if (u < lo[2]) u = lo[2]; U.z = u; dU.z = u - cur.ub.z;
-            u = U.w; if (u > hi[3]) u = hi[3]; if (u < lo[3]) u = lo[3]; U.w = u; dU.w = u - cur.ub.w;
+            u = U.x; if (u > hi[0]) u = hi[0]; if (u < lo[0]) u = lo[0]; U.x = u; dU.x = u - ub.x;
+            u = U.y; if (u > hi[1]) u = hi[1]; if (u < lo[1]) u = lo[1]; U.y = u; dU.y = u - ub.y;
+            u = U.z; if (u > hi[2]) u = hi[2]; if (u < lo[2]) u = lo[2]; U.z = u; dU.z = u - ub.z;
+            u = U.w; if (u > hi[3]) u = hi[3]; if (u < lo[3]) u = lo[3]; U.w = u; dU.w = u - ub.w;
         }
         if (wi == 0) {
             if (U_alpha && c < n_alpha) {
@@ -906,11 +918,18 @@ k_forward_tiled(RecLayout L, int T, int n_alpha, const double *__restrict__ rec,
             const d4 Wu = Pn(cur.Luu, dU, zero, ncu);
             partial += dU.x * (0.5 * Wu.x + cur.lu.x) + dU.y * (0.5 * Wu.y + cur.lu.y)
                      + dU.z * (0.5 * Wu.z + cur.lu.z) + dU.w * (0.5 * Wu.w + cur.lu.w);
+            __builtin_amdgcn_sched_barrier(0);
+            cur.Luu = ld4(rR, oLuu); cur.lu = ld4(rR, olu);
+            __builtin_amdgcn_sched_barrier(0);
         }
         // state cost rows of this tile, then the linearised dynamics for this tile
         d4 Wz = zero, Zn = zero;
 #pragma unroll
         for (int k = 0; k < NT; k++) Wz = Pn(cur.Lc[k], Zk[k], Wz, nchunk(k));
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int k = 0; k < NT; k++) cur.Lc[k] = ld4(rR, oLc[k]);
+        __builtin_amdgcn_sched_barrier(0);
         partial += 0.5 * (Zi.x * Wz.x + Zi.y * Wz.y + Zi.z * Wz.z + Zi.w * Wz.w);
 #pragma unroll
         for (int k = 0; k < NT; k++) {
@@ -919,6 +938,11 @@ k_forward_tiled(RecLayout L, int T, int n_alpha, const double *__restrict__ rec,
             Zn = Pn(Ya, Zk[k], Zn, nchunk(k));
         }
         Zn = Pn(cur.Yb, dU, Zn, ncu);
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int k = 0; k < NT; k++) cur.Ya[k] = ld4(rR, oA[k]);
+        cur.Yb = ld4(rR, oB);
+        __builtin_amdgcn_sched_barrier(0);
         lds_store(zn + wi * TILE, lane, Zn);
         __syncthreads();
     }
