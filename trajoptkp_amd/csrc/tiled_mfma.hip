@@ -45,6 +45,18 @@ __device__ __forceinline__ d4 Pn(const d4 &Y, const d4 &X, d4 acc, int nc)
     if (nc > 3) acc = MFMA(Y.w, X.w, acc);
     return acc;
 }
+// k-th tile of a contraction over NT row tiles: every tile but the last is full (4 chunks, straight-line code so
+// the LDS reads of the following tiles are issued ahead of the MFMAs); only the last tile is cut to the chunks
+// that hold rows of z (ncl, wave-uniform).
+template <int NT>
+__device__ __forceinline__ d4 Pk(int k, const d4 &Y, const d4 &X, d4 acc, int ncl)
+{
+    if (k < NT - 1) {
+        acc = MFMA(Y.x, X.x, acc); acc = MFMA(Y.y, X.y, acc); acc = MFMA(Y.z, X.z, acc); acc = MFMA(Y.w, X.w, acc);
+        return acc;
+    }
+    return Pn(Y, X, acc, ncl);
+}
 __device__ __forceinline__ double trcp(double x)
 {
     double r = __builtin_amdgcn_rcp(x);
@@ -137,6 +149,7 @@ k_backward_tiled(RecLayout L, int T, const double *__restrict__ rec, const doubl
     double *sRow = sQ + TILE;                       // 16x16 row-major scratch + slow-path work area (3*256+32)
     // MFMA k-chunks (4 rows each) of row tile kt that hold rows < nz; empty tiles still issue one (zero) chunk
     auto nchunk = [&](int kt) { const int rows = nz - 16 * kt; return rows >= 16 ? 4 : (rows + 3) / 4; };
+    const int ncl = nchunk(NT - 1);
 
 #ifdef KP_DEBUG_DUMP
     // diagnostic build only (tools/tiled_debug.cpp): NT x NT (or 1 x NT) tile grids of step KP_DEBUG_T
@@ -246,21 +259,24 @@ k_backward_tiled(RecLayout L, int T, const double *__restrict__ rec, const doubl
         for (int i = 0; i < NT; i++) {
             for (int j = 0; j < NT; j++) {
                 d4 acc = zero;
+#pragma unroll
                 for (int k = 0; k < NT; k++)
-                    acc = Pn(lds_tile(bufV + (k * NT + i) * TILE, lane), lds_tile(bufF + (k * NT + j) * TILE, lane), acc, nchunk(k));
+                    acc = Pk<NT>(k, lds_tile(bufV + (k * NT + i) * TILE, lane), lds_tile(bufF + (k * NT + j) * TILE, lane), acc, ncl);
                 lds_store(bufT + (i * NT + j) * TILE, lane, acc);
             }
             d4 acc = zero;
+#pragma unroll
             for (int k = 0; k < NT; k++)
-                acc = Pn(lds_tile(bufV + (k * NT + i) * TILE, lane), lds_tile(bufFu + k * TILE, lane), acc, nchunk(k));
+                acc = Pk<NT>(k, lds_tile(bufV + (k * NT + i) * TILE, lane), lds_tile(bufFu + k * TILE, lane), acc, ncl);
             lds_store(bufTu + i * TILE, lane, acc);
         }
         __syncthreads();
         DUMP(0, bufV, NT); DUMP(1, bufT, NT); DUMP(2, bufF, NT);
         // ---- Quu = l_uu + Fu' Tu ; Quz = Luz + Fu' Tz ; Qzz = Lzz + Fz' Tz (into bufV: V' is dead) ---------
         d4 Quu = load_Luu(rs);
+#pragma unroll
         for (int k = 0; k < NT; k++)
-            Quu = Pn(lds_tile(bufFu + k * TILE, lane), lds_tile(bufTu + k * TILE, lane), Quu, nchunk(k));
+            Quu = Pk<NT>(k, lds_tile(bufFu + k * TILE, lane), lds_tile(bufTu + k * TILE, lane), Quu, ncl);
         {
             d4 Qr = Quu;
             Qr.x += 0.5 * lam2d[0]; Qr.y += 0.5 * lam2d[1]; Qr.z += 0.5 * lam2d[2]; Qr.w += 0.5 * lam2d[3];
@@ -268,15 +284,17 @@ k_backward_tiled(RecLayout L, int T, const double *__restrict__ rec, const doubl
         }
         for (int j = 0; j < NT; j++) {
             d4 acc = load_Luz(rs, j);
+#pragma unroll
             for (int k = 0; k < NT; k++)
-                acc = Pn(lds_tile(bufFu + k * TILE, lane), lds_tile(bufT + (k * NT + j) * TILE, lane), acc, nchunk(k));
+                acc = Pk<NT>(k, lds_tile(bufFu + k * TILE, lane), lds_tile(bufT + (k * NT + j) * TILE, lane), acc, ncl);
             lds_store(bufQuz + j * TILE, lane, acc);
         }
         for (int i = 0; i < NT; i++)
             for (int j = 0; j < NT; j++) {
                 d4 acc = load_Lzz(rs, i, j);
+#pragma unroll
                 for (int k = 0; k < NT; k++)
-                    acc = Pn(lds_tile(bufF + (k * NT + i) * TILE, lane), lds_tile(bufT + (k * NT + j) * TILE, lane), acc, nchunk(k));
+                    acc = Pk<NT>(k, lds_tile(bufF + (k * NT + i) * TILE, lane), lds_tile(bufT + (k * NT + j) * TILE, lane), acc, ncl);
                 lds_store(bufV + (i * NT + j) * TILE, lane, acc);
             }
         __syncthreads();
@@ -515,6 +533,7 @@ k_backward_tiled_mw(RecLayout L, int T, const double *__restrict__ rec, const do
     double *sQ = bufG + NT * TILE;
     double *sRow = sQ + TILE;
     auto nchunk = [&](int kt) { const int rows = nz - 16 * kt; return rows >= 16 ? 4 : (rows + 3) / 4; };
+    const int ncl = nchunk(NT - 1);
     TileSrc S = {n, m, L.off_A, L.off_B, L.off_lxx, L.off_lx, L.off_luu, L.off_lu};
 
     const double *R0 = rec + (size_t)b * T * L.stride;
@@ -575,7 +594,7 @@ k_backward_tiled_mw(RecLayout L, int T, const double *__restrict__ rec, const do
                 d4 acc = zero;
 #pragma unroll
                 for (int k = 0; k < NT; k++)
-                    acc = Pn(lds_tile(bufV + (k * NT + i) * TILE, lane), lds_tile(bufF + (k * NT + j) * TILE, lane), acc, nchunk(k));
+                    acc = Pk<NT>(k, lds_tile(bufV + (k * NT + i) * TILE, lane), lds_tile(bufF + (k * NT + j) * TILE, lane), acc, ncl);
                 lds_store(bufT + e * TILE, lane, acc);
             }
 #pragma unroll
@@ -584,7 +603,7 @@ k_backward_tiled_mw(RecLayout L, int T, const double *__restrict__ rec, const do
                 d4 acc = zero;
 #pragma unroll
                 for (int k = 0; k < NT; k++)
-                    acc = Pn(lds_tile(bufV + (k * NT + e) * TILE, lane), lds_tile(bufFu + k * TILE, lane), acc, nchunk(k));
+                    acc = Pk<NT>(k, lds_tile(bufV + (k * NT + e) * TILE, lane), lds_tile(bufFu + k * TILE, lane), acc, ncl);
                 lds_store(bufTu + e * TILE, lane, acc);
             }
         __syncthreads();
@@ -593,7 +612,7 @@ k_backward_tiled_mw(RecLayout L, int T, const double *__restrict__ rec, const do
             d4 Quu = pLuu;
 #pragma unroll
             for (int k = 0; k < NT; k++)
-                Quu = Pn(lds_tile(bufFu + k * TILE, lane), lds_tile(bufTu + k * TILE, lane), Quu, nchunk(k));
+                Quu = Pk<NT>(k, lds_tile(bufFu + k * TILE, lane), lds_tile(bufTu + k * TILE, lane), Quu, ncl);
             Quu.x += 0.5 * lam2d[0]; Quu.y += 0.5 * lam2d[1]; Quu.z += 0.5 * lam2d[2]; Quu.w += 0.5 * lam2d[3];
             lds_store(sQ, lane, Quu);                 // Quu + lambda I
         }
@@ -603,7 +622,7 @@ k_backward_tiled_mw(RecLayout L, int T, const double *__restrict__ rec, const do
                 d4 acc = pLuz[e / W];
 #pragma unroll
                 for (int k = 0; k < NT; k++)
-                    acc = Pn(lds_tile(bufFu + k * TILE, lane), lds_tile(bufT + (k * NT + e) * TILE, lane), acc, nchunk(k));
+                    acc = Pk<NT>(k, lds_tile(bufFu + k * TILE, lane), lds_tile(bufT + (k * NT + e) * TILE, lane), acc, ncl);
                 lds_store(bufQuz + e * TILE, lane, acc);
             }
         d4 Qzz[SL];
@@ -614,7 +633,7 @@ k_backward_tiled_mw(RecLayout L, int T, const double *__restrict__ rec, const do
                 d4 acc = pL[e / W];
 #pragma unroll
                 for (int k = 0; k < NT; k++)
-                    acc = Pn(lds_tile(bufF + (k * NT + i) * TILE, lane), lds_tile(bufT + (k * NT + j) * TILE, lane), acc, nchunk(k));
+                    acc = Pk<NT>(k, lds_tile(bufF + (k * NT + i) * TILE, lane), lds_tile(bufT + (k * NT + j) * TILE, lane), acc, ncl);
                 Qzz[e / W] = acc;
             }
         if (t > 0) prefetch(t - 1);                   // in flight behind phases D-F
@@ -810,6 +829,7 @@ k_forward_tiled(RecLayout L, int T, int n_alpha, const double *__restrict__ rec,
     const int b = blockIdx.x;
     const int ncu = (m + 3) >> 2;
     auto nchunk = [&](int kt) { const int rows = nz2 - 16 * kt; return rows >= 16 ? 4 : (rows + 3) / 4; };
+    const int ncl = nchunk(NT - 1);
 
     // per-lane source byte offsets (OOBT = structural zero); p = contraction (state) index, o = output index
     int oK[NT][4], ok_[NT][4], oA[NT][4], oLc[NT][4], oB[4], oLuu[4], olu[4], oub[4];
@@ -894,7 +914,7 @@ k_forward_tiled(RecLayout L, int T, int n_alpha, const double *__restrict__ rec,
         const d4 ub = cur.ub;
         d4 U = ub;
 #pragma unroll
-        for (int k = 0; k < NT; k++) U = Pn(cur.YkK[k] + cur.Ykk[k], Zk[k], U, nchunk(k));
+        for (int k = 0; k < NT; k++) U = Pk<NT>(k, cur.YkK[k] + cur.Ykk[k], Zk[k], U, ncl);
         __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
         for (int k = 0; k < NT; k++) { cur.YkK[k] = ld4(rK, oK[k]); cur.Ykk[k] = ld4(rk, ok_[k]); }
@@ -925,7 +945,7 @@ k_forward_tiled(RecLayout L, int T, int n_alpha, const double *__restrict__ rec,
         // state cost rows of this tile, then the linearised dynamics for this tile
         d4 Wz = zero, Zn = zero;
 #pragma unroll
-        for (int k = 0; k < NT; k++) Wz = Pn(cur.Lc[k], Zk[k], Wz, nchunk(k));
+        for (int k = 0; k < NT; k++) Wz = Pk<NT>(k, cur.Lc[k], Zk[k], Wz, ncl);
         __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
         for (int k = 0; k < NT; k++) cur.Lc[k] = ld4(rR, oLc[k]);
@@ -935,7 +955,7 @@ k_forward_tiled(RecLayout L, int T, int n_alpha, const double *__restrict__ rec,
         for (int k = 0; k < NT; k++) {
             d4 Ya = cur.Ya[k];
             Ya.x += oneA[k][0]; Ya.y += oneA[k][1]; Ya.z += oneA[k][2]; Ya.w += oneA[k][3];
-            Zn = Pn(Ya, Zk[k], Zn, nchunk(k));
+            Zn = Pk<NT>(k, Ya, Zk[k], Zn, ncl);
         }
         Zn = Pn(cur.Yb, dU, Zn, ncu);
         __builtin_amdgcn_sched_barrier(0);
