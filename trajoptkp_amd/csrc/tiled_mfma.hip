@@ -758,6 +758,257 @@ k_backward_tiled_mw(RecLayout L, int T, const double *__restrict__ rec, const do
     if (threadIdx.x == 0) status[b] = fail;
 }
 
+
+// ---------------------------------------------------------------------------------------------
+// Backward pass, NT wavefronts per trajectory, COLUMN decomposition: wave w owns column tile w of Tz, Quz,
+// Qzz and V'.  Tz(:,w) and Qzz(:,w) never leave the wave's registers (Qzz(i,w) = Lzz(i,w) + sum_k Fz(k,i)'Tz(k,w)
+// only needs the wave's own Tz column), Quu is summed from per-wave partials Fu(w)'Tu(w), and the only tiles
+// exchanged through LDS are Fz/Fu (staged once per step), X, G and the unsymmetrised V' for the transpose:
+//   A  prefetched Fz(:,w), Fu(w): registers -> LDS                                        | barrier
+//   BC Tz(:,w), Tu(w), Quu partial, Quz(w), Qzz(:,w)          (straight-line, 4*NT^2*2+... MFMAs)  | barrier
+//   D  Quu = l_uu + partials; LDL' (every wave); solve / K / k / G for column tile w       | barrier
+//   E  acc(i,w) = Qzz(i,w) + X_i' G_w -> LDS                                               | barrier
+//   F  V'(i,w) = (acc(i,w) + acc(w,i)')/2                (the barrier after the next A orders it)
+// All source tiles are single-buffered: re-requested for step t-1 right behind their last use in step t.
+template <int M, int NT>
+__global__ void __launch_bounds__(64 * NT)
+k_backward_tiled_col(RecLayout L, int T, const double *__restrict__ rec, const double *__restrict__ lambda,
+                     int pd_stride, double *__restrict__ Kout, double *__restrict__ kout,
+                     double *__restrict__ delta_J, int *__restrict__ status)
+{
+    extern __shared__ __attribute__((aligned(16))) double sh[];
+    constexpr int NCU = (M + 3) / 4;
+    constexpr int NZZ = NT * NT;
+    const int n = L.n, m = M, nz = n + 1;
+    const int lane = threadIdx.x & 63, c = lane & 15, q = lane >> 4;
+    const int w = threadIdx.x >> 6;                  // this wave's column tile
+    const int b = blockIdx.x;
+    const double lam = lambda[b];
+    double *bufV = sh;                               // V' (NT x NT tiles, tile (i,j) at i*NT+j)
+    double *bufF = bufV + NZZ * TILE;                // Fz
+    double *bufT = bufF + NZZ * TILE;                // unsymmetrised V' for the transpose
+    double *bufFu = bufT + NZZ * TILE;               // NT
+    double *bufQuz = bufFu + NT * TILE;              // NT
+    double *bufX = bufQuz + NT * TILE;               // NT
+    double *bufG = bufX + NT * TILE;                 // NT
+    double *bufQp = bufG + NT * TILE;                // NT: per-wave partials of Fu'Tu
+    double *sQ = bufQp + NT * TILE + w * TILE;       // NT: this wave's image of Quu + lambda I
+    double *sRow = bufQp + 2 * NT * TILE;            // slow-path work area
+    auto nchunk = [&](int kt) { const int rows = nz - 16 * kt; return rows >= 16 ? 4 : (rows + 3) / 4; };
+    const int ncl = nchunk(NT - 1);
+    const int ncw = (w < NT - 1) ? 4 : ncl;          // chunks of row tile w
+    TileSrc S = {n, m, L.off_A, L.off_B, L.off_lxx, L.off_lx, L.off_luu, L.off_lu};
+
+    const double *R0 = rec + (size_t)b * T * L.stride;
+    const int rec_bytes = L.rec * 8;
+    const d4 zero = {0.0, 0.0, 0.0, 0.0};
+    const int tn = n >> 4, cn = n & 15;
+    const bool lane_nn = (c == cn) && (q == (cn & 3));
+    const int reg_nn = cn >> 2;
+    d4 nn_keep;
+    nn_keep.x = (lane_nn && reg_nn == 0) ? 0.0 : 1.0; nn_keep.y = (lane_nn && reg_nn == 1) ? 0.0 : 1.0;
+    nn_keep.z = (lane_nn && reg_nn == 2) ? 0.0 : 1.0; nn_keep.w = (lane_nn && reg_nn == 3) ? 0.0 : 1.0;
+    const d4 nn_one = 1.0 - nn_keep;
+    double lam2d[4];
+#pragma unroll
+    for (int r = 0; r < 4; r++) lam2d[r] = (4 * r + q == c && c < m) ? 2.0 * lam : 0.0;
+
+    // source tiles of the current step (column w): Fz(k,w), Lzz(k,w), Fu(w), Luz(w), Luu
+    d4 pF[NT], pL[NT], pFu, pLuz, pLuu;
+    auto rsrc_of = [&](int t) { return __builtin_amdgcn_make_buffer_rsrc((void *)(R0 + (size_t)t * L.stride), 0, rec_bytes, 0x00020000); };
+    {
+        __amdgpu_buffer_rsrc_t rs = rsrc_of(T - 1);
+#pragma unroll
+        for (int k = 0; k < NT; k++) { pF[k] = ld_Fz(rs, S, k, w, q, c); pL[k] = ld_Lzz(rs, S, k, w, q, c); }
+        pFu = ld_Fu(rs, S, w, q, c); pLuz = ld_Luz(rs, S, w, q, c); pLuu = ld_Luu(rs, S, q, c);
+    }
+    // V' <- Lzz(T-1)   (iLQR.cpp:537-539)
+#pragma unroll
+    for (int k = 0; k < NT; k++) lds_store(bufV + (k * NT + w) * TILE, lane, pL[k]);
+
+    int pd_counter = 0, fail = 0;
+    double dJ = 0.0;
+    for (int t = T - 1; t >= 0; t--) {
+        pd_counter++;
+        const bool check_pd = pd_counter >= pd_stride;
+        const bool more = t > 0;
+        __amdgpu_buffer_rsrc_t rn = more ? rsrc_of(t - 1) : __builtin_amdgcn_make_buffer_rsrc((void *)R0, 0, 0, 0x00020000);
+        // ---- A: stage Fz(:,w) (+ the homogeneous 1) and Fu(w) ----------------------------------------------
+#pragma unroll
+        for (int k = 0; k < NT; k++) {
+            d4 f = pF[k];
+            if (k == tn && w == tn) f = f + nn_one;                    // Fz(n,n) = 1
+            lds_store(bufF + (k * NT + w) * TILE, lane, f);
+        }
+        lds_store(bufFu + w * TILE, lane, pFu);
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int k = 0; k < NT; k++) pF[k] = ld_Fz(rn, S, k, w, q, c);
+        pFu = ld_Fu(rn, S, w, q, c);
+        __builtin_amdgcn_sched_barrier(0);
+        __syncthreads();
+        // ---- BC: Tz(:,w), Tu(w), Quu partial, Quz(w), Qzz(:,w) ------------------------------------------------
+        d4 Fc[NT], Tz[NT];
+#pragma unroll
+        for (int k = 0; k < NT; k++) Fc[k] = lds_tile(bufF + (k * NT + w) * TILE, lane);
+#pragma unroll
+        for (int i = 0; i < NT; i++) {
+            d4 acc = zero;
+#pragma unroll
+            for (int k = 0; k < NT; k++) acc = Pk<NT>(k, lds_tile(bufV + (k * NT + i) * TILE, lane), Fc[k], acc, ncl);
+            Tz[i] = acc;
+        }
+        {
+            d4 Tu = zero;
+#pragma unroll
+            for (int k = 0; k < NT; k++) Tu = Pk<NT>(k, lds_tile(bufV + (k * NT + w) * TILE, lane), lds_tile(bufFu + k * TILE, lane), Tu, ncl);
+            lds_store(bufQp + w * TILE, lane, Pn(lds_tile(bufFu + w * TILE, lane), Tu, zero, ncw));
+        }
+        {
+            d4 acc = pLuz;
+#pragma unroll
+            for (int k = 0; k < NT; k++) acc = Pk<NT>(k, lds_tile(bufFu + k * TILE, lane), Tz[k], acc, ncl);
+            lds_store(bufQuz + w * TILE, lane, acc);
+        }
+        d4 Qzz[NT];
+#pragma unroll
+        for (int i = 0; i < NT; i++) {
+            d4 acc = pL[i];
+#pragma unroll
+            for (int k = 0; k < NT; k++) acc = Pk<NT>(k, lds_tile(bufF + (k * NT + i) * TILE, lane), Tz[k], acc, ncl);
+            Qzz[i] = acc;
+        }
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int k = 0; k < NT; k++) pL[k] = ld_Lzz(rn, S, k, w, q, c);
+        pLuz = ld_Luz(rn, S, w, q, c);
+        __builtin_amdgcn_sched_barrier(0);
+        __syncthreads();
+        // ---- D: Quu, LDL' (every wave: keeps the PD verdict block-uniform), solve / K / G for column tile w ----
+        d4 Quu = pLuu;
+#pragma unroll
+        for (int k = 0; k < NT; k++) Quu = Quu + lds_tile(bufQp + k * TILE, lane);
+        pLuu = ld_Luu(rn, S, q, c);
+        {
+            d4 Qr = Quu;
+            Qr.x += 0.5 * lam2d[0]; Qr.y += 0.5 * lam2d[1]; Qr.z += 0.5 * lam2d[2]; Qr.w += 0.5 * lam2d[3];
+            lds_store(sQ, lane, Qr);                  // this wave's private image (same-wave LDS accesses are ordered)
+        }
+        auto qel = [&](int i, int j) { return sQ[(i >> 2) * 64 + j + 16 * (i & 3)]; };
+        double Lm[M][M], dd[M], rd[M];
+        bool pos = true;
+#pragma unroll
+        for (int j = 0; j < M; j++) {
+            double ww[M];
+            double dj = qel(j, j);
+#pragma unroll
+            for (int kk = 0; kk < j; kk++) { ww[kk] = Lm[j][kk] * dd[kk]; dj -= Lm[j][kk] * ww[kk]; }
+            dd[j] = dj;
+            pos = pos && (dj > 0.0);
+            const double rj = trcp(dj);
+            rd[j] = rj;
+#pragma unroll
+            for (int i = j + 1; i < M; i++) {
+                double v = qel(i, j);
+#pragma unroll
+                for (int kk = 0; kk < j; kk++) v -= Lm[i][kk] * ww[kk];
+                Lm[i][j] = v * rj;
+            }
+        }
+        if (check_pd) {                       // CheckMatrixPD every pd_stride steps   :587-595
+            if (!pos) { fail = t + 1; break; }
+            pd_counter = 0;
+        }
+        double *winv = sRow + 256 + 256;
+        if (!pos) {
+            if (threadIdx.x == 0) {
+                for (int i = 0; i < m; i++) for (int j = 0; j < m; j++) sRow[i * 16 + j] = qel(i, j);
+                tslow_ldlt_inverse(m, sRow, sRow + 256, winv, sRow + 768, (int *)(sRow + 784));
+            }
+            __syncthreads();
+        }
+        d4 Gw;
+        {
+            const double *zt = bufQuz + w * TILE;
+            double x[M];
+#pragma unroll
+            for (int i = 0; i < M; i++) x[i] = zt[(i >> 2) * 64 + c + 16 * (i & 3)];
+            if (pos) {
+#pragma unroll
+                for (int jj = 0; jj < M; jj++) {
+#pragma unroll
+                    for (int i = jj + 1; i < M; i++) x[i] -= Lm[i][jj] * x[jj];
+                }
+#pragma unroll
+                for (int i = 0; i < M; i++) x[i] *= rd[i];
+#pragma unroll
+                for (int jj = M - 1; jj >= 0; jj--) {
+#pragma unroll
+                    for (int i = 0; i < jj; i++) x[i] -= Lm[jj][i] * x[jj];
+                }
+            } else {
+                double y[M];
+#pragma unroll
+                for (int i = 0; i < M; i++) {
+                    double sacc = 0.0;
+#pragma unroll
+                    for (int pp = 0; pp < M; pp++) sacc += (-winv[i + pp * m]) * x[pp];
+                    y[i] = -sacc;
+                }
+#pragma unroll
+                for (int i = 0; i < M; i++) x[i] = y[i];
+            }
+            const int col = 16 * w + c;
+            double xr[4] = {0.0, 0.0, 0.0, 0.0};
+#pragma unroll
+            for (int i = 0; i < M; i++)
+                if (q == (i & 3)) xr[i >> 2] = (col <= n) ? x[i] : 0.0;
+            d4 X = {xr[0], xr[1], xr[2], xr[3]};
+            lds_store(bufX + w * TILE, lane, X);
+            __amdgpu_buffer_rsrc_t rK = __builtin_amdgcn_make_buffer_rsrc((void *)(Kout + ((size_t)b * T + t) * m * n), 0, m * n * 8, 0x00020000);
+            __amdgpu_buffer_rsrc_t rk = __builtin_amdgcn_make_buffer_rsrc((void *)(kout + ((size_t)b * T + t) * m), 0, m * 8, 0x00020000);
+#pragma unroll
+            for (int r = 0; r < NCU; r++) {
+                const int row = 4 * r + q;
+                const double kv = -xr[r];
+                __builtin_amdgcn_raw_buffer_store_b64(__builtin_bit_cast(u32x2t, kv), rK, (row < m && col < n) ? 8 * (row + col * m) : OOBT, 0, 0);
+                __builtin_amdgcn_raw_buffer_store_b64(__builtin_bit_cast(u32x2t, kv), rk, (row < m && col == n) ? 8 * row : OOBT, 0, 0);
+            }
+            if (w == tn) {
+                double kk = 0.0;
+#pragma unroll
+                for (int i = 0; i < M; i++) kk += x[i] * x[i];
+                if (lane_nn) dJ -= lam * kk;
+            }
+            d4 Quu2 = Quu;
+            Quu2.x += lam2d[0]; Quu2.y += lam2d[1]; Quu2.z += lam2d[2]; Quu2.w += lam2d[3];
+            Gw = Pn(Quu2, -X, zero, NCU);              // G = (Quu + 2 lambda I) K'
+        }
+        __syncthreads();
+        // ---- E: acc(i,w) = Qzz(i,w) + X_i' G_w -> bufT -------------------------------------------------------
+#pragma unroll
+        for (int i = 0; i < NT; i++) {
+            Qzz[i] = Pn(lds_tile(bufX + i * TILE, lane), Gw, Qzz[i], NCU);
+            lds_store(bufT + (i * NT + w) * TILE, lane, Qzz[i]);
+        }
+        __syncthreads();
+        // ---- F: V'(i,w) = (acc(i,w) + acc(w,i)')/2   (:610) -----------------------------------------------------
+#pragma unroll
+        for (int i = 0; i < NT; i++) {
+            const double *pt = bufT + (w * NT + i) * TILE + (c >> 2) * 64 + (c & 3) * 16 + q;      // (tile (w,i))'
+            d4 at;
+            at.x = pt[0]; at.y = pt[4]; at.z = pt[8]; at.w = pt[12];
+            d4 na = 0.5 * (Qzz[i] + at);
+            if (i == tn && w == tn) na = na * nn_keep;
+            lds_store(bufV + (i * NT + w) * TILE, lane, na);
+        }
+    }
+    if (w == tn && lane_nn) delta_J[b] = dJ;
+    if (threadIdx.x == 0) status[b] = fail;
+}
+
+size_t backward_col_lds_bytes(int nt) { return sizeof(double) * ((size_t)(3 * nt * nt + 7 * nt) * TILE + 3 * 256 + 64); }
+
 size_t backward_tiled_lds_bytes(int nt) { return sizeof(double) * ((size_t)(3 * nt * nt + 5 * nt + 1) * TILE + 3 * 256 + 64); }
 
 static int tiled_nt(int n)
@@ -781,13 +1032,31 @@ static bool use_multiwave(const Ctx *c)
     const char *e = getenv("KPILQR_TILED_WAVES");       // diagnostic: 1 = force single-wave, 4 = force multi-wave
     if (e && atoi(e) == 1) return false;
     if (e && atoi(e) == 4) return true;
-    return c->d.batch * 4 <= c->n_simd;
+    return false;
+}
+
+// Which backward kernel: the column decomposition (NT waves per trajectory) while a workgroup per trajectory
+// still leaves SIMDs to spare, the one-wave-per-trajectory kernel for large batches.  KPILQR_TILED_WAVES
+// overrides (tests / diagnostics): 0 = column, 1 = one wave, 4 = the earlier 4-wave item-dealing kernel.
+static bool use_column(const Ctx *c, int nt)
+{
+    const char *e = getenv("KPILQR_TILED_WAVES");
+    if (e) return atoi(e) == 0;
+    return c->d.batch * nt <= c->n_simd;
 }
 
 template <int M, int NT>
 static hipError_t launch_bt(Ctx *c, int pd_stride)
 {
     const size_t lds = backward_tiled_lds_bytes(NT);
+    if (use_column(c, NT)) {
+        const size_t ldc = backward_col_lds_bytes(NT);
+        hipError_t e = hipFuncSetAttribute((const void *)k_backward_tiled_col<M, NT>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)ldc);
+        if (e != hipSuccess) return e;
+        hipLaunchKernelGGL((k_backward_tiled_col<M, NT>), dim3(c->d.batch), dim3(64 * NT), ldc, c->stream, c->L, c->d.T, c->rec,
+                           c->lambda, pd_stride, c->K, c->k, c->delta_J, c->status);
+        return hipGetLastError();
+    }
     if (use_multiwave(c)) {
         hipError_t e = hipFuncSetAttribute((const void *)k_backward_tiled_mw<M, NT, 4>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
         if (e != hipSuccess) return e;
