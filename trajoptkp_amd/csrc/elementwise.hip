@@ -363,6 +363,10 @@ static hipError_t launch_cost_rows(Ctx *c)
     dim3 grid((c->d.T + TT - 1) / TT, c->d.batch);
     const int per = c->d.nr * (1 + N + M), nout = N * N + N + M * M + M;
     const size_t lds = sizeof(double) * (TT * (per > nout ? per : nout) + 2 * c->d.nr);
+    if (lds > 64 * 1024) {       // large states stage a few steps of 30 KB outputs: opt in to the CU's full 160 KB
+        hipError_t e = hipFuncSetAttribute((const void *)k_cost_derivs_rows<N, M>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        if (e != hipSuccess) return e;
+    }
     hipLaunchKernelGGL((k_cost_derivs_rows<N, M>), grid, dim3(256), lds, c->stream, c->L, c->d.nr, c->d.T, c->r,
                        c->r_x, c->r_u, c->w_run, c->w_term, c->rec);
     return hipGetLastError();
@@ -372,7 +376,7 @@ hipError_t launch_cost_derivs(Ctx *c)
 {
     const int per_ = c->d.nr * (1 + c->n + c->d.m), nout_ = c->n * c->n + c->n + c->d.m * c->d.m + c->d.m;
     const size_t lds_rows = sizeof(double) * ((256 / (c->n + c->d.m)) * (per_ > nout_ ? per_ : nout_) + 2 * c->d.nr);
-    if (lds_rows <= 64 * 1024) {
+    if (lds_rows <= 64 * 1024) {      // (n=62 was tried on the rows kernel with 95 KB of LDS: 20.3 ms vs 16.0 ms generic)
         if (c->n == 14 && c->d.m == 7) return launch_cost_rows<14, 7>(c);
         if (c->n == 4 && c->d.m == 1) return launch_cost_rows<4, 1>(c);
         if (c->n == 20 && c->d.m == 7) return launch_cost_rows<20, 7>(c);
