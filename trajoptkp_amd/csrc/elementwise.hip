@@ -224,29 +224,47 @@ k_cost_derivs(RecLayout L, int nr, int T,
         sh[w] = v;
     }
     __syncthreads();
-    const int nout = n * n + n + m * m + m;
-    for (int w = threadIdx.x; w < nt * nout; w += blockDim.x) {
-        const int tt = w / nout, o = w - tt * nout;
+    // l_xx in 2x2 blocks (n = 2*dof is even): two 16-byte LDS reads feed four accumulators, each of which still
+    // sums over the residuals in index order with the reference's association -- bit-identical, half the LDS
+    // traffic of one thread per element (the n = 62 case is LDS-bound).
+    const int hb = n >> 1, nblk = hb * hb;
+    for (int w = threadIdx.x; w < nt * nblk; w += blockDim.x) {
+        const int tt = w / nblk, o = w - tt * nblk;
         const int t = t0 + tt;
         const double *wt = (t == T - 1) ? w_term : w_run;   // Optimiser.cpp:208-211
+        const double *srx = sh + tt * per + nr;
+        const int a = 2 * (o / hb), bb = 2 * (o - (o / hb) * hb);
+        double a00 = 0.0, a01 = 0.0, a10 = 0.0, a11 = 0.0;
+        for (int i = 0; i < nr; i++) {
+            const double w2 = wt[i] * 2;
+            const double xa0 = srx[i * n + a], xa1 = srx[i * n + a + 1];
+            const double xb0 = srx[i * n + bb], xb1 = srx[i * n + bb + 1];
+            const double va0 = w2 * xa0, va1 = w2 * xa1;
+            a00 += va0 * xb0; a01 += va0 * xb1; a10 += va1 * xb0; a11 += va1 * xb1;
+        }
+        double *dst = rec + ((size_t)b * T + t) * L.stride + L.off_lxx;
+        dst[a * n + bb] = a00; dst[a * n + bb + 1] = a01;
+        dst[(a + 1) * n + bb] = a10; dst[(a + 1) * n + bb + 1] = a11;
+    }
+    const int nrest = n + m * m + m;
+    for (int w = threadIdx.x; w < nt * nrest; w += blockDim.x) {
+        const int tt = w / nrest, o = w - tt * nrest;
+        const int t = t0 + tt;
+        const double *wt = (t == T - 1) ? w_term : w_run;
         const double *sr = sh + tt * per, *srx = sr + nr, *sru = srx + nr * n;
         double acc = 0.0;
         int dst;
-        if (o < n * n) {                       // l_xx(a,b), stored row-major
-            const int a = o / n, bb = o - a * n;
-            for (int i = 0; i < nr; i++) acc += ((wt[i] * 2) * srx[i * n + a]) * srx[i * n + bb];
-            dst = L.off_lxx + o;
-        } else if (o < n * n + n) {            // l_x(a)
-            const int a = o - n * n;
+        if (o < n) {                           // l_x(a)
+            const int a = o;
             for (int i = 0; i < nr; i++) acc += ((wt[i] * 2) * sr[i]) * srx[i * n + a];
             dst = L.off_lx + a;
-        } else if (o < n * n + n + m * m) {    // l_uu(a,b)
-            const int q = o - n * n - n;
+        } else if (o < n + m * m) {            // l_uu(a,b)
+            const int q = o - n;
             const int a = q / m, bb = q - a * m;
             for (int i = 0; i < nr; i++) acc += ((wt[i] * 2) * sru[i * m + a]) * sru[i * m + bb];
             dst = L.off_luu + q;
         } else {                               // l_u(a)
-            const int a = o - n * n - n - m * m;
+            const int a = o - n - m * m;
             for (int i = 0; i < nr; i++) acc += ((wt[i] * 2) * sr[i]) * sru[i * m + a];
             dst = L.off_lu + a;
         }
