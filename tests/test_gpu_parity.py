@@ -584,3 +584,41 @@ def test_svr_dof_importance_and_alphas():
                                           o["l_u"], o["l_uu"], p["u_nom"][b], p["ctrl_lim"], want_U=True)
         assert np.max(np.abs(cost[b] - c_ref)) <= 1e-9 * np.max(np.abs(c_ref))
         assert relerr(U[b], U_ref) < 1e-9
+
+
+def test_fused_batch_independence_lambda_clamp_and_alphas():
+    """The scenario tests of the materialising pipeline, on the fused sweeps."""
+    # replicas are bit-identical; a trajectory does not depend on its batch neighbours
+    p1 = synth.make_problem(task="panda_reaching", T=200, batch=2, min_N=5)
+    g1 = run_fused(p1)
+    gt = run_fused(synth.tile_problem(p1, 5))
+    for rep in range(5):
+        for b in range(2):
+            assert np.array_equal(gt["K"][rep * 2 + b], g1["K"][b])
+            assert np.array_equal(gt["cost_pred"][rep * 2 + b], g1["cost_pred"][b])
+    gs = run_fused(synth.make_problem(task="panda_reaching", T=200, batch=1, min_N=5, first_b=1))
+    assert np.array_equal(gs["K"][0], g1["K"][1])
+    # per-trajectory lambda, down to the reference's min_lambda
+    p = synth.make_problem(task="panda_reaching", T=80, batch=3, min_N=5)
+    lams = np.array([0.1, 10.0, 1e-4])
+    g = run_fused(p, lam=lams)
+    for b in range(3):
+        o = pipeline.run_trajectory(p, b, lam=float(lams[b]), want_U=True)
+        assert relerr(g["K"][b], o["K"]) < K_RTOL_TIGHT and relerr(g["k"][b], o["k"]) < K_RTOL_TIGHT
+        assert np.max(np.abs(g["cost_pred"][b] - o["cost_pred"])) <= 1e-9 * np.max(np.abs(o["cost_pred"]))
+    # active clamp (iLQR.cpp:883-889)
+    p = synth.make_problem(task="panda_reaching", T=100, batch=1, min_N=5)
+    p["ctrl_lim"] = np.stack([p["u_nom"][0].min(0) - 1e-3, p["u_nom"][0].max(0) + 1e-3], axis=1).reshape(-1)
+    o = pipeline.run_trajectory(p, 0, want_U=True)
+    g = run_fused(p)
+    assert np.any(o["U_alpha"] == p["ctrl_lim"][1::2][None, None, :]) or np.any(o["U_alpha"] == p["ctrl_lim"][0::2][None, None, :])
+    assert relerr(g["U_alpha"][0], o["U_alpha"]) < 1e-9
+    assert np.max(np.abs(g["cost_pred"][0] - o["cost_pred"])) <= 1e-9 * np.max(np.abs(o["cost_pred"]))
+    # three alphas, acrobot shape
+    p = synth.make_problem(task="acrobot", T=60, batch=2, min_N=3, config_id=1, dense_residuals=True)
+    g = run_fused(p, n_alpha=3)
+    for b in range(2):
+        o = pipeline.run_trajectory(p, b, n_alpha=3, want_U=True)
+        assert g["cost_pred"].shape == (2, 3)
+        assert np.max(np.abs(g["cost_pred"][b] - o["cost_pred"])) <= 1e-9 * np.max(np.abs(o["cost_pred"]))
+        assert relerr(g["U_alpha"][b], o["U_alpha"]) < 1e-9
