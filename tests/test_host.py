@@ -160,3 +160,20 @@ def test_on_disk_formats_match_the_reference_writers(tmp_path):
     assert txt[0] == ("Cost reduction,Optimisation time (ms),Number iterations,Average num dofs,Average percent derivs,"
                       "Average time derivs (ms),Average time BP (ms),Average time FP (ms)")
     assert txt[1] == "0.912346,41.25,5,7,20.5,3,0,13"        # int(int(0+1.6)+2.7)=3 -> 3; 0; int(10.2)=10,13,13
+
+
+@pytest.mark.gpu
+def test_batched_optimiser_matches_single_trajectory_runs():
+    """iLQR_GPU_Batch: B acrobot problems from different starts through ONE context (dims.batch = B) follow,
+    trajectory by trajectory, the same accepted-cost sequence as B separate single-trajectory optimisations --
+    per-trajectory lambda schedule, PD retry, acceptance and convergence included."""
+    q0s = np.array([[3.1415, 0.3], [2.6, -0.4], [3.5, 0.1], [1.2, 0.8]])
+    for fused in (False, True):
+        res = host.run_acrobot_batch(q0s, T=100, min_N=5, max_iter=7, min_iter=2, torque_weight=1e-3, fused=fused)
+        for b, q0 in enumerate(q0s):
+            single = host.run_acrobot(T=100, min_N=5, max_iter=7, min_iter=2, torque_weight=1e-3,
+                                      method=f"set_interval+{'fused' if fused else 'unfused'}+q0={q0[0]},{q0[1]}")
+            assert res["iterations"][b] == single["iterations"], (fused, b, res["iterations"], single["iterations"])
+            assert np.allclose(res["cost_history"][b], single["cost_history"], rtol=1e-9), (fused, b)
+            assert np.allclose(res["U"][b], single["U"], rtol=1e-7, atol=1e-9)
+        assert res["stats"][7] >= 1.0 and np.all(np.isfinite(res["stats"]))

@@ -1,12 +1,14 @@
 // host_capi.cpp -- small C entry points over the C++ host classes so that the Python tests can drive
 // them (key-point generators against the oracle; the acrobot plumbing optimisation end to end).
 #include <chrono>
+#include <cstdio>
 #include <cstring>
 #include <memory>
 
 #include "AcrobotModel.h"
 #include "FileHandler.h"
 #include "iLQR_GPU.h"
+#include "iLQR_GPU_Batch.h"
 
 extern "C" {
 
@@ -48,6 +50,7 @@ int kpilqr_host_run_acrobot(int T, int min_N, int max_iter, int min_iter, const 
 {
     // keypoint_method_name may carry options after a '+': "set_interval+unfused", "set_interval+analytic"
     std::string spec = keypoint_method_name ? keypoint_method_name : "";
+    const std::string keypoint_method_full = spec;
     const bool unfused = spec.find("+unfused") != std::string::npos, fused = spec.find("+fused") != std::string::npos, analytic = spec.find("+analytic") != std::string::npos;
     const bool lowpass = spec.find("+low_pass") != std::string::npos, fir = spec.find("+FIR") != std::string::npos;
     if (spec.find('+') != std::string::npos) spec = spec.substr(0, spec.find('+'));
@@ -59,6 +62,11 @@ int kpilqr_host_run_acrobot(int T, int min_N, int max_iter, int min_iter, const 
     if (torque_weight >= 0) { mt->residual_list[4].weight = torque_weight; mt->residual_list[4].weight_terminal = torque_weight; }
     if (keypoint_method_name) mt->keypoint_method = keypoint_method_name;
     sim->main_data->q[0] = 3.1415; sim->main_data->q[1] = 0.3;
+    {   // "+q0=a,b": another start
+        std::string full = keypoint_method_full;
+        const size_t at = full.find("+q0=");
+        if (at != std::string::npos) std::sscanf(full.c_str() + at + 4, "%lf,%lf", &sim->main_data->q[0], &sim->main_data->q[1]);
+    }
     *sim->master_reset_data = *sim->main_data;
     auto diff = std::make_shared<Differentiator>(mt, sim);
     iLQR_GPU opt(mt, sim, diff, T);
@@ -74,6 +82,36 @@ int kpilqr_host_run_acrobot(int T, int min_N, int max_iter, int min_iter, const 
     if (K0_out) for (int c = 0; c < 4; c++) K0_out[c] = opt.K[0](0, c);
     if (timings_ms) { timings_ms[0] = opt.avg_time_get_derivs_ms; timings_ms[1] = opt.avg_time_backwards_pass_ms; timings_ms[2] = opt.avg_time_forwards_pass_ms; timings_ms[3] = opt.opt_time_ms; }
     return opt.num_iterations;
+}
+
+// B acrobot swing-ups from different starts q0[b] = (q0s[2b], q0s[2b+1]) optimised TOGETHER through one context
+// with dims.batch = B (iLQR_GPU_Batch).  cost_history: [B][cost_cap] (initial cost first), iterations [B],
+// U_out [B][T], stats [8] = line-search statistics of the last iteration.  Returns 0 or <0.
+int kpilqr_host_run_acrobot_batch(int B, int T, int min_N, int max_iter, int min_iter, double torque_weight, const double *q0s,
+                                  int fused, double *cost_history, int cost_cap, int *iterations, double *U_out, double *stats)
+{
+    std::vector<iLQR_GPU_Batch::Problem> probs;
+    for (int b = 0; b < B; b++) {
+        auto sim = std::make_shared<AcrobotSimulator>(0.01, 8);
+        auto mt = std::make_shared<AcrobotTranslator>(sim);
+        mt->min_N = min_N;
+        if (torque_weight >= 0) { mt->residual_list[4].weight = torque_weight; mt->residual_list[4].weight_terminal = torque_weight; }
+        sim->main_data->q[0] = q0s[2 * b]; sim->main_data->q[1] = q0s[2 * b + 1];
+        *sim->master_reset_data = *sim->main_data;
+        probs.push_back({mt, sim, std::make_shared<Differentiator>(mt, sim)});
+    }
+    iLQR_GPU_Batch opt(probs, T, 0, fused != 0);
+    if (!opt.ok()) return -2;
+    std::vector<std::vector<MatrixXd>> U0(B, std::vector<MatrixXd>(T, MatrixXd(1, 1)));
+    auto U = opt.OptimiseAll(U0, max_iter, min_iter);
+    for (int b = 0; b < B; b++) {
+        const int nh = (int)opt.cost_history[b].size();
+        for (int i = 0; i < cost_cap; i++) cost_history[(size_t)b * cost_cap + i] = i < nh ? opt.cost_history[b][i] : -1.0;
+        iterations[b] = opt.num_iterations[b];
+        if (U_out) for (int t = 0; t < T; t++) U_out[(size_t)b * T + t] = U[b][t](0);
+    }
+    if (stats) for (int i = 0; i < 8; i++) stats[i] = opt.linesearch_stats[i];
+    return 0;
 }
 
 // Host FD-harness microbenchmark (no GPU involved): Acrobot, T saved states, every DoF
