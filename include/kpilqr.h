@@ -186,6 +186,17 @@ int  kpilqr_forward_linear(kpilqr_ctx *ctx, const double *alphas, double *cost_p
 /* ---- one whole iteration (STEP 1b + 1c + 2 + 3) enqueued back to back ------------------------ */
 int  kpilqr_iterate(kpilqr_ctx *ctx, const double *lambda, int pd_check_stride, const double *alphas);
 
+/* ---- several GPUs: trajectories are sharded, one context (and one process or thread) per GPU; the only collective
+ * is the line-search cost reduction named by the design: one all-reduce of 8 doubles per iteration over RCCL/xGMI,
+ *   vec8 = [ sum_b J_pred(alpha_1..6), sum_b delta_J, number of trajectories with a valid backward pass ]
+ * summed over the trajectories of every rank whose status is 0.  Rank 0 creates the 128-byte RCCL unique id and the
+ * host distributes it (file, pipe, MPI -- the library does no networking of its own); without kpilqr_comm_init the
+ * call returns this rank's sums.  Enqueued on the context's stream after the forward pass; vec8 (host, may be NULL)
+ * is valid after kpilqr_sync.  RCCL is loaded on first use (dlopen), not at link time. */
+int  kpilqr_comm_unique_id(char id[128]);
+int  kpilqr_comm_init(kpilqr_ctx *ctx, int nranks, int rank, const char id[128]);
+int  kpilqr_allreduce_linesearch(kpilqr_ctx *ctx, double vec8[8]);
+
 /* ---- debug / oracle hooks: inject or read the intermediates in the reference's layout -------
  * (the reference exposes A, B, l_x ... as public members, include/Optimiser/Optimiser.h:194-211,
  * and GenTestingData dumps them, src/GenTestingData.cpp:795-797).  NULL pointers are skipped. */

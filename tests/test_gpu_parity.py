@@ -622,3 +622,23 @@ def test_fused_batch_independence_lambda_clamp_and_alphas():
         assert g["cost_pred"].shape == (2, 3)
         assert np.max(np.abs(g["cost_pred"][b] - o["cost_pred"])) <= 1e-9 * np.max(np.abs(o["cost_pred"]))
         assert relerr(g["U_alpha"][b], o["U_alpha"]) < 1e-9
+
+
+def test_c_abi_linesearch_allreduce_single_rank():
+    """kpilqr_allreduce_linesearch: local pack (valid trajectories only) and, with a 1-rank RCCL communicator, the
+    all-reduce itself; both must equal the sums computed on the host and trajoptkp_amd.distributed's packing."""
+    import torch
+    from trajoptkp_amd import distributed as kd
+    p = synth.make_problem(task="panda_reaching", T=64, batch=5, min_N=5)
+    with Engine(p["dof"], p["m"], p["T"], p["nr"], batch=5) as e:
+        synth.upload(e, p)
+        e.iterate(p["lam"], 100, orc.alphas(6))
+        res = e.results()
+        ref = np.concatenate([res["cost_pred"][res["status"] == 0].sum(0), [res["delta_J"][res["status"] == 0].sum(), float((res["status"] == 0).sum())]])
+        v0 = e.allreduce_linesearch()                       # no communicator: this rank's sums
+        assert np.allclose(v0, ref, rtol=1e-13) and v0[7] == 5.0
+        e.comm_init(1, 0, e.comm_unique_id())               # RCCL, one rank
+        v1 = e.allreduce_linesearch()
+        assert np.array_equal(v1, v0)
+        cost = torch.as_tensor(res["cost_pred"]); dJ = torch.as_tensor(res["delta_J"]); st = torch.as_tensor(res["status"])
+        assert np.allclose(kd.pack_linesearch(cost, dJ, st).numpy(), v0, rtol=1e-13)

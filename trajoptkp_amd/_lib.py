@@ -23,6 +23,7 @@ SYMBOLS = [
     "kpilqr_get_cost_derivs", "kpilqr_backward_variant", "kpilqr_forward_variant",
     "kpilqr_upload_states", "kpilqr_generate_keypoints", "kpilqr_get_keypoints",
     "kpilqr_filter_dynamics", "kpilqr_dof_importance",
+    "kpilqr_comm_unique_id", "kpilqr_comm_init", "kpilqr_allreduce_linesearch",
 ]
 
 
@@ -99,6 +100,9 @@ def load():
     L.kpilqr_get_keypoints.argtypes = [vp, vp, vp, C.c_int]
     L.kpilqr_filter_dynamics.argtypes = [vp, C.c_char_p, vp, C.c_int]
     L.kpilqr_dof_importance.argtypes = [vp, C.c_int, vp]
+    L.kpilqr_comm_unique_id.argtypes = [vp]
+    L.kpilqr_comm_init.argtypes = [vp, C.c_int, C.c_int, vp]
+    L.kpilqr_allreduce_linesearch.argtypes = [vp, vp]
     for s in SYMBOLS:
         getattr(L, s)          # raises AttributeError if the .so lacks a declared symbol
     _lib = L

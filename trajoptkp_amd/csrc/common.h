@@ -73,6 +73,11 @@ struct Ctx {
     int *kp_count = nullptr;      // [batch*dof]
     bool have_states = false;
 
+    // RCCL communicator for the line-search reduction (kpilqr_comm_init), and its 8-double device buffer
+    void *comm = nullptr;
+    int comm_ranks = 1;
+    double *ls8 = nullptr;
+
     // FD job buffers (grow on demand)
     int njobs = 0, nnom = 0, nslots = 0;   // slot = run of consecutive jobs with one (b, t)
     int *slot_start = nullptr;             // [nslots+1] (device)
@@ -104,6 +109,12 @@ struct Ctx {
 // elementwise.hip
 hipError_t launch_fd_difference(Ctx *c);
 hipError_t launch_build_segmap(Ctx *c);
+// comm.cpp (RCCL opened lazily) and the pack kernel of elementwise.hip
+const char *comm_unique_id(char *id128);
+const char *comm_init(Ctx *c, int nranks, int rank, const char *id128);
+void comm_destroy(Ctx *c);
+const char *comm_allreduce8(Ctx *c, double *dev8);
+hipError_t launch_pack_linesearch(Ctx *c, double *dev8);
 // keypoints.hip
 hipError_t launch_generate_keypoints(Ctx *c, int method, int min_N, int max_N, double dt, const double *thr_dev,
                                      const double *X_dev, unsigned long long *mask_dev, int *count_dev);

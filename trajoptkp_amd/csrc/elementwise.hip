@@ -513,6 +513,37 @@ hipError_t launch_dof_importance(Ctx *c, int sampling, double *sums_dev)
     return hipGetLastError();
 }
 
+// Line-search statistics of this rank's trajectories: out[0..5] = sum over trajectories with a valid backward
+// pass of cost_pred[b][alpha] (first 6 alphas), out[6] = sum of delta_J, out[7] = their number.  One workgroup,
+// fixed summation order (lane-strided partials, then a tree), so a rank's contribution is reproducible.
+__global__ void __launch_bounds__(256)
+k_pack_linesearch(int batch, int n_alpha, const double *__restrict__ cost_pred, const double *__restrict__ delta_J,
+                  const int *__restrict__ status, double *__restrict__ out)
+{
+    __shared__ double part[8][256];
+    double acc[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+    for (int b = threadIdx.x; b < batch; b += 256) {
+        if (status[b] != 0) continue;
+        for (int a = 0; a < 6 && a < n_alpha; a++) acc[a] += cost_pred[(size_t)b * n_alpha + a];
+        acc[6] += delta_J[b];
+        acc[7] += 1.0;
+    }
+    for (int i = 0; i < 8; i++) part[i][threadIdx.x] = acc[i];
+    __syncthreads();
+    for (int s = 128; s > 0; s >>= 1) {
+        if (threadIdx.x < s) for (int i = 0; i < 8; i++) part[i][threadIdx.x] += part[i][threadIdx.x + s];
+        __syncthreads();
+    }
+    if (threadIdx.x < 8) out[threadIdx.x] = part[threadIdx.x][0];
+}
+
+hipError_t launch_pack_linesearch(Ctx *c, double *dev8)
+{
+    hipLaunchKernelGGL(k_pack_linesearch, dim3(1), dim3(256), 0, c->stream, c->d.batch, c->d.n_alpha, c->cost_pred, c->delta_J,
+                       c->status, dev8);
+    return hipGetLastError();
+}
+
 // ---------------------------------------------------------------------------------------------
 // Debug hooks: reference layout (column-major, separate arrays) <-> step records.
 __global__ void __launch_bounds__(256)

@@ -136,9 +136,10 @@ void kpilqr_destroy(kpilqr_ctx *c)
 {
     if (!c) return;
     (void)hipStreamSynchronize(c->stream);
+    comm_destroy(c);
     void *ptrs[] = {c->rec, c->K, c->k, c->r, c->r_x, c->r_u, c->w_run, c->w_term, c->u_nom, c->ctrl_lim,
                     c->lambda, c->alphas, c->cost_pred, c->delta_J, c->traj_cost, c->status, c->segmap,
-                    c->kp_offsets, c->kp_times, c->X_states, c->kp_thr, c->kp_mask, c->kp_count, c->job_b, c->job_t, c->job_col, c->job_nom, c->job_mode,
+                    c->kp_offsets, c->kp_times, c->X_states, c->kp_thr, c->kp_mask, c->kp_count, c->ls8, c->job_b, c->job_t, c->job_col, c->job_nom, c->job_mode,
                     c->xplus, c->xminus, c->xnom, c->stage, c->slot_start};
     for (void *p : ptrs) if (p) (void)hipFree(p);
     if (c->own_stream) (void)hipStreamDestroy(c->stream);
@@ -549,6 +550,33 @@ int kpilqr_iterate(kpilqr_ctx *c, const double *lambda, int pd_check_stride, con
     int rc = run_backward(c, pd_check_stride);
     if (rc) return rc;
     return run_forward(c, nullptr);
+}
+
+// ---- multi-GPU: the line-search cost reduction -----------------------------------------------------------
+int kpilqr_comm_unique_id(char id[128])
+{
+    if (!id) return KPILQR_ERR_ARG;
+    if (const char *e = comm_unique_id(id)) return set_err(nullptr, KPILQR_ERR_HIP, std::string("RCCL: ") + e);
+    return KPILQR_OK;
+}
+
+int kpilqr_comm_init(kpilqr_ctx *c, int nranks, int rank, const char id[128])
+{
+    if (!c || !id || nranks < 1 || rank < 0 || rank >= nranks) return KPILQR_ERR_ARG;
+    if (c->comm) return set_err(c, KPILQR_ERR_STATE, "communicator already initialised");
+    KP_HIP(c, hipSetDevice(c->d.device));
+    if (const char *e = comm_init(c, nranks, rank, id)) return set_err(c, KPILQR_ERR_HIP, std::string("RCCL: ") + e);
+    return KPILQR_OK;
+}
+
+int kpilqr_allreduce_linesearch(kpilqr_ctx *c, double vec8[8])
+{
+    if (!c) return KPILQR_ERR_ARG;
+    if (!c->ls8) KP_HIP(c, hipMalloc((void **)&c->ls8, 8 * sizeof(double)));
+    KP_HIP(c, launch_pack_linesearch(c, c->ls8));
+    if (const char *e = comm_allreduce8(c, c->ls8)) return set_err(c, KPILQR_ERR_HIP, std::string("RCCL: ") + e);
+    if (vec8) KP_HIP(c, hipMemcpyAsync(vec8, c->ls8, 8 * sizeof(double), hipMemcpyDeviceToHost, c->stream));
+    return KPILQR_OK;
 }
 
 // ---- debug / oracle hooks -------------------------------------------------------------------------

@@ -217,6 +217,22 @@ class Engine:
         self.sync()
         return (cost, U) if want_U else cost
 
+    # -- several GPUs: the line-search cost reduction through the C ABI (RCCL) ---------------------------
+    def comm_unique_id(self):
+        buf = (C.c_char * 128)()
+        self._ck(self._L.kpilqr_comm_unique_id(C.cast(buf, C.c_void_p)))
+        return bytes(buf)
+
+    def comm_init(self, nranks, rank, unique_id):
+        buf = C.create_string_buffer(unique_id, 128)
+        self._ck(self._L.kpilqr_comm_init(self._h, int(nranks), int(rank), C.cast(buf, C.c_void_p)))
+
+    def allreduce_linesearch(self):
+        out = np.zeros(8)
+        self._ck(self._L.kpilqr_allreduce_linesearch(self._h, _ptr(out)))
+        self.sync()
+        return out
+
     def iterate(self, lam=None, pd_stride=100, alphas=None):
         """Enqueue STEP 1b + 1c + 2 + 3 back to back (asynchronous)."""
         lam = None if lam is None else _f64(np.broadcast_to(np.asarray(lam, dtype=np.float64), (self.batch,)))
