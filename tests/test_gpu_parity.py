@@ -642,3 +642,21 @@ def test_c_abi_linesearch_allreduce_single_rank():
         assert np.array_equal(v1, v0)
         cost = torch.as_tensor(res["cost_pred"]); dJ = torch.as_tensor(res["delta_J"]); st = torch.as_tensor(res["status"])
         assert np.allclose(kd.pack_linesearch(cost, dJ, st).numpy(), v0, rtol=1e-13)
+
+
+def test_fused_two_wave_backward_variant(monkeypatch):
+    """KPILQR_FUSED_WAVES=2: the control-side / state-side two-wave split of the fused backward pass (kept as a
+    measured alternative) computes the same gains."""
+    monkeypatch.setenv("KPILQR_FUSED_WAVES", "2")
+    for kw in (PROBLEMS["panda_T64"], PROBLEMS["acrobot_T100"], dict(task="panda_reaching", T=301, batch=3, min_N=4)):
+        p = synth.make_problem(**kw)
+        check_fused(run_fused(p), p)
+    # PD failure is reported through the shared flag by both waves
+    p = synth.make_problem(task="panda_reaching", T=64, batch=2, min_N=5, dense_residuals=True)
+    p["w_run"] = -np.abs(p["w_run"]) - 1.0
+    with Engine(p["dof"], p["m"], p["T"], p["nr"], batch=2, fused=True) as e:
+        synth.upload(e, p)
+        e.fd_difference()
+        st, _ = e.backward(1e-4, 1)
+    o = [pipeline.run_trajectory(p, b, lam=1e-4, pd_stride=1, stages=("fd", "interp", "cost", "bwd"))["status"] for b in range(2)]
+    assert list(st) == o and all(v > 0 for v in o)

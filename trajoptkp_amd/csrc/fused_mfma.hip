@@ -21,6 +21,7 @@
 //
 // Everything else (homogeneous form, LDL' solve, slow path, stores) is riccati_mfma.hip / forward_mfma.hip.
 // Per launch the kernels read Kp*(n^2+nm) + T*nr*(1+n+m) doubles instead of T*(2n^2+nm+n+m^2+m).
+#include <cstdlib>
 #include "common.h"
 
 namespace kpilqr {
@@ -437,6 +438,401 @@ k_backward_fused_excl(RecLayout L, FusedArgs F, int T, const double *__restrict_
     backward_fused_body<N, M>(L, F, T, rec, lambda, pd_stride, Kout, kout, delta_J, status);
 }
 
+
+// ---------------------------------------------------------------------------------------------------------
+// Backward pass, TWO wavefronts per trajectory.  A lone wavefront cannot use a SIMD's FP64 pipe fully (it issues
+// a v_fma_f64 every 8 cycles, two co-resident waves every 4; dependent FP64 MFMAs cost 78-94 cycles, interleaved
+// ones 70): at one trajectory per SIMD the single-wave kernel leaves ~25 % on the table (B=2048 runs 1.28x
+// faster per trajectory than B=1024).  Here a trajectory's step is split by FUNCTION across two waves, so a
+// batch of #SIMDs trajectories puts two waves on every SIMD:
+//   wave U (control side): Tu = V'Fu, Quu = l_uu + Fu'Tu, LDL', the solve, K/k stores, G = (Quu + 2 lambda I)K';
+//                          off the critical path: next step's B columns (a4) and [l_uu | l_u] = Ru'W[Ru | r] (a6)
+//   wave Z (state side):   Tz = V'Fz, Quz = [0 l_u] + Fu'Tz, Qzz = Lzz + Fz'Tz, V' = Qzz + X'G, (V+V')/2;
+//                          off the critical path: next step's A,B columns and Lzz = Rz'WRz
+// exchanging through LDS: V' (Z->U), Quz (Z->U), [0 l_u] (U->Z), X and G (U->Z); three s_barrier per step.
+template <int NV>
+__device__ __forceinline__ void load_vals(__amdgpu_buffer_rsrc_t rT, const int *offs, int tk, int T, int strideB, double *out)
+{
+    const bool ok = (unsigned)tk < (unsigned)T;
+    const int base = ok ? tk * strideB : 0;
+#pragma unroll
+    for (int r = 0; r < NV; r++) out[r] = fbld(rT, (ok && offs[r] != OOBF) ? base + offs[r] : OOBF);
+}
+
+#define F2_Q 0                                   // Quu + lambda I, row-major stride 16 (U private)
+#define F2_Z (F2_Q + 16 * 16)                    // Quz, [col][row] stride 17 (Z -> U)
+#define F2_S (F2_Z + 16 * 17)                    // transpose scratch, stride 17 (Z private)
+#define F2_V (F2_S + 16 * 17)                    // V' tile, D layout (Z -> U)
+#define F2_X (F2_V + 256)                        // X tile (U -> Z)
+#define F2_G (F2_X + 256)                        // G tile (U -> Z)
+#define F2_L (F2_G + 256)                        // [0 l_u] tile of the NEXT step (U -> Z)
+#define F2_SLOW (F2_L + 256)                     // slow-path work area (U private)
+#define F2_FLAG (F2_SLOW + 2 * 256 + 32)
+#define F2_TOTAL (F2_FLAG + 2)
+
+__device__ __forceinline__ d4 lds_tile4(const double *t, int lane)
+{
+    d4 v; v.x = t[lane]; v.y = t[64 + lane]; v.z = t[128 + lane]; v.w = t[192 + lane];
+    return v;
+}
+__device__ __forceinline__ void lds_store4(double *t, int lane, const d4 &v)
+{
+    t[lane] = v.x; t[64 + lane] = v.y; t[128 + lane] = v.z; t[192 + lane] = v.w;
+}
+
+// Column tracker walking down for NV values per lane (a4), shared by the two roles.
+template <int NV>
+struct DownTracker {
+    int offs[NV];
+    int lo, idx, s, nb, nb2;
+    double sv[NV], av[NV], pv[NV];
+    __device__ __forceinline__ void init(__amdgpu_buffer_rsrc_t rT, const int *kp_offsets, const int *kp_times, bool has, size_t list, int T, int strideB)
+    {
+        lo = has ? kp_offsets[list] : 0;
+        const int hi = has ? kp_offsets[list + 1] : 0;
+        idx = hi - 1;
+        s = has ? kp_times[idx] : -1;
+        nb = (has && idx - 1 >= lo) ? kp_times[idx - 1] : -1;
+        nb2 = (has && idx - 2 >= lo) ? kp_times[idx - 2] : -1;
+        load_vals<NV>(rT, offs, s, T, strideB, sv);
+        load_vals<NV>(rT, offs, nb, T, strideB, pv);
+#pragma unroll
+        for (int i = 0; i < NV; i++) av[i] = 0.0;
+    }
+    __device__ __forceinline__ void advance(__amdgpu_buffer_rsrc_t rT, const int *kp_times, int t, int T, int strideB)
+    {
+        if (t < s) {                                 // per lane: crossed the start of the current segment
+            const double den = (double)(s - nb);
+            const double rinv = frcp(den);
+#pragma unroll
+            for (int i = 0; i < NV; i++) {
+                const double ev = sv[i];
+                sv[i] = pv[i];
+                av[i] = fdiv(ev - sv[i], den, rinv);
+            }
+            s = nb; idx--;
+            nb = nb2;
+            nb2 = (idx - 2 >= lo) ? kp_times[idx - 2] : -1;
+            load_vals<NV>(rT, offs, nb, T, strideB, pv);
+        }
+    }
+    __device__ __forceinline__ double value(int i, double dt) const { return lerp_nc(sv[i], dt, av[i]); }
+};
+
+// ---- wave U: control side ------------------------------------------------------------------------------------
+template <int N, int M>
+__device__ __forceinline__ void fused2_role_U(double *sh, RecLayout L, FusedArgs F, int T, const double *__restrict__ rec, double lam,
+                                              int pd_stride, double *__restrict__ Kout, double *__restrict__ kout,
+                                              double *__restrict__ delta_J, int *__restrict__ status)
+{
+    constexpr int NCZ = (N + 1 + 3) / 4;
+    constexpr int NCU = (M + 3) / 4;
+    constexpr int n = N, m = M;
+    const int lane = threadIdx.x & 63, c = lane & 15, q = lane >> 4;
+    const int b = blockIdx.x;
+    const int nr = F.nr, ncr = (nr + 3) >> 2;
+    const int strideB = L.stride * 8;
+    int *sflag = (int *)(sh + F2_FLAG);
+    DownTracker<4> tr;                           // B rows of column c (c < m), key-point list of DoF c
+    int oRu[4], oR1[4], oKst[4], okst[4];
+    double w2run[4], lam2d[4];
+    d4 Wt;
+    {
+        double wt[4];
+#pragma unroll
+        for (int r = 0; r < 4; r++) {
+            const int row = 4 * r + q;
+            tr.offs[r] = (row < n && c < m) ? 8 * (L.off_B + row * m + c) : OOBF;
+            oRu[r] = (row < nr && c < m) ? 8 * (row * m + c) : OOBF;
+            oR1[r] = (row < nr && c == n) ? 8 * row : OOBF;
+            w2run[r] = (row < nr) ? 2.0 * F.w_run[row] : 0.0;
+            wt[r] = (row < nr) ? 2.0 * F.w_term[row] : 0.0;
+            oKst[r] = (row < m && c < n) ? 8 * (row + c * m) : OOBF;
+            okst[r] = (row < m && c == n) ? 8 * row : OOBF;
+            lam2d[r] = (row == c && row < m) ? 2.0 * lam : 0.0;
+        }
+        Wt.x = wt[0]; Wt.y = wt[1]; Wt.z = wt[2]; Wt.w = wt[3];
+    }
+    const d4 Wr = {w2run[0], w2run[1], w2run[2], w2run[3]};
+    const u64 mask_n = (c == n) ? ~0ull : 0ull, mask_u = (c < m) ? ~0ull : 0ull;
+    const bool lane_nn = (c == n) && (q == (n & 3));
+    const d4 zero = {0.0, 0.0, 0.0, 0.0};
+    const double *R0 = rec + (size_t)b * T * L.stride;
+    __amdgpu_buffer_rsrc_t rT = frsrc(R0, T * strideB);
+    const double *rb = F.r + (size_t)b * (T + 1) * nr;
+    const double *rub = F.r_u + (size_t)b * (T + 1) * nr * m;
+    d4 Ru, R1;
+    auto load_res = [&](int t) {
+        const bool ok = t >= 0;
+        __amdgpu_buffer_rsrc_t rA = frsrc(rub + (size_t)(ok ? t : 0) * nr * m, ok ? nr * m * 8 : 0);
+        __amdgpu_buffer_rsrc_t rR = frsrc(rb + (size_t)(ok ? t : 0) * nr, ok ? nr * 8 : 0);
+        Ru.x = fbld(rA, oRu[0]); Ru.y = fbld(rA, oRu[1]); Ru.z = fbld(rA, oRu[2]); Ru.w = fbld(rA, oRu[3]);
+        R1.x = fbld(rR, oR1[0]); R1.y = fbld(rR, oR1[1]); R1.z = fbld(rR, oR1[2]); R1.w = fbld(rR, oR1[3]);
+    };
+    auto cost_tile = [&](const d4 &W2) -> d4 {         // [l_uu | l_u] = Ru' W [Ru | r]
+        d4 Rur;
+        Rur.x = bits_or(Ru.x, R1.x); Rur.y = bits_or(Ru.y, R1.y); Rur.z = bits_or(Ru.z, R1.z); Rur.w = bits_or(Ru.w, R1.w);
+        return PR(Ru, Rur * W2, zero, ncr);
+    };
+    auto publish_luz = [&](const d4 &LU) {
+        d4 Luz;
+        Luz.x = bits_and(LU.x, mask_n); Luz.y = bits_and(LU.y, mask_n); Luz.z = bits_and(LU.z, mask_n); Luz.w = bits_and(LU.w, mask_n);
+        lds_store4(sh + F2_L, lane, Luz);
+    };
+    tr.init(rT, F.kp_offsets, F.kp_times, c < m, (size_t)b * F.dof + c, T, strideB);
+    d4 Fu;
+    auto lerp_Fu = [&](int t) {
+        const double dt = (double)(t - tr.s);
+        Fu.x = tr.value(0, dt); Fu.y = tr.value(1, dt); Fu.z = tr.value(2, dt); Fu.w = tr.value(3, dt);
+    };
+    // prologue: step T-1, terminal weights
+    load_res(T - 1);
+    lerp_Fu(T - 1);
+    d4 LU = cost_tile(Wt);
+    load_res(T - 2);
+    publish_luz(LU);
+    if (lane == 0) sflag[0] = 0;
+    __syncthreads();
+
+    int pd_counter = 0, fail = 0;
+    double dJ = 0.0;
+    for (int t = T - 1; t >= 0; t--) {
+        pd_counter++;
+        const bool check_pd = pd_counter >= pd_stride;
+        if (check_pd) pd_counter = 0;
+        // ---- phase 1: Tu, Quu, LDL' ---------------------------------------------------------------------------
+        const d4 V = lds_tile4(sh + F2_V, lane);
+        d4 Luu;
+        Luu.x = bits_and(LU.x, mask_u); Luu.y = bits_and(LU.y, mask_u); Luu.z = bits_and(LU.z, mask_u); Luu.w = bits_and(LU.w, mask_u);
+        const d4 Tu = PS<NCZ>(V, Fu, zero);
+        const d4 Quu = PS<NCZ>(Fu, Tu, Luu);                                 // :577
+        sh[F2_Q + q * 16 + c] = Quu.x + 0.5 * lam2d[0];
+        if (NCU > 1) sh[F2_Q + (4 + q) * 16 + c] = Quu.y + 0.5 * lam2d[1];
+        if (NCU > 2) sh[F2_Q + (8 + q) * 16 + c] = Quu.z + 0.5 * lam2d[2];
+        if (NCU > 3) sh[F2_Q + (12 + q) * 16 + c] = Quu.w + 0.5 * lam2d[3];
+        // (same-wave LDS accesses execute in order: no barrier between these stores and the reads below)
+        double Lm[M][M], dd[M], rd[M];
+        bool pos = true;
+#pragma unroll
+        for (int j = 0; j < M; j++) {
+            double w[M];
+            double dj = sh[F2_Q + j * 16 + j];
+#pragma unroll
+            for (int kk = 0; kk < j; kk++) { w[kk] = Lm[j][kk] * dd[kk]; dj -= Lm[j][kk] * w[kk]; }
+            dd[j] = dj;
+            pos = pos && (dj > 0.0);
+            const double rj = frcp(dj);
+            rd[j] = rj;
+#pragma unroll
+            for (int i = j + 1; i < M; i++) {
+                double v = sh[F2_Q + i * 16 + j];
+#pragma unroll
+                for (int kk = 0; kk < j; kk++) v -= Lm[i][kk] * w[kk];
+                Lm[i][j] = v * rj;
+            }
+        }
+        if (check_pd && !pos && lane == 0) sflag[0] = t + 1;                 // CheckMatrixPD   :587-595
+        __syncthreads();
+        if (sflag[0]) { fail = sflag[0]; break; }
+        // ---- phase 2: solve, K/k, G ---------------------------------------------------------------------------
+        double x[M];
+        if (pos) {
+#pragma unroll
+            for (int i = 0; i < M; i++) x[i] = sh[F2_Z + c * 17 + i];
+#pragma unroll
+            for (int j = 0; j < M; j++) {
+#pragma unroll
+                for (int i = j + 1; i < M; i++) x[i] -= Lm[i][j] * x[j];
+            }
+#pragma unroll
+            for (int i = 0; i < M; i++) x[i] *= rd[i];
+#pragma unroll
+            for (int j = M - 1; j >= 0; j--) {
+#pragma unroll
+                for (int i = 0; i < j; i++) x[i] -= Lm[j][i] * x[j];
+            }
+        } else {
+            // indefinite on an unchecked step: Eigen's pivoted LDLT + explicit inverse (iLQR.cpp:597-604)
+            double *wa = sh + F2_SLOW, *wx = wa + 256, *wt = wx + 256;
+            int *trp = (int *)(wt + 16);
+            if (lane == 0) fslow_ldlt_inverse(L.m, sh + F2_Q, 16, wa, wx, wt, trp);
+            __builtin_amdgcn_wave_barrier();
+#pragma unroll
+            for (int i = 0; i < M; i++) {
+                double sacc = 0.0;
+#pragma unroll
+                for (int p = 0; p < M; p++) sacc += (-wx[i + p * m]) * sh[F2_Z + c * 17 + p];
+                x[i] = -sacc;
+            }
+        }
+        d4 Xp = zero;
+        {
+            double xr[4] = {0.0, 0.0, 0.0, 0.0};
+#pragma unroll
+            for (int i = 0; i < M; i++)
+                if (q == (i & 3)) xr[i >> 2] = x[i];
+            Xp.x = xr[0]; Xp.y = xr[1]; Xp.z = xr[2]; Xp.w = xr[3];
+        }
+        const d4 Kp = -Xp;
+        {
+            __amdgpu_buffer_rsrc_t rK = frsrc(Kout + ((size_t)b * T + t) * m * n, m * n * 8);
+            __amdgpu_buffer_rsrc_t rk = frsrc(kout + ((size_t)b * T + t) * m, m * 8);
+            const double kv[4] = {Kp.x, Kp.y, Kp.z, Kp.w};
+#pragma unroll
+            for (int r = 0; r < NCU; r++) {
+                __builtin_amdgcn_raw_buffer_store_b64(__builtin_bit_cast(u32x2f, kv[r]), rK, oKst[r], 0, 0);
+                __builtin_amdgcn_raw_buffer_store_b64(__builtin_bit_cast(u32x2f, kv[r]), rk, okst[r], 0, 0);
+            }
+        }
+        {
+            double kk = 0.0;
+#pragma unroll
+            for (int i = 0; i < M; i++) kk += x[i] * x[i];
+            if (lane_nn) dJ -= lam * kk;                                      // :612-613
+        }
+        d4 Quu2 = Quu;
+        Quu2.x += lam2d[0]; Quu2.y += lam2d[1]; Quu2.z += lam2d[2]; Quu2.w += lam2d[3];
+        const d4 G = PS<NCU>(Quu2, Kp, zero);
+        lds_store4(sh + F2_X, lane, Xp);
+        lds_store4(sh + F2_G, lane, G);
+        __syncthreads();
+        // ---- phase 3 (off the critical path): next step's B columns and [l_uu | l_u] -----------------------------
+        if (t > 0) {
+            tr.advance(rT, F.kp_times, t - 1, T, strideB);
+            lerp_Fu(t - 1);
+            LU = cost_tile(Wr);
+            load_res(t - 2);
+            publish_luz(LU);
+        }
+        __syncthreads();
+    }
+    if (lane_nn) delta_J[b] = dJ;
+    if (lane == 0) status[b] = fail;
+}
+
+// ---- wave Z: state side ---------------------------------------------------------------------------------------
+template <int N, int M>
+__device__ __forceinline__ void fused2_role_Z(double *sh, RecLayout L, FusedArgs F, int T, const double *__restrict__ rec, int pd_stride)
+{
+    constexpr int NCZ = (N + 1 + 3) / 4;
+    constexpr int NCU = (M + 3) / 4;
+    constexpr int n = N, m = M;
+    const int lane = threadIdx.x & 63, c = lane & 15, q = lane >> 4;
+    const int b = blockIdx.x;
+    const int nr = F.nr, ncr = (nr + 3) >> 2;
+    const int strideB = L.stride * 8;
+    const int *sflag = (const int *)(sh + F2_FLAG);
+    DownTracker<8> tr;                           // A rows then B rows of column c
+    int oRx[4], oR1[4];
+    double w2run[4];
+    d4 Wt;
+    {
+        double wt[4];
+#pragma unroll
+        for (int r = 0; r < 4; r++) {
+            const int row = 4 * r + q;
+            tr.offs[r] = (row < n && c < n) ? 8 * (L.off_A + row * n + c) : OOBF;
+            tr.offs[4 + r] = (row < n && c < m) ? 8 * (L.off_B + row * m + c) : OOBF;
+            oRx[r] = (row < nr && c < n) ? 8 * (row * n + c) : OOBF;
+            oR1[r] = (row < nr && c == n) ? 8 * row : OOBF;
+            w2run[r] = (row < nr) ? 2.0 * F.w_run[row] : 0.0;
+            wt[r] = (row < nr) ? 2.0 * F.w_term[row] : 0.0;
+        }
+        Wt.x = wt[0]; Wt.y = wt[1]; Wt.z = wt[2]; Wt.w = wt[3];
+    }
+    const d4 Wr = {w2run[0], w2run[1], w2run[2], w2run[3]};
+    const bool lane_nn = (c == n) && (q == (n & 3));
+    constexpr int REG_NN = n >> 2;
+    const d4 zero = {0.0, 0.0, 0.0, 0.0};
+    const double *R0 = rec + (size_t)b * T * L.stride;
+    __amdgpu_buffer_rsrc_t rT = frsrc(R0, T * strideB);
+    const double *rb = F.r + (size_t)b * (T + 1) * nr;
+    const double *rxb = F.r_x + (size_t)b * (T + 1) * nr * n;
+    d4 Rx, R1;
+    auto load_res = [&](int t) {
+        const bool ok = t >= 0;
+        __amdgpu_buffer_rsrc_t rA = frsrc(rxb + (size_t)(ok ? t : 0) * nr * n, ok ? nr * n * 8 : 0);
+        __amdgpu_buffer_rsrc_t rR = frsrc(rb + (size_t)(ok ? t : 0) * nr, ok ? nr * 8 : 0);
+        Rx.x = fbld(rA, oRx[0]); Rx.y = fbld(rA, oRx[1]); Rx.z = fbld(rA, oRx[2]); Rx.w = fbld(rA, oRx[3]);
+        R1.x = fbld(rR, oR1[0]); R1.y = fbld(rR, oR1[1]); R1.z = fbld(rR, oR1[2]); R1.w = fbld(rR, oR1[3]);
+    };
+    auto cost_tile = [&](const d4 &W2) -> d4 {         // Lzz = [l_xx l_x; l_x' *] = Rz' W Rz
+        d4 Rz;
+        Rz.x = bits_or(Rx.x, R1.x); Rz.y = bits_or(Rx.y, R1.y); Rz.z = bits_or(Rx.z, R1.z); Rz.w = bits_or(Rx.w, R1.w);
+        return PR(Rz, Rz * W2, zero, ncr);
+    };
+    const int kd = (c < F.dof) ? c : c - F.dof;
+    tr.init(rT, F.kp_offsets, F.kp_times, c < n, (size_t)b * F.dof + kd, T, strideB);
+#pragma unroll
+    for (int r = 0; r < 4; r++) if (c == n && 4 * r + q == n) tr.sv[r] = 1.0;       // Fz(n,n) = 1
+    d4 Fz, Fu;
+    auto lerp_F = [&](int t) {
+        const double dt = (double)(t - tr.s);
+        Fz.x = tr.value(0, dt); Fz.y = tr.value(1, dt); Fz.z = tr.value(2, dt); Fz.w = tr.value(3, dt);
+        Fu.x = tr.value(4, dt); Fu.y = tr.value(5, dt); Fu.z = tr.value(6, dt); Fu.w = tr.value(7, dt);
+    };
+    // prologue: step T-1, terminal weights; V' <- Lzz(T-1)   (iLQR.cpp:537-539)
+    load_res(T - 1);
+    lerp_F(T - 1);
+    d4 Lzz = cost_tile(Wt);
+    load_res(T - 2);
+    d4 V = Lzz;
+    lds_store4(sh + F2_V, lane, V);
+    __syncthreads();
+
+    int pd_counter = 0;
+    (void)pd_stride; (void)pd_counter;
+    for (int t = T - 1; t >= 0; t--) {
+        // ---- phase 1: Tz, Quz, Qzz --------------------------------------------------------------------------
+        const d4 Luz = lds_tile4(sh + F2_L, lane);
+        const d4 Tz = PS<NCZ>(V, Fz, zero);
+        const d4 Quz = PS<NCZ>(Fu, Tz, Luz);                                  // :572,579
+        sh[F2_Z + c * 17 + q] = Quz.x;
+        if (NCU > 1) sh[F2_Z + c * 17 + 4 + q] = Quz.y;
+        if (NCU > 2) sh[F2_Z + c * 17 + 8 + q] = Quz.z;
+        if (NCU > 3) sh[F2_Z + c * 17 + 12 + q] = Quz.w;
+        const d4 Qzz = PS<NCZ>(Fz, Tz, Lzz);                                  // :570,575
+        __syncthreads();
+        if (sflag[0]) break;
+        // ---- phase 2 (off the critical path): next step's A,B columns and Lzz -----------------------------------
+        if (t > 0) {
+            tr.advance(rT, F.kp_times, t - 1, T, strideB);
+            lerp_F(t - 1);
+            Lzz = cost_tile(Wr);
+            load_res(t - 2);
+        }
+        __syncthreads();
+        // ---- phase 3: V' = Qzz + X'G, (V+V')/2 ------------------------------------------------------------------
+        const d4 Xp = lds_tile4(sh + F2_X, lane), G = lds_tile4(sh + F2_G, lane);
+        const d4 acc = PS<NCU>(Xp, G, Qzz);                                   // :606-607
+        sh[F2_S + (q) * 17 + c] = acc.x;
+        sh[F2_S + (4 + q) * 17 + c] = acc.y;
+        sh[F2_S + (8 + q) * 17 + c] = acc.z;
+        sh[F2_S + (12 + q) * 17 + c] = acc.w;
+        V.x = 0.5 * (acc.x + sh[F2_S + c * 17 + q]);                          // :610
+        V.y = 0.5 * (acc.y + sh[F2_S + c * 17 + 4 + q]);
+        V.z = 0.5 * (acc.z + sh[F2_S + c * 17 + 8 + q]);
+        V.w = 0.5 * (acc.w + sh[F2_S + c * 17 + 12 + q]);
+        if (lane_nn) fset_reg<REG_NN>(V, 0.0);
+        lds_store4(sh + F2_V, lane, V);
+        __syncthreads();
+    }
+}
+
+template <int N, int M>
+__global__ void __launch_bounds__(128) __attribute__((amdgpu_waves_per_eu(2, 2)))
+k_backward_fused2(RecLayout L, FusedArgs F, int T, int role_shift, const double *__restrict__ rec, const double *__restrict__ lambda,
+                  int pd_stride, double *__restrict__ Kout, double *__restrict__ kout,
+                  double *__restrict__ delta_J, int *__restrict__ status)
+{
+    __shared__ __attribute__((aligned(16))) double sh[F2_TOTAL];
+    // The role is wave-uniform and the compiler must know it (readfirstlane): scalar branches, SGPR descriptors.
+    // Which wave plays which role can alternate with the block index (role_shift) to mix U and Z waves on a SIMD.
+    const bool isU = ((__builtin_amdgcn_readfirstlane(threadIdx.x >> 6) ^ (blockIdx.x >> role_shift)) & 1) == 0;
+    if (isU) fused2_role_U<N, M>(sh, L, F, T, rec, lambda[blockIdx.x], pd_stride, Kout, kout, delta_J, status);
+    else     fused2_role_Z<N, M>(sh, L, F, T, rec, pd_stride);
+}
+
 // ---------------------------------------------------------------------------------------------------------
 // Forward pass.  The column tracker walks UP in time; its tiles (row = A row, col = A column) are turned into
 // the Y operands (row = contraction index) through a padded LDS transpose, off the Z dependency chain.
@@ -681,6 +1077,17 @@ hipError_t launch_backward_fused(Ctx *c, int pd_stride)
     dim3 grid(c->d.batch), block(64);
     const bool excl = c->d.batch <= c->n_simd;
     const FusedArgs F = fused_args(c);
+    const char *e2 = getenv("KPILQR_FUSED_WAVES");              // diagnostic: 1 = one wave per trajectory, 2 = two
+    const bool two = e2 ? atoi(e2) == 2 : false;
+    if (two) {
+        dim3 block2(128);
+        const char *rs = getenv("KPILQR_ROLE_SHIFT");
+        const int role_shift = rs ? atoi(rs) : 9;
+        if (n == 14 && m == 7) hipLaunchKernelGGL((k_backward_fused2<14, 7>), grid, block2, 0, c->stream, c->L, F, c->d.T, role_shift, c->rec, c->lambda, pd_stride, c->K, c->k, c->delta_J, c->status);
+        else if (n == 4 && m == 1) hipLaunchKernelGGL((k_backward_fused2<4, 1>), grid, block2, 0, c->stream, c->L, F, c->d.T, role_shift, c->rec, c->lambda, pd_stride, c->K, c->k, c->delta_J, c->status);
+        else return hipErrorInvalidValue;
+        return hipGetLastError();
+    }
 #define LAUNCH(NN, MM)                                                                                       \
     do {                                                                                                     \
         if (excl)                                                                                            \

@@ -519,7 +519,7 @@ k_backward_tiled_mw(RecLayout L, int T, const double *__restrict__ rec, const do
     constexpr int SN = (NT + W - 1) / W;             // slots for the NT item families (deal starts at wave 0)
     const int n = L.n, m = M, nz = n + 1;
     const int lane = threadIdx.x & 63, c = lane & 15, q = lane >> 4;
-    const int w = threadIdx.x >> 6;
+    const int w = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const int b = blockIdx.x;
     const double lam = lambda[b];
     double *bufV = sh;
@@ -781,7 +781,7 @@ k_backward_tiled_col(RecLayout L, int T, const double *__restrict__ rec, const d
     constexpr int NZZ = NT * NT;
     const int n = L.n, m = M, nz = n + 1;
     const int lane = threadIdx.x & 63, c = lane & 15, q = lane >> 4;
-    const int w = threadIdx.x >> 6;                  // this wave's column tile
+    const int w = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);    // this wave's column tile (wave-uniform)
     const int b = blockIdx.x;
     const double lam = lambda[b];
     double *bufV = sh;                               // V' (NT x NT tiles, tile (i,j) at i*NT+j)
@@ -1094,7 +1094,7 @@ k_forward_tiled(RecLayout L, int T, int n_alpha, const double *__restrict__ rec,
     __shared__ double red[NT * 64];
     const int n = L.n, m = L.m, nz2 = n + 2;
     const int lane = threadIdx.x & 63, c = lane & 15, q = lane >> 4;
-    const int wi = threadIdx.x >> 6;                 // this wave's row tile
+    const int wi = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);   // this wave's row tile (wave-uniform)
     const int b = blockIdx.x;
     const int ncu = (m + 3) >> 2;
     auto nchunk = [&](int kt) { const int rows = nz2 - 16 * kt; return rows >= 16 ? 4 : (rows + 3) / 4; };
