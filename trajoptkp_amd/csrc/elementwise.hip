@@ -39,22 +39,38 @@ k_fd_difference(RecLayout L, int T, int nslots, const int *__restrict__ slot_sta
     if (live) { j0 = slot_start[slot]; nj = slot_start[slot + 1] - j0; }
     for (int cidx = lane; cidx < ncol; cidx += 64) present[cidx] = 0;
     __syncthreads();
-    for (int w = lane; w < nj * n; w += 64) {
-        const int j = w / n, row = w - j * n;
-        const int job = j0 + j;
-        const int mode = job_mode[job];
-        const double xp = xplus[(size_t)job * n + row];
-        const double xm = xminus[(size_t)job * n + row];
-        double v;
-        if (mode == 0) {
-            v = (xp - xm) / (2 * eps);
-        } else {
-            const double x0 = xnom[(size_t)job_nom[job] * n + row];
-            v = (mode == 1) ? (xp - x0) / (eps) : (x0 - xm) / (eps);
+    // four elements per lane per trip: the eight loads are issued before the first division, so a trip exposes one
+    // memory latency instead of four (few waves are resident when the per-slot LDS image is large, n = 62)
+    for (int w0 = lane; w0 < nj * n; w0 += 4 * 64) {
+        double xp[4], xm[4];
+        int jobs_[4], rows_[4], modes_[4];
+#pragma unroll
+        for (int u = 0; u < 4; u++) {
+            const int w = w0 + 64 * u;
+            const bool ok = w < nj * n;
+            const int j = ok ? w / n : 0;
+            rows_[u] = ok ? w - j * n : -1;
+            jobs_[u] = j0 + j;
+            const size_t at = (size_t)jobs_[u] * n + (ok ? rows_[u] : 0);
+            xp[u] = ok ? xplus[at] : 0.0;
+            xm[u] = ok ? xminus[at] : 0.0;
+            modes_[u] = ok ? job_mode[jobs_[u]] : 0;
         }
-        const int col = job_col[job];
-        sv[col * n + row] = v;
-        if (row == 0) present[col] = 1;
+#pragma unroll
+        for (int u = 0; u < 4; u++) {
+            if (rows_[u] < 0) continue;
+            const int job = jobs_[u], row = rows_[u], mode = modes_[u];
+            double v;
+            if (mode == 0) {
+                v = (xp[u] - xm[u]) / (2 * eps);
+            } else {
+                const double x0 = xnom[(size_t)job_nom[job] * n + row];
+                v = (mode == 1) ? (xp[u] - x0) / (eps) : (x0 - xm[u]) / (eps);
+            }
+            const int col = job_col[job];
+            sv[col * n + row] = v;
+            if (row == 0) present[col] = 1;
+        }
     }
     __syncthreads();
     if (live) {
