@@ -17,11 +17,10 @@
 //     cost: lane-local  sum_r Z_r * P(Lc, Z)_r / 2 + dU_r * (P(Luu, dU)_r / 2 + l_u)   with
 //           Lc = [l_xx 0 l_x; 0 0 0; l_x' 0 0]; per-lane partial sums over t, one cross-lane
 //           reduction at the end.
-#include "common.h"
+#include "mfma_common.h"
 
 namespace kpilqr {
 
-typedef double d4 __attribute__((ext_vector_type(4)));
 #define MFMA(a, b, c) __builtin_amdgcn_mfma_f64_16x16x4f64((a), (b), (c), 0, 0, 0)
 
 template <int NC>

@@ -22,11 +22,10 @@
 // Everything else (homogeneous form, LDL' solve, slow path, stores) is riccati_mfma.hip / forward_mfma.hip.
 // Per launch the kernels read Kp*(n^2+nm) + T*nr*(1+n+m) doubles instead of T*(2n^2+nm+n+m^2+m).
 #include <cstdlib>
-#include "common.h"
+#include "mfma_common.h"
 
 namespace kpilqr {
 
-typedef double d4 __attribute__((ext_vector_type(4)));
 typedef unsigned int u32x2f __attribute__((ext_vector_type(2)));
 typedef unsigned long long u64;
 #define MFMA(a, b, c) __builtin_amdgcn_mfma_f64_16x16x4f64((a), (b), (c), 0, 0, 0)
@@ -87,63 +86,6 @@ __device__ __forceinline__ double lerp_nc(double sv, double dt, double av)
 #pragma clang fp contract(off)
     const double p = dt * av;
     return sv + p;
-}
-
-// Eigen's pivoted LDLT + solve(I) (slow path; identical to riccati_mfma.hip's)
-__device__ static __attribute__((noinline)) void fslow_ldlt_inverse(int m, const double *M, int ms, double *a, double *x, double *temp, int *tr)
-{
-#define AA(i, j) a[(i) + (j) * m]
-#define XX(i, j) x[(i) + (j) * m]
-    for (int j = 0; j < m; j++) for (int i = 0; i < m; i++) AA(i, j) = M[i * ms + j];
-    for (int k = 0; k < m; k++) {
-        int big = k; double bv = fabs(AA(k, k));
-        for (int i = k + 1; i < m; i++) if (fabs(AA(i, i)) > bv) { bv = fabs(AA(i, i)); big = i; }
-        tr[k] = big;
-        if (big != k) {
-            for (int j = 0; j < k; j++) { double t = AA(k, j); AA(k, j) = AA(big, j); AA(big, j) = t; }
-            for (int i = big + 1; i < m; i++) { double t = AA(i, k); AA(i, k) = AA(i, big); AA(i, big) = t; }
-            { double t = AA(k, k); AA(k, k) = AA(big, big); AA(big, big) = t; }
-            for (int i = k + 1; i < big; i++) { double t = AA(i, k); AA(i, k) = AA(big, i); AA(big, i) = t; }
-        }
-        if (k > 0) {
-            for (int j = 0; j < k; j++) temp[j] = AA(j, j) * AA(k, j);
-            double dot = 0.0;
-            for (int j = 0; j < k; j++) dot += AA(k, j) * temp[j];
-            AA(k, k) -= dot;
-            for (int i = k + 1; i < m; i++) {
-                double d2 = 0.0;
-                for (int j = 0; j < k; j++) d2 += AA(i, j) * temp[j];
-                AA(i, k) -= d2;
-            }
-        }
-        const double akk = AA(k, k);
-        const bool valid = fabs(akk) > 0.0;
-        if (k == 0 && !valid) { for (int j = 0; j < m; j++) tr[j] = j; break; }
-        if (valid) for (int i = k + 1; i < m; i++) AA(i, k) /= akk;
-    }
-    for (int c = 0; c < m; c++) for (int r = 0; r < m; r++) XX(r, c) = (r == c) ? 1.0 : 0.0;
-    for (int k = 0; k < m; k++)
-        if (tr[k] != k) for (int c = 0; c < m; c++) { double t = XX(k, c); XX(k, c) = XX(tr[k], c); XX(tr[k], c) = t; }
-    for (int c = 0; c < m; c++)
-        for (int k = 0; k < m; k++) {
-            const double b = XX(k, c);
-            for (int i = k + 1; i < m; i++) XX(i, c) -= b * AA(i, k);
-        }
-    for (int i = 0; i < m; i++) {
-        const double d = AA(i, i);
-        for (int c = 0; c < m; c++) {
-            if (fabs(d) > 2.2250738585072014e-308) XX(i, c) /= d; else XX(i, c) = 0.0;
-        }
-    }
-    for (int c = 0; c < m; c++)
-        for (int k = m - 1; k >= 0; k--) {
-            const double b = XX(k, c);
-            for (int i = 0; i < k; i++) XX(i, c) -= b * AA(k, i);
-        }
-    for (int k = m - 1; k >= 0; k--)
-        if (tr[k] != k) for (int c = 0; c < m; c++) { double t = XX(k, c); XX(k, c) = XX(tr[k], c); XX(tr[k], c) = t; }
-#undef AA
-#undef XX
 }
 
 struct FusedArgs {
@@ -365,7 +307,7 @@ __device__ __forceinline__ void backward_fused_body(RecLayout L, FusedArgs F, in
         } else {
             double *wa = sh + FLDS_SLOW, *wx = wa + 256, *wt = wx + 256;
             int *tr = (int *)(wt + 16);
-            if (lane == 0) fslow_ldlt_inverse(L.m, sh + FLDS_Q, FMS, wa, wx, wt, tr);
+            if (lane == 0) kp_slow_ldlt_inverse(L.m, sh + FLDS_Q, FMS, wa, wx, wt, tr);
             __syncthreads();
 #pragma unroll
             for (int i = 0; i < M; i++) {
@@ -655,7 +597,7 @@ __device__ __forceinline__ void fused2_role_U(double *sh, RecLayout L, FusedArgs
             // indefinite on an unchecked step: Eigen's pivoted LDLT + explicit inverse (iLQR.cpp:597-604)
             double *wa = sh + F2_SLOW, *wx = wa + 256, *wt = wx + 256;
             int *trp = (int *)(wt + 16);
-            if (lane == 0) fslow_ldlt_inverse(L.m, sh + F2_Q, 16, wa, wx, wt, trp);
+            if (lane == 0) kp_slow_ldlt_inverse(L.m, sh + F2_Q, 16, wa, wx, wt, trp);
             __builtin_amdgcn_wave_barrier();
 #pragma unroll
             for (int i = 0; i < M; i++) {

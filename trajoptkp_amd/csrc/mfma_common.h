@@ -1,0 +1,96 @@
+// mfma_common.h -- device helpers shared by the FP64 MFMA kernels (riccati_mfma.hip, forward_mfma.hip,
+// tiled_mfma.hip, fused_mfma.hip): the tile type and primitive, bounds-checked buffer loads, a ~1 ulp reciprocal,
+// and the slow path of the backward pass (Eigen's pivoted LDLT + explicit inverse).
+#pragma once
+#include "common.h"
+
+namespace kpilqr {
+
+typedef double d4 __attribute__((ext_vector_type(4)));
+typedef unsigned int u32x2 __attribute__((ext_vector_type(2)));
+
+// D = A*B + C on the FP64 matrix core, 16x16 output, 4 rows of the contraction per instruction.
+#define KP_MFMA(a, b, c) __builtin_amdgcn_mfma_f64_16x16x4f64((a), (b), (c), 0, 0, 0)
+// byte offset that lies outside every buffer descriptor used here: the load returns 0, the store is dropped
+#define KP_OOB 0x7ffffff0
+
+__device__ __forceinline__ double kp_bld(__amdgpu_buffer_rsrc_t r, int byte_off)
+{
+    return __builtin_bit_cast(double, __builtin_amdgcn_raw_buffer_load_b64(r, byte_off, 0, 0));
+}
+__device__ __forceinline__ __amdgpu_buffer_rsrc_t kp_rsrc(const void *p, int bytes)
+{
+    return __builtin_amdgcn_make_buffer_rsrc((void *)p, 0, bytes, 0x00020000);
+}
+// 1/x to ~1 ulp: v_rcp_f64 seed + two Newton steps (the pivots are O(lambda)..O(1): no scaling needed; a
+// non-positive or non-finite pivot is caught by the callers' `pos` test and takes the slow path).
+__device__ __forceinline__ double kp_rcp(double x)
+{
+    double r = __builtin_amdgcn_rcp(x);
+    r = __builtin_fma(__builtin_fma(-x, r, 1.0), r, r);
+    r = __builtin_fma(__builtin_fma(-x, r, 1.0), r, r);
+    return r;
+}
+
+// Eigen's LDLT (symmetric pivoting, in place on the lower triangle) followed by solve(Identity), restated line
+// for line as the reference uses it when Q_uu + lambda I is not PD on an unchecked step
+// (src/Optimiser/iLQR.cpp:597-604); identical to generic.hip's dev_ldlt_inverse and oracle/orc_ldlt_inverse.
+// M: m x m row-major with row stride ms; a, x: m*m work/result (column-major); temp: m; tr: m ints.
+// Run by ONE lane; noinline with a run-time m so that the rare path costs no registers in the hot loop.
+__device__ static __attribute__((noinline)) void kp_slow_ldlt_inverse(int m, const double *M, int ms, double *a, double *x, double *temp, int *tr)
+{
+#define AA(i, j) a[(i) + (j) * m]
+#define XX(i, j) x[(i) + (j) * m]
+    for (int j = 0; j < m; j++) for (int i = 0; i < m; i++) AA(i, j) = M[i * ms + j];
+    for (int k = 0; k < m; k++) {
+        int big = k; double bv = fabs(AA(k, k));
+        for (int i = k + 1; i < m; i++) if (fabs(AA(i, i)) > bv) { bv = fabs(AA(i, i)); big = i; }
+        tr[k] = big;
+        if (big != k) {
+            for (int j = 0; j < k; j++) { double t = AA(k, j); AA(k, j) = AA(big, j); AA(big, j) = t; }
+            for (int i = big + 1; i < m; i++) { double t = AA(i, k); AA(i, k) = AA(i, big); AA(i, big) = t; }
+            { double t = AA(k, k); AA(k, k) = AA(big, big); AA(big, big) = t; }
+            for (int i = k + 1; i < big; i++) { double t = AA(i, k); AA(i, k) = AA(big, i); AA(big, i) = t; }
+        }
+        if (k > 0) {
+            for (int j = 0; j < k; j++) temp[j] = AA(j, j) * AA(k, j);
+            double dot = 0.0;
+            for (int j = 0; j < k; j++) dot += AA(k, j) * temp[j];
+            AA(k, k) -= dot;
+            for (int i = k + 1; i < m; i++) {
+                double d2 = 0.0;
+                for (int j = 0; j < k; j++) d2 += AA(i, j) * temp[j];
+                AA(i, k) -= d2;
+            }
+        }
+        const double akk = AA(k, k);
+        const bool valid = fabs(akk) > 0.0;
+        if (k == 0 && !valid) { for (int j = 0; j < m; j++) tr[j] = j; break; }
+        if (valid) for (int i = k + 1; i < m; i++) AA(i, k) /= akk;
+    }
+    for (int c = 0; c < m; c++) for (int r = 0; r < m; r++) XX(r, c) = (r == c) ? 1.0 : 0.0;
+    for (int k = 0; k < m; k++)
+        if (tr[k] != k) for (int c = 0; c < m; c++) { double t = XX(k, c); XX(k, c) = XX(tr[k], c); XX(tr[k], c) = t; }
+    for (int c = 0; c < m; c++)
+        for (int k = 0; k < m; k++) {
+            const double b = XX(k, c);
+            for (int i = k + 1; i < m; i++) XX(i, c) -= b * AA(i, k);
+        }
+    for (int i = 0; i < m; i++) {
+        const double d = AA(i, i);
+        for (int c = 0; c < m; c++) {
+            if (fabs(d) > 2.2250738585072014e-308) XX(i, c) /= d; else XX(i, c) = 0.0;
+        }
+    }
+    for (int c = 0; c < m; c++)
+        for (int k = m - 1; k >= 0; k--) {
+            const double b = XX(k, c);
+            for (int i = 0; i < k; i++) XX(i, c) -= b * AA(k, i);
+        }
+    for (int k = m - 1; k >= 0; k--)
+        if (tr[k] != k) for (int c = 0; c < m; c++) { double t = XX(k, c); XX(k, c) = XX(tr[k], c); XX(tr[k], c) = t; }
+#undef AA
+#undef XX
+}
+
+}  // namespace kpilqr

@@ -29,13 +29,11 @@
 // O(1e-14) relative for the PD, lambda-regularised systems the algorithm accepts.  When a pivot is
 // not positive (Q_uu + lambda I indefinite between two PD checks) the kernel falls back to a
 // line-for-line port of Eigen's pivoted LDLT so that even that case follows the reference.
-#include "common.h"
+#include "mfma_common.h"
 
 namespace kpilqr {
 
-typedef double d4 __attribute__((ext_vector_type(4)));
-
-#define MFMA(a, b, c) __builtin_amdgcn_mfma_f64_16x16x4f64((a), (b), (c), 0, 0, 0)
+#define MFMA KP_MFMA
 
 // acc + Y' X over NC row-chunks (rows 0 .. 4*NC-1 of Y and X).
 template <int NC>
@@ -52,7 +50,6 @@ __device__ __forceinline__ d4 P(const d4 &Y, const d4 &X, d4 acc)
 // element is a structural zero carry an out-of-range offset and the hardware returns 0 for them
 // without touching memory.  No select on the loaded value means nothing consumes it until the MFMA
 // that needs it, so the loads of step t-1 stay in flight behind the whole of step t.
-typedef unsigned int u32x2 __attribute__((ext_vector_type(2)));
 #define OOB 0x7ffffff0
 
 __device__ __forceinline__ double bld(__amdgpu_buffer_rsrc_t r, int byte_off)
@@ -110,63 +107,6 @@ __device__ __forceinline__ void load_step(const double *R, int rec_bytes, const 
     s.Luz.y = NCU > 1 ? bld(r, o.luz[1]) : 0.0; s.Luu.y = NCU > 1 ? bld(r, o.luu[1]) : 0.0;
     s.Luz.z = NCU > 2 ? bld(r, o.luz[2]) : 0.0; s.Luu.z = NCU > 2 ? bld(r, o.luu[2]) : 0.0;
     s.Luz.w = NCU > 3 ? bld(r, o.luz[3]) : 0.0; s.Luu.w = NCU > 3 ? bld(r, o.luu[3]) : 0.0;
-}
-
-// Eigen's pivoted LDLT + solve(I) (slow path; identical to generic.hip's dev_ldlt_inverse).
-__device__ static __attribute__((noinline)) void slow_ldlt_inverse(int m, const double *M, int ms, double *a, double *x, double *temp, int *tr)
-{
-#define AA(i, j) a[(i) + (j) * m]
-#define XX(i, j) x[(i) + (j) * m]
-    for (int j = 0; j < m; j++) for (int i = 0; i < m; i++) AA(i, j) = M[i * ms + j];
-    for (int k = 0; k < m; k++) {
-        int big = k; double bv = fabs(AA(k, k));
-        for (int i = k + 1; i < m; i++) if (fabs(AA(i, i)) > bv) { bv = fabs(AA(i, i)); big = i; }
-        tr[k] = big;
-        if (big != k) {
-            for (int j = 0; j < k; j++) { double t = AA(k, j); AA(k, j) = AA(big, j); AA(big, j) = t; }
-            for (int i = big + 1; i < m; i++) { double t = AA(i, k); AA(i, k) = AA(i, big); AA(i, big) = t; }
-            { double t = AA(k, k); AA(k, k) = AA(big, big); AA(big, big) = t; }
-            for (int i = k + 1; i < big; i++) { double t = AA(i, k); AA(i, k) = AA(big, i); AA(big, i) = t; }
-        }
-        if (k > 0) {
-            for (int j = 0; j < k; j++) temp[j] = AA(j, j) * AA(k, j);
-            double dot = 0.0;
-            for (int j = 0; j < k; j++) dot += AA(k, j) * temp[j];
-            AA(k, k) -= dot;
-            for (int i = k + 1; i < m; i++) {
-                double d2 = 0.0;
-                for (int j = 0; j < k; j++) d2 += AA(i, j) * temp[j];
-                AA(i, k) -= d2;
-            }
-        }
-        const double akk = AA(k, k);
-        const bool valid = fabs(akk) > 0.0;
-        if (k == 0 && !valid) { for (int j = 0; j < m; j++) tr[j] = j; break; }
-        if (valid) for (int i = k + 1; i < m; i++) AA(i, k) /= akk;
-    }
-    for (int c = 0; c < m; c++) for (int r = 0; r < m; r++) XX(r, c) = (r == c) ? 1.0 : 0.0;
-    for (int k = 0; k < m; k++)
-        if (tr[k] != k) for (int c = 0; c < m; c++) { double t = XX(k, c); XX(k, c) = XX(tr[k], c); XX(tr[k], c) = t; }
-    for (int c = 0; c < m; c++)
-        for (int k = 0; k < m; k++) {
-            const double b = XX(k, c);
-            for (int i = k + 1; i < m; i++) XX(i, c) -= b * AA(i, k);
-        }
-    for (int i = 0; i < m; i++) {
-        const double d = AA(i, i);
-        for (int c = 0; c < m; c++) {
-            if (fabs(d) > 2.2250738585072014e-308) XX(i, c) /= d; else XX(i, c) = 0.0;
-        }
-    }
-    for (int c = 0; c < m; c++)
-        for (int k = m - 1; k >= 0; k--) {
-            const double b = XX(k, c);
-            for (int i = 0; i < k; i++) XX(i, c) -= b * AA(k, i);
-        }
-    for (int k = m - 1; k >= 0; k--)
-        if (tr[k] != k) for (int c = 0; c < m; c++) { double t = XX(k, c); XX(k, c) = XX(tr[k], c); XX(tr[k], c) = t; }
-#undef AA
-#undef XX
 }
 
 // LDS map (doubles).  MS: row stride of the Quu image; MZ: column stride of the Quz image (odd ->
@@ -319,7 +259,7 @@ __device__ __forceinline__ void backward_body(RecLayout L, int T, const double *
             // LDLT + explicit inverse exactly (iLQR.cpp:597-604).
             double *wa = sh + LDS_SLOW, *wx = wa + 256, *wt = wx + 256;
             int *tr = (int *)(wt + 16);
-            if (lane == 0) slow_ldlt_inverse(L.m, sh + LDS_Q, MS, wa, wx, wt, tr);
+            if (lane == 0) kp_slow_ldlt_inverse(L.m, sh + LDS_Q, MS, wa, wx, wt, tr);
             __syncthreads();
 #pragma unroll
             for (int i = 0; i < M; i++) {

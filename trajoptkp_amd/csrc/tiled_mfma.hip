@@ -13,11 +13,10 @@
 // A workgroup is exactly one wavefront, so LDS traffic needs no s_barrier; __syncthreads() is kept as
 // the compiler-level ordering point (it lowers to nothing for a 64-thread workgroup).
 #include <cstdlib>
-#include "common.h"
+#include "mfma_common.h"
 
 namespace kpilqr {
 
-typedef double d4 __attribute__((ext_vector_type(4)));
 typedef unsigned int u32x2t __attribute__((ext_vector_type(2)));
 #define MFMA(a, b, c) __builtin_amdgcn_mfma_f64_16x16x4f64((a), (b), (c), 0, 0, 0)
 #define OOBT 0x7ffffff0
@@ -63,63 +62,6 @@ __device__ __forceinline__ double trcp(double x)
     r = __builtin_fma(__builtin_fma(-x, r, 1.0), r, r);
     r = __builtin_fma(__builtin_fma(-x, r, 1.0), r, r);
     return r;
-}
-
-// Eigen's pivoted LDLT + solve(I) on a row-major m x m image (slow path, see riccati_mfma.hip)
-__device__ static __attribute__((noinline)) void tslow_ldlt_inverse(int m, const double *M, double *a, double *x, double *temp, int *tr)
-{
-#define AA(i, j) a[(i) + (j) * m]
-#define XX(i, j) x[(i) + (j) * m]
-    for (int j = 0; j < m; j++) for (int i = 0; i < m; i++) AA(i, j) = M[i * 16 + j];
-    for (int k = 0; k < m; k++) {
-        int big = k; double bv = fabs(AA(k, k));
-        for (int i = k + 1; i < m; i++) if (fabs(AA(i, i)) > bv) { bv = fabs(AA(i, i)); big = i; }
-        tr[k] = big;
-        if (big != k) {
-            for (int j = 0; j < k; j++) { double t = AA(k, j); AA(k, j) = AA(big, j); AA(big, j) = t; }
-            for (int i = big + 1; i < m; i++) { double t = AA(i, k); AA(i, k) = AA(i, big); AA(i, big) = t; }
-            { double t = AA(k, k); AA(k, k) = AA(big, big); AA(big, big) = t; }
-            for (int i = k + 1; i < big; i++) { double t = AA(i, k); AA(i, k) = AA(big, i); AA(big, i) = t; }
-        }
-        if (k > 0) {
-            for (int j = 0; j < k; j++) temp[j] = AA(j, j) * AA(k, j);
-            double dot = 0.0;
-            for (int j = 0; j < k; j++) dot += AA(k, j) * temp[j];
-            AA(k, k) -= dot;
-            for (int i = k + 1; i < m; i++) {
-                double d2 = 0.0;
-                for (int j = 0; j < k; j++) d2 += AA(i, j) * temp[j];
-                AA(i, k) -= d2;
-            }
-        }
-        const double akk = AA(k, k);
-        const bool valid = fabs(akk) > 0.0;
-        if (k == 0 && !valid) { for (int j = 0; j < m; j++) tr[j] = j; break; }
-        if (valid) for (int i = k + 1; i < m; i++) AA(i, k) /= akk;
-    }
-    for (int c = 0; c < m; c++) for (int r = 0; r < m; r++) XX(r, c) = (r == c) ? 1.0 : 0.0;
-    for (int k = 0; k < m; k++)
-        if (tr[k] != k) for (int c = 0; c < m; c++) { double t = XX(k, c); XX(k, c) = XX(tr[k], c); XX(tr[k], c) = t; }
-    for (int c = 0; c < m; c++)
-        for (int k = 0; k < m; k++) {
-            const double b = XX(k, c);
-            for (int i = k + 1; i < m; i++) XX(i, c) -= b * AA(i, k);
-        }
-    for (int i = 0; i < m; i++) {
-        const double d = AA(i, i);
-        for (int c = 0; c < m; c++) {
-            if (fabs(d) > 2.2250738585072014e-308) XX(i, c) /= d; else XX(i, c) = 0.0;
-        }
-    }
-    for (int c = 0; c < m; c++)
-        for (int k = m - 1; k >= 0; k--) {
-            const double b = XX(k, c);
-            for (int i = 0; i < k; i++) XX(i, c) -= b * AA(k, i);
-        }
-    for (int k = m - 1; k >= 0; k--)
-        if (tr[k] != k) for (int c = 0; c < m; c++) { double t = XX(k, c); XX(k, c) = XX(tr[k], c); XX(tr[k], c) = t; }
-#undef AA
-#undef XX
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -330,7 +272,7 @@ k_backward_tiled(RecLayout L, int T, const double *__restrict__ rec, const doubl
             // indefinite on an unchecked step: Eigen's pivoted LDLT + explicit inverse (iLQR.cpp:597-604)
             if (lane == 0) {
                 for (int i = 0; i < m; i++) for (int j = 0; j < m; j++) sRow[i * 16 + j] = qel(i, j);
-                tslow_ldlt_inverse(m, sRow, sRow + 256, winv, sRow + 768, (int *)(sRow + 784));
+                kp_slow_ldlt_inverse(m, sRow, 16, sRow + 256, winv, sRow + 768, (int *)(sRow + 784));
             }
             __syncthreads();
         }
@@ -435,16 +377,7 @@ k_backward_tiled(RecLayout L, int T, const double *__restrict__ rec, const doubl
 
 
 // ---------------------------------------------------------------------------------------------
-// Backward pass, W wavefronts per trajectory (small batches: one trajectory spreads over the SIMDs of a CU).
-// Same algebra and LDS images as k_backward_tiled; every phase's OUTPUT TILES are dealt round-robin to the
-// waves (item e -> wave e % W, register slot e / W) and the phases are separated by s_barrier:
-//   A  prefetched Fz/Fu tiles of step t: registers -> LDS                               | barrier
-//   B  Tz(i,j) = sum_k V'(k,i)' Fz(k,j),  Tu(i)                                          | barrier
-//   C  Quu, Quz(j), Qzz(i,j) (Qzz stays in the owner's registers); issue step t-1 loads  | barrier
-//   D  LDL' of Quu + lambda I in every wave (redundant, keeps the PD verdict block-uniform),
-//      solve + K/k stores + G(j) by the owner of column tile j                           | barrier
-//   E  acc(i,j) = Qzz(i,j) + X_i' G_j -> bufT (Tz is dead)                               | barrier
-//   F  V'(i,j) = (acc(i,j) + acc(j,i)')/2 -> bufV   (transposed LDS read of the partner tile)
+// Tile loaders shared by the multi-wave kernels (bounds-checked: structural zeros come back as 0).
 struct TileSrc { int n, m; int off_A, off_B, off_lxx, off_lx, off_luu, off_lu; };
 
 __device__ __forceinline__ d4 ld_Lzz(__amdgpu_buffer_rsrc_t rs, const TileSrc &S, int ti, int tj, int q, int c)
@@ -505,259 +438,6 @@ __device__ __forceinline__ d4 ld_Luu(__amdgpu_buffer_rsrc_t rs, const TileSrc &S
     d4 o = {v[0], v[1], v[2], v[3]};
     return o;
 }
-
-template <int M, int NT, int W>
-__global__ void __launch_bounds__(64 * W)
-k_backward_tiled_mw(RecLayout L, int T, const double *__restrict__ rec, const double *__restrict__ lambda,
-                    int pd_stride, double *__restrict__ Kout, double *__restrict__ kout,
-                    double *__restrict__ delta_J, int *__restrict__ status)
-{
-    extern __shared__ __attribute__((aligned(16))) double sh[];
-    constexpr int NCU = (M + 3) / 4;
-    constexpr int NZZ = NT * NT;                     // Fz / Tz / Qzz items
-    constexpr int SL = (NZZ + W - 1) / W;            // register slots per wave for the NT x NT item families
-    constexpr int SN = (NT + W - 1) / W;             // slots for the NT item families (deal starts at wave 0)
-    const int n = L.n, m = M, nz = n + 1;
-    const int lane = threadIdx.x & 63, c = lane & 15, q = lane >> 4;
-    const int w = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-    const int b = blockIdx.x;
-    const double lam = lambda[b];
-    double *bufV = sh;
-    double *bufF = bufV + NZZ * TILE;
-    double *bufT = bufF + NZZ * TILE;
-    double *bufFu = bufT + NZZ * TILE;
-    double *bufTu = bufFu + NT * TILE;
-    double *bufQuz = bufTu + NT * TILE;
-    double *bufX = bufQuz + NT * TILE;
-    double *bufG = bufX + NT * TILE;
-    double *sQ = bufG + NT * TILE;
-    double *sRow = sQ + TILE;
-    auto nchunk = [&](int kt) { const int rows = nz - 16 * kt; return rows >= 16 ? 4 : (rows + 3) / 4; };
-    const int ncl = nchunk(NT - 1);
-    TileSrc S = {n, m, L.off_A, L.off_B, L.off_lxx, L.off_lx, L.off_luu, L.off_lu};
-
-    const double *R0 = rec + (size_t)b * T * L.stride;
-    const int rec_bytes = L.rec * 8;
-    const d4 zero = {0.0, 0.0, 0.0, 0.0};
-    const int tn = n >> 4, cn = n & 15;
-    const bool lane_nn = (c == cn) && (q == (cn & 3));
-    const int reg_nn = cn >> 2;
-    d4 nn_keep;
-    nn_keep.x = (lane_nn && reg_nn == 0) ? 0.0 : 1.0; nn_keep.y = (lane_nn && reg_nn == 1) ? 0.0 : 1.0;
-    nn_keep.z = (lane_nn && reg_nn == 2) ? 0.0 : 1.0; nn_keep.w = (lane_nn && reg_nn == 3) ? 0.0 : 1.0;
-    double lam2d[4];
-#pragma unroll
-    for (int r = 0; r < 4; r++) lam2d[r] = (4 * r + q == c && c < m) ? 2.0 * lam : 0.0;
-    // owners of the single / NT-family items
-    constexpr int W_QUU = NT % W;                    // Quu after the NT Quz items
-    // prefetched source tiles of one step
-    d4 pF[SL], pL[SL], pFu[SN], pLuz[SN], pLuu;
-    auto prefetch = [&](int t) {
-        __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc((void *)(R0 + (size_t)t * L.stride), 0, rec_bytes, 0x00020000);
-#pragma unroll
-        for (int e = 0; e < NZZ; e++)
-            if (e % W == w) { pF[e / W] = ld_Fz(rs, S, e / NT, e % NT, q, c); pL[e / W] = ld_Lzz(rs, S, e / NT, e % NT, q, c); }
-#pragma unroll
-        for (int e = 0; e < NT; e++)
-            if (e % W == w) { pFu[e / W] = ld_Fu(rs, S, e, q, c); pLuz[e / W] = ld_Luz(rs, S, e, q, c); }
-        if (w == W_QUU) pLuu = ld_Luu(rs, S, q, c);
-    };
-
-    // V' <- Lzz(T-1)   (iLQR.cpp:537-539); then the tiles of step T-1 itself
-    prefetch(T - 1);
-#pragma unroll
-    for (int e = 0; e < NZZ; e++)
-        if (e % W == w) lds_store(bufV + e * TILE, lane, pL[e / W]);
-
-    int pd_counter = 0, fail = 0;
-    double dJ = 0.0;
-    for (int t = T - 1; t >= 0; t--) {
-        pd_counter++;
-        const bool check_pd = pd_counter >= pd_stride;
-        // ---- A: stage Fz (+ the homogeneous 1), Fu ---------------------------------------------------------
-#pragma unroll
-        for (int e = 0; e < NZZ; e++)
-            if (e % W == w) {
-                d4 f = pF[e / W];
-                if (e / NT == e % NT && e / NT == tn) f = f + (1.0 - nn_keep);       // Fz(n,n) = 1
-                lds_store(bufF + e * TILE, lane, f);
-            }
-#pragma unroll
-        for (int e = 0; e < NT; e++)
-            if (e % W == w) lds_store(bufFu + e * TILE, lane, pFu[e / W]);
-        __syncthreads();
-        // ---- B: Tz = V' Fz, Tu = V' Fu ------------------------------------------------------------------
-#pragma unroll
-        for (int e = 0; e < NZZ; e++)
-            if (e % W == w) {
-                const int i = e / NT, j = e % NT;
-                d4 acc = zero;
-#pragma unroll
-                for (int k = 0; k < NT; k++)
-                    acc = Pk<NT>(k, lds_tile(bufV + (k * NT + i) * TILE, lane), lds_tile(bufF + (k * NT + j) * TILE, lane), acc, ncl);
-                lds_store(bufT + e * TILE, lane, acc);
-            }
-#pragma unroll
-        for (int e = 0; e < NT; e++)
-            if ((NZZ + e) % W == w) {
-                d4 acc = zero;
-#pragma unroll
-                for (int k = 0; k < NT; k++)
-                    acc = Pk<NT>(k, lds_tile(bufV + (k * NT + e) * TILE, lane), lds_tile(bufFu + k * TILE, lane), acc, ncl);
-                lds_store(bufTu + e * TILE, lane, acc);
-            }
-        __syncthreads();
-        // ---- C: Quu, Quz, Qzz -----------------------------------------------------------------------------
-        if (w == W_QUU) {
-            d4 Quu = pLuu;
-#pragma unroll
-            for (int k = 0; k < NT; k++)
-                Quu = Pk<NT>(k, lds_tile(bufFu + k * TILE, lane), lds_tile(bufTu + k * TILE, lane), Quu, ncl);
-            Quu.x += 0.5 * lam2d[0]; Quu.y += 0.5 * lam2d[1]; Quu.z += 0.5 * lam2d[2]; Quu.w += 0.5 * lam2d[3];
-            lds_store(sQ, lane, Quu);                 // Quu + lambda I
-        }
-#pragma unroll
-        for (int e = 0; e < NT; e++)
-            if (e % W == w) {
-                d4 acc = pLuz[e / W];
-#pragma unroll
-                for (int k = 0; k < NT; k++)
-                    acc = Pk<NT>(k, lds_tile(bufFu + k * TILE, lane), lds_tile(bufT + (k * NT + e) * TILE, lane), acc, ncl);
-                lds_store(bufQuz + e * TILE, lane, acc);
-            }
-        d4 Qzz[SL];
-#pragma unroll
-        for (int e = 0; e < NZZ; e++)
-            if (e % W == w) {
-                const int i = e / NT, j = e % NT;
-                d4 acc = pL[e / W];
-#pragma unroll
-                for (int k = 0; k < NT; k++)
-                    acc = Pk<NT>(k, lds_tile(bufF + (k * NT + i) * TILE, lane), lds_tile(bufT + (k * NT + j) * TILE, lane), acc, ncl);
-                Qzz[e / W] = acc;
-            }
-        if (t > 0) prefetch(t - 1);                   // in flight behind phases D-F
-        __syncthreads();
-        // ---- D: LDL' (every wave), solve / K / G (owner of column tile j) ------------------------------------
-        auto qel = [&](int i, int j) { return sQ[(i >> 2) * 64 + j + 16 * (i & 3)]; };
-        double Lm[M][M], dd[M], rd[M];
-        bool pos = true;
-#pragma unroll
-        for (int j = 0; j < M; j++) {
-            double ww[M];
-            double dj = qel(j, j);
-#pragma unroll
-            for (int kk = 0; kk < j; kk++) { ww[kk] = Lm[j][kk] * dd[kk]; dj -= Lm[j][kk] * ww[kk]; }
-            dd[j] = dj;
-            pos = pos && (dj > 0.0);
-            const double rj = trcp(dj);
-            rd[j] = rj;
-#pragma unroll
-            for (int i = j + 1; i < M; i++) {
-                double v = qel(i, j);
-#pragma unroll
-                for (int kk = 0; kk < j; kk++) v -= Lm[i][kk] * ww[kk];
-                Lm[i][j] = v * rj;
-            }
-        }
-        if (check_pd) {                       // CheckMatrixPD every pd_stride steps   :587-595
-            if (!pos) { fail = t + 1; break; }          // block-uniform: every wave factored the same Quu
-            pd_counter = 0;
-        }
-        double *winv = sRow + 256 + 256;
-        if (!pos) {
-            if (threadIdx.x == 0) {
-                for (int i = 0; i < m; i++) for (int j = 0; j < m; j++) sRow[i * 16 + j] = qel(i, j);
-                tslow_ldlt_inverse(m, sRow, sRow + 256, winv, sRow + 768, (int *)(sRow + 784));
-            }
-            __syncthreads();
-        }
-        d4 Quu2 = lds_tile(sQ, lane);
-        Quu2.x += 0.5 * lam2d[0]; Quu2.y += 0.5 * lam2d[1]; Quu2.z += 0.5 * lam2d[2]; Quu2.w += 0.5 * lam2d[3];
-#pragma unroll
-        for (int j = 0; j < NT; j++)
-            if (j % W == w) {
-                const double *zt = bufQuz + j * TILE;
-                double x[M];
-#pragma unroll
-                for (int i = 0; i < M; i++) x[i] = zt[(i >> 2) * 64 + c + 16 * (i & 3)];
-                if (pos) {
-#pragma unroll
-                    for (int jj = 0; jj < M; jj++) {
-#pragma unroll
-                        for (int i = jj + 1; i < M; i++) x[i] -= Lm[i][jj] * x[jj];
-                    }
-#pragma unroll
-                    for (int i = 0; i < M; i++) x[i] *= rd[i];
-#pragma unroll
-                    for (int jj = M - 1; jj >= 0; jj--) {
-#pragma unroll
-                        for (int i = 0; i < jj; i++) x[i] -= Lm[jj][i] * x[jj];
-                    }
-                } else {
-                    double y[M];
-#pragma unroll
-                    for (int i = 0; i < M; i++) {
-                        double sacc = 0.0;
-#pragma unroll
-                        for (int pp = 0; pp < M; pp++) sacc += (-winv[i + pp * m]) * x[pp];
-                        y[i] = -sacc;
-                    }
-#pragma unroll
-                    for (int i = 0; i < M; i++) x[i] = y[i];
-                }
-                const int col = 16 * j + c;
-                double xr[4] = {0.0, 0.0, 0.0, 0.0};
-#pragma unroll
-                for (int i = 0; i < M; i++)
-                    if (q == (i & 3)) xr[i >> 2] = (col <= n) ? x[i] : 0.0;
-                d4 X = {xr[0], xr[1], xr[2], xr[3]};
-                lds_store(bufX + j * TILE, lane, X);
-                __amdgpu_buffer_rsrc_t rK = __builtin_amdgcn_make_buffer_rsrc((void *)(Kout + ((size_t)b * T + t) * m * n), 0, m * n * 8, 0x00020000);
-                __amdgpu_buffer_rsrc_t rk = __builtin_amdgcn_make_buffer_rsrc((void *)(kout + ((size_t)b * T + t) * m), 0, m * 8, 0x00020000);
-#pragma unroll
-                for (int r = 0; r < NCU; r++) {
-                    const int row = 4 * r + q;
-                    const double kv = -xr[r];
-                    __builtin_amdgcn_raw_buffer_store_b64(__builtin_bit_cast(u32x2t, kv), rK, (row < m && col < n) ? 8 * (row + col * m) : OOBT, 0, 0);
-                    __builtin_amdgcn_raw_buffer_store_b64(__builtin_bit_cast(u32x2t, kv), rk, (row < m && col == n) ? 8 * row : OOBT, 0, 0);
-                }
-                if (j == tn) {
-                    double kk = 0.0;
-#pragma unroll
-                    for (int i = 0; i < M; i++) kk += x[i] * x[i];
-                    if (lane_nn) dJ -= lam * kk;
-                }
-                lds_store(bufG + j * TILE, lane, Pn(Quu2, -X, zero, NCU));   // G = (Quu + 2 lambda I) K'
-            }
-        __syncthreads();
-        // ---- E: acc = Qzz + X'G -> bufT ---------------------------------------------------------------------
-#pragma unroll
-        for (int e = 0; e < NZZ; e++)
-            if (e % W == w) {
-                const int i = e / NT, j = e % NT;
-                Qzz[e / W] = Pn(lds_tile(bufX + i * TILE, lane), lds_tile(bufG + j * TILE, lane), Qzz[e / W], NCU);
-                lds_store(bufT + e * TILE, lane, Qzz[e / W]);
-            }
-        __syncthreads();
-        // ---- F: V'(i,j) = (acc(i,j) + acc(j,i)')/2   (:610) --------------------------------------------------
-#pragma unroll
-        for (int e = 0; e < NZZ; e++)
-            if (e % W == w) {
-                const int i = e / NT, j = e % NT;
-                const double *pt = bufT + (j * NT + i) * TILE + (c >> 2) * 64 + (c & 3) * 16 + q;   // (tile ji)'
-                d4 at;
-                at.x = pt[0]; at.y = pt[4]; at.z = pt[8]; at.w = pt[12];
-                d4 na = 0.5 * (Qzz[e / W] + at);
-                if (i == tn && j == tn) na = na * nn_keep;
-                lds_store(bufV + e * TILE, lane, na);
-            }
-        // (the barrier after the next step's phase A orders these stores before phase B reads them)
-    }
-    if (w == tn % W && lane_nn) delta_J[b] = dJ;
-    if (threadIdx.x == 0) status[b] = fail;
-}
-
 
 // ---------------------------------------------------------------------------------------------
 // Backward pass, NT wavefronts per trajectory, COLUMN decomposition: wave w owns column tile w of Tz, Quz,
@@ -923,7 +603,7 @@ k_backward_tiled_col(RecLayout L, int T, const double *__restrict__ rec, const d
         if (!pos) {
             if (threadIdx.x == 0) {
                 for (int i = 0; i < m; i++) for (int j = 0; j < m; j++) sRow[i * 16 + j] = qel(i, j);
-                tslow_ldlt_inverse(m, sRow, sRow + 256, winv, sRow + 768, (int *)(sRow + 784));
+                kp_slow_ldlt_inverse(m, sRow, 16, sRow + 256, winv, sRow + 768, (int *)(sRow + 784));
             }
             __syncthreads();
         }
@@ -1026,18 +706,9 @@ bool backward_tiled_supported(int n, int m)
     return nt >= 2 && nt <= 4 && (m == 7 || m == 1) && backward_tiled_lds_bytes(nt) <= 160 * 1024;
 }
 
-// Below this many trajectories per SIMD-quad the multi-wave kernel (4 waves per trajectory) is used.
-static bool use_multiwave(const Ctx *c)
-{
-    const char *e = getenv("KPILQR_TILED_WAVES");       // diagnostic: 1 = force single-wave, 4 = force multi-wave
-    if (e && atoi(e) == 1) return false;
-    if (e && atoi(e) == 4) return true;
-    return false;
-}
-
 // Which backward kernel: the column decomposition (NT waves per trajectory) while a workgroup per trajectory
 // still leaves SIMDs to spare, the one-wave-per-trajectory kernel for large batches.  KPILQR_TILED_WAVES
-// overrides (tests / diagnostics): 0 = column, 1 = one wave, 4 = the earlier 4-wave item-dealing kernel.
+// overrides (tests / diagnostics): 0 = column, 1 = one wave.
 static bool use_column(const Ctx *c, int nt)
 {
     const char *e = getenv("KPILQR_TILED_WAVES");
@@ -1054,13 +725,6 @@ static hipError_t launch_bt(Ctx *c, int pd_stride)
         hipError_t e = hipFuncSetAttribute((const void *)k_backward_tiled_col<M, NT>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)ldc);
         if (e != hipSuccess) return e;
         hipLaunchKernelGGL((k_backward_tiled_col<M, NT>), dim3(c->d.batch), dim3(64 * NT), ldc, c->stream, c->L, c->d.T, c->rec,
-                           c->lambda, pd_stride, c->K, c->k, c->delta_J, c->status);
-        return hipGetLastError();
-    }
-    if (use_multiwave(c)) {
-        hipError_t e = hipFuncSetAttribute((const void *)k_backward_tiled_mw<M, NT, 4>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-        if (e != hipSuccess) return e;
-        hipLaunchKernelGGL((k_backward_tiled_mw<M, NT, 4>), dim3(c->d.batch), dim3(256), lds, c->stream, c->L, c->d.T, c->rec,
                            c->lambda, pd_stride, c->K, c->k, c->delta_J, c->status);
         return hipGetLastError();
     }
