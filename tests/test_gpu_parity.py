@@ -660,3 +660,29 @@ def test_fused_two_wave_backward_variant(monkeypatch):
         st, _ = e.backward(1e-4, 1)
     o = [pipeline.run_trajectory(p, b, lam=1e-4, pd_stride=1, stages=("fd", "interp", "cost", "bwd"))["status"] for b in range(2)]
     assert list(st) == o and all(v > 0 for v in o)
+
+
+def test_fused_long_horizon_ragged_keypoints():
+    """T=1500 with very different key-point densities per DoF (one DoF only at 0 and T-1: a single 1499-step
+    segment; one DoF at every step), fused against the oracle and against the materialising kernels."""
+    T, dof = 1500, 7
+    p = synth.make_problem(task="panda_reaching", T=T, batch=2, min_N=1)
+    rng = np.random.default_rng(3)
+    dens = [0.0, 1.0, 0.5, 0.02, 0.2, 0.003, 0.9]
+    rows = []
+    for b in range(2):
+        offs = np.zeros(T + 1, np.int32); cols = []
+        for t in range(T):
+            offs[t] = len(cols)
+            if t == 0 or t == T - 1:
+                cols.extend(range(dof))
+            else:
+                cols.extend([i for i in range(dof) if rng.uniform() < dens[(i + b) % dof]])
+        offs[T] = len(cols)
+        rows.append((offs, np.asarray(cols, np.int32)))
+    p["kp_rows"] = rows
+    g = run_fused(p)
+    gu = run_engine(p)
+    for b in range(2):
+        assert relerr(g["K"][b], gu["K"][b]) < K_RTOL_TIGHT and relerr(g["cost_pred"][b], gu["cost_pred"][b]) < 1e-9
+    check_fused(g, p)
