@@ -358,11 +358,9 @@ def test_set_AB_and_cost_derivs_hooks_roundtrip():
 
 
 @pytest.mark.parametrize("task,T,batch", [("panda_pushing", 60, 2), ("high_dof_push", 24, 2), ("panda_pushing", 301, 3)])
-@pytest.mark.parametrize("waves", ["1", "0"])
-def test_tiled_mfma_large_state(task, T, batch, waves, monkeypatch):
-    """n = 20 (2x2 tiles) and n = 62 (4x4 tiles): tiled MFMA backward pass (one wave per trajectory, and
-    and NT waves per trajectory in the column decomposition = "0") against the oracle, and the generic kernel bit-exact beside it."""
-    monkeypatch.setenv("KPILQR_TILED_WAVES", waves)
+def test_tiled_mfma_large_state(task, T, batch):
+    """n = 20 (2x2 tiles) and n = 62 (4x4 tiles): tiled MFMA backward pass (NT waves per trajectory, column
+    decomposition) and forward pass against the oracle, and the generic kernel bit-exact beside it."""
     p = synth.make_problem(task=task, T=T, batch=batch, min_N=4, dense_residuals=True, one_sided_frac=0.1)
     g = run_engine(p)
     ge = run_engine(p, generic=True)

@@ -66,318 +66,7 @@ __device__ __forceinline__ double trcp(double x)
 
 // ---------------------------------------------------------------------------------------------
 // Backward pass.  z = [dx; 1] has nz = n+1 entries covered by NT row tiles.
-template <int M, int NT>
-__global__ void __launch_bounds__(64)
-k_backward_tiled(RecLayout L, int T, const double *__restrict__ rec, const double *__restrict__ lambda,
-                 int pd_stride, double *__restrict__ Kout, double *__restrict__ kout,
-                 double *__restrict__ delta_J, int *__restrict__ status)
-{
-    extern __shared__ __attribute__((aligned(16))) double sh[];
-    constexpr int NCU = (M + 3) / 4;
-    const int n = L.n, m = M, nz = n + 1;
-    const int lane = threadIdx.x, c = lane & 15, q = lane >> 4;
-    const int b = blockIdx.x;
-    const double lam = lambda[b];
-    // LDS map
-    double *bufV = sh;                              // NT*NT tiles: V', later Qzz and the new V'
-    double *bufF = bufV + NT * NT * TILE;           // Fz
-    double *bufT = bufF + NT * NT * TILE;           // Tz
-    double *bufFu = bufT + NT * NT * TILE;          // NT tiles
-    double *bufTu = bufFu + NT * TILE;              // NT tiles
-    double *bufQuz = bufTu + NT * TILE;             // NT tiles (row tile 0, column tile j)
-    double *bufX = bufQuz + NT * TILE;              // NT tiles: X = (Quu + lambda I)^-1 Quz
-    double *bufG = bufX + NT * TILE;                // NT tiles
-    double *sQ = bufG + NT * TILE;                  // one tile: Quu + lambda I in D layout
-    double *sRow = sQ + TILE;                       // 16x16 row-major scratch + slow-path work area (3*256+32)
-    // MFMA k-chunks (4 rows each) of row tile kt that hold rows < nz; empty tiles still issue one (zero) chunk
-    auto nchunk = [&](int kt) { const int rows = nz - 16 * kt; return rows >= 16 ? 4 : (rows + 3) / 4; };
-    const int ncl = nchunk(NT - 1);
-
-#ifdef KP_DEBUG_DUMP
-    // diagnostic build only (tools/tiled_debug.cpp): NT x NT (or 1 x NT) tile grids of step KP_DEBUG_T
-    auto dump = [&](int slot, const double *buf, int rows_t, int t) {
-        if (b != 0 || t != T - 1 - KP_DEBUG_STEP) return;
-        double *dst = delta_J + 16 + (size_t)slot * 64 * 64;
-        for (int i = 0; i < rows_t; i++) for (int j = 0; j < NT; j++) {
-            const d4 v = lds_tile(buf + (i * NT + j) * TILE, lane);
-            const double vv[4] = {v.x, v.y, v.z, v.w};
-            for (int r = 0; r < 4; r++) dst[(16 * i + 4 * r + q) * 64 + 16 * j + c] = vv[r];
-        }
-    };
-#define DUMP(slot, buf, rows_t) dump(slot, buf, rows_t, t)
-#else
-#define DUMP(slot, buf, rows_t)
-#endif
-    const double *R0 = rec + (size_t)b * T * L.stride;
-    const int rec_bytes = L.rec * 8;
-    const d4 zero = {0.0, 0.0, 0.0, 0.0};
-
-    // tile loaders (bounds-checked: structural zeros come back as 0 from out-of-range offsets)
-    auto load_Lzz = [&](__amdgpu_buffer_rsrc_t rs, int ti, int tj) -> d4 {
-        double v[4];
-#pragma unroll
-        for (int r = 0; r < 4; r++) {
-            const int row = 16 * ti + 4 * r + q, col = 16 * tj + c;
-            const int off = (row < n && col < n) ? 8 * (L.off_lxx + row * n + col)
-                          : (col == n && row < n) ? 8 * (L.off_lx + row)
-                          : (row == n && col < n) ? 8 * (L.off_lx + col) : OOBT;
-            v[r] = tbld(rs, off);
-        }
-        d4 o = {v[0], v[1], v[2], v[3]};
-        return o;
-    };
-    auto load_Fz = [&](__amdgpu_buffer_rsrc_t rs, int ti, int tj) -> d4 {
-        double v[4];
-#pragma unroll
-        for (int r = 0; r < 4; r++) {
-            const int row = 16 * ti + 4 * r + q, col = 16 * tj + c;
-            v[r] = tbld(rs, (row < n && col < n) ? 8 * (L.off_A + row * n + col) : OOBT) + ((row == n && col == n) ? 1.0 : 0.0);
-        }
-        d4 o = {v[0], v[1], v[2], v[3]};
-        return o;
-    };
-    auto load_Fu = [&](__amdgpu_buffer_rsrc_t rs, int ti) -> d4 {
-        double v[4];
-#pragma unroll
-        for (int r = 0; r < 4; r++) {
-            const int row = 16 * ti + 4 * r + q;
-            v[r] = tbld(rs, (row < n && c < m) ? 8 * (L.off_B + row * m + c) : OOBT);
-        }
-        d4 o = {v[0], v[1], v[2], v[3]};
-        return o;
-    };
-    auto load_Luz = [&](__amdgpu_buffer_rsrc_t rs, int tj) -> d4 {     // [0 l_u]: column n of the u x z block
-        double v[4];
-#pragma unroll
-        for (int r = 0; r < 4; r++) {
-            const int row = 4 * r + q, col = 16 * tj + c;
-            v[r] = tbld(rs, (row < m && col == n) ? 8 * (L.off_lu + row) : OOBT);
-        }
-        d4 o = {v[0], v[1], v[2], v[3]};
-        return o;
-    };
-    auto load_Luu = [&](__amdgpu_buffer_rsrc_t rs) -> d4 {
-        double v[4];
-#pragma unroll
-        for (int r = 0; r < 4; r++) {
-            const int row = 4 * r + q;
-            v[r] = tbld(rs, (row < m && c < m) ? 8 * (L.off_luu + row * m + c) : OOBT);
-        }
-        d4 o = {v[0], v[1], v[2], v[3]};
-        return o;
-    };
-
-    // V_x = l_x[T-1]; V_xx = l_xx[T-1]   (iLQR.cpp:537-539)
-    {
-        __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc((void *)(R0 + (size_t)(T - 1) * L.stride), 0, rec_bytes, 0x00020000);
-        for (int i = 0; i < NT; i++) for (int j = 0; j < NT; j++) lds_store(bufV + (i * NT + j) * TILE, lane, load_Lzz(rs, i, j));
-    }
-    __syncthreads();
-
-    // element (n,n): tile (tn,tn), lane (c = n&15, q = (n&15)&3), register (n&15)>>2
-    const int tn = n >> 4, cn = n & 15;
-    const bool lane_nn = (c == cn) && (q == (cn & 3));
-    const int reg_nn = cn >> 2;
-    d4 nn_keep;
-    nn_keep.x = (lane_nn && reg_nn == 0) ? 0.0 : 1.0; nn_keep.y = (lane_nn && reg_nn == 1) ? 0.0 : 1.0;
-    nn_keep.z = (lane_nn && reg_nn == 2) ? 0.0 : 1.0; nn_keep.w = (lane_nn && reg_nn == 3) ? 0.0 : 1.0;
-    double lam2d[4];
-#pragma unroll
-    for (int r = 0; r < 4; r++) lam2d[r] = (4 * r + q == c && c < m) ? 2.0 * lam : 0.0;
-
-    int pd_counter = 0, fail = 0;
-    double dJ = 0.0;
-    for (int t = T - 1; t >= 0; t--) {
-        __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc((void *)(R0 + (size_t)t * L.stride), 0, rec_bytes, 0x00020000);
-        pd_counter++;
-        const bool check_pd = pd_counter >= pd_stride;
-        // ---- stage Fz, Fu --------------------------------------------------------------------------
-        for (int i = 0; i < NT; i++) {
-            for (int j = 0; j < NT; j++) lds_store(bufF + (i * NT + j) * TILE, lane, load_Fz(rs, i, j));
-            lds_store(bufFu + i * TILE, lane, load_Fu(rs, i));
-        }
-        __syncthreads();
-        // ---- Tz = V' Fz,  Tu = V' Fu   (V' symmetric: tile (k,i) as Y gives V'[i][k]) -------------------
-        for (int i = 0; i < NT; i++) {
-            for (int j = 0; j < NT; j++) {
-                d4 acc = zero;
-#pragma unroll
-                for (int k = 0; k < NT; k++)
-                    acc = Pk<NT>(k, lds_tile(bufV + (k * NT + i) * TILE, lane), lds_tile(bufF + (k * NT + j) * TILE, lane), acc, ncl);
-                lds_store(bufT + (i * NT + j) * TILE, lane, acc);
-            }
-            d4 acc = zero;
-#pragma unroll
-            for (int k = 0; k < NT; k++)
-                acc = Pk<NT>(k, lds_tile(bufV + (k * NT + i) * TILE, lane), lds_tile(bufFu + k * TILE, lane), acc, ncl);
-            lds_store(bufTu + i * TILE, lane, acc);
-        }
-        __syncthreads();
-        DUMP(0, bufV, NT); DUMP(1, bufT, NT); DUMP(2, bufF, NT);
-        // ---- Quu = l_uu + Fu' Tu ; Quz = Luz + Fu' Tz ; Qzz = Lzz + Fz' Tz (into bufV: V' is dead) ---------
-        d4 Quu = load_Luu(rs);
-#pragma unroll
-        for (int k = 0; k < NT; k++)
-            Quu = Pk<NT>(k, lds_tile(bufFu + k * TILE, lane), lds_tile(bufTu + k * TILE, lane), Quu, ncl);
-        {
-            d4 Qr = Quu;
-            Qr.x += 0.5 * lam2d[0]; Qr.y += 0.5 * lam2d[1]; Qr.z += 0.5 * lam2d[2]; Qr.w += 0.5 * lam2d[3];
-            lds_store(sQ, lane, Qr);
-        }
-        for (int j = 0; j < NT; j++) {
-            d4 acc = load_Luz(rs, j);
-#pragma unroll
-            for (int k = 0; k < NT; k++)
-                acc = Pk<NT>(k, lds_tile(bufFu + k * TILE, lane), lds_tile(bufT + (k * NT + j) * TILE, lane), acc, ncl);
-            lds_store(bufQuz + j * TILE, lane, acc);
-        }
-        for (int i = 0; i < NT; i++)
-            for (int j = 0; j < NT; j++) {
-                d4 acc = load_Lzz(rs, i, j);
-#pragma unroll
-                for (int k = 0; k < NT; k++)
-                    acc = Pk<NT>(k, lds_tile(bufF + (k * NT + i) * TILE, lane), lds_tile(bufT + (k * NT + j) * TILE, lane), acc, ncl);
-                lds_store(bufV + (i * NT + j) * TILE, lane, acc);
-            }
-        __syncthreads();
-        DUMP(3, bufV, NT); DUMP(4, bufQuz, 1);
-        // ---- unpivoted LDL' of Quu + lambda I, redundantly per lane (element (i,j) of the D-layout image) ---
-        auto qel = [&](int i, int j) { return sQ[(i >> 2) * 64 + j + 16 * (i & 3)]; };
-        double Lm[M][M], dd[M], rd[M];
-        bool pos = true;
-#pragma unroll
-        for (int j = 0; j < M; j++) {
-            double w[M];
-            double dj = qel(j, j);
-#pragma unroll
-            for (int kk = 0; kk < j; kk++) { w[kk] = Lm[j][kk] * dd[kk]; dj -= Lm[j][kk] * w[kk]; }
-            dd[j] = dj;
-            pos = pos && (dj > 0.0);
-            const double rj = trcp(dj);
-            rd[j] = rj;
-#pragma unroll
-            for (int i = j + 1; i < M; i++) {
-                double v = qel(i, j);
-#pragma unroll
-                for (int kk = 0; kk < j; kk++) v -= Lm[i][kk] * w[kk];
-                Lm[i][j] = v * rj;
-            }
-        }
-        if (check_pd) {                       // CheckMatrixPD every pd_stride steps   :587-595
-            if (!pos) { fail = t + 1; break; }
-            pd_counter = 0;
-        }
-        double *winv = sRow + 256 + 256;      // explicit inverse of the slow path (column-major m x m)
-        if (!pos) {
-            // indefinite on an unchecked step: Eigen's pivoted LDLT + explicit inverse (iLQR.cpp:597-604)
-            if (lane == 0) {
-                for (int i = 0; i < m; i++) for (int j = 0; j < m; j++) sRow[i * 16 + j] = qel(i, j);
-                kp_slow_ldlt_inverse(m, sRow, 16, sRow + 256, winv, sRow + 768, (int *)(sRow + 784));
-            }
-            __syncthreads();
-        }
-        // ---- X = (Quu + lambda I)^-1 Quz, column by column; K' = -X out; delta_J -= lambda k'k -----------
-        for (int j = 0; j < NT; j++) {
-            const double *zt = bufQuz + j * TILE;
-            double x[M];
-#pragma unroll
-            for (int i = 0; i < M; i++) x[i] = zt[(i >> 2) * 64 + c + 16 * (i & 3)];
-            if (pos) {
-#pragma unroll
-                for (int jj = 0; jj < M; jj++) {
-#pragma unroll
-                    for (int i = jj + 1; i < M; i++) x[i] -= Lm[i][jj] * x[jj];
-                }
-#pragma unroll
-                for (int i = 0; i < M; i++) x[i] *= rd[i];
-#pragma unroll
-                for (int jj = M - 1; jj >= 0; jj--) {
-#pragma unroll
-                    for (int i = 0; i < jj; i++) x[i] -= Lm[jj][i] * x[jj];
-                }
-            } else {
-                double y[M];
-#pragma unroll
-                for (int i = 0; i < M; i++) {
-                    double sacc = 0.0;
-#pragma unroll
-                    for (int p = 0; p < M; p++) sacc += (-winv[i + p * m]) * x[p];
-                    y[i] = -sacc;
-                }
-#pragma unroll
-                for (int i = 0; i < M; i++) x[i] = y[i];
-            }
-            const int col = 16 * j + c;
-            double xr[4] = {0.0, 0.0, 0.0, 0.0};
-#pragma unroll
-            for (int i = 0; i < M; i++)
-                if (q == (i & 3)) xr[i >> 2] = (col <= n) ? x[i] : 0.0;
-            d4 X = {xr[0], xr[1], xr[2], xr[3]};
-            lds_store(bufX + j * TILE, lane, X);
-            // K (m x n column-major) / k through bounds-checked stores
-            __amdgpu_buffer_rsrc_t rK = __builtin_amdgcn_make_buffer_rsrc((void *)(Kout + ((size_t)b * T + t) * m * n), 0, m * n * 8, 0x00020000);
-            __amdgpu_buffer_rsrc_t rk = __builtin_amdgcn_make_buffer_rsrc((void *)(kout + ((size_t)b * T + t) * m), 0, m * 8, 0x00020000);
-#pragma unroll
-            for (int r = 0; r < NCU; r++) {
-                const int row = 4 * r + q;
-                const double kv = -xr[r];
-                __builtin_amdgcn_raw_buffer_store_b64(__builtin_bit_cast(u32x2t, kv), rK, (row < m && col < n) ? 8 * (row + col * m) : OOBT, 0, 0);
-                __builtin_amdgcn_raw_buffer_store_b64(__builtin_bit_cast(u32x2t, kv), rk, (row < m && col == n) ? 8 * row : OOBT, 0, 0);
-            }
-            if (j == tn) {
-                double kk = 0.0;
-#pragma unroll
-                for (int i = 0; i < M; i++) kk += x[i] * x[i];
-                if (lane_nn) dJ -= lam * kk;      // = k'Q_u + k'Q_uu k  (:612-613), cancellation-free form
-            }
-        }
-        __syncthreads();
-        // ---- G = (Quu + 2 lambda I) K' ;  V' = Qzz + X'G   (= Qzz - K''(Quu + 2 lambda I)K', :606-607) ---------
-        d4 Quu2 = Quu;
-        Quu2.x += lam2d[0]; Quu2.y += lam2d[1]; Quu2.z += lam2d[2]; Quu2.w += lam2d[3];
-        for (int j = 0; j < NT; j++) {
-            const d4 X = lds_tile(bufX + j * TILE, lane);
-            lds_store(bufG + j * TILE, lane, Pn(Quu2, -X, zero, NCU));
-        }
-        __syncthreads();
-        DUMP(5, bufX, 1); DUMP(6, bufG, 1);
-        for (int i = 0; i < NT; i++) {
-            const d4 Xi = lds_tile(bufX + i * TILE, lane);
-            for (int j = 0; j < NT; j++) {
-                double *vt = bufV + (i * NT + j) * TILE;
-                lds_store(vt, lane, Pn(Xi, lds_tile(bufG + j * TILE, lane), lds_tile(vt, lane), NCU));
-            }
-        }
-        __syncthreads();
-        DUMP(7, bufV, NT);
-        // ---- V' = (V' + V'')/2   (:610): tile (i,j) against the transpose of tile (j,i), transposed through
-        //      a padded row-major scratch image (stride 17: conflict-free column reads) -----------------------
-        for (int i = 0; i < NT; i++)
-            for (int j = i; j < NT; j++) {
-                double *tij = bufV + (i * NT + j) * TILE, *tji = bufV + (j * NT + i) * TILE;
-                const d4 a = lds_tile(tij, lane), bb = lds_tile(tji, lane);
-                double *s0 = sRow, *s1 = sRow + 272;
-                s0[(q) * 17 + c] = a.x;  s0[(4 + q) * 17 + c] = a.y;  s0[(8 + q) * 17 + c] = a.z;  s0[(12 + q) * 17 + c] = a.w;
-                s1[(q) * 17 + c] = bb.x; s1[(4 + q) * 17 + c] = bb.y; s1[(8 + q) * 17 + c] = bb.z; s1[(12 + q) * 17 + c] = bb.w;
-                __syncthreads();
-                d4 at, bt;       // at = (tile ji)', bt = (tile ij)'
-                at.x = s1[c * 17 + q]; at.y = s1[c * 17 + 4 + q]; at.z = s1[c * 17 + 8 + q]; at.w = s1[c * 17 + 12 + q];
-                bt.x = s0[c * 17 + q]; bt.y = s0[c * 17 + 4 + q]; bt.z = s0[c * 17 + 8 + q]; bt.w = s0[c * 17 + 12 + q];
-                d4 na = 0.5 * (a + at), nb = 0.5 * (bb + bt);
-                if (i == tn && j == tn) na = na * nn_keep;      // V'(n,n) is a constant nobody reads: keep it 0
-                lds_store(tij, lane, na);
-                if (j != i) lds_store(tji, lane, nb);
-                __syncthreads();
-            }
-        DUMP(8, bufV, NT);
-    }
-    if (lane_nn) delta_J[b] = dJ;
-    if (lane == 0) status[b] = fail;
-}
-
-
-// ---------------------------------------------------------------------------------------------
-// Tile loaders shared by the multi-wave kernels (bounds-checked: structural zeros come back as 0).
+// Tile loaders (bounds-checked: structural zeros come back as 0).
 struct TileSrc { int n, m; int off_A, off_B, off_lxx, off_lx, off_luu, off_lu; };
 
 __device__ __forceinline__ d4 ld_Lzz(__amdgpu_buffer_rsrc_t rs, const TileSrc &S, int ti, int tj, int q, int c)
@@ -689,7 +378,7 @@ k_backward_tiled_col(RecLayout L, int T, const double *__restrict__ rec, const d
 
 size_t backward_col_lds_bytes(int nt) { return sizeof(double) * ((size_t)(3 * nt * nt + 7 * nt) * TILE + 3 * 256 + 64); }
 
-size_t backward_tiled_lds_bytes(int nt) { return sizeof(double) * ((size_t)(3 * nt * nt + 5 * nt + 1) * TILE + 3 * 256 + 64); }
+size_t backward_tiled_lds_bytes(int nt) { return backward_col_lds_bytes(nt); }
 
 static int tiled_nt(int n)
 {
@@ -706,32 +395,14 @@ bool backward_tiled_supported(int n, int m)
     return nt >= 2 && nt <= 4 && (m == 7 || m == 1) && backward_tiled_lds_bytes(nt) <= 160 * 1024;
 }
 
-// Which backward kernel: the column decomposition (NT waves per trajectory) while a workgroup per trajectory
-// still leaves SIMDs to spare, the one-wave-per-trajectory kernel for large batches.  KPILQR_TILED_WAVES
-// overrides (tests / diagnostics): 0 = column, 1 = one wave.
-static bool use_column(const Ctx *c, int nt)
-{
-    const char *e = getenv("KPILQR_TILED_WAVES");
-    if (e) return atoi(e) == 0;
-    return c->d.batch * nt <= c->n_simd;
-}
-
 template <int M, int NT>
 static hipError_t launch_bt(Ctx *c, int pd_stride)
 {
-    const size_t lds = backward_tiled_lds_bytes(NT);
-    if (use_column(c, NT)) {
-        const size_t ldc = backward_col_lds_bytes(NT);
-        hipError_t e = hipFuncSetAttribute((const void *)k_backward_tiled_col<M, NT>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)ldc);
-        if (e != hipSuccess) return e;
-        hipLaunchKernelGGL((k_backward_tiled_col<M, NT>), dim3(c->d.batch), dim3(64 * NT), ldc, c->stream, c->L, c->d.T, c->rec,
-                           c->lambda, pd_stride, c->K, c->k, c->delta_J, c->status);
-        return hipGetLastError();
-    }
-    hipError_t e = hipFuncSetAttribute((const void *)k_backward_tiled<M, NT>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    const size_t ldc = backward_col_lds_bytes(NT);
+    hipError_t e = hipFuncSetAttribute((const void *)k_backward_tiled_col<M, NT>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)ldc);
     if (e != hipSuccess) return e;
-    hipLaunchKernelGGL((k_backward_tiled<M, NT>), dim3(c->d.batch), dim3(64), lds, c->stream, c->L, c->d.T, c->rec, c->lambda,
-                       pd_stride, c->K, c->k, c->delta_J, c->status);
+    hipLaunchKernelGGL((k_backward_tiled_col<M, NT>), dim3(c->d.batch), dim3(64 * NT), ldc, c->stream, c->L, c->d.T, c->rec,
+                       c->lambda, pd_stride, c->K, c->k, c->delta_J, c->status);
     return hipGetLastError();
 }
 
