@@ -34,17 +34,23 @@ def one(upload=True):
     if upload:
         e.upload_fd(p["job_b"], p["job_t"], p["job_col"], p["job_mode"], p["xplus"], p["xminus"],
                     job_nom=p["job_nom"], xnom=p["xnom"], eps=p["eps"])
-        e.upload_residuals(p["r"], p["r_x"], p["r_u"])
+        if upload == "analytic":          # closed-form residual Jacobians stay resident (reaching: selector rows)
+            e.upload_residuals(p["r"])
+        else:
+            e.upload_residuals(p["r"], p["r_x"], p["r_u"])
     e.iterate(lam)
     if upload:
         e._ck(e._L.kpilqr_download_gains(e._h, _ptr(K), _ptr(kk)))
     e.sync()
 
-for mode in (True, False):
+for mode in (True, "analytic", False):
+    if mode == "analytic":
+        up_bytes = sum(p[k].nbytes for k in ("xplus", "xminus", "xnom", "r"))
     one(mode); one(mode)
     t0 = time.perf_counter()
     for _ in range(steps):
         one(mode)
     dt = (time.perf_counter() - t0) / steps
-    print(f"B={B} {'PCIe-inclusive' if mode else 'resident      '}: {dt*1e3:8.2f} ms/batch-iteration = {B/dt:9.1f} trajectory-iterations/s"
+    label = {True: "PCIe-inclusive          ", "analytic": "PCIe-inclusive, J const ", False: "resident                "}[mode]
+    print(f"B={B} {label}: {dt*1e3:8.2f} ms/batch-iteration = {B/dt:9.1f} trajectory-iterations/s"
           + (f"   (H2D {up_bytes/1e9:.2f} GB + D2H {dn_bytes/1e9:.2f} GB per iteration -> {(up_bytes+dn_bytes)/dt/1e9:.1f} GB/s over PCIe)" if mode else ""), flush=True)
