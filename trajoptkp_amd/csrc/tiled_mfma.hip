@@ -426,6 +426,7 @@ k_forward_tiled(RecLayout L, int T, int n_alpha, const double *__restrict__ rec,
                 const double *__restrict__ alphas, double *__restrict__ cost_pred, double *__restrict__ U_alpha)
 {
     __shared__ __attribute__((aligned(16))) double zbuf[2][NT * TILE];
+    __shared__ __attribute__((aligned(16))) double upart[NT * TILE];        // per-wave partials of K dx + alpha k
     __shared__ double red[NT * 64];
     const int n = L.n, m = L.m, nz2 = n + 2;
     const int lane = threadIdx.x & 63, c = lane & 15, q = lane >> 4;
@@ -434,9 +435,10 @@ k_forward_tiled(RecLayout L, int T, int n_alpha, const double *__restrict__ rec,
     const int ncu = (m + 3) >> 2;
     auto nchunk = [&](int kt) { const int rows = nz2 - 16 * kt; return rows >= 16 ? 4 : (rows + 3) / 4; };
     const int ncl = nchunk(NT - 1);
+    const int ncw = nchunk(wi);
 
     // per-lane source byte offsets (OOBT = structural zero); p = contraction (state) index, o = output index
-    int oK[NT][4], ok_[NT][4], oA[NT][4], oLc[NT][4], oB[4], oLuu[4], olu[4], oub[4];
+    int oKw[4], okw[4], oA[NT][4], oLc[NT][4], oB[4], oLuu[4], olu[4], oub[4];
     double oneA[NT][4], lo[4], hi[4];
     const int o = 16 * wi + c;
 #pragma unroll
@@ -444,8 +446,6 @@ k_forward_tiled(RecLayout L, int T, int n_alpha, const double *__restrict__ rec,
 #pragma unroll
         for (int r = 0; r < 4; r++) {
             const int pp = 16 * k + 4 * r + q;
-            oK[k][r] = (pp < n && c < m) ? 8 * (pp * m + c) : OOBT;
-            ok_[k][r] = (pp == n && c < m) ? 8 * c : OOBT;
             oA[k][r] = (pp < n && o < n) ? 8 * (L.off_A + o * n + pp) : OOBT;
             oneA[k][r] = ((pp == n && o == n) || (pp == n + 1 && o == n + 1)) ? 1.0 : 0.0;
             oLc[k][r] = (pp < n && o < n) ? 8 * (L.off_lxx + pp * n + o)
@@ -455,6 +455,9 @@ k_forward_tiled(RecLayout L, int T, int n_alpha, const double *__restrict__ rec,
 #pragma unroll
     for (int r = 0; r < 4; r++) {
         const int row = 4 * r + q;
+        const int pw = 16 * wi + row;                                   // this wave's slice of the state index
+        oKw[r] = (pw < n && c < m) ? 8 * (pw * m + c) : OOBT;
+        okw[r] = (pw == n && c < m) ? 8 * c : OOBT;
         oB[r] = (row < m && o < n) ? 8 * (L.off_B + o * m + row) : OOBT;
         oLuu[r] = (row < m && c < m) ? 8 * (L.off_luu + row * m + c) : OOBT;
         olu[r] = (row < m) ? 8 * (L.off_lu + row) : OOBT;
@@ -463,6 +466,7 @@ k_forward_tiled(RecLayout L, int T, int n_alpha, const double *__restrict__ rec,
         hi[r] = (row < m) ? ctrl_lim[2 * row + 1] : 1.0e300;
     }
     const double my_alpha = (c < n_alpha) ? alphas[c] : 0.0;
+    d4 Zi;                                                               // this wave's tile of Z, kept in registers
     {
         double zr[4];
 #pragma unroll
@@ -470,58 +474,56 @@ k_forward_tiled(RecLayout L, int T, int n_alpha, const double *__restrict__ rec,
             const int row = 16 * wi + 4 * r + q;
             zr[r] = (row == n) ? my_alpha : (row == n + 1) ? 1.0 : 0.0;
         }
-        d4 Z0 = {zr[0], zr[1], zr[2], zr[3]};
-        lds_store(zbuf[0] + wi * TILE, lane, Z0);
+        Zi.x = zr[0]; Zi.y = zr[1]; Zi.z = zr[2]; Zi.w = zr[3];
+        lds_store(zbuf[0] + wi * TILE, lane, Zi);
     }
     const d4 zero = {0.0, 0.0, 0.0, 0.0};
     double partial = 0.0;
 
-    struct Tiles { d4 YkK[NT], Ykk[NT], Ya[NT], Lc[NT], Yb, Luu, lu, ub; };
+    struct Tiles { d4 Ykw, Ya[NT], Lc[NT], Yb, Luu, lu, ub; };
     const int rec_bytes = L.rec * 8;
     auto ld4 = [&](__amdgpu_buffer_rsrc_t rs, const int *off) -> d4 {
         d4 v; v.x = tbld(rs, off[0]); v.y = tbld(rs, off[1]); v.z = tbld(rs, off[2]); v.w = tbld(rs, off[3]);
         return v;
     };
-    auto load_tiles = [&](int t, Tiles &s) {
-        __amdgpu_buffer_rsrc_t rR = __builtin_amdgcn_make_buffer_rsrc((void *)(rec + ((size_t)b * T + t) * L.stride), 0, rec_bytes, 0x00020000);
-        __amdgpu_buffer_rsrc_t rK = __builtin_amdgcn_make_buffer_rsrc((void *)(Kin + ((size_t)b * T + t) * m * n), 0, m * n * 8, 0x00020000);
-        __amdgpu_buffer_rsrc_t rk = __builtin_amdgcn_make_buffer_rsrc((void *)(kin + ((size_t)b * T + t) * m), 0, m * 8, 0x00020000);
-        __amdgpu_buffer_rsrc_t ru = __builtin_amdgcn_make_buffer_rsrc((void *)(u_nom + ((size_t)b * T + t) * m), 0, m * 8, 0x00020000);
-#pragma unroll
-        for (int k = 0; k < NT; k++) {
-            s.YkK[k] = ld4(rK, oK[k]); s.Ykk[k] = ld4(rk, ok_[k]);
-            s.Ya[k] = ld4(rR, oA[k]);  s.Lc[k] = ld4(rR, oLc[k]);
-        }
-        s.Yb = ld4(rR, oB); s.Luu = ld4(rR, oLuu); s.lu = ld4(rR, olu); s.ub = ld4(ru, oub);
+    auto rs_of = [&](const double *base, size_t step_elems, int t, int bytes) {
+        const bool ok = t < T;
+        return __builtin_amdgcn_make_buffer_rsrc((void *)(base + ((size_t)b * T + (ok ? t : 0)) * step_elems), 0, ok ? bytes : 0, 0x00020000);
     };
-    // Single-buffered tiles: each group is re-requested for step t+1 right behind its last use in step t (a whole
-    // step of latency cover, half the registers of a double buffer and no copies).  The identity entries of Ya
-    // (alpha and the homogeneous 1 carry over) are patched in after the load.
+    // Single-buffered tiles: each group is re-requested for step t+1 right behind its last use in step t.
+    // Every wave forms only ITS slice of the control law, P([K' ; k'] rows of tile wi, Z_wi) (4 MFMAs instead of
+    // 4*NT); the slices are summed through LDS (one extra barrier), then every wave clamps the same U.
     Tiles cur;
-    load_tiles(0, cur);
+    {
+        __amdgpu_buffer_rsrc_t rR = rs_of(rec, L.stride, 0, rec_bytes), rK = rs_of(Kin, (size_t)m * n, 0, m * n * 8);
+        __amdgpu_buffer_rsrc_t rk = rs_of(kin, m, 0, m * 8), ru = rs_of(u_nom, m, 0, m * 8);
+        cur.Ykw = ld4(rK, oKw) + ld4(rk, okw);
+#pragma unroll
+        for (int k = 0; k < NT; k++) { cur.Ya[k] = ld4(rR, oA[k]); cur.Lc[k] = ld4(rR, oLc[k]); }
+        cur.Yb = ld4(rR, oB); cur.Luu = ld4(rR, oLuu); cur.lu = ld4(rR, olu); cur.ub = ld4(ru, oub);
+    }
     __syncthreads();
-    const __amdgpu_buffer_rsrc_t rNone = __builtin_amdgcn_make_buffer_rsrc((void *)Kin, 0, 0, 0x00020000);
 
     for (int t = 0; t < T; t++) {
-        const bool more = t + 1 < T;
-        const __amdgpu_buffer_rsrc_t rR = more ? __builtin_amdgcn_make_buffer_rsrc((void *)(rec + ((size_t)b * T + t + 1) * L.stride), 0, rec_bytes, 0x00020000) : rNone;
-        const __amdgpu_buffer_rsrc_t rK = more ? __builtin_amdgcn_make_buffer_rsrc((void *)(Kin + ((size_t)b * T + t + 1) * m * n), 0, m * n * 8, 0x00020000) : rNone;
-        const __amdgpu_buffer_rsrc_t rk = more ? __builtin_amdgcn_make_buffer_rsrc((void *)(kin + ((size_t)b * T + t + 1) * m), 0, m * 8, 0x00020000) : rNone;
-        const __amdgpu_buffer_rsrc_t ru = more ? __builtin_amdgcn_make_buffer_rsrc((void *)(u_nom + ((size_t)b * T + t + 1) * m), 0, m * 8, 0x00020000) : rNone;
+        const __amdgpu_buffer_rsrc_t rR = rs_of(rec, L.stride, t + 1, rec_bytes), rK = rs_of(Kin, (size_t)m * n, t + 1, m * n * 8);
+        const __amdgpu_buffer_rsrc_t rk = rs_of(kin, m, t + 1, m * 8), ru = rs_of(u_nom, m, t + 1, m * 8);
         const double *zc = zbuf[t & 1];
         double *zn = zbuf[(t + 1) & 1];
-        d4 Zk[NT];
-#pragma unroll
-        for (int k = 0; k < NT; k++) Zk[k] = lds_tile(zc + k * TILE, lane);
-        const d4 Zi = lds_tile(zc + wi * TILE, lane);
-        // control law + clamp (every wave; :876-890)
+        // ---- this wave's slice of K dx + alpha k -------------------------------------------------------------
+        lds_store(upart + wi * TILE, lane, Pn(cur.Ykw, Zi, zero, ncw));
+        __builtin_amdgcn_sched_barrier(0);
+        cur.Ykw = ld4(rK, oKw) + ld4(rk, okw);
+        __builtin_amdgcn_sched_barrier(0);
+        __syncthreads();
+        // ---- control law + clamp (every wave; :876-890) --------------------------------------------------------
         const d4 ub = cur.ub;
         d4 U = ub;
 #pragma unroll
-        for (int k = 0; k < NT; k++) U = Pk<NT>(k, cur.YkK[k] + cur.Ykk[k], Zk[k], U, ncl);
-        __builtin_amdgcn_sched_barrier(0);
+        for (int k = 0; k < NT; k++) U = U + lds_tile(upart + k * TILE, lane);
+        d4 Zk[NT];
 #pragma unroll
-        for (int k = 0; k < NT; k++) { cur.YkK[k] = ld4(rK, oK[k]); cur.Ykk[k] = ld4(rk, ok_[k]); }
+        for (int k = 0; k < NT; k++) Zk[k] = lds_tile(zc + k * TILE, lane);
+        __builtin_amdgcn_sched_barrier(0);
         cur.ub = ld4(ru, oub);
         __builtin_amdgcn_sched_barrier(0);
         d4 dU;
@@ -546,7 +548,7 @@ k_forward_tiled(RecLayout L, int T, int n_alpha, const double *__restrict__ rec,
             cur.Luu = ld4(rR, oLuu); cur.lu = ld4(rR, olu);
             __builtin_amdgcn_sched_barrier(0);
         }
-        // state cost rows of this tile, then the linearised dynamics for this tile
+        // ---- state cost rows of this tile, then the linearised dynamics for this tile ------------------------------
         d4 Wz = zero, Zn = zero;
 #pragma unroll
         for (int k = 0; k < NT; k++) Wz = Pk<NT>(k, cur.Lc[k], Zk[k], Wz, ncl);
@@ -567,6 +569,7 @@ k_forward_tiled(RecLayout L, int T, int n_alpha, const double *__restrict__ rec,
         for (int k = 0; k < NT; k++) cur.Ya[k] = ld4(rR, oA[k]);
         cur.Yb = ld4(rR, oB);
         __builtin_amdgcn_sched_barrier(0);
+        Zi = Zn;
         lds_store(zn + wi * TILE, lane, Zn);
         __syncthreads();
     }
