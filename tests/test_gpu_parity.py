@@ -684,3 +684,23 @@ def test_fused_long_horizon_ragged_keypoints():
     for b in range(2):
         assert relerr(g["K"][b], gu["K"][b]) < K_RTOL_TIGHT and relerr(g["cost_pred"][b], gu["cost_pred"][b]) < 1e-9
     check_fused(g, p)
+
+
+def test_fused_indefinite_quu_on_unchecked_steps():
+    """Q_uu + lambda I indefinite while no PD check is due (pd_stride > T): the reference inverts it anyway with
+    Eigen's pivoted LDLT (iLQR.cpp:597-604).  The fused backward pass (running-inverse fast path, LDL' fallback,
+    pivoted slow path) must land on the same gains."""
+    p = synth.make_problem(task="panda_reaching", T=64, batch=2, min_N=5, dense_residuals=True)
+    assert np.any(p["r_u"] != 0)
+    p["w_run"] = p["w_run"].copy(); p["w_term"] = p["w_term"].copy()
+    p["w_run"][:] = -np.abs(p["w_run"]) - 1.0            # negative control-residual weights: l_uu indefinite
+    for lam in (1e-4, 0.3):
+        with Engine(p["dof"], p["m"], p["T"], p["nr"], batch=2, fused=True) as e:
+            synth.upload(e, p)
+            e.fd_difference()
+            st, _ = e.backward(lam, 1000)
+            K, k = e.gains()
+        for b in range(2):
+            o = pipeline.run_trajectory(p, b, lam=lam, pd_stride=1000, stages=("fd", "interp", "cost", "bwd"))
+            assert st[b] == 0 and o["status"] == 0
+            assert relerr(K[b], o["K"]) < 1e-6 and relerr(k[b], o["k"]) < 1e-6, (lam, b, relerr(K[b], o["K"]))

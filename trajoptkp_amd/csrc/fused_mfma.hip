@@ -30,6 +30,9 @@ typedef unsigned int u32x2f __attribute__((ext_vector_type(2)));
 typedef unsigned long long u64;
 #define MFMA(a, b, c) __builtin_amdgcn_mfma_f64_16x16x4f64((a), (b), (c), 0, 0, 0)
 #define OOBF 0x7ffffff0
+#ifndef KP_NS
+#define KP_NS 1
+#endif
 #define BIGT 0x3fffffff
 
 template <int NC>
@@ -201,6 +204,11 @@ __device__ __forceinline__ void backward_fused_body(RecLayout L, FusedArgs F, in
     d4 W2 = {w2term[0], w2term[1], w2term[2], w2term[3]};     // terminal weights at t = T-1, running after
     int pd_counter = 0, fail = 0;
     double dJ = 0.0;
+    d4 Xinv = zero, Iu;                          // running inverse of Quu + lambda I (KP_NS) and the identity of the u-block
+    bool haveX = false;
+    Iu.x = (q == c && c < m) ? 1.0 : 0.0; Iu.y = (4 + q == c && c < m) ? 1.0 : 0.0;
+    Iu.z = (8 + q == c && c < m) ? 1.0 : 0.0; Iu.w = (12 + q == c && c < m) ? 1.0 : 0.0;
+    (void)haveX; (void)Iu;
 
     for (int t = T - 1; t >= 0; t--) {
         // ---- a4: this step's A and B columns --------------------------------------------------------------
@@ -249,77 +257,130 @@ __device__ __forceinline__ void backward_fused_body(RecLayout L, FusedArgs F, in
         // ---- Tu = V' Fu ; Quu = l_uu + Fu' Tu --------------------------------------- :577
         d4 Tu = PS<NCZ>(V, Fu, zero);
         d4 Quu = PS<NCZ>(Fu, Tu, Luu);
-        sh[FLDS_Q + q * FMS + c] = Quu.x + 0.5 * lam2d[0];
-        if (NCU > 1) sh[FLDS_Q + (4 + q) * FMS + c] = Quu.y + 0.5 * lam2d[1];
-        if (NCU > 2) sh[FLDS_Q + (8 + q) * FMS + c] = Quu.z + 0.5 * lam2d[2];
-        if (NCU > 3) sh[FLDS_Q + (12 + q) * FMS + c] = Quu.w + 0.5 * lam2d[3];
         // ---- Tz, Quz, Qzz --------------------------------------------------------------- :570-579
         d4 Tz = PS<NCZ>(V, Fz, zero);
         d4 Quz = PS<NCZ>(Fu, Tz, Luz);
         d4 Qzz = PS<NCZ>(Fz, Tz, Lzz);
-        sh[FLDS_Z + c * FMZ + q] = Quz.x;
-        if (NCU > 1) sh[FLDS_Z + c * FMZ + 4 + q] = Quz.y;
-        if (NCU > 2) sh[FLDS_Z + c * FMZ + 8 + q] = Quz.z;
-        if (NCU > 3) sh[FLDS_Z + c * FMZ + 12 + q] = Quz.w;
-        __syncthreads();
+        d4 Qr = Quu;                                  // Quu + lambda I
+        Qr.x += 0.5 * lam2d[0]; Qr.y += 0.5 * lam2d[1]; Qr.z += 0.5 * lam2d[2]; Qr.w += 0.5 * lam2d[3];
 
-        // ---- unpivoted LDL' of Quu + lambda I, redundantly in every lane ----
-        double Lm[M][M], dd[M], rd[M];
-        bool pos = true;
-#pragma unroll
-        for (int j = 0; j < M; j++) {
-            double w[M];
-            double dj = sh[FLDS_Q + j * FMS + j];
-#pragma unroll
-            for (int kk = 0; kk < j; kk++) { w[kk] = Lm[j][kk] * dd[kk]; dj -= Lm[j][kk] * w[kk]; }
-            dd[j] = dj;
-            pos = pos && (dj > 0.0);
-            const double rj = frcp(dj);
-            rd[j] = rj;
-#pragma unroll
-            for (int i = j + 1; i < M; i++) {
-                double v = sh[FLDS_Q + i * FMS + j];
-#pragma unroll
-                for (int kk = 0; kk < j; kk++) v -= Lm[i][kk] * w[kk];
-                Lm[i][j] = v * rj;
+        // ---- X = (Quu + lambda I)^-1 Quz.  Fast path (KP_NS): the inverse changes little from one step to the next,
+        //      so it is refreshed by Newton-Schulz steps Xinv <- Xinv + Xinv (I - Q Xinv) on the matrix core (4 MFMAs
+        //      each, quadratic convergence; the count is chosen from the measured residual so that it ends below
+        //      1e-15) and X = Xinv Quz is one more product -- the reference, too, forms the explicit inverse and
+        //      multiplies (iLQR.cpp:597-604).  The LDL' path below runs on the first step, on every checked step
+        //      (it gives the PD verdict of :587-595), and whenever the residual is too large to converge fast.
+        d4 Xp = zero;
+        bool done = false;
+#if KP_NS
+        if (haveX && !check_pd) {
+            d4 R = Iu - PS<NCU>(Qr, Xinv, zero);       // I - Q Xinv  (Q symmetric up to rounding: Q'X = QX)
+            double rmax = fabs(R.x);
+            if (NCU > 1) rmax = fmax(rmax, fabs(R.y));
+            if (NCU > 2) rmax = fmax(rmax, fabs(R.z));
+            if (NCU > 3) rmax = fmax(rmax, fabs(R.w));
+            // rows of R sum at most m entries: ||R||_inf <= m * max|R_ij|; thresholds on the entry bound e = m*rmax
+            const double e = (double)m * rmax;
+            const bool too_big = __builtin_amdgcn_ballot_w64(!(e < 0.11)) != 0;
+            if (!too_big) {
+                const int iters = (__builtin_amdgcn_ballot_w64(e >= 1.3e-2) != 0) ? 4
+                                : (__builtin_amdgcn_ballot_w64(e >= 1.7e-4) != 0) ? 3
+                                : (__builtin_amdgcn_ballot_w64(e >= 3.0e-8) != 0) ? 2 : 1;
+                Xinv = PS<NCU>(Xinv, R, Xinv);                             // Xinv + Xinv'R  (Xinv symmetric)
+                if (iters > 1) {
+                    R = Iu - PS<NCU>(Qr, Xinv, zero); Xinv = PS<NCU>(Xinv, R, Xinv);
+                    if (iters > 2) {
+                        R = Iu - PS<NCU>(Qr, Xinv, zero); Xinv = PS<NCU>(Xinv, R, Xinv);
+                        if (iters > 3) { R = Iu - PS<NCU>(Qr, Xinv, zero); Xinv = PS<NCU>(Xinv, R, Xinv); }
+                    }
+                }
+                Xp = PS<NCU>(Xinv, Quz, zero);                             // Xinv' Quz = (Quu + lambda I)^-1 Quz
+                done = true;
             }
         }
-        if (check_pd) {                       // CheckMatrixPD every pd_stride steps   :587-595
-            if (!pos) { fail = t + 1; break; }
-            pd_counter = 0;
-        }
-        double x[M];
-        if (pos) {
-#pragma unroll
-            for (int i = 0; i < M; i++) x[i] = sh[FLDS_Z + c * FMZ + i];
+#endif
+        if (!done) {
+            sh[FLDS_Q + q * FMS + c] = Qr.x;
+            if (NCU > 1) sh[FLDS_Q + (4 + q) * FMS + c] = Qr.y;
+            if (NCU > 2) sh[FLDS_Q + (8 + q) * FMS + c] = Qr.z;
+            if (NCU > 3) sh[FLDS_Q + (12 + q) * FMS + c] = Qr.w;
+            sh[FLDS_Z + c * FMZ + q] = Quz.x;
+            if (NCU > 1) sh[FLDS_Z + c * FMZ + 4 + q] = Quz.y;
+            if (NCU > 2) sh[FLDS_Z + c * FMZ + 8 + q] = Quz.z;
+            if (NCU > 3) sh[FLDS_Z + c * FMZ + 12 + q] = Quz.w;
+            __syncthreads();
+            // ---- unpivoted LDL' of Quu + lambda I, redundantly in every lane ----
+            double Lm[M][M], dd[M], rd[M];
+            bool pos = true;
 #pragma unroll
             for (int j = 0; j < M; j++) {
+                double w[M];
+                double dj = sh[FLDS_Q + j * FMS + j];
 #pragma unroll
-                for (int i = j + 1; i < M; i++) x[i] -= Lm[i][j] * x[j];
+                for (int kk = 0; kk < j; kk++) { w[kk] = Lm[j][kk] * dd[kk]; dj -= Lm[j][kk] * w[kk]; }
+                dd[j] = dj;
+                pos = pos && (dj > 0.0);
+                const double rj = frcp(dj);
+                rd[j] = rj;
+#pragma unroll
+                for (int i = j + 1; i < M; i++) {
+                    double v = sh[FLDS_Q + i * FMS + j];
+#pragma unroll
+                    for (int kk = 0; kk < j; kk++) v -= Lm[i][kk] * w[kk];
+                    Lm[i][j] = v * rj;
+                }
             }
-#pragma unroll
-            for (int i = 0; i < M; i++) x[i] *= rd[i];
-#pragma unroll
-            for (int j = M - 1; j >= 0; j--) {
-#pragma unroll
-                for (int i = 0; i < j; i++) x[i] -= Lm[j][i] * x[j];
+            if (check_pd) {                       // CheckMatrixPD every pd_stride steps   :587-595
+                if (!pos) { fail = t + 1; break; }
+                pd_counter = 0;
             }
-        } else {
-            double *wa = sh + FLDS_SLOW, *wx = wa + 256, *wt = wx + 256;
-            int *tr = (int *)(wt + 16);
-            if (lane == 0) kp_slow_ldlt_inverse(L.m, sh + FLDS_Q, FMS, wa, wx, wt, tr);
-            __syncthreads();
+            double x[M];
+            auto ldl_solve = [&](double *v) {
 #pragma unroll
-            for (int i = 0; i < M; i++) {
-                double sacc = 0.0;
+                for (int j = 0; j < M; j++) {
 #pragma unroll
-                for (int p = 0; p < M; p++) sacc += (-wx[i + p * m]) * sh[FLDS_Z + c * FMZ + p];
-                x[i] = -sacc;
+                    for (int i = j + 1; i < M; i++) v[i] -= Lm[i][j] * v[j];
+                }
+#pragma unroll
+                for (int i = 0; i < M; i++) v[i] *= rd[i];
+#pragma unroll
+                for (int j = M - 1; j >= 0; j--) {
+#pragma unroll
+                    for (int i = 0; i < j; i++) v[i] -= Lm[j][i] * v[j];
+                }
+            };
+            if (pos) {
+#pragma unroll
+                for (int i = 0; i < M; i++) x[i] = sh[FLDS_Z + c * FMZ + i];
+                ldl_solve(x);
+#if KP_NS
+                // seed the fast path: column c of the inverse in lane c (c < m), as a tile
+                double y[M];
+#pragma unroll
+                for (int i = 0; i < M; i++) y[i] = (i == c) ? 1.0 : 0.0;
+                ldl_solve(y);
+                double yr[4] = {0.0, 0.0, 0.0, 0.0};
+#pragma unroll
+                for (int i = 0; i < M; i++)
+                    if (q == (i & 3)) yr[i >> 2] = (c < m) ? y[i] : 0.0;
+                Xinv.x = yr[0]; Xinv.y = yr[1]; Xinv.z = yr[2]; Xinv.w = yr[3];
+                haveX = true;
+#endif
+            } else {
+                double *wa = sh + FLDS_SLOW, *wx = wa + 256, *wt = wx + 256;
+                int *tr = (int *)(wt + 16);
+                if (lane == 0) kp_slow_ldlt_inverse(L.m, sh + FLDS_Q, FMS, wa, wx, wt, tr);
+                __syncthreads();
+#pragma unroll
+                for (int i = 0; i < M; i++) {
+                    double sacc = 0.0;
+#pragma unroll
+                    for (int p = 0; p < M; p++) sacc += (-wx[i + p * m]) * sh[FLDS_Z + c * FMZ + p];
+                    x[i] = -sacc;
+                }
+                __syncthreads();
+                haveX = false;
             }
-            __syncthreads();
-        }
-        d4 Xp = zero;
-        {
             double xr[4] = {0.0, 0.0, 0.0, 0.0};
 #pragma unroll
             for (int i = 0; i < M; i++)
@@ -337,11 +398,13 @@ __device__ __forceinline__ void backward_fused_body(RecLayout L, FusedArgs F, in
                 __builtin_amdgcn_raw_buffer_store_b64(__builtin_bit_cast(u32x2f, kv[r]), rk, okst[r], 0, 0);
             }
         }
-        {
-            double kk = 0.0;
-#pragma unroll
-            for (int i = 0; i < M; i++) kk += x[i] * x[i];
-            if (lane_nn) dJ -= lam * kk;
+        // delta_J += k'Q_u + k'Q_uu k = -lambda k'k (:612-613): lanes of column n keep the squares of their rows,
+        // the four row groups are added once after the sweep
+        if (c == n) {
+            dJ -= lam * (Xp.x * Xp.x);
+            if (NCU > 1) dJ -= lam * (Xp.y * Xp.y);
+            if (NCU > 2) dJ -= lam * (Xp.z * Xp.z);
+            if (NCU > 3) dJ -= lam * (Xp.w * Xp.w);
         }
         d4 Quu2 = Quu;
         Quu2.x += lam2d[0]; Quu2.y += lam2d[1]; Quu2.z += lam2d[2]; Quu2.w += lam2d[3];
@@ -359,6 +422,8 @@ __device__ __forceinline__ void backward_fused_body(RecLayout L, FusedArgs F, in
         if (lane_nn) fset_reg<REG_NN>(V, 0.0);
         __syncthreads();
     }
+    dJ += __shfl_xor(dJ, 16);
+    dJ += __shfl_xor(dJ, 32);
     if (lane_nn) delta_J[b] = dJ;
     if (lane == 0) status[b] = fail;
 }
