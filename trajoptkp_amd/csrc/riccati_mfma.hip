@@ -122,8 +122,7 @@ __device__ __forceinline__ void load_step(const double *R, int rec_bytes, const 
 #define LDS_TOTAL (LDS_PF + 32)
 
 // ABL: ablation switches for tools/ablate_backward.cpp only (0 in the product): 1 = always load the
-// same record (no HBM streaming), 2 = skip the LDL' solve, 4 = skip the K/k stores, 8 = skip the
-// symmetrisation transpose.
+// same record (no HBM streaming), 4 = skip the K/k stores, 8 = skip the symmetrisation transpose.
 template <int R> __device__ __forceinline__ void set_reg(d4 &v, double x) { if (R == 0) v.x = x; else if (R == 1) v.y = x; else if (R == 2) v.z = x; else v.w = x; }
 
 template <int N, int M, int ABL>
@@ -178,6 +177,10 @@ __device__ __forceinline__ void backward_body(RecLayout L, int T, const double *
     double dJ = 0.0;
     int fail = 0;
     const d4 zero = {0.0, 0.0, 0.0, 0.0};
+    d4 Xinv = zero, Iu;                          // running inverse of Quu + lambda I and the identity of the u-block
+    bool haveX = false;
+    Iu.x = (q == c && c < m) ? 1.0 : 0.0; Iu.y = (4 + q == c && c < m) ? 1.0 : 0.0;
+    Iu.z = (8 + q == c && c < m) ? 1.0 : 0.0; Iu.w = (12 + q == c && c < m) ? 1.0 : 0.0;
 
     for (int t = T - 1; t >= 0; t--) {
         // the loads issued one step ago are consumed here; then the next record is requested at once
@@ -193,86 +196,130 @@ __device__ __forceinline__ void backward_body(RecLayout L, int T, const double *
         // ---- Tu = V' Fu ; Quu = l_uu + Fu' Tu --------------------------------------- :577
         d4 Tu = P<NCZ>(V, cur.Fu, zero);
         d4 Quu = P<NCZ>(cur.Fu, Tu, cur.Luu);
-        // Quu + lambda I -> LDS image (row-major, stride MS); every lane stores (columns >= m hold zeros)
-        sh[LDS_Q + q * MS + c] = Quu.x + 0.5 * lam2d[0];
-        if (NCU > 1) sh[LDS_Q + (4 + q) * MS + c] = Quu.y + 0.5 * lam2d[1];
-        if (NCU > 2) sh[LDS_Q + (8 + q) * MS + c] = Quu.z + 0.5 * lam2d[2];
-        if (NCU > 3) sh[LDS_Q + (12 + q) * MS + c] = Quu.w + 0.5 * lam2d[3];
         // ---- Tz, Quz, Qzz --------------------------------------------------------------- :570-579
         d4 Tz = P<NCZ>(V, cur.Fz, zero);
         d4 Quz = P<NCZ>(cur.Fu, Tz, cur.Luz);
         d4 Qzz = P<NCZ>(cur.Fz, Tz, cur.Lzz);
-        sh[LDS_Z + c * MZ + q] = Quz.x;
-        if (NCU > 1) sh[LDS_Z + c * MZ + 4 + q] = Quz.y;
-        if (NCU > 2) sh[LDS_Z + c * MZ + 8 + q] = Quz.z;
-        if (NCU > 3) sh[LDS_Z + c * MZ + 12 + q] = Quz.w;
-        __syncthreads();
+        d4 Qr = Quu;                                  // Quu + lambda I
+        Qr.x += 0.5 * lam2d[0]; Qr.y += 0.5 * lam2d[1]; Qr.z += 0.5 * lam2d[2]; Qr.w += 0.5 * lam2d[3];
 
-        // ---- unpivoted LDL' of Quu + lambda I, redundantly in every lane (lower triangle) ----
-        double Lm[M][M], dd[M], rd[M];
-        bool pos = true;
-#pragma unroll
-        for (int j = 0; j < ((ABL & 2) ? 0 : M); j++) {
-            double w[M];
-            double dj = sh[LDS_Q + j * MS + j];
-#pragma unroll
-            for (int kk = 0; kk < j; kk++) { w[kk] = Lm[j][kk] * dd[kk]; dj -= Lm[j][kk] * w[kk]; }
-            dd[j] = dj;
-            pos = pos && (dj > 0.0);
-            const double rj = fast_rcp(dj);
-            rd[j] = rj;
-#pragma unroll
-            for (int i = j + 1; i < M; i++) {
-                double v = sh[LDS_Q + i * MS + j];
-#pragma unroll
-                for (int kk = 0; kk < j; kk++) v -= Lm[i][kk] * w[kk];
-                Lm[i][j] = v * rj;
-            }
-        }
-        if (check_pd) {                       // CheckMatrixPD every pd_stride steps   :587-595
-            if (!pos) { fail = t + 1; break; }
-            pd_counter = 0;
-        }
-
-        // ---- every lane solves (Quu + lambda I) x = Quz[:, c] for its own column c --------------
-        double x[M];
-        if (ABL & 2) {
-#pragma unroll
-            for (int i = 0; i < M; i++) x[i] = 1e-3 * sh[LDS_Z + c * MZ + i];
-        } else if (pos) {
-#pragma unroll
-            for (int i = 0; i < M; i++) x[i] = sh[LDS_Z + c * MZ + i];
-#pragma unroll
-            for (int j = 0; j < M; j++) {            // L y = z
-#pragma unroll
-                for (int i = j + 1; i < M; i++) x[i] -= Lm[i][j] * x[j];
-            }
-#pragma unroll
-            for (int i = 0; i < M; i++) x[i] *= rd[i];   // D
-#pragma unroll
-            for (int j = M - 1; j >= 0; j--) {       // L' x = y
-#pragma unroll
-                for (int i = 0; i < j; i++) x[i] -= Lm[j][i] * x[j];
-            }
-        } else {
-            // Q_uu + lambda I is not PD and this is not a checked step: follow Eigen's pivoted
-            // LDLT + explicit inverse exactly (iLQR.cpp:597-604).
-            double *wa = sh + LDS_SLOW, *wx = wa + 256, *wt = wx + 256;
-            int *tr = (int *)(wt + 16);
-            if (lane == 0) kp_slow_ldlt_inverse(L.m, sh + LDS_Q, MS, wa, wx, wt, tr);
-            __syncthreads();
-#pragma unroll
-            for (int i = 0; i < M; i++) {
-                double sacc = 0.0;
-#pragma unroll
-                for (int p = 0; p < M; p++) sacc += (-wx[i + p * m]) * sh[LDS_Z + c * MZ + p];
-                x[i] = -sacc;
-            }
-            __syncthreads();
-        }
-        // X = (Quu + lambda I)^-1 Quz and K' = -X as tiles in D layout: register r of lane (c,q) = X[4r+q][c]
+        // ---- X = (Quu + lambda I)^-1 Quz.  Fast path: the inverse changes little from one step to the next, so
+        //      it is refreshed by Newton-Schulz steps Xinv <- Xinv + Xinv (I - Q Xinv) on the matrix core (4 MFMAs
+        //      each, quadratic convergence; the count is chosen from the measured residual so that it ends below
+        //      1e-15) and X = Xinv Quz is one more product -- the reference, too, forms the explicit inverse and
+        //      multiplies (iLQR.cpp:597-604).  The LDL' path below runs on the first step, on every checked step
+        //      (it gives the PD verdict of :587-595), and whenever the residual is too large to converge fast.
         d4 Xp = zero;
-        {
+        bool done = false;
+        if (haveX && !check_pd) {
+            d4 R = Iu - P<NCU>(Qr, Xinv, zero);        // I - Q Xinv  (Q symmetric up to rounding: Q'X = QX)
+            double rmax = fabs(R.x);
+            if (NCU > 1) rmax = fmax(rmax, fabs(R.y));
+            if (NCU > 2) rmax = fmax(rmax, fabs(R.z));
+            if (NCU > 3) rmax = fmax(rmax, fabs(R.w));
+            const double e = (double)m * rmax;         // bound on the row sums of |R|
+            const bool too_big = __builtin_amdgcn_ballot_w64(!(e < 0.11)) != 0;
+            if (!too_big) {
+                const int iters = (__builtin_amdgcn_ballot_w64(e >= 1.3e-2) != 0) ? 4
+                                : (__builtin_amdgcn_ballot_w64(e >= 1.7e-4) != 0) ? 3
+                                : (__builtin_amdgcn_ballot_w64(e >= 3.0e-8) != 0) ? 2 : 1;
+                Xinv = P<NCU>(Xinv, R, Xinv);                              // Xinv + Xinv'R  (Xinv symmetric)
+                if (iters > 1) {
+                    R = Iu - P<NCU>(Qr, Xinv, zero); Xinv = P<NCU>(Xinv, R, Xinv);
+                    if (iters > 2) {
+                        R = Iu - P<NCU>(Qr, Xinv, zero); Xinv = P<NCU>(Xinv, R, Xinv);
+                        if (iters > 3) { R = Iu - P<NCU>(Qr, Xinv, zero); Xinv = P<NCU>(Xinv, R, Xinv); }
+                    }
+                }
+                Xp = P<NCU>(Xinv, Quz, zero);                              // Xinv' Quz = (Quu + lambda I)^-1 Quz
+                done = true;
+            }
+        }
+        if (!done) {
+            // Quu + lambda I -> LDS image (row-major, stride MS) and Quz (column-major, stride MZ) for the per-lane solve
+            sh[LDS_Q + q * MS + c] = Qr.x;
+            if (NCU > 1) sh[LDS_Q + (4 + q) * MS + c] = Qr.y;
+            if (NCU > 2) sh[LDS_Q + (8 + q) * MS + c] = Qr.z;
+            if (NCU > 3) sh[LDS_Q + (12 + q) * MS + c] = Qr.w;
+            sh[LDS_Z + c * MZ + q] = Quz.x;
+            if (NCU > 1) sh[LDS_Z + c * MZ + 4 + q] = Quz.y;
+            if (NCU > 2) sh[LDS_Z + c * MZ + 8 + q] = Quz.z;
+            if (NCU > 3) sh[LDS_Z + c * MZ + 12 + q] = Quz.w;
+            __syncthreads();
+            // ---- unpivoted LDL' of Quu + lambda I, redundantly in every lane (lower triangle) ----
+            double Lm[M][M], dd[M], rd[M];
+            bool pos = true;
+#pragma unroll
+            for (int j = 0; j < M; j++) {
+                double w[M];
+                double dj = sh[LDS_Q + j * MS + j];
+#pragma unroll
+                for (int kk = 0; kk < j; kk++) { w[kk] = Lm[j][kk] * dd[kk]; dj -= Lm[j][kk] * w[kk]; }
+                dd[j] = dj;
+                pos = pos && (dj > 0.0);
+                const double rj = fast_rcp(dj);
+                rd[j] = rj;
+#pragma unroll
+                for (int i = j + 1; i < M; i++) {
+                    double v = sh[LDS_Q + i * MS + j];
+#pragma unroll
+                    for (int kk = 0; kk < j; kk++) v -= Lm[i][kk] * w[kk];
+                    Lm[i][j] = v * rj;
+                }
+            }
+            if (check_pd) {                       // CheckMatrixPD every pd_stride steps   :587-595
+                if (!pos) { fail = t + 1; break; }
+                pd_counter = 0;
+            }
+            auto ldl_solve = [&](double *v) {
+#pragma unroll
+                for (int j = 0; j < M; j++) {            // L y = z
+#pragma unroll
+                    for (int i = j + 1; i < M; i++) v[i] -= Lm[i][j] * v[j];
+                }
+#pragma unroll
+                for (int i = 0; i < M; i++) v[i] *= rd[i];   // D
+#pragma unroll
+                for (int j = M - 1; j >= 0; j--) {       // L' x = y
+#pragma unroll
+                    for (int i = 0; i < j; i++) v[i] -= Lm[j][i] * v[j];
+                }
+            };
+            // ---- every lane solves (Quu + lambda I) x = Quz[:, c] for its own column c --------------
+            double x[M];
+            if (pos) {
+#pragma unroll
+                for (int i = 0; i < M; i++) x[i] = sh[LDS_Z + c * MZ + i];
+                ldl_solve(x);
+                // seed the fast path: column c of the inverse in lane c (c < m), as a tile
+                double y[M];
+#pragma unroll
+                for (int i = 0; i < M; i++) y[i] = (i == c) ? 1.0 : 0.0;
+                ldl_solve(y);
+                double yr[4] = {0.0, 0.0, 0.0, 0.0};
+#pragma unroll
+                for (int i = 0; i < M; i++)
+                    if (q == (i & 3)) yr[i >> 2] = (c < m) ? y[i] : 0.0;
+                Xinv.x = yr[0]; Xinv.y = yr[1]; Xinv.z = yr[2]; Xinv.w = yr[3];
+                haveX = true;
+            } else {
+                // Q_uu + lambda I is not PD and this is not a checked step: follow Eigen's pivoted
+                // LDLT + explicit inverse exactly (iLQR.cpp:597-604).
+                double *wa = sh + LDS_SLOW, *wx = wa + 256, *wt = wx + 256;
+                int *tr = (int *)(wt + 16);
+                if (lane == 0) kp_slow_ldlt_inverse(L.m, sh + LDS_Q, MS, wa, wx, wt, tr);
+                __syncthreads();
+#pragma unroll
+                for (int i = 0; i < M; i++) {
+                    double sacc = 0.0;
+#pragma unroll
+                    for (int p = 0; p < M; p++) sacc += (-wx[i + p * m]) * sh[LDS_Z + c * MZ + p];
+                    x[i] = -sacc;
+                }
+                __syncthreads();
+                haveX = false;
+            }
+            // X as a tile in D layout: register r of lane (c,q) = X[4r+q][c]
             double xr[4] = {0.0, 0.0, 0.0, 0.0};
 #pragma unroll
             for (int i = 0; i < M; i++)
@@ -293,12 +340,13 @@ __device__ __forceinline__ void backward_body(RecLayout L, int T, const double *
             }
         }
         // ---- delta_J += k'Q_u + k'Q_uu k  (:612-613).  With (Q_uu + lambda I) k = -Q_u this is
-        //      k'(Q_uu k + Q_u) = -lambda k'k, evaluated in that cancellation-free form (lane of column n).
-        {
-            double kk = 0.0;
-#pragma unroll
-            for (int i = 0; i < M; i++) kk += x[i] * x[i];
-            if (lane_nn) dJ -= lam * kk;
+        //      k'(Q_uu k + Q_u) = -lambda k'k, evaluated in that cancellation-free form: the lanes of column n keep
+        //      the squares of their rows, the four row groups are added once after the sweep.
+        if (c == n) {
+            dJ -= lam * (Xp.x * Xp.x);
+            if (NCU > 1) dJ -= lam * (Xp.y * Xp.y);
+            if (NCU > 2) dJ -= lam * (Xp.z * Xp.z);
+            if (NCU > 3) dJ -= lam * (Xp.w * Xp.w);
         }
         // ---- V' = Qzz + K''Quu K' + K''Quz + Quz'K'   (:606-607).  Substituting Quz = -(Quu + lambda I) K'
         //      gives V' = Qzz - K''(Quu + 2 lambda I) K' = Qzz + X'[(Quu + 2 lambda I) K']: two products.
@@ -321,7 +369,9 @@ __device__ __forceinline__ void backward_body(RecLayout L, int T, const double *
         if (lane_nn) set_reg<REG_NN>(V, 0.0);      // element (n,n) carries nothing: keep it at zero
         __syncthreads();
     }
-    // delta_J lives in lane_nn; status is uniform
+    // delta_J: the four row groups of column n; status is uniform
+    dJ += __shfl_xor(dJ, 16);
+    dJ += __shfl_xor(dJ, 32);
     if (lane_nn) delta_J[b] = dJ;
     if (lane == 0) status[b] = fail;
 }
