@@ -197,6 +197,10 @@ k_backward_tiled_col(RecLayout L, int T, const double *__restrict__ rec, const d
 
     int pd_counter = 0, fail = 0;
     double dJ = 0.0;
+    d4 Xinv = zero, Iu;                          // running inverse of Quu + lambda I, identity of the u-block
+    bool haveX = false;
+    Iu.x = (q == c && c < m) ? 1.0 : 0.0; Iu.y = (4 + q == c && c < m) ? 1.0 : 0.0;
+    Iu.z = (8 + q == c && c < m) ? 1.0 : 0.0; Iu.w = (12 + q == c && c < m) ? 1.0 : 0.0;
     for (int t = T - 1; t >= 0; t--) {
         pd_counter++;
         const bool check_pd = pd_counter >= pd_stride;
@@ -233,12 +237,10 @@ k_backward_tiled_col(RecLayout L, int T, const double *__restrict__ rec, const d
             for (int k = 0; k < NT; k++) Tu = Pk<NT>(k, lds_tile(bufV + (k * NT + w) * TILE, lane), lds_tile(bufFu + k * TILE, lane), Tu, ncl);
             lds_store(bufQp + w * TILE, lane, Pn(lds_tile(bufFu + w * TILE, lane), Tu, zero, ncw));
         }
-        {
-            d4 acc = pLuz;
+        d4 Quzw = pLuz;                                                     // Quz(w): also kept in registers for the fast path
 #pragma unroll
-            for (int k = 0; k < NT; k++) acc = Pk<NT>(k, lds_tile(bufFu + k * TILE, lane), Tz[k], acc, ncl);
-            lds_store(bufQuz + w * TILE, lane, acc);
-        }
+        for (int k = 0; k < NT; k++) Quzw = Pk<NT>(k, lds_tile(bufFu + k * TILE, lane), Tz[k], Quzw, ncl);
+        lds_store(bufQuz + w * TILE, lane, Quzw);
         d4 Qzz[NT];
 #pragma unroll
         for (int i = 0; i < NT; i++) {
@@ -258,63 +260,100 @@ k_backward_tiled_col(RecLayout L, int T, const double *__restrict__ rec, const d
 #pragma unroll
         for (int k = 0; k < NT; k++) Quu = Quu + lds_tile(bufQp + k * TILE, lane);
         pLuu = ld_Luu(rn, S, q, c);
-        {
-            d4 Qr = Quu;
-            Qr.x += 0.5 * lam2d[0]; Qr.y += 0.5 * lam2d[1]; Qr.z += 0.5 * lam2d[2]; Qr.w += 0.5 * lam2d[3];
+        d4 Qr = Quu;
+        Qr.x += 0.5 * lam2d[0]; Qr.y += 0.5 * lam2d[1]; Qr.z += 0.5 * lam2d[2]; Qr.w += 0.5 * lam2d[3];
+        // X(w) = (Quu + lambda I)^-1 Quz(w).  Fast path as in riccati_mfma.hip: every wave keeps the running inverse
+        // and refreshes it with Newton-Schulz steps on the matrix core (identical inputs in every wave, so the
+        // decisions below are block-uniform); LDL' on the first step, on checked steps (PD verdict) and when the
+        // residual is too large to converge fast.
+        d4 X = zero;
+        bool done = false;
+        if (haveX && !check_pd) {
+            d4 R = Iu - Pn(Qr, Xinv, zero, NCU);
+            double rmax = fmax(fmax(fabs(R.x), fabs(R.y)), fmax(fabs(R.z), fabs(R.w)));
+            const double e = (double)m * rmax;
+            const bool too_big = __builtin_amdgcn_ballot_w64(!(e < 0.11)) != 0;
+            if (!too_big) {
+                const int iters = (__builtin_amdgcn_ballot_w64(e >= 1.3e-2) != 0) ? 4
+                                : (__builtin_amdgcn_ballot_w64(e >= 1.7e-4) != 0) ? 3
+                                : (__builtin_amdgcn_ballot_w64(e >= 3.0e-8) != 0) ? 2 : 1;
+                Xinv = Pn(Xinv, R, Xinv, NCU);
+                if (iters > 1) {
+                    R = Iu - Pn(Qr, Xinv, zero, NCU); Xinv = Pn(Xinv, R, Xinv, NCU);
+                    if (iters > 2) {
+                        R = Iu - Pn(Qr, Xinv, zero, NCU); Xinv = Pn(Xinv, R, Xinv, NCU);
+                        if (iters > 3) { R = Iu - Pn(Qr, Xinv, zero, NCU); Xinv = Pn(Xinv, R, Xinv, NCU); }
+                    }
+                }
+                X = Pn(Xinv, Quzw, zero, NCU);
+                done = true;
+            }
+        }
+        if (!done) {
             lds_store(sQ, lane, Qr);                  // this wave's private image (same-wave LDS accesses are ordered)
-        }
-        auto qel = [&](int i, int j) { return sQ[(i >> 2) * 64 + j + 16 * (i & 3)]; };
-        double Lm[M][M], dd[M], rd[M];
-        bool pos = true;
+            auto qel = [&](int i, int j) { return sQ[(i >> 2) * 64 + j + 16 * (i & 3)]; };
+            double Lm[M][M], dd[M], rd[M];
+            bool pos = true;
 #pragma unroll
-        for (int j = 0; j < M; j++) {
-            double ww[M];
-            double dj = qel(j, j);
+            for (int j = 0; j < M; j++) {
+                double ww[M];
+                double dj = qel(j, j);
 #pragma unroll
-            for (int kk = 0; kk < j; kk++) { ww[kk] = Lm[j][kk] * dd[kk]; dj -= Lm[j][kk] * ww[kk]; }
-            dd[j] = dj;
-            pos = pos && (dj > 0.0);
-            const double rj = trcp(dj);
-            rd[j] = rj;
+                for (int kk = 0; kk < j; kk++) { ww[kk] = Lm[j][kk] * dd[kk]; dj -= Lm[j][kk] * ww[kk]; }
+                dd[j] = dj;
+                pos = pos && (dj > 0.0);
+                const double rj = trcp(dj);
+                rd[j] = rj;
 #pragma unroll
-            for (int i = j + 1; i < M; i++) {
-                double v = qel(i, j);
+                for (int i = j + 1; i < M; i++) {
+                    double v = qel(i, j);
 #pragma unroll
-                for (int kk = 0; kk < j; kk++) v -= Lm[i][kk] * ww[kk];
-                Lm[i][j] = v * rj;
+                    for (int kk = 0; kk < j; kk++) v -= Lm[i][kk] * ww[kk];
+                    Lm[i][j] = v * rj;
+                }
             }
-        }
-        if (check_pd) {                       // CheckMatrixPD every pd_stride steps   :587-595
-            if (!pos) { fail = t + 1; break; }
-            pd_counter = 0;
-        }
-        double *winv = sRow + 256 + 256;
-        if (!pos) {
-            if (threadIdx.x == 0) {
-                for (int i = 0; i < m; i++) for (int j = 0; j < m; j++) sRow[i * 16 + j] = qel(i, j);
-                kp_slow_ldlt_inverse(m, sRow, 16, sRow + 256, winv, sRow + 768, (int *)(sRow + 784));
+            if (check_pd) {                       // CheckMatrixPD every pd_stride steps   :587-595
+                if (!pos) { fail = t + 1; break; }
+                pd_counter = 0;
             }
-            __syncthreads();
-        }
-        d4 Gw;
-        {
+            double *winv = sRow + 256 + 256;
+            if (!pos) {
+                if (threadIdx.x == 0) {
+                    for (int i = 0; i < m; i++) for (int j = 0; j < m; j++) sRow[i * 16 + j] = qel(i, j);
+                    kp_slow_ldlt_inverse(m, sRow, 16, sRow + 256, winv, sRow + 768, (int *)(sRow + 784));
+                }
+                __syncthreads();
+            }
+            auto ldl_solve = [&](double *v) {
+#pragma unroll
+                for (int jj = 0; jj < M; jj++) {
+#pragma unroll
+                    for (int i = jj + 1; i < M; i++) v[i] -= Lm[i][jj] * v[jj];
+                }
+#pragma unroll
+                for (int i = 0; i < M; i++) v[i] *= rd[i];
+#pragma unroll
+                for (int jj = M - 1; jj >= 0; jj--) {
+#pragma unroll
+                    for (int i = 0; i < jj; i++) v[i] -= Lm[jj][i] * v[jj];
+                }
+            };
             const double *zt = bufQuz + w * TILE;
             double x[M];
 #pragma unroll
             for (int i = 0; i < M; i++) x[i] = zt[(i >> 2) * 64 + c + 16 * (i & 3)];
             if (pos) {
+                ldl_solve(x);
+                double y[M];                          // seed the fast path: column c of the inverse in lane c (c < m)
 #pragma unroll
-                for (int jj = 0; jj < M; jj++) {
+                for (int i = 0; i < M; i++) y[i] = (i == c) ? 1.0 : 0.0;
+                ldl_solve(y);
+                double yr[4] = {0.0, 0.0, 0.0, 0.0};
 #pragma unroll
-                    for (int i = jj + 1; i < M; i++) x[i] -= Lm[i][jj] * x[jj];
-                }
-#pragma unroll
-                for (int i = 0; i < M; i++) x[i] *= rd[i];
-#pragma unroll
-                for (int jj = M - 1; jj >= 0; jj--) {
-#pragma unroll
-                    for (int i = 0; i < jj; i++) x[i] -= Lm[jj][i] * x[jj];
-                }
+                for (int i = 0; i < M; i++)
+                    if (q == (i & 3)) yr[i >> 2] = (c < m) ? y[i] : 0.0;
+                Xinv.x = yr[0]; Xinv.y = yr[1]; Xinv.z = yr[2]; Xinv.w = yr[3];
+                haveX = true;
             } else {
                 double y[M];
 #pragma unroll
@@ -326,28 +365,32 @@ k_backward_tiled_col(RecLayout L, int T, const double *__restrict__ rec, const d
                 }
 #pragma unroll
                 for (int i = 0; i < M; i++) x[i] = y[i];
+                haveX = false;
             }
-            const int col = 16 * w + c;
+            const int colx = 16 * w + c;
             double xr[4] = {0.0, 0.0, 0.0, 0.0};
 #pragma unroll
             for (int i = 0; i < M; i++)
-                if (q == (i & 3)) xr[i >> 2] = (col <= n) ? x[i] : 0.0;
-            d4 X = {xr[0], xr[1], xr[2], xr[3]};
+                if (q == (i & 3)) xr[i >> 2] = (colx <= n) ? x[i] : 0.0;
+            X.x = xr[0]; X.y = xr[1]; X.z = xr[2]; X.w = xr[3];
+        }
+        d4 Gw;
+        {
+            const int col = 16 * w + c;
             lds_store(bufX + w * TILE, lane, X);
             __amdgpu_buffer_rsrc_t rK = __builtin_amdgcn_make_buffer_rsrc((void *)(Kout + ((size_t)b * T + t) * m * n), 0, m * n * 8, 0x00020000);
             __amdgpu_buffer_rsrc_t rk = __builtin_amdgcn_make_buffer_rsrc((void *)(kout + ((size_t)b * T + t) * m), 0, m * 8, 0x00020000);
+            const double xv[4] = {X.x, X.y, X.z, X.w};
 #pragma unroll
             for (int r = 0; r < NCU; r++) {
                 const int row = 4 * r + q;
-                const double kv = -xr[r];
+                const double kv = -xv[r];
                 __builtin_amdgcn_raw_buffer_store_b64(__builtin_bit_cast(u32x2t, kv), rK, (row < m && col < n) ? 8 * (row + col * m) : OOBT, 0, 0);
                 __builtin_amdgcn_raw_buffer_store_b64(__builtin_bit_cast(u32x2t, kv), rk, (row < m && col == n) ? 8 * row : OOBT, 0, 0);
             }
-            if (w == tn) {
-                double kk = 0.0;
+            if (col == n) {                           // delta_J -= lambda k'k: lane-local squares, reduced after the sweep
 #pragma unroll
-                for (int i = 0; i < M; i++) kk += x[i] * x[i];
-                if (lane_nn) dJ -= lam * kk;
+                for (int r = 0; r < NCU; r++) dJ -= lam * (xv[r] * xv[r]);
             }
             d4 Quu2 = Quu;
             Quu2.x += lam2d[0]; Quu2.y += lam2d[1]; Quu2.z += lam2d[2]; Quu2.w += lam2d[3];
@@ -372,6 +415,8 @@ k_backward_tiled_col(RecLayout L, int T, const double *__restrict__ rec, const d
             lds_store(bufV + (i * NT + w) * TILE, lane, na);
         }
     }
+    dJ += __shfl_xor(dJ, 16);
+    dJ += __shfl_xor(dJ, 32);
     if (w == tn && lane_nn) delta_J[b] = dJ;
     if (threadIdx.x == 0) status[b] = fail;
 }
