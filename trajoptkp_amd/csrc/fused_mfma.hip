@@ -972,9 +972,12 @@ __device__ __forceinline__ void forward_fused_body(RecLayout L, FusedArgs F, int
             pend = true;
         }
     };
+    // Y operands: step t uses (Ya, Yb); during step t the tiles of step t+1 are fetched from LDS (staged during
+    // step t-1) and those of step t+2 are staged.
     d4 Ya, Yb;
     stage_cols(0);
     fetch_Y(Ya, Yb);
+    if (T > 1) { advance(1); stage_cols(1); }
 
     // single-buffered tiles: each is re-requested for step t+1 right behind its last use in step t
     Tiles cur = nxt;
@@ -987,18 +990,22 @@ __device__ __forceinline__ void forward_fused_body(RecLayout L, FusedArgs F, int
         __amdgpu_buffer_rsrc_t rRx = more ? frsrc(rxb + (size_t)(t + 1) * nr * n, nr * n * 8) : rNone;
         __amdgpu_buffer_rsrc_t rRu = more ? frsrc(rub + (size_t)(t + 1) * nr * m, nr * m * 8) : rNone;
         __amdgpu_buffer_rsrc_t rR = more ? frsrc(rb + (size_t)(t + 1) * nr, nr * 8) : rNone;
-        // control law + clamp
+        // Order of the step: every product is a dependent MFMA chain whose result is usable ~100 cycles after its last
+        // issue, so independent work is placed behind each chain before its consumer:
+        //   U chain | A dx chain | clamp (U ready) | B du | r_u du | r_x dx | a4 of step t+1 (VALU + LDS) | cost (Jx ready)
         const d4 Yk = cur.YkK + cur.Ykk;
         const d4 ub = cur.ub;
-        d4 U = PS<NCZ>(Yk, Z, ub);
+        d4 U = PS<NCZ>(Yk, Z, ub);                     // u_nom + K dx + alpha k   (:879)
         __builtin_amdgcn_sched_barrier(0);
         cur.YkK.x = fbld(rK, oK[0]); cur.YkK.y = fbld(rK, oK[1]); cur.YkK.z = fbld(rK, oK[2]); cur.YkK.w = fbld(rK, oK[3]);
         cur.Ykk.x = fbld(rk, ok_[0]); cur.Ykk.y = fbld(rk, ok_[1]); cur.Ykk.z = fbld(rk, ok_[2]); cur.Ykk.w = fbld(rk, ok_[3]);
         __builtin_amdgcn_sched_barrier(0);
+        d4 Zn = PS<NCZ>(Ya, Z, zero);                  // A dx (does not need the controls)
+        __builtin_amdgcn_sched_barrier(0);
         d4 dU;
         {
             double u;
-            // rows >= 4*NCU of U hold no control (exact zeros): only the first NCU registers are clamped
+            // rows >= 4*NCU of U hold no control (exact zeros): only the first NCU registers are clamped (:883-889)
             dU = zero;
             u = U.x; if (u > hi[0]) u = hi[0]; if (u < lo[0]) u = lo[0]; U.x = u; dU.x = u - ub.x;
             if (NCU > 1) { u = U.y; if (u > hi[1]) u = hi[1]; if (u < lo[1]) u = lo[1]; U.y = u; dU.y = u - ub.y; }
@@ -1009,22 +1016,25 @@ __device__ __forceinline__ void forward_fused_body(RecLayout L, FusedArgs F, int
         cur.ub.x = fbld(ru, oub[0]); cur.ub.y = NCU > 1 ? fbld(ru, oub[1]) : 0.0;
         cur.ub.z = NCU > 2 ? fbld(ru, oub[2]) : 0.0; cur.ub.w = NCU > 3 ? fbld(ru, oub[3]) : 0.0;
         __builtin_amdgcn_sched_barrier(0);
+        Zn = PS<NCU>(Yb, dU, Zn);                      // + B du: the next state
+        const d4 Ju = PS<NCU>(cur.RuT, dU, zero);
+        const d4 Jx = PR(cur.RxT, Z, zero, ncx);
+        Z = Zn;
+        __builtin_amdgcn_sched_barrier(0);
+        cur.RxT.x = fbld(rRx, oRxT[0]); cur.RxT.y = fbld(rRx, oRxT[1]); cur.RxT.z = fbld(rRx, oRxT[2]); cur.RxT.w = fbld(rRx, oRxT[3]);
+        cur.RuT.x = fbld(rRu, oRuT[0]); cur.RuT.y = NCU > 1 ? fbld(rRu, oRuT[1]) : 0.0;
+        cur.RuT.z = NCU > 2 ? fbld(rRu, oRuT[2]) : 0.0; cur.RuT.w = NCU > 3 ? fbld(rRu, oRuT[3]) : 0.0;
+        if (more) fetch_Y(Ya, Yb);                     // Y operands of step t+1 (staged during step t-1 ... see below)
+        __builtin_amdgcn_sched_barrier(0);
         if (U_alpha && c < n_alpha) {
             double *Ua = U_alpha + (((size_t)b * n_alpha + c) * T + t) * m;
             const double uv[4] = {U.x, U.y, U.z, U.w};
 #pragma unroll
             for (int r = 0; r < NCU; r++) { const int row = 4 * r + q; if (row < m) Ua[row] = uv[r]; }
         }
-        // a4 for step t+1 (column layout -> LDS), off the Z chain
-        if (more) { advance(t + 1); stage_cols(t + 1); }
+        // a4 for step t+2 (column layout -> LDS): fills the latency of the products above
+        if (t + 2 < T) { advance(t + 2); stage_cols(t + 2); }
         // quadratic cost model on the residuals: sum_k w_k [Jx_k (2 r_k + Jx_k) + Ju_k (2 r_k + Ju_k)]
-        const d4 Jx = PR(cur.RxT, Z, zero, ncx);
-        const d4 Ju = PS<NCU>(cur.RuT, dU, zero);
-        __builtin_amdgcn_sched_barrier(0);
-        cur.RxT.x = fbld(rRx, oRxT[0]); cur.RxT.y = fbld(rRx, oRxT[1]); cur.RxT.z = fbld(rRx, oRxT[2]); cur.RxT.w = fbld(rRx, oRxT[3]);
-        cur.RuT.x = fbld(rRu, oRuT[0]); cur.RuT.y = NCU > 1 ? fbld(rRu, oRuT[1]) : 0.0;
-        cur.RuT.z = NCU > 2 ? fbld(rRu, oRuT[2]) : 0.0; cur.RuT.w = NCU > 3 ? fbld(rRu, oRuT[3]) : 0.0;
-        __builtin_amdgcn_sched_barrier(0);
         if (t == T - 1) {                     // terminal weights at the last step (Optimiser.cpp:209-211)
 #pragma unroll
             for (int r = 0; r < 4; r++) wcur[r] = (4 * r + q < nr) ? F.w_term[4 * r + q] : 0.0;
@@ -1037,12 +1047,6 @@ __device__ __forceinline__ void forward_fused_body(RecLayout L, FusedArgs F, int
         __builtin_amdgcn_sched_barrier(0);
         cur.rv.x = fbld(rR, oR[0]); cur.rv.y = fbld(rR, oR[1]); cur.rv.z = fbld(rR, oR[2]); cur.rv.w = fbld(rR, oR[3]);
         __builtin_amdgcn_sched_barrier(0);
-        // linearised dynamics, then the Y operands of step t+1 come back from LDS behind the MFMAs
-        d4 Zn = PS<NCZ>(Ya, Z, zero);
-        Zn = PS<NCU>(Yb, dU, Zn);
-        Z = Zn;
-        __builtin_amdgcn_sched_barrier(0);
-        if (more) fetch_Y(Ya, Yb);
     }
     partial += __shfl_xor(partial, 16);
     partial += __shfl_xor(partial, 32);
