@@ -124,8 +124,11 @@ __device__ __forceinline__ void forward_body(RecLayout L, int T, int n_alpha, co
         if (t + 1 < T) load_tiles(t + 1, nxt);
         __builtin_amdgcn_sched_barrier(0);     // keep the prefetch AHEAD of this step's compute
 
-        // control law + clamp
+        // Order of the step: every product is a dependent MFMA chain whose result is usable ~100 cycles after its last
+        // issue, so an independent chain follows each one before its consumer:
+        //   U chain | A dx chain | clamp (U ready) | B du | l_uu du | Lc Z | cost
         d4 U = PF<NCZ>(Yk, Z, ub);        // u_nom + K dx + alpha k
+        d4 Zn = PF<NCZ>(Ya, Z, zero);     // A dx (does not need the controls)
         d4 dU;
         {
             double u;
@@ -134,6 +137,9 @@ __device__ __forceinline__ void forward_body(RecLayout L, int T, int n_alpha, co
             u = U.z; if (u > hi[2]) u = hi[2]; if (u < lo[2]) u = lo[2]; U.z = u; dU.z = u - ub.z;
             u = U.w; if (u > hi[3]) u = hi[3]; if (u < lo[3]) u = lo[3]; U.w = u; dU.w = u - ub.w;
         }
+        Zn = PF<NCU>(Yb, dU, Zn);         // + B du: the next state
+        d4 Wu = PF<NCU>(Luu, dU, zero);
+        d4 Wz = PF<NCZ>(Lc, Z, zero);
         if (U_alpha && c < n_alpha) {
             double *Ua = U_alpha + (((size_t)b * n_alpha + c) * T + t) * m;
             const double uv[4] = {U.x, U.y, U.z, U.w};
@@ -141,14 +147,9 @@ __device__ __forceinline__ void forward_body(RecLayout L, int T, int n_alpha, co
             for (int r = 0; r < NCU; r++) { const int row = 4 * r + q; if (row < m) Ua[row] = uv[r]; }
         }
         // cost of this step on the quadratic model (lane-local partial sums)
-        d4 Wz = PF<NCZ>(Lc, Z, zero);
-        d4 Wu = PF<NCU>(Luu, dU, zero);
-        partial += 0.5 * (Z.x * Wz.x + Z.y * Wz.y + Z.z * Wz.z + Z.w * Wz.w);
         partial += dU.x * (0.5 * Wu.x + lu.x) + dU.y * (0.5 * Wu.y + lu.y)
                  + dU.z * (0.5 * Wu.z + lu.z) + dU.w * (0.5 * Wu.w + lu.w);
-        // linearised dynamics
-        d4 Zn = PF<NCZ>(Ya, Z, zero);
-        Zn = PF<NCU>(Yb, dU, Zn);
+        partial += 0.5 * (Z.x * Wz.x + Z.y * Wz.y + Z.z * Wz.z + Z.w * Wz.w);
         Z = Zn;
     }
     // column sums: lanes c, c+16, c+32, c+48
