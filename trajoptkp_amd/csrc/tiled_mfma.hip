@@ -2,16 +2,16 @@
 // n+2 <= 16*NT, NT = 2..4 (Panda pushing n=20, low/moderate/heavy clutter n=38..62), m <= 8.
 // Same formulation as riccati_mfma.hip / forward_mfma.hip (homogeneous coordinate, P(Y,X) = Y'X on
 // v_mfma_f64_16x16x4_f64, tiles in the accumulator layout), but the matrices are NT x NT grids of
-// 16x16 tiles that live in LDS (one wavefront per trajectory, up to 143 KB of the CU's 160 KB at NT=4),
-// and products loop over tiles.  This is where the per-step A'V_xxA is a real contraction
-// (62^3 at the high-DoF configuration): the FP64 matrix core does 1024 FMAs per ~80-cycle issue.
+// 16x16 tiles that live in LDS (NT wavefronts per trajectory, each owning one column of tiles; up to 158 KB of
+// the CU's 160 KB at NT=4), and products loop over tiles.  This is where the per-step A'V_xxA is a real
+// contraction (62^3 at the high-DoF configuration): the FP64 matrix core does 1024 FMAs per ~80-cycle issue.
 //
 // Reference: iLQR::BackwardsPassQuuRegularisation + CheckMatrixPD, src/Optimiser/iLQR.cpp:535-670;
 // control law / clamp of iLQR::ForwardsPassParallel, src/Optimiser/iLQR.cpp:876-890.
 //
-// LDS tile image: 256 doubles, register r of lane l at [r*64 + l]  (element (4r + (l>>4), l&15)).
-// A workgroup is exactly one wavefront, so LDS traffic needs no s_barrier; __syncthreads() is kept as
-// the compiler-level ordering point (it lowers to nothing for a 64-thread workgroup).
+// LDS tile image: 256 doubles, register r of lane l at [r*64 + l]  (element (4r + (l>>4), l&15)): a tile is
+// read back as an MFMA operand with conflict-free 8-byte accesses.  The waves of a workgroup meet at s_barrier
+// between the phases of a step (the barrier waits for LDS traffic only, so global loads stay in flight).
 #include <cstdlib>
 #include "mfma_common.h"
 
