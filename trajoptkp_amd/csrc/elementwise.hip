@@ -229,6 +229,8 @@ k_cost_derivs(RecLayout L, int nr, int T,
     const int b = blockIdx.y;
     const int t0 = blockIdx.x * COST_TT;
     const int nt = min(COST_TT, T - t0);
+    double *sw = sh + COST_TT * per;               // [2][nr]: doubled running / terminal weights (w*2 is exact)
+    for (int w = threadIdx.x; w < 2 * nr; w += blockDim.x) sw[w] = ((w < nr) ? w_run[w] : w_term[w - nr]) * 2;
     // stage: [tt][ r(nr) | r_x(nr*n) | r_u(nr*m) ]
     for (int w = threadIdx.x; w < nt * per; w += blockDim.x) {
         const int tt = w / per, e = w - tt * per;
@@ -247,41 +249,42 @@ k_cost_derivs(RecLayout L, int nr, int T,
     for (int w = threadIdx.x; w < nt * nblk; w += blockDim.x) {
         const int tt = w / nblk, o = w - tt * nblk;
         const int t = t0 + tt;
-        const double *wt = (t == T - 1) ? w_term : w_run;   // Optimiser.cpp:208-211
+        const double *wt2 = sw + ((t == T - 1) ? nr : 0);   // Optimiser.cpp:208-211
         const double *srx = sh + tt * per + nr;
         const int a = 2 * (o / hb), bb = 2 * (o - (o / hb) * hb);
         double a00 = 0.0, a01 = 0.0, a10 = 0.0, a11 = 0.0;
         for (int i = 0; i < nr; i++) {
-            const double w2 = wt[i] * 2;
+            const double w2 = wt2[i];
             const double xa0 = srx[i * n + a], xa1 = srx[i * n + a + 1];
             const double xb0 = srx[i * n + bb], xb1 = srx[i * n + bb + 1];
             const double va0 = w2 * xa0, va1 = w2 * xa1;
             a00 += va0 * xb0; a01 += va0 * xb1; a10 += va1 * xb0; a11 += va1 * xb1;
         }
+        // 16-byte stores: the record stride is a multiple of 16 doubles and off_lxx, a*n and bb are even
         double *dst = rec + ((size_t)b * T + t) * L.stride + L.off_lxx;
-        dst[a * n + bb] = a00; dst[a * n + bb + 1] = a01;
-        dst[(a + 1) * n + bb] = a10; dst[(a + 1) * n + bb + 1] = a11;
+        *reinterpret_cast<double2 *>(dst + a * n + bb) = make_double2(a00, a01);
+        *reinterpret_cast<double2 *>(dst + (a + 1) * n + bb) = make_double2(a10, a11);
     }
     const int nrest = n + m * m + m;
     for (int w = threadIdx.x; w < nt * nrest; w += blockDim.x) {
         const int tt = w / nrest, o = w - tt * nrest;
         const int t = t0 + tt;
-        const double *wt = (t == T - 1) ? w_term : w_run;
+        const double *wt2 = sw + ((t == T - 1) ? nr : 0);
         const double *sr = sh + tt * per, *srx = sr + nr, *sru = srx + nr * n;
         double acc = 0.0;
         int dst;
         if (o < n) {                           // l_x(a)
             const int a = o;
-            for (int i = 0; i < nr; i++) acc += ((wt[i] * 2) * sr[i]) * srx[i * n + a];
+            for (int i = 0; i < nr; i++) acc += (wt2[i] * sr[i]) * srx[i * n + a];
             dst = L.off_lx + a;
         } else if (o < n + m * m) {            // l_uu(a,b)
             const int q = o - n;
             const int a = q / m, bb = q - a * m;
-            for (int i = 0; i < nr; i++) acc += ((wt[i] * 2) * sru[i * m + a]) * sru[i * m + bb];
+            for (int i = 0; i < nr; i++) acc += (wt2[i] * sru[i * m + a]) * sru[i * m + bb];
             dst = L.off_luu + q;
         } else {                               // l_u(a)
             const int a = o - n - m * m;
-            for (int i = 0; i < nr; i++) acc += ((wt[i] * 2) * sr[i]) * sru[i * m + a];
+            for (int i = 0; i < nr; i++) acc += (wt2[i] * sr[i]) * sru[i * m + a];
             dst = L.off_lu + a;
         }
         rec[((size_t)b * T + t) * L.stride + dst] = acc;
@@ -416,7 +419,7 @@ hipError_t launch_cost_derivs(Ctx *c)
         if (c->n == 20 && c->d.m == 7) return launch_cost_rows<20, 7>(c);
     }
     dim3 grid((c->d.T + COST_TT - 1) / COST_TT, c->d.batch);
-    const size_t lds = sizeof(double) * COST_TT * c->d.nr * (1 + c->n + c->d.m);
+    const size_t lds = sizeof(double) * (COST_TT * c->d.nr * (1 + c->n + c->d.m) + 2 * c->d.nr);
     hipLaunchKernelGGL(k_cost_derivs, grid, dim3(256), lds, c->stream, c->L, c->d.nr, c->d.T, c->r, c->r_x,
                        c->r_u, c->w_run, c->w_term, c->rec);
     return hipGetLastError();
