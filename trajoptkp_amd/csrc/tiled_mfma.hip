@@ -484,7 +484,8 @@ k_forward_tiled(RecLayout L, int T, int n_alpha, const double *__restrict__ rec,
 
     // per-lane source byte offsets (OOBT = structural zero); p = contraction (state) index, o = output index
     int oKw[4], okw[4], oA[NT][4], oLc[NT][4], oB[4], oLuu[4], olu[4], oub[4];
-    double oneA[NT][4], lo[4], hi[4];
+    double oneT[4], lo[4], hi[4];                    // identity entries of Ya: rows n, n+1 live in row tile tnz only
+    const int tnz = n >> 4;
     const int o = 16 * wi + c;
 #pragma unroll
     for (int k = 0; k < NT; k++)
@@ -492,7 +493,6 @@ k_forward_tiled(RecLayout L, int T, int n_alpha, const double *__restrict__ rec,
         for (int r = 0; r < 4; r++) {
             const int pp = 16 * k + 4 * r + q;
             oA[k][r] = (pp < n && o < n) ? 8 * (L.off_A + o * n + pp) : OOBT;
-            oneA[k][r] = ((pp == n && o == n) || (pp == n + 1 && o == n + 1)) ? 1.0 : 0.0;
             oLc[k][r] = (pp < n && o < n) ? 8 * (L.off_lxx + pp * n + o)
                       : (pp == n + 1 && o < n) ? 8 * (L.off_lx + o)
                       : (o == n + 1 && pp < n) ? 8 * (L.off_lx + pp) : OOBT;
@@ -500,6 +500,8 @@ k_forward_tiled(RecLayout L, int T, int n_alpha, const double *__restrict__ rec,
 #pragma unroll
     for (int r = 0; r < 4; r++) {
         const int row = 4 * r + q;
+        const int pt = 16 * tnz + row;
+        oneT[r] = ((pt == n && o == n) || (pt == n + 1 && o == n + 1)) ? 1.0 : 0.0;
         const int pw = 16 * wi + row;                                   // this wave's slice of the state index
         oKw[r] = (pw < n && c < m) ? 8 * (pw * m + c) : OOBT;
         okw[r] = (pw == n && c < m) ? 8 * c : OOBT;
@@ -605,7 +607,7 @@ k_forward_tiled(RecLayout L, int T, int n_alpha, const double *__restrict__ rec,
 #pragma unroll
         for (int k = 0; k < NT; k++) {
             d4 Ya = cur.Ya[k];
-            Ya.x += oneA[k][0]; Ya.y += oneA[k][1]; Ya.z += oneA[k][2]; Ya.w += oneA[k][3];
+            if (k == tnz) { Ya.x += oneT[0]; Ya.y += oneT[1]; Ya.z += oneT[2]; Ya.w += oneT[3]; }
             Zn = Pk<NT>(k, Ya, Zk[k], Zn, ncl);
         }
         Zn = Pn(cur.Yb, dU, Zn, ncu);
