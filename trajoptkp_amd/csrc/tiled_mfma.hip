@@ -21,6 +21,7 @@ typedef unsigned int u32x2t __attribute__((ext_vector_type(2)));
 #define MFMA(a, b, c) __builtin_amdgcn_mfma_f64_16x16x4f64((a), (b), (c), 0, 0, 0)
 #define OOBT 0x7ffffff0
 #define TILE 256
+#define TPAD 272                                     // 16 x 17: padded row-major tile (transposed reads without bank conflicts)
 
 __device__ __forceinline__ double tbld(__amdgpu_buffer_rsrc_t r, int byte_off)
 {
@@ -155,14 +156,14 @@ k_backward_tiled_col(RecLayout L, int T, const double *__restrict__ rec, const d
     const double lam = lambda[b];
     double *bufV = sh;                               // V' (NT x NT tiles, tile (i,j) at i*NT+j)
     double *bufF = bufV + NZZ * TILE;                // Fz
-    double *bufT = bufF + NZZ * TILE;                // unsymmetrised V' for the transpose
-    double *bufFu = bufT + NZZ * TILE;               // NT
+    double *bufT = bufF + NZZ * TILE;                // unsymmetrised V' for the transpose: row-major tiles, row stride 17
+    double *bufFu = bufT + NZZ * TPAD;               // NT
     double *bufQuz = bufFu + NT * TILE;              // NT
     double *bufX = bufQuz + NT * TILE;               // NT
     double *bufG = bufX + NT * TILE;                 // NT
     double *bufQp = bufG + NT * TILE;                // NT: per-wave partials of Fu'Tu
     double *sQ = bufQp + NT * TILE + w * TILE;       // NT: this wave's image of Quu + lambda I
-    double *sRow = bufQp + 2 * NT * TILE;            // slow-path work area
+    double *sRow = bufT;                             // slow-path work area (phase D: bufT is free between F and E)
     auto nchunk = [&](int kt) { const int rows = nz - 16 * kt; return rows >= 16 ? 4 : (rows + 3) / 4; };
     const int ncl = nchunk(NT - 1);
     const int ncw = (w < NT - 1) ? 4 : ncl;          // chunks of row tile w
@@ -401,13 +402,14 @@ k_backward_tiled_col(RecLayout L, int T, const double *__restrict__ rec, const d
 #pragma unroll
         for (int i = 0; i < NT; i++) {
             Qzz[i] = Pn(lds_tile(bufX + i * TILE, lane), Gw, Qzz[i], NCU);
-            lds_store(bufT + (i * NT + w) * TILE, lane, Qzz[i]);
+            double *pw = bufT + (i * NT + w) * TPAD + q * 17 + c;           // element (4r+q, c) at (4r+q)*17 + c
+            pw[0] = Qzz[i].x; pw[4 * 17] = Qzz[i].y; pw[8 * 17] = Qzz[i].z; pw[12 * 17] = Qzz[i].w;
         }
         __syncthreads();
         // ---- F: V'(i,w) = (acc(i,w) + acc(w,i)')/2   (:610) -----------------------------------------------------
 #pragma unroll
         for (int i = 0; i < NT; i++) {
-            const double *pt = bufT + (w * NT + i) * TILE + (c >> 2) * 64 + (c & 3) * 16 + q;      // (tile (w,i))'
+            const double *pt = bufT + (w * NT + i) * TPAD + c * 17 + q;     // (tile (w,i))': element (c, 4r+q); <= 2-way bank conflicts
             d4 at;
             at.x = pt[0]; at.y = pt[4]; at.z = pt[8]; at.w = pt[12];
             d4 na = 0.5 * (Qzz[i] + at);
@@ -421,7 +423,11 @@ k_backward_tiled_col(RecLayout L, int T, const double *__restrict__ rec, const d
     if (threadIdx.x == 0) status[b] = fail;
 }
 
-size_t backward_col_lds_bytes(int nt) { return sizeof(double) * ((size_t)(3 * nt * nt + 7 * nt) * TILE + 3 * 256 + 64); }
+size_t backward_col_lds_bytes(int nt)
+{
+    const size_t tpad = (size_t)nt * nt * TPAD;     // bufT, which also hosts the slow-path work area (832 doubles)
+    return sizeof(double) * ((size_t)(2 * nt * nt + 7 * nt) * TILE + (tpad > 832 ? tpad : 832));
+}
 
 size_t backward_tiled_lds_bytes(int nt) { return backward_col_lds_bytes(nt); }
 
