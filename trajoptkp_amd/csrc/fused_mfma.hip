@@ -60,13 +60,6 @@ __device__ __forceinline__ __amdgpu_buffer_rsrc_t frsrc(const void *p, int bytes
 {
     return __builtin_amdgcn_make_buffer_rsrc((void *)p, 0, bytes, 0x00020000);
 }
-__device__ __forceinline__ double frcp(double x)
-{
-    double r = __builtin_amdgcn_rcp(x);
-    r = __builtin_fma(__builtin_fma(-x, r, 1.0), r, r);
-    r = __builtin_fma(__builtin_fma(-x, r, 1.0), r, r);
-    return r;
-}
 // correctly rounded a/den for a normal-range quotient: one residual correction on top of a ~1 ulp reciprocal
 // (the hardware division expansion without its scaling / fix-up tail; den is a small positive integer)
 __device__ __forceinline__ double fdiv(double a, double den, double rinv)
@@ -214,7 +207,7 @@ __device__ __forceinline__ void backward_fused_body(RecLayout L, FusedArgs F, in
         // ---- a4: this step's A and B columns --------------------------------------------------------------
         if (t < s) {                                   // per lane: crossed the start of the current segment
             const double den = (double)(s - nb);
-            const double rinv = frcp(den);
+            const double rinv = kp_rcp(den);
 #pragma unroll
             for (int i = 0; i < 8; i++) {
                 const double ev = sv[i];
@@ -310,55 +303,23 @@ __device__ __forceinline__ void backward_fused_body(RecLayout L, FusedArgs F, in
             if (NCU > 3) sh[FLDS_Z + c * FMZ + 12 + q] = Quz.w;
             __syncthreads();
             // ---- unpivoted LDL' of Quu + lambda I, redundantly in every lane ----
-            double Lm[M][M], dd[M], rd[M];
-            bool pos = true;
-#pragma unroll
-            for (int j = 0; j < M; j++) {
-                double w[M];
-                double dj = sh[FLDS_Q + j * FMS + j];
-#pragma unroll
-                for (int kk = 0; kk < j; kk++) { w[kk] = Lm[j][kk] * dd[kk]; dj -= Lm[j][kk] * w[kk]; }
-                dd[j] = dj;
-                pos = pos && (dj > 0.0);
-                const double rj = frcp(dj);
-                rd[j] = rj;
-#pragma unroll
-                for (int i = j + 1; i < M; i++) {
-                    double v = sh[FLDS_Q + i * FMS + j];
-#pragma unroll
-                    for (int kk = 0; kk < j; kk++) v -= Lm[i][kk] * w[kk];
-                    Lm[i][j] = v * rj;
-                }
-            }
+            double Lm[M][M], rd[M];
+            const bool pos = kp_ldl_factor<M>([&](int i, int j) { return sh[FLDS_Q + i * FMS + j]; }, Lm, rd);
             if (check_pd) {                       // CheckMatrixPD every pd_stride steps   :587-595
                 if (!pos) { fail = t + 1; break; }
                 pd_counter = 0;
             }
             double x[M];
-            auto ldl_solve = [&](double *v) {
-#pragma unroll
-                for (int j = 0; j < M; j++) {
-#pragma unroll
-                    for (int i = j + 1; i < M; i++) v[i] -= Lm[i][j] * v[j];
-                }
-#pragma unroll
-                for (int i = 0; i < M; i++) v[i] *= rd[i];
-#pragma unroll
-                for (int j = M - 1; j >= 0; j--) {
-#pragma unroll
-                    for (int i = 0; i < j; i++) v[i] -= Lm[j][i] * v[j];
-                }
-            };
             if (pos) {
 #pragma unroll
                 for (int i = 0; i < M; i++) x[i] = sh[FLDS_Z + c * FMZ + i];
-                ldl_solve(x);
+                kp_ldl_solve<M>(Lm, rd, x);
 #if KP_NS
                 // seed the fast path: column c of the inverse in lane c (c < m), as a tile
                 double y[M];
 #pragma unroll
                 for (int i = 0; i < M; i++) y[i] = (i == c) ? 1.0 : 0.0;
-                ldl_solve(y);
+                kp_ldl_solve<M>(Lm, rd, y);
                 double yr[4] = {0.0, 0.0, 0.0, 0.0};
 #pragma unroll
                 for (int i = 0; i < M; i++)
@@ -510,7 +471,7 @@ struct DownTracker {
     {
         if (t < s) {                                 // per lane: crossed the start of the current segment
             const double den = (double)(s - nb);
-            const double rinv = frcp(den);
+            const double rinv = kp_rcp(den);
 #pragma unroll
             for (int i = 0; i < NV; i++) {
                 const double ev = sv[i];
@@ -618,26 +579,8 @@ __device__ __forceinline__ void fused2_role_U(double *sh, RecLayout L, FusedArgs
         if (NCU > 2) sh[F2_Q + (8 + q) * 16 + c] = Quu.z + 0.5 * lam2d[2];
         if (NCU > 3) sh[F2_Q + (12 + q) * 16 + c] = Quu.w + 0.5 * lam2d[3];
         // (same-wave LDS accesses execute in order: no barrier between these stores and the reads below)
-        double Lm[M][M], dd[M], rd[M];
-        bool pos = true;
-#pragma unroll
-        for (int j = 0; j < M; j++) {
-            double w[M];
-            double dj = sh[F2_Q + j * 16 + j];
-#pragma unroll
-            for (int kk = 0; kk < j; kk++) { w[kk] = Lm[j][kk] * dd[kk]; dj -= Lm[j][kk] * w[kk]; }
-            dd[j] = dj;
-            pos = pos && (dj > 0.0);
-            const double rj = frcp(dj);
-            rd[j] = rj;
-#pragma unroll
-            for (int i = j + 1; i < M; i++) {
-                double v = sh[F2_Q + i * 16 + j];
-#pragma unroll
-                for (int kk = 0; kk < j; kk++) v -= Lm[i][kk] * w[kk];
-                Lm[i][j] = v * rj;
-            }
-        }
+        double Lm[M][M], rd[M];
+        const bool pos = kp_ldl_factor<M>([&](int i, int j) { return sh[F2_Q + i * 16 + j]; }, Lm, rd);
         if (check_pd && !pos && lane == 0) sflag[0] = t + 1;                 // CheckMatrixPD   :587-595
         __syncthreads();
         if (sflag[0]) { fail = sflag[0]; break; }
@@ -646,18 +589,7 @@ __device__ __forceinline__ void fused2_role_U(double *sh, RecLayout L, FusedArgs
         if (pos) {
 #pragma unroll
             for (int i = 0; i < M; i++) x[i] = sh[F2_Z + c * 17 + i];
-#pragma unroll
-            for (int j = 0; j < M; j++) {
-#pragma unroll
-                for (int i = j + 1; i < M; i++) x[i] -= Lm[i][j] * x[j];
-            }
-#pragma unroll
-            for (int i = 0; i < M; i++) x[i] *= rd[i];
-#pragma unroll
-            for (int j = M - 1; j >= 0; j--) {
-#pragma unroll
-                for (int i = 0; i < j; i++) x[i] -= Lm[j][i] * x[j];
-            }
+            kp_ldl_solve<M>(Lm, rd, x);
         } else {
             // indefinite on an unchecked step: Eigen's pivoted LDLT + explicit inverse (iLQR.cpp:597-604)
             double *wa = sh + F2_SLOW, *wx = wa + 256, *wt = wx + 256;
@@ -958,7 +890,7 @@ __device__ __forceinline__ void forward_fused_body(RecLayout L, FusedArgs F, int
     auto advance = [&](int t) {
         if (pend) {                           // slope of the segment entered one step ago (its end column has landed)
             const double den = (double)(e - s);
-            const double rinv = frcp(den);
+            const double rinv = kp_rcp(den);
 #pragma unroll
             for (int i = 0; i < 8; i++) av[i] = (e != BIGT) ? fdiv(ev[i] - sv[i], den, rinv) : 0.0;
             pend = false;

@@ -32,6 +32,52 @@ __device__ __forceinline__ double kp_rcp(double x)
     return r;
 }
 
+// Unpivoted LDL' of an m x m SPD matrix, done redundantly by every lane from a broadcast image (`qel(i,j)` returns
+// element (i,j)): L (unit lower, strictly lower part stored) and the reciprocals of D.  Returns false when a pivot is
+// not positive -- the callers then report the PD failure (checked steps) or take the pivoted slow path.
+template <int M, class QEl>
+__device__ __forceinline__ bool kp_ldl_factor(QEl qel, double (&Lm)[M][M], double (&rd)[M])
+{
+    double dd[M];
+    bool pos = true;
+#pragma unroll
+    for (int j = 0; j < M; j++) {
+        double w[M];
+        double dj = qel(j, j);
+#pragma unroll
+        for (int kk = 0; kk < j; kk++) { w[kk] = Lm[j][kk] * dd[kk]; dj -= Lm[j][kk] * w[kk]; }
+        dd[j] = dj;
+        pos = pos && (dj > 0.0);
+        const double rj = kp_rcp(dj);
+        rd[j] = rj;
+#pragma unroll
+        for (int i = j + 1; i < M; i++) {
+            double v = qel(i, j);
+#pragma unroll
+            for (int kk = 0; kk < j; kk++) v -= Lm[i][kk] * w[kk];
+            Lm[i][j] = v * rj;
+        }
+    }
+    return pos;
+}
+// x <- (L D L')^-1 x
+template <int M>
+__device__ __forceinline__ void kp_ldl_solve(const double (&Lm)[M][M], const double (&rd)[M], double (&x)[M])
+{
+#pragma unroll
+    for (int j = 0; j < M; j++) {            // L y = z
+#pragma unroll
+        for (int i = j + 1; i < M; i++) x[i] -= Lm[i][j] * x[j];
+    }
+#pragma unroll
+    for (int i = 0; i < M; i++) x[i] *= rd[i];   // D
+#pragma unroll
+    for (int j = M - 1; j >= 0; j--) {       // L' x = y
+#pragma unroll
+        for (int i = 0; i < j; i++) x[i] -= Lm[j][i] * x[j];
+    }
+}
+
 // Eigen's LDLT (symmetric pivoting, in place on the lower triangle) followed by solve(Identity), restated line
 // for line as the reference uses it when Q_uu + lambda I is not PD on an unchecked step
 // (src/Optimiser/iLQR.cpp:597-604); identical to generic.hip's dev_ldlt_inverse and oracle/orc_ldlt_inverse.

@@ -57,16 +57,6 @@ __device__ __forceinline__ double bld(__amdgpu_buffer_rsrc_t r, int byte_off)
     return __builtin_bit_cast(double, __builtin_amdgcn_raw_buffer_load_b64(r, byte_off, 0, 0));
 }
 
-// 1/x to ~1 ulp: v_rcp_f64 seed + two Newton steps (the pivots are O(lambda)..O(1): no scaling needed;
-// a non-positive or non-finite pivot is caught by the `pos` test and takes the slow path).
-__device__ __forceinline__ double fast_rcp(double x)
-{
-    double r = __builtin_amdgcn_rcp(x);
-    r = __builtin_fma(__builtin_fma(-x, r, 1.0), r, r);
-    r = __builtin_fma(__builtin_fma(-x, r, 1.0), r, r);
-    return r;
-}
-
 // Pull one whole step record into this XCD's L2 a few steps before its tile loads are issued: one
 // LDS-DMA dword per 64-byte sector (the data lands in a scratch LDS row nobody reads).  It costs no
 // VGPR, and it takes the page-table walk and the HBM fetch of that record off the critical path --
@@ -247,55 +237,23 @@ __device__ __forceinline__ void backward_body(RecLayout L, int T, const double *
             if (NCU > 3) sh[LDS_Z + c * MZ + 12 + q] = Quz.w;
             __syncthreads();
             // ---- unpivoted LDL' of Quu + lambda I, redundantly in every lane (lower triangle) ----
-            double Lm[M][M], dd[M], rd[M];
-            bool pos = true;
-#pragma unroll
-            for (int j = 0; j < M; j++) {
-                double w[M];
-                double dj = sh[LDS_Q + j * MS + j];
-#pragma unroll
-                for (int kk = 0; kk < j; kk++) { w[kk] = Lm[j][kk] * dd[kk]; dj -= Lm[j][kk] * w[kk]; }
-                dd[j] = dj;
-                pos = pos && (dj > 0.0);
-                const double rj = fast_rcp(dj);
-                rd[j] = rj;
-#pragma unroll
-                for (int i = j + 1; i < M; i++) {
-                    double v = sh[LDS_Q + i * MS + j];
-#pragma unroll
-                    for (int kk = 0; kk < j; kk++) v -= Lm[i][kk] * w[kk];
-                    Lm[i][j] = v * rj;
-                }
-            }
+            double Lm[M][M], rd[M];
+            const bool pos = kp_ldl_factor<M>([&](int i, int j) { return sh[LDS_Q + i * MS + j]; }, Lm, rd);
             if (check_pd) {                       // CheckMatrixPD every pd_stride steps   :587-595
                 if (!pos) { fail = t + 1; break; }
                 pd_counter = 0;
             }
-            auto ldl_solve = [&](double *v) {
-#pragma unroll
-                for (int j = 0; j < M; j++) {            // L y = z
-#pragma unroll
-                    for (int i = j + 1; i < M; i++) v[i] -= Lm[i][j] * v[j];
-                }
-#pragma unroll
-                for (int i = 0; i < M; i++) v[i] *= rd[i];   // D
-#pragma unroll
-                for (int j = M - 1; j >= 0; j--) {       // L' x = y
-#pragma unroll
-                    for (int i = 0; i < j; i++) v[i] -= Lm[j][i] * v[j];
-                }
-            };
             // ---- every lane solves (Quu + lambda I) x = Quz[:, c] for its own column c --------------
             double x[M];
             if (pos) {
 #pragma unroll
                 for (int i = 0; i < M; i++) x[i] = sh[LDS_Z + c * MZ + i];
-                ldl_solve(x);
+                kp_ldl_solve<M>(Lm, rd, x);
                 // seed the fast path: column c of the inverse in lane c (c < m), as a tile
                 double y[M];
 #pragma unroll
                 for (int i = 0; i < M; i++) y[i] = (i == c) ? 1.0 : 0.0;
-                ldl_solve(y);
+                kp_ldl_solve<M>(Lm, rd, y);
                 double yr[4] = {0.0, 0.0, 0.0, 0.0};
 #pragma unroll
                 for (int i = 0; i < M; i++)

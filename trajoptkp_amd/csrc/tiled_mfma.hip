@@ -57,13 +57,6 @@ __device__ __forceinline__ d4 Pk(int k, const d4 &Y, const d4 &X, d4 acc, int nc
     }
     return Pn(Y, X, acc, ncl);
 }
-__device__ __forceinline__ double trcp(double x)
-{
-    double r = __builtin_amdgcn_rcp(x);
-    r = __builtin_fma(__builtin_fma(-x, r, 1.0), r, r);
-    r = __builtin_fma(__builtin_fma(-x, r, 1.0), r, r);
-    return r;
-}
 
 // ---------------------------------------------------------------------------------------------
 // Backward pass.  z = [dx; 1] has nz = n+1 entries covered by NT row tiles.
@@ -293,26 +286,8 @@ k_backward_tiled_col(RecLayout L, int T, const double *__restrict__ rec, const d
         if (!done) {
             lds_store(sQ, lane, Qr);                  // this wave's private image (same-wave LDS accesses are ordered)
             auto qel = [&](int i, int j) { return sQ[(i >> 2) * 64 + j + 16 * (i & 3)]; };
-            double Lm[M][M], dd[M], rd[M];
-            bool pos = true;
-#pragma unroll
-            for (int j = 0; j < M; j++) {
-                double ww[M];
-                double dj = qel(j, j);
-#pragma unroll
-                for (int kk = 0; kk < j; kk++) { ww[kk] = Lm[j][kk] * dd[kk]; dj -= Lm[j][kk] * ww[kk]; }
-                dd[j] = dj;
-                pos = pos && (dj > 0.0);
-                const double rj = trcp(dj);
-                rd[j] = rj;
-#pragma unroll
-                for (int i = j + 1; i < M; i++) {
-                    double v = qel(i, j);
-#pragma unroll
-                    for (int kk = 0; kk < j; kk++) v -= Lm[i][kk] * ww[kk];
-                    Lm[i][j] = v * rj;
-                }
-            }
+            double Lm[M][M], rd[M];
+            const bool pos = kp_ldl_factor<M>([&](int i, int j) { return qel(i, j); }, Lm, rd);
             if (check_pd) {                       // CheckMatrixPD every pd_stride steps   :587-595
                 if (!pos) { fail = t + 1; break; }
                 pd_counter = 0;
@@ -325,30 +300,16 @@ k_backward_tiled_col(RecLayout L, int T, const double *__restrict__ rec, const d
                 }
                 __syncthreads();
             }
-            auto ldl_solve = [&](double *v) {
-#pragma unroll
-                for (int jj = 0; jj < M; jj++) {
-#pragma unroll
-                    for (int i = jj + 1; i < M; i++) v[i] -= Lm[i][jj] * v[jj];
-                }
-#pragma unroll
-                for (int i = 0; i < M; i++) v[i] *= rd[i];
-#pragma unroll
-                for (int jj = M - 1; jj >= 0; jj--) {
-#pragma unroll
-                    for (int i = 0; i < jj; i++) v[i] -= Lm[jj][i] * v[jj];
-                }
-            };
             const double *zt = bufQuz + w * TILE;
             double x[M];
 #pragma unroll
             for (int i = 0; i < M; i++) x[i] = zt[(i >> 2) * 64 + c + 16 * (i & 3)];
             if (pos) {
-                ldl_solve(x);
+                kp_ldl_solve<M>(Lm, rd, x);
                 double y[M];                          // seed the fast path: column c of the inverse in lane c (c < m)
 #pragma unroll
                 for (int i = 0; i < M; i++) y[i] = (i == c) ? 1.0 : 0.0;
-                ldl_solve(y);
+                kp_ldl_solve<M>(Lm, rd, y);
                 double yr[4] = {0.0, 0.0, 0.0, 0.0};
 #pragma unroll
                 for (int i = 0; i < M; i++)
