@@ -266,30 +266,9 @@ __device__ __forceinline__ void backward_fused_body(RecLayout L, FusedArgs F, in
         d4 Xp = zero;
         bool done = false;
 #if KP_NS
-        if (haveX && !check_pd) {
-            d4 R = Iu - PS<NCU>(Qr, Xinv, zero);       // I - Q Xinv  (Q symmetric up to rounding: Q'X = QX)
-            double rmax = fabs(R.x);
-            if (NCU > 1) rmax = fmax(rmax, fabs(R.y));
-            if (NCU > 2) rmax = fmax(rmax, fabs(R.z));
-            if (NCU > 3) rmax = fmax(rmax, fabs(R.w));
-            // rows of R sum at most m entries: ||R||_inf <= m * max|R_ij|; thresholds on the entry bound e = m*rmax
-            const double e = (double)m * rmax;
-            const bool too_big = __builtin_amdgcn_ballot_w64(!(e < 0.11)) != 0;
-            if (!too_big) {
-                const int iters = (__builtin_amdgcn_ballot_w64(e >= 1.3e-2) != 0) ? 4
-                                : (__builtin_amdgcn_ballot_w64(e >= 1.7e-4) != 0) ? 3
-                                : (__builtin_amdgcn_ballot_w64(e >= 3.0e-8) != 0) ? 2 : 1;
-                Xinv = PS<NCU>(Xinv, R, Xinv);                             // Xinv + Xinv'R  (Xinv symmetric)
-                if (iters > 1) {
-                    R = Iu - PS<NCU>(Qr, Xinv, zero); Xinv = PS<NCU>(Xinv, R, Xinv);
-                    if (iters > 2) {
-                        R = Iu - PS<NCU>(Qr, Xinv, zero); Xinv = PS<NCU>(Xinv, R, Xinv);
-                        if (iters > 3) { R = Iu - PS<NCU>(Qr, Xinv, zero); Xinv = PS<NCU>(Xinv, R, Xinv); }
-                    }
-                }
-                Xp = PS<NCU>(Xinv, Quz, zero);                             // Xinv' Quz = (Quu + lambda I)^-1 Quz
-                done = true;
-            }
+        if (haveX && !check_pd && kp_inverse_refresh<NCU>(Qr, Iu, Xinv, m)) {
+            Xp = PS<NCU>(Xinv, Quz, zero);                                 // Xinv' Quz = (Quu + lambda I)^-1 Quz
+            done = true;
         }
 #endif
         if (!done) {

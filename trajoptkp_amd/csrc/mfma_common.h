@@ -32,6 +32,48 @@ __device__ __forceinline__ double kp_rcp(double x)
     return r;
 }
 
+// acc + Y'X over NC 4-row chunks: the one primitive of these kernels (tiles in the accumulator layout are their own
+// transpose as the A operand and the next B operand as they are).
+template <int NC>
+__device__ __forceinline__ d4 kp_P(const d4 &Y, const d4 &X, d4 acc)
+{
+    acc = KP_MFMA(Y.x, X.x, acc);
+    if (NC > 1) acc = KP_MFMA(Y.y, X.y, acc);
+    if (NC > 2) acc = KP_MFMA(Y.z, X.z, acc);
+    if (NC > 3) acc = KP_MFMA(Y.w, X.w, acc);
+    return acc;
+}
+
+// Running inverse of Q = Quu + lambda I (m x m, rows/cols < 4*NCU of a tile): Newton-Schulz steps
+// Xinv <- Xinv + Xinv (I - Q Xinv) on the matrix core, 4 MFMAs each, quadratic convergence.  The number of steps is
+// chosen from the measured residual so that the last one ends below 1e-15 (bound on the row sums of |I - Q Xinv|:
+// m * max entry).  Returns false, leaving Xinv untouched, when the residual is too large to converge in four
+// steps (the caller then factorises).  Q and Xinv are symmetric up to rounding, so Q'X = QX and X'R = XR.
+template <int NCU>
+__device__ __forceinline__ bool kp_inverse_refresh(const d4 &Qr, const d4 &Iu, d4 &Xinv, int m)
+{
+    const d4 zero = {0.0, 0.0, 0.0, 0.0};
+    d4 R = Iu - kp_P<NCU>(Qr, Xinv, zero);
+    double rmax = fabs(R.x);
+    if (NCU > 1) rmax = fmax(rmax, fabs(R.y));
+    if (NCU > 2) rmax = fmax(rmax, fabs(R.z));
+    if (NCU > 3) rmax = fmax(rmax, fabs(R.w));
+    const double e = (double)m * rmax;
+    if (__builtin_amdgcn_ballot_w64(!(e < 0.11)) != 0) return false;
+    const int iters = (__builtin_amdgcn_ballot_w64(e >= 1.3e-2) != 0) ? 4
+                    : (__builtin_amdgcn_ballot_w64(e >= 1.7e-4) != 0) ? 3
+                    : (__builtin_amdgcn_ballot_w64(e >= 3.0e-8) != 0) ? 2 : 1;
+    Xinv = kp_P<NCU>(Xinv, R, Xinv);
+    if (iters > 1) {
+        R = Iu - kp_P<NCU>(Qr, Xinv, zero); Xinv = kp_P<NCU>(Xinv, R, Xinv);
+        if (iters > 2) {
+            R = Iu - kp_P<NCU>(Qr, Xinv, zero); Xinv = kp_P<NCU>(Xinv, R, Xinv);
+            if (iters > 3) { R = Iu - kp_P<NCU>(Qr, Xinv, zero); Xinv = kp_P<NCU>(Xinv, R, Xinv); }
+        }
+    }
+    return true;
+}
+
 // Unpivoted LDL' of an m x m SPD matrix, done redundantly by every lane from a broadcast image (`qel(i,j)` returns
 // element (i,j)): L (unit lower, strictly lower part stored) and the reciprocals of D.  Returns false when a pivot is
 // not positive -- the callers then report the PD failure (checked steps) or take the pivoted slow path.

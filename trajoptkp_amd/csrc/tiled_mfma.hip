@@ -262,26 +262,9 @@ k_backward_tiled_col(RecLayout L, int T, const double *__restrict__ rec, const d
         // residual is too large to converge fast.
         d4 X = zero;
         bool done = false;
-        if (haveX && !check_pd) {
-            d4 R = Iu - Pn(Qr, Xinv, zero, NCU);
-            double rmax = fmax(fmax(fabs(R.x), fabs(R.y)), fmax(fabs(R.z), fabs(R.w)));
-            const double e = (double)m * rmax;
-            const bool too_big = __builtin_amdgcn_ballot_w64(!(e < 0.11)) != 0;
-            if (!too_big) {
-                const int iters = (__builtin_amdgcn_ballot_w64(e >= 1.3e-2) != 0) ? 4
-                                : (__builtin_amdgcn_ballot_w64(e >= 1.7e-4) != 0) ? 3
-                                : (__builtin_amdgcn_ballot_w64(e >= 3.0e-8) != 0) ? 2 : 1;
-                Xinv = Pn(Xinv, R, Xinv, NCU);
-                if (iters > 1) {
-                    R = Iu - Pn(Qr, Xinv, zero, NCU); Xinv = Pn(Xinv, R, Xinv, NCU);
-                    if (iters > 2) {
-                        R = Iu - Pn(Qr, Xinv, zero, NCU); Xinv = Pn(Xinv, R, Xinv, NCU);
-                        if (iters > 3) { R = Iu - Pn(Qr, Xinv, zero, NCU); Xinv = Pn(Xinv, R, Xinv, NCU); }
-                    }
-                }
-                X = Pn(Xinv, Quzw, zero, NCU);
-                done = true;
-            }
+        if (haveX && !check_pd && kp_inverse_refresh<NCU>(Qr, Iu, Xinv, m)) {
+            X = Pn(Xinv, Quzw, zero, NCU);
+            done = true;
         }
         if (!done) {
             lds_store(sQ, lane, Qr);                  // this wave's private image (same-wave LDS accesses are ordered)
