@@ -55,7 +55,7 @@ typedef struct {
                                            (kpilqr_interpolate / kpilqr_cost_derivs still do that on request, and the
                                            set_AB / set_cost_derivs hooks do not feed the fused sweeps).  Needs
                                            canonical key-points: per DoF strictly increasing, first 0, last T-1.
-                                           Pays off from ~512 trajectories per GPU (Panda: 84k vs 67k iterations/s at
+                                           Pays off from ~400 trajectories per GPU (Panda: 100k vs 68k iterations/s at
                                            batch 1024); below that the materialising pipeline is faster. */
 
 enum {
