@@ -531,7 +531,7 @@ k_forward_tiled(RecLayout L, int T, int n_alpha, const double *__restrict__ rec,
             u = U.z; if (u > hi[2]) u = hi[2]; if (u < lo[2]) u = lo[2]; U.z = u; dU.z = u - ub.z;
             u = U.w; if (u > hi[3]) u = hi[3]; if (u < lo[3]) u = lo[3]; U.w = u; dU.w = u - ub.w;
         }
-        if (wi == 0) {
+        if (wi == NT - 1) {                        // control cost and U_alpha by the LAST wave (its row tile is the shortest)
             if (U_alpha && c < n_alpha) {
                 double *Ua = U_alpha + (((size_t)b * n_alpha + c) * T + t) * m;
                 const double uv[4] = {U.x, U.y, U.z, U.w};
