@@ -642,10 +642,13 @@ def test_c_abi_linesearch_allreduce_single_rank():
         assert np.allclose(kd.pack_linesearch(cost, dJ, st).numpy(), v0, rtol=1e-13)
 
 
-def test_fused_two_wave_backward_variant(monkeypatch):
-    """KPILQR_FUSED_WAVES=2: the control-side / state-side two-wave split of the fused backward pass (kept as a
-    measured alternative) computes the same gains."""
-    monkeypatch.setenv("KPILQR_FUSED_WAVES", "2")
+@pytest.mark.parametrize("waves", ["2", "3"])
+def test_fused_two_wave_backward_variant(monkeypatch, waves):
+    """KPILQR_FUSED_WAVES=2: the control-side / state-side two-wave split of the fused backward pass; =3: the
+    producer / consumer wave pair.  Both compute the same gains as the one-wave kernel."""
+    monkeypatch.setenv("KPILQR_FUSED_WAVES", waves)
+    if waves == "3":
+        monkeypatch.setenv("KPILQR_ROLE_SHIFT", "0")             # alternate the roles with the block index
     for kw in (PROBLEMS["panda_T64"], PROBLEMS["acrobot_T100"], dict(task="panda_reaching", T=301, batch=3, min_N=4)):
         p = synth.make_problem(**kw)
         check_fused(run_fused(p), p)

@@ -118,16 +118,23 @@ __device__ __forceinline__ void load_col(__amdgpu_buffer_rsrc_t rT, const ColOff
 
 template <int R> __device__ __forceinline__ void fset_reg(d4 &v, double x) { if (R == 0) v.x = x; else if (R == 1) v.y = x; else if (R == 2) v.z = x; else v.w = x; }
 
-template <int N, int M>
-__device__ __forceinline__ void backward_fused_body(RecLayout L, FusedArgs F, int T, const double *__restrict__ rec,
+// PC = false: one wavefront per trajectory does everything.  PC = true: this is the CONSUMER wave of a two-wave block; the
+// step's tiles Fz, Fu, Lzz, [l_uu | l_u] come from the LDS ring filled by the producer wave (fusedpc_producer below), LDS
+// hand-offs inside the step are wave-local, and the only block barrier is the one that ends a step.
+#define FPC_TILES 4
+#define FPC_BUF (FPC_TILES * 256)
+__device__ __forceinline__ d4 lds_tile4(const double *t, int lane);
+template <int N, int M, bool PC>
+__device__ __forceinline__ void backward_fused_body(double *sh, const double *pcbuf, int *sflag, RecLayout L, FusedArgs F, int T,
+                const double *__restrict__ rec,
                 const double *__restrict__ lambda, int pd_stride, double *__restrict__ Kout, double *__restrict__ kout,
                 double *__restrict__ delta_J, int *__restrict__ status)
 {
     constexpr int NCZ = (N + 1 + 3) / 4;
     constexpr int NCU = (M + 3) / 4;
     constexpr int n = N, m = M;
-    __shared__ __attribute__((aligned(16))) double sh[FLDS_TOTAL];
-    const int lane = threadIdx.x, c = lane & 15, q = lane >> 4;
+    auto wsync = [&]() { if (PC) __builtin_amdgcn_wave_barrier(); else __syncthreads(); };
+    const int lane = threadIdx.x & 63, c = lane & 15, q = lane >> 4;
     const int b = blockIdx.x;
     const double lam = lambda[b];
     const int nr = F.nr, ncr = (nr + 3) >> 2;
@@ -172,7 +179,7 @@ __device__ __forceinline__ void backward_fused_body(RecLayout L, FusedArgs F, in
 
     // ---- column tracker, walking DOWN in time ----------------------------------------------------------
     const int kd = (c < F.dof) ? c : c - F.dof;
-    const bool has = c < n;
+    const bool has = !PC && c < n;
     const int lo = has ? F.kp_offsets[(size_t)b * F.dof + kd] : 0;
     const int hi = has ? F.kp_offsets[(size_t)b * F.dof + kd + 1] : 0;
     int idx = hi - 1;
@@ -180,18 +187,21 @@ __device__ __forceinline__ void backward_fused_body(RecLayout L, FusedArgs F, in
     int nb = (has && idx - 1 >= lo) ? F.kp_times[idx - 1] : -1;
     int nb2 = (has && idx - 2 >= lo) ? F.kp_times[idx - 2] : -1;
     double sv[8], av[8], pv[8];
-    load_col(rT, co, s, T, strideB, sv);
-    load_col(rT, co, nb, T, strideB, pv);
-#pragma unroll
-    for (int i = 0; i < 8; i++) av[i] = 0.0;
-    // Fz(n,n) = 1: lane c == n walks no list (never crosses), so its constant start value carries the 1
-#pragma unroll
-    for (int r = 0; r < 4; r++) if (c == n && 4 * r + q == n) sv[r] = 1.0;
-
-    // single-buffered: the residual tiles are consumed by the first MFMAs of a step and re-requested for the
-    // next step right behind them (a whole step of latency cover, no register copies)
     ResTiles cur;
-    load_res(T - 1, cur);
+    if constexpr (!PC) {
+        load_col(rT, co, s, T, strideB, sv);
+        load_col(rT, co, nb, T, strideB, pv);
+#pragma unroll
+        for (int i = 0; i < 8; i++) av[i] = 0.0;
+        // Fz(n,n) = 1: lane c == n walks no list (never crosses), so its constant start value carries the 1
+#pragma unroll
+        for (int r = 0; r < 4; r++) if (c == n && 4 * r + q == n) sv[r] = 1.0;
+        // single-buffered: the residual tiles are consumed by the first MFMAs of a step and re-requested for the
+        // next step right behind them (a whole step of latency cover, no register copies)
+        load_res(T - 1, cur);
+    } else {
+        __syncthreads();                               // the producer has published step T-1
+    }
     const d4 zero = {0.0, 0.0, 0.0, 0.0};
     d4 V = zero;
     d4 W2 = {w2term[0], w2term[1], w2term[2], w2term[3]};     // terminal weights at t = T-1, running after
@@ -204,6 +214,13 @@ __device__ __forceinline__ void backward_fused_body(RecLayout L, FusedArgs F, in
     (void)haveX; (void)Iu;
 
     for (int t = T - 1; t >= 0; t--) {
+        d4 Fz, Fu, Lzz, LU;
+        const bool term = (t == T - 1);
+        if constexpr (PC) {
+            const double *tb = pcbuf + (t & 1) * FPC_BUF;
+            Fz = lds_tile4(tb, lane); Fu = lds_tile4(tb + 256, lane);
+            Lzz = lds_tile4(tb + 512, lane); LU = lds_tile4(tb + 768, lane);
+        } else {
         // ---- a4: this step's A and B columns --------------------------------------------------------------
         if (t < s) {                                   // per lane: crossed the start of the current segment
             const double den = (double)(s - nb);
@@ -220,23 +237,22 @@ __device__ __forceinline__ void backward_fused_body(RecLayout L, FusedArgs F, in
             load_col(rT, co, nb, T, strideB, pv);
         }
         const double dt = (double)(t - s);
-        d4 Fz, Fu;
         Fz.x = lerp_nc(sv[0], dt, av[0]); Fz.y = lerp_nc(sv[1], dt, av[1]);
         Fz.z = lerp_nc(sv[2], dt, av[2]); Fz.w = lerp_nc(sv[3], dt, av[3]);
         Fu.x = lerp_nc(sv[4], dt, av[4]); Fu.y = lerp_nc(sv[5], dt, av[5]);
         Fu.z = lerp_nc(sv[6], dt, av[6]); Fu.w = lerp_nc(sv[7], dt, av[7]);
         // ---- a6: Lzz, l_uu, l_u from the residuals --------------------------------------------------------
-        const bool term = (t == T - 1);
         d4 Rz, Rur;
         Rz.x = bits_or(cur.Rx.x, cur.R1.x); Rz.y = bits_or(cur.Rx.y, cur.R1.y);
         Rz.z = bits_or(cur.Rx.z, cur.R1.z); Rz.w = bits_or(cur.Rx.w, cur.R1.w);
         Rur.x = bits_or(cur.Ru.x, cur.R1.x); Rur.y = bits_or(cur.Ru.y, cur.R1.y);
         Rur.z = bits_or(cur.Ru.z, cur.R1.z); Rur.w = bits_or(cur.Ru.w, cur.R1.w);
-        const d4 Lzz = PR(Rz, Rz * W2, zero, ncr);
-        const d4 LU = PR(cur.Ru, Rur * W2, zero, ncr);
+        Lzz = PR(Rz, Rz * W2, zero, ncr);
+        LU = PR(cur.Ru, Rur * W2, zero, ncr);
         __builtin_amdgcn_sched_barrier(0);
         if (t > 0) load_res(t - 1, cur);
         __builtin_amdgcn_sched_barrier(0);
+        }
         d4 Luu, Luz;
         Luu.x = bits_and(LU.x, mask_u); Luu.y = bits_and(LU.y, mask_u); Luu.z = bits_and(LU.z, mask_u); Luu.w = bits_and(LU.w, mask_u);
         Luz.x = bits_and(LU.x, mask_n); Luz.y = bits_and(LU.y, mask_n); Luz.z = bits_and(LU.z, mask_n); Luz.w = bits_and(LU.w, mask_n);
@@ -280,12 +296,16 @@ __device__ __forceinline__ void backward_fused_body(RecLayout L, FusedArgs F, in
             if (NCU > 1) sh[FLDS_Z + c * FMZ + 4 + q] = Quz.y;
             if (NCU > 2) sh[FLDS_Z + c * FMZ + 8 + q] = Quz.z;
             if (NCU > 3) sh[FLDS_Z + c * FMZ + 12 + q] = Quz.w;
-            __syncthreads();
+            wsync();
             // ---- unpivoted LDL' of Quu + lambda I, redundantly in every lane ----
             double Lm[M][M], rd[M];
             const bool pos = kp_ldl_factor<M>([&](int i, int j) { return sh[FLDS_Q + i * FMS + j]; }, Lm, rd);
             if (check_pd) {                       // CheckMatrixPD every pd_stride steps   :587-595
-                if (!pos) { fail = t + 1; break; }
+                if (!pos) {
+                    fail = t + 1;
+                    if (PC) { if (lane == 0) sflag[0] = fail; __syncthreads(); }      // the producer leaves with us
+                    break;
+                }
                 pd_counter = 0;
             }
             double x[M];
@@ -310,7 +330,7 @@ __device__ __forceinline__ void backward_fused_body(RecLayout L, FusedArgs F, in
                 double *wa = sh + FLDS_SLOW, *wx = wa + 256, *wt = wx + 256;
                 int *tr = (int *)(wt + 16);
                 if (lane == 0) kp_slow_ldlt_inverse(L.m, sh + FLDS_Q, FMS, wa, wx, wt, tr);
-                __syncthreads();
+                wsync();
 #pragma unroll
                 for (int i = 0; i < M; i++) {
                     double sacc = 0.0;
@@ -318,7 +338,7 @@ __device__ __forceinline__ void backward_fused_body(RecLayout L, FusedArgs F, in
                     for (int p = 0; p < M; p++) sacc += (-wx[i + p * m]) * sh[FLDS_Z + c * FMZ + p];
                     x[i] = -sacc;
                 }
-                __syncthreads();
+                wsync();
                 haveX = false;
             }
             double xr[4] = {0.0, 0.0, 0.0, 0.0};
@@ -354,13 +374,14 @@ __device__ __forceinline__ void backward_fused_body(RecLayout L, FusedArgs F, in
         sh[FLDS_V + (4 + q) * FVS + c] = acc.y;
         sh[FLDS_V + (8 + q) * FVS + c] = acc.z;
         sh[FLDS_V + (12 + q) * FVS + c] = acc.w;
-        __syncthreads();
+        wsync();
         V.x = 0.5 * (acc.x + sh[FLDS_V + c * FVS + q]);
         V.y = 0.5 * (acc.y + sh[FLDS_V + c * FVS + 4 + q]);
         V.z = 0.5 * (acc.z + sh[FLDS_V + c * FVS + 8 + q]);
         V.w = 0.5 * (acc.w + sh[FLDS_V + c * FVS + 12 + q]);
         if (lane_nn) fset_reg<REG_NN>(V, 0.0);
-        __syncthreads();
+        if (PC) __syncthreads();                       // end of step: the ring slot is free, the next one is full
+        else wsync();
     }
     dJ += __shfl_xor(dJ, 16);
     dJ += __shfl_xor(dJ, 32);
@@ -374,7 +395,8 @@ k_backward_fused(RecLayout L, FusedArgs F, int T, const double *__restrict__ rec
                  int pd_stride, double *__restrict__ Kout, double *__restrict__ kout,
                  double *__restrict__ delta_J, int *__restrict__ status)
 {
-    backward_fused_body<N, M>(L, F, T, rec, lambda, pd_stride, Kout, kout, delta_J, status);
+    __shared__ __attribute__((aligned(16))) double sh[FLDS_TOTAL];
+    backward_fused_body<N, M, false>(sh, nullptr, nullptr, L, F, T, rec, lambda, pd_stride, Kout, kout, delta_J, status);
 }
 template <int N, int M>
 __global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(1, 1)))
@@ -382,7 +404,8 @@ k_backward_fused_excl(RecLayout L, FusedArgs F, int T, const double *__restrict_
                       int pd_stride, double *__restrict__ Kout, double *__restrict__ kout,
                       double *__restrict__ delta_J, int *__restrict__ status)
 {
-    backward_fused_body<N, M>(L, F, T, rec, lambda, pd_stride, Kout, kout, delta_J, status);
+    __shared__ __attribute__((aligned(16))) double sh[FLDS_TOTAL];
+    backward_fused_body<N, M, false>(sh, nullptr, nullptr, L, F, T, rec, lambda, pd_stride, Kout, kout, delta_J, status);
 }
 
 
@@ -752,6 +775,108 @@ k_backward_fused2(RecLayout L, FusedArgs F, int T, int role_shift, const double 
 }
 
 // ---------------------------------------------------------------------------------------------------------
+// Backward pass, PRODUCER / CONSUMER wave pair per trajectory.  Unlike the U/Z split above the dependency runs one
+// way only: the producer wave evaluates what does not depend on V' -- this step's A, B columns (a4) and the cost
+// tiles Lzz = Rz'WRz, [l_uu | l_u] = Ru'W[Ru | r] (a6) -- one step AHEAD of the consumer and hands them over through a
+// two-slot LDS ring; the consumer wave runs the Riccati chain proper (backward_fused_body<.., PC = true>).  One
+// s_barrier per step: at the end of step t the consumer has read slot t&1 and the producer has filled slot (t-1)&1.
+// Two waves per SIMD at batch = #SIMDs: the producer's independent MFMAs and FP64 FMAs issue into the bubbles of the
+// consumer's dependent chain.
+template <int N, int M>
+__device__ __forceinline__ void fusedpc_producer(double *pcbuf, int *sflag, RecLayout L, FusedArgs F, int T, const double *__restrict__ rec)
+{
+    constexpr int n = N, m = M;
+    const int lane = threadIdx.x & 63, c = lane & 15, q = lane >> 4;
+    const int b = blockIdx.x;
+    const int nr = F.nr, ncr = (nr + 3) >> 2;
+    const int strideB = L.stride * 8;
+    DownTracker<8> tr;                           // A rows then B rows of column c
+    int oRx[4], oR1[4], oRu[4];
+    d4 Wt, Wr;
+    {
+        double wt[4], wr[4];
+#pragma unroll
+        for (int r = 0; r < 4; r++) {
+            const int row = 4 * r + q;
+            tr.offs[r] = (row < n && c < n) ? 8 * (L.off_A + row * n + c) : OOBF;
+            tr.offs[4 + r] = (row < n && c < m) ? 8 * (L.off_B + row * m + c) : OOBF;
+            oRx[r] = (row < nr && c < n) ? 8 * (row * n + c) : OOBF;
+            oR1[r] = (row < nr && c == n) ? 8 * row : OOBF;
+            oRu[r] = (row < nr && c < m) ? 8 * (row * m + c) : OOBF;
+            wr[r] = (row < nr) ? 2.0 * F.w_run[row] : 0.0;
+            wt[r] = (row < nr) ? 2.0 * F.w_term[row] : 0.0;
+        }
+        Wt.x = wt[0]; Wt.y = wt[1]; Wt.z = wt[2]; Wt.w = wt[3];
+        Wr.x = wr[0]; Wr.y = wr[1]; Wr.z = wr[2]; Wr.w = wr[3];
+    }
+    const d4 zero = {0.0, 0.0, 0.0, 0.0};
+    const double *R0 = rec + (size_t)b * T * L.stride;
+    __amdgpu_buffer_rsrc_t rT = frsrc(R0, T * strideB);
+    const double *rb = F.r + (size_t)b * (T + 1) * nr;
+    const double *rxb = F.r_x + (size_t)b * (T + 1) * nr * n;
+    const double *rub = F.r_u + (size_t)b * (T + 1) * nr * m;
+    d4 Rx, R1, Ru;
+    auto load_res = [&](int t) {
+        const bool ok = t >= 0;
+        const size_t tt = ok ? t : 0;
+        __amdgpu_buffer_rsrc_t rA = frsrc(rxb + tt * nr * n, ok ? nr * n * 8 : 0);
+        __amdgpu_buffer_rsrc_t rR = frsrc(rb + tt * nr, ok ? nr * 8 : 0);
+        __amdgpu_buffer_rsrc_t rU = frsrc(rub + tt * nr * m, ok ? nr * m * 8 : 0);
+        Rx.x = fbld(rA, oRx[0]); Rx.y = fbld(rA, oRx[1]); Rx.z = fbld(rA, oRx[2]); Rx.w = fbld(rA, oRx[3]);
+        R1.x = fbld(rR, oR1[0]); R1.y = fbld(rR, oR1[1]); R1.z = fbld(rR, oR1[2]); R1.w = fbld(rR, oR1[3]);
+        Ru.x = fbld(rU, oRu[0]); Ru.y = fbld(rU, oRu[1]); Ru.z = fbld(rU, oRu[2]); Ru.w = fbld(rU, oRu[3]);
+    };
+    const int kd = (c < F.dof) ? c : c - F.dof;
+    tr.init(rT, F.kp_offsets, F.kp_times, c < n, (size_t)b * F.dof + kd, T, strideB);
+#pragma unroll
+    for (int r = 0; r < 4; r++) if (c == n && 4 * r + q == n) tr.sv[r] = 1.0;       // Fz(n,n) = 1
+    auto publish = [&](int t, const d4 &W2) {
+        const double dt = (double)(t - tr.s);
+        d4 Fz, Fu, Rz, Rur;
+        Fz.x = tr.value(0, dt); Fz.y = tr.value(1, dt); Fz.z = tr.value(2, dt); Fz.w = tr.value(3, dt);
+        Fu.x = tr.value(4, dt); Fu.y = tr.value(5, dt); Fu.z = tr.value(6, dt); Fu.w = tr.value(7, dt);
+        Rz.x = bits_or(Rx.x, R1.x); Rz.y = bits_or(Rx.y, R1.y); Rz.z = bits_or(Rx.z, R1.z); Rz.w = bits_or(Rx.w, R1.w);
+        Rur.x = bits_or(Ru.x, R1.x); Rur.y = bits_or(Ru.y, R1.y); Rur.z = bits_or(Ru.z, R1.z); Rur.w = bits_or(Ru.w, R1.w);
+        const d4 Lzz = PR(Rz, Rz * W2, zero, ncr);
+        const d4 LU = PR(Ru, Rur * W2, zero, ncr);
+        load_res(t - 1);
+        double *tb = pcbuf + (t & 1) * FPC_BUF;
+        lds_store4(tb, lane, Fz); lds_store4(tb + 256, lane, Fu);
+        lds_store4(tb + 512, lane, Lzz); lds_store4(tb + 768, lane, LU);
+    };
+    load_res(T - 1);
+    if (lane == 0) sflag[0] = 0;
+    publish(T - 1, Wt);                                   // terminal weights   (iLQR.cpp:537-539)
+    __syncthreads();
+    for (int t = T - 1; t >= 0; t--) {
+        if (t > 0) {
+            tr.advance(rT, F.kp_times, t - 1, T, strideB);
+            publish(t - 1, Wr);
+        }
+        __syncthreads();
+        if (sflag[0]) break;
+    }
+}
+
+#define FPC_RING FLDS_TOTAL
+#define FPC_FLAG (FPC_RING + 2 * FPC_BUF)
+#define FPC_TOTAL (FPC_FLAG + 2)
+template <int N, int M>
+__global__ void __launch_bounds__(128) __attribute__((amdgpu_waves_per_eu(2, 2)))
+k_backward_fusedpc(RecLayout L, FusedArgs F, int T, int role_shift, const double *__restrict__ rec, const double *__restrict__ lambda,
+                   int pd_stride, double *__restrict__ Kout, double *__restrict__ kout,
+                   double *__restrict__ delta_J, int *__restrict__ status)
+{
+    __shared__ __attribute__((aligned(16))) double sh[FPC_TOTAL];
+    const bool consumer = ((__builtin_amdgcn_readfirstlane(threadIdx.x >> 6) ^ (blockIdx.x >> role_shift)) & 1) == 0;
+    if (consumer)
+        backward_fused_body<N, M, true>(sh, sh + FPC_RING, (int *)(sh + FPC_FLAG), L, F, T, rec, lambda, pd_stride, Kout, kout,
+                                        delta_J, status);
+    else
+        fusedpc_producer<N, M>(sh + FPC_RING, (int *)(sh + FPC_FLAG), L, F, T, rec);
+}
+
+// ---------------------------------------------------------------------------------------------------------
 // Forward pass.  The column tracker walks UP in time; its tiles (row = A row, col = A column) are turned into
 // the Y operands (row = contraction index) through a padded LDS transpose, off the Z dependency chain.
 template <int NCZ, int NCU>
@@ -1007,6 +1132,15 @@ hipError_t launch_backward_fused(Ctx *c, int pd_stride)
         const int role_shift = rs ? atoi(rs) : 9;
         if (n == 14 && m == 7) hipLaunchKernelGGL((k_backward_fused2<14, 7>), grid, block2, 0, c->stream, c->L, F, c->d.T, role_shift, c->rec, c->lambda, pd_stride, c->K, c->k, c->delta_J, c->status);
         else if (n == 4 && m == 1) hipLaunchKernelGGL((k_backward_fused2<4, 1>), grid, block2, 0, c->stream, c->L, F, c->d.T, role_shift, c->rec, c->lambda, pd_stride, c->K, c->k, c->delta_J, c->status);
+        else return hipErrorInvalidValue;
+        return hipGetLastError();
+    }
+    if (e2 && atoi(e2) == 3) {                                  // producer / consumer wave pair
+        dim3 block2(128);
+        const char *rs = getenv("KPILQR_ROLE_SHIFT");
+        const int role_shift = rs ? atoi(rs) : 9;
+        if (n == 14 && m == 7) hipLaunchKernelGGL((k_backward_fusedpc<14, 7>), grid, block2, 0, c->stream, c->L, F, c->d.T, role_shift, c->rec, c->lambda, pd_stride, c->K, c->k, c->delta_J, c->status);
+        else if (n == 4 && m == 1) hipLaunchKernelGGL((k_backward_fusedpc<4, 1>), grid, block2, 0, c->stream, c->L, F, c->d.T, role_shift, c->rec, c->lambda, pd_stride, c->K, c->k, c->delta_J, c->status);
         else return hipErrorInvalidValue;
         return hipGetLastError();
     }
