@@ -135,6 +135,7 @@ int kpilqr_create(const kpilqr_dims *dims, void *stream, kpilqr_ctx **out)
 void kpilqr_destroy(kpilqr_ctx *c)
 {
     if (!c) return;
+    (void)hipSetDevice(c->d.device);
     (void)hipStreamSynchronize(c->stream);
     comm_destroy(c);
     void *ptrs[] = {c->rec, c->K, c->k, c->r, c->r_x, c->r_u, c->w_run, c->w_term, c->u_nom, c->ctrl_lim,
@@ -156,6 +157,7 @@ int kpilqr_get_dims(kpilqr_ctx *c, kpilqr_dims *out)
 int kpilqr_host_alloc(kpilqr_ctx *c, size_t bytes, void **pinned)
 {
     if (!c || !pinned) return KPILQR_ERR_ARG;
+    KP_HIP(c, hipSetDevice(c->d.device));          // one context = one device; the caller may drive several
     KP_HIP(c, hipHostMalloc(pinned, bytes ? bytes : 1, hipHostMallocDefault));
     return KPILQR_OK;
 }
@@ -163,6 +165,7 @@ int kpilqr_host_alloc(kpilqr_ctx *c, size_t bytes, void **pinned)
 int kpilqr_host_free(kpilqr_ctx *c, void *pinned)
 {
     if (!c) return KPILQR_ERR_ARG;
+    KP_HIP(c, hipSetDevice(c->d.device));          // one context = one device; the caller may drive several
     if (pinned) KP_HIP(c, hipHostFree(pinned));
     return KPILQR_OK;
 }
@@ -170,6 +173,7 @@ int kpilqr_host_free(kpilqr_ctx *c, void *pinned)
 int kpilqr_sync(kpilqr_ctx *c)
 {
     if (!c) return KPILQR_ERR_ARG;
+    KP_HIP(c, hipSetDevice(c->d.device));          // one context = one device; the caller may drive several
     KP_HIP(c, hipStreamSynchronize(c->stream));
     return KPILQR_OK;
 }
@@ -177,6 +181,7 @@ int kpilqr_sync(kpilqr_ctx *c)
 int kpilqr_device_ptr(kpilqr_ctx *c, int which, void **dptr, size_t *bytes)
 {
     if (!c || !dptr) return KPILQR_ERR_ARG;
+    KP_HIP(c, hipSetDevice(c->d.device));          // one context = one device; the caller may drive several
     const size_t B = c->d.batch, T = c->d.T, n = c->n, m = c->d.m, nr = c->d.nr;
     void *p = nullptr; size_t sz = 0;
     switch (which) {
@@ -203,6 +208,7 @@ int kpilqr_device_ptr(kpilqr_ctx *c, int which, void **dptr, size_t *bytes)
 int kpilqr_set_keypoints(kpilqr_ctx *c, const int *kp_offsets, const int *kp_times)
 {
     if (!c || !kp_offsets || !kp_times) return KPILQR_ERR_ARG;
+    KP_HIP(c, hipSetDevice(c->d.device));          // one context = one device; the caller may drive several
     const size_t nlists = (size_t)c->d.batch * c->d.dof;
     const int total = kp_offsets[nlists];
     if (kp_offsets[0] != 0 || total < 0) return set_err(c, KPILQR_ERR_ARG, "kp_offsets must start at 0");
@@ -237,6 +243,7 @@ static int ensure_stage(kpilqr_ctx *c, size_t bytes);
 int kpilqr_upload_states(kpilqr_ctx *c, const double *X)
 {
     if (!c || !X) return KPILQR_ERR_ARG;
+    KP_HIP(c, hipSetDevice(c->d.device));          // one context = one device; the caller may drive several
     const size_t count = (size_t)c->d.batch * c->d.T * c->n;
     if (!c->X_states) KP_HIP(c, hipMalloc((void **)&c->X_states, count * sizeof(double)));
     KP_HIP(c, hipMemcpyAsync(c->X_states, X, count * sizeof(double), hipMemcpyHostToDevice, c->stream));
@@ -247,6 +254,7 @@ int kpilqr_upload_states(kpilqr_ctx *c, const double *X)
 int kpilqr_generate_keypoints(kpilqr_ctx *c, const char *method, int min_N, int max_N, const double *thresholds, double dt)
 {
     if (!c || !method) return KPILQR_ERR_ARG;
+    KP_HIP(c, hipSetDevice(c->d.device));          // one context = one device; the caller may drive several
     int mth = -1;
     if (strcmp(method, "set_interval") == 0) mth = 0;
     else if (strcmp(method, "adaptive_jerk") == 0) mth = 1;
@@ -283,6 +291,7 @@ int kpilqr_generate_keypoints(kpilqr_ctx *c, const char *method, int min_N, int 
 int kpilqr_get_keypoints(kpilqr_ctx *c, int *kp_offsets, int *kp_times, int times_capacity)
 {
     if (!c || !kp_offsets) return KPILQR_ERR_ARG;
+    KP_HIP(c, hipSetDevice(c->d.device));          // one context = one device; the caller may drive several
     if (!c->have_kp) return set_err(c, KPILQR_ERR_STATE, "no key-points set");
     const size_t nlists = (size_t)c->d.batch * c->d.dof;
     KP_HIP(c, hipMemcpyAsync(kp_offsets, c->kp_offsets, (nlists + 1) * sizeof(int), hipMemcpyDeviceToHost, c->stream));
@@ -301,6 +310,7 @@ int kpilqr_upload_fd(kpilqr_ctx *c, int njobs, const int *job_b, const int *job_
                      const double *xminus, int nnom, const double *xnom, double eps)
 {
     if (!c || njobs < 0 || nnom < 0) return KPILQR_ERR_ARG;
+    KP_HIP(c, hipSetDevice(c->d.device));          // one context = one device; the caller may drive several
     if (njobs > 0 && (!job_b || !job_t || !job_col || !job_mode || !xplus || !xminus))
         return set_err(c, KPILQR_ERR_ARG, "null FD job array");
     if (!(eps > 0.0)) return set_err(c, KPILQR_ERR_ARG, "eps must be positive");
@@ -366,6 +376,7 @@ int kpilqr_upload_fd(kpilqr_ctx *c, int njobs, const int *job_b, const int *job_
 int kpilqr_fd_difference(kpilqr_ctx *c)
 {
     if (!c) return KPILQR_ERR_ARG;
+    KP_HIP(c, hipSetDevice(c->d.device));          // one context = one device; the caller may drive several
     KP_HIP(c, launch_fd_difference(c));
     return KPILQR_OK;
 }
@@ -373,6 +384,7 @@ int kpilqr_fd_difference(kpilqr_ctx *c)
 int kpilqr_interpolate(kpilqr_ctx *c)
 {
     if (!c) return KPILQR_ERR_ARG;
+    KP_HIP(c, hipSetDevice(c->d.device));          // one context = one device; the caller may drive several
     if (!c->have_kp) return set_err(c, KPILQR_ERR_STATE, "kpilqr_interpolate before kpilqr_set_keypoints");
     KP_HIP(c, launch_interpolate(c));
     return KPILQR_OK;
@@ -382,6 +394,7 @@ int kpilqr_interpolate(kpilqr_ctx *c)
 int kpilqr_filter_dynamics(kpilqr_ctx *c, const char *method, const double *coefs, int ncoef)
 {
     if (!c || !method || !coefs) return KPILQR_ERR_ARG;
+    KP_HIP(c, hipSetDevice(c->d.device));          // one context = one device; the caller may drive several
     int mth = strcmp(method, "low_pass") == 0 ? 0 : strcmp(method, "FIR") == 0 ? 1 : -1;
     if (mth < 0) return set_err(c, KPILQR_ERR_ARG, "Filtering method not recognised (low_pass, FIR)");
     if (ncoef < 1 || ncoef > 16) return set_err(c, KPILQR_ERR_ARG, "1..16 filter coefficients");
@@ -400,6 +413,7 @@ int kpilqr_upload_residuals(kpilqr_ctx *c, const double *r, const double *r_x, c
                             const double *w_run, const double *w_term)
 {
     if (!c) return KPILQR_ERR_ARG;
+    KP_HIP(c, hipSetDevice(c->d.device));          // one context = one device; the caller may drive several
     const size_t B = c->d.batch, T1 = c->d.T + 1, n = c->n, m = c->d.m, nr = c->d.nr;
     if (r) KP_HIP(c, hipMemcpyAsync(c->r, r, B * T1 * nr * 8, hipMemcpyHostToDevice, c->stream));
     if (r_x) KP_HIP(c, hipMemcpyAsync(c->r_x, r_x, B * T1 * nr * n * 8, hipMemcpyHostToDevice, c->stream));
@@ -412,6 +426,7 @@ int kpilqr_upload_residuals(kpilqr_ctx *c, const double *r, const double *r_x, c
 int kpilqr_cost_derivs(kpilqr_ctx *c)
 {
     if (!c) return KPILQR_ERR_ARG;
+    KP_HIP(c, hipSetDevice(c->d.device));          // one context = one device; the caller may drive several
     KP_HIP(c, launch_cost_derivs(c));
     return KPILQR_OK;
 }
@@ -419,6 +434,7 @@ int kpilqr_cost_derivs(kpilqr_ctx *c)
 int kpilqr_trajectory_cost(kpilqr_ctx *c, double *cost)
 {
     if (!c) return KPILQR_ERR_ARG;
+    KP_HIP(c, hipSetDevice(c->d.device));          // one context = one device; the caller may drive several
     KP_HIP(c, launch_trajectory_cost(c));
     if (cost) KP_HIP(c, hipMemcpyAsync(cost, c->traj_cost, (size_t)c->d.batch * 8, hipMemcpyDeviceToHost, c->stream));
     return KPILQR_OK;
@@ -450,6 +466,7 @@ static int run_backward(kpilqr_ctx *c, int pd_stride)
 int kpilqr_backward(kpilqr_ctx *c, const double *lambda, int pd_check_stride, int *status, double *delta_J)
 {
     if (!c) return KPILQR_ERR_ARG;
+    KP_HIP(c, hipSetDevice(c->d.device));          // one context = one device; the caller may drive several
     if (pd_check_stride < 1) return set_err(c, KPILQR_ERR_ARG, "pd_check_stride must be >= 1");
     if (lambda) KP_HIP(c, hipMemcpyAsync(c->lambda, lambda, (size_t)c->d.batch * 8, hipMemcpyHostToDevice, c->stream));
     int rc = run_backward(c, pd_check_stride);
@@ -462,6 +479,7 @@ int kpilqr_backward(kpilqr_ctx *c, const double *lambda, int pd_check_stride, in
 int kpilqr_download_gains(kpilqr_ctx *c, double *K, double *k)
 {
     if (!c) return KPILQR_ERR_ARG;
+    KP_HIP(c, hipSetDevice(c->d.device));          // one context = one device; the caller may drive several
     const size_t B = c->d.batch, T = c->d.T, n = c->n, m = c->d.m;
     if (K) KP_HIP(c, hipMemcpyAsync(K, c->K, B * T * n * m * 8, hipMemcpyDeviceToHost, c->stream));
     if (k) KP_HIP(c, hipMemcpyAsync(k, c->k, B * T * m * 8, hipMemcpyDeviceToHost, c->stream));
@@ -472,6 +490,7 @@ int kpilqr_download_gains(kpilqr_ctx *c, double *K, double *k)
 int kpilqr_dof_importance(kpilqr_ctx *c, int sampling_k_interval, double *sums)
 {
     if (!c || !sums) return KPILQR_ERR_ARG;
+    KP_HIP(c, hipSetDevice(c->d.device));          // one context = one device; the caller may drive several
     if (sampling_k_interval < 1) return set_err(c, KPILQR_ERR_ARG, "sampling_k_interval must be >= 1");
     const size_t bytes = (size_t)c->d.batch * c->d.dof * sizeof(double);
     int rc = ensure_stage(c, bytes);
@@ -485,6 +504,7 @@ int kpilqr_dof_importance(kpilqr_ctx *c, int sampling_k_interval, double *sums)
 int kpilqr_upload_nominal(kpilqr_ctx *c, const double *u_nom, const double *ctrl_lim)
 {
     if (!c) return KPILQR_ERR_ARG;
+    KP_HIP(c, hipSetDevice(c->d.device));          // one context = one device; the caller may drive several
     const size_t B = c->d.batch, T = c->d.T, m = c->d.m;
     if (u_nom) KP_HIP(c, hipMemcpyAsync(c->u_nom, u_nom, B * T * m * 8, hipMemcpyHostToDevice, c->stream));
     if (ctrl_lim) KP_HIP(c, hipMemcpyAsync(c->ctrl_lim, ctrl_lim, 2 * m * 8, hipMemcpyHostToDevice, c->stream));
@@ -519,6 +539,7 @@ static int run_forward(kpilqr_ctx *c, double *U_dev)
 int kpilqr_forward_linear(kpilqr_ctx *c, const double *alphas, double *cost_pred, double *U_alpha)
 {
     if (!c) return KPILQR_ERR_ARG;
+    KP_HIP(c, hipSetDevice(c->d.device));          // one context = one device; the caller may drive several
     const size_t B = c->d.batch, T = c->d.T, m = c->d.m, na = c->d.n_alpha;
     if (alphas) KP_HIP(c, hipMemcpyAsync(c->alphas, alphas, na * 8, hipMemcpyHostToDevice, c->stream));
     double *U_dev = nullptr;
@@ -538,6 +559,7 @@ int kpilqr_forward_linear(kpilqr_ctx *c, const double *alphas, double *cost_pred
 int kpilqr_iterate(kpilqr_ctx *c, const double *lambda, int pd_check_stride, const double *alphas)
 {
     if (!c) return KPILQR_ERR_ARG;
+    KP_HIP(c, hipSetDevice(c->d.device));          // one context = one device; the caller may drive several
     if (!c->have_kp) return set_err(c, KPILQR_ERR_STATE, "kpilqr_iterate before kpilqr_set_keypoints");
     if (pd_check_stride < 1) return set_err(c, KPILQR_ERR_ARG, "pd_check_stride must be >= 1");
     if (lambda) KP_HIP(c, hipMemcpyAsync(c->lambda, lambda, (size_t)c->d.batch * 8, hipMemcpyHostToDevice, c->stream));
@@ -572,6 +594,7 @@ int kpilqr_comm_init(kpilqr_ctx *c, int nranks, int rank, const char id[128])
 int kpilqr_allreduce_linesearch(kpilqr_ctx *c, double vec8[8])
 {
     if (!c) return KPILQR_ERR_ARG;
+    KP_HIP(c, hipSetDevice(c->d.device));          // one context = one device; the caller may drive several
     if (!c->ls8) KP_HIP(c, hipMalloc((void **)&c->ls8, 8 * sizeof(double)));
     KP_HIP(c, launch_pack_linesearch(c, c->ls8));
     if (const char *e = comm_allreduce8(c, c->ls8)) return set_err(c, KPILQR_ERR_HIP, std::string("RCCL: ") + e);
@@ -583,6 +606,7 @@ int kpilqr_allreduce_linesearch(kpilqr_ctx *c, double vec8[8])
 int kpilqr_set_AB(kpilqr_ctx *c, const double *A, const double *B)
 {
     if (!c) return KPILQR_ERR_ARG;
+    KP_HIP(c, hipSetDevice(c->d.device));          // one context = one device; the caller may drive several
     const size_t BT = (size_t)c->d.batch * c->d.T, n = c->n, m = c->d.m;
     const size_t szA = BT * n * n * 8, szB = BT * n * m * 8;
     int rc = ensure_stage(c, szA + szB);
@@ -598,6 +622,7 @@ int kpilqr_set_AB(kpilqr_ctx *c, const double *A, const double *B)
 int kpilqr_get_AB(kpilqr_ctx *c, double *A, double *B)
 {
     if (!c) return KPILQR_ERR_ARG;
+    KP_HIP(c, hipSetDevice(c->d.device));          // one context = one device; the caller may drive several
     const size_t BT = (size_t)c->d.batch * c->d.T, n = c->n, m = c->d.m;
     const size_t szA = BT * n * n * 8, szB = BT * n * m * 8;
     int rc = ensure_stage(c, szA + szB);
@@ -613,6 +638,7 @@ int kpilqr_get_AB(kpilqr_ctx *c, double *A, double *B)
 int kpilqr_set_cost_derivs(kpilqr_ctx *c, const double *l_x, const double *l_xx, const double *l_u, const double *l_uu)
 {
     if (!c) return KPILQR_ERR_ARG;
+    KP_HIP(c, hipSetDevice(c->d.device));          // one context = one device; the caller may drive several
     const size_t BT = (size_t)c->d.batch * c->d.T, n = c->n, m = c->d.m;
     const size_t s1 = BT * n * 8, s2 = BT * n * n * 8, s3 = BT * m * 8, s4 = BT * m * m * 8;
     int rc = ensure_stage(c, s1 + s2 + s3 + s4);
@@ -631,6 +657,7 @@ int kpilqr_set_cost_derivs(kpilqr_ctx *c, const double *l_x, const double *l_xx,
 int kpilqr_get_cost_derivs(kpilqr_ctx *c, double *l_x, double *l_xx, double *l_u, double *l_uu)
 {
     if (!c) return KPILQR_ERR_ARG;
+    KP_HIP(c, hipSetDevice(c->d.device));          // one context = one device; the caller may drive several
     const size_t BT = (size_t)c->d.batch * c->d.T, n = c->n, m = c->d.m;
     const size_t s1 = BT * n * 8, s2 = BT * n * n * 8, s3 = BT * m * 8, s4 = BT * m * m * 8;
     int rc = ensure_stage(c, s1 + s2 + s3 + s4);
