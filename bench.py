@@ -265,6 +265,21 @@ def main():
                          "iteration_algorithmic_GBps": sum(ab.values()) * B / (elapsed / args.steps) / 1e9,
                          "iteration_frac_of_hbm_peak": sum(ab.values()) * B / (elapsed / args.steps) / 1e9 / HBM_PEAK_GBS},
         }
+        # second ceiling of the dominant kernel: the SIMD's FP64 unit.  Issued v_mfma_f64_16x16x4 per trajectory-step
+        # from the PMC pass (profiles/r01_pmc_counters.json), 2048 flop and 64 busy cycles each = 32 flop/clk/SIMD
+        # (profiles/r01_fp64_mfma_probe.txt) -> chip peak 1024 SIMDs x 32 x 2.4 GHz.  Issued, not algorithmic, flops:
+        # the control-side products fill 7 of a tile's 16 columns.
+        try:
+            if fused and args.task == "panda_reaching" and not args.generic:
+                cnt = json.load(open(os.path.join(ROOT, "profiles", "r01_pmc_counters.json")))["derived"]["backward_fused"]
+                issued = cnt["mfma_per_step_per_trajectory"] * 2048.0 * T * B
+                peak_tf = 1024 * 32 * 2.4e9 / 1e12
+                ach_tf = issued / (stage_ms[dom] * 1e-3) / 1e12
+                out["fp64_unit"] = {"kernel": out["roofline"]["kernel"], "issued_mfma_TFLOPs": ach_tf, "peak_TFLOPs": peak_tf,
+                                    "frac": ach_tf / peak_tf,
+                                    "mfma_per_trajectory_step": cnt["mfma_per_step_per_trajectory"]}
+        except Exception:
+            pass
         if secondary is not None:
             out["materialising_pipeline"] = secondary
         if world == 1 and not args.no_cpu_baseline:
