@@ -642,10 +642,11 @@ def test_c_abi_linesearch_allreduce_single_rank():
         assert np.allclose(kd.pack_linesearch(cost, dJ, st).numpy(), v0, rtol=1e-13)
 
 
-@pytest.mark.parametrize("waves", ["2", "3"])
+@pytest.mark.parametrize("waves", ["1", "2", "3"])
 def test_fused_two_wave_backward_variant(monkeypatch, waves):
-    """KPILQR_FUSED_WAVES=2: the control-side / state-side two-wave split of the fused backward pass; =3: the
-    producer / consumer wave pair.  Both compute the same gains as the one-wave kernel."""
+    """The three wave organisations of the fused backward pass compute the same gains:
+    KPILQR_FUSED_WAVES=1 one wave per trajectory (the default above #SIMDs/2 trajectories), =2 the control-side /
+    state-side split, =3 the producer / consumer pair (the default up to #SIMDs/2 trajectories)."""
     monkeypatch.setenv("KPILQR_FUSED_WAVES", waves)
     if waves == "3":
         monkeypatch.setenv("KPILQR_ROLE_SHIFT", "0")             # alternate the roles with the block index

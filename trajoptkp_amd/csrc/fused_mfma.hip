@@ -862,9 +862,8 @@ __device__ __forceinline__ void fusedpc_producer(double *pcbuf, int *sflag, RecL
 #define FPC_FLAG (FPC_RING + 2 * FPC_BUF)
 #define FPC_TOTAL (FPC_FLAG + 2)
 template <int N, int M>
-__global__ void __launch_bounds__(128) __attribute__((amdgpu_waves_per_eu(2, 2)))
-k_backward_fusedpc(RecLayout L, FusedArgs F, int T, int role_shift, const double *__restrict__ rec, const double *__restrict__ lambda,
-                   int pd_stride, double *__restrict__ Kout, double *__restrict__ kout,
+__device__ __forceinline__ void backward_fusedpc_block(RecLayout L, FusedArgs F, int T, int role_shift, const double *__restrict__ rec,
+                   const double *__restrict__ lambda, int pd_stride, double *__restrict__ Kout, double *__restrict__ kout,
                    double *__restrict__ delta_J, int *__restrict__ status)
 {
     __shared__ __attribute__((aligned(16))) double sh[FPC_TOTAL];
@@ -874,6 +873,23 @@ k_backward_fusedpc(RecLayout L, FusedArgs F, int T, int role_shift, const double
                                         delta_J, status);
     else
         fusedpc_producer<N, M>(sh + FPC_RING, (int *)(sh + FPC_FLAG), L, F, T, rec);
+}
+template <int N, int M>
+__global__ void __launch_bounds__(128) __attribute__((amdgpu_waves_per_eu(2, 2)))
+k_backward_fusedpc(RecLayout L, FusedArgs F, int T, int role_shift, const double *__restrict__ rec, const double *__restrict__ lambda,
+                   int pd_stride, double *__restrict__ Kout, double *__restrict__ kout,
+                   double *__restrict__ delta_J, int *__restrict__ status)
+{
+    backward_fusedpc_block<N, M>(L, F, T, role_shift, rec, lambda, pd_stride, Kout, kout, delta_J, status);
+}
+// at most one wave per SIMD: while 2 x batch <= #SIMDs every wave of every pair gets a SIMD (and its FP64 unit) to itself
+template <int N, int M>
+__global__ void __launch_bounds__(128) __attribute__((amdgpu_waves_per_eu(1, 1)))
+k_backward_fusedpc_excl(RecLayout L, FusedArgs F, int T, int role_shift, const double *__restrict__ rec, const double *__restrict__ lambda,
+                        int pd_stride, double *__restrict__ Kout, double *__restrict__ kout,
+                        double *__restrict__ delta_J, int *__restrict__ status)
+{
+    backward_fusedpc_block<N, M>(L, F, T, role_shift, rec, lambda, pd_stride, Kout, kout, delta_J, status);
 }
 
 // ---------------------------------------------------------------------------------------------------------
@@ -1124,24 +1140,32 @@ hipError_t launch_backward_fused(Ctx *c, int pd_stride)
     dim3 grid(c->d.batch), block(64);
     const bool excl = c->d.batch <= c->n_simd;
     const FusedArgs F = fused_args(c);
-    const char *e2 = getenv("KPILQR_FUSED_WAVES");              // diagnostic: 1 = one wave per trajectory, 2 = two
-    const bool two = e2 ? atoi(e2) == 2 : false;
-    if (two) {
-        dim3 block2(128);
-        const char *rs = getenv("KPILQR_ROLE_SHIFT");
-        const int role_shift = rs ? atoi(rs) : 9;
+    // Wave organisation of the backward sweep.  While every wave of a producer/consumer pair can have a SIMD to itself
+    // (2 x batch <= #SIMDs) the pair is the fastest form (4.2 vs 5.8 ms per sweep, tools/small_batch_variants.sh);
+    // beyond that the FP64 unit is shared and one wave per trajectory wins.
+    // KPILQR_FUSED_WAVES forces a form: 1 = one wave, 2 = control/state split, 3 = producer/consumer.
+    const char *e2 = getenv("KPILQR_FUSED_WAVES");
+    const int form = e2 ? atoi(e2) : (2 * c->d.batch <= c->n_simd ? 3 : 1);
+    const char *rs = getenv("KPILQR_ROLE_SHIFT");
+    const int role_shift = rs ? atoi(rs) : 9;
+    dim3 block2(128);
+    if (form == 2) {
         if (n == 14 && m == 7) hipLaunchKernelGGL((k_backward_fused2<14, 7>), grid, block2, 0, c->stream, c->L, F, c->d.T, role_shift, c->rec, c->lambda, pd_stride, c->K, c->k, c->delta_J, c->status);
         else if (n == 4 && m == 1) hipLaunchKernelGGL((k_backward_fused2<4, 1>), grid, block2, 0, c->stream, c->L, F, c->d.T, role_shift, c->rec, c->lambda, pd_stride, c->K, c->k, c->delta_J, c->status);
         else return hipErrorInvalidValue;
         return hipGetLastError();
     }
-    if (e2 && atoi(e2) == 3) {                                  // producer / consumer wave pair
-        dim3 block2(128);
-        const char *rs = getenv("KPILQR_ROLE_SHIFT");
-        const int role_shift = rs ? atoi(rs) : 9;
-        if (n == 14 && m == 7) hipLaunchKernelGGL((k_backward_fusedpc<14, 7>), grid, block2, 0, c->stream, c->L, F, c->d.T, role_shift, c->rec, c->lambda, pd_stride, c->K, c->k, c->delta_J, c->status);
-        else if (n == 4 && m == 1) hipLaunchKernelGGL((k_backward_fusedpc<4, 1>), grid, block2, 0, c->stream, c->L, F, c->d.T, role_shift, c->rec, c->lambda, pd_stride, c->K, c->k, c->delta_J, c->status);
+    if (form == 3) {
+        const bool pexcl = 2 * c->d.batch <= c->n_simd;
+#define LAUNCHPC(NN, MM)                                                                                              \
+        do {                                                                                                          \
+            if (pexcl) hipLaunchKernelGGL((k_backward_fusedpc_excl<NN, MM>), grid, block2, 0, c->stream, c->L, F, c->d.T, role_shift, c->rec, c->lambda, pd_stride, c->K, c->k, c->delta_J, c->status); \
+            else hipLaunchKernelGGL((k_backward_fusedpc<NN, MM>), grid, block2, 0, c->stream, c->L, F, c->d.T, role_shift, c->rec, c->lambda, pd_stride, c->K, c->k, c->delta_J, c->status); \
+        } while (0)
+        if (n == 14 && m == 7) LAUNCHPC(14, 7);
+        else if (n == 4 && m == 1) LAUNCHPC(4, 1);
         else return hipErrorInvalidValue;
+#undef LAUNCHPC
         return hipGetLastError();
     }
 #define LAUNCH(NN, MM)                                                                                       \
