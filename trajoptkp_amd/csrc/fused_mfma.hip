@@ -1089,7 +1089,7 @@ __device__ __forceinline__ void forward_fused_body(RecLayout L, FusedArgs F, int
         // quadratic cost model on the residuals: sum_k w_k [Jx_k (2 r_k + Jx_k) + Ju_k (2 r_k + Ju_k)]
         if (t == T - 1) {                     // terminal weights at the last step (Optimiser.cpp:209-211)
 #pragma unroll
-            for (int r = 0; r < 4; r++) wcur[r] = (4 * r + q < nr) ? F.w_term[4 * r + q] : 0.0;
+            for (int r = 0; r < 4; r++) wcur[r] = (4 * r + q < nr) ? F.w_term[4 * r + q] : 0.0;   // (hoisting these loads out of the loop measured 0.9 ms slower)
         }
         const d4 r2 = cur.rv + cur.rv;
         partial += wcur[0] * (Jx.x * (r2.x + Jx.x) + Ju.x * (r2.x + Ju.x))
@@ -1120,6 +1120,247 @@ k_forward_fused_excl(RecLayout L, FusedArgs F, int T, int n_alpha, const double 
                      const double *__restrict__ alphas, double *__restrict__ cost_pred, double *__restrict__ U_alpha)
 {
     forward_fused_body<NCZ, NCU>(L, F, T, n_alpha, rec, Kin, kin, u_nom, ctrl_lim, alphas, cost_pred, U_alpha);
+}
+
+// ---------------------------------------------------------------------------------------------------------
+// Forward pass, STATE / COST wave pair per trajectory (small batches: every wave has a SIMD to itself).  Only the state
+// recursion is serial in time: wave S keeps Z and runs  U = u_nom + K dx + alpha k | clamp | Z' = A dx + B du  (10 MFMAs a
+// step) and publishes (Z_t, dU_t); wave C, one step behind, scores the candidates (Jx = r_x dx, Ju = r_u du, the weighted
+// quadratic: 6 MFMAs + the FP64 VALU work) and, one step ahead, interpolates the A, B columns of the next step (a4) into
+// the transposing LDS tiles S reads.  One s_barrier per step, two ring slots each way.
+#define FSC_Y 544                                 // one Y slot: A then B, [16][17] each
+#define FSC_YS 0
+#define FSC_ZS (2 * FSC_Y)                        // two (Z, dU) slots, D layout
+#define FSC_TOTAL (FSC_ZS + 2 * 512)
+
+template <int NCZ, int NCU>
+__device__ __forceinline__ void forward_sc_state(double *sh, RecLayout L, int T, int n_alpha, const double *__restrict__ Kin,
+               const double *__restrict__ kin, const double *__restrict__ u_nom, const double *__restrict__ ctrl_lim,
+               const double *__restrict__ alphas, double *__restrict__ U_alpha)
+{
+    const int n = L.n, m = L.m;
+    const int lane = threadIdx.x & 63, c = lane & 15, q = lane >> 4;
+    const int b = blockIdx.x;
+    int oK[4], ok_[4], oub[4];
+    double lo[NCU], hi[NCU];
+#pragma unroll
+    for (int r = 0; r < 4; r++) {
+        const int row = 4 * r + q;
+        oK[r] = (row < n && c < m) ? 8 * (row * m + c) : OOBF;
+        ok_[r] = (row == n && c < m) ? 8 * c : OOBF;
+        oub[r] = (row < m) ? 8 * row : OOBF;
+        if (r < NCU) {
+            lo[r] = (row < m) ? ctrl_lim[2 * row] : -1.0e300;
+            hi[r] = (row < m) ? ctrl_lim[2 * row + 1] : 1.0e300;
+        }
+    }
+    const double my_alpha = (c < n_alpha) ? alphas[c] : 0.0;
+    d4 Z;
+    {
+        double zr[4];
+#pragma unroll
+        for (int r = 0; r < 4; r++) {
+            const int row = 4 * r + q;
+            zr[r] = (row == n) ? my_alpha : (row == n + 1) ? 1.0 : 0.0;
+        }
+        Z.x = zr[0]; Z.y = zr[1]; Z.z = zr[2]; Z.w = zr[3];
+    }
+    const d4 zero = {0.0, 0.0, 0.0, 0.0};
+    // two alternating tile sets (even / odd steps): each is re-requested for step t+2 right behind its use in step t, so a
+    // load has two whole steps to land -- the short S step leaves less cover than the one-wave kernel has
+    struct STiles { d4 YkK, Ykk, ub; };
+    const __amdgpu_buffer_rsrc_t rNone = frsrc(Kin, 0);
+    auto request = [&](int t, STiles &s_) {
+        const bool ok = t < T;
+        __amdgpu_buffer_rsrc_t rK = ok ? frsrc(Kin + ((size_t)b * T + t) * m * n, m * n * 8) : rNone;
+        __amdgpu_buffer_rsrc_t rk = ok ? frsrc(kin + ((size_t)b * T + t) * m, m * 8) : rNone;
+        __amdgpu_buffer_rsrc_t ru = ok ? frsrc(u_nom + ((size_t)b * T + t) * m, m * 8) : rNone;
+        s_.YkK.x = fbld(rK, oK[0]); s_.YkK.y = fbld(rK, oK[1]); s_.YkK.z = fbld(rK, oK[2]); s_.YkK.w = fbld(rK, oK[3]);
+        s_.Ykk.x = fbld(rk, ok_[0]); s_.Ykk.y = fbld(rk, ok_[1]); s_.Ykk.z = fbld(rk, ok_[2]); s_.Ykk.w = fbld(rk, ok_[3]);
+        s_.ub.x = fbld(ru, oub[0]); s_.ub.y = NCU > 1 ? fbld(ru, oub[1]) : 0.0;
+        s_.ub.z = NCU > 2 ? fbld(ru, oub[2]) : 0.0; s_.ub.w = NCU > 3 ? fbld(ru, oub[3]) : 0.0;
+    };
+    auto step = [&](int t, STiles &s_) {
+        const double *shA = sh + FSC_YS + (t & 1) * FSC_Y, *shB = shA + 272;
+        d4 Ya, Yb;                                     // Ya(p, o) = A(o, p);  Yb(p, o) = B(o, p)
+        Ya.x = shA[c * 17 + q];      Ya.y = shA[c * 17 + 4 + q];
+        Ya.z = shA[c * 17 + 8 + q];  Ya.w = shA[c * 17 + 12 + q];
+        Yb.x = shB[c * 17 + q];                Yb.y = NCU > 1 ? shB[c * 17 + 4 + q] : 0.0;
+        Yb.z = NCU > 2 ? shB[c * 17 + 8 + q] : 0.0; Yb.w = NCU > 3 ? shB[c * 17 + 12 + q] : 0.0;
+        const d4 Yk = s_.YkK + s_.Ykk;
+        const d4 ub = s_.ub;
+        d4 U = PS<NCZ>(Yk, Z, ub);                     // u_nom + K dx + alpha k   (:879)
+        __builtin_amdgcn_sched_barrier(0);
+        request(t + 2, s_);
+        __builtin_amdgcn_sched_barrier(0);
+        d4 Zn = PS<NCZ>(Ya, Z, zero);                  // A dx
+        d4 dU = zero;
+        {
+            double u;                                  // clamp (:883-889)
+            u = U.x; if (u > hi[0]) u = hi[0]; if (u < lo[0]) u = lo[0]; U.x = u; dU.x = u - ub.x;
+            if (NCU > 1) { u = U.y; if (u > hi[1]) u = hi[1]; if (u < lo[1]) u = lo[1]; U.y = u; dU.y = u - ub.y; }
+            if (NCU > 2) { u = U.z; if (u > hi[2]) u = hi[2]; if (u < lo[2]) u = lo[2]; U.z = u; dU.z = u - ub.z; }
+            if (NCU > 3) { u = U.w; if (u > hi[3]) u = hi[3]; if (u < lo[3]) u = lo[3]; U.w = u; dU.w = u - ub.w; }
+        }
+        double *zs = sh + FSC_ZS + (t & 1) * 512;
+        lds_store4(zs, lane, Z);                       // the state this step started from, and its control change
+        lds_store4(zs + 256, lane, dU);
+        Z = PS<NCU>(Yb, dU, Zn);                       // + B du: the next state
+        if (U_alpha && c < n_alpha) {
+            double *Ua = U_alpha + (((size_t)b * n_alpha + c) * T + t) * m;
+            const double uv[4] = {U.x, U.y, U.z, U.w};
+#pragma unroll
+            for (int r = 0; r < NCU; r++) { const int row = 4 * r + q; if (row < m) Ua[row] = uv[r]; }
+        }
+        __syncthreads();
+    };
+    STiles ta, tb;
+    request(0, ta);
+    request(1, tb);
+    __syncthreads();                                   // Y(0) is staged
+    for (int t = 0; t < T; t += 2) {
+        step(t, ta);
+        if (t + 1 < T) step(t + 1, tb);
+    }
+}
+
+template <int NCZ, int NCU>
+__device__ __forceinline__ void forward_sc_cost(double *sh, RecLayout L, FusedArgs F, int T, int n_alpha, const double *__restrict__ rec,
+               double *__restrict__ cost_pred)
+{
+    const int n = L.n, m = L.m;
+    const int lane = threadIdx.x & 63, c = lane & 15, q = lane >> 4;
+    const int b = blockIdx.x;
+    const int nr = F.nr;
+    const int strideB = L.stride * 8;
+    const int ncx = (n + 3) >> 2;
+    ColOffs co;
+    int oRxT[4], oRuT[4], oR[4];
+    double wcur[4], wterm[4];
+#pragma unroll
+    for (int r = 0; r < 4; r++) {
+        const int row = 4 * r + q;
+        co.a[r] = (row < n && c < n) ? 8 * (L.off_A + row * n + c) : OOBF;
+        co.b[r] = (row < n && c < m) ? 8 * (L.off_B + row * m + c) : OOBF;
+        oRxT[r] = (row < n && c < nr) ? 8 * (c * n + row) : OOBF;     // RxT(p=row, k=c) = r_x[k][p]
+        oRuT[r] = (row < m && c < nr) ? 8 * (c * m + row) : OOBF;     // RuT(p=row, k=c) = r_u[k][p]
+        oR[r] = (row < nr) ? 8 * row : OOBF;
+        wcur[r] = (row < nr) ? F.w_run[row] : 0.0;
+        wterm[r] = (row < nr) ? F.w_term[row] : 0.0;   // in registers from the start: a load inside the time loop makes the
+                                                       // compiler drain every outstanding prefetch (vmcnt(0)) each step here
+    }
+    const d4 zero = {0.0, 0.0, 0.0, 0.0};
+    double partial = 0.0;
+    const double *R0 = rec + (size_t)b * T * L.stride;
+    __amdgpu_buffer_rsrc_t rT = frsrc(R0, T * strideB);
+    const double *rb = F.r + (size_t)b * (T + 1) * nr;
+    const double *rxb = F.r_x + (size_t)b * (T + 1) * nr * n;
+    const double *rub = F.r_u + (size_t)b * (T + 1) * nr * m;
+    struct CTiles { d4 RxT, RuT, rv; };
+    const __amdgpu_buffer_rsrc_t rNone = frsrc(rb, 0);
+    auto request = [&](int t, CTiles &s_) {
+        const bool ok = t < T;
+        __amdgpu_buffer_rsrc_t rRx = ok ? frsrc(rxb + (size_t)t * nr * n, nr * n * 8) : rNone;
+        __amdgpu_buffer_rsrc_t rRu = ok ? frsrc(rub + (size_t)t * nr * m, nr * m * 8) : rNone;
+        __amdgpu_buffer_rsrc_t rR = ok ? frsrc(rb + (size_t)t * nr, nr * 8) : rNone;
+        s_.RxT.x = fbld(rRx, oRxT[0]); s_.RxT.y = fbld(rRx, oRxT[1]); s_.RxT.z = fbld(rRx, oRxT[2]); s_.RxT.w = fbld(rRx, oRxT[3]);
+        s_.RuT.x = fbld(rRu, oRuT[0]); s_.RuT.y = NCU > 1 ? fbld(rRu, oRuT[1]) : 0.0;
+        s_.RuT.z = NCU > 2 ? fbld(rRu, oRuT[2]) : 0.0; s_.RuT.w = NCU > 3 ? fbld(rRu, oRuT[3]) : 0.0;
+        s_.rv.x = fbld(rR, oR[0]); s_.rv.y = fbld(rR, oR[1]); s_.rv.z = fbld(rR, oR[2]); s_.rv.w = fbld(rR, oR[3]);
+    };
+    // ---- column tracker, walking UP in time (as in forward_fused_body) ----
+    const int kd = (c < F.dof) ? c : c - F.dof;
+    const bool has = c < n;
+    const int klo = has ? F.kp_offsets[(size_t)b * F.dof + kd] : 0;
+    const int khi = has ? F.kp_offsets[(size_t)b * F.dof + kd + 1] : 0;
+    int idx = klo;
+    int s = has ? F.kp_times[idx] : 0;
+    int e = (has && idx + 1 < khi) ? F.kp_times[idx + 1] : BIGT;
+    int nb = (has && idx + 2 < khi) ? F.kp_times[idx + 2] : BIGT;
+    double sv[8], ev[8], av[8];
+    load_col(rT, co, has ? s : BIGT, T, strideB, sv);
+    load_col(rT, co, e, T, strideB, ev);
+    bool pend = true;
+#pragma unroll
+    for (int i = 0; i < 8; i++) av[i] = 0.0;
+#pragma unroll
+    for (int r = 0; r < 4; r++) if ((c == n || c == n + 1) && 4 * r + q == c) sv[r] = 1.0;
+    auto stage_cols = [&](int t) {
+        double *shA = sh + FSC_YS + (t & 1) * FSC_Y, *shB = shA + 272;
+        const double dt = (double)(t - s);
+        shA[(q) * 17 + c] = lerp_nc(sv[0], dt, av[0]);      shA[(4 + q) * 17 + c] = lerp_nc(sv[1], dt, av[1]);
+        shA[(8 + q) * 17 + c] = lerp_nc(sv[2], dt, av[2]);  shA[(12 + q) * 17 + c] = lerp_nc(sv[3], dt, av[3]);
+        shB[(q) * 17 + c] = lerp_nc(sv[4], dt, av[4]);      shB[(4 + q) * 17 + c] = lerp_nc(sv[5], dt, av[5]);
+        shB[(8 + q) * 17 + c] = lerp_nc(sv[6], dt, av[6]);  shB[(12 + q) * 17 + c] = lerp_nc(sv[7], dt, av[7]);
+    };
+    auto advance = [&](int t) {
+        if (pend) {
+            const double den = (double)(e - s);
+            const double rinv = kp_rcp(den);
+#pragma unroll
+            for (int i = 0; i < 8; i++) av[i] = (e != BIGT) ? fdiv(ev[i] - sv[i], den, rinv) : 0.0;
+            pend = false;
+        }
+        if (t >= e) {
+#pragma unroll
+            for (int i = 0; i < 8; i++) { sv[i] = ev[i]; av[i] = 0.0; }
+            s = e; e = nb; idx++;
+            load_col(rT, co, e, T, strideB, ev);
+            nb = (idx + 2 < khi) ? F.kp_times[idx + 2] : BIGT;
+            pend = true;
+        }
+    };
+    // iteration t: score step t-1 (tiles re-requested for step t+1 right behind their use), then stage the A, B columns of
+    // step t+1 for wave S
+    auto iter = [&](int t, CTiles &s_) {               // s_ holds the tiles of step t-1
+        if (t >= 1) {
+            const int tt = t - 1;
+            const double *zs = sh + FSC_ZS + (tt & 1) * 512;
+            const d4 Zt = lds_tile4(zs, lane), dU = lds_tile4(zs + 256, lane);
+            const d4 Ju = PS<NCU>(s_.RuT, dU, zero);
+            const d4 Jx = PR(s_.RxT, Zt, zero, ncx);
+            const d4 r2 = s_.rv + s_.rv;
+            __builtin_amdgcn_sched_barrier(0);
+            request(tt + 2, s_);
+            __builtin_amdgcn_sched_barrier(0);
+            if (tt == T - 1) {                // terminal weights at the last step (Optimiser.cpp:209-211)
+#pragma unroll
+                for (int r = 0; r < 4; r++) wcur[r] = wterm[r];
+            }
+            // sum_k w_k [Jx_k (2 r_k + Jx_k) + Ju_k (2 r_k + Ju_k)]
+            partial += wcur[0] * (Jx.x * (r2.x + Jx.x) + Ju.x * (r2.x + Ju.x))
+                     + wcur[1] * (Jx.y * (r2.y + Jx.y) + Ju.y * (r2.y + Ju.y))
+                     + wcur[2] * (Jx.z * (r2.z + Jx.z) + Ju.z * (r2.z + Ju.z))
+                     + wcur[3] * (Jx.w * (r2.w + Jx.w) + Ju.w * (r2.w + Ju.w));
+        }
+        if (t + 1 < T) { advance(t + 1); stage_cols(t + 1); }
+        if (t < T) __syncthreads();
+    };
+    CTiles ta, tb;                                     // ta: even steps, tb: odd steps
+    request(0, ta);
+    request(1, tb);
+    stage_cols(0);
+    __syncthreads();
+    iter(0, tb);
+    for (int t = 1; t <= T; t += 2) {
+        iter(t, ta);                                   // scores the even step t-1
+        if (t + 1 <= T) iter(t + 1, tb);               // scores the odd step t
+    }
+    partial += __shfl_xor(partial, 16);
+    partial += __shfl_xor(partial, 32);
+    if (q == 0 && c < n_alpha) cost_pred[(size_t)b * n_alpha + c] = partial;
+}
+
+template <int NCZ, int NCU>
+__global__ void __launch_bounds__(128) __attribute__((amdgpu_waves_per_eu(1, 1)))
+k_forward_fused_sc(RecLayout L, FusedArgs F, int T, int n_alpha, const double *__restrict__ rec, const double *__restrict__ Kin,
+                   const double *__restrict__ kin, const double *__restrict__ u_nom, const double *__restrict__ ctrl_lim,
+                   const double *__restrict__ alphas, double *__restrict__ cost_pred, double *__restrict__ U_alpha)
+{
+    __shared__ __attribute__((aligned(16))) double sh[FSC_TOTAL];
+    const bool state = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6) == 0;
+    if (state) forward_sc_state<NCZ, NCU>(sh, L, T, n_alpha, Kin, kin, u_nom, ctrl_lim, alphas, U_alpha);
+    else       forward_sc_cost<NCZ, NCU>(sh, L, F, T, n_alpha, rec, cost_pred);
 }
 
 bool fused_supported(int n, int m, int nr, int dof, int T, int stride, int n_alpha)
@@ -1190,6 +1431,20 @@ hipError_t launch_forward_fused(Ctx *c, double *U_alpha_dev)
     dim3 grid(c->d.batch), block(64);
     const bool excl = c->d.batch <= c->n_simd;
     const FusedArgs F = fused_args(c);
+    // state / cost wave pair while each wave gets its own SIMD (KPILQR_FUSED_FWD_WAVES = 1 | 2 forces a form)
+    const char *ew = getenv("KPILQR_FUSED_FWD_WAVES");
+    const int form = ew ? atoi(ew) : (2 * c->d.batch <= c->n_simd ? 2 : 1);
+    if (form == 2) {
+        dim3 block2(128);
+        if (n == 14 && m == 7)
+            hipLaunchKernelGGL((k_forward_fused_sc<4, 2>), grid, block2, 0, c->stream, c->L, F, c->d.T, c->d.n_alpha, c->rec, c->K, c->k,
+                               c->u_nom, c->ctrl_lim, c->alphas, c->cost_pred, U_alpha_dev);
+        else if (n == 4 && m == 1)
+            hipLaunchKernelGGL((k_forward_fused_sc<2, 1>), grid, block2, 0, c->stream, c->L, F, c->d.T, c->d.n_alpha, c->rec, c->K, c->k,
+                               c->u_nom, c->ctrl_lim, c->alphas, c->cost_pred, U_alpha_dev);
+        else return hipErrorInvalidValue;
+        return hipGetLastError();
+    }
 #define LAUNCH(NCZ, NCU)                                                                                          \
     do {                                                                                                          \
         if (excl)                                                                                                 \
