@@ -87,7 +87,7 @@ def main():
     ap.add_argument("--unfused", action="store_true",
                     help="materialise A,B (interpolate) and l_* (cost_derivs) with their own kernels instead of "
                          "evaluating them inside the sweeps (KPILQR_FLAG_FUSED)")
-    ap.add_argument("--fused", action="store_true", help="force the fused sweeps even below the crossover batch (384)")
+    ap.add_argument("--fused", action="store_true", help="(default) fused sweeps: a4+a6 inside a7/a8")
     ap.add_argument("--no-secondary", action="store_true", help="skip the materialising-pipeline side measurement")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     args = ap.parse_args()
@@ -125,9 +125,9 @@ def main():
     torch.cuda.set_stream(stream)
     eng = Engine(p["dof"], p["m"], T, p["nr"], batch=B, device=local_rank, stream=stream.cuda_stream,
                  generic=args.generic,
-                 # below ~384 trajectories per GPU the elementwise stages are too small to be worth folding into the
-                 # latency-bound sweeps (profiles/r01_fused_crossover.txt): B=1 142 it/s unfused vs 115 fused
-                 fused=not args.unfused and not args.generic and (args.fused or B >= 384))
+                 # fused sweeps at every batch size: wave pairs per trajectory up to #SIMDs/2 trajectories, one wave
+                 # per trajectory beyond (tools/small_batch_variants.sh: B=1 161 vs 143 it/s materialising)
+                 fused=not args.unfused and not args.generic)
     fused = "fused" in eng.backward_variant
     synth.upload(eng, p)
     lam = np.full(B, p["lam"])
