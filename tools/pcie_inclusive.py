@@ -22,7 +22,7 @@ def pinned(a):
 keep = []
 for k in ("xplus", "xminus", "xnom", "r", "r_x", "r_u"):
     t, v = pinned(p[k]); keep.append(t); p[k] = v
-e = Engine(p["dof"], p["m"], T, p["nr"], batch=B)
+e = Engine(p["dof"], p["m"], T, p["nr"], batch=B, fused=True)
 synth.upload(e, p)
 tK, K = pinned(np.zeros((B, T, e.n, e.m))); tk, kk = pinned(np.zeros((B, T, e.m)))
 lam = np.full(B, 0.1)
