@@ -376,6 +376,32 @@ def test_tiled_mfma_large_state(task, T, batch):
         assert relerr(g["cost_pred"][b], o["cost_pred"]) < 1e-9
 
 
+@pytest.mark.parametrize("task,T,batch", [("walker", 150, 2), ("hopper", 150, 2), ("pentabot", 100, 2), ("arm8", 120, 2)])
+def test_tiled_mfma_other_control_dims(task, T, batch):
+    """num_ctrl other than 1 and 7 (walker 6, hopper / pentabot 3, an 8-joint arm) run on the tiled MFMA kernels
+    through the padded catch-all instantiation of the backward kernel, small states with two tiles."""
+    p = synth.make_problem(task=task, T=T, batch=batch, min_N=3, dense_residuals=True, one_sided_frac=0.1)
+    g = run_engine(p)
+    # (the one-tile forward kernel takes any n + 2 <= 16, m <= 8; larger states use the tiled forward kernel)
+    assert g["variants"][0] == "mfma_f64_tiled" and g["variants"][1] in ("mfma_f64_tiled", "mfma_f64_t1"), g["variants"]
+    for b in range(batch):
+        o = pipeline.run_trajectory(p, b, want_U=True)
+        assert g["status"][b] == 0
+        assert relerr(g["K"][b], o["K"]) < K_RTOL_TIGHT, relerr(g["K"][b], o["K"])
+        assert relerr(g["k"][b], o["k"]) < K_RTOL_TIGHT
+        assert abs(g["delta_J"][b] - o["delta_J"]) <= 1e-9 * abs(o["delta_J"])
+        assert relerr(g["cost_pred"][b], o["cost_pred"]) < 1e-9
+        assert relerr(g["U_alpha"][b], o["U_alpha"]) < 1e-9
+    # indefinite Quu + lambda I on a checked step is reported at the same step as by the oracle
+    p["w_run"] = -np.abs(p["w_run"]) - 1.0
+    with Engine(p["dof"], p["m"], p["T"], p["nr"], batch=batch) as e:
+        synth.upload(e, p)
+        e.fd_difference(); e.interpolate(); e.cost_derivs()
+        st, _ = e.backward(1e-4, 1)
+    o = [pipeline.run_trajectory(p, b, lam=1e-4, pd_stride=1, stages=("fd", "interp", "cost", "bwd"))["status"] for b in range(batch)]
+    assert list(st) == o and all(v > 0 for v in o)
+
+
 # ---- fused sweeps (KPILQR_FLAG_FUSED): a4 + a6 evaluated inside the backward / forward kernels --------------
 def run_fused(p, pd_stride=100, lam=None, n_alpha=6, use_iterate=False):
     lam = p["lam"] if lam is None else lam

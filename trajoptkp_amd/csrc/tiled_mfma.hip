@@ -142,7 +142,10 @@ k_backward_tiled_col(RecLayout L, int T, const double *__restrict__ rec, const d
     extern __shared__ __attribute__((aligned(16))) double sh[];
     constexpr int NCU = (M + 3) / 4;
     constexpr int NZZ = NT * NT;
-    const int n = L.n, m = M, nz = n + 1;
+    // M = 8 is the catch-all instantiation for any num_ctrl <= 8 (walker 6, hopper / pentabot 3, ...): the m x m system is
+    // padded with identity rows to 8 x 8 for the (rare) per-lane LDL' steps; everything else works on tiles anyway.
+    constexpr bool PAD = (M == 8);
+    const int n = L.n, m = PAD ? L.m : M, nz = n + 1;
     const int lane = threadIdx.x & 63, c = lane & 15, q = lane >> 4;
     const int w = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);    // this wave's column tile (wave-uniform)
     const int b = blockIdx.x;
@@ -268,7 +271,10 @@ k_backward_tiled_col(RecLayout L, int T, const double *__restrict__ rec, const d
         }
         if (!done) {
             lds_store(sQ, lane, Qr);                  // this wave's private image (same-wave LDS accesses are ordered)
-            auto qel = [&](int i, int j) { return sQ[(i >> 2) * 64 + j + 16 * (i & 3)]; };
+            auto qel = [&](int i, int j) {
+                if (PAD && (i >= m || j >= m)) return (i == j) ? 1.0 : 0.0;
+                return sQ[(i >> 2) * 64 + j + 16 * (i & 3)];
+            };
             double Lm[M][M], rd[M];
             const bool pos = kp_ldl_factor<M>([&](int i, int j) { return qel(i, j); }, Lm, rd);
             if (check_pd) {                       // CheckMatrixPD every pd_stride steps   :587-595
@@ -305,7 +311,7 @@ k_backward_tiled_col(RecLayout L, int T, const double *__restrict__ rec, const d
                 for (int i = 0; i < M; i++) {
                     double sacc = 0.0;
 #pragma unroll
-                    for (int pp = 0; pp < M; pp++) sacc += (-winv[i + pp * m]) * x[pp];
+                    for (int pp = 0; pp < M; pp++) sacc += (!PAD || (i < m && pp < m)) ? (-winv[i + pp * m]) * x[pp] : 0.0;
                     y[i] = -sacc;
                 }
 #pragma unroll
@@ -387,7 +393,7 @@ static int tiled_nt(int n)
 bool backward_tiled_supported(int n, int m)
 {
     const int nt = tiled_nt(n);
-    return nt >= 2 && nt <= 4 && (m == 7 || m == 1) && backward_tiled_lds_bytes(nt) <= 160 * 1024;
+    return nt >= 2 && nt <= 4 && m >= 1 && m <= 8 && backward_tiled_lds_bytes(nt) <= 160 * 1024;
 }
 
 template <int M, int NT>
@@ -406,6 +412,7 @@ hipError_t launch_backward_tiled(Ctx *c, int pd_stride)
     const int nt = tiled_nt(c->n), m = c->d.m;
     if (m == 7) { if (nt == 2) return launch_bt<7, 2>(c, pd_stride); if (nt == 3) return launch_bt<7, 3>(c, pd_stride); if (nt == 4) return launch_bt<7, 4>(c, pd_stride); }
     if (m == 1) { if (nt == 2) return launch_bt<1, 2>(c, pd_stride); if (nt == 3) return launch_bt<1, 3>(c, pd_stride); if (nt == 4) return launch_bt<1, 4>(c, pd_stride); }
+    if (m >= 1 && m <= 8) { if (nt == 2) return launch_bt<8, 2>(c, pd_stride); if (nt == 3) return launch_bt<8, 3>(c, pd_stride); if (nt == 4) return launch_bt<8, 4>(c, pd_stride); }
     return hipErrorInvalidValue;
 }
 

@@ -22,6 +22,17 @@ TASKS = {
     # TaskConfigs/rigid_body_manipulation/twoD_push_heavy_clutter.yaml:12-136
     "high_dof_push": dict(dof=31, m=7, nr=11, dt=0.008, lim=[87, 87, 87, 87, 12, 12, 12],
                           w_run=[1.0, 0.5] + [0.1] * 9, w_term=[100.0, 50.0] + [1.0] * 9),
+    # other control dimensions among the reference's task plugins (joint / actuator counts of
+    # TaskConfigs/locomotion/walk_plane.yaml, locomotion/hopper.yaml, toys/pentabot.yaml); weights synthetic
+    "walker": dict(dof=9, m=6, nr=4, dt=0.005, lim=[1.0] * 6,
+                   w_run=[1.0, 0.5, 0.1, 0.01], w_term=[10.0, 5.0, 1.0, 0.1]),
+    "hopper": dict(dof=6, m=3, nr=4, dt=0.005, lim=[1.0] * 3,
+                   w_run=[1.0, 0.5, 0.1, 0.01], w_term=[10.0, 5.0, 1.0, 0.1]),
+    "pentabot": dict(dof=5, m=3, nr=3, dt=0.01, lim=[5.0] * 3,
+                     w_run=[1.0, 0.1, 0.01], w_term=[100.0, 1.0, 0.1]),
+    # a fully actuated 8-joint arm: num_ctrl = 8, the largest the padded tiled backward kernel takes
+    "arm8": dict(dof=8, m=8, nr=6, dt=0.008, lim=[50.0] * 8,
+                 w_run=[1.0, 0.5, 0.1, 0.1, 0.01, 0.01], w_term=[100.0, 50.0, 1.0, 1.0, 0.1, 0.1]),
 }
 
 
