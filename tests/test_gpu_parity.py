@@ -345,7 +345,7 @@ def test_empty_fd_upload_and_rerun_is_idempotent():
 
 def test_set_AB_and_cost_derivs_hooks_roundtrip():
     rng = np.random.default_rng(5)
-    with Engine(3, 2, 9, 4, batch=2) as e:      # odd sizes: n=6, m=2 (generic kernels)
+    with Engine(3, 2, 9, 4, batch=2) as e:      # odd sizes: n=6, m=2 (tiled kernels through the catch-all num_ctrl instantiation)
         A = rng.standard_normal((2, 9, 6, 6)); B = rng.standard_normal((2, 9, 2, 6))
         lx = rng.standard_normal((2, 9, 6)); lxx = rng.standard_normal((2, 9, 6, 6))
         lu = rng.standard_normal((2, 9, 2)); luu = rng.standard_normal((2, 9, 2, 2))
@@ -354,7 +354,7 @@ def test_set_AB_and_cost_derivs_hooks_roundtrip():
         assert np.array_equal(A, A2) and np.array_equal(B, B2)
         for x, y in zip((lx, lxx, lu, luu), g):
             assert np.array_equal(x, y)
-        assert e.backward_variant == "generic_lds"
+        assert e.backward_variant == "mfma_f64_tiled"
 
 
 @pytest.mark.parametrize("task,T,batch", [("panda_pushing", 60, 2), ("high_dof_push", 24, 2), ("panda_pushing", 301, 3)])
@@ -403,6 +403,17 @@ def test_tiled_mfma_other_control_dims(task, T, batch):
 
 
 # ---- fused sweeps (KPILQR_FLAG_FUSED): a4 + a6 evaluated inside the backward / forward kernels --------------
+@pytest.fixture(params=["auto", "one_wave"])
+def wave_form(request, monkeypatch):
+    """The fused sweeps choose their wave organisation from the batch size (wave pairs per trajectory up to #SIMDs/2
+    trajectories, one wave per trajectory beyond): the small parity cases would only ever see the pairs, so they are
+    also run with the one-wave kernels of the headline batch forced."""
+    if request.param == "one_wave":
+        monkeypatch.setenv("KPILQR_FUSED_WAVES", "1")
+        monkeypatch.setenv("KPILQR_FUSED_FWD_WAVES", "1")
+    return request.param
+
+
 def run_fused(p, pd_stride=100, lam=None, n_alpha=6, use_iterate=False):
     lam = p["lam"] if lam is None else lam
     with Engine(p["dof"], p["m"], p["T"], p["nr"], batch=p["batch"], n_alpha=n_alpha, fused=True) as e:
@@ -435,7 +446,7 @@ def check_fused(g, p, ref=None):
             assert relerr(g["U_alpha"][b], o["U_alpha"]) < 1e-9
 
 
-def test_fused_sweeps_match_oracle(case):
+def test_fused_sweeps_match_oracle(case, wave_form):
     name, p, ref = case
     if p["dof"] * 2 + 2 > 16:
         with Engine(p["dof"], p["m"], p["T"], p["nr"], batch=p["batch"], fused=True) as e:
@@ -445,7 +456,7 @@ def test_fused_sweeps_match_oracle(case):
     check_fused(run_fused(p, use_iterate=True), p, ref)
 
 
-def test_fused_ragged_keypoints_and_dense_keypoints():
+def test_fused_ragged_keypoints_and_dense_keypoints(wave_form):
     """Per-DoF key-point lists (every lane walks its own list), and key-points at EVERY step."""
     T, dof = 120, 7
     p = synth.make_problem(task="panda_reaching", T=T, batch=2, min_N=1, dense_residuals=True)
@@ -467,14 +478,14 @@ def test_fused_ragged_keypoints_and_dense_keypoints():
 
 
 @pytest.mark.parametrize("T", [1, 2, 3, 7])
-def test_fused_tiny_horizons(T):
+def test_fused_tiny_horizons(T, wave_form):
     if T == 1:
         pytest.skip("the reference's key-point generators need T >= 2")
     p = synth.make_problem(task="panda_reaching", T=T, batch=2, min_N=5, dense_residuals=True)
     check_fused(run_fused(p), p)
 
 
-def test_fused_full_size_panda_T3000():
+def test_fused_full_size_panda_T3000(wave_form):
     p = synth.make_problem(task="panda_reaching", T=3000, batch=2, min_N=5)
     g = run_fused(p)
     gu = run_engine(p)
@@ -485,7 +496,7 @@ def test_fused_full_size_panda_T3000():
     check_fused(g, p)                                            # ... and against the oracle
 
 
-def test_fused_pd_failure_and_noncanonical_keypoints():
+def test_fused_pd_failure_and_noncanonical_keypoints(wave_form):
     p = synth.make_problem(task="panda_reaching", T=64, batch=2, min_N=5, dense_residuals=True)
     p["w_run"] = p["w_run"].copy(); p["w_term"] = p["w_term"].copy()
     # negative control-residual weights make l_uu (hence Q_uu + lambda I) indefinite
@@ -610,7 +621,7 @@ def test_svr_dof_importance_and_alphas():
         assert relerr(U[b], U_ref) < 1e-9
 
 
-def test_fused_batch_independence_lambda_clamp_and_alphas():
+def test_fused_batch_independence_lambda_clamp_and_alphas(wave_form):
     """The scenario tests of the materialising pipeline, on the fused sweeps."""
     # replicas are bit-identical; a trajectory does not depend on its batch neighbours
     p1 = synth.make_problem(task="panda_reaching", T=200, batch=2, min_N=5)
@@ -692,7 +703,7 @@ def test_fused_two_wave_backward_variant(monkeypatch, waves):
     assert list(st) == o and all(v > 0 for v in o)
 
 
-def test_fused_long_horizon_ragged_keypoints():
+def test_fused_long_horizon_ragged_keypoints(wave_form):
     """T=1500 with very different key-point densities per DoF (one DoF only at 0 and T-1: a single 1499-step
     segment; one DoF at every step), fused against the oracle and against the materialising kernels."""
     T, dof = 1500, 7
@@ -718,7 +729,7 @@ def test_fused_long_horizon_ragged_keypoints():
     check_fused(g, p)
 
 
-def test_fused_indefinite_quu_on_unchecked_steps():
+def test_fused_indefinite_quu_on_unchecked_steps(wave_form):
     """Q_uu + lambda I indefinite while no PD check is due (pd_stride > T): the reference inverts it anyway with
     Eigen's pivoted LDLT (iLQR.cpp:597-604).  The fused backward pass (running-inverse fast path, LDL' fallback,
     pivoted slow path) must land on the same gains."""
