@@ -376,10 +376,10 @@ def test_tiled_mfma_large_state(task, T, batch):
         assert relerr(g["cost_pred"][b], o["cost_pred"]) < 1e-9
 
 
-@pytest.mark.parametrize("task,T,batch", [("walker", 150, 2), ("hopper", 150, 2), ("pentabot", 100, 2), ("arm8", 120, 2)])
+@pytest.mark.parametrize("task,T,batch", [("walker", 150, 2), ("arm8", 120, 2), ("arm5x2", 100, 2)])
 def test_tiled_mfma_other_control_dims(task, T, batch):
-    """num_ctrl other than 1 and 7 (walker 6, hopper / pentabot 3, an 8-joint arm) run on the tiled MFMA kernels
-    through the padded catch-all instantiation of the backward kernel, small states with two tiles."""
+    """num_ctrl other than 1 and 7 (walker 6, an 8-joint arm, a 5-joint arm with 2 motors) run on the tiled MFMA
+    kernels through the padded catch-all instantiation of the backward kernel, small states with two tiles."""
     p = synth.make_problem(task=task, T=T, batch=batch, min_N=3, dense_residuals=True, one_sided_frac=0.1)
     g = run_engine(p)
     # (the one-tile forward kernel takes any n + 2 <= 16, m <= 8; larger states use the tiled forward kernel)
@@ -400,6 +400,19 @@ def test_tiled_mfma_other_control_dims(task, T, batch):
         st, _ = e.backward(1e-4, 1)
     o = [pipeline.run_trajectory(p, b, lam=1e-4, pd_stride=1, stages=("fd", "interp", "cost", "bwd"))["status"] for b in range(batch)]
     assert list(st) == o and all(v > 0 for v in o)
+
+
+@pytest.mark.parametrize("task,T,batch", [("hopper", 150, 2), ("pentabot", 100, 3)])
+def test_one_tile_shapes_of_the_other_task_plugins(task, T, batch, wave_form):
+    """hopper / floating cube (n=12, m=3) and pentabot (n=10, m=3) have one-tile instantiations like Panda and
+    Acrobot: materialising kernels and fused sweeps (both wave organisations) against the oracle."""
+    p = synth.make_problem(task=task, T=T, batch=batch, min_N=3, dense_residuals=True, one_sided_frac=0.1)
+    g = run_engine(p)
+    assert g["variants"] == ("mfma_f64_t1", "mfma_f64_t1"), g["variants"]
+    ref = [pipeline.run_trajectory(p, b, want_U=True) for b in range(batch)]
+    check_fused(g, p, ref)
+    check_fused(run_fused(p), p, ref)
+    check_fused(run_fused(p, use_iterate=True), p, ref)
 
 
 # ---- fused sweeps (KPILQR_FLAG_FUSED): a4 + a6 evaluated inside the backward / forward kernels --------------

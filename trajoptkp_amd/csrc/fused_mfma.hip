@@ -1365,8 +1365,7 @@ k_forward_fused_sc(RecLayout L, FusedArgs F, int T, int n_alpha, const double *_
 
 bool fused_supported(int n, int m, int nr, int dof, int T, int stride, int n_alpha)
 {
-    const bool shape = (n == 14 && m == 7) || (n == 4 && m == 1);
-    return shape && nr >= 1 && nr <= 16 && m <= dof && n_alpha <= 16 && (long long)T * stride * 8 < 0x7ffffff0LL;
+    return kp_t1_shape(n, m) && nr >= 1 && nr <= 16 && m <= dof && n_alpha <= 16 && (long long)T * stride * 8 < 0x7ffffff0LL;
 }
 
 static FusedArgs fused_args(const Ctx *c)
@@ -1403,11 +1402,11 @@ hipError_t launch_backward_fused(Ctx *c, int pd_stride)
             if (pexcl) hipLaunchKernelGGL((k_backward_fusedpc_excl<NN, MM>), grid, block2, 0, c->stream, c->L, F, c->d.T, role_shift, c->rec, c->lambda, pd_stride, c->K, c->k, c->delta_J, c->status); \
             else hipLaunchKernelGGL((k_backward_fusedpc<NN, MM>), grid, block2, 0, c->stream, c->L, F, c->d.T, role_shift, c->rec, c->lambda, pd_stride, c->K, c->k, c->delta_J, c->status); \
         } while (0)
-        if (n == 14 && m == 7) LAUNCHPC(14, 7);
-        else if (n == 4 && m == 1) LAUNCHPC(4, 1);
-        else return hipErrorInvalidValue;
+#define KP_X(NN, MM) if (n == NN && m == MM) { LAUNCHPC(NN, MM); return hipGetLastError(); }
+        KP_T1_SHAPES(KP_X)
+#undef KP_X
 #undef LAUNCHPC
-        return hipGetLastError();
+        return hipErrorInvalidValue;
     }
 #define LAUNCH(NN, MM)                                                                                       \
     do {                                                                                                     \
@@ -1418,11 +1417,11 @@ hipError_t launch_backward_fused(Ctx *c, int pd_stride)
             hipLaunchKernelGGL((k_backward_fused<NN, MM>), grid, block, 0, c->stream, c->L, F, c->d.T,       \
                                c->rec, c->lambda, pd_stride, c->K, c->k, c->delta_J, c->status);             \
     } while (0)
-    if (n == 14 && m == 7) LAUNCH(14, 7);
-    else if (n == 4 && m == 1) LAUNCH(4, 1);
-    else return hipErrorInvalidValue;
+#define KP_X(NN, MM) if (n == NN && m == MM) { LAUNCH(NN, MM); return hipGetLastError(); }
+    KP_T1_SHAPES(KP_X)
+#undef KP_X
 #undef LAUNCH
-    return hipGetLastError();
+    return hipErrorInvalidValue;
 }
 
 hipError_t launch_forward_fused(Ctx *c, double *U_alpha_dev)
@@ -1434,16 +1433,18 @@ hipError_t launch_forward_fused(Ctx *c, double *U_alpha_dev)
     // state / cost wave pair while each wave gets its own SIMD (KPILQR_FUSED_FWD_WAVES = 1 | 2 forces a form)
     const char *ew = getenv("KPILQR_FUSED_FWD_WAVES");
     const int form = ew ? atoi(ew) : (2 * c->d.batch <= c->n_simd ? 2 : 1);
+    const int ncz = (n + 2 + 3) / 4, ncu = (m + 3) / 4;       // tile chunks of [dx; alpha; 1] and of the controls
     if (form == 2) {
         dim3 block2(128);
-        if (n == 14 && m == 7)
-            hipLaunchKernelGGL((k_forward_fused_sc<4, 2>), grid, block2, 0, c->stream, c->L, F, c->d.T, c->d.n_alpha, c->rec, c->K, c->k,
-                               c->u_nom, c->ctrl_lim, c->alphas, c->cost_pred, U_alpha_dev);
-        else if (n == 4 && m == 1)
-            hipLaunchKernelGGL((k_forward_fused_sc<2, 1>), grid, block2, 0, c->stream, c->L, F, c->d.T, c->d.n_alpha, c->rec, c->K, c->k,
-                               c->u_nom, c->ctrl_lim, c->alphas, c->cost_pred, U_alpha_dev);
-        else return hipErrorInvalidValue;
-        return hipGetLastError();
+#define LAUNCHSC(NCZ, NCU)                                                                                              \
+        if (ncz == NCZ && ncu == NCU) {                                                                                 \
+            hipLaunchKernelGGL((k_forward_fused_sc<NCZ, NCU>), grid, block2, 0, c->stream, c->L, F, c->d.T, c->d.n_alpha, c->rec, \
+                               c->K, c->k, c->u_nom, c->ctrl_lim, c->alphas, c->cost_pred, U_alpha_dev);                \
+            return hipGetLastError();                                                                                   \
+        }
+        LAUNCHSC(4, 2) LAUNCHSC(2, 1) LAUNCHSC(4, 1) LAUNCHSC(3, 1)
+#undef LAUNCHSC
+        return hipErrorInvalidValue;
     }
 #define LAUNCH(NCZ, NCU)                                                                                          \
     do {                                                                                                          \
@@ -1456,11 +1457,11 @@ hipError_t launch_forward_fused(Ctx *c, double *U_alpha_dev)
                                c->d.n_alpha, c->rec, c->K, c->k, c->u_nom, c->ctrl_lim, c->alphas, c->cost_pred,  \
                                U_alpha_dev);                                                                      \
     } while (0)
-    if (n == 14 && m == 7) LAUNCH(4, 2);
-    else if (n == 4 && m == 1) LAUNCH(2, 1);
-    else return hipErrorInvalidValue;
+#define KP_X(NCZ, NCU) if (ncz == NCZ && ncu == NCU) { LAUNCH(NCZ, NCU); return hipGetLastError(); }
+    KP_X(4, 2) KP_X(2, 1) KP_X(4, 1) KP_X(3, 1)
+#undef KP_X
 #undef LAUNCH
-    return hipGetLastError();
+    return hipErrorInvalidValue;
 }
 
 }  // namespace kpilqr

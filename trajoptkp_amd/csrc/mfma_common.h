@@ -34,6 +34,18 @@ __device__ __forceinline__ double kp_rcp(double x)
 
 // acc + Y'X over NC 4-row chunks: the one primitive of these kernels (tiles in the accumulator layout are their own
 // transpose as the A operand and the next B operand as they are).
+// One-tile shapes (n + 1 <= 16) that have their own backward / fused kernel instantiations: Panda reaching and push_soft
+// (14,7), Acrobot and piston (4,1), hopper and floating cube (12,3), pentabot (10,3) -- the joint / actuator counts of the
+// reference's TaskConfigs.  Everything else goes to the tiled kernels (any n + 2 <= 64, num_ctrl <= 8).
+#define KP_T1_SHAPES(X) X(14, 7) X(4, 1) X(12, 3) X(10, 3)
+static inline bool kp_t1_shape(int n, int m)
+{
+#define KP_X(NN, MM) if (n == NN && m == MM) return true;
+    KP_T1_SHAPES(KP_X)
+#undef KP_X
+    return false;
+}
+
 template <int NC>
 __device__ __forceinline__ d4 kp_P(const d4 &Y, const d4 &X, d4 acc)
 {

@@ -339,7 +339,7 @@ k_backward_mfma_excl(RecLayout L, int T, const double *__restrict__ rec, const d
 
 bool backward_mfma_supported(int n, int m)
 {
-    return (n == 14 && m == 7) || (n == 4 && m == 1);
+    return kp_t1_shape(n, m);
 }
 
 hipError_t launch_backward_mfma(Ctx *c, int pd_stride)
@@ -356,11 +356,11 @@ hipError_t launch_backward_mfma(Ctx *c, int pd_stride)
             hipLaunchKernelGGL((k_backward_mfma<NN, MM>), grid, block, 0, c->stream, c->L, c->d.T,        \
                                c->rec, c->lambda, pd_stride, c->K, c->k, c->delta_J, c->status);          \
     } while (0)
-    if (n == 14 && m == 7) LAUNCH(14, 7);
-    else if (n == 4 && m == 1) LAUNCH(4, 1);
-    else return hipErrorInvalidValue;
+#define KP_X(NN, MM) if (n == NN && m == MM) { LAUNCH(NN, MM); return hipGetLastError(); }
+    KP_T1_SHAPES(KP_X)
+#undef KP_X
 #undef LAUNCH
-    return hipGetLastError();
+    return hipErrorInvalidValue;
 }
 
 }  // namespace kpilqr

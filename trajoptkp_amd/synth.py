@@ -30,6 +30,9 @@ TASKS = {
                    w_run=[1.0, 0.5, 0.1, 0.01], w_term=[10.0, 5.0, 1.0, 0.1]),
     "pentabot": dict(dof=5, m=3, nr=3, dt=0.01, lim=[5.0] * 3,
                      w_run=[1.0, 0.1, 0.01], w_term=[100.0, 1.0, 0.1]),
+    # an under-actuated 5-joint arm with 2 motors: a shape with no instantiation of its own (tiled catch-all)
+    "arm5x2": dict(dof=5, m=2, nr=3, dt=0.01, lim=[5.0] * 2,
+                   w_run=[1.0, 0.1, 0.01], w_term=[100.0, 1.0, 0.1]),
     # a fully actuated 8-joint arm: num_ctrl = 8, the largest the padded tiled backward kernel takes
     "arm8": dict(dof=8, m=8, nr=6, dt=0.008, lim=[50.0] * 8,
                  w_run=[1.0, 0.5, 0.1, 0.1, 0.01, 0.01], w_term=[100.0, 50.0, 1.0, 1.0, 0.1, 0.1]),
