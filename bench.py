@@ -286,6 +286,9 @@ def main():
             try:
                 out["cpu_baseline"] = cpu_baseline(args.task, T, args.min_N)
                 out["gpu_over_cpu"] = value / out["cpu_baseline"]["value"]
+                # a single trajectory cannot use 16 CPU threads either: the latency comparison for --batch 1
+                if out["cpu_baseline"].get("single_thread_value"):
+                    out["gpu_over_cpu_single_thread"] = value / out["cpu_baseline"]["single_thread_value"]
             except Exception as ex:   # the baseline is reporting only; never hide the GPU number
                 out["cpu_baseline"] = {"error": repr(ex)}
         print(json.dumps(out), flush=True)
