@@ -39,46 +39,59 @@ k_fd_difference(RecLayout L, int T, int nslots, const int *__restrict__ slot_sta
     if (live) { j0 = slot_start[slot]; nj = slot_start[slot + 1] - j0; }
     for (int cidx = lane; cidx < ncol; cidx += 64) present[cidx] = 0;
     __syncthreads();
-    // four elements per lane per trip: the eight loads are issued before the first division, so a trip exposes one
-    // memory latency instead of four (few waves are resident when the per-slot LDS image is large, n = 62)
-    for (int w0 = lane; w0 < nj * n; w0 += 4 * 64) {
-        double xp[4], xm[4];
+    // eight elements per lane per trip as four 16-byte pairs (n = 2*dof is even, so a pair never straddles two jobs): the
+    // eight loads are issued before the first division, so a trip exposes one memory latency instead of eight (few waves
+    // are resident when the per-slot LDS image is large, n = 62)
+    const int npair = (nj * n) >> 1;
+    const double2 *xp2 = (const double2 *)(xplus + (size_t)j0 * n), *xm2 = (const double2 *)(xminus + (size_t)j0 * n);
+    for (int w0 = lane; w0 < npair; w0 += 4 * 64) {
+        double2 xp[4], xm[4];
         int jobs_[4], rows_[4], modes_[4];
 #pragma unroll
         for (int u = 0; u < 4; u++) {
             const int w = w0 + 64 * u;
-            const bool ok = w < nj * n;
-            const int j = ok ? w / n : 0;
-            rows_[u] = ok ? w - j * n : -1;
+            const bool ok = w < npair;
+            const int j = ok ? (2 * w) / n : 0;
+            rows_[u] = ok ? 2 * w - j * n : -1;
             jobs_[u] = j0 + j;
-            const size_t at = (size_t)jobs_[u] * n + (ok ? rows_[u] : 0);
-            xp[u] = ok ? xplus[at] : 0.0;
-            xm[u] = ok ? xminus[at] : 0.0;
+            xp[u] = ok ? xp2[w] : make_double2(0.0, 0.0);
+            xm[u] = ok ? xm2[w] : make_double2(0.0, 0.0);
             modes_[u] = ok ? job_mode[jobs_[u]] : 0;
         }
 #pragma unroll
         for (int u = 0; u < 4; u++) {
             if (rows_[u] < 0) continue;
             const int job = jobs_[u], row = rows_[u], mode = modes_[u];
-            double v;
+            double v0, v1;
             if (mode == 0) {
-                v = (xp[u] - xm[u]) / (2 * eps);
+                v0 = (xp[u].x - xm[u].x) / (2 * eps);
+                v1 = (xp[u].y - xm[u].y) / (2 * eps);
             } else {
-                const double x0 = xnom[(size_t)job_nom[job] * n + row];
-                v = (mode == 1) ? (xp[u] - x0) / (eps) : (x0 - xm[u]) / (eps);
+                const double *x0 = xnom + (size_t)job_nom[job] * n + row;
+                v0 = (mode == 1) ? (xp[u].x - x0[0]) / (eps) : (x0[0] - xm[u].x) / (eps);
+                v1 = (mode == 1) ? (xp[u].y - x0[1]) / (eps) : (x0[1] - xm[u].y) / (eps);
             }
             const int col = job_col[job];
-            sv[col * n + row] = v;
+            sv[col * n + row] = v0;
+            sv[col * n + row + 1] = v1;
             if (row == 0) present[col] = 1;
         }
     }
     __syncthreads();
     if (live) {
         double *R = rec + ((size_t)job_b[j0] * T + job_t[j0]) * L.stride;
-        for (int e = lane; e < ne; e += 64) {
-            int row, col;
-            if (e < n * n) { row = e / n; col = e - row * n; }
-            else { const int q = e - n * n; row = q / m; col = n + (q - row * m); }
+        // A block: two adjacent columns of a row per lane (n is even and the record is 128-byte aligned: one 16-byte store
+        // when both columns are held by the slot); B block: one element per lane
+        for (int e2 = lane; e2 < (n * n) >> 1; e2 += 64) {
+            const int e = 2 * e2, row = e / n, col = e - row * n;
+            const bool p0 = present[col] != 0, p1 = present[col + 1] != 0;
+            const double v0 = sv[col * n + row], v1 = sv[(col + 1) * n + row];
+            if (p0 && p1) *(double2 *)(R + e) = make_double2(v0, v1);
+            else if (p0) R[e] = v0;
+            else if (p1) R[e + 1] = v1;
+        }
+        for (int e = n * n + lane; e < ne; e += 64) {
+            const int q = e - n * n, row = q / m, col = n + (q - row * m);
             if (present[col]) R[e] = sv[col * n + row];
         }
     }
