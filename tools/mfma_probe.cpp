@@ -6,6 +6,7 @@
 #include <vector>
 typedef double d4 __attribute__((ext_vector_type(4)));
 #define MFMA(a, b, c) __builtin_amdgcn_mfma_f64_16x16x4f64((a), (b), (c), 0, 0, 0)
+#define MFMA4(a, b, c) __builtin_amdgcn_mfma_f64_4x4x4f64((a), (b), (c), 0, 0, 0)
 
 template <int MODE>
 __global__ void __launch_bounds__(64) probe(double *out, unsigned long long *stamps, int iters, double seed)
@@ -36,6 +37,15 @@ __global__ void __launch_bounds__(64) probe(double *out, unsigned long long *sta
             c1 = MFMA(a, b, c1); f2 = __builtin_fma(f2, a, b); f3 = __builtin_fma(f3, a, b);
             c2 = MFMA(a, b, c2); f4 = __builtin_fma(f4, a, b); f5 = __builtin_fma(f5, a, b);
             c3 = MFMA(a, b, c3); f6 = __builtin_fma(f6, a, b); f7 = __builtin_fma(f7, a, b);
+        } else if (MODE == 7) {   // 8 independent v_mfma_f64_4x4x4_4b (four 4x4x4 blocks each; one double per lane in, one out)
+            f0 = MFMA4(a, b, f0); f1 = MFMA4(a, b, f1); f2 = MFMA4(a, b, f2); f3 = MFMA4(a, b, f3);
+            f4 = MFMA4(b, a, f4); f5 = MFMA4(b, a, f5); f6 = MFMA4(b, a, f6); f7 = MFMA4(b, a, f7);
+        } else if (MODE == 8) {   // 8 dependent 4x4x4 (accumulator chain)
+            f0 = MFMA4(a, b, f0); f0 = MFMA4(b, a, f0); f0 = MFMA4(a, b, f0); f0 = MFMA4(b, a, f0);
+            f0 = MFMA4(a, b, f0); f0 = MFMA4(b, a, f0); f0 = MFMA4(a, b, f0); f0 = MFMA4(b, a, f0);
+        } else if (MODE == 9) {   // 8 dependent 4x4x4, result feeds the next B operand
+            f0 = MFMA4(a, f0, f1); f0 = MFMA4(a, f0, f1); f0 = MFMA4(a, f0, f1); f0 = MFMA4(a, f0, f1);
+            f0 = MFMA4(a, f0, f1); f0 = MFMA4(a, f0, f1); f0 = MFMA4(a, f0, f1); f0 = MFMA4(a, f0, f1);
         } else if (MODE == 6) {   // 8 dependent rcp-free divisions emulation: v_rcp_f64 chain
             f0 = __builtin_amdgcn_rcp(f0 + 1.5); f0 = __builtin_amdgcn_rcp(f0 + 1.5); f0 = __builtin_amdgcn_rcp(f0 + 1.5); f0 = __builtin_amdgcn_rcp(f0 + 1.5);
             f0 = __builtin_amdgcn_rcp(f0 + 1.5); f0 = __builtin_amdgcn_rcp(f0 + 1.5); f0 = __builtin_amdgcn_rcp(f0 + 1.5); f0 = __builtin_amdgcn_rcp(f0 + 1.5);
@@ -78,6 +88,9 @@ int main()
         run<4>("v_fma_f64 dependent", blocks, 8, out, st);
         run<5>("4 mfma + 8 fma interleaved (per 12)", blocks, 12, out, st);
         run<6>("v_rcp_f64+add dependent (per pair)", blocks, 8, out, st);
+        run<7>("mfma_f64_4x4x4_4b independent", blocks, 8, out, st);
+        run<8>("mfma_f64_4x4x4_4b acc chain", blocks, 8, out, st);
+        run<9>("mfma_f64_4x4x4_4b D->B operand chain", blocks, 8, out, st);
     }
     return 0;
 }
