@@ -55,8 +55,8 @@ typedef struct {
                                            (kpilqr_interpolate / kpilqr_cost_derivs still do that on request, and the
                                            set_AB / set_cost_derivs hooks do not feed the fused sweeps).  Needs
                                            canonical key-points: per DoF strictly increasing, first 0, last T-1.
-                                           Faster at every batch size (Panda, T=3000: 162 vs 143 iterations/s for one
-                                           trajectory, 101k vs 69k at batch 1024). */
+                                           Faster at every batch size (Panda, T=3000: 170 vs 142 iterations/s for one
+                                           trajectory, 102k vs 68k at batch 1024). */
 
 enum {
     KPILQR_OK = 0,

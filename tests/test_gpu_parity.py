@@ -698,8 +698,9 @@ def test_fused_two_wave_backward_variant(monkeypatch, waves):
     KPILQR_FUSED_WAVES=1 one wave per trajectory (the default above #SIMDs/2 trajectories), =2 the control-side /
     state-side split, =3 the producer / consumer pair (the default up to #SIMDs/2 trajectories)."""
     monkeypatch.setenv("KPILQR_FUSED_WAVES", waves)
-    # forward sweep: one wave per trajectory with "1", the state / cost wave pair otherwise
-    monkeypatch.setenv("KPILQR_FUSED_FWD_WAVES", "1" if waves == "1" else "2")
+    # forward sweep: one wave per trajectory with "1", the state / cost pair with "2", the state / cost / staging triple
+    # (the default up to #SIMDs/4 trajectories) with "3"
+    monkeypatch.setenv("KPILQR_FUSED_FWD_WAVES", waves)
     if waves == "3":
         monkeypatch.setenv("KPILQR_ROLE_SHIFT", "0")             # alternate the roles with the block index
     for kw in (PROBLEMS["panda_T64"], PROBLEMS["acrobot_T100"], dict(task="panda_reaching", T=301, batch=3, min_N=4)):

@@ -1224,7 +1224,8 @@ __device__ __forceinline__ void forward_sc_state(double *sh, RecLayout L, int T,
     }
 }
 
-template <int NCZ, int NCU>
+// ROLE 0: score and stage (second wave of the pair); 1: score only; 2: stage the A, B columns only (third wave of the triple)
+template <int NCZ, int NCU, int ROLE = 0>
 __device__ __forceinline__ void forward_sc_cost(double *sh, RecLayout L, FusedArgs F, int T, int n_alpha, const double *__restrict__ rec,
                double *__restrict__ cost_pred)
 {
@@ -1278,8 +1279,10 @@ __device__ __forceinline__ void forward_sc_cost(double *sh, RecLayout L, FusedAr
     int e = (has && idx + 1 < khi) ? F.kp_times[idx + 1] : BIGT;
     int nb = (has && idx + 2 < khi) ? F.kp_times[idx + 2] : BIGT;
     double sv[8], ev[8], av[8];
-    load_col(rT, co, has ? s : BIGT, T, strideB, sv);
-    load_col(rT, co, e, T, strideB, ev);
+    if (ROLE != 1) {
+        load_col(rT, co, has ? s : BIGT, T, strideB, sv);
+        load_col(rT, co, e, T, strideB, ev);
+    }
     bool pend = true;
 #pragma unroll
     for (int i = 0; i < 8; i++) av[i] = 0.0;
@@ -1313,7 +1316,7 @@ __device__ __forceinline__ void forward_sc_cost(double *sh, RecLayout L, FusedAr
     // iteration t: score step t-1 (tiles re-requested for step t+1 right behind their use), then stage the A, B columns of
     // step t+1 for wave S
     auto iter = [&](int t, CTiles &s_) {               // s_ holds the tiles of step t-1
-        if (t >= 1) {
+        if (ROLE != 2 && t >= 1) {
             const int tt = t - 1;
             const double *zs = sh + FSC_ZS + (tt & 1) * 512;
             const d4 Zt = lds_tile4(zs, lane), dU = lds_tile4(zs + 256, lane);
@@ -1333,13 +1336,12 @@ __device__ __forceinline__ void forward_sc_cost(double *sh, RecLayout L, FusedAr
                      + wcur[2] * (Jx.z * (r2.z + Jx.z) + Ju.z * (r2.z + Ju.z))
                      + wcur[3] * (Jx.w * (r2.w + Jx.w) + Ju.w * (r2.w + Ju.w));
         }
-        if (t + 1 < T) { advance(t + 1); stage_cols(t + 1); }
+        if (ROLE != 1 && t + 1 < T) { advance(t + 1); stage_cols(t + 1); }
         if (t < T) __syncthreads();
     };
     CTiles ta, tb;                                     // ta: even steps, tb: odd steps
-    request(0, ta);
-    request(1, tb);
-    stage_cols(0);
+    if (ROLE != 2) { request(0, ta); request(1, tb); }
+    if (ROLE != 1) stage_cols(0);
     __syncthreads();
     iter(0, tb);
     for (int t = 1; t <= T; t += 2) {
@@ -1348,7 +1350,7 @@ __device__ __forceinline__ void forward_sc_cost(double *sh, RecLayout L, FusedAr
     }
     partial += __shfl_xor(partial, 16);
     partial += __shfl_xor(partial, 32);
-    if (q == 0 && c < n_alpha) cost_pred[(size_t)b * n_alpha + c] = partial;
+    if (ROLE != 2 && q == 0 && c < n_alpha) cost_pred[(size_t)b * n_alpha + c] = partial;
 }
 
 template <int NCZ, int NCU>
@@ -1361,6 +1363,21 @@ k_forward_fused_sc(RecLayout L, FusedArgs F, int T, int n_alpha, const double *_
     const bool state = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6) == 0;
     if (state) forward_sc_state<NCZ, NCU>(sh, L, T, n_alpha, Kin, kin, u_nom, ctrl_lim, alphas, U_alpha);
     else       forward_sc_cost<NCZ, NCU>(sh, L, F, T, n_alpha, rec, cost_pred);
+}
+
+// state + cost + staging waves (4 x batch <= #SIMDs: one 3-wave workgroup per CU): the cost wave of the pair is the longer
+// one (1 360 vs 1 130 cycles per step); its a4 half goes to a third wave
+template <int NCZ, int NCU>
+__global__ void __launch_bounds__(192) __attribute__((amdgpu_waves_per_eu(1, 1)))
+k_forward_fused_sc3(RecLayout L, FusedArgs F, int T, int n_alpha, const double *__restrict__ rec, const double *__restrict__ Kin,
+                    const double *__restrict__ kin, const double *__restrict__ u_nom, const double *__restrict__ ctrl_lim,
+                    const double *__restrict__ alphas, double *__restrict__ cost_pred, double *__restrict__ U_alpha)
+{
+    __shared__ __attribute__((aligned(16))) double sh[FSC_TOTAL];
+    const int role = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    if (role == 0) forward_sc_state<NCZ, NCU>(sh, L, T, n_alpha, Kin, kin, u_nom, ctrl_lim, alphas, U_alpha);
+    else if (role == 1) forward_sc_cost<NCZ, NCU, 1>(sh, L, F, T, n_alpha, rec, cost_pred);
+    else forward_sc_cost<NCZ, NCU, 2>(sh, L, F, T, n_alpha, rec, cost_pred);
 }
 
 bool fused_supported(int n, int m, int nr, int dof, int T, int stride, int n_alpha)
@@ -1432,8 +1449,20 @@ hipError_t launch_forward_fused(Ctx *c, double *U_alpha_dev)
     const FusedArgs F = fused_args(c);
     // state / cost wave pair while each wave gets its own SIMD (KPILQR_FUSED_FWD_WAVES = 1 | 2 forces a form)
     const char *ew = getenv("KPILQR_FUSED_FWD_WAVES");
-    const int form = ew ? atoi(ew) : (2 * c->d.batch <= c->n_simd ? 2 : 1);
+    const int form = ew ? atoi(ew) : (4 * c->d.batch <= c->n_simd ? 3 : 2 * c->d.batch <= c->n_simd ? 2 : 1);
     const int ncz = (n + 2 + 3) / 4, ncu = (m + 3) / 4;       // tile chunks of [dx; alpha; 1] and of the controls
+    if (form == 3) {
+        dim3 block3(192);
+#define LAUNCHSC3(NCZ, NCU)                                                                                             \
+        if (ncz == NCZ && ncu == NCU) {                                                                                 \
+            hipLaunchKernelGGL((k_forward_fused_sc3<NCZ, NCU>), grid, block3, 0, c->stream, c->L, F, c->d.T, c->d.n_alpha, c->rec, \
+                               c->K, c->k, c->u_nom, c->ctrl_lim, c->alphas, c->cost_pred, U_alpha_dev);                \
+            return hipGetLastError();                                                                                   \
+        }
+        LAUNCHSC3(4, 2) LAUNCHSC3(2, 1) LAUNCHSC3(4, 1) LAUNCHSC3(3, 1)
+#undef LAUNCHSC3
+        return hipErrorInvalidValue;
+    }
     if (form == 2) {
         dim3 block2(128);
 #define LAUNCHSC(NCZ, NCU)                                                                                              \
