@@ -152,7 +152,9 @@ def main():
     dJ_view = torch.as_tensor(eng.device_array(10, (B,)), device="cuda")          # KPILQR_BUF_DELTA_J
     st_view = torch.as_tensor(eng.device_array(11, (B,), "<i4"), device="cuda")   # KPILQR_BUF_STATUS
 
+    a6 = eng.backward_variant.endswith("_a6")         # tiled shapes: a6 inside the sweeps, A and B still materialised
     stages = ("fd_difference", "backward", "forward") if fused else \
+             ("fd_difference", "interpolate", "backward", "forward") if a6 else \
              ("fd_difference", "interpolate", "cost_derivs", "backward", "forward")
 
     def one_step(events=None):

@@ -56,7 +56,10 @@ typedef struct {
                                            set_AB / set_cost_derivs hooks do not feed the fused sweeps).  Needs
                                            canonical key-points: per DoF strictly increasing, first 0, last T-1.
                                            Faster at every batch size (Panda, T=3000: 170 vs 142 iterations/s for one
-                                           trajectory, 102k vs 68k at batch 1024). */
+                                           trajectory, 102k vs 68k at batch 1024).  On a tiled shape (n+2 > 16) the
+                                           library may form only the cost derivatives inside the sweeps (variant
+                                           "mfma_f64_tiled_a6": four-tile states from ~100 trajectories up); A and B
+                                           are then still materialised and kpilqr_iterate skips kpilqr_cost_derivs. */
 
 enum {
     KPILQR_OK = 0,

@@ -65,6 +65,7 @@ struct Ctx {
     bool have_kp = false;
     bool kp_canonical = false;   // every DoF list strictly increasing, first 0, last T-1 (what the fused sweeps walk)
     bool fused = false;          // KPILQR_FLAG_FUSED and a supported shape
+    bool tiled_a6 = false;       // KPILQR_FLAG_FUSED on a tiled shape: the cost derivatives (a6) are formed inside the sweeps
 
     // nominal states for on-device key-point placement (kpilqr_upload_states), allocated on first use
     double *X_states = nullptr;   // [batch][T][n]
@@ -141,6 +142,7 @@ bool forward_mfma_supported(int n, int m, int n_alpha);
 hipError_t launch_forward_mfma(Ctx *c, double *U_alpha_dev);
 
 // tiled_mfma.hip: n+2 <= 64 (NT x NT grids of 16x16 tiles in LDS), m in {1,7}
+int tiled_tiles(int n);                       // tiles per side of the tiled kernels' state grid
 bool backward_tiled_supported(int n, int m);
 hipError_t launch_backward_tiled(Ctx *c, int pd_stride);
 size_t backward_tiled_lds_bytes(int nt);

@@ -124,6 +124,20 @@ int kpilqr_create(const kpilqr_dims *dims, void *stream, kpilqr_ctx **out)
         c->fused = true;
         c->bwd_variant = c->fwd_variant = "mfma_f64_t1_fused";
     }
+    // the same flag on a tiled shape: a6 (cost derivatives) inside the sweeps, A and B still materialised by k_interpolate
+    // It replaces k_cost_derivs (HBM-bound: n^2 doubles written per step, so its time grows with batch x n^2) by
+    // NT*ceil(nr/4) + 6 MFMAs per wave-step of the latency-bound backward sweep (+9 % at four tiles, whatever the batch):
+    // a gain from ~100 trajectories of a four-tile state up (n = 62, B = 128, T = 5000: 74.4 -> 70.6 ms), a loss for two or
+    // three tiles at the batches measured.  KPILQR_TILED_A6 = 0 | 1 overrides the choice.
+    if ((dims->flags & KPILQR_FLAG_FUSED) && !c->fused && dims->nr <= 16 &&
+        strcmp(c->bwd_variant, "mfma_f64_tiled") == 0 && strcmp(c->fwd_variant, "mfma_f64_tiled") == 0) {
+        const char *ea = getenv("KPILQR_TILED_A6");
+        const bool want = ea ? atoi(ea) != 0 : (tiled_tiles(c->n) == 4 && dims->batch >= 96);
+        if (want) {
+            c->tiled_a6 = true;
+            c->bwd_variant = c->fwd_variant = "mfma_f64_tiled_a6";
+        }
+    }
     if (strcmp(c->bwd_variant, "generic_lds") == 0 && backward_generic_lds_bytes(c->n, dims->m) > 160 * 1024) {
         kpilqr_destroy(c);
         return set_err(nullptr, KPILQR_ERR_ARG, "state dimension too large for the generic backward kernel (LDS)");
@@ -458,7 +472,7 @@ static int run_backward(kpilqr_ctx *c, int pd_stride)
         return KPILQR_OK;
     }
     if (strcmp(c->bwd_variant, "mfma_f64_t1") == 0) KP_HIP(c, launch_backward_mfma(c, pd_stride));
-    else if (strcmp(c->bwd_variant, "mfma_f64_tiled") == 0) KP_HIP(c, launch_backward_tiled(c, pd_stride));
+    else if (strncmp(c->bwd_variant, "mfma_f64_tiled", 14) == 0) KP_HIP(c, launch_backward_tiled(c, pd_stride));
     else KP_HIP(c, launch_backward_generic(c, pd_stride));
     return KPILQR_OK;
 }
@@ -531,7 +545,7 @@ static int run_forward(kpilqr_ctx *c, double *U_dev)
         return KPILQR_OK;
     }
     if (strcmp(c->fwd_variant, "mfma_f64_t1") == 0) KP_HIP(c, launch_forward_mfma(c, U_dev));
-    else if (strcmp(c->fwd_variant, "mfma_f64_tiled") == 0) KP_HIP(c, launch_forward_tiled(c, U_dev));
+    else if (strncmp(c->fwd_variant, "mfma_f64_tiled", 14) == 0) KP_HIP(c, launch_forward_tiled(c, U_dev));
     else KP_HIP(c, launch_forward_generic(c, U_dev));
     return KPILQR_OK;
 }
@@ -567,7 +581,7 @@ int kpilqr_iterate(kpilqr_ctx *c, const double *lambda, int pd_check_stride, con
     KP_HIP(c, launch_fd_difference(c));
     if (!c->fused) {              // the fused sweeps interpolate A,B and form l_* themselves
         KP_HIP(c, launch_interpolate(c));
-        KP_HIP(c, launch_cost_derivs(c));
+        if (!c->tiled_a6) KP_HIP(c, launch_cost_derivs(c));      // tiled + flag: l_* are formed inside the sweeps
     }
     int rc = run_backward(c, pd_check_stride);
     if (rc) return rc;

@@ -122,6 +122,49 @@ __device__ __forceinline__ d4 ld_Luu(__amdgpu_buffer_rsrc_t rs, const TileSrc &S
     return o;
 }
 
+// a6 inside the sweeps (KPILQR_FLAG_FUSED on a tiled shape): the cost tiles are formed from the residuals and their
+// Jacobians instead of being read from the records -- Lzz(k,w) = Rz_k' W Rz_w with Rz = [r_x | r] (one column tile each),
+// l_uu = Ru' W Ru, l_u = Ru' W r, W = diag(2 w): ModelTranslator::CostDerivativesFromResiduals
+// (ModelTranslator.cpp:552-583) as in fused_mfma.hip, so l_xx (n^2 doubles per step) is neither written nor read.
+struct CostSrc { const double *r, *r_x, *r_u, *w_run, *w_term; int nr; };
+
+// element (res = 4r+q, col = 16*tj + c) of r_x [nr][n]
+__device__ __forceinline__ d4 ld_Rx(__amdgpu_buffer_rsrc_t rs, int n, int nr, int tj, int q, int c)
+{
+    double v[4];
+#pragma unroll
+    for (int r = 0; r < 4; r++) {
+        const int res = 4 * r + q, col = 16 * tj + c;
+        v[r] = tbld(rs, (res < nr && col < n) ? 8 * (res * n + col) : OOBT);
+    }
+    d4 o = {v[0], v[1], v[2], v[3]};
+    return o;
+}
+// r [nr] in column `cn` of a tile (the homogeneous column n lives in tile n>>4 at column n&15)
+__device__ __forceinline__ d4 ld_R1(__amdgpu_buffer_rsrc_t rs, int nr, int cn, int q, int c)
+{
+    double v[4];
+#pragma unroll
+    for (int r = 0; r < 4; r++) {
+        const int res = 4 * r + q;
+        v[r] = tbld(rs, (res < nr && c == cn) ? 8 * res : OOBT);
+    }
+    d4 o = {v[0], v[1], v[2], v[3]};
+    return o;
+}
+// element (res, c) of r_u [nr][m]
+__device__ __forceinline__ d4 ld_Ru(__amdgpu_buffer_rsrc_t rs, int m, int nr, int q, int c)
+{
+    double v[4];
+#pragma unroll
+    for (int r = 0; r < 4; r++) {
+        const int res = 4 * r + q;
+        v[r] = tbld(rs, (res < nr && c < m) ? 8 * (res * m + c) : OOBT);
+    }
+    d4 o = {v[0], v[1], v[2], v[3]};
+    return o;
+}
+
 // ---------------------------------------------------------------------------------------------
 // Backward pass, NT wavefronts per trajectory, COLUMN decomposition: wave w owns column tile w of Tz, Quz,
 // Qzz and V'.  Tz(:,w) and Qzz(:,w) never leave the wave's registers (Qzz(i,w) = Lzz(i,w) + sum_k Fz(k,i)'Tz(k,w)
@@ -133,9 +176,9 @@ __device__ __forceinline__ d4 ld_Luu(__amdgpu_buffer_rsrc_t rs, const TileSrc &S
 //   E  acc(i,w) = Qzz(i,w) + X_i' G_w -> LDS                                               | barrier
 //   F  V'(i,w) = (acc(i,w) + acc(w,i)')/2                (the barrier after the next A orders it)
 // All source tiles are single-buffered: re-requested for step t-1 right behind their last use in step t.
-template <int M, int NT>
+template <int M, int NT, bool A6>
 __global__ void __launch_bounds__(64 * NT)
-k_backward_tiled_col(RecLayout L, int T, const double *__restrict__ rec, const double *__restrict__ lambda,
+k_backward_tiled_col(RecLayout L, CostSrc CS, int T, const double *__restrict__ rec, const double *__restrict__ lambda,
                      int pd_stride, double *__restrict__ Kout, double *__restrict__ kout,
                      double *__restrict__ delta_J, int *__restrict__ status)
 {
@@ -179,18 +222,76 @@ k_backward_tiled_col(RecLayout L, int T, const double *__restrict__ rec, const d
 #pragma unroll
     for (int r = 0; r < 4; r++) lam2d[r] = (4 * r + q == c && c < m) ? 2.0 * lam : 0.0;
 
-    // source tiles of the current step (column w): Fz(k,w), Lzz(k,w), Fu(w), Luz(w), Luu
+    // source tiles of the current step (column w): Fz(k,w), Lzz(k,w), Fu(w), Luz(w), Luu -- with A6 the cost tiles are
+    // formed from residual tiles instead: pL[k] holds Rx_k (r_x rows, column tile k), pLuz the r column, pLuu Ru
     d4 pF[NT], pL[NT], pFu, pLuz, pLuu;
     auto rsrc_of = [&](int t) { return __builtin_amdgcn_make_buffer_rsrc((void *)(R0 + (size_t)t * L.stride), 0, rec_bytes, 0x00020000); };
+    const int nr = CS.nr, ncr = (nr + 3) >> 2;
+    const double *rb = CS.r + (size_t)b * (T + 1) * nr, *rxb = CS.r_x + (size_t)b * (T + 1) * nr * n,
+                 *rub = CS.r_u + (size_t)b * (T + 1) * nr * m;
+    d4 W2run = zero, W2term = zero;
+    if (A6) {
+        double a[4], e[4];
+#pragma unroll
+        for (int r = 0; r < 4; r++) {
+            const int res = 4 * r + q;
+            a[r] = (res < nr) ? 2.0 * CS.w_run[res] : 0.0;
+            e[r] = (res < nr) ? 2.0 * CS.w_term[res] : 0.0;
+        }
+        W2run.x = a[0]; W2run.y = a[1]; W2run.z = a[2]; W2run.w = a[3];
+        W2term.x = e[0]; W2term.y = e[1]; W2term.z = e[2]; W2term.w = e[3];
+    }
+    auto load_cost = [&](int t, bool ok) {            // the cost sources of step t (zero-size descriptors when !ok)
+        if (A6) {
+            const size_t tt = ok ? t : 0;
+            __amdgpu_buffer_rsrc_t rX = __builtin_amdgcn_make_buffer_rsrc((void *)(rxb + tt * nr * n), 0, ok ? nr * n * 8 : 0, 0x00020000);
+            __amdgpu_buffer_rsrc_t rR = __builtin_amdgcn_make_buffer_rsrc((void *)(rb + tt * nr), 0, ok ? nr * 8 : 0, 0x00020000);
+            __amdgpu_buffer_rsrc_t rU = __builtin_amdgcn_make_buffer_rsrc((void *)(rub + tt * nr * m), 0, ok ? nr * m * 8 : 0, 0x00020000);
+#pragma unroll
+            for (int k = 0; k < NT; k++) pL[k] = ld_Rx(rX, n, nr, k, q, c);
+            pLuz = ld_R1(rR, nr, cn, q, c);
+            pLuu = ld_Ru(rU, m, nr, q, c);
+        } else {
+            __amdgpu_buffer_rsrc_t rs = ok ? rsrc_of(t) : __builtin_amdgcn_make_buffer_rsrc((void *)R0, 0, 0, 0x00020000);
+#pragma unroll
+            for (int k = 0; k < NT; k++) pL[k] = ld_Lzz(rs, S, k, w, q, c);
+            pLuz = ld_Luz(rs, S, w, q, c); pLuu = ld_Luu(rs, S, q, c);
+        }
+    };
+    // cost tiles of the step whose sources are in pL / pLuz / pLuu:  cL[k] = Lzz(k,w), cLuz = Luz(w), cLuu
+    d4 cL[NT], cLuz, cLuu;
+    auto form_cost = [&](const d4 &W2) {
+        if (A6) {
+            d4 Rzw = pL[0];                            // column tile w of Rz (w is wave-uniform: selects, no indexing)
+#pragma unroll
+            for (int k = 0; k < NT; k++) if (k == w) Rzw = pL[k];
+            const d4 R1w = (w == tn) ? pLuz : zero;
+            const d4 WRz = (Rzw + R1w) * W2;
+#pragma unroll
+            for (int k = 0; k < NT; k++) {
+                d4 Rzk = pL[k];
+                if (k == tn) Rzk = Rzk + pLuz;
+                cL[k] = Pn(Rzk, WRz, zero, ncr);
+            }
+            cLuz = (w == tn) ? Pn(pLuu, pLuz * W2, zero, ncr) : zero;     // l_u in column n
+            cLuu = (w == 0) ? Pn(pLuu, pLuu * W2, zero, ncr) : zero;
+        } else {
+#pragma unroll
+            for (int k = 0; k < NT; k++) cL[k] = pL[k];
+            cLuz = pLuz; cLuu = pLuu;
+        }
+    };
     {
         __amdgpu_buffer_rsrc_t rs = rsrc_of(T - 1);
 #pragma unroll
-        for (int k = 0; k < NT; k++) { pF[k] = ld_Fz(rs, S, k, w, q, c); pL[k] = ld_Lzz(rs, S, k, w, q, c); }
-        pFu = ld_Fu(rs, S, w, q, c); pLuz = ld_Luz(rs, S, w, q, c); pLuu = ld_Luu(rs, S, q, c);
+        for (int k = 0; k < NT; k++) pF[k] = ld_Fz(rs, S, k, w, q, c);
+        pFu = ld_Fu(rs, S, w, q, c);
+        load_cost(T - 1, true);
     }
-    // V' <- Lzz(T-1)   (iLQR.cpp:537-539)
+    // V' <- Lzz(T-1)   (iLQR.cpp:537-539), terminal weights (Optimiser.cpp:208-211)
+    form_cost(W2term);
 #pragma unroll
-    for (int k = 0; k < NT; k++) lds_store(bufV + (k * NT + w) * TILE, lane, pL[k]);
+    for (int k = 0; k < NT; k++) lds_store(bufV + (k * NT + w) * TILE, lane, cL[k]);
 
     int pd_counter = 0, fail = 0;
     double dJ = 0.0;
@@ -218,6 +319,7 @@ k_backward_tiled_col(RecLayout L, int T, const double *__restrict__ rec, const d
         __builtin_amdgcn_sched_barrier(0);
         __syncthreads();
         // ---- BC: Tz(:,w), Tu(w), Quu partial, Quz(w), Qzz(:,w) ------------------------------------------------
+        form_cost(t == T - 1 ? W2term : W2run);        // cL, cLuz, cLuu of this step (A6: from the residual tiles)
         d4 Fc[NT], Tz[NT];
 #pragma unroll
         for (int k = 0; k < NT; k++) Fc[k] = lds_tile(bufF + (k * NT + w) * TILE, lane);
@@ -232,31 +334,30 @@ k_backward_tiled_col(RecLayout L, int T, const double *__restrict__ rec, const d
             d4 Tu = zero;
 #pragma unroll
             for (int k = 0; k < NT; k++) Tu = Pk<NT>(k, lds_tile(bufV + (k * NT + w) * TILE, lane), lds_tile(bufFu + k * TILE, lane), Tu, ncl);
-            lds_store(bufQp + w * TILE, lane, Pn(lds_tile(bufFu + w * TILE, lane), Tu, zero, ncw));
+            // A6: l_uu rides in wave 0's partial (the other waves never form it)
+            lds_store(bufQp + w * TILE, lane, Pn(lds_tile(bufFu + w * TILE, lane), Tu, (A6 && w == 0) ? cLuu : zero, ncw));
         }
-        d4 Quzw = pLuz;                                                     // Quz(w): also kept in registers for the fast path
+        d4 Quzw = cLuz;                                                     // Quz(w): also kept in registers for the fast path
 #pragma unroll
         for (int k = 0; k < NT; k++) Quzw = Pk<NT>(k, lds_tile(bufFu + k * TILE, lane), Tz[k], Quzw, ncl);
         lds_store(bufQuz + w * TILE, lane, Quzw);
         d4 Qzz[NT];
 #pragma unroll
         for (int i = 0; i < NT; i++) {
-            d4 acc = pL[i];
+            d4 acc = cL[i];
 #pragma unroll
             for (int k = 0; k < NT; k++) acc = Pk<NT>(k, lds_tile(bufF + (k * NT + i) * TILE, lane), Tz[k], acc, ncl);
             Qzz[i] = acc;
         }
+        const d4 Luu_t = cLuu;
         __builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-        for (int k = 0; k < NT; k++) pL[k] = ld_Lzz(rn, S, k, w, q, c);
-        pLuz = ld_Luz(rn, S, w, q, c);
+        load_cost(t - 1, more);
         __builtin_amdgcn_sched_barrier(0);
         __syncthreads();
         // ---- D: Quu, LDL' (every wave: keeps the PD verdict block-uniform), solve / K / G for column tile w ----
-        d4 Quu = pLuu;
+        d4 Quu = A6 ? zero : Luu_t;
 #pragma unroll
         for (int k = 0; k < NT; k++) Quu = Quu + lds_tile(bufQp + k * TILE, lane);
-        pLuu = ld_Luu(rn, S, q, c);
         d4 Qr = Quu;
         Qr.x += 0.5 * lam2d[0]; Qr.y += 0.5 * lam2d[1]; Qr.z += 0.5 * lam2d[2]; Qr.w += 0.5 * lam2d[3];
         // X(w) = (Quu + lambda I)^-1 Quz(w).  Fast path as in riccati_mfma.hip: every wave keeps the running inverse
@@ -390,21 +491,29 @@ static int tiled_nt(int n)
     return nt;
 }
 
+int tiled_tiles(int n) { return tiled_nt(n); }
+
 bool backward_tiled_supported(int n, int m)
 {
     const int nt = tiled_nt(n);
     return nt >= 2 && nt <= 4 && m >= 1 && m <= 8 && backward_tiled_lds_bytes(nt) <= 160 * 1024;
 }
 
+template <int M, int NT, bool A6>
+static hipError_t launch_bt2(Ctx *c, int pd_stride)
+{
+    const size_t ldc = backward_col_lds_bytes(NT);
+    hipError_t e = hipFuncSetAttribute((const void *)k_backward_tiled_col<M, NT, A6>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)ldc);
+    if (e != hipSuccess) return e;
+    const CostSrc CS = {c->r, c->r_x, c->r_u, c->w_run, c->w_term, c->d.nr};
+    hipLaunchKernelGGL((k_backward_tiled_col<M, NT, A6>), dim3(c->d.batch), dim3(64 * NT), ldc, c->stream, c->L, CS, c->d.T, c->rec,
+                       c->lambda, pd_stride, c->K, c->k, c->delta_J, c->status);
+    return hipGetLastError();
+}
 template <int M, int NT>
 static hipError_t launch_bt(Ctx *c, int pd_stride)
 {
-    const size_t ldc = backward_col_lds_bytes(NT);
-    hipError_t e = hipFuncSetAttribute((const void *)k_backward_tiled_col<M, NT>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)ldc);
-    if (e != hipSuccess) return e;
-    hipLaunchKernelGGL((k_backward_tiled_col<M, NT>), dim3(c->d.batch), dim3(64 * NT), ldc, c->stream, c->L, c->d.T, c->rec,
-                       c->lambda, pd_stride, c->K, c->k, c->delta_J, c->status);
-    return hipGetLastError();
+    return c->tiled_a6 ? launch_bt2<M, NT, true>(c, pd_stride) : launch_bt2<M, NT, false>(c, pd_stride);
 }
 
 hipError_t launch_backward_tiled(Ctx *c, int pd_stride)
@@ -421,15 +530,16 @@ hipError_t launch_backward_tiled(Ctx *c, int pd_stride)
 // NT wavefronts per trajectory: wave i owns row tile i of Z+ and of Lc Z (its column of Ya / Lc tiles goes
 // global -> registers, prefetched one step ahead), every wave forms the (cheap) control law itself, and the
 // Z tiles are exchanged through a double-buffered LDS image with ONE s_barrier per time-step.
-template <int NT>
+template <int NT, bool A6>
 __global__ void __launch_bounds__(64 * NT)
-k_forward_tiled(RecLayout L, int T, int n_alpha, const double *__restrict__ rec, const double *__restrict__ Kin,
+k_forward_tiled(RecLayout L, CostSrc CS, int T, int n_alpha, const double *__restrict__ rec, const double *__restrict__ Kin,
                 const double *__restrict__ kin, const double *__restrict__ u_nom, const double *__restrict__ ctrl_lim,
                 const double *__restrict__ alphas, double *__restrict__ cost_pred, double *__restrict__ U_alpha)
 {
     __shared__ __attribute__((aligned(16))) double zbuf[2][NT * TILE];
     __shared__ __attribute__((aligned(16))) double upart[NT * TILE];        // per-wave partials of K dx + alpha k
     __shared__ double red[NT * 64];
+    __shared__ __attribute__((aligned(16))) double jpart[A6 ? NT * TILE : 1];   // A6: per-wave partials of r_x dx
     const int n = L.n, m = L.m, nz2 = n + 2;
     const int lane = threadIdx.x & 63, c = lane & 15, q = lane >> 4;
     const int wi = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);   // this wave's row tile (wave-uniform)
@@ -469,6 +579,24 @@ k_forward_tiled(RecLayout L, int T, int n_alpha, const double *__restrict__ rec,
         lo[r] = (row < m) ? ctrl_lim[2 * row] : -1.0e300;
         hi[r] = (row < m) ? ctrl_lim[2 * row + 1] : 1.0e300;
     }
+    // A6: the candidates are scored on the residuals, sum_k w_k [Jx_k (2 r_k + Jx_k) + Ju_k (2 r_k + Ju_k)] with
+    // Jx = r_x dx (each wave forms the partial of its own slice of the state, summed through LDS) and Ju = r_u du,
+    // instead of through l_xx, l_x, l_uu, l_u: NT*4 MFMAs per wave-step less, and l_xx is never read.
+    const int nr = CS.nr;
+    int oRxT[4], oRuT[4], oRr[4];
+    double wrun[4], wterm[4];
+#pragma unroll
+    for (int r = 0; r < 4; r++) {
+        const int row = 4 * r + q;
+        const int pw = 16 * wi + row;
+        oRxT[r] = (A6 && pw < n && c < nr) ? 8 * (c * n + pw) : OOBT;          // RxT(p = pw, k = c) = r_x[k][p]
+        oRuT[r] = (A6 && row < m && c < nr) ? 8 * (c * m + row) : OOBT;        // RuT(p = row, k = c) = r_u[k][p]
+        oRr[r] = (A6 && row < nr) ? 8 * row : OOBT;
+        wrun[r] = (A6 && row < nr) ? CS.w_run[row] : 0.0;
+        wterm[r] = (A6 && row < nr) ? CS.w_term[row] : 0.0;
+    }
+    const double *rb = CS.r + (size_t)b * (T + 1) * nr, *rxb = CS.r_x + (size_t)b * (T + 1) * nr * n,
+                 *rub = CS.r_u + (size_t)b * (T + 1) * nr * m;
     const double my_alpha = (c < n_alpha) ? alphas[c] : 0.0;
     d4 Zi;                                                               // this wave's tile of Z, kept in registers
     {
@@ -484,7 +612,7 @@ k_forward_tiled(RecLayout L, int T, int n_alpha, const double *__restrict__ rec,
     const d4 zero = {0.0, 0.0, 0.0, 0.0};
     double partial = 0.0;
 
-    struct Tiles { d4 Ykw, Ya[NT], Lc[NT], Yb, Luu, lu, ub; };
+    struct Tiles { d4 Ykw, Ya[NT], Lc[NT], Yb, Luu, lu, ub; };        // A6: Lc[0] = RxT (own slice), Luu = RuT, lu = r
     const int rec_bytes = L.rec * 8;
     auto ld4 = [&](__amdgpu_buffer_rsrc_t rs, const int *off) -> d4 {
         d4 v; v.x = tbld(rs, off[0]); v.y = tbld(rs, off[1]); v.z = tbld(rs, off[2]); v.w = tbld(rs, off[3]);
@@ -493,6 +621,10 @@ k_forward_tiled(RecLayout L, int T, int n_alpha, const double *__restrict__ rec,
     auto rs_of = [&](const double *base, size_t step_elems, int t, int bytes) {
         const bool ok = t < T;
         return __builtin_amdgcn_make_buffer_rsrc((void *)(base + ((size_t)b * T + (ok ? t : 0)) * step_elems), 0, ok ? bytes : 0, 0x00020000);
+    };
+    auto rs_res = [&](const double *base_b, size_t step_elems, int t, int bytes) {        // residual arrays: base already at trajectory b
+        const bool ok = t < T;
+        return __builtin_amdgcn_make_buffer_rsrc((void *)(base_b + (size_t)(ok ? t : 0) * step_elems), 0, ok ? bytes : 0, 0x00020000);
     };
     // Single-buffered tiles: each group is re-requested for step t+1 right behind its last use in step t.
     // Every wave forms only ITS slice of the control law, P([K' ; k'] rows of tile wi, Z_wi) (4 MFMAs instead of
@@ -503,8 +635,13 @@ k_forward_tiled(RecLayout L, int T, int n_alpha, const double *__restrict__ rec,
         __amdgpu_buffer_rsrc_t rk = rs_of(kin, m, 0, m * 8), ru = rs_of(u_nom, m, 0, m * 8);
         cur.Ykw = ld4(rK, oKw) + ld4(rk, okw);
 #pragma unroll
-        for (int k = 0; k < NT; k++) { cur.Ya[k] = ld4(rR, oA[k]); cur.Lc[k] = ld4(rR, oLc[k]); }
-        cur.Yb = ld4(rR, oB); cur.Luu = ld4(rR, oLuu); cur.lu = ld4(rR, olu); cur.ub = ld4(ru, oub);
+        for (int k = 0; k < NT; k++) { cur.Ya[k] = ld4(rR, oA[k]); if (!A6) cur.Lc[k] = ld4(rR, oLc[k]); }
+        cur.Yb = ld4(rR, oB); cur.ub = ld4(ru, oub);
+        if (A6) {
+            cur.Lc[0] = ld4(rs_res(rxb, (size_t)nr * n, 0, nr * n * 8), oRxT);
+            cur.Luu = ld4(rs_res(rub, (size_t)nr * m, 0, nr * m * 8), oRuT);
+            cur.lu = ld4(rs_res(rb, nr, 0, nr * 8), oRr);
+        } else { cur.Luu = ld4(rR, oLuu); cur.lu = ld4(rR, olu); }
     }
     __syncthreads();
 
@@ -515,8 +652,10 @@ k_forward_tiled(RecLayout L, int T, int n_alpha, const double *__restrict__ rec,
         double *zn = zbuf[(t + 1) & 1];
         // ---- this wave's slice of K dx + alpha k -------------------------------------------------------------
         lds_store(upart + wi * TILE, lane, Pn(cur.Ykw, Zi, zero, ncw));
+        if (A6) lds_store(jpart + wi * TILE, lane, Pn(cur.Lc[0], Zi, zero, ncw));        // this wave's slice of r_x dx
         __builtin_amdgcn_sched_barrier(0);
         cur.Ykw = ld4(rK, oKw) + ld4(rk, okw);
+        if (A6) cur.Lc[0] = ld4(rs_res(rxb, (size_t)nr * n, t + 1, nr * n * 8), oRxT);
         __builtin_amdgcn_sched_barrier(0);
         __syncthreads();
         // ---- control law + clamp (every wave; :876-890) --------------------------------------------------------
@@ -545,22 +684,41 @@ k_forward_tiled(RecLayout L, int T, int n_alpha, const double *__restrict__ rec,
 #pragma unroll
                 for (int r = 0; r < 4; r++) { const int row = 4 * r + q; if (row < m) Ua[row] = uv[r]; }
             }
+            if (A6) {
+                d4 Jx = zero;
+#pragma unroll
+                for (int k = 0; k < NT; k++) Jx = Jx + lds_tile(jpart + k * TILE, lane);
+                const d4 Ju = Pn(cur.Luu, dU, zero, ncu);
+                const d4 r2 = cur.lu + cur.lu;
+                const bool last = (t == T - 1);                        // terminal weights (Optimiser.cpp:209-211)
+                const double w0 = last ? wterm[0] : wrun[0], w1 = last ? wterm[1] : wrun[1];
+                const double w2 = last ? wterm[2] : wrun[2], w3 = last ? wterm[3] : wrun[3];
+                partial += w0 * (Jx.x * (r2.x + Jx.x) + Ju.x * (r2.x + Ju.x)) + w1 * (Jx.y * (r2.y + Jx.y) + Ju.y * (r2.y + Ju.y))
+                         + w2 * (Jx.z * (r2.z + Jx.z) + Ju.z * (r2.z + Ju.z)) + w3 * (Jx.w * (r2.w + Jx.w) + Ju.w * (r2.w + Ju.w));
+                __builtin_amdgcn_sched_barrier(0);
+                cur.Luu = ld4(rs_res(rub, (size_t)nr * m, t + 1, nr * m * 8), oRuT);
+                cur.lu = ld4(rs_res(rb, nr, t + 1, nr * 8), oRr);
+                __builtin_amdgcn_sched_barrier(0);
+            } else {
             const d4 Wu = Pn(cur.Luu, dU, zero, ncu);
             partial += dU.x * (0.5 * Wu.x + cur.lu.x) + dU.y * (0.5 * Wu.y + cur.lu.y)
                      + dU.z * (0.5 * Wu.z + cur.lu.z) + dU.w * (0.5 * Wu.w + cur.lu.w);
             __builtin_amdgcn_sched_barrier(0);
             cur.Luu = ld4(rR, oLuu); cur.lu = ld4(rR, olu);
             __builtin_amdgcn_sched_barrier(0);
+            }
         }
         // ---- state cost rows of this tile, then the linearised dynamics for this tile ------------------------------
         d4 Wz = zero, Zn = zero;
+        if (!A6) {
 #pragma unroll
-        for (int k = 0; k < NT; k++) Wz = Pk<NT>(k, cur.Lc[k], Zk[k], Wz, ncl);
-        __builtin_amdgcn_sched_barrier(0);
+            for (int k = 0; k < NT; k++) Wz = Pk<NT>(k, cur.Lc[k], Zk[k], Wz, ncl);
+            __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
-        for (int k = 0; k < NT; k++) cur.Lc[k] = ld4(rR, oLc[k]);
-        __builtin_amdgcn_sched_barrier(0);
-        partial += 0.5 * (Zi.x * Wz.x + Zi.y * Wz.y + Zi.z * Wz.z + Zi.w * Wz.w);
+            for (int k = 0; k < NT; k++) cur.Lc[k] = ld4(rR, oLc[k]);
+            __builtin_amdgcn_sched_barrier(0);
+            partial += 0.5 * (Zi.x * Wz.x + Zi.y * Wz.y + Zi.z * Wz.z + Zi.w * Wz.w);
+        }
 #pragma unroll
         for (int k = 0; k < NT; k++) {
             d4 Ya = cur.Ya[k];
@@ -598,9 +756,16 @@ bool forward_tiled_supported(int n, int m, int n_alpha)
 hipError_t launch_forward_tiled(Ctx *c, double *U_alpha_dev)
 {
     const int nt = tiled_nt(c->n);
+    const CostSrc CS = {c->r, c->r_x, c->r_u, c->w_run, c->w_term, c->d.nr};
 #define LAUNCH_FT(NT)                                                                                               \
-    hipLaunchKernelGGL((k_forward_tiled<NT>), dim3(c->d.batch), dim3(64 * NT), 0, c->stream, c->L, c->d.T,        \
-                       c->d.n_alpha, c->rec, c->K, c->k, c->u_nom, c->ctrl_lim, c->alphas, c->cost_pred, U_alpha_dev)
+    do {                                                                                                            \
+        if (c->tiled_a6)                                                                                            \
+            hipLaunchKernelGGL((k_forward_tiled<NT, true>), dim3(c->d.batch), dim3(64 * NT), 0, c->stream, c->L, CS, c->d.T, \
+                               c->d.n_alpha, c->rec, c->K, c->k, c->u_nom, c->ctrl_lim, c->alphas, c->cost_pred, U_alpha_dev); \
+        else                                                                                                        \
+            hipLaunchKernelGGL((k_forward_tiled<NT, false>), dim3(c->d.batch), dim3(64 * NT), 0, c->stream, c->L, CS, c->d.T, \
+                               c->d.n_alpha, c->rec, c->K, c->k, c->u_nom, c->ctrl_lim, c->alphas, c->cost_pred, U_alpha_dev); \
+    } while (0)
     if (nt == 2) LAUNCH_FT(2); else if (nt == 3) LAUNCH_FT(3); else if (nt == 4) LAUNCH_FT(4); else return hipErrorInvalidValue;
 #undef LAUNCH_FT
     return hipGetLastError();

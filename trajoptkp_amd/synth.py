@@ -22,6 +22,9 @@ TASKS = {
     # TaskConfigs/rigid_body_manipulation/twoD_push_heavy_clutter.yaml:12-136
     "high_dof_push": dict(dof=31, m=7, nr=11, dt=0.008, lim=[87, 87, 87, 87, 12, 12, 12],
                           w_run=[1.0, 0.5] + [0.1] * 9, w_term=[100.0, 50.0] + [1.0] * 9),
+    # TaskConfigs/rigid_body_manipulation/twoD_push_light_clutter.yaml: 7 joints + 4 bodies x 3 (n = 38: three tiles)
+    "light_clutter_push": dict(dof=19, m=7, nr=7, dt=0.008, lim=[87, 87, 87, 87, 12, 12, 12],
+                               w_run=[1.0, 0.5] + [0.1] * 5, w_term=[100.0, 50.0] + [1.0] * 5),
     # other control dimensions among the reference's task plugins (joint / actuator counts of
     # TaskConfigs/locomotion/walk_plane.yaml, locomotion/hopper.yaml, toys/pentabot.yaml); weights synthetic
     "walker": dict(dof=9, m=6, nr=4, dt=0.005, lim=[1.0] * 6,
