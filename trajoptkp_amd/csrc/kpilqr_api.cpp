@@ -110,7 +110,10 @@ int kpilqr_create(const kpilqr_dims *dims, void *stream, kpilqr_ctx **out)
     (void)hipMemsetAsync(c->rec, 0, B * T * c->L.stride * sizeof(double), c->stream);
     (void)hipMemsetAsync(c->K, 0, B * T * n * m * sizeof(double), c->stream);
     (void)hipMemsetAsync(c->k, 0, B * T * m * sizeof(double), c->stream);
+    (void)hipMemsetAsync(c->r, 0, B * (T + 1) * nr * sizeof(double), c->stream);
+    (void)hipMemsetAsync(c->r_x, 0, B * (T + 1) * nr * n * sizeof(double), c->stream);
     (void)hipMemsetAsync(c->r_u, 0, B * (T + 1) * nr * m * sizeof(double), c->stream);
+    (void)hipMemsetAsync(c->u_nom, 0, B * T * m * sizeof(double), c->stream);
     (void)hipMemsetAsync(c->status, 0, B * sizeof(int), c->stream);
 
     const bool generic = (dims->flags & KPILQR_FLAG_GENERIC_KERNELS) != 0;
