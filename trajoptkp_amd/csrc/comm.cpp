@@ -15,6 +15,7 @@ typedef struct { char internal[128]; } kp_ncclUniqueId;
 typedef void *kp_ncclComm_t;
 struct Rccl {
     void *lib = nullptr;
+    bool ready = false;                        // every symbol below resolved
     int (*GetUniqueId)(kp_ncclUniqueId *) = nullptr;
     int (*CommInitRank)(kp_ncclComm_t *, int, kp_ncclUniqueId, int) = nullptr;
     int (*AllReduce)(const void *, void *, size_t, int, int, kp_ncclComm_t, hipStream_t) = nullptr;
@@ -25,7 +26,8 @@ static Rccl g_rccl;
 
 static const char *rccl_open()
 {
-    if (g_rccl.lib) return nullptr;
+    if (g_rccl.ready) return nullptr;
+    if (g_rccl.lib) { dlclose(g_rccl.lib); g_rccl = Rccl(); }      // an earlier attempt found the library but not its symbols
     const char *names[] = {"librccl.so.1", "librccl.so", "/opt/rocm/lib/librccl.so.1"};
     for (const char *nm : names) { g_rccl.lib = dlopen(nm, RTLD_NOW | RTLD_GLOBAL); if (g_rccl.lib) break; }
     if (!g_rccl.lib) return "RCCL (librccl.so) not found";
@@ -34,7 +36,12 @@ static const char *rccl_open()
     g_rccl.AllReduce = (int (*)(const void *, void *, size_t, int, int, kp_ncclComm_t, hipStream_t))dlsym(g_rccl.lib, "ncclAllReduce");
     g_rccl.CommDestroy = (int (*)(kp_ncclComm_t))dlsym(g_rccl.lib, "ncclCommDestroy");
     g_rccl.GetErrorString = (const char *(*)(int))dlsym(g_rccl.lib, "ncclGetErrorString");
-    if (!g_rccl.GetUniqueId || !g_rccl.CommInitRank || !g_rccl.AllReduce || !g_rccl.CommDestroy) return "RCCL symbols missing";
+    if (!g_rccl.GetUniqueId || !g_rccl.CommInitRank || !g_rccl.AllReduce || !g_rccl.CommDestroy) {
+        dlclose(g_rccl.lib);
+        g_rccl = Rccl();
+        return "RCCL symbols missing";
+    }
+    g_rccl.ready = true;
     return nullptr;
 }
 

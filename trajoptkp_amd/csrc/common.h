@@ -95,7 +95,20 @@ struct Ctx {
 
     const char *bwd_variant = "";
     const char *fwd_variant = "";
+
+    // Diagnostic switches, read from the environment ONCE by kpilqr_create; the launchers only
+    // look here.  0 = let the library choose.
+    struct Tuning {
+        int fused_bwd_waves = 0;   // KPILQR_FUSED_WAVES: 1 one wave, 2 control/state split, 3 producer/consumer pair
+        int fused_fwd_waves = 0;   // KPILQR_FUSED_FWD_WAVES: 1 | 2 | 3
+        int role_shift = 9;        // KPILQR_ROLE_SHIFT (wave-pair role placement probe)
+        int tiled_nt_min = 0;      // KPILQR_TILED_NT_MIN: run the tiled kernels with more tiles than needed
+        int tiled_a6 = -1;         // KPILQR_TILED_A6: -1 auto, 0 | 1
+        int tiled_a4 = -1;         // KPILQR_TILED_A4: -1 auto, 0 | 1 (a4 inside the tiled sweeps)
+    } tune;
 };
+
+Ctx::Tuning read_tuning_from_env();
 
 #define KP_HIP(ctx, call)                                                        \
     do {                                                                         \
@@ -109,6 +122,7 @@ struct Ctx {
 // ---- launchers (defined in the .hip files) --------------------------------------------------
 // elementwise.hip
 hipError_t launch_fd_difference(Ctx *c);
+int fd_difference_waves(int n, int m);       // 0: the dims do not fit the kernel's LDS image
 hipError_t launch_build_segmap(Ctx *c);
 // comm.cpp (RCCL opened lazily) and the pack kernel of elementwise.hip
 const char *comm_unique_id(char *id128);
@@ -142,11 +156,11 @@ bool forward_mfma_supported(int n, int m, int n_alpha);
 hipError_t launch_forward_mfma(Ctx *c, double *U_alpha_dev);
 
 // tiled_mfma.hip: n+2 <= 64 (NT x NT grids of 16x16 tiles in LDS), m in {1,7}
-int tiled_tiles(int n);                       // tiles per side of the tiled kernels' state grid
-bool backward_tiled_supported(int n, int m);
+int tiled_tiles(int n, int nt_min);                       // tiles per side of the tiled kernels' state grid
+bool backward_tiled_supported(int n, int m, int nt_min);
 hipError_t launch_backward_tiled(Ctx *c, int pd_stride);
 size_t backward_tiled_lds_bytes(int nt);
-bool forward_tiled_supported(int n, int m, int n_alpha);
+bool forward_tiled_supported(int n, int m, int n_alpha, int nt_min);
 hipError_t launch_forward_tiled(Ctx *c, double *U_alpha_dev);
 // fused_mfma.hip: a4 + a6 evaluated inside the sweeps (n+2 <= 16)
 bool fused_supported(int n, int m, int nr, int dof, int T, int stride, int n_alpha);

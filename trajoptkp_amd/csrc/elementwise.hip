@@ -31,7 +31,7 @@ k_fd_difference(RecLayout L, int T, int nslots, const int *__restrict__ slot_sta
     extern __shared__ __attribute__((aligned(16))) double sh[];
     const int n = L.n, m = L.m, ncol = n + m, ne = n * n + n * m;
     const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
-    const int slot = blockIdx.x * FD_WAVES + wave;
+    const int slot = blockIdx.x * (blockDim.x >> 6) + wave;      // 1..FD_WAVES waves per block (LDS budget)
     double *sv = sh + wave * (ncol * n + ncol);          // [col][row] values, then per-column job id + 1
     int *present = (int *)(sv + ncol * n);
     const bool live = slot < nslots;
@@ -97,13 +97,30 @@ k_fd_difference(RecLayout L, int T, int nslots, const int *__restrict__ slot_sta
     }
 }
 
+// waves per block of k_fd_difference: as many slot images ((n+m)(n+1) doubles each) as fit in half of the CU's 160 KB of
+// LDS (two blocks resident), at most FD_WAVES; 0 = not even one image fits (kpilqr_create refuses such dims)
+int fd_difference_waves(int n, int m)
+{
+    const size_t per_wave = sizeof(double) * (size_t)(n + m) * (n + 1);
+    if (per_wave > 160 * 1024) return 0;
+    int w = (int)((80 * 1024) / per_wave);
+    if (w < 1) w = 1;
+    return w > FD_WAVES ? FD_WAVES : w;
+}
+
 hipError_t launch_fd_difference(Ctx *c)
 {
     if (c->njobs == 0 || c->nslots == 0) return hipSuccess;
     const int ncol = c->n + c->d.m;
-    const size_t lds = sizeof(double) * FD_WAVES * (ncol * c->n + ncol);
-    const int blocks = (c->nslots + FD_WAVES - 1) / FD_WAVES;
-    hipLaunchKernelGGL(k_fd_difference, dim3(blocks), dim3(64 * FD_WAVES), lds, c->stream, c->L, c->d.T, c->nslots,
+    const int nw = fd_difference_waves(c->n, c->d.m);
+    if (nw < 1) return hipErrorInvalidValue;
+    const size_t lds = sizeof(double) * nw * (ncol * c->n + ncol);
+    const int blocks = (c->nslots + nw - 1) / nw;
+    if (lds > 64 * 1024) {
+        hipError_t e = hipFuncSetAttribute((const void *)k_fd_difference, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        if (e != hipSuccess) return e;
+    }
+    hipLaunchKernelGGL(k_fd_difference, dim3(blocks), dim3(64 * nw), lds, c->stream, c->L, c->d.T, c->nslots,
                        c->slot_start, c->job_b, c->job_t, c->job_col, c->job_mode, c->job_nom, c->xplus,
                        c->xminus, c->xnom, c->eps, c->rec);
     return hipGetLastError();

@@ -1401,10 +1401,8 @@ hipError_t launch_backward_fused(Ctx *c, int pd_stride)
     // (2 x batch <= #SIMDs) the pair is the fastest form (4.2 vs 5.8 ms per sweep, tools/small_batch_variants.sh);
     // beyond that the FP64 unit is shared and one wave per trajectory wins.
     // KPILQR_FUSED_WAVES forces a form: 1 = one wave, 2 = control/state split, 3 = producer/consumer.
-    const char *e2 = getenv("KPILQR_FUSED_WAVES");
-    const int form = e2 ? atoi(e2) : (2 * c->d.batch <= c->n_simd ? 3 : 1);
-    const char *rs = getenv("KPILQR_ROLE_SHIFT");
-    const int role_shift = rs ? atoi(rs) : 9;
+    const int form = c->tune.fused_bwd_waves ? c->tune.fused_bwd_waves : (2 * c->d.batch <= c->n_simd ? 3 : 1);
+    const int role_shift = c->tune.role_shift;
     dim3 block2(128);
     if (form == 2) {
         if (n == 14 && m == 7) hipLaunchKernelGGL((k_backward_fused2<14, 7>), grid, block2, 0, c->stream, c->L, F, c->d.T, role_shift, c->rec, c->lambda, pd_stride, c->K, c->k, c->delta_J, c->status);
@@ -1448,8 +1446,8 @@ hipError_t launch_forward_fused(Ctx *c, double *U_alpha_dev)
     const bool excl = c->d.batch <= c->n_simd;
     const FusedArgs F = fused_args(c);
     // state / cost wave pair while each wave gets its own SIMD (KPILQR_FUSED_FWD_WAVES = 1 | 2 forces a form)
-    const char *ew = getenv("KPILQR_FUSED_FWD_WAVES");
-    const int form = ew ? atoi(ew) : (4 * c->d.batch <= c->n_simd ? 3 : 2 * c->d.batch <= c->n_simd ? 2 : 1);
+    const int form = c->tune.fused_fwd_waves ? c->tune.fused_fwd_waves
+                   : (4 * c->d.batch <= c->n_simd ? 3 : 2 * c->d.batch <= c->n_simd ? 2 : 1);
     const int ncz = (n + 2 + 3) / 4, ncu = (m + 3) / 4;       // tile chunks of [dx; alpha; 1] and of the controls
     if (form == 3) {
         dim3 block3(192);

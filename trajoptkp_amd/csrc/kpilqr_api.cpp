@@ -39,6 +39,26 @@ static int regrow(kpilqr_ctx *c, T **p, size_t count)
     return KPILQR_OK;
 }
 
+static int env_int(const char *name, int dflt)
+{
+    const char *e = getenv(name);
+    return (e && *e) ? atoi(e) : dflt;
+}
+
+namespace kpilqr {
+Ctx::Tuning read_tuning_from_env()
+{
+    Ctx::Tuning t;
+    t.fused_bwd_waves = env_int("KPILQR_FUSED_WAVES", 0);
+    t.fused_fwd_waves = env_int("KPILQR_FUSED_FWD_WAVES", 0);
+    t.role_shift = env_int("KPILQR_ROLE_SHIFT", 9);
+    t.tiled_nt_min = env_int("KPILQR_TILED_NT_MIN", 0);
+    t.tiled_a6 = env_int("KPILQR_TILED_A6", -1);
+    t.tiled_a4 = env_int("KPILQR_TILED_A4", -1);
+    return t;
+}
+}  // namespace kpilqr
+
 extern "C" {
 
 int kpilqr_version(void) { return KPILQR_VERSION; }
@@ -58,10 +78,13 @@ int kpilqr_create(const kpilqr_dims *dims, void *stream, kpilqr_ctx **out)
                        std::string("no HIP device available (libkpilqr has no CPU fallback): ") +
                            (e != hipSuccess ? hipGetErrorString(e) : "device count 0"));
     if (dims->device < 0 || dims->device >= ndev) return set_err(nullptr, KPILQR_ERR_ARG, "device ordinal out of range");
+    if (fd_difference_waves(2 * dims->dof, dims->m) < 1)
+        return set_err(nullptr, KPILQR_ERR_ARG, "state/control dimensions too large: one key-point's FD columns ((n+m)(n+1) doubles) exceed the CU's 160 KB of LDS");
     if (hipSetDevice(dims->device) != hipSuccess) return set_err(nullptr, KPILQR_ERR_NO_DEVICE, "hipSetDevice failed");
 
     kpilqr_ctx *c = new (std::nothrow) kpilqr_ctx();
     if (!c) return set_err(nullptr, KPILQR_ERR_ALLOC, "host allocation failed");
+    c->tune = read_tuning_from_env();           // the only place the environment is looked at
     c->d = *dims;
     c->n = 2 * dims->dof;
     c->L = RecLayout(c->n, dims->m);
@@ -119,9 +142,9 @@ int kpilqr_create(const kpilqr_dims *dims, void *stream, kpilqr_ctx **out)
     const bool generic = (dims->flags & KPILQR_FLAG_GENERIC_KERNELS) != 0;
     const bool force_tiled = (dims->flags & KPILQR_FLAG_TILED_KERNELS) != 0;
     c->bwd_variant = (!generic && !force_tiled && backward_mfma_supported(c->n, dims->m)) ? "mfma_f64_t1"
-                   : (!generic && backward_tiled_supported(c->n, dims->m)) ? "mfma_f64_tiled" : "generic_lds";
+                   : (!generic && backward_tiled_supported(c->n, dims->m, c->tune.tiled_nt_min)) ? "mfma_f64_tiled" : "generic_lds";
     c->fwd_variant = (!generic && !force_tiled && forward_mfma_supported(c->n, dims->m, dims->n_alpha)) ? "mfma_f64_t1"
-                   : (!generic && forward_tiled_supported(c->n, dims->m, dims->n_alpha)) ? "mfma_f64_tiled" : "generic_lds";
+                   : (!generic && forward_tiled_supported(c->n, dims->m, dims->n_alpha, c->tune.tiled_nt_min)) ? "mfma_f64_tiled" : "generic_lds";
     if ((dims->flags & KPILQR_FLAG_FUSED) && !generic && !force_tiled &&
         fused_supported(c->n, dims->m, dims->nr, dims->dof, dims->T, c->L.stride, dims->n_alpha)) {
         c->fused = true;
@@ -134,8 +157,8 @@ int kpilqr_create(const kpilqr_dims *dims, void *stream, kpilqr_ctx **out)
     // three tiles at the batches measured.  KPILQR_TILED_A6 = 0 | 1 overrides the choice.
     if ((dims->flags & KPILQR_FLAG_FUSED) && !c->fused && dims->nr <= 16 &&
         strcmp(c->bwd_variant, "mfma_f64_tiled") == 0 && strcmp(c->fwd_variant, "mfma_f64_tiled") == 0) {
-        const char *ea = getenv("KPILQR_TILED_A6");
-        const bool want = ea ? atoi(ea) != 0 : (tiled_tiles(c->n) == 4 && dims->batch >= 96);
+        const bool want = c->tune.tiled_a6 >= 0 ? c->tune.tiled_a6 != 0
+                                                : (tiled_tiles(c->n, c->tune.tiled_nt_min) == 4 && dims->batch >= 96);
         if (want) {
             c->tiled_a6 = true;
             c->bwd_variant = c->fwd_variant = "mfma_f64_tiled_a6";

@@ -482,20 +482,19 @@ size_t backward_col_lds_bytes(int nt)
 
 size_t backward_tiled_lds_bytes(int nt) { return backward_col_lds_bytes(nt); }
 
-static int tiled_nt(int n)
+static int tiled_nt(int n, int nt_min)
 {
     int nt = (n + 1 + 15) / 16;
     if (nt < 2) nt = 2;
-    const char *e = getenv("KPILQR_TILED_NT_MIN");      // diagnostic: run with more tiles than needed
-    if (e && atoi(e) > nt) nt = atoi(e);
+    if (nt_min > nt) nt = nt_min;                       // diagnostic (KPILQR_TILED_NT_MIN): more tiles than needed
     return nt;
 }
 
-int tiled_tiles(int n) { return tiled_nt(n); }
+int tiled_tiles(int n, int nt_min) { return tiled_nt(n, nt_min); }
 
-bool backward_tiled_supported(int n, int m)
+bool backward_tiled_supported(int n, int m, int nt_min)
 {
-    const int nt = tiled_nt(n);
+    const int nt = tiled_nt(n, nt_min);
     return nt >= 2 && nt <= 4 && m >= 1 && m <= 8 && backward_tiled_lds_bytes(nt) <= 160 * 1024;
 }
 
@@ -518,7 +517,7 @@ static hipError_t launch_bt(Ctx *c, int pd_stride)
 
 hipError_t launch_backward_tiled(Ctx *c, int pd_stride)
 {
-    const int nt = tiled_nt(c->n), m = c->d.m;
+    const int nt = tiled_nt(c->n, c->tune.tiled_nt_min), m = c->d.m;
     if (m == 7) { if (nt == 2) return launch_bt<7, 2>(c, pd_stride); if (nt == 3) return launch_bt<7, 3>(c, pd_stride); if (nt == 4) return launch_bt<7, 4>(c, pd_stride); }
     if (m == 1) { if (nt == 2) return launch_bt<1, 2>(c, pd_stride); if (nt == 3) return launch_bt<1, 3>(c, pd_stride); if (nt == 4) return launch_bt<1, 4>(c, pd_stride); }
     if (m >= 1 && m <= 8) { if (nt == 2) return launch_bt<8, 2>(c, pd_stride); if (nt == 3) return launch_bt<8, 3>(c, pd_stride); if (nt == 4) return launch_bt<8, 4>(c, pd_stride); }
@@ -747,15 +746,15 @@ k_forward_tiled(RecLayout L, CostSrc CS, int T, int n_alpha, const double *__res
     }
 }
 
-bool forward_tiled_supported(int n, int m, int n_alpha)
+bool forward_tiled_supported(int n, int m, int n_alpha, int nt_min)
 {
-    const int nt = tiled_nt(n);
+    const int nt = tiled_nt(n, nt_min);
     return nt >= 2 && nt <= 4 && m <= 16 && n_alpha <= 16;
 }
 
 hipError_t launch_forward_tiled(Ctx *c, double *U_alpha_dev)
 {
-    const int nt = tiled_nt(c->n);
+    const int nt = tiled_nt(c->n, c->tune.tiled_nt_min);
     const CostSrc CS = {c->r, c->r_x, c->r_u, c->w_run, c->w_term, c->d.nr};
 #define LAUNCH_FT(NT)                                                                                               \
     do {                                                                                                            \

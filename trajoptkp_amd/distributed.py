@@ -26,8 +26,12 @@ def pack_linesearch(cost_pred, delta_J, status):
     n_alpha = cp.shape[1]
     if n_alpha > 6:
         raise ValueError("the reduction vector carries at most 6 alphas")
-    out[:n_alpha] = (cp * ok[:, None]).sum(0)
-    out[6] = (torch.as_tensor(delta_J).to(cp.device) * ok).sum()
+    # torch.where, not multiplication: a trajectory whose backward pass failed keeps stale gains and its rollout may
+    # hold inf/NaN (inf * 0 = NaN would poison the sum); k_pack_linesearch skips such rows the same way
+    zero = torch.zeros((), dtype=cp.dtype, device=cp.device)
+    out[:n_alpha] = torch.where(ok[:, None], cp, zero).sum(0)
+    dJ = torch.as_tensor(delta_J).to(cp.device)
+    out[6] = torch.where(ok, dJ, zero.to(dJ.dtype)).sum()
     out[7] = ok.sum()
     return out
 
