@@ -155,6 +155,171 @@ def make_problem(task="panda_reaching", T=3000, batch=1, min_N=5, config_id=2, d
     )
 
 
+def contact_trajectory(rng, dof, T, dt, n_joints=7):
+    """synthetic nominal state trajectory of a pushing task -- a cubic-spline reach of the arm
+    joints (plus a small smooth wiggle, as a tracking controller leaves) and a contact event at t in U(800, 2200)
+    (scaled to the horizon) that puts a velocity step of 0.2 m/s on the body DoFs, decaying with friction.
+    Returns X [T, 2*dof] (positions, then velocities), the input of the key-point generators."""
+    tt = np.arange(T) * dt
+    tau = tt / max(tt[-1], dt)
+    q = np.zeros((T, dof)); v = np.zeros((T, dof))
+    nj = min(n_joints, dof)
+    q0 = rng.uniform(-1.0, 1.0, nj); q1 = q0 + rng.uniform(-1.2, 1.2, nj)
+    sp = 3 * tau ** 2 - 2 * tau ** 3
+    dsp = (6 * tau - 6 * tau ** 2) / max(tt[-1], dt)
+    amp = rng.uniform(0.0, 0.03, nj); om = rng.uniform(2.0, 9.0, nj); ph = rng.uniform(0, 2 * np.pi, nj)
+    q[:, :nj] = q0 + (q1 - q0) * sp[:, None] + amp * np.sin(om * tt[:, None] + ph)
+    v[:, :nj] = (q1 - q0) * dsp[:, None] + amp * om * np.cos(om * tt[:, None] + ph)
+    if dof > nj:
+        tc = int(rng.uniform(800.0, 2200.0) * T / 3000.0)
+        tc = min(max(tc, 2), T - 3)
+        dirs = rng.uniform(-1.0, 1.0, dof - nj)
+        dirs *= 0.2 / max(np.max(np.abs(dirs)), 1e-9)
+        after = np.maximum(tt - tt[tc], 0.0)
+        on = (np.arange(T) >= tc)[:, None]
+        decay = np.exp(-after / 1.5)[:, None]
+        v[:, nj:] = on * dirs * decay
+        q[:, nj:] = on * dirs * 1.5 * (1.0 - decay)
+        # the arm feels the contact too: a small velocity kick on two joints
+        for j in rng.choice(nj, size=min(2, nj), replace=False):
+            kick = rng.uniform(-0.05, 0.05)
+            v[:, j] += on[:, 0] * kick * decay[:, 0]
+            q[:, j] += on[:, 0] * kick * 1.5 * (1.0 - decay[:, 0])
+    return np.concatenate([q, v], axis=1)
+
+
+def dynamics_dense_smooth(rng, dof, m, dt, T, n_events=3):
+    """Dense (every step) Jacobians of a random mechanical system whose parameters vary smoothly in time, with a few
+    contact-like events that switch the stiffness/damping of single DoFs -- the input of the emulated
+    `iterative_error` key-point placement.  Column-major stacks A [T, n, n], B [T, m, n]."""
+    n = 2 * dof
+    G = rng.standard_normal((dof, dof))
+    Mass = np.diag(rng.uniform(0.5, 3.0, dof)) + 0.1 * G @ G.T / dof + 2.0 * np.eye(dof)
+    Minv = np.linalg.inv(Mass)
+    tt = np.arange(T) * dt
+    stiff0 = rng.uniform(0.0, 20.0, dof); damp0 = rng.uniform(0.1, 2.0, dof)
+    om = rng.uniform(0.05, 0.6, (2, dof)); ph = rng.uniform(0, 2 * np.pi, (2, dof)); amp = rng.uniform(0.0, 0.5, (2, dof))
+    amp[:, rng.uniform(size=dof) < 0.4] = 0.0                          # some DoFs hardly change: few key-points
+    stiff = stiff0 * (1.0 + amp[0] * np.sin(om[0] * tt[:, None] + ph[0]))
+    damp = damp0 * (1.0 + amp[1] * np.sin(om[1] * tt[:, None] + ph[1]))
+    # contact-rich DoFs: band-limited jitter (correlation time ~25 steps) on top of the slow variation
+    rough = rng.uniform(size=dof) < 0.5
+    kern = np.hanning(51); kern /= kern.sum()
+    for j in np.nonzero(rough)[0]:
+        stiff[:, j] *= 1.0 + 0.3 * np.convolve(rng.standard_normal(T + 50), kern, mode="valid")
+        damp[:, j] *= 1.0 + 0.3 * np.convolve(rng.standard_normal(T + 50), kern, mode="valid")
+    for _ in range(n_events):
+        te = int(rng.integers(T // 10, T - T // 10)); j = int(rng.integers(0, dof))
+        ramp = np.clip((np.arange(T) - te) / 40.0, 0.0, 1.0)
+        stiff[:, j] += ramp * rng.uniform(5.0, 30.0)
+        damp[:, j] += ramp * rng.uniform(0.5, 3.0)
+    A = np.zeros((T, n, n)); B = np.zeros((T, m, n))
+    Ar = np.broadcast_to(np.eye(n), (T, n, n)).copy()                   # row-major A[t, r, c]
+    Ar[:, :dof, dof:] += dt * np.eye(dof)
+    Ar[:, dof:, :dof] += dt * (-Minv[None, :, :] * stiff[:, None, :])
+    Ar[:, dof:, dof:] += dt * (-Minv[None, :, :] * damp[:, None, :])
+    A[:] = np.swapaxes(Ar, 1, 2)
+    Bk = np.zeros((n, m)); Bk[dof:, :] = dt * Minv[:, :m]
+    B[:] = Bk.T
+    return A, B
+
+
+def rows_from_dof_lists(dof, T, lists):
+    """Per-DoF sorted key-point times -> the reference's rows (CSR over time: offs [T+1], cols)."""
+    per_t = [[] for _ in range(T)]
+    for i in range(dof):
+        for t in lists[i]:
+            per_t[int(t)].append(i)
+    offs = np.zeros(T + 1, np.int32); cols = []
+    for t in range(T):
+        offs[t] = len(cols); cols.extend(per_t[t])
+    offs[T] = len(cols)
+    return offs, np.asarray(cols, np.int32)
+
+
+def make_ragged_problem(task, T, kp_rows, dyn=None, config_id=3, dense_residuals=True, one_sided_frac=0.0, lam=0.1,
+                        eps=1e-6, first_b=0):
+    """Like make_problem, but with one key-point row list PER TRAJECTORY (adaptive_jerk / iterative_error style:
+    every DoF has its own key-point times) and FD jobs only where the reference would compute them: at step t the
+    columns of the DoFs listed in keypoints[t] (control column i for i < num_ctrl, velocity column i+dof, position
+    column i; Differentiator.cpp:81-428).  dyn: optional list of dense (A [T,n,n], B [T,m,n]) per trajectory (else a
+    random walk over the union of key-point times)."""
+    cfg = TASKS[task]
+    dof, m, nr, dt = cfg["dof"], cfg["m"], cfg["nr"], cfg["dt"]
+    n = 2 * dof
+    batch = len(kp_rows)
+    lim = np.asarray(cfg["lim"], dtype=np.float64)
+    ctrl_lim = np.stack([-lim, lim], axis=1).reshape(-1)
+    job_b, job_t, job_col, job_mode, job_nom, xplus, xminus, xnom = [], [], [], [], [], [], [], []
+    r = np.zeros((batch, T + 1, nr)); r_x = np.zeros((batch, T + 1, nr, n)); r_u = np.zeros((batch, T + 1, nr, m))
+    u_nom = np.zeros((batch, T, m))
+    nom_base = 0
+    for b in range(batch):
+        rng = np.random.default_rng(seed_for(config_id, first_b + b))
+        offs, cols = kp_rows[b]
+        kp_t = np.nonzero(np.diff(offs))[0].astype(np.int32)
+        if dyn is not None:
+            A_kp, B_kp = dyn[b][0][kp_t], dyn[b][1][kp_t]
+        else:
+            A_kp, B_kp = _dynamics_keypoints(rng, dof, m, dt, kp_t)
+        x0 = rng.standard_normal((len(kp_t), n))
+        for k, t in enumerate(kp_t):
+            ds = np.asarray(cols[offs[t]:offs[t + 1]], np.int64)
+            cc = np.concatenate([n + ds[ds < m], dof + ds, ds]).astype(np.int32)          # ctrl, vel, pos
+            J = np.concatenate([B_kp[k][ds[ds < m]], A_kp[k][dof + ds], A_kp[k][ds]], axis=0)   # [ncol, n] columns
+            mode = np.zeros(len(cc), np.uint8)
+            if one_sided_frac > 0:
+                u = rng.uniform(size=len(cc))
+                mode[u < one_sided_frac] = 1
+                mode[u < one_sided_frac / 2] = 2
+            xp = x0[k][None, :] + eps * J; xm = x0[k][None, :] - eps * J
+            xp = np.where((mode == 2)[:, None], x0[k][None, :], xp)
+            xm = np.where((mode == 1)[:, None], x0[k][None, :], xm)
+            job_b.append(np.full(len(cc), b, np.int32)); job_t.append(np.full(len(cc), t, np.int32))
+            job_col.append(cc); job_mode.append(mode); job_nom.append(np.full(len(cc), nom_base + k, np.int32))
+            xplus.append(xp); xminus.append(xm)
+        xnom.append(x0); nom_base += len(kp_t)
+        scale = np.linspace(0.5, 0.05, T + 1)[:, None]
+        r[b] = rng.standard_normal((T + 1, nr)) * scale
+        if dense_residuals:
+            r_x[b] = rng.standard_normal((T + 1, nr, n)) * 0.3
+            r_u[b] = rng.standard_normal((T + 1, nr, m)) * 0.05
+        else:
+            for i in range(nr):
+                r_x[b, :, i, i % n] = 1.0
+        u_nom[b] = rng.uniform(-0.3, 0.3, (T, m)) * lim[None, :m]
+    return dict(
+        task=task, dof=dof, n=n, m=m, nr=nr, T=T, batch=batch, dt=dt, eps=eps, lam=lam,
+        kp_rows=list(kp_rows), kp_times=None,
+        job_b=np.concatenate(job_b), job_t=np.concatenate(job_t), job_col=np.concatenate(job_col),
+        job_mode=np.concatenate(job_mode), job_nom=np.concatenate(job_nom),
+        xplus=np.concatenate(xplus), xminus=np.concatenate(xminus), xnom=np.concatenate(xnom),
+        r=r, r_x=r_x, r_u=r_u, w_run=np.asarray(cfg["w_run"], np.float64), w_term=np.asarray(cfg["w_term"], np.float64),
+        u_nom=u_nom, ctrl_lim=ctrl_lim,
+    )
+
+
+def bisect_keypoints(rng, dof, T, min_N, density):
+    """Cheap stand-in for the iterative_error placement when no dense A is at hand: recursive bisection of [0, T-1]
+    per DoF, splitting an interval with a probability that depends on the DoF (`density` [dof] in 0..1) -- the same
+    list structure GenerateKeyPointsIteratively emits (KeyPointGenerator.cpp:449-548): per DoF sorted, first 0, last
+    T-1, gaps that are powers-of-two fractions of the horizon."""
+    lists = []
+    for i in range(dof):
+        pts = {0, T - 1}
+        stack = [(0, T - 1)]
+        while stack:
+            a, b = stack.pop()
+            if b - a <= min_N:
+                continue
+            mid = (a + b) // 2
+            if rng.uniform() < density[i]:
+                pts.add(mid)
+                stack.append((a, mid)); stack.append((mid, b))
+        lists.append(sorted(pts))
+    return rows_from_dof_lists(dof, T, lists)
+
+
 def tile_problem(p, reps):
     """Replicate a problem `reps` times along the batch axis (bench: few unique seeds, full batch)."""
     B0 = p["batch"]
