@@ -796,3 +796,83 @@ def test_fused_indefinite_quu_on_unchecked_steps(wave_form):
             o = pipeline.run_trajectory(p, b, lam=lam, pd_stride=1000, stages=("fd", "interp", "cost", "bwd"))
             assert st[b] == 0 and o["status"] == 0
             assert relerr(K[b], o["K"]) < 1e-6 and relerr(k[b], o["k"]) < 1e-6, (lam, b, relerr(K[b], o["K"]))
+
+
+# ---- asynchronous boundary: pinned slab, device-side slot table / validation, chunk pipeline --------------------------
+def _staged(p, fused):
+    with Engine(p["dof"], p["m"], p["T"], p["nr"], batch=p["batch"], fused=fused) as e:
+        synth.upload(e, p)
+        e.iterate(p["lam"], 100, orc.alphas(6))
+        res = e.results(); K, k = e.gains()
+    return K, k, res
+
+
+@pytest.mark.parametrize("task,T,batch,fused", [("panda_reaching", 200, 13, True), ("panda_reaching", 200, 13, False),
+                                                ("panda_pushing", 90, 5, False), ("acrobot", 100, 3, True)])
+def test_fd_slab_and_streamed_iteration_are_bit_identical(task, T, batch, fused):
+    """The one-slab upload (slot table from the caller, or built on the device) and the chunk-pipelined iteration give
+    the bytes of the array-by-array upload + kpilqr_iterate, whatever the number of chunks."""
+    p = synth.make_problem(task=task, T=T, batch=batch, min_N=5, dense_residuals=True, one_sided_frac=0.2)
+    K0, k0, res0 = _staged(p, fused)
+    for with_slots in (True, False):
+        with Engine(p["dof"], p["m"], T, p["nr"], batch=batch, fused=fused) as e:
+            synth.upload(e, p)                                    # key-points, weights, limits, nominal controls, residuals
+            e.upload_fd([], [], [], [], np.zeros((0, p["n"])), np.zeros((0, p["n"])))     # forget the FD payload
+            s = e.fd_slab(p["job_b"], p["job_t"], p["job_col"], p["job_mode"], p["xplus"], p["xminus"], p["job_nom"], p["xnom"],
+                          with_slots=with_slots)
+            e.upload_fd_slab(s, p["eps"])
+            e.iterate(p["lam"], 100, orc.alphas(6))
+            res = e.results(); K, k = e.gains()
+        assert np.array_equal(K, K0) and np.array_equal(k, k0), (task, with_slots)
+        assert np.array_equal(res["cost_pred"], res0["cost_pred"]) and np.array_equal(res["delta_J"], res0["delta_J"])
+    for nchunks in (1, 3, 4, 7, batch):
+        with Engine(p["dof"], p["m"], T, p["nr"], batch=batch, fused=fused) as e:
+            e.set_keypoints_rows(p["kp_rows"])
+            e.upload_residuals(None, None, None, p["w_run"], p["w_term"])
+            e.upload_nominal(None, p["ctrl_lim"])
+            e.forward_linear(orc.alphas(6), fetch=False)         # alphas resident (the sweep itself runs on garbage once)
+            s = e.fd_slab(p["job_b"], p["job_t"], p["job_col"], p["job_mode"], p["xplus"], p["xminus"], p["job_nom"], p["xnom"])
+            pin = {}
+            for name in ("r", "r_x", "r_u", "u_nom"):
+                pin[name] = e.pinned(p[name].shape); pin[name][...] = p[name]
+            lam = e.pinned(batch); lam[:] = p["lam"]
+            K = e.pinned(K0.shape); k = e.pinned(k0.shape)
+            cp = e.pinned((batch, 6)); dJ = e.pinned(batch); st = e.pinned(batch, np.int32)
+            for _ in range(2):                                    # twice back to back: nothing waits in between
+                e.iterate_streamed(fd=s, eps=p["eps"], lam=lam, K=K, k=k, cost_pred=cp, delta_J=dJ, status=st, nchunks=nchunks, **pin)
+            e.sync()
+            assert np.array_equal(K, K0) and np.array_equal(k, k0), (task, nchunks)
+            assert np.array_equal(cp, res0["cost_pred"]) and np.array_equal(dJ, res0["delta_J"]) and np.all(st == 0)
+            # and the ordinary calls after a streamed iteration see its results (the chunk streams are joined)
+            K2, k2 = e.gains()
+            assert np.array_equal(K2, K0)
+
+
+def test_fd_indices_are_checked_on_the_device():
+    """A job with an out-of-range trajectory, time, column, mode or nominal row is skipped by the kernel (no
+    out-of-bounds write) and reported by the next kpilqr_sync; the valid jobs still land."""
+    from trajoptkp_amd.engine import KpilqrError
+    p = synth.make_problem(task="panda_reaching", T=40, batch=2, min_N=5, one_sided_frac=0.3)
+    with Engine(p["dof"], p["m"], p["T"], p["nr"], batch=2) as e:
+        synth.upload(e, p)
+        e.fd_difference(); e.sync()
+        A0, B0 = e.get_AB()
+    for field, bad in (("job_b", 2), ("job_b", -1), ("job_t", 40), ("job_col", 21), ("job_mode", 3), ("job_nom", 10**6)):
+        q = dict(p); q[field] = p[field].copy()
+        j = int(np.nonzero(p["job_mode"] != 0)[0][0]) if field == "job_nom" else 5
+        q[field][j] = bad
+        with Engine(p["dof"], p["m"], p["T"], p["nr"], batch=2) as e:
+            e.set_keypoints_rows(q["kp_rows"])
+            e.upload_fd(q["job_b"], q["job_t"], q["job_col"], q["job_mode"], q["xplus"], q["xminus"], job_nom=q["job_nom"], xnom=q["xnom"], eps=q["eps"])
+            e.fd_difference()
+            with pytest.raises(KpilqrError) as ei:
+                e.sync()
+            assert ei.value.code == -1 and "FD job" in str(ei.value), field
+            e.sync()                                              # the flag is cleared once reported
+            A, B = e.get_AB()
+        # every other key-point is untouched by the bad job
+        t_bad, b_bad = int(p["job_t"][j]), int(p["job_b"][j])
+        mask = np.ones(A0.shape[:2], bool); mask[b_bad, t_bad] = False
+        if field in ("job_b", "job_t"):
+            mask[b_bad, t_bad:min(t_bad + 1, 40)] = False
+        assert np.array_equal(A[mask], A0[mask]) and np.array_equal(B[mask], B0[mask]), field

@@ -1,56 +1,103 @@
-"""PCIe-inclusive iteration rate: every iteration re-uploads the FD payload and the
-residuals + Jacobians from PINNED host memory and downloads K,k, as a host that re-linearises every
-iteration would.  Not the bench metric (bench.py keeps inputs resident)."""
-import sys, time, ctypes
+"""PCIe-inclusive iteration rate: every iteration re-uploads the FD payload and the residuals
+(+ Jacobians) from PINNED host memory and downloads K, k, as a host that re-linearises every iteration does.
+Not the bench metric (bench.py keeps inputs resident; it reports these figures in `pcie_inclusive`).
+
+  python tools/pcie_inclusive.py [batch] [steps]
+
+Forms: "serial"  = kpilqr_upload_fd + kpilqr_upload_residuals + kpilqr_iterate + kpilqr_download_gains + sync per iteration
+       "chunks=N" = kpilqr_iterate_streamed over N trajectory chunks (H2D | kernels | D2H overlapped), one sync at the end
+       of the timed loop ("pipelined") or after every iteration ("per-iteration sync").
+"""
+import sys
+import time
+
 import numpy as np
-import torch
+
 sys.path.insert(0, ".")
-from trajoptkp_amd import Engine, synth
-from trajoptkp_amd.engine import _ptr
-
-B = int(sys.argv[1]) if len(sys.argv) > 1 else 256
-T, steps = 3000, 5
-p0 = synth.make_problem(task="panda_reaching", T=T, batch=8, min_N=5)
-p = synth.tile_problem(p0, B // 8)
+from trajoptkp_amd import Engine, synth   # noqa: E402
 
 
-def pinned(a):
-    t = torch.empty(a.shape, dtype=torch.float64, pin_memory=True)
-    v = t.numpy(); v[...] = a
-    return t, v
+def measure(B=256, steps=5, T=3000, task="panda_reaching", chunk_list=(4, 8, 16), quiet=False):
+    uniq = min(8, B)
+    p0 = synth.make_problem(task=task, T=T, batch=uniq, min_N=5)
+    p = synth.tile_problem(p0, B // uniq)
+    B = p["batch"]
+    out = {"batch": B, "T": T, "task": task, "steps": steps}
+    with Engine(p["dof"], p["m"], T, p["nr"], batch=B, fused=True) as e:
+        synth.upload(e, p)
+        alphas = np.array([(i / 6.0) ** 2 for i in range(1, 7)])
+        e.iterate(p["lam"], 100, alphas); e.sync()
+        K0, k0 = e.gains()
+        pin = {}
+        for name in ("r", "r_x", "r_u", "u_nom", "xplus", "xminus", "xnom"):
+            pin[name] = e.pinned(p[name].shape); pin[name][...] = p[name]
+        ints = {}
+        for name, dt in (("job_b", np.int32), ("job_t", np.int32), ("job_col", np.int32), ("job_nom", np.int32), ("job_mode", np.uint8)):
+            ints[name] = e.pinned(p[name].shape, dt); ints[name][...] = p[name]
+        lam = e.pinned(B); lam[:] = p["lam"]
+        K = e.pinned(K0.shape); k = e.pinned(k0.shape)
+        slab = e.fd_slab(p["job_b"], p["job_t"], p["job_col"], p["job_mode"], p["xplus"], p["xminus"], p["job_nom"], p["xnom"])
+        fd_bytes = slab["layout"].bytes
+        res_bytes = {True: pin["r"].nbytes + pin["r_x"].nbytes + pin["r_u"].nbytes, False: pin["r"].nbytes}
+        dn_bytes = K.nbytes + k.nbytes
+        from trajoptkp_amd.engine import _ptr
 
-keep = []
-for k in ("xplus", "xminus", "xnom", "r", "r_x", "r_u"):
-    t, v = pinned(p[k]); keep.append(t); p[k] = v
-e = Engine(p["dof"], p["m"], T, p["nr"], batch=B, fused=True)
-synth.upload(e, p)
-tK, K = pinned(np.zeros((B, T, e.n, e.m))); tk, kk = pinned(np.zeros((B, T, e.m)))
-lam = np.full(B, 0.1)
-up_bytes = sum(p[k].nbytes for k in ("xplus", "xminus", "xnom", "r", "r_x", "r_u"))
-dn_bytes = K.nbytes + kk.nbytes
+        def serial(full):
+            e.upload_fd(ints["job_b"], ints["job_t"], ints["job_col"], ints["job_mode"], pin["xplus"], pin["xminus"],
+                        job_nom=ints["job_nom"], xnom=pin["xnom"], eps=p["eps"])
+            if full:
+                e.upload_residuals(pin["r"], pin["r_x"], pin["r_u"])
+            else:
+                e.upload_residuals(pin["r"])
+            e.iterate(lam)
+            e._ck(e._L.kpilqr_download_gains(e._h, _ptr(K), _ptr(k)))
+            e.sync()
+
+        def streamed(full, nchunks, sync_each):
+            kw = dict(r=pin["r"], r_x=pin["r_x"], r_u=pin["r_u"]) if full else dict(r=pin["r"])
+            e.iterate_streamed(fd=slab, eps=p["eps"], lam=lam, K=K, k=k, nchunks=nchunks, **kw)
+            if sync_each:
+                e.sync()
+
+        def timed(fn, *a):
+            fn(*a); fn(*a); e.sync()
+            t0 = time.perf_counter()
+            for _ in range(steps):
+                fn(*a)
+            e.sync()
+            return (time.perf_counter() - t0) / steps
+
+        rows = []
+        for full in (True, False):
+            up = fd_bytes + res_bytes[full]
+            label = "full payload" if full else "resident Jacobians"
+            dt = timed(serial, full)
+            rows.append((label, "serial", dt, up))
+            for nc in chunk_list:
+                for sync_each in (True, False):
+                    K[...] = 0
+                    dt = timed(streamed, full, nc, sync_each)
+                    assert np.array_equal(K, K0) and np.array_equal(k, k0), "streamed K differs from the staged path"
+                    rows.append((label, f"chunks={nc} " + ("per-iteration sync" if sync_each else "pipelined"), dt, up))
+        e.iterate(lam); e.sync()
+        t0 = time.perf_counter()
+        for _ in range(steps):
+            e.iterate(lam)
+        e.sync()
+        dt_res = (time.perf_counter() - t0) / steps
+    out["resident_traj_it_per_s"] = B / dt_res
+    out["rows"] = [dict(payload=a, form=b, ms_per_iteration=1e3 * dt, traj_it_per_s=B / dt, h2d_GB=up / 1e9, d2h_GB=dn_bytes / 1e9,
+                        link_GBps=(up + dn_bytes) / dt / 1e9) for (a, b, dt, up) in rows]
+    if not quiet:
+        print(f"B={B} resident: {1e3 * dt_res:8.2f} ms/batch-iteration = {B / dt_res:9.1f} trajectory-iterations/s")
+        for r in out["rows"]:
+            print(f"B={B} {r['payload']:18s} {r['form']:32s}: {r['ms_per_iteration']:8.2f} ms = {r['traj_it_per_s']:9.1f} traj-it/s"
+                  f"  (H2D {r['h2d_GB']:.2f} GB + D2H {r['d2h_GB']:.2f} GB -> {r['link_GBps']:.1f} GB/s)", flush=True)
+    return out
 
 
-def one(upload=True):
-    if upload:
-        e.upload_fd(p["job_b"], p["job_t"], p["job_col"], p["job_mode"], p["xplus"], p["xminus"],
-                    job_nom=p["job_nom"], xnom=p["xnom"], eps=p["eps"])
-        if upload == "analytic":          # closed-form residual Jacobians stay resident (reaching: selector rows)
-            e.upload_residuals(p["r"])
-        else:
-            e.upload_residuals(p["r"], p["r_x"], p["r_u"])
-    e.iterate(lam)
-    if upload:
-        e._ck(e._L.kpilqr_download_gains(e._h, _ptr(K), _ptr(kk)))
-    e.sync()
-
-for mode in (True, "analytic", False):
-    if mode == "analytic":
-        up_bytes = sum(p[k].nbytes for k in ("xplus", "xminus", "xnom", "r"))
-    one(mode); one(mode)
-    t0 = time.perf_counter()
-    for _ in range(steps):
-        one(mode)
-    dt = (time.perf_counter() - t0) / steps
-    label = {True: "PCIe-inclusive          ", "analytic": "PCIe-inclusive, J const ", False: "resident                "}[mode]
-    print(f"B={B} {label}: {dt*1e3:8.2f} ms/batch-iteration = {B/dt:9.1f} trajectory-iterations/s"
-          + (f"   (H2D {up_bytes/1e9:.2f} GB + D2H {dn_bytes/1e9:.2f} GB per iteration -> {(up_bytes+dn_bytes)/dt/1e9:.1f} GB/s over PCIe)" if mode else ""), flush=True)
+if __name__ == "__main__":
+    B = int(sys.argv[1]) if len(sys.argv) > 1 else 256
+    steps = int(sys.argv[2]) if len(sys.argv) > 2 else 5
+    chunks = tuple(int(x) for x in sys.argv[3].split(",")) if len(sys.argv) > 3 else (4, 8, 16)
+    measure(B, steps, chunk_list=chunks)

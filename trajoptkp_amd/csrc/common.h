@@ -79,15 +79,38 @@ struct Ctx {
     int comm_ranks = 1;
     double *ls8 = nullptr;
 
-    // FD job buffers (grow on demand)
-    int njobs = 0, nnom = 0, nslots = 0;   // slot = run of consecutive jobs with one (b, t)
+    // FD job buffers: ONE device slab (grown on demand) whose layout mirrors the host slab of kpilqr_fd_slab_layout,
+    // so that an upload is one hipMemcpyAsync; the pointers below point into it and are recomputed by every upload
+    char *fd_dev = nullptr;
+    size_t fd_dev_cap = 0;                 // bytes
+    int njobs = 0, nnom = 0;
+    int nslots = 0;                        // slot = run of consecutive jobs with one (b, t); < 0: the count lives in nslots_dev
     int *slot_start = nullptr;             // [nslots+1] (device)
-    size_t slot_cap = 0;
-    size_t job_cap = 0, nom_cap = 0;
+    int *nslots_dev = nullptr;             // device int: slot count when the table was built on the device
+    int *slot_scratch = nullptr;           // per-1024-job block counts / offsets of the device slot build
+    size_t slot_scratch_cap = 0;           // ints
     int *job_b = nullptr, *job_t = nullptr, *job_col = nullptr, *job_nom = nullptr;
     unsigned char *job_mode = nullptr;
     double *xplus = nullptr, *xminus = nullptr, *xnom = nullptr;
     double eps = 1e-6;
+    // a view of a trajectory range (kpilqr_iterate_streamed) has shifted per-trajectory pointers; the FD jobs carry
+    // ABSOLUTE trajectory indices, so fd_difference addresses the records through the unshifted base
+    double *rec_fd_base = nullptr;
+    int fd_batch_total = 0;
+    // device-side argument checks raise bits here; kpilqr_sync reads it back through the pinned mirror
+    int *err_flag = nullptr;
+    int *err_flag_host = nullptr;          // pinned
+
+    // trajectory-chunk pipeline of kpilqr_iterate_streamed: H2D(c+1) | kernels(c) | D2H(c-1) on separate streams
+    // three streams: with the context's own stream that is the runtime's default of four hardware queues -- a fourth
+    // chunk stream shares a queue with another one and the pipeline stalls (measured: B=256, resident Jacobians,
+    // 22.7 ms with 3 chunks on 3 streams, 31.7 ms with 4 on 4; profiles/r02_pcie_inclusive.txt)
+    static constexpr int kPipeStreams = 3;
+    hipStream_t pipe_stream[kPipeStreams] = {nullptr, nullptr, nullptr};
+    hipEvent_t pipe_done[kPipeStreams] = {nullptr, nullptr, nullptr};
+    hipEvent_t pipe_in = nullptr;
+    bool pipe_ready = false, pipe_dirty = false;
+    int pipe_chunks = 0;
 
     // staging for debug hooks / U_alpha
     double *stage = nullptr;
@@ -105,6 +128,7 @@ struct Ctx {
         int tiled_nt_min = 0;      // KPILQR_TILED_NT_MIN: run the tiled kernels with more tiles than needed
         int tiled_a6 = -1;         // KPILQR_TILED_A6: -1 auto, 0 | 1
         int tiled_a4 = -1;         // KPILQR_TILED_A4: -1 auto, 0 | 1 (a4 inside the tiled sweeps)
+        int pipe_copy = -1;        // KPILQR_PIPE_COPY: chunk pipeline copies by kernel: bit 0 uploads, bit 1 downloads (-1 auto)
     } tune;
 };
 
@@ -122,6 +146,9 @@ Ctx::Tuning read_tuning_from_env();
 // ---- launchers (defined in the .hip files) --------------------------------------------------
 // elementwise.hip
 hipError_t launch_fd_difference(Ctx *c);
+hipError_t launch_build_slots(Ctx *c);
+hipError_t launch_copy_out(hipStream_t s, double *dst_host, const double *src_dev, size_t count);   // D2H by a kernel
+hipError_t launch_copy_in(hipStream_t s, void *dst_dev, const void *src_host, size_t bytes);        // H2D by a kernel       // slot table + count from job_b / job_t, on the device
 int fd_difference_waves(int n, int m);       // 0: the dims do not fit the kernel's LDS image
 hipError_t launch_build_segmap(Ctx *c);
 // comm.cpp (RCCL opened lazily) and the pack kernel of elementwise.hip

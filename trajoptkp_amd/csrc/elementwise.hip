@@ -20,23 +20,41 @@ namespace kpilqr {
 // order of the record's [A|B] block, so both the HBM reads and the HBM writes are coalesced.
 // Columns the slot does not hold are left untouched (ragged key-points).
 #define FD_WAVES 4
+// error bits raised by the device-side checks (Ctx::err_flag, reported by kpilqr_sync)
+#define KP_ERRBIT_FD_INDEX 1        // FD job with trajectory / time / column / mode / nominal row out of range
+
+// The slot count is either known on the host (`nslots`, the caller handed the slot table over) or lives on the device
+// (`nslots_ptr`, written by k_slots_write): the blocks stride over the slots, so the launch never needs it on the host.
+// Indices are validated here (a bad one would be an out-of-bounds write): an invalid slot or job is skipped and the
+// context's error flag raised -- the host never walks the job arrays.
 __global__ void __launch_bounds__(64 * FD_WAVES)
-k_fd_difference(RecLayout L, int T, int nslots, const int *__restrict__ slot_start,
+k_fd_difference(RecLayout L, int T, int batch, int nnom, int nslots, const int *__restrict__ nslots_ptr,
+                const int *__restrict__ slot_start,
                 const int *__restrict__ job_b, const int *__restrict__ job_t,
                 const int *__restrict__ job_col, const unsigned char *__restrict__ job_mode,
                 const int *__restrict__ job_nom,
                 const double *__restrict__ xplus, const double *__restrict__ xminus,
-                const double *__restrict__ xnom, double eps, double *__restrict__ rec)
+                const double *__restrict__ xnom, double eps, double *__restrict__ rec, int *__restrict__ err_flag)
 {
     extern __shared__ __attribute__((aligned(16))) double sh[];
     const int n = L.n, m = L.m, ncol = n + m, ne = n * n + n * m;
+    const int nw = blockDim.x >> 6;                              // 1..FD_WAVES waves per block (LDS budget)
     const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
-    const int slot = blockIdx.x * (blockDim.x >> 6) + wave;      // 1..FD_WAVES waves per block (LDS budget)
+    const int ns = nslots_ptr ? *nslots_ptr : nslots;
     double *sv = sh + wave * (ncol * n + ncol);          // [col][row] values, then per-column job id + 1
     int *present = (int *)(sv + ncol * n);
-    const bool live = slot < nslots;
-    int j0 = 0, nj = 0;
-    if (live) { j0 = slot_start[slot]; nj = slot_start[slot + 1] - j0; }
+    for (int base = blockIdx.x * nw; base < ns; base += gridDim.x * nw) {        // block-uniform trip count
+    const int slot = base + wave;
+    bool live = slot < ns;
+    int j0 = 0, nj = 0, sb = 0, st = 0;
+    if (live) {
+        j0 = slot_start[slot]; nj = slot_start[slot + 1] - j0;
+        sb = job_b[j0]; st = job_t[j0];
+        if (nj < 0 || (unsigned)sb >= (unsigned)batch || (unsigned)st >= (unsigned)T) {
+            if (lane == 0) atomicOr(err_flag, KP_ERRBIT_FD_INDEX);
+            live = false; nj = 0;
+        }
+    }
     for (int cidx = lane; cidx < ncol; cidx += 64) present[cidx] = 0;
     __syncthreads();
     // eight elements per lane per trip as four 16-byte pairs (n = 2*dof is even, so a pair never straddles two jobs): the
@@ -62,16 +80,19 @@ k_fd_difference(RecLayout L, int T, int nslots, const int *__restrict__ slot_sta
         for (int u = 0; u < 4; u++) {
             if (rows_[u] < 0) continue;
             const int job = jobs_[u], row = rows_[u], mode = modes_[u];
+            const int col = job_col[job];
+            if ((unsigned)col >= (unsigned)ncol || mode > 2) { atomicOr(err_flag, KP_ERRBIT_FD_INDEX); continue; }
             double v0, v1;
             if (mode == 0) {
                 v0 = (xp[u].x - xm[u].x) / (2 * eps);
                 v1 = (xp[u].y - xm[u].y) / (2 * eps);
             } else {
-                const double *x0 = xnom + (size_t)job_nom[job] * n + row;
+                const int nom = job_nom[job];
+                if ((unsigned)nom >= (unsigned)nnom) { atomicOr(err_flag, KP_ERRBIT_FD_INDEX); continue; }
+                const double *x0 = xnom + (size_t)nom * n + row;
                 v0 = (mode == 1) ? (xp[u].x - x0[0]) / (eps) : (x0[0] - xm[u].x) / (eps);
                 v1 = (mode == 1) ? (xp[u].y - x0[1]) / (eps) : (x0[1] - xm[u].y) / (eps);
             }
-            const int col = job_col[job];
             sv[col * n + row] = v0;
             sv[col * n + row + 1] = v1;
             if (row == 0) present[col] = 1;
@@ -79,7 +100,7 @@ k_fd_difference(RecLayout L, int T, int nslots, const int *__restrict__ slot_sta
     }
     __syncthreads();
     if (live) {
-        double *R = rec + ((size_t)job_b[j0] * T + job_t[j0]) * L.stride;
+        double *R = rec + ((size_t)sb * T + st) * L.stride;
         // A block: two adjacent columns of a row per lane (n is even and the record is 128-byte aligned: one 16-byte store
         // when both columns are held by the slot); B block: one element per lane
         for (int e2 = lane; e2 < (n * n) >> 1; e2 += 64) {
@@ -94,6 +115,8 @@ k_fd_difference(RecLayout L, int T, int nslots, const int *__restrict__ slot_sta
             const int q = e - n * n, row = q / m, col = n + (q - row * m);
             if (present[col]) R[e] = sv[col * n + row];
         }
+    }
+    __syncthreads();                                            // the LDS image is reused by the next trip
     }
 }
 
@@ -115,14 +138,95 @@ hipError_t launch_fd_difference(Ctx *c)
     const int nw = fd_difference_waves(c->n, c->d.m);
     if (nw < 1) return hipErrorInvalidValue;
     const size_t lds = sizeof(double) * nw * (ncol * c->n + ncol);
-    const int blocks = (c->nslots + nw - 1) / nw;
+    // slot count on the host: one trip per block; on the device (c->nslots < 0): a fixed grid that strides over the slots
+    const bool on_dev = c->nslots < 0;
+    int blocks = on_dev ? (c->n_simd / 4) * 8 : (c->nslots + nw - 1) / nw;
+    if (on_dev) { const int ub = (c->njobs + nw - 1) / nw; if (blocks > ub) blocks = ub; }
     if (lds > 64 * 1024) {
         hipError_t e = hipFuncSetAttribute((const void *)k_fd_difference, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
         if (e != hipSuccess) return e;
     }
-    hipLaunchKernelGGL(k_fd_difference, dim3(blocks), dim3(64 * nw), lds, c->stream, c->L, c->d.T, c->nslots,
+    hipLaunchKernelGGL(k_fd_difference, dim3(blocks), dim3(64 * nw), lds, c->stream, c->L, c->d.T, c->fd_batch_total, c->nnom,
+                       on_dev ? 0 : c->nslots, on_dev ? c->nslots_dev : nullptr,
                        c->slot_start, c->job_b, c->job_t, c->job_col, c->job_mode, c->job_nom, c->xplus,
-                       c->xminus, c->xnom, c->eps, c->rec);
+                       c->xminus, c->xnom, c->eps, c->rec_fd_base, c->err_flag);
+    return hipGetLastError();
+}
+
+// ---- slot table on the device: a slot starts at job j when j == 0 or (job_b, job_t) differs from job j-1 -----------------
+// count per block -> exclusive scan of the block counts (one block) -> each block writes its starts in order.
+#define SLOT_BLOCK 1024
+__device__ __forceinline__ bool slot_head(const int *job_b, const int *job_t, int j)
+{
+    return j == 0 || job_b[j] != job_b[j - 1] || job_t[j] != job_t[j - 1];
+}
+__global__ void __launch_bounds__(256)
+k_slots_count(int njobs, const int *__restrict__ job_b, const int *__restrict__ job_t, int *__restrict__ block_count)
+{
+    __shared__ int part[256];
+    const int j0 = blockIdx.x * SLOT_BLOCK;
+    int cnt = 0;
+    for (int i = threadIdx.x; i < SLOT_BLOCK; i += 256) { const int j = j0 + i; if (j < njobs && slot_head(job_b, job_t, j)) cnt++; }
+    part[threadIdx.x] = cnt;
+    __syncthreads();
+    for (int s = 128; s > 0; s >>= 1) { if (threadIdx.x < s) part[threadIdx.x] += part[threadIdx.x + s]; __syncthreads(); }
+    if (threadIdx.x == 0) block_count[blockIdx.x] = part[0];
+}
+__global__ void __launch_bounds__(1024)
+k_slots_scan(int nblocks, int njobs, int *__restrict__ block_count, int *__restrict__ nslots_out, int *__restrict__ slot_start)
+{
+    __shared__ int part[1024];
+    __shared__ int carry;
+    if (threadIdx.x == 0) carry = 0;
+    __syncthreads();
+    for (int base = 0; base < nblocks; base += 1024) {
+        const int i = base + threadIdx.x;
+        const int v = i < nblocks ? block_count[i] : 0;
+        part[threadIdx.x] = v;
+        __syncthreads();
+        for (int off = 1; off < 1024; off <<= 1) {               // Hillis-Steele inclusive scan
+            const int add = threadIdx.x >= off ? part[threadIdx.x - off] : 0;
+            __syncthreads();
+            part[threadIdx.x] += add;
+            __syncthreads();
+        }
+        if (i < nblocks) block_count[i] = carry + part[threadIdx.x] - v;      // exclusive offset of block i
+        __syncthreads();
+        if (threadIdx.x == 1023) carry += part[1023];
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) { *nslots_out = carry; slot_start[carry] = njobs; }
+}
+__global__ void __launch_bounds__(256)
+k_slots_write(int njobs, const int *__restrict__ job_b, const int *__restrict__ job_t, const int *__restrict__ block_offset,
+              int *__restrict__ slot_start)
+{
+    __shared__ int part[256];
+    const int j0 = blockIdx.x * SLOT_BLOCK + threadIdx.x * 4;                // four consecutive jobs per thread
+    bool h[4];
+    int cnt = 0;
+#pragma unroll
+    for (int u = 0; u < 4; u++) { const int j = j0 + u; h[u] = j < njobs && slot_head(job_b, job_t, j); cnt += h[u]; }
+    part[threadIdx.x] = cnt;
+    __syncthreads();
+    for (int off = 1; off < 256; off <<= 1) {
+        const int add = threadIdx.x >= off ? part[threadIdx.x - off] : 0;
+        __syncthreads();
+        part[threadIdx.x] += add;
+        __syncthreads();
+    }
+    int at = block_offset[blockIdx.x] + part[threadIdx.x] - cnt;
+#pragma unroll
+    for (int u = 0; u < 4; u++) if (h[u]) slot_start[at++] = j0 + u;
+}
+
+hipError_t launch_build_slots(Ctx *c)
+{
+    if (c->njobs == 0) return hipSuccess;
+    const int nb = (c->njobs + SLOT_BLOCK - 1) / SLOT_BLOCK;
+    hipLaunchKernelGGL(k_slots_count, dim3(nb), dim3(256), 0, c->stream, c->njobs, c->job_b, c->job_t, c->slot_scratch);
+    hipLaunchKernelGGL(k_slots_scan, dim3(1), dim3(1024), 0, c->stream, nb, c->njobs, c->slot_scratch, c->nslots_dev, c->slot_start);
+    hipLaunchKernelGGL(k_slots_write, dim3(nb), dim3(256), 0, c->stream, c->njobs, c->job_b, c->job_t, c->slot_scratch, c->slot_start);
     return hipGetLastError();
 }
 
@@ -590,6 +694,41 @@ hipError_t launch_pack_linesearch(Ctx *c, double *dev8)
 {
     hipLaunchKernelGGL(k_pack_linesearch, dim3(1), dim3(256), 0, c->stream, c->d.batch, c->d.n_alpha, c->cost_pred, c->delta_J,
                        c->status, dev8);
+    return hipGetLastError();
+}
+
+// ---------------------------------------------------------------------------------------------
+// Device -> pinned host copy done by a KERNEL (pinned memory is mapped into the device's address space).  On this
+// platform SDMA copies in the two directions of the link do not overlap (56 GB/s aggregate, tools/pcie_probe.py), a
+// kernel storing to host memory while SDMA uploads does (85-100 GB/s aggregate, tools/pcie_duplex_probe.cpp): the chunk
+// pipeline of kpilqr_iterate_streamed downloads K, k this way.  32 workgroups saturate the link.
+__global__ void __launch_bounds__(256)
+k_copy_out(const double *__restrict__ src, double *__restrict__ dst, size_t count)
+{
+    const size_t tid = (size_t)blockIdx.x * blockDim.x + threadIdx.x, nth = (size_t)gridDim.x * blockDim.x;
+    if ((((size_t)src | (size_t)dst) & 15) == 0) {
+        const size_t n2 = count >> 1;
+        const double2 *s2 = (const double2 *)src; double2 *d2 = (double2 *)dst;
+        for (size_t i = tid; i < n2; i += nth) d2[i] = s2[i];
+        if (tid == 0 && (count & 1)) dst[count - 1] = src[count - 1];
+    } else {
+        for (size_t i = tid; i < count; i += nth) dst[i] = src[i];
+    }
+}
+
+hipError_t launch_copy_out(hipStream_t s, double *dst_host, const double *src_dev, size_t count)
+{
+    if (count == 0) return hipSuccess;
+    hipLaunchKernelGGL(k_copy_out, dim3(32), dim3(256), 0, s, src_dev, dst_host, count);
+    return hipGetLastError();
+}
+// the same kernel the other way round (loads from pinned host memory): an upload that is a kernel on the chunk's own
+// stream never sits in a shared SDMA queue behind another chunk's copy that is still waiting for its kernels
+hipError_t launch_copy_in(hipStream_t s, void *dst_dev, const void *src_host, size_t bytes)
+{
+    if (bytes == 0) return hipSuccess;
+    if ((bytes & 7) || (((size_t)dst_dev | (size_t)src_host) & 7)) return hipMemcpyAsync(dst_dev, src_host, bytes, hipMemcpyHostToDevice, s);
+    hipLaunchKernelGGL(k_copy_out, dim3(32), dim3(256), 0, s, (const double *)src_host, (double *)dst_dev, bytes >> 3);
     return hipGetLastError();
 }
 

@@ -22,6 +22,35 @@ static int set_err(kpilqr_ctx *c, int code, const std::string &msg)
     return code;
 }
 
+// memory the DMA engines can read in place: an async copy from it never has to be waited for before the call returns
+static bool is_pinned(const void *p)
+{
+    if (!p) return true;
+    hipPointerAttribute_t a;
+    if (hipPointerGetAttributes(&a, p) != hipSuccess) { (void)hipGetLastError(); return false; }
+    return a.type == hipMemoryTypeHost;
+}
+
+// chunk streams of kpilqr_iterate_streamed -> the context's stream: everything enqueued by a streamed iteration is
+// ordered before whatever the caller enqueues next
+static int join_pipeline(kpilqr_ctx *c)
+{
+    if (!c->pipe_dirty) return KPILQR_OK;
+    for (int i = 0; i < Ctx::kPipeStreams; i++) {
+        KP_HIP(c, hipEventRecord(c->pipe_done[i], c->pipe_stream[i]));
+        KP_HIP(c, hipStreamWaitEvent(c->stream, c->pipe_done[i], 0));
+    }
+    c->pipe_dirty = false;
+    return KPILQR_OK;
+}
+
+// every enqueueing entry point: select the context's device (several contexts per host thread), join the chunk streams
+#define KP_ENTER(c)                                                   \
+    do {                                                              \
+        KP_HIP(c, hipSetDevice((c)->d.device));                       \
+        if ((c)->pipe_dirty) { int rcj_ = join_pipeline(c); if (rcj_) return rcj_; } \
+    } while (0)
+
 template <class T>
 static hipError_t dalloc(T **p, size_t count)
 {
@@ -55,6 +84,7 @@ Ctx::Tuning read_tuning_from_env()
     t.tiled_nt_min = env_int("KPILQR_TILED_NT_MIN", 0);
     t.tiled_a6 = env_int("KPILQR_TILED_A6", -1);
     t.tiled_a4 = env_int("KPILQR_TILED_A4", -1);
+    t.pipe_copy = env_int("KPILQR_PIPE_COPY", -1);
     return t;
 }
 }  // namespace kpilqr
@@ -123,6 +153,9 @@ int kpilqr_create(const kpilqr_dims *dims, void *stream, kpilqr_ctx **out)
     TRY(dalloc(&c->status, B));
     TRY(dalloc(&c->segmap, B * dims->dof * T));
     TRY(dalloc(&c->kp_offsets, B * dims->dof + 1));
+    TRY(dalloc(&c->nslots_dev, 1));
+    TRY(dalloc(&c->err_flag, 1));
+    TRY(hipHostMalloc((void **)&c->err_flag_host, sizeof(int), hipHostMallocDefault));
 #undef TRY
     if (rc != hipSuccess) {
         std::string msg = std::string("hipMalloc failed: ") + hipGetErrorString(rc);
@@ -138,6 +171,10 @@ int kpilqr_create(const kpilqr_dims *dims, void *stream, kpilqr_ctx **out)
     (void)hipMemsetAsync(c->r_u, 0, B * (T + 1) * nr * m * sizeof(double), c->stream);
     (void)hipMemsetAsync(c->u_nom, 0, B * T * m * sizeof(double), c->stream);
     (void)hipMemsetAsync(c->status, 0, B * sizeof(int), c->stream);
+    (void)hipMemsetAsync(c->err_flag, 0, sizeof(int), c->stream);
+    (void)hipMemsetAsync(c->nslots_dev, 0, sizeof(int), c->stream);
+    c->rec_fd_base = c->rec;
+    c->fd_batch_total = dims->batch;
 
     const bool generic = (dims->flags & KPILQR_FLAG_GENERIC_KERNELS) != 0;
     const bool force_tiled = (dims->flags & KPILQR_FLAG_TILED_KERNELS) != 0;
@@ -177,12 +214,20 @@ void kpilqr_destroy(kpilqr_ctx *c)
     if (!c) return;
     (void)hipSetDevice(c->d.device);
     (void)hipStreamSynchronize(c->stream);
+    if (c->pipe_ready) {
+        for (int i = 0; i < Ctx::kPipeStreams; i++) {
+            if (c->pipe_stream[i]) { (void)hipStreamSynchronize(c->pipe_stream[i]); (void)hipStreamDestroy(c->pipe_stream[i]); }
+            if (c->pipe_done[i]) (void)hipEventDestroy(c->pipe_done[i]);
+        }
+        if (c->pipe_in) (void)hipEventDestroy(c->pipe_in);
+    }
     comm_destroy(c);
     void *ptrs[] = {c->rec, c->K, c->k, c->r, c->r_x, c->r_u, c->w_run, c->w_term, c->u_nom, c->ctrl_lim,
                     c->lambda, c->alphas, c->cost_pred, c->delta_J, c->traj_cost, c->status, c->segmap,
-                    c->kp_offsets, c->kp_times, c->X_states, c->kp_thr, c->kp_mask, c->kp_count, c->ls8, c->job_b, c->job_t, c->job_col, c->job_nom, c->job_mode,
-                    c->xplus, c->xminus, c->xnom, c->stage, c->slot_start};
+                    c->kp_offsets, c->kp_times, c->X_states, c->kp_thr, c->kp_mask, c->kp_count, c->ls8, c->fd_dev,
+                    c->stage, c->nslots_dev, c->slot_scratch, c->err_flag};
     for (void *p : ptrs) if (p) (void)hipFree(p);
+    if (c->err_flag_host) (void)hipHostFree(c->err_flag_host);
     if (c->own_stream) (void)hipStreamDestroy(c->stream);
     delete c;
 }
@@ -197,7 +242,7 @@ int kpilqr_get_dims(kpilqr_ctx *c, kpilqr_dims *out)
 int kpilqr_host_alloc(kpilqr_ctx *c, size_t bytes, void **pinned)
 {
     if (!c || !pinned) return KPILQR_ERR_ARG;
-    KP_HIP(c, hipSetDevice(c->d.device));          // one context = one device; the caller may drive several
+    KP_ENTER(c);
     KP_HIP(c, hipHostMalloc(pinned, bytes ? bytes : 1, hipHostMallocDefault));
     return KPILQR_OK;
 }
@@ -205,7 +250,7 @@ int kpilqr_host_alloc(kpilqr_ctx *c, size_t bytes, void **pinned)
 int kpilqr_host_free(kpilqr_ctx *c, void *pinned)
 {
     if (!c) return KPILQR_ERR_ARG;
-    KP_HIP(c, hipSetDevice(c->d.device));          // one context = one device; the caller may drive several
+    KP_ENTER(c);
     if (pinned) KP_HIP(c, hipHostFree(pinned));
     return KPILQR_OK;
 }
@@ -213,15 +258,22 @@ int kpilqr_host_free(kpilqr_ctx *c, void *pinned)
 int kpilqr_sync(kpilqr_ctx *c)
 {
     if (!c) return KPILQR_ERR_ARG;
-    KP_HIP(c, hipSetDevice(c->d.device));          // one context = one device; the caller may drive several
+    KP_ENTER(c);
+    KP_HIP(c, hipMemcpyAsync(c->err_flag_host, c->err_flag, sizeof(int), hipMemcpyDeviceToHost, c->stream));
     KP_HIP(c, hipStreamSynchronize(c->stream));
+    if (*c->err_flag_host) {                     // raised by a device-side argument check since the last sync
+        const int bits = *c->err_flag_host;
+        KP_HIP(c, hipMemsetAsync(c->err_flag, 0, sizeof(int), c->stream));
+        return set_err(c, KPILQR_ERR_ARG, (bits & 1) ? "FD job index out of range (trajectory, time, column, mode or nominal row): the job was skipped"
+                                                     : "device-side argument check failed");
+    }
     return KPILQR_OK;
 }
 
 int kpilqr_device_ptr(kpilqr_ctx *c, int which, void **dptr, size_t *bytes)
 {
     if (!c || !dptr) return KPILQR_ERR_ARG;
-    KP_HIP(c, hipSetDevice(c->d.device));          // one context = one device; the caller may drive several
+    KP_ENTER(c);
     const size_t B = c->d.batch, T = c->d.T, n = c->n, m = c->d.m, nr = c->d.nr;
     void *p = nullptr; size_t sz = 0;
     switch (which) {
@@ -248,7 +300,7 @@ int kpilqr_device_ptr(kpilqr_ctx *c, int which, void **dptr, size_t *bytes)
 int kpilqr_set_keypoints(kpilqr_ctx *c, const int *kp_offsets, const int *kp_times)
 {
     if (!c || !kp_offsets || !kp_times) return KPILQR_ERR_ARG;
-    KP_HIP(c, hipSetDevice(c->d.device));          // one context = one device; the caller may drive several
+    KP_ENTER(c);
     const size_t nlists = (size_t)c->d.batch * c->d.dof;
     const int total = kp_offsets[nlists];
     if (kp_offsets[0] != 0 || total < 0) return set_err(c, KPILQR_ERR_ARG, "kp_offsets must start at 0");
@@ -271,8 +323,8 @@ int kpilqr_set_keypoints(kpilqr_ctx *c, const int *kp_offsets, const int *kp_tim
     KP_HIP(c, hipMemcpyAsync(c->kp_offsets, kp_offsets, (nlists + 1) * sizeof(int), hipMemcpyHostToDevice, c->stream));
     KP_HIP(c, hipMemcpyAsync(c->kp_times, kp_times, (size_t)total * sizeof(int), hipMemcpyHostToDevice, c->stream));
     KP_HIP(c, launch_build_segmap(c));
-    // the host arrays may be pageable: make the copies complete before returning control
-    KP_HIP(c, hipStreamSynchronize(c->stream));
+    // pageable host arrays: make the copies complete before returning control (pinned ones are read in place)
+    if (!(is_pinned(kp_offsets) && is_pinned(kp_times))) KP_HIP(c, hipStreamSynchronize(c->stream));
     c->have_kp = true;
     return KPILQR_OK;
 }
@@ -283,7 +335,7 @@ static int ensure_stage(kpilqr_ctx *c, size_t bytes);
 int kpilqr_upload_states(kpilqr_ctx *c, const double *X)
 {
     if (!c || !X) return KPILQR_ERR_ARG;
-    KP_HIP(c, hipSetDevice(c->d.device));          // one context = one device; the caller may drive several
+    KP_ENTER(c);
     const size_t count = (size_t)c->d.batch * c->d.T * c->n;
     if (!c->X_states) KP_HIP(c, hipMalloc((void **)&c->X_states, count * sizeof(double)));
     KP_HIP(c, hipMemcpyAsync(c->X_states, X, count * sizeof(double), hipMemcpyHostToDevice, c->stream));
@@ -294,7 +346,7 @@ int kpilqr_upload_states(kpilqr_ctx *c, const double *X)
 int kpilqr_generate_keypoints(kpilqr_ctx *c, const char *method, int min_N, int max_N, const double *thresholds, double dt)
 {
     if (!c || !method) return KPILQR_ERR_ARG;
-    KP_HIP(c, hipSetDevice(c->d.device));          // one context = one device; the caller may drive several
+    KP_ENTER(c);
     int mth = -1;
     if (strcmp(method, "set_interval") == 0) mth = 0;
     else if (strcmp(method, "adaptive_jerk") == 0) mth = 1;
@@ -331,7 +383,7 @@ int kpilqr_generate_keypoints(kpilqr_ctx *c, const char *method, int min_N, int 
 int kpilqr_get_keypoints(kpilqr_ctx *c, int *kp_offsets, int *kp_times, int times_capacity)
 {
     if (!c || !kp_offsets) return KPILQR_ERR_ARG;
-    KP_HIP(c, hipSetDevice(c->d.device));          // one context = one device; the caller may drive several
+    KP_ENTER(c);
     if (!c->have_kp) return set_err(c, KPILQR_ERR_STATE, "no key-points set");
     const size_t nlists = (size_t)c->d.batch * c->d.dof;
     KP_HIP(c, hipMemcpyAsync(kp_offsets, c->kp_offsets, (nlists + 1) * sizeof(int), hipMemcpyDeviceToHost, c->stream));
@@ -345,64 +397,80 @@ int kpilqr_get_keypoints(kpilqr_ctx *c, int *kp_offsets, int *kp_times, int time
     return total;
 }
 
+static size_t al16(size_t x) { return (x + 15) & ~(size_t)15; }
+
+static void fd_layout(int n, int njobs, int nnom, int nslots, kpilqr_fd_layout *L)
+{
+    const size_t J = (size_t)njobs, N = (size_t)nnom, S = (size_t)(nslots > 0 ? nslots : njobs) + 1;
+    size_t o = 0;
+    L->xplus = o; o = al16(o + J * n * sizeof(double));
+    L->xminus = o; o = al16(o + J * n * sizeof(double));
+    L->xnom = o; o = al16(o + N * n * sizeof(double));
+    L->job_b = o; o = al16(o + J * sizeof(int));
+    L->job_t = o; o = al16(o + J * sizeof(int));
+    L->job_col = o; o = al16(o + J * sizeof(int));
+    L->job_nom = o; o = al16(o + J * sizeof(int));
+    L->slot_start = o; o = al16(o + S * sizeof(int));
+    L->job_mode = o; o = al16(o + J);
+    L->bytes = o;
+}
+
+int kpilqr_fd_slab_layout(kpilqr_ctx *c, int njobs, int nnom, int nslots, kpilqr_fd_layout *out)
+{
+    if (!c || !out || njobs < 0 || nnom < 0 || nslots < 0) return KPILQR_ERR_ARG;
+    fd_layout(c->n, njobs, nnom, nslots, out);
+    return KPILQR_OK;
+}
+
+// device slab with the layout of (njobs, nnom, nslots); grows (with a stream sync) only when it has to
+static int fd_bind(kpilqr_ctx *c, int njobs, int nnom, int nslots, kpilqr_fd_layout *L)
+{
+    fd_layout(c->n, njobs, nnom, nslots, L);
+    if (L->bytes > c->fd_dev_cap) {
+        KP_HIP(c, hipStreamSynchronize(c->stream));
+        if (c->fd_dev) KP_HIP(c, hipFree(c->fd_dev));
+        c->fd_dev = nullptr; c->fd_dev_cap = 0;
+        const size_t cap = L->bytes + L->bytes / 8 + 4096;
+        KP_HIP(c, hipMalloc((void **)&c->fd_dev, cap));
+        c->fd_dev_cap = cap;
+    }
+    char *base = c->fd_dev;
+    c->xplus = (double *)(base + L->xplus); c->xminus = (double *)(base + L->xminus); c->xnom = (double *)(base + L->xnom);
+    c->job_b = (int *)(base + L->job_b); c->job_t = (int *)(base + L->job_t); c->job_col = (int *)(base + L->job_col);
+    c->job_nom = (int *)(base + L->job_nom); c->slot_start = (int *)(base + L->slot_start);
+    c->job_mode = (unsigned char *)(base + L->job_mode);
+    const size_t nb = (size_t)njobs / 1024 + 2;
+    if (nslots <= 0 && nb > c->slot_scratch_cap) {
+        KP_HIP(c, hipStreamSynchronize(c->stream));
+        if (c->slot_scratch) KP_HIP(c, hipFree(c->slot_scratch));
+        c->slot_scratch = nullptr; c->slot_scratch_cap = 0;
+        KP_HIP(c, dalloc(&c->slot_scratch, nb + nb / 4));
+        c->slot_scratch_cap = nb + nb / 4;
+    }
+    return KPILQR_OK;
+}
+
 int kpilqr_upload_fd(kpilqr_ctx *c, int njobs, const int *job_b, const int *job_t, const int *job_col,
                      const unsigned char *job_mode, const int *job_nom, const double *xplus,
                      const double *xminus, int nnom, const double *xnom, double eps)
 {
     if (!c || njobs < 0 || nnom < 0) return KPILQR_ERR_ARG;
-    KP_HIP(c, hipSetDevice(c->d.device));          // one context = one device; the caller may drive several
+    KP_ENTER(c);
     if (njobs > 0 && (!job_b || !job_t || !job_col || !job_mode || !xplus || !xminus))
         return set_err(c, KPILQR_ERR_ARG, "null FD job array");
+    if (nnom > 0 && !xnom) return set_err(c, KPILQR_ERR_ARG, "nnom > 0 without xnom");
     if (!(eps > 0.0)) return set_err(c, KPILQR_ERR_ARG, "eps must be positive");
     const int n = c->n;
-    // validate indices on the host: a bad index would be an out-of-bounds device write
-    for (int j = 0; j < njobs; j++) {
-        if (job_b[j] < 0 || job_b[j] >= c->d.batch || job_t[j] < 0 || job_t[j] >= c->d.T ||
-            job_col[j] < 0 || job_col[j] >= n + c->d.m || job_mode[j] > 2)
-            return set_err(c, KPILQR_ERR_ARG, "FD job index out of range");
-        if (job_mode[j] != 0 && (!job_nom || !xnom || job_nom[j] < 0 || job_nom[j] >= nnom))
-            return set_err(c, KPILQR_ERR_ARG, "one-sided FD job without a valid nominal state");
-    }
-    if ((size_t)njobs > c->job_cap) {
-        KP_HIP(c, hipStreamSynchronize(c->stream));
-        const size_t cap = (size_t)njobs + (size_t)njobs / 8 + 64;
-        int rc;
-        if ((rc = regrow(c, &c->job_b, cap)) || (rc = regrow(c, &c->job_t, cap)) || (rc = regrow(c, &c->job_col, cap)) ||
-            (rc = regrow(c, &c->job_nom, cap)) || (rc = regrow(c, &c->job_mode, cap)) ||
-            (rc = regrow(c, &c->xplus, cap * n)) || (rc = regrow(c, &c->xminus, cap * n)))
-            return rc;
-        c->job_cap = cap;
-    }
-    if ((size_t)nnom > c->nom_cap || !c->xnom) {
-        KP_HIP(c, hipStreamSynchronize(c->stream));
-        const size_t cap = (size_t)nnom + (size_t)nnom / 8 + 64;
-        int rc;
-        if ((rc = regrow(c, &c->xnom, cap * n))) return rc;
-        c->nom_cap = cap;
-    }
-    // slot table: maximal runs of consecutive jobs with the same (trajectory, time)
-    std::vector<int> slots;
-    slots.reserve((size_t)njobs / 8 + 2);
-    for (int j = 0; j < njobs; j++)
-        if (j == 0 || job_b[j] != job_b[j - 1] || job_t[j] != job_t[j - 1]) slots.push_back(j);
-    const int nslots = (int)slots.size();
-    slots.push_back(njobs);
-    if ((size_t)nslots + 1 > c->slot_cap) {
-        KP_HIP(c, hipStreamSynchronize(c->stream));
-        const size_t cap = (size_t)nslots + (size_t)nslots / 8 + 64;
-        int rc = regrow(c, &c->slot_start, cap + 1);
-        if (rc) return rc;
-        c->slot_cap = cap + 1;
-    }
-    KP_HIP(c, hipMemcpyAsync(c->slot_start, slots.data(), ((size_t)nslots + 1) * sizeof(int), hipMemcpyHostToDevice, c->stream));
-    KP_HIP(c, hipStreamSynchronize(c->stream));      // `slots` is a local, pageable vector
-    c->nslots = nslots;
+    kpilqr_fd_layout L;
+    int rc = fd_bind(c, njobs, nnom, 0, &L);
+    if (rc) return rc;
     const size_t J = njobs;
     if (njobs) {
         KP_HIP(c, hipMemcpyAsync(c->job_b, job_b, J * sizeof(int), hipMemcpyHostToDevice, c->stream));
         KP_HIP(c, hipMemcpyAsync(c->job_t, job_t, J * sizeof(int), hipMemcpyHostToDevice, c->stream));
         KP_HIP(c, hipMemcpyAsync(c->job_col, job_col, J * sizeof(int), hipMemcpyHostToDevice, c->stream));
         KP_HIP(c, hipMemcpyAsync(c->job_mode, job_mode, J, hipMemcpyHostToDevice, c->stream));
+        // no nominal rows given: one-sided jobs then fail the device-side range check (nnom = 0) and are reported
         if (job_nom) KP_HIP(c, hipMemcpyAsync(c->job_nom, job_nom, J * sizeof(int), hipMemcpyHostToDevice, c->stream));
         else KP_HIP(c, hipMemsetAsync(c->job_nom, 0, J * sizeof(int), c->stream));
         KP_HIP(c, hipMemcpyAsync(c->xplus, xplus, J * n * sizeof(double), hipMemcpyHostToDevice, c->stream));
@@ -410,13 +478,36 @@ int kpilqr_upload_fd(kpilqr_ctx *c, int njobs, const int *job_b, const int *job_
     }
     if (nnom) KP_HIP(c, hipMemcpyAsync(c->xnom, xnom, (size_t)nnom * n * sizeof(double), hipMemcpyHostToDevice, c->stream));
     c->njobs = njobs; c->nnom = nnom; c->eps = eps;
+    c->nslots = njobs ? -1 : 0;                      // the table and its length are produced on the device
+    KP_HIP(c, launch_build_slots(c));
+    // pageable sources: the caller may free them on return, so wait for the copies; pinned ones are read in place
+    if (!(is_pinned(job_b) && is_pinned(job_t) && is_pinned(job_col) && is_pinned(job_mode) && is_pinned(job_nom) &&
+          is_pinned(xplus) && is_pinned(xminus) && is_pinned(xnom)))
+        KP_HIP(c, hipStreamSynchronize(c->stream));
+    return KPILQR_OK;
+}
+
+int kpilqr_upload_fd_slab(kpilqr_ctx *c, const void *slab, int njobs, int nnom, int nslots, double eps)
+{
+    if (!c || njobs < 0 || nnom < 0 || nslots < 0 || (njobs > 0 && !slab)) return KPILQR_ERR_ARG;
+    KP_ENTER(c);
+    if (!(eps > 0.0)) return set_err(c, KPILQR_ERR_ARG, "eps must be positive");
+    if (nslots > njobs) return set_err(c, KPILQR_ERR_ARG, "more slots than jobs");
+    kpilqr_fd_layout L;
+    int rc = fd_bind(c, njobs, nnom, nslots, &L);
+    if (rc) return rc;
+    if (njobs) KP_HIP(c, hipMemcpyAsync(c->fd_dev, slab, L.bytes, hipMemcpyHostToDevice, c->stream));   // the one DMA
+    c->njobs = njobs; c->nnom = nnom; c->eps = eps;
+    if (nslots > 0 || njobs == 0) c->nslots = nslots;
+    else { c->nslots = -1; KP_HIP(c, launch_build_slots(c)); }
+    if (!is_pinned(slab)) KP_HIP(c, hipStreamSynchronize(c->stream));
     return KPILQR_OK;
 }
 
 int kpilqr_fd_difference(kpilqr_ctx *c)
 {
     if (!c) return KPILQR_ERR_ARG;
-    KP_HIP(c, hipSetDevice(c->d.device));          // one context = one device; the caller may drive several
+    KP_ENTER(c);
     KP_HIP(c, launch_fd_difference(c));
     return KPILQR_OK;
 }
@@ -424,7 +515,7 @@ int kpilqr_fd_difference(kpilqr_ctx *c)
 int kpilqr_interpolate(kpilqr_ctx *c)
 {
     if (!c) return KPILQR_ERR_ARG;
-    KP_HIP(c, hipSetDevice(c->d.device));          // one context = one device; the caller may drive several
+    KP_ENTER(c);
     if (!c->have_kp) return set_err(c, KPILQR_ERR_STATE, "kpilqr_interpolate before kpilqr_set_keypoints");
     KP_HIP(c, launch_interpolate(c));
     return KPILQR_OK;
@@ -434,7 +525,7 @@ int kpilqr_interpolate(kpilqr_ctx *c)
 int kpilqr_filter_dynamics(kpilqr_ctx *c, const char *method, const double *coefs, int ncoef)
 {
     if (!c || !method || !coefs) return KPILQR_ERR_ARG;
-    KP_HIP(c, hipSetDevice(c->d.device));          // one context = one device; the caller may drive several
+    KP_ENTER(c);
     int mth = strcmp(method, "low_pass") == 0 ? 0 : strcmp(method, "FIR") == 0 ? 1 : -1;
     if (mth < 0) return set_err(c, KPILQR_ERR_ARG, "Filtering method not recognised (low_pass, FIR)");
     if (ncoef < 1 || ncoef > 16) return set_err(c, KPILQR_ERR_ARG, "1..16 filter coefficients");
@@ -453,7 +544,7 @@ int kpilqr_upload_residuals(kpilqr_ctx *c, const double *r, const double *r_x, c
                             const double *w_run, const double *w_term)
 {
     if (!c) return KPILQR_ERR_ARG;
-    KP_HIP(c, hipSetDevice(c->d.device));          // one context = one device; the caller may drive several
+    KP_ENTER(c);
     const size_t B = c->d.batch, T1 = c->d.T + 1, n = c->n, m = c->d.m, nr = c->d.nr;
     if (r) KP_HIP(c, hipMemcpyAsync(c->r, r, B * T1 * nr * 8, hipMemcpyHostToDevice, c->stream));
     if (r_x) KP_HIP(c, hipMemcpyAsync(c->r_x, r_x, B * T1 * nr * n * 8, hipMemcpyHostToDevice, c->stream));
@@ -466,7 +557,7 @@ int kpilqr_upload_residuals(kpilqr_ctx *c, const double *r, const double *r_x, c
 int kpilqr_cost_derivs(kpilqr_ctx *c)
 {
     if (!c) return KPILQR_ERR_ARG;
-    KP_HIP(c, hipSetDevice(c->d.device));          // one context = one device; the caller may drive several
+    KP_ENTER(c);
     KP_HIP(c, launch_cost_derivs(c));
     return KPILQR_OK;
 }
@@ -474,7 +565,7 @@ int kpilqr_cost_derivs(kpilqr_ctx *c)
 int kpilqr_trajectory_cost(kpilqr_ctx *c, double *cost)
 {
     if (!c) return KPILQR_ERR_ARG;
-    KP_HIP(c, hipSetDevice(c->d.device));          // one context = one device; the caller may drive several
+    KP_ENTER(c);
     KP_HIP(c, launch_trajectory_cost(c));
     if (cost) KP_HIP(c, hipMemcpyAsync(cost, c->traj_cost, (size_t)c->d.batch * 8, hipMemcpyDeviceToHost, c->stream));
     return KPILQR_OK;
@@ -506,7 +597,7 @@ static int run_backward(kpilqr_ctx *c, int pd_stride)
 int kpilqr_backward(kpilqr_ctx *c, const double *lambda, int pd_check_stride, int *status, double *delta_J)
 {
     if (!c) return KPILQR_ERR_ARG;
-    KP_HIP(c, hipSetDevice(c->d.device));          // one context = one device; the caller may drive several
+    KP_ENTER(c);
     if (pd_check_stride < 1) return set_err(c, KPILQR_ERR_ARG, "pd_check_stride must be >= 1");
     if (lambda) KP_HIP(c, hipMemcpyAsync(c->lambda, lambda, (size_t)c->d.batch * 8, hipMemcpyHostToDevice, c->stream));
     int rc = run_backward(c, pd_check_stride);
@@ -519,7 +610,7 @@ int kpilqr_backward(kpilqr_ctx *c, const double *lambda, int pd_check_stride, in
 int kpilqr_download_gains(kpilqr_ctx *c, double *K, double *k)
 {
     if (!c) return KPILQR_ERR_ARG;
-    KP_HIP(c, hipSetDevice(c->d.device));          // one context = one device; the caller may drive several
+    KP_ENTER(c);
     const size_t B = c->d.batch, T = c->d.T, n = c->n, m = c->d.m;
     if (K) KP_HIP(c, hipMemcpyAsync(K, c->K, B * T * n * m * 8, hipMemcpyDeviceToHost, c->stream));
     if (k) KP_HIP(c, hipMemcpyAsync(k, c->k, B * T * m * 8, hipMemcpyDeviceToHost, c->stream));
@@ -530,7 +621,7 @@ int kpilqr_download_gains(kpilqr_ctx *c, double *K, double *k)
 int kpilqr_dof_importance(kpilqr_ctx *c, int sampling_k_interval, double *sums)
 {
     if (!c || !sums) return KPILQR_ERR_ARG;
-    KP_HIP(c, hipSetDevice(c->d.device));          // one context = one device; the caller may drive several
+    KP_ENTER(c);
     if (sampling_k_interval < 1) return set_err(c, KPILQR_ERR_ARG, "sampling_k_interval must be >= 1");
     const size_t bytes = (size_t)c->d.batch * c->d.dof * sizeof(double);
     int rc = ensure_stage(c, bytes);
@@ -544,7 +635,7 @@ int kpilqr_dof_importance(kpilqr_ctx *c, int sampling_k_interval, double *sums)
 int kpilqr_upload_nominal(kpilqr_ctx *c, const double *u_nom, const double *ctrl_lim)
 {
     if (!c) return KPILQR_ERR_ARG;
-    KP_HIP(c, hipSetDevice(c->d.device));          // one context = one device; the caller may drive several
+    KP_ENTER(c);
     const size_t B = c->d.batch, T = c->d.T, m = c->d.m;
     if (u_nom) KP_HIP(c, hipMemcpyAsync(c->u_nom, u_nom, B * T * m * 8, hipMemcpyHostToDevice, c->stream));
     if (ctrl_lim) KP_HIP(c, hipMemcpyAsync(c->ctrl_lim, ctrl_lim, 2 * m * 8, hipMemcpyHostToDevice, c->stream));
@@ -579,7 +670,7 @@ static int run_forward(kpilqr_ctx *c, double *U_dev)
 int kpilqr_forward_linear(kpilqr_ctx *c, const double *alphas, double *cost_pred, double *U_alpha)
 {
     if (!c) return KPILQR_ERR_ARG;
-    KP_HIP(c, hipSetDevice(c->d.device));          // one context = one device; the caller may drive several
+    KP_ENTER(c);
     const size_t B = c->d.batch, T = c->d.T, m = c->d.m, na = c->d.n_alpha;
     if (alphas) KP_HIP(c, hipMemcpyAsync(c->alphas, alphas, na * 8, hipMemcpyHostToDevice, c->stream));
     double *U_dev = nullptr;
@@ -599,7 +690,7 @@ int kpilqr_forward_linear(kpilqr_ctx *c, const double *alphas, double *cost_pred
 int kpilqr_iterate(kpilqr_ctx *c, const double *lambda, int pd_check_stride, const double *alphas)
 {
     if (!c) return KPILQR_ERR_ARG;
-    KP_HIP(c, hipSetDevice(c->d.device));          // one context = one device; the caller may drive several
+    KP_ENTER(c);
     if (!c->have_kp) return set_err(c, KPILQR_ERR_STATE, "kpilqr_iterate before kpilqr_set_keypoints");
     if (pd_check_stride < 1) return set_err(c, KPILQR_ERR_ARG, "pd_check_stride must be >= 1");
     if (lambda) KP_HIP(c, hipMemcpyAsync(c->lambda, lambda, (size_t)c->d.batch * 8, hipMemcpyHostToDevice, c->stream));
@@ -612,6 +703,149 @@ int kpilqr_iterate(kpilqr_ctx *c, const double *lambda, int pd_check_stride, con
     int rc = run_backward(c, pd_check_stride);
     if (rc) return rc;
     return run_forward(c, nullptr);
+}
+
+// ---- whole iteration, pipelined over chunks of trajectories ------------------------------------------------------------
+static int pipe_setup(kpilqr_ctx *c)
+{
+    if (c->pipe_ready) return KPILQR_OK;
+    for (int i = 0; i < Ctx::kPipeStreams; i++) {
+        KP_HIP(c, hipStreamCreateWithFlags(&c->pipe_stream[i], hipStreamNonBlocking));
+        KP_HIP(c, hipEventCreateWithFlags(&c->pipe_done[i], hipEventDisableTiming));
+    }
+    KP_HIP(c, hipEventCreateWithFlags(&c->pipe_in, hipEventDisableTiming));
+    c->pipe_ready = true;
+    return KPILQR_OK;
+}
+
+// A view of trajectories [b0, b0+nb) of context c on stream s: every per-trajectory pointer shifted, so the ordinary
+// launchers run unchanged on the chunk.  n_simd is the chunk's SHARE of the chip: the launchers pick their wave
+// organisation (wave pairs / triples per trajectory) as if the whole batch were in flight, which it is.
+static void make_view(const kpilqr_ctx *c, int b0, int nb, hipStream_t s, kpilqr_ctx *v)
+{
+    *v = *c;
+    const size_t T = c->d.T, n = c->n, m = c->d.m, nr = c->d.nr, na = c->d.n_alpha, dof = c->d.dof, o = (size_t)b0;
+    v->d.batch = nb; v->stream = s; v->own_stream = false;
+    v->rec += o * T * c->L.stride; v->K += o * T * n * m; v->k += o * T * m;
+    v->r += o * (T + 1) * nr; v->r_x += o * (T + 1) * nr * n; v->r_u += o * (T + 1) * nr * m;
+    v->u_nom += o * T * m; v->lambda += o; v->cost_pred += o * na; v->delta_J += o; v->traj_cost += o; v->status += o;
+    v->segmap += o * dof * T; v->kp_offsets += o * dof;
+    long long share = (long long)c->n_simd * nb / c->d.batch;
+    v->n_simd = share < 4 ? 4 : (int)share;
+}
+
+int kpilqr_iterate_streamed(kpilqr_ctx *c, const kpilqr_stream_io *io, int pd_check_stride, int nchunks)
+{
+    if (!c || !io) return KPILQR_ERR_ARG;
+    KP_HIP(c, hipSetDevice(c->d.device));
+    if (!c->have_kp) return set_err(c, KPILQR_ERR_STATE, "kpilqr_iterate_streamed before kpilqr_set_keypoints");
+    if (pd_check_stride < 1) return set_err(c, KPILQR_ERR_ARG, "pd_check_stride must be >= 1");
+    const int B = c->d.batch;
+    if (nchunks < 1) nchunks = Ctx::kPipeStreams;          // 0: one chunk per pipeline stream
+    if (nchunks > B) nchunks = B;
+    if (io->fd_slab && (io->nslots < 1 || io->njobs < 1 || !io->traj_slot_first || (io->nnom > 0 && !io->traj_nom_first)))
+        return set_err(c, KPILQR_ERR_ARG, "streamed FD payload needs the slot table and the per-trajectory slot / nominal-row offsets");
+    const void *hostp[] = {io->fd_slab, io->r, io->r_x, io->r_u, io->u_nom, io->lambda, io->K, io->k, io->cost_pred, io->delta_J, io->status};
+    for (const void *p : hostp) if (!is_pinned(p)) return set_err(c, KPILQR_ERR_ARG, "kpilqr_iterate_streamed: host buffers must be pinned (kpilqr_host_alloc)");
+    if (c->fused) { int rc = check_fused(c); if (rc) return rc; }
+    int rc = pipe_setup(c);
+    if (rc) return rc;
+    // the chunk -> stream map must not change while earlier chunks are still in flight (same-stream order is what
+    // protects a chunk's device buffers from the next iteration's uploads)
+    if (c->pipe_dirty && c->pipe_chunks != nchunks) { rc = join_pipeline(c); if (rc) return rc; }
+    c->pipe_chunks = nchunks;
+
+    const int n = c->n, m = c->d.m, nr = c->d.nr, T = c->d.T, na = c->d.n_alpha;
+    // uploads by SDMA, downloads by a copy kernel: the only pairing whose two directions overlap inside this pipeline
+    // (KPILQR_PIPE_COPY: bit 0 uploads by kernel, bit 1 downloads by kernel; profiles/r02_pcie_inclusive.txt)
+    const int pipe_copy = c->tune.pipe_copy >= 0 ? c->tune.pipe_copy : 2;
+    const bool k_up = pipe_copy & 1, k_down = pipe_copy & 2;
+    auto h2d = [&](void *dst, const void *src, size_t bytes, hipStream_t st) -> hipError_t {
+        return k_up ? launch_copy_in(st, dst, src, bytes) : hipMemcpyAsync(dst, src, bytes, hipMemcpyHostToDevice, st);
+    };
+    kpilqr_fd_layout L{};
+    const char *slab = (const char *)io->fd_slab;
+    if (slab) {
+        // (re)bind the device slab; a growth synchronises every stream first
+        kpilqr_fd_layout probe;
+        fd_layout(n, io->njobs, io->nnom, io->nslots, &probe);
+        if (probe.bytes > c->fd_dev_cap) {
+            rc = join_pipeline(c); if (rc) return rc;
+            for (int i = 0; i < Ctx::kPipeStreams; i++) KP_HIP(c, hipStreamSynchronize(c->pipe_stream[i]));
+        }
+        rc = fd_bind(c, io->njobs, io->nnom, io->nslots, &L);
+        if (rc) return rc;
+        c->njobs = io->njobs; c->nnom = io->nnom; c->nslots = io->nslots; c->eps = io->eps;
+        if (io->traj_slot_first[0] != 0 || io->traj_slot_first[B] != io->nslots)
+            return set_err(c, KPILQR_ERR_ARG, "traj_slot_first must run from 0 to nslots");
+    }
+    // order the chunk streams behind whatever the caller enqueued on the context's stream so far (key-points, weights ...)
+    KP_HIP(c, hipEventRecord(c->pipe_in, c->stream));
+    const int *h_slot = slab ? (const int *)(slab + L.slot_start) : nullptr;
+
+    for (int ch = 0; ch < nchunks; ch++) {
+        const int b0 = (int)((long long)B * ch / nchunks), b1 = (int)((long long)B * (ch + 1) / nchunks), nb = b1 - b0;
+        if (nb <= 0) continue;
+        hipStream_t s = c->pipe_stream[ch % Ctx::kPipeStreams];
+        KP_HIP(c, hipStreamWaitEvent(s, c->pipe_in, 0));
+        kpilqr_ctx v;
+        make_view(c, b0, nb, s, &v);
+        const size_t o = b0, cnt = nb;
+        // ---- H2D of the chunk ------------------------------------------------------------------------------------
+        if (slab) {
+            const int s0 = io->traj_slot_first[b0], s1 = io->traj_slot_first[b1];
+            const int j0 = s0 < io->nslots ? h_slot[s0] : io->njobs, j1 = s1 < io->nslots ? h_slot[s1] : io->njobs;
+            if (s1 < s0 || j1 < j0 || j1 > io->njobs) return set_err(c, KPILQR_ERR_ARG, "slot table / traj_slot_first not monotone");
+            const size_t J = (size_t)(j1 - j0), jo = (size_t)j0;
+            if (J) {
+                KP_HIP(c, h2d(c->xplus + jo * n, slab + L.xplus + jo * n * 8, J * n * 8, s));
+                KP_HIP(c, h2d(c->xminus + jo * n, slab + L.xminus + jo * n * 8, J * n * 8, s));
+                KP_HIP(c, h2d(c->job_b + jo, slab + L.job_b + jo * 4, J * 4, s));
+                KP_HIP(c, h2d(c->job_t + jo, slab + L.job_t + jo * 4, J * 4, s));
+                KP_HIP(c, h2d(c->job_col + jo, slab + L.job_col + jo * 4, J * 4, s));
+                KP_HIP(c, h2d(c->job_nom + jo, slab + L.job_nom + jo * 4, J * 4, s));
+                KP_HIP(c, h2d(c->job_mode + jo, slab + L.job_mode + jo, J, s));
+                KP_HIP(c, h2d(c->slot_start + s0, slab + L.slot_start + (size_t)s0 * 4, (size_t)(s1 - s0 + 1) * 4, s));
+            }
+            if (io->nnom > 0) {
+                const int q0 = io->traj_nom_first[b0], q1 = io->traj_nom_first[b1];
+                if (q1 < q0 || q1 > io->nnom) return set_err(c, KPILQR_ERR_ARG, "traj_nom_first not monotone");
+                if (q1 > q0) KP_HIP(c, h2d(c->xnom + (size_t)q0 * n, slab + L.xnom + (size_t)q0 * n * 8, (size_t)(q1 - q0) * n * 8, s));
+            }
+            v.slot_start = c->slot_start + s0; v.nslots = s1 - s0; v.njobs = (int)J;
+        } else {
+            v.njobs = 0; v.nslots = 0;      // no new FD payload: the key-point columns already in the records are reused
+        }
+        if (io->r) KP_HIP(c, h2d(v.r, io->r + o * (T + 1) * nr, cnt * (T + 1) * nr * 8, s));
+        if (io->r_x) KP_HIP(c, h2d(v.r_x, io->r_x + o * (T + 1) * nr * n, cnt * (T + 1) * nr * n * 8, s));
+        if (io->r_u) KP_HIP(c, h2d(v.r_u, io->r_u + o * (T + 1) * nr * m, cnt * (T + 1) * nr * m * 8, s));
+        if (io->u_nom) KP_HIP(c, h2d(v.u_nom, io->u_nom + o * T * m, cnt * T * m * 8, s));
+        if (io->lambda) KP_HIP(c, h2d(v.lambda, io->lambda + o, cnt * 8, s));
+        // ---- kernels of the chunk --------------------------------------------------------------------------------
+        KP_HIP(c, launch_fd_difference(&v));
+        if (!c->fused) {
+            KP_HIP(c, launch_interpolate(&v));
+            if (!c->tiled_a6) KP_HIP(c, launch_cost_derivs(&v));
+        }
+        rc = run_backward(&v, pd_check_stride);
+        if (rc) { c->err = v.err; return rc; }
+        rc = run_forward(&v, nullptr);
+        if (rc) { c->err = v.err; return rc; }
+        // ---- D2H of the chunk ------------------------------------------------------------------------------------
+        // K, k by a copy kernel: it overlaps with the SDMA uploads of the next chunks (two SDMA directions do not)
+        if (k_down) {
+            if (io->K) KP_HIP(c, launch_copy_out(s, io->K + o * T * n * m, v.K, cnt * T * n * m));
+            if (io->k) KP_HIP(c, launch_copy_out(s, io->k + o * T * m, v.k, cnt * T * m));
+        } else {
+            if (io->K) KP_HIP(c, hipMemcpyAsync(io->K + o * T * n * m, v.K, cnt * T * n * m * 8, hipMemcpyDeviceToHost, s));
+            if (io->k) KP_HIP(c, hipMemcpyAsync(io->k + o * T * m, v.k, cnt * T * m * 8, hipMemcpyDeviceToHost, s));
+        }
+        if (io->cost_pred) KP_HIP(c, hipMemcpyAsync(io->cost_pred + o * na, v.cost_pred, cnt * na * 8, hipMemcpyDeviceToHost, s));
+        if (io->delta_J) KP_HIP(c, hipMemcpyAsync(io->delta_J + o, v.delta_J, cnt * 8, hipMemcpyDeviceToHost, s));
+        if (io->status) KP_HIP(c, hipMemcpyAsync(io->status + o, v.status, cnt * 4, hipMemcpyDeviceToHost, s));
+    }
+    c->pipe_dirty = true;
+    return KPILQR_OK;
 }
 
 // ---- multi-GPU: the line-search cost reduction -----------------------------------------------------------
@@ -634,7 +868,7 @@ int kpilqr_comm_init(kpilqr_ctx *c, int nranks, int rank, const char id[128])
 int kpilqr_allreduce_linesearch(kpilqr_ctx *c, double vec8[8])
 {
     if (!c) return KPILQR_ERR_ARG;
-    KP_HIP(c, hipSetDevice(c->d.device));          // one context = one device; the caller may drive several
+    KP_ENTER(c);
     if (!c->ls8) KP_HIP(c, hipMalloc((void **)&c->ls8, 8 * sizeof(double)));
     KP_HIP(c, launch_pack_linesearch(c, c->ls8));
     if (const char *e = comm_allreduce8(c, c->ls8)) return set_err(c, KPILQR_ERR_HIP, std::string("RCCL: ") + e);
@@ -646,7 +880,7 @@ int kpilqr_allreduce_linesearch(kpilqr_ctx *c, double vec8[8])
 int kpilqr_set_AB(kpilqr_ctx *c, const double *A, const double *B)
 {
     if (!c) return KPILQR_ERR_ARG;
-    KP_HIP(c, hipSetDevice(c->d.device));          // one context = one device; the caller may drive several
+    KP_ENTER(c);
     const size_t BT = (size_t)c->d.batch * c->d.T, n = c->n, m = c->d.m;
     const size_t szA = BT * n * n * 8, szB = BT * n * m * 8;
     int rc = ensure_stage(c, szA + szB);
@@ -662,7 +896,7 @@ int kpilqr_set_AB(kpilqr_ctx *c, const double *A, const double *B)
 int kpilqr_get_AB(kpilqr_ctx *c, double *A, double *B)
 {
     if (!c) return KPILQR_ERR_ARG;
-    KP_HIP(c, hipSetDevice(c->d.device));          // one context = one device; the caller may drive several
+    KP_ENTER(c);
     const size_t BT = (size_t)c->d.batch * c->d.T, n = c->n, m = c->d.m;
     const size_t szA = BT * n * n * 8, szB = BT * n * m * 8;
     int rc = ensure_stage(c, szA + szB);
@@ -678,7 +912,7 @@ int kpilqr_get_AB(kpilqr_ctx *c, double *A, double *B)
 int kpilqr_set_cost_derivs(kpilqr_ctx *c, const double *l_x, const double *l_xx, const double *l_u, const double *l_uu)
 {
     if (!c) return KPILQR_ERR_ARG;
-    KP_HIP(c, hipSetDevice(c->d.device));          // one context = one device; the caller may drive several
+    KP_ENTER(c);
     const size_t BT = (size_t)c->d.batch * c->d.T, n = c->n, m = c->d.m;
     const size_t s1 = BT * n * 8, s2 = BT * n * n * 8, s3 = BT * m * 8, s4 = BT * m * m * 8;
     int rc = ensure_stage(c, s1 + s2 + s3 + s4);
@@ -697,7 +931,7 @@ int kpilqr_set_cost_derivs(kpilqr_ctx *c, const double *l_x, const double *l_xx,
 int kpilqr_get_cost_derivs(kpilqr_ctx *c, double *l_x, double *l_xx, double *l_u, double *l_uu)
 {
     if (!c) return KPILQR_ERR_ARG;
-    KP_HIP(c, hipSetDevice(c->d.device));          // one context = one device; the caller may drive several
+    KP_ENTER(c);
     const size_t BT = (size_t)c->d.batch * c->d.T, n = c->n, m = c->d.m;
     const size_t s1 = BT * n * 8, s2 = BT * n * n * 8, s3 = BT * m * 8, s4 = BT * m * m * 8;
     int rc = ensure_stage(c, s1 + s2 + s3 + s4);

@@ -51,6 +51,7 @@ class Engine:
             raise KpilqrError(rc, (self._L.kpilqr_strerror(None) or b"").decode())
         self._h = h
         self._keep = []
+        self._pinned = []
 
     # -- plumbing -------------------------------------------------------------------------------
     def _ck(self, rc):
@@ -60,6 +61,10 @@ class Engine:
 
     def close(self):
         if getattr(self, "_h", None):
+            self._L.kpilqr_sync(self._h)
+            for p in self._pinned:
+                self._L.kpilqr_host_free(self._h, C.c_void_p(p))
+            self._pinned = []
             self._L.kpilqr_destroy(self._h)
             self._h = None
 
@@ -140,6 +145,75 @@ class Engine:
         self._keep += [jb, jt, jc, jm, xp, xm, jn, xn]
         self._ck(self._L.kpilqr_upload_fd(self._h, nj, _ptr(jb), _ptr(jt), _ptr(jc), _ptr(jm), _ptr(jn),
                                           _ptr(xp), _ptr(xm), nnom, _ptr(xn), float(eps)))
+
+    # -- asynchronous boundary: pinned memory, one slab, chunk pipeline -------------------------------
+    def pinned(self, shape, dtype=np.float64):
+        """numpy array in pinned host memory owned by the context (kpilqr_host_alloc); freed with the engine."""
+        shape = (shape,) if np.isscalar(shape) else tuple(shape)
+        nbytes = max(int(np.prod(shape)) * np.dtype(dtype).itemsize, 1)
+        p = C.c_void_p()
+        self._ck(self._L.kpilqr_host_alloc(self._h, nbytes, C.byref(p)))
+        self._pinned.append(p.value)
+        buf = (C.c_char * nbytes).from_address(p.value)
+        return np.frombuffer(buf, dtype=dtype, count=int(np.prod(shape))).reshape(shape)
+
+    def fd_slab(self, job_b, job_t, job_col, job_mode, xplus, xminus, job_nom=None, xnom=None, with_slots=True):
+        """Packs FD jobs (grouped by key-point, sorted by trajectory) into ONE pinned slab in the layout of
+        kpilqr_fd_slab_layout.  Returns a dict for upload_fd_slab / iterate_streamed."""
+        jb = np.asarray(job_b, np.int32); jt = np.asarray(job_t, np.int32)
+        nj = len(jt)
+        nnom = 0 if xnom is None else len(xnom)
+        head = np.ones(nj, bool)
+        head[1:] = (jb[1:] != jb[:-1]) | (jt[1:] != jt[:-1])
+        slot_start = np.concatenate([np.nonzero(head)[0], [nj]]).astype(np.int32)
+        nslots = len(slot_start) - 1 if with_slots else 0
+        lay = _lib.FdLayout()
+        self._ck(self._L.kpilqr_fd_slab_layout(self._h, nj, nnom, nslots, C.byref(lay)))
+        slab = self.pinned(lay.bytes, np.uint8)
+
+        def put(off, a, dt):
+            a = np.ascontiguousarray(a, dt)
+            slab[off:off + a.nbytes] = a.view(np.uint8).reshape(-1)
+        put(lay.xplus, xplus, np.float64); put(lay.xminus, xminus, np.float64)
+        if nnom:
+            put(lay.xnom, xnom, np.float64)
+        put(lay.job_b, jb, np.int32); put(lay.job_t, jt, np.int32); put(lay.job_col, job_col, np.int32)
+        put(lay.job_nom, np.zeros(nj, np.int32) if job_nom is None else job_nom, np.int32)
+        if with_slots:
+            put(lay.slot_start, slot_start, np.int32)
+        put(lay.job_mode, job_mode, np.uint8)
+        # per-trajectory offsets for the chunk pipeline
+        slot_b = jb[slot_start[:-1]]
+        tsf = self.pinned(self.batch + 1, np.int32); tsf[:] = np.searchsorted(slot_b, np.arange(self.batch + 1))
+        tnf = self.pinned(self.batch + 1, np.int32)
+        if nnom and job_nom is not None:
+            jn = np.asarray(job_nom, np.int64)
+            lo = np.full(self.batch + 1, nnom, np.int64)
+            np.minimum.at(lo, jb, jn)
+            for b in range(self.batch - 1, -1, -1):
+                lo[b] = min(lo[b], lo[b + 1])
+            lo[0] = 0
+            tnf[:] = lo
+        else:
+            tnf[:] = 0
+        return dict(slab=slab, njobs=nj, nnom=nnom, nslots=nslots, traj_slot_first=tsf, traj_nom_first=tnf, layout=lay)
+
+    def upload_fd_slab(self, s, eps=1e-6):
+        self._ck(self._L.kpilqr_upload_fd_slab(self._h, _ptr(s["slab"]), s["njobs"], s["nnom"], s["nslots"], float(eps)))
+
+    def iterate_streamed(self, fd=None, eps=1e-6, r=None, r_x=None, r_u=None, u_nom=None, lam=None, K=None, k=None,
+                         cost_pred=None, delta_J=None, status=None, pd_stride=100, nchunks=0):
+        """kpilqr_iterate_streamed: every array must come from self.pinned(); asynchronous (sync() to wait)."""
+        io = _lib.StreamIO()
+        if fd is not None:
+            io.fd_slab = fd["slab"].ctypes.data; io.njobs = fd["njobs"]; io.nnom = fd["nnom"]; io.nslots = fd["nslots"]
+            io.traj_slot_first = fd["traj_slot_first"].ctypes.data; io.traj_nom_first = fd["traj_nom_first"].ctypes.data
+        io.eps = float(eps)
+        for name, a in (("r", r), ("r_x", r_x), ("r_u", r_u), ("u_nom", u_nom), ("lam", lam), ("K", K), ("k", k),
+                        ("cost_pred", cost_pred), ("delta_J", delta_J), ("status", status)):
+            if a is not None:
+                setattr(io, name, a.ctypes.data)
+        self._ck(self._L.kpilqr_iterate_streamed(self._h, C.byref(io), int(pd_stride), int(nchunks)))
 
     def fd_difference(self):
         self._ck(self._L.kpilqr_fd_difference(self._h))
