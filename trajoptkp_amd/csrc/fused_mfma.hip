@@ -366,9 +366,11 @@ __device__ __forceinline__ void backward_fused_body(double *sh, const double *pc
             if (NCU > 2) dJ -= lam * (Xp.z * Xp.z);
             if (NCU > 3) dJ -= lam * (Xp.w * Xp.w);
         }
-        d4 Quu2 = Quu;
-        Quu2.x += lam2d[0]; Quu2.y += lam2d[1]; Quu2.z += lam2d[2]; Quu2.w += lam2d[3];
-        d4 G = PS<NCU>(Quu2, Kp, zero);
+        // V' = Qzz + K'Quu K + K'Quz + Quz'K (:606-607) with K = -X, (Quu + lambda I) X = Quz:
+        //    = Qzz - X'(Quz + lambda X)     -- one product; G = (Quu + 2 lambda I)K' is never formed
+        d4 G;
+        G.x = -__builtin_fma(lam, Xp.x, Quz.x); G.y = -__builtin_fma(lam, Xp.y, Quz.y);
+        G.z = -__builtin_fma(lam, Xp.z, Quz.z); G.w = -__builtin_fma(lam, Xp.w, Quz.w);
         d4 acc = PS<NCU>(Xp, G, Qzz);
         sh[FLDS_V + (q) * FVS + c] = acc.x;
         sh[FLDS_V + (4 + q) * FVS + c] = acc.y;

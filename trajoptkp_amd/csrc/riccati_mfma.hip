@@ -288,9 +288,10 @@ __device__ __forceinline__ void backward_body(RecLayout L, int T, const double *
         }
         // ---- V' = Qzz + K''Quu K' + K''Quz + Quz'K'   (:606-607).  Substituting Quz = -(Quu + lambda I) K'
         //      gives V' = Qzz - K''(Quu + 2 lambda I) K' = Qzz + X'[(Quu + 2 lambda I) K']: two products.
-        d4 Quu2 = Quu;
-        Quu2.x += lam2d[0]; Quu2.y += lam2d[1]; Quu2.z += lam2d[2]; Quu2.w += lam2d[3];
-        d4 G = P<NCU>(Quu2, Kp, zero);             // (Quu + 2 lambda I) K'  (Quu symmetric up to rounding)
+        //      and since (Quu + lambda I) X = Quz that bracket is -(Quz + lambda X): ONE product.
+        d4 G;
+        G.x = -__builtin_fma(lam, Xp.x, Quz.x); G.y = -__builtin_fma(lam, Xp.y, Quz.y);
+        G.z = -__builtin_fma(lam, Xp.z, Quz.z); G.w = -__builtin_fma(lam, Xp.w, Quz.w);
         d4 acc = P<NCU>(Xp, G, Qzz);
 
         // ---- V' = (V' + V'')/2 through an LDS transpose   (:610) -----------------------------------

@@ -444,9 +444,9 @@ k_backward_tiled_col(RecLayout L, CostSrc CS, int T, const double *__restrict__ 
 #pragma unroll
                 for (int r = 0; r < NCU; r++) dJ -= lam * (xv[r] * xv[r]);
             }
-            d4 Quu2 = Quu;
-            Quu2.x += lam2d[0]; Quu2.y += lam2d[1]; Quu2.z += lam2d[2]; Quu2.w += lam2d[3];
-            Gw = Pn(Quu2, -X, zero, NCU);              // G = (Quu + 2 lambda I) K'
+            // G = (Quu + 2 lambda I) K' = -(Quz + lambda X) because (Quu + lambda I) X = Quz: no product needed
+            Gw.x = -__builtin_fma(lam, X.x, Quzw.x); Gw.y = -__builtin_fma(lam, X.y, Quzw.y);
+            Gw.z = -__builtin_fma(lam, X.z, Quzw.z); Gw.w = -__builtin_fma(lam, X.w, Quzw.w);
         }
         __syncthreads();
         // ---- E: acc(i,w) = Qzz(i,w) + X_i' G_w -> bufT -------------------------------------------------------

@@ -4,9 +4,10 @@
 
 AcrobotSimulator::AcrobotSimulator(double timestep, int fd_threads) : dt(timestep)
 {
-    main_data = new SimData();
-    master_reset_data = new SimData();
-    for (int i = 0; i < fd_threads; i++) fd_data.push_back(new SimData());
+    auto fresh = [] { SimData *d = new SimData(); d->nq = 2; d->nv = 2; d->nu = 1; return d; };
+    main_data = fresh();
+    master_reset_data = fresh();
+    for (int i = 0; i < fd_threads; i++) fd_data.push_back(fresh());
 }
 
 AcrobotSimulator::~AcrobotSimulator()
@@ -27,7 +28,7 @@ bool AcrobotSimulator::AppendSystemStateToEnd(SimData *d)
 bool AcrobotSimulator::ForwardSimulator(SimData *d) const
 {
     const double m1 = 1.0, m2 = 1.0, l1 = 1.0, lc1 = 0.5, lc2 = 0.5, I1 = 1.0 / 12.0, I2 = 1.0 / 12.0, g = 9.81, damp = 0.05;
-    const double q1 = d->q[0], q2 = d->q[1], v1 = d->v[0], v2 = d->v[1];
+    const double q1 = d->qpos[0], q2 = d->qpos[1], v1 = d->qvel[0], v2 = d->qvel[1];
     const double c2 = std::cos(q2), s2 = std::sin(q2);
     const double M11 = I1 + I2 + m1 * lc1 * lc1 + m2 * (l1 * l1 + lc2 * lc2 + 2 * l1 * lc2 * c2);
     const double M12 = I2 + m2 * (lc2 * lc2 + l1 * lc2 * c2);
@@ -36,11 +37,11 @@ bool AcrobotSimulator::ForwardSimulator(SimData *d) const
     const double C1 = -h * v2 * (2 * v1 + v2), C2 = h * v1 * v1;
     const double G1 = -(m1 * lc1 + m2 * l1) * g * std::sin(q1) - m2 * lc2 * g * std::sin(q1 + q2);
     const double G2 = -m2 * lc2 * g * std::sin(q1 + q2);
-    const double f1 = d->u[0] - C1 - G1 - damp * v1, f2 = -C2 - G2 - damp * v2;
+    const double f1 = d->ctrl[0] - C1 - G1 - damp * v1, f2 = -C2 - G2 - damp * v2;
     const double det = M11 * M22 - M12 * M12;
     const double a1 = (M22 * f1 - M12 * f2) / det, a2 = (M11 * f2 - M12 * f1) / det;
-    d->v[0] = v1 + dt * a1; d->v[1] = v2 + dt * a2;
-    d->q[0] = q1 + dt * d->v[0]; d->q[1] = q2 + dt * d->v[1];
+    d->qvel[0] = v1 + dt * a1; d->qvel[1] = v2 + dt * a2;
+    d->qpos[0] = q1 + dt * d->qvel[0]; d->qpos[1] = q2 + dt * d->qvel[1];
     d->time += dt;
     return true;
 }
@@ -60,7 +61,7 @@ AcrobotTranslator::AcrobotTranslator(std::shared_ptr<PhysicsSimulator> sim)
 
 void AcrobotTranslator::Residuals(SimData *d, MatrixXd &r)     // Acrobot.cpp:26-55 (targets are zero)
 {
-    r(0) = d->q[0]; r(1) = d->q[1]; r(2) = d->v[0]; r(3) = d->v[1]; r(4) = d->u[0];
+    r(0) = d->qpos[0]; r(1) = d->qpos[1]; r(2) = d->qvel[0]; r(3) = d->qvel[1]; r(4) = d->ctrl[0];
 }
 
 bool AcrobotTranslator::ResidualJacobians(SimData *, double *r_x, double *r_u)
@@ -76,23 +77,23 @@ bool AcrobotTranslator::ResidualJacobians(SimData *, double *r_x, double *r_u)
 MatrixXd AcrobotTranslator::ReturnStateVector(SimData *d, const stateVectorList &)
 {
     MatrixXd x(4, 1);
-    x(0) = d->q[0]; x(1) = d->q[1]; x(2) = d->v[0]; x(3) = d->v[1];
+    x(0) = d->qpos[0]; x(1) = d->qpos[1]; x(2) = d->qvel[0]; x(3) = d->qvel[1];
     return x;
 }
 
 bool AcrobotTranslator::SetStateVector(const MatrixXd &x, SimData *d, const stateVectorList &)
 {
     if (x.rows() != 4) return false;                               // size mismatch -> false, as ModelTranslator.cpp:989-994
-    d->q[0] = x(0); d->q[1] = x(1); d->v[0] = x(2); d->v[1] = x(3);
+    d->qpos[0] = x(0); d->qpos[1] = x(1); d->qvel[0] = x(2); d->qvel[1] = x(3);
     return true;
 }
 
-MatrixXd AcrobotTranslator::ReturnControlVector(SimData *d, const stateVectorList &) { MatrixXd u(1, 1); u(0) = d->u[0]; return u; }
+MatrixXd AcrobotTranslator::ReturnControlVector(SimData *d, const stateVectorList &) { MatrixXd u(1, 1); u(0) = d->ctrl[0]; return u; }
 
 bool AcrobotTranslator::SetControlVector(const MatrixXd &u, SimData *d, const stateVectorList &)
 {
     if (u.rows() != 1) return false;
-    d->u[0] = u(0);
+    d->ctrl[0] = u(0);
     return true;
 }
 

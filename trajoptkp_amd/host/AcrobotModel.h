@@ -5,11 +5,7 @@
 // It stands in for MuJoCo, which is not available in this image; it is NOT a MuJoCo re-implementation.
 #pragma once
 #include "ModelTranslator.h"
-
-struct SimData {
-    double time = 0.0;
-    double q[2] = {0, 0}, v[2] = {0, 0}, u[1] = {0};
-};
+#include "SimData.h"
 
 class AcrobotSimulator : public PhysicsSimulator {
 public:
@@ -20,6 +16,7 @@ public:
     bool AppendSystemStateToEnd(SimData *d) override;
     bool CopySystemState(SimData *dst, const SimData *src) const override { *dst = *src; return true; }
     double ReturnModelTimeStep() const override { return dt; }
+    int nv() const override { return 2; }
 private:
     double dt;
 };

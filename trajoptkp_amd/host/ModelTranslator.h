@@ -27,6 +27,9 @@ public:
     // reference does (src/Differentiator/Differentiator.cpp:464-663).  Tasks like reaching
     // (src/ModelTranslator/Reaching.cpp:43-54: r = [q - q*, qdot]) have constant selector Jacobians.
     virtual bool ResidualJacobians(SimData *d, double *r_x, double *r_u) { (void)d; (void)r_x; (void)r_u; return false; }
+    // index of state-vector position entry `state_index` in the simulator's velocity (tangent) vector -- what the
+    // reference indexes vel_diff / dpos with (src/ModelTranslator/ModelTranslator.cpp:1707-1709)
+    virtual int StateIndexToQposIndex(int state_index, const stateVectorList &sv) { (void)sv; return state_index; }
     virtual MatrixXd ReturnStateVector(SimData *d, const stateVectorList &sv) = 0;       // [q; qdot], 2*dof x 1
     virtual bool SetStateVector(const MatrixXd &x, SimData *d, const stateVectorList &sv) = 0;
     virtual MatrixXd ReturnControlVector(SimData *d, const stateVectorList &sv) = 0;

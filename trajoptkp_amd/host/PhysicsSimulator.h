@@ -5,7 +5,7 @@
 #pragma once
 #include <vector>
 
-struct SimData;   // opaque simulator state (mjData in the reference)
+struct SimData;   // simulator state (mjData in the reference; SimData.h for the stand-in models of this tree)
 
 class PhysicsSimulator {
 public:
@@ -22,6 +22,17 @@ public:
     virtual void InitModelForFiniteDifferencing() {}
     virtual void ResetModelAfterFiniteDifferencing() const {}
     virtual double ReturnModelTimeStep() const = 0;
+
+    // ---- tangent-space position arithmetic (models with free / ball joints: nq != nv) --------------------------------
+    // mjModel::nv: the size of the velocity (tangent) vector
+    virtual int nv() const = 0;
+    // mj_differentiatePos(m, qvel, dt, qpos1, qpos2): qvel [nv] = (qpos(d2) (-) qpos(d1)) / dt, quaternion differences as
+    // rotation vectors (src/Optimiser/iLQR.cpp:857-861, src/Differentiator/Differentiator.cpp:170-174,288-292,388-393).
+    // Default: plain coordinate difference (hinge / slide joints only, nq == nv).
+    virtual void DifferentiatePos(double *qvel, double dt, const SimData *d1, const SimData *d2) const;
+    // mj_integratePos(m, qpos, dpos, eps) with dpos = e_{vel_index} (Differentiator.cpp:349-357):
+    // qpos(d) <- qpos(d) (+) eps * e_{vel_index}.  Default: qpos[vel_index] += eps.
+    virtual void IntegratePos(SimData *d, int vel_index, double eps) const;
 
     std::vector<SimData *> saved_systems_state_list;
     SimData *main_data = nullptr;

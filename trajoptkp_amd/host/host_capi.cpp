@@ -61,11 +61,11 @@ int kpilqr_host_run_acrobot(int T, int min_N, int max_iter, int min_iter, const 
     mt->min_N = min_N;
     if (torque_weight >= 0) { mt->residual_list[4].weight = torque_weight; mt->residual_list[4].weight_terminal = torque_weight; }
     if (keypoint_method_name) mt->keypoint_method = keypoint_method_name;
-    sim->main_data->q[0] = 3.1415; sim->main_data->q[1] = 0.3;
+    sim->main_data->qpos[0] = 3.1415; sim->main_data->qpos[1] = 0.3;
     {   // "+q0=a,b": another start
         std::string full = keypoint_method_full;
         const size_t at = full.find("+q0=");
-        if (at != std::string::npos) std::sscanf(full.c_str() + at + 4, "%lf,%lf", &sim->main_data->q[0], &sim->main_data->q[1]);
+        if (at != std::string::npos) std::sscanf(full.c_str() + at + 4, "%lf,%lf", &sim->main_data->qpos[0], &sim->main_data->qpos[1]);
     }
     *sim->master_reset_data = *sim->main_data;
     auto diff = std::make_shared<Differentiator>(mt, sim);
@@ -96,7 +96,7 @@ int kpilqr_host_run_acrobot_batch(int B, int T, int min_N, int max_iter, int min
         auto mt = std::make_shared<AcrobotTranslator>(sim);
         mt->min_N = min_N;
         if (torque_weight >= 0) { mt->residual_list[4].weight = torque_weight; mt->residual_list[4].weight_terminal = torque_weight; }
-        sim->main_data->q[0] = q0s[2 * b]; sim->main_data->q[1] = q0s[2 * b + 1];
+        sim->main_data->qpos[0] = q0s[2 * b]; sim->main_data->qpos[1] = q0s[2 * b + 1];
         *sim->master_reset_data = *sim->main_data;
         probs.push_back({mt, sim, std::make_shared<Differentiator>(mt, sim)});
     }
@@ -123,9 +123,9 @@ int kpilqr_host_fd_bench(int T, int reps, int mode, int fd_threads, double *seco
 {
     auto sim = std::make_shared<AcrobotSimulator>(0.01, fd_threads);
     auto mt = std::make_shared<AcrobotTranslator>(sim);
-    sim->main_data->q[0] = 3.1415; sim->main_data->q[1] = 0.3;
+    sim->main_data->qpos[0] = 3.1415; sim->main_data->qpos[1] = 0.3;
     for (int t = 0; t < T; t++) {
-        sim->main_data->u[0] = 0.5 * ((t % 7) - 3);
+        sim->main_data->ctrl[0] = 0.5 * ((t % 7) - 3);
         sim->AppendSystemStateToEnd(sim->main_data);
         sim->ForwardSimulator(sim->main_data);
     }
