@@ -293,10 +293,18 @@ def test_bad_arguments_fail_loudly():
     with Engine(7, 7, 20, 14) as e:
         with pytest.raises(KpilqrError):
             e.interpolate()                                      # before set_keypoints
+        # FD job indices are checked on the device: the bad job is skipped and the next sync reports it
+        e.set_keypoints_rows([synth.keypoint_rows_set_interval(7, 20, 5)])
+        e.upload_fd([0], [25], [0], [0], np.zeros((1, 14)), np.zeros((1, 14)))   # t out of range
+        e.fd_difference()
         with pytest.raises(KpilqrError):
-            e.upload_fd([0], [25], [0], [0], np.zeros((1, 14)), np.zeros((1, 14)))   # t out of range
+            e.sync()
+        e.upload_fd([0], [5], [0], [1], np.zeros((1, 14)), np.zeros((1, 14)))    # one-sided, no nominal
+        e.fd_difference()
         with pytest.raises(KpilqrError):
-            e.upload_fd([0], [5], [0], [1], np.zeros((1, 14)), np.zeros((1, 14)))    # one-sided, no nominal
+            e.sync()
+        with pytest.raises(KpilqrError):
+            e.upload_fd([0], [5], [0], [0], np.zeros((1, 14)), np.zeros((1, 14)), eps=0.0)
 
 
 @pytest.mark.parametrize("T", [2, 3, 7])

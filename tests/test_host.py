@@ -177,3 +177,153 @@ def test_batched_optimiser_matches_single_trajectory_runs():
             assert np.allclose(res["cost_history"][b], single["cost_history"], rtol=1e-9), (fused, b)
             assert np.allclose(res["U"][b], single["U"], rtol=1e-7, atol=1e-9)
         assert res["stats"][7] >= 1.0 and np.all(np.isfinite(res["stats"]))
+
+
+# ---- a1 / a5: the host finite differences against the numpy restatement of the reference's loops ------------------------
+def _fd_states(model, rng, k):
+    out = []
+    for _ in range(k):
+        if model.name == b"acrobot":
+            q = rng.uniform(-3, 3, 2)
+        else:
+            ax = rng.standard_normal(3); ax /= np.linalg.norm(ax); th = rng.uniform(0.1, 2.5)
+            q = np.concatenate([rng.uniform(-1, 1, 3), [np.cos(th / 2)], np.sin(th / 2) * ax])
+        out.append((q, rng.uniform(-1.5, 1.5, model.nv), rng.uniform(-0.9, 0.9, model.nu) * model.limits[1::2]))
+    return out
+
+
+@pytest.mark.parametrize("name", ["acrobot", "floating_body"])
+def test_host_finite_differences_match_the_restated_reference_loops(name):
+    """Differentiator::DynamicsDerivatives (jobs -> a2 differencing by the oracle) and ::ResidualDerivatives against
+    oracle/host_fd.py: hinge model and free-joint model (tangent-space position rows), central and one-sided control
+    columns (control at its limit), a subset of DoFs."""
+    from oracle import host_fd, oracle as orc
+    M = host.Model(name)
+    rng = np.random.default_rng(11)
+    n, m, dof = 2 * M.dof, M.nu, M.dof
+    for case, (q, v, u) in enumerate(_fd_states(M, rng, 4)):
+        cols = list(range(dof)) if case % 2 == 0 else sorted(rng.choice(dof, size=max(1, dof // 2), replace=False).tolist())
+        if case >= 2:                              # a control at its upper / lower limit: one-sided columns (:94-143)
+            u = u.copy(); u[0] = M.limits[1] if case == 2 else M.limits[0]
+        g = M.host_fd(q, v, u, cols)
+        nj = len(g["job_col"])
+        assert nj == sum(2 + (i < m) for i in cols)
+        A = np.zeros((1, n, n)); B = np.zeros((1, m, n))
+        orc.fd_difference(n, m, np.zeros(nj, np.int32), g["job_col"], g["job_mode"], np.zeros(nj, np.int32),
+                          g["xplus"], g["xminus"], g["xnom"][None, :], 1e-6, A, B)
+        A_ref, B_ref = host_fd.dynamics_derivatives(M, q, v, u, cols)
+        if case >= 2 and 0 in cols:
+            assert g["job_mode"][list(g["job_col"]).index(n)] == (2 if case == 2 else 1)
+        # column-major per step: A[0, c, r]
+        assert np.array_equal(A[0].T, A_ref), (name, case, np.max(np.abs(A[0].T - A_ref)))
+        assert np.array_equal(B[0].T, B_ref), (name, case, np.max(np.abs(B[0].T - B_ref)))
+        r_x, r_u = host_fd.residual_derivatives(M, q, v, u)
+        assert np.array_equal(g["r_x"], r_x) and np.array_equal(g["r_u"], r_u), (name, case)
+
+
+def test_free_joint_jacobian_is_the_tangent_space_jacobian():
+    """The free-joint columns are derivatives in the tangent space: they agree with an independent Jacobian obtained by
+    perturbing with rotation vectors on the LEFT-composed chart of the nominal next state (numpy quaternion algebra)."""
+    M = host.Model("floating_body")
+    rng = np.random.default_rng(3)
+    (q, v, u), = _fd_states(M, rng, 1)
+    g = M.host_fd(q, v, u, list(range(6)))
+    n, eps = 12, 1e-6
+    A = np.zeros((n, n))
+    for j, col in enumerate(g["job_col"]):
+        if col < n:
+            A[:, col] = (g["xplus"][j] - g["xminus"][j]) / (2 * eps)
+
+    def qmul(a, b):
+        return np.array([a[0]*b[0]-a[1]*b[1]-a[2]*b[2]-a[3]*b[3], a[0]*b[1]+a[1]*b[0]+a[2]*b[3]-a[3]*b[2],
+                         a[0]*b[2]-a[1]*b[3]+a[2]*b[0]+a[3]*b[1], a[0]*b[3]+a[1]*b[2]-a[2]*b[1]+a[3]*b[0]])
+
+    def qexp(w):
+        th = np.linalg.norm(w)
+        return np.concatenate([[np.cos(th / 2)], np.sin(th / 2) * w / th]) if th > 0 else np.array([1.0, 0, 0, 0])
+
+    def qlog(qq):
+        qq = qq if qq[0] >= 0 else -qq
+        s = np.linalg.norm(qq[1:])
+        return 2 * np.arctan2(s, qq[0]) * qq[1:] / s if s > 0 else np.zeros(3)
+
+    qn, vn = M.step(q, v, u)
+
+    def f(dx):          # tangent perturbation of (q, v) -> tangent difference of the next state from the nominal one
+        qq = np.concatenate([q[:3] + dx[:3], qmul(q[3:], qexp(dx[3:6]))])
+        q2, v2 = M.step(qq, v + dx[6:], u)
+        conj = q[3:].copy()
+        conj = qn[3:] * np.array([1, -1, -1, -1])
+        return np.concatenate([q2[:3] - qn[:3], qlog(qmul(conj, q2[3:])), v2 - vn])
+
+    h = 1e-5
+    J = np.stack([(f(h * e) - f(-h * e)) / (2 * h) for e in np.eye(12)], axis=1)
+    assert np.max(np.abs(A - J)) < 5e-6, np.max(np.abs(A - J))
+
+
+# ---- a9: the shim's control flow against the oracle's restatement of iLQR::Iteration ---------------------------------------
+def _replay_trace(res, max_iter, min_iter):
+    """Feeds the cost sequences the shim saw to the oracle's a9 functions (orc_update_lambda :636-657, orc_linesearch_accept
+    :490-528, orc_check_convergence Optimiser.cpp:30-37) and demands the same lambda trajectory, acceptance decisions,
+    best alpha and iteration count (:319-340)."""
+    lam, old_cost = 0.1, res["cost_history"][0]                      # Optimiser.h:239
+    expected_iterations = 0
+    derivs_next = True
+    for i, row in enumerate(res["trace"]):
+        expected_iterations += 1
+        assert bool(row["derivatives"]) == derivs_next                # skip the derivatives after a rejected step (:419)
+        assert row["lambda_in"] == lam, (i, row["lambda_in"], lam)
+        exited = False
+        for attempt in range(int(row["backward_passes"])):
+            last = attempt == int(row["backward_passes"]) - 1
+            valid = last and not bool(row["lambda_exit"])
+            lam, exited = orc.update_lambda(lam, valid)
+            assert exited == (last and bool(row["lambda_exit"]))
+        assert lam == row["lambda_after_backward"]
+        if exited:
+            break
+        assert row["old_cost"] == old_cost
+        costs = row["rollout_costs"]
+        assert len(costs) == 6 and not np.any(np.isnan(costs))       # the reference rolls every alpha out
+        best, new_cost, accepted, lam = orc.linesearch_accept(costs, old_cost, lam)
+        assert best == int(row["best"]) and accepted == bool(row["accepted"]) and new_cost == row["new_cost"], (i, best, row)
+        assert lam == row["lambda_out"]
+        conv = orc.check_convergence(old_cost, new_cost)
+        assert conv == bool(row["converged"])
+        assert res["cost_history"][i + 1] == new_cost
+        derivs_next = accepted
+        if accepted:
+            old_cost = new_cost
+        if conv and i >= min_iter:
+            break
+    assert expected_iterations == res["iterations"] == len(res["trace"])
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("model,T,opts", [("acrobot", 100, ""), ("acrobot", 100, "+unfused"), ("acrobot", 60, "+adaptive_jerk"),
+                                          ("floating_body", 80, "")])
+def test_iteration_control_flow_matches_the_oracle(model, T, opts):
+    M = host.Model(model)
+    rng = np.random.default_rng(5)
+    u0 = None if model == "acrobot" else 0.2 * rng.standard_normal((T, M.nu))
+    for max_iter, min_iter in ((8, 2), (4, 0)):
+        res = host.optimise(model, T=T, max_iter=max_iter, min_iter=min_iter, options=opts, u_init=u0)
+        assert len(res["trace"]) >= 1
+        _replay_trace(res, max_iter, min_iter)
+        h = res["cost_history"]
+        assert np.all(np.diff(h) <= 1e-12)          # never worse; a run that only rejects (lambda exit) is a valid case
+
+
+@pytest.mark.gpu
+def test_free_joint_model_optimises_and_pruned_line_search_is_an_option():
+    """Floating body (free joint: tangent-space FD columns and state feedback): the cost falls from the first iteration on; the
+    GPU-ordered line search (opt-in) accepts only improving steps too but may stop at another alpha."""
+    rng = np.random.default_rng(5)
+    u0 = 0.2 * rng.standard_normal((80, 3))
+    ref = host.optimise("floating_body", T=80, max_iter=10, min_iter=2, u_init=u0)
+    assert ref["cost_history"][-1] < 0.9 * ref["cost_history"][0], ref["cost_history"]      # 0.8 s at 4 N: a fifth of the cost
+    pr = host.optimise("floating_body", T=80, max_iter=10, min_iter=2, options="+pruned", u_init=u0)
+    assert np.all(np.diff(pr["cost_history"]) <= 1e-12)
+    for row in pr["trace"]:
+        tried = row["rollout_costs"][~np.isnan(row["rollout_costs"])]
+        assert len(tried) >= 1 and (not row["accepted"] or row["new_cost"] == tried.min() or row["new_cost"] in tried)

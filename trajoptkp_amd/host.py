@@ -39,6 +39,10 @@ def load_host():
     H.kpilqr_host_task_file.argtypes = [C.c_char_p, C.c_int, C.c_int, C.c_int, vp, vp]
     H.kpilqr_host_save_summary.argtypes = [C.c_char_p, C.c_int, C.c_int, vp, vp]
     H.kpilqr_host_run_acrobot_batch.argtypes = [C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_double, vp, C.c_int, vp, C.c_int, vp, vp, vp]
+    H.kpilqr_host_model_info.argtypes = [C.c_char_p, vp, vp, vp]
+    H.kpilqr_host_model_op.argtypes = [C.c_char_p, C.c_int, vp, vp, vp, vp, C.c_double, C.c_int, vp, vp]
+    H.kpilqr_host_model_fd.argtypes = [C.c_char_p, vp, vp, vp, C.c_int, vp, C.c_int, C.c_double, vp, vp, vp, vp, vp, vp, vp]
+    H.kpilqr_host_optimise.argtypes = [C.c_char_p, C.c_int, C.c_int, C.c_int, C.c_char_p, vp, vp, C.c_int, vp, vp]
     _host = H
     return H
 
@@ -125,3 +129,85 @@ def run_acrobot_batch(q0s, T=100, min_N=5, max_iter=6, min_iter=2, torque_weight
     if rc < 0:
         raise RuntimeError(f"kpilqr_host_run_acrobot_batch failed: {rc}")
     return dict(iterations=its, cost_history=[hist[b][hist[b] >= 0] for b in range(B)], U=U, stats=stats)
+
+
+# ---- stand-in models by name ("acrobot", "floating_body"): primitives for the oracle's restatement of the host FD loops ----
+class Model:
+    """The primitives of a stand-in simulator/task pair, one C call each (no GPU involved)."""
+
+    def __init__(self, name):
+        self.name = name.encode()
+        H = load_host()
+        info = np.zeros(6, np.int32); lim = np.zeros(32); dt = np.zeros(1)
+        if H.kpilqr_host_model_info(self.name, _p(info), _p(lim), _p(dt)) != 0:
+            raise ValueError(f"unknown model {name}")
+        self.nq, self.nv, self.nu, self.dof, self.dof_quat, self.nr = (int(v) for v in info)
+        self.limits = lim[:2 * self.nu].copy(); self.dt = float(dt[0])
+        self.tangent = self.dof != self.dof_quat
+
+    def _op(self, op, qpos, qvel, ctrl, other=None, arg=0.0, index=0):
+        H = load_host()
+        q = np.ascontiguousarray(qpos, np.float64); v = np.ascontiguousarray(qvel, np.float64); u = np.ascontiguousarray(ctrl, np.float64)
+        o = None if other is None else np.ascontiguousarray(other, np.float64)
+        oq = np.zeros(32); ov = np.zeros(32)
+        rc = H.kpilqr_host_model_op(self.name, op, _p(q), _p(v), _p(u), _p(o), float(arg), int(index), _p(oq), _p(ov))
+        if rc != 0:
+            raise RuntimeError(f"kpilqr_host_model_op({op}) failed: {rc}")
+        return oq, ov
+
+    def step(self, qpos, qvel, ctrl):
+        oq, ov = self._op(0, qpos, qvel, ctrl)
+        return oq[:self.nq].copy(), ov[:self.nv].copy()
+
+    def residuals(self, qpos, qvel, ctrl):
+        return self._op(1, qpos, qvel, ctrl)[0][:self.nr].copy()
+
+    def state_vector(self, qpos, qvel, ctrl=None):
+        return self._op(2, qpos, qvel, np.zeros(self.nu) if ctrl is None else ctrl)[0][:2 * self.dof].copy()
+
+    def integrate_pos(self, qpos, index, eps):
+        return self._op(3, qpos, np.zeros(self.nv), np.zeros(self.nu), arg=eps, index=index)[0][:self.nq].copy()
+
+    def differentiate_pos(self, dt, qpos1, qpos2):
+        return self._op(4, qpos1, np.zeros(self.nv), np.zeros(self.nu), other=qpos2, arg=dt)[1][:self.nv].copy()
+
+    def host_fd(self, qpos, qvel, ctrl, cols, central=True, eps=1e-6):
+        """Differentiator::DynamicsDerivatives + ::ResidualDerivatives of the PRODUCT at one state."""
+        H = load_host()
+        n = 2 * self.dof
+        cols = np.ascontiguousarray(cols, np.int32)
+        cap = 3 * len(cols)
+        jc = np.zeros(cap, np.int32); jm = np.zeros(cap, np.uint8)
+        xp = np.zeros((cap, n)); xm = np.zeros((cap, n)); xn = np.zeros(n)
+        r_x = np.zeros((self.nr, n)); r_u = np.zeros((self.nr, self.nu))
+        q = np.ascontiguousarray(qpos, np.float64); v = np.ascontiguousarray(qvel, np.float64); u = np.ascontiguousarray(ctrl, np.float64)
+        nj = H.kpilqr_host_model_fd(self.name, _p(q), _p(v), _p(u), len(cols), _p(cols), int(central), float(eps),
+                                    _p(jc), _p(jm), _p(xp), _p(xm), _p(xn), _p(r_x), _p(r_u))
+        if nj < 0:
+            raise RuntimeError("kpilqr_host_model_fd failed")
+        return dict(job_col=jc[:nj], job_mode=jm[:nj], xplus=xp[:nj], xminus=xm[:nj], xnom=xn, r_x=r_x, r_u=r_u)
+
+
+TRACE_FIELDS = ("derivatives", "lambda_in", "backward_passes", "lambda_exit", "lambda_after_backward", "old_cost", "new_cost",
+                "best", "accepted", "converged", "lambda_out", "n_alpha")
+
+
+def optimise(model, T=100, max_iter=8, min_iter=2, options="", u_init=None):
+    """iLQR_GPU::Optimise on a stand-in model (needs the GPU).  Returns cost history, controls and the per-iteration trace."""
+    H = load_host()
+    hist = np.full(max_iter + 2, np.nan); trace = np.full((max_iter, 24), np.nan)
+    M = Model(model)
+    U = np.zeros((T, M.nu))
+    ui = None if u_init is None else np.ascontiguousarray(u_init, np.float64)
+    it = H.kpilqr_host_optimise(model.encode(), T, max_iter, min_iter, options.encode(), _p(ui), _p(hist), len(hist), _p(trace), _p(U))
+    if it < 0:
+        raise RuntimeError(f"kpilqr_host_optimise failed: {it}")
+    rows = []
+    for w in trace[:it]:
+        if np.isnan(w[1]):
+            break
+        d = {k: w[i] for i, k in enumerate(TRACE_FIELDS)}
+        na = int(w[11]) if not np.isnan(w[11]) else 0
+        d["rollout_costs"] = w[12:12 + na].copy(); d["predicted"] = w[18:18 + na].copy()
+        rows.append(d)
+    return dict(iterations=it, cost_history=hist[~np.isnan(hist)], U=U, trace=rows)

@@ -1,6 +1,8 @@
 #include "Differentiator.h"
+#include "SimData.h"
 
 #include <algorithm>
+#include <cstdio>
 #include <cstdlib>
 #include <cstring>
 #include <thread>
@@ -73,20 +75,51 @@ void fd_keypoint(ModelTranslator &mt, PhysicsSimulator &sim, std::atomic<long> &
     SimData *src = sim.saved_systems_state_list[data_index];
     auto reset = [&]() { sim.CopySystemState(d, src); };
     long steps = 0;
+    // Models with free / ball joints (dof != dof_quat): the position rows of every column are tangent-space
+    // differences, mj_differentiatePos on the full next states (:170-174,288-292,388-393).  The device differences plain
+    // vectors, so the rows are handed over already differenced against the step's other state:
+    //   central  x+ = (plus (-) minus), x- = 0;   forward  x+ = (plus (-) nominal);   backward  x- = -(nominal (-) minus)
+    // with the position entries of the nominal row set to 0.  Hinge / slide models keep plain coordinates (identical there).
+    const bool tangent = sv.dof != sv.dof_quat;
+    SimData *nomS = nullptr, *plusS = nullptr, *minusS = nullptr;
+    std::vector<double> vd;
+    if (tangent) {
+        if ((int)sim.fd_scratch.size() < 3 * (tid + 1)) { std::fprintf(stderr, "Differentiator: simulator has no fd_scratch states for tangent-space differences\n"); std::exit(1); }
+        nomS = sim.fd_scratch[3 * tid]; plusS = sim.fd_scratch[3 * tid + 1]; minusS = sim.fd_scratch[3 * tid + 2];
+        vd.resize(sim.nv());
+    }
+    auto tangent_rows = [&](MatrixXd &x, const SimData *from, const SimData *to, double sign) {
+        sim.DifferentiatePos(vd.data(), 1.0, from, to);
+        for (int j = 0; j < dof; j++) x(j) = sign * vd[mt.StateIndexToQposIndex(j, sv)];
+    };
 
     reset();                                                   // unperturbed next state (:66-71)
     sim.ForwardSimulator(d);
-    sink.nominal(mt.ReturnStateVector(d, sv));
+    {
+        MatrixXd xn = mt.ReturnStateVector(d, sv);
+        if (tangent) { sim.CopySystemState(nomS, d); for (int j = 0; j < dof; j++) xn(j) = 0.0; }
+        sink.nominal(xn);
+    }
     reset();
     const MatrixXd u0 = mt.ReturnControlVector(d, sv);
     const MatrixXd x0 = mt.ReturnStateVector(d, sv);
+    MatrixXd v0(dof, 1);
+    for (int j = 0; j < dof; j++) v0(j) = x0(dof + j);
     const MatrixXd lim = mt.ReturnControlLimits(sv);
-    auto stepped = [&](int skip_stage) {
+    auto stepped = [&](int skip_stage, SimData *keep) {
         steps++;
         sim.ForwardSimulatorWithSkip(d, skip_stage, 1);
+        if (tangent) sim.CopySystemState(keep, d);
         return mt.ReturnStateVector(d, sv);
     };
     const MatrixXd zero_state(n, 1);
+    // position rows of a finished column (mode as emitted: 0 central, 1 forward, 2 backward)
+    auto finish = [&](int mode, bool have_p, bool have_m, MatrixXd &xp, MatrixXd &xm) {
+        if (!tangent) return;
+        if (mode == 0 && have_p && have_m) { tangent_rows(xp, minusS, plusS, 1.0); for (int j = 0; j < dof; j++) xm(j) = 0.0; }
+        else if (mode == 1 && have_p) tangent_rows(xp, nomS, plusS, 1.0);
+        else if (mode == 2 && have_m) tangent_rows(xm, minusS, nomS, -1.0);
+    };
 
     for (int i : cols) {
         if (i < num_ctrl) {                                   // ---- controls (:81-223)
@@ -95,34 +128,37 @@ void fd_keypoint(ModelTranslator &mt, PhysicsSimulator &sim, std::atomic<long> &
             const bool fwd = !(up(i) > lim(2 * i + 1));
             const bool bwd = (central_diff || !fwd) && !(um(i) < lim(2 * i));
             MatrixXd xp = zero_state, xm = zero_state;
-            if (fwd) { mt.SetControlVector(up, d, sv); xp = stepped(2); reset(); }
-            if (bwd) { mt.SetControlVector(um, d, sv); xm = stepped(2); reset(); }
-            sink.job(n + i, (fwd && bwd) || (!fwd && !bwd) ? 0 : fwd ? 1 : 2, xp, xm);
+            if (fwd) { mt.SetControlVector(up, d, sv); xp = stepped(2, plusS); reset(); }
+            if (bwd) { mt.SetControlVector(um, d, sv); xm = stepped(2, minusS); reset(); }
+            const int mode = (fwd && bwd) || (!fwd && !bwd) ? 0 : fwd ? 1 : 2;
+            finish(mode, fwd, bwd, xp, xm);
+            sink.job(n + i, mode, xp, xm);
         }
         {                                                       // ---- velocities (:226-325)
-            MatrixXd xq = x0; xq(dof + i) += eps;
-            mt.SetStateVector(xq, d, sv);
-            MatrixXd xp = stepped(1), xm = zero_state;
+            MatrixXd vq = v0; vq(i) += eps;
+            mt.SetVelocityVector(vq, d, sv);
+            MatrixXd xp = stepped(1, plusS), xm = zero_state;
             reset();
             if (central_diff) {
-                xq = x0; xq(dof + i) -= eps;
-                mt.SetStateVector(xq, d, sv);
-                xm = stepped(1);
+                vq = v0; vq(i) -= eps;
+                mt.SetVelocityVector(vq, d, sv);
+                xm = stepped(1, minusS);
                 reset();
             }
+            finish(central_diff ? 0 : 1, true, central_diff, xp, xm);
             sink.job(dof + i, central_diff ? 0 : 1, xp, xm);
         }
-        {                                                       // ---- positions (:328-428), hinge/slide joints
-            MatrixXd xq = x0; xq(i) += eps;
-            mt.SetStateVector(xq, d, sv);
-            MatrixXd xp = stepped(0), xm = zero_state;
+        {                                                       // ---- positions (:328-428): mj_integratePos on the tangent index
+            const int qi = mt.StateIndexToQposIndex(i, sv);
+            sim.IntegratePos(d, qi, eps);
+            MatrixXd xp = stepped(0, plusS), xm = zero_state;
             reset();
             if (central_diff) {
-                xq = x0; xq(i) -= eps;
-                mt.SetStateVector(xq, d, sv);
-                xm = stepped(0);
+                sim.IntegratePos(d, qi, -eps);
+                xm = stepped(0, minusS);
                 reset();
             }
+            finish(central_diff ? 0 : 1, true, central_diff, xp, xm);
             sink.job(i, central_diff ? 0 : 1, xp, xm);
         }
     }
@@ -225,27 +261,45 @@ void Differentiator::DynamicsDerivativesBatch(FDStaging &st, int b, const std::v
     st.nnom = nom0 + (int)times.size();
 }
 
+// Differentiator::ResidualDerivatives (src/Differentiator/Differentiator.cpp:464-663), central differences: controls with
+// the reference's limit-aware one-sided fallback (:496-556), velocities through the state vector (:575-623), positions
+// through mj_integratePos on the tangent index (:626-656); the state is restored from the saved one after every column.
 void Differentiator::ResidualDerivatives(double *r_x, double *r_u, int data_index, int tid, double eps)
 {
     const stateVectorList &sv = model_translator->current_state_vector;
     const int dof = sv.dof, m = sv.num_ctrl, n = 2 * dof, nr = (int)model_translator->residual_list.size();
     SimData *d = MuJoCo_helper->fd_data[tid];
     SimData *src = MuJoCo_helper->saved_systems_state_list[data_index];
-    MuJoCo_helper->CopySystemState(d, src);
+    auto reset = [&]() { MuJoCo_helper->CopySystemState(d, src); };
+    reset();
     if (model_translator->ResidualJacobians(d, r_x, r_u)) return;      // closed form: no differencing
+    const bool central_diff = true;                                     // Optimiser.cpp:325-338
+    MatrixXd r0(nr, 1), rp(nr, 1), rm(nr, 1);
+    model_translator->Residuals(d, r0);                                 // :487
     const MatrixXd x0 = model_translator->ReturnStateVector(d, sv), u0 = model_translator->ReturnControlVector(d, sv);
-    MatrixXd rp(nr, 1), rm(nr, 1);
-    for (int i = 0; i < m; i++) {                                // :r_u
-        MatrixXd u = u0; u(i) += eps; model_translator->SetControlVector(u, d, sv); model_translator->Residuals(d, rp);
-        u = u0; u(i) -= eps; model_translator->SetControlVector(u, d, sv); model_translator->Residuals(d, rm);
-        for (int j = 0; j < nr; j++) r_u[j * m + i] = (rp(j) - rm(j)) / (2 * eps);
-        model_translator->SetControlVector(u0, d, sv);
+    const MatrixXd lim = model_translator->ReturnControlLimits(sv);
+    MatrixXd v0(dof, 1);
+    for (int j = 0; j < dof; j++) v0(j) = x0(dof + j);
+    for (int i = 0; i < m; i++) {                                       // ---- r_u (:496-556)
+        MatrixXd u = u0; u(i) += eps;
+        const bool fwd = !(u(i) > lim(2 * i + 1));
+        if (fwd) { model_translator->SetControlVector(u, d, sv); model_translator->Residuals(d, rp); reset(); }
+        u = u0; u(i) -= eps;
+        const bool bwd = (central_diff || !fwd) && !(u(i) < lim(2 * i));
+        if (bwd) { model_translator->SetControlVector(u, d, sv); model_translator->Residuals(d, rm); reset(); }
+        for (int j = 0; j < nr; j++)
+            r_u[j * m + i] = (fwd && bwd) ? (rp(j) - rm(j)) / (2 * eps) : fwd ? (rp(j) - r0(j)) / (eps) : bwd ? (r0(j) - rm(j)) / (eps) : 0.0;
     }
-    for (int i = 0; i < n; i++) {                                // :r_x (positions then velocities)
-        MatrixXd x = x0; x(i) += eps; model_translator->SetStateVector(x, d, sv); model_translator->Residuals(d, rp);
-        x = x0; x(i) -= eps; model_translator->SetStateVector(x, d, sv); model_translator->Residuals(d, rm);
+    for (int i = 0; i < dof; i++) {                                     // ---- velocities -> r_x column i + dof (:575-623)
+        MatrixXd v = v0; v(i) += eps; model_translator->SetVelocityVector(v, d, sv); model_translator->Residuals(d, rp); reset();
+        v = v0; v(i) -= eps; model_translator->SetVelocityVector(v, d, sv); model_translator->Residuals(d, rm); reset();
+        for (int j = 0; j < nr; j++) r_x[j * n + dof + i] = (rp(j) - rm(j)) / (2 * eps);
+    }
+    for (int i = 0; i < dof; i++) {                                     // ---- positions -> r_x column i (:626-656)
+        const int qi = model_translator->StateIndexToQposIndex(i, sv);
+        MuJoCo_helper->IntegratePos(d, qi, eps); model_translator->Residuals(d, rp); reset();
+        MuJoCo_helper->IntegratePos(d, qi, -eps); model_translator->Residuals(d, rm); reset();
         for (int j = 0; j < nr; j++) r_x[j * n + i] = (rp(j) - rm(j)) / (2 * eps);
-        model_translator->SetStateVector(x0, d, sv);
     }
 }
 

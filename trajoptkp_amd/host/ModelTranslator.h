@@ -32,6 +32,14 @@ public:
     virtual int StateIndexToQposIndex(int state_index, const stateVectorList &sv) { (void)sv; return state_index; }
     virtual MatrixXd ReturnStateVector(SimData *d, const stateVectorList &sv) = 0;       // [q; qdot], 2*dof x 1
     virtual bool SetStateVector(const MatrixXd &x, SimData *d, const stateVectorList &sv) = 0;
+    // velocities only (ModelTranslator::SetVelocityVector, what the velocity columns of the finite differences perturb:
+    // src/Differentiator/Differentiator.cpp:241-245); the default goes through the whole state vector
+    virtual bool SetVelocityVector(const MatrixXd &velocities, SimData *d, const stateVectorList &sv)
+    {
+        MatrixXd x = ReturnStateVector(d, sv);
+        for (int i = 0; i < sv.dof; i++) x(sv.dof + i) = velocities(i);
+        return SetStateVector(x, d, sv);
+    }
     virtual MatrixXd ReturnControlVector(SimData *d, const stateVectorList &sv) = 0;
     virtual bool SetControlVector(const MatrixXd &u, SimData *d, const stateVectorList &sv) = 0;
     virtual MatrixXd ReturnControlLimits(const stateVectorList &sv) = 0;                // [lo0,hi0,lo1,hi1,...]

@@ -38,4 +38,7 @@ public:
     SimData *main_data = nullptr;
     SimData *master_reset_data = nullptr;
     std::vector<SimData *> fd_data;        // one per FD worker thread
+    // three more states per FD worker (nominal / plus / minus next state) for models whose position differences are
+    // taken in the tangent space -- the reference keeps them as mj_getState arrays (Differentiator.cpp:53-60)
+    std::vector<SimData *> fd_scratch;
 };

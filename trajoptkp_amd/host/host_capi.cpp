@@ -1,11 +1,13 @@
 // host_capi.cpp -- small C entry points over the C++ host classes so that the Python tests can drive
 // them (key-point generators against the oracle; the acrobot plumbing optimisation end to end).
 #include <chrono>
+#include <cmath>
 #include <cstdio>
 #include <cstring>
 #include <memory>
 
 #include "AcrobotModel.h"
+#include "FloatingBodyModel.h"
 #include "FileHandler.h"
 #include "iLQR_GPU.h"
 #include "iLQR_GPU_Batch.h"
@@ -112,6 +114,146 @@ int kpilqr_host_run_acrobot_batch(int B, int T, int min_N, int max_iter, int min
     }
     if (stats) for (int i = 0; i < 8; i++) stats[i] = opt.linesearch_stats[i];
     return 0;
+}
+
+// ---- stand-in models by name, for the oracle tests of the host finite differences (a1, a5) and of the control flow (a9) ----
+namespace {
+struct Model {
+    std::shared_ptr<PhysicsSimulator> sim;
+    std::shared_ptr<ModelTranslator> mt;
+};
+bool make_model(const char *name, int fd_threads, Model &M)
+{
+    const std::string nm = name ? name : "";
+    if (nm == "acrobot") {
+        auto sim = std::make_shared<AcrobotSimulator>(0.01, fd_threads);
+        M.sim = sim; M.mt = std::make_shared<AcrobotTranslator>(sim);
+        sim->main_data->qpos[0] = 3.1415; sim->main_data->qpos[1] = 0.3;
+        return true;
+    }
+    if (nm == "floating_body") {
+        auto sim = std::make_shared<FloatingBodySimulator>(0.01, fd_threads);
+        M.sim = sim; M.mt = std::make_shared<FloatingBodyTranslator>(sim);
+        return true;
+    }
+    return false;
+}
+void load_state(SimData *d, const double *qpos, const double *qvel, const double *ctrl)
+{
+    for (int i = 0; i < d->nq; i++) d->qpos[i] = qpos[i];
+    for (int i = 0; i < d->nv; i++) d->qvel[i] = qvel[i];
+    for (int i = 0; i < d->nu; i++) d->ctrl[i] = ctrl[i];
+}
+}  // namespace
+
+// info[0..5] = nq, nv, nu, dof, dof_quat, nr; limits [2*nu]; dt
+int kpilqr_host_model_info(const char *model, int *info, double *limits, double *dt)
+{
+    Model M;
+    if (!make_model(model, 1, M)) return -1;
+    const stateVectorList &sv = M.mt->current_state_vector;
+    info[0] = M.sim->main_data->nq; info[1] = M.sim->main_data->nv; info[2] = M.sim->main_data->nu;
+    info[3] = sv.dof; info[4] = sv.dof_quat; info[5] = (int)M.mt->residual_list.size();
+    const MatrixXd lim = M.mt->ReturnControlLimits(sv);
+    for (int i = 0; i < 2 * sv.num_ctrl; i++) limits[i] = lim(i);
+    *dt = M.sim->ReturnModelTimeStep();
+    return 0;
+}
+
+// The model's primitives, one call each (what the numpy restatement of the reference's FD loops is written on):
+//   op 0  step:           next qpos / qvel after ForwardSimulator          -> out_q [nq], out_v [nv]
+//   op 1  residuals:      Residuals(state)                                 -> out_q [nr]
+//   op 2  state vector:   ReturnStateVector(state)                         -> out_q [2*dof]
+//   op 3  integrate pos:  qpos (+) eps * e_index                           -> out_q [nq]       (arg = eps, index)
+//   op 4  differentiate:  (qpos2 (-) qpos) / dt with qpos2 in `other`      -> out_v [nv]       (arg = dt)
+int kpilqr_host_model_op(const char *model, int op, const double *qpos, const double *qvel, const double *ctrl,
+                         const double *other, double arg, int index, double *out_q, double *out_v)
+{
+    Model M;
+    if (!make_model(model, 1, M)) return -1;
+    const stateVectorList &sv = M.mt->current_state_vector;
+    SimData *d = M.sim->main_data;
+    load_state(d, qpos, qvel, ctrl);
+    if (op == 0) {
+        M.sim->ForwardSimulator(d);
+        for (int i = 0; i < d->nq; i++) out_q[i] = d->qpos[i];
+        for (int i = 0; i < d->nv; i++) out_v[i] = d->qvel[i];
+    } else if (op == 1) {
+        MatrixXd r((int)M.mt->residual_list.size(), 1);
+        M.mt->Residuals(d, r);
+        for (int i = 0; i < r.rows(); i++) out_q[i] = r(i);
+    } else if (op == 2) {
+        const MatrixXd x = M.mt->ReturnStateVector(d, sv);
+        for (int i = 0; i < x.rows(); i++) out_q[i] = x(i);
+    } else if (op == 3) {
+        M.sim->IntegratePos(d, index, arg);
+        for (int i = 0; i < d->nq; i++) out_q[i] = d->qpos[i];
+    } else if (op == 4) {
+        SimData *d2 = M.sim->fd_data[0];
+        *d2 = *d;
+        for (int i = 0; i < d->nq; i++) d2->qpos[i] = other[i];
+        M.sim->DifferentiatePos(out_v, arg, d, d2);
+    } else return -2;
+    return 0;
+}
+
+// The product's host FD at ONE state: Differentiator::DynamicsDerivatives for the DoFs `cols` (jobs in the layout of
+// kpilqr_upload_fd; returns the number of jobs) and ::ResidualDerivatives (r_x [nr][2 dof], r_u [nr][nu]).
+int kpilqr_host_model_fd(const char *model, const double *qpos, const double *qvel, const double *ctrl, int ncols, const int *cols,
+                         int central, double eps, int *job_col, unsigned char *job_mode, double *xplus, double *xminus, double *xnom,
+                         double *r_x, double *r_u)
+{
+    Model M;
+    if (!make_model(model, 2, M)) return -1;
+    const int n = 2 * M.mt->current_state_vector.dof;
+    load_state(M.sim->main_data, qpos, qvel, ctrl);
+    M.sim->AppendSystemStateToEnd(M.sim->main_data);
+    Differentiator diff(M.mt, M.sim);
+    FDJobs jobs;
+    diff.DynamicsDerivatives(jobs, 0, std::vector<int>(cols, cols + ncols), 0, 0, central != 0, eps);
+    for (int j = 0; j < jobs.njobs(); j++) { job_col[j] = jobs.job_col[j]; job_mode[j] = jobs.job_mode[j]; }
+    std::memcpy(xplus, jobs.xplus.data(), sizeof(double) * jobs.xplus.size());
+    std::memcpy(xminus, jobs.xminus.data(), sizeof(double) * jobs.xminus.size());
+    std::memcpy(xnom, jobs.xnom.data(), sizeof(double) * n);
+    if (r_x && r_u) diff.ResidualDerivatives(r_x, r_u, 0, 0, eps);
+    return jobs.njobs();
+}
+
+// Optimise() of a stand-in model on the GPU engine with the per-iteration decisions written out for the a9 parity test:
+// trace [max_iter][24] = derivatives, lambda_in, backward_passes, lambda_exit, lambda_after_backward, old_cost, new_cost,
+// best, accepted, converged, lambda_out, n_alpha, rollout_costs[6], predicted[6].  options: "+pruned" (GPU-ordered line
+// search), "+unfused", "+adaptive_jerk" ... (key-point method name).  Returns iterations run or < 0.
+int kpilqr_host_optimise(const char *model, int T, int max_iter, int min_iter, const char *options, const double *u_init /*[T][nu] or NULL*/,
+                         double *cost_history, int cost_cap, double *trace, double *U_out)
+{
+    Model M;
+    if (!make_model(model, 8, M)) return -1;
+    const std::string opt = options ? options : "";
+    for (const char *km : {"set_interval", "adaptive_jerk", "velocity_change", "iterative_error"})
+        if (opt.find(std::string("+") + km) != std::string::npos) M.mt->keypoint_method = km;
+    *M.sim->master_reset_data = *M.sim->main_data;
+    auto diff = std::make_shared<Differentiator>(M.mt, M.sim);
+    iLQR_GPU ilqr(M.mt, M.sim, diff, T);
+    if (!ilqr.ok()) return -2;
+    if (opt.find("+unfused") != std::string::npos) ilqr.SetFused(false);
+    if (opt.find("+pruned") != std::string::npos) ilqr.linesearch_mode = iLQR_GPU::LINESEARCH_PRUNED;
+    const int m = M.mt->current_state_vector.num_ctrl;
+    std::vector<MatrixXd> U0(T, MatrixXd(m, 1));
+    if (u_init) for (int t = 0; t < T; t++) for (int i = 0; i < m; i++) U0[t](i) = u_init[(size_t)t * m + i];
+    std::vector<MatrixXd> U = ilqr.Optimise(M.sim->main_data, U0, max_iter, min_iter, T);
+    const int nh = (int)ilqr.cost_history.size();
+    for (int i = 0; i < nh && i < cost_cap; i++) cost_history[i] = ilqr.cost_history[i];
+    for (size_t it = 0; it < ilqr.trace.size() && (int)it < max_iter; it++) {
+        const iLQR_GPU::IterationTrace &tr = ilqr.trace[it];
+        double *w = trace + it * 24;
+        for (int i = 0; i < 24; i++) w[i] = std::nan("");
+        w[0] = tr.derivatives; w[1] = tr.lambda_in; w[2] = tr.backward_passes; w[3] = tr.lambda_exit; w[4] = tr.lambda_after_backward;
+        w[5] = tr.old_cost; w[6] = tr.new_cost; w[7] = tr.best; w[8] = tr.accepted; w[9] = tr.converged; w[10] = tr.lambda_out;
+        w[11] = (double)tr.rollout_costs.size();
+        for (size_t a = 0; a < tr.rollout_costs.size() && a < 6; a++) { w[12 + a] = tr.rollout_costs[a]; w[18 + a] = tr.predicted[a]; }
+    }
+    if (U_out) for (int t = 0; t < T; t++) for (int i = 0; i < m; i++) U_out[(size_t)t * m + i] = U[t](i);
+    return ilqr.num_iterations;
 }
 
 // Host FD-harness microbenchmark (no GPU involved): Acrobot, T saved states, every DoF

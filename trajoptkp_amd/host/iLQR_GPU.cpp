@@ -1,8 +1,10 @@
 // iLQR_GPU.cpp -- host control flow of one optimisation, line-cited against src/Optimiser/iLQR.cpp.
 #include "iLQR_GPU.h"
+#include "SimData.h"
 
 #include <algorithm>
 #include <chrono>
+#include <cmath>
 #include <cstdio>
 #include <cstdlib>
 
@@ -98,7 +100,7 @@ std::vector<MatrixXd> iLQR_GPU::Optimise(SimData *d, std::vector<MatrixXd> initi
 {
     const auto opt_start = clk::now();
     Resize(activeModelTranslator->current_state_vector.dof, activeModelTranslator->current_state_vector.num_ctrl, horizon);
-    cost_history.clear(); time_get_derivs_ms.clear(); time_backwards_pass_ms.clear(); time_forwardsPass_ms.clear();
+    cost_history.clear(); time_get_derivs_ms.clear(); time_backwards_pass_ms.clear(); time_forwardsPass_ms.clear(); trace.clear();
     percentage_derivs_per_iteration.clear();
     num_iterations = 0;
     old_cost = RolloutTrajectory(d, true, initial_controls);
@@ -189,23 +191,32 @@ bool iLQR_GPU::UpdateLambda(bool valid_backwards_pass)
     return lambda_exit;
 }
 
-// One closed-loop simulator rollout with the chosen alpha: the reference's ForwardsPassParallel
-// (iLQR.cpp:824-934) for ONE alpha, used to confirm the GPU's prediction.
-double iLQR_GPU::ForwardsPassConfirm(double alpha, std::vector<MatrixXd> &U_out, std::vector<MatrixXd> &X_out)
+// iLQR::ForwardsPassParallel (iLQR.cpp:824-934): one closed-loop simulator rollout with step size alpha on
+// fd_data[thread_id]; returns its cost and the controls it applied.
+double iLQR_GPU::ForwardsPassParallel(int thread_id, double alpha, std::vector<MatrixXd> &U_out)
 {
     const stateVectorList &sv = activeModelTranslator->current_state_vector;
     const int n = 2 * dof, m = num_ctrl;
-    SimData *d = MuJoCo_helper->fd_data[0];
+    const bool tangent = sv.dof != sv.dof_quat;
+    SimData *d = MuJoCo_helper->fd_data[thread_id];
     MuJoCo_helper->CopySystemState(d, MuJoCo_helper->saved_systems_state_list[0]);
     double cost = 0.0;
-    MatrixXd r((int)w_run.size(), 1);
-    X_out[0] = activeModelTranslator->ReturnStateVector(d, sv);
+    MatrixXd r((int)w_run.size(), 1), fbk(n, 1);
+    std::vector<double> vel_diff(tangent ? MuJoCo_helper->nv() : 0);
     for (int t = 0; t < horizon_length; t++) {
         const MatrixXd x = activeModelTranslator->ReturnStateVector(d, sv);
+        if (!tangent) {
+            for (int p = 0; p < n; p++) fbk(p) = x(p) - X_old[t](p);                     // :853
+        } else {
+            // position differences in the tangent space: mj_differentiatePos(vel_diff, 1.0, state_old, state_new) (:857-868)
+            MuJoCo_helper->DifferentiatePos(vel_diff.data(), 1.0, MuJoCo_helper->saved_systems_state_list[t], d);
+            for (int j = 0; j < dof; j++) fbk(j) = vel_diff[activeModelTranslator->StateIndexToQposIndex(j, sv)];
+            for (int j = 0; j < dof; j++) fbk(j + dof) = x(dof + j) - X_old[t](dof + j);  // :871-873
+        }
         MatrixXd u(m, 1);
         for (int i = 0; i < m; i++) {
             double fb = 0.0;
-            for (int p = 0; p < n; p++) fb += K[t](i, p) * (x(p) - X_old[t](p));       // :853,876
+            for (int p = 0; p < n; p++) fb += K[t](i, p) * fbk(p);                      // :876
             double v = U_old[t](i) + (alpha * k[t](i)) + fb;                            // :879
             if (v > ctrl_lim[2 * i + 1]) v = ctrl_lim[2 * i + 1];                       // :883-889
             if (v < ctrl_lim[2 * i]) v = ctrl_lim[2 * i];
@@ -213,10 +224,9 @@ double iLQR_GPU::ForwardsPassConfirm(double alpha, std::vector<MatrixXd> &U_out,
         }
         activeModelTranslator->SetControlVector(u, d, sv);
         activeModelTranslator->Residuals(d, r);
-        cost += activeModelTranslator->CostFunction(r, sv, t == horizon_length - 1);
+        cost += activeModelTranslator->CostFunction(r, sv, t == horizon_length - 1);   // :899-912
         U_out[t] = u;
         MuJoCo_helper->ForwardSimulator(d);
-        X_out[t + 1] = activeModelTranslator->ReturnStateVector(d, sv);
     }
     return cost;
 }
@@ -225,26 +235,31 @@ double iLQR_GPU::ForwardsPassConfirm(double alpha, std::vector<MatrixXd> &U_out,
 void iLQR_GPU::Iteration(int iteration_num, bool &converged, bool &lambda_exit)
 {
     (void)iteration_num;
-    const int n = 2 * dof, m = num_ctrl, T = horizon_length;
+    const int n = 2 * dof, m = num_ctrl, T = horizon_length, na = (int)alphas.size();
+    IterationTrace tr;
+    tr.derivatives = cost_reduced_last_iter;
     auto t0 = clk::now();
     if (cost_reduced_last_iter) GenerateDerivatives();                                  // STEP 1 (:419)
     time_get_derivs_ms.push_back(ms_since(t0));
 
     t0 = clk::now();
     bool valid = false;                                                                 // STEP 2 (:435-442)
+    tr.lambda_in = lambda;
     while (!valid) {
         valid = BackwardsPassQuuRegularisation();
+        tr.backward_passes++;
         lambda_exit = UpdateLambda(valid);
         if (lambda_exit) break;
     }
+    tr.lambda_after_backward = lambda; tr.lambda_exit = lambda_exit;
     time_backwards_pass_ms.push_back(ms_since(t0));
-    if (lambda_exit) return;
+    if (lambda_exit) { tr.lambda_out = lambda; tr.old_cost = tr.new_cost = old_cost; trace.push_back(tr); return; }
 
     t0 = clk::now();                                                                    // STEP 3
     for (int t = 0; t < T; t++) for (int i = 0; i < m; i++) host_unom[(size_t)t * m + i] = U_old[t](i);
     int rc = kpilqr_upload_nominal(ctx, host_unom, ctrl_lim.data());
     if (rc) fatal("kpilqr_upload_nominal", rc);
-    std::vector<double> pred(alphas.size());
+    std::vector<double> pred(na);
     if ((rc = kpilqr_forward_linear(ctx, alphas.data(), pred.data(), nullptr))) fatal("kpilqr_forward_linear", rc);
     if ((rc = kpilqr_download_gains(ctx, host_K, host_k))) fatal("kpilqr_download_gains", rc);
     if ((rc = kpilqr_sync(ctx))) fatal("kpilqr_sync", rc);
@@ -252,27 +267,39 @@ void iLQR_GPU::Iteration(int iteration_num, bool &converged, bool &lambda_exit)
         for (int c = 0; c < n; c++) for (int r = 0; r < m; r++) K[t](r, c) = host_K[((size_t)t * n + c) * m + r];
         for (int r = 0; r < m; r++) k[t](r) = host_k[(size_t)t * m + r];
     }
-    // candidates in order of predicted cost; each is confirmed with one simulator rollout until one
-    // improves the true cost (the reference rolls all six out in parallel and takes the best, :478-502)
-    std::vector<int> order(alphas.size());
-    for (size_t i = 0; i < order.size(); i++) order[i] = (int)i;
-    std::sort(order.begin(), order.end(), [&](int a, int b) { return pred[a] < pred[b]; });
-    std::vector<MatrixXd> U_try(T, MatrixXd(m, 1)), X_try(T + 1, MatrixXd(n, 1));
+    tr.predicted = pred;
+    tr.rollout_costs.assign(na, std::nan(""));
+    std::vector<std::vector<MatrixXd>> U_try(na, std::vector<MatrixXd>(T, MatrixXd(m, 1)));
+    int best = -1;
     new_cost = old_cost;
-    for (int idx : order) {
-        const double c = ForwardsPassConfirm(alphas[idx], U_try, X_try);
-        if (c < old_cost) { new_cost = c; break; }
+    if (linesearch_mode == LINESEARCH_REFERENCE) {
+        // all alphas rolled out in parallel, one fd_data slot per pool worker (:478-487: std::async per alpha)
+        activeDifferentiator->pool().parallel_for(na, [&](int i, int tid) { tr.rollout_costs[i] = ForwardsPassParallel(tid, alphas[i], U_try[i]); });
+        best = (int)(std::min_element(tr.rollout_costs.begin(), tr.rollout_costs.end()) - tr.rollout_costs.begin());   // :490
+        if (tr.rollout_costs[best] < old_cost) new_cost = tr.rollout_costs[best];        // :494-502
+    } else {
+        // candidates in order of the GPU's predicted cost; each is confirmed with one simulator rollout until one improves
+        std::vector<int> order(na);
+        for (int i = 0; i < na; i++) order[i] = i;
+        std::sort(order.begin(), order.end(), [&](int a, int b) { return pred[a] < pred[b]; });
+        for (int idx : order) {
+            tr.rollout_costs[idx] = ForwardsPassParallel(0, alphas[idx], U_try[idx]);
+            if (tr.rollout_costs[idx] < old_cost) { new_cost = tr.rollout_costs[idx]; best = idx; break; }
+        }
     }
     time_forwardsPass_ms.push_back(ms_since(t0));
+    tr.best = best; tr.old_cost = old_cost; tr.new_cost = new_cost;
 
     converged = CheckForConvergence(old_cost, new_cost);                                // STEP 4 (:515)
+    tr.converged = converged;
     if (new_cost < old_cost) {
-        // UpdateNominal (:936-948) from the confirming rollout
+        // SaveBestRollout + UpdateNominal (Optimiser.cpp:441-469, iLQR.cpp:936-948): the winning controls are replayed on
+        // main_data, which refreshes the saved states, the nominal trajectory and the residuals in one pass
         const stateVectorList &sv = activeModelTranslator->current_state_vector;
         SimData *d = MuJoCo_helper->main_data;
         MuJoCo_helper->CopySystemState(d, MuJoCo_helper->saved_systems_state_list[0]);
         for (int t = 0; t < T; t++) {
-            U_old[t] = U_try[t];
+            U_old[t] = U_try[best][t];
             activeModelTranslator->SetControlVector(U_old[t], d, sv);
             MuJoCo_helper->ForwardSimulator(d);
             activeModelTranslator->Residuals(d, residuals[t]);
@@ -281,11 +308,14 @@ void iLQR_GPU::Iteration(int iteration_num, bool &converged, bool &lambda_exit)
         }
         old_cost = new_cost;
         cost_reduced_last_iter = true;
+        tr.accepted = true;
     } else {
         cost_reduced_last_iter = false;
         lambda *= lambda_factor; lambda *= lambda_factor;                               // :525-527
         if (lambda > max_lambda) lambda = max_lambda;
     }
+    tr.lambda_out = lambda;
+    trace.push_back(tr);
     cost_history.push_back(new_cost);
 }
 

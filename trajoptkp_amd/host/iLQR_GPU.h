@@ -31,12 +31,35 @@ public:
     void SetFused(bool on) { if (on != use_fused) { use_fused = on; recreate_ctx = true; Resize(dof, num_ctrl, horizon_length); } }
     std::string BackwardVariant() const { return ctx ? kpilqr_backward_variant(ctx) : ""; }
 
+    // STEP 3, the line search.  LINESEARCH_REFERENCE (default): every alpha is rolled out closed-loop through the
+    // simulator, concurrently on the FD pool (one fd_data slot per worker), the arg-min is taken and accepted iff it
+    // beats the old cost -- src/Optimiser/iLQR.cpp:463-503.  LINESEARCH_PRUNED: the GPU's linearised prediction
+    // (kpilqr_forward_linear) orders the candidates and the first one whose confirming rollout improves is taken
+    // (at most n_alpha serial rollouts, usually one): cheaper, but NOT the reference's accepted trajectory.
+    enum { LINESEARCH_REFERENCE = 0, LINESEARCH_PRUNED = 1 };
+    int linesearch_mode = LINESEARCH_REFERENCE;
+    // what every iteration decided, for the parity tests against the oracle's a9 functions
+    struct IterationTrace {
+        bool derivatives = false;               // STEP 1 ran (cost_reduced_last_iter)
+        double lambda_in = 0;                   // lambda entering STEP 2
+        int backward_passes = 0;                // PD retries (:435-442)
+        bool lambda_exit = false;
+        double lambda_after_backward = 0;
+        std::vector<double> rollout_costs;      // per alpha (REFERENCE mode: all of them; PRUNED: the ones tried, else NaN)
+        std::vector<double> predicted;          // GPU prediction per alpha (cost change of the linearised model)
+        double old_cost = 0, new_cost = 0;
+        int best = -1;
+        bool accepted = false, converged = false;
+        double lambda_out = 0;
+    };
+    std::vector<IterationTrace> trace;
+
 private:
     void Iteration(int iteration_num, bool &converged, bool &lambda_exit);
     void GenerateDerivatives();
     bool BackwardsPassQuuRegularisation();
     bool UpdateLambda(bool valid_backwards_pass);
-    double ForwardsPassConfirm(double alpha, std::vector<MatrixXd> &U_out, std::vector<MatrixXd> &X_out);
+    double ForwardsPassParallel(int thread_id, double alpha, std::vector<MatrixXd> &U_out);
     void fatal(const char *what, int rc);
 
     kpilqr_ctx *ctx = nullptr;

@@ -1,5 +1,6 @@
 // iLQR_GPU_Batch.cpp -- see the header.  Line citations are to src/Optimiser/iLQR.cpp unless noted.
 #include "iLQR_GPU_Batch.h"
+#include "SimData.h"
 
 #include <algorithm>
 #include <cstdio>
@@ -81,25 +82,33 @@ double iLQR_GPU_Batch::Rollout(int b, SimData *start, const std::vector<MatrixXd
     return cost;
 }
 
-// one closed-loop rollout with alpha (ForwardsPassParallel :824-934 for ONE alpha)
-double iLQR_GPU_Batch::ConfirmRollout(int b, double alpha, std::vector<MatrixXd> &U_out, std::vector<MatrixXd> &X_out)
+// one closed-loop rollout with alpha on fd_data[tid] (ForwardsPassParallel :824-934)
+double iLQR_GPU_Batch::ConfirmRollout(int b, int tid, double alpha, std::vector<MatrixXd> &U_out)
 {
     ModelTranslator &mt = *P[b].model_translator;
     PhysicsSimulator &sim = *P[b].MuJoCo_helper;
     const stateVectorList &sv = mt.current_state_vector;
     const int n = 2 * dof, m = num_ctrl;
+    const bool tangent = sv.dof != sv.dof_quat;
     Traj &s = S[b];
-    SimData *d = sim.fd_data[0];
+    SimData *d = sim.fd_data[tid];
     sim.CopySystemState(d, sim.saved_systems_state_list[0]);
     double cost = 0.0;
-    MatrixXd r(nr, 1);
-    X_out[0] = mt.ReturnStateVector(d, sv);
+    MatrixXd r(nr, 1), fbk(n, 1);
+    std::vector<double> vel_diff(tangent ? sim.nv() : 0);
     for (int t = 0; t < T; t++) {
         const MatrixXd x = mt.ReturnStateVector(d, sv);
+        if (!tangent) {
+            for (int p = 0; p < n; p++) fbk(p) = x(p) - s.X_old[t](p);                          // :853
+        } else {                                                                               // :857-873
+            sim.DifferentiatePos(vel_diff.data(), 1.0, sim.saved_systems_state_list[t], d);
+            for (int j = 0; j < dof; j++) fbk(j) = vel_diff[mt.StateIndexToQposIndex(j, sv)];
+            for (int j = 0; j < dof; j++) fbk(j + dof) = x(dof + j) - s.X_old[t](dof + j);
+        }
         MatrixXd u(m, 1);
         for (int i = 0; i < m; i++) {
             double fb = 0.0;
-            for (int p = 0; p < n; p++) fb += K[b][t](i, p) * (x(p) - s.X_old[t](p));       // :853,876
+            for (int p = 0; p < n; p++) fb += K[b][t](i, p) * fbk(p);                           // :876
             double v = s.U_old[t](i) + (alpha * k[b][t](i)) + fb;                              // :879
             if (v > ctrl_lim[2 * i + 1]) v = ctrl_lim[2 * i + 1];                              // :883-889
             if (v < ctrl_lim[2 * i]) v = ctrl_lim[2 * i];
@@ -110,7 +119,6 @@ double iLQR_GPU_Batch::ConfirmRollout(int b, double alpha, std::vector<MatrixXd>
         cost += mt.CostFunction(r, sv, t == T - 1);
         U_out[t] = u;
         sim.ForwardSimulator(d);
-        X_out[t + 1] = mt.ReturnStateVector(d, sv);
     }
     return cost;
 }
@@ -180,7 +188,7 @@ std::vector<std::vector<MatrixXd>> iLQR_GPU_Batch::OptimiseAll(const std::vector
     }
     std::vector<double> lam_used(B), pred((size_t)B * alphas.size()), dJ(B);
     std::vector<int> status(B);
-    std::vector<MatrixXd> U_try(T, MatrixXd(m, 1)), X_try(T + 1, MatrixXd(n, 1));
+    std::vector<std::vector<MatrixXd>> U_try(alphas.size(), std::vector<MatrixXd>(T, MatrixXd(m, 1)));
     for (int it = 0; it < max_iterations; it++) {
         std::vector<int> active, regen;
         for (int b = 0; b < B; b++) if (!S[b].done) { active.push_back(b); num_iterations[b]++; if (S[b].cost_reduced_last_iter) regen.push_back(b); }
@@ -229,14 +237,24 @@ std::vector<std::vector<MatrixXd>> iLQR_GPU_Batch::OptimiseAll(const std::vector
                 for (int c = 0; c < n; c++) for (int r = 0; r < m; r++) K[b][t](r, c) = host_K[(((size_t)b * T + t) * n + c) * m + r];
                 for (int r = 0; r < m; r++) k[b][t](r) = host_k[((size_t)b * T + t) * m + r];
             }
-            std::vector<int> order(alphas.size());
-            for (size_t i = 0; i < order.size(); i++) order[i] = (int)i;
-            const double *pb = &pred[(size_t)b * alphas.size()];
-            std::sort(order.begin(), order.end(), [&](int a, int c) { return pb[a] < pb[c]; });
+            const int na = (int)alphas.size();
+            int best = -1;
             s.new_cost = s.old_cost;
-            for (int idx : order) {
-                const double c = ConfirmRollout(b, alphas[idx], U_try, X_try);
-                if (c < s.old_cost) { s.new_cost = c; break; }
+            if (linesearch_mode == 0) {
+                // the reference's line search (:463-503): every alpha rolled out (on this trajectory's FD pool), arg-min
+                std::vector<double> costs(na);
+                P[b].differentiator->pool().parallel_for(na, [&](int i, int tid) { costs[i] = ConfirmRollout(b, tid, alphas[i], U_try[i]); });
+                best = (int)(std::min_element(costs.begin(), costs.end()) - costs.begin());
+                if (costs[best] < s.old_cost) s.new_cost = costs[best];
+            } else {
+                std::vector<int> order(na);
+                for (int i = 0; i < na; i++) order[i] = i;
+                const double *pb = &pred[(size_t)b * na];
+                std::sort(order.begin(), order.end(), [&](int a, int c) { return pb[a] < pb[c]; });
+                for (int idx : order) {
+                    const double c = ConfirmRollout(b, 0, alphas[idx], U_try[idx]);
+                    if (c < s.old_cost) { s.new_cost = c; best = idx; break; }
+                }
             }
             // STEP 4 (:515-528, Optimiser.cpp:30-37)
             const bool converged = ((s.old_cost - s.new_cost) / s.new_cost) < epsConverge;
@@ -247,7 +265,7 @@ std::vector<std::vector<MatrixXd>> iLQR_GPU_Batch::OptimiseAll(const std::vector
                 SimData *d = sim.main_data;
                 sim.CopySystemState(d, sim.saved_systems_state_list[0]);
                 for (int t = 0; t < T; t++) {                                              // UpdateNominal (:936-948)
-                    s.U_old[t] = U_try[t];
+                    s.U_old[t] = U_try[best][t];
                     mt.SetControlVector(s.U_old[t], d, sv);
                     sim.ForwardSimulator(d);
                     mt.Residuals(d, s.residuals[t]);

@@ -41,6 +41,9 @@ public:
     // regularisation / line search constants (include/Optimiser/Optimiser.h:239-242,259,303)
     double max_lambda = 10.0, min_lambda = 0.0001, lambda_factor = 10, epsConverge = 0.02;
     int num_parallel_rollouts = 6;
+    // 0: the reference's line search (all alphas rolled out on the trajectory's FD pool, arg-min, accept iff it beats the
+    // old cost: iLQR.cpp:463-503); 1: GPU-predicted order, first improving candidate (see iLQR_GPU.h)
+    int linesearch_mode = 0;
 
 private:
     struct Traj {
@@ -51,7 +54,7 @@ private:
         std::vector<int> kp_offsets, kp_times;      // per-DoF CSR of the current key-points
     };
     double Rollout(int b, SimData *start, const std::vector<MatrixXd> &controls);
-    double ConfirmRollout(int b, double alpha, std::vector<MatrixXd> &U_out, std::vector<MatrixXd> &X_out);
+    double ConfirmRollout(int b, int tid, double alpha, std::vector<MatrixXd> &U_out);
     void GenerateDerivatives(const std::vector<int> &who);
     void fatal(const char *what, int rc);
 
