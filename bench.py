@@ -149,14 +149,13 @@ def time_config(torch, stream, dev, p, steps, warmup, fused, generic, world=1, d
     eng = Engine(p["dof"], p["m"], T, p["nr"], batch=B, device=dev, stream=stream.cuda_stream, generic=generic,
                  fused=fused and not generic)
     is_fused = "fused" in eng.backward_variant
-    a6 = eng.backward_variant.endswith("_a6")
-    a4a6 = eng.backward_variant.endswith("_a4a6")
+    tail = eng.backward_variant.rsplit("_", 1)[-1] if "tiled_" in eng.backward_variant else ""
+    a4, a6 = "a4" in tail, "a6" in tail          # tiled shapes: which of a4 / a6 run inside the sweeps
     synth.upload(eng, p)
     lam = np.full(B, p["lam"])
     alphas = np.array([(i / 6.0) ** 2 for i in range(1, 7)])
-    stages = ("fd_difference", "backward", "forward") if (is_fused or a4a6) else \
-             ("fd_difference", "interpolate", "backward", "forward") if a6 else \
-             ("fd_difference", "interpolate", "cost_derivs", "backward", "forward")
+    stages = ("fd_difference",) + (() if (is_fused or a4) else ("interpolate",)) + (() if (is_fused or a6) else ("cost_derivs",)) \
+        + ("backward", "forward")
     calls = {"fd_difference": eng.fd_difference, "interpolate": eng.interpolate, "cost_derivs": eng.cost_derivs,
              "backward": lambda: eng.backward(None, 100, fetch=False), "forward": lambda: eng.forward_linear(None, fetch=False)}
     eng.fd_difference()
@@ -207,9 +206,13 @@ def roofline_of(p, p0, r, pmc=None):
     t_bwd = r["stage_ms"]["backward"] * 1e-3
     Kp_steps = float(np.mean([np.count_nonzero(np.diff(o)) for (o, _) in p0["kp_rows"]]))
     ab = algorithmic_bytes(p["dof"], m, nr, T, Kp_steps, 6)
-    inside = r["fused"] or r["variants"]["backward"].endswith("_a4a6")
-    kb = fused_bytes(n, m, nr, T, kp_pairs(p0), 6)["backward"] if inside else \
-        (ab["backward"] - 8 * T * (n * n + n + m * m + m) + 8 * T * nr * (1 + n + m)) if r["variants"]["backward"].endswith("_a6") else ab["backward"]
+    var = r["variants"]["backward"]
+    tail = var.rsplit("_", 1)[-1] if "tiled_" in var else ""
+    a4, a6 = r["fused"] or "a4" in tail, r["fused"] or "a6" in tail
+    pairs = kp_pairs(p0)
+    kb = 8 * T * (m * n + m)                                                        # gains out
+    kb += 8 * (pairs[0] * 2 * n + pairs[1] * n) if a4 else 8 * T * (n * n + n * m)   # A, B: key-point columns or every step
+    kb += 8 * T * nr * (1 + n + m) if a6 else 8 * T * (n * n + n + m * m + m)         # residuals + Jacobians or l_*
     flops = flops_a7(n, m) * T * B
     ach_tf = flops / t_bwd / 1e12
     traffic = None

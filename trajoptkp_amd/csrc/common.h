@@ -66,6 +66,7 @@ struct Ctx {
     bool kp_canonical = false;   // every DoF list strictly increasing, first 0, last T-1 (what the fused sweeps walk)
     bool fused = false;          // KPILQR_FLAG_FUSED and a supported shape
     bool tiled_a6 = false;       // KPILQR_FLAG_FUSED on a tiled shape: the cost derivatives (a6) are formed inside the sweeps
+    bool tiled_a4 = false;       // KPILQR_FLAG_FUSED on a tiled shape: A, B are interpolated (a4) inside the sweeps
 
     // nominal states for on-device key-point placement (kpilqr_upload_states), allocated on first use
     double *X_states = nullptr;   // [batch][T][n]
@@ -189,6 +190,7 @@ hipError_t launch_backward_tiled(Ctx *c, int pd_stride);
 size_t backward_tiled_lds_bytes(int nt);
 bool forward_tiled_supported(int n, int m, int n_alpha, int nt_min);
 hipError_t launch_forward_tiled(Ctx *c, double *U_alpha_dev);
+bool tiled_a4_supported(int n, int m, int dof, int T, int stride);
 // fused_mfma.hip: a4 + a6 evaluated inside the sweeps (n+2 <= 16)
 bool fused_supported(int n, int m, int nr, int dof, int T, int stride, int n_alpha);
 hipError_t launch_backward_fused(Ctx *c, int pd_stride);
