@@ -93,6 +93,10 @@ void kpilqr_destroy(kpilqr_ctx *ctx);
 int  kpilqr_version(void);
 const char *kpilqr_strerror(kpilqr_ctx *ctx);       /* last error text of this context (or global) */
 int  kpilqr_get_dims(kpilqr_ctx *ctx, kpilqr_dims *out);
+/* iLQR_SVR::Resize (src/Optimiser/iLQR_SVR.cpp:38-193): the state-vector reduction changes dof (and possibly num_ctrl,
+ * horizon) between optimisations.  Re-sizes the context IN PLACE: device allocations are kept and only grown when the new
+ * sizes do not fit; kernel families are re-selected; everything uploaded before is forgotten.  Synchronous. */
+int  kpilqr_resize(kpilqr_ctx *ctx, int new_dof, int new_num_ctrl, int new_horizon);
 
 /* Pinned host staging memory (the "one pinned hipMemcpyAsync" of the design). */
 int  kpilqr_host_alloc(kpilqr_ctx *ctx, size_t bytes, void **pinned);
@@ -219,7 +223,7 @@ int  kpilqr_download_gains(kpilqr_ctx *ctx, double *K, double *k);
 /* iLQR_SVR::LeastImportantDofs, "sampling and summing" branch (src/Optimiser/iLQR_SVR.cpp:952-968), on the gains of
  * the last backward pass: sums [batch][dof] = (sum over t = 0, s, 2s, ... and controls j of
  * |K[t](j,i)| + |K[t](j,i+dof)|) / T.  The SVD branch (:902-950) and the state-vector resize it triggers stay on
- * the host (a resize is kpilqr_destroy + kpilqr_create with the new dof). */
+ * the host (host/SVR.h; the resize is kpilqr_resize). */
 int  kpilqr_dof_importance(kpilqr_ctx *ctx, int sampling_k_interval, double *sums);
 
 /* ---- STEP 3: forward pass over the line-search alphas ----------------------------------------

@@ -271,3 +271,16 @@ def linesearch_accept(costs, old_cost, lam, factor=10.0, max_lambda=10.0):
     best = lib().orc_linesearch_accept(len(costs), _c(costs), old_cost, C.byref(nc), C.byref(acc),
                                        C.byref(l), factor, max_lambda)
     return best, nc.value, bool(acc.value), l.value
+
+
+def dof_importance_svd(dof, m, T, sampling, K):
+    """iLQR_SVR::LeastImportantDofs, singular-vector branch (src/Optimiser/iLQR_SVR.cpp:902-925), restated on numpy's
+    SVD (LAPACK) in place of Eigen::JacobiSVD: K [T][n][m] column-major m x n per step.  Parity unpinned."""
+    sums = np.zeros(dof)
+    for t in range(0, T, sampling):
+        Kt = np.asarray(K[t]).T                      # m x n
+        _, S, Vt = np.linalg.svd(Kt, full_matrices=True)
+        V = Vt.T
+        for mm in range(min(3, m)):
+            sums += np.abs(V[:dof, mm] * S[mm]) + np.abs(V[dof:2 * dof, mm] * S[mm])
+    return sums / T

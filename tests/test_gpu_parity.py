@@ -892,3 +892,52 @@ def test_fd_indices_are_checked_on_the_device():
         if field in ("job_b", "job_t"):
             mask[b_bad, t_bad:min(t_bad + 1, 40)] = False
         assert np.array_equal(A[mask], A0[mask]) and np.array_equal(B[mask], B0[mask]), field
+
+
+# ---- f3: iLQR_SVR's variable state vector: kpilqr_resize re-uses the context (src/Optimiser/iLQR_SVR.cpp:38-193) -------------
+def test_resize_in_place_reuses_allocations_and_matches_fresh_contexts():
+    """Shrink the state vector, grow it back, change the control count and the horizon: after every kpilqr_resize the
+    context gives the bytes of a freshly created one, and as long as the new sizes fit the device buffers stay put."""
+    from trajoptkp_amd import _lib
+    import ctypes as C
+    shapes = [("panda_reaching", 200), ("pentabot", 150), ("panda_reaching", 200), ("acrobot", 100), ("panda_pushing", 120), ("hopper", 260)]
+
+    def run(e, p):
+        synth.upload(e, p)
+        e.iterate(p["lam"], 100, orc.alphas(6))
+        res = e.results()
+        return e.gains() + (res["cost_pred"], res["delta_J"], res["status"])
+
+    def ptr(e, which):
+        q, sz = C.c_void_p(), C.c_size_t()
+        e._ck(e._L.kpilqr_device_ptr(e._h, which, C.byref(q), C.byref(sz)))
+        return q.value, sz.value
+
+    for fused in (True, False):
+        first = synth.make_problem(task=shapes[0][0], T=shapes[0][1], batch=2, min_N=5, dense_residuals=True)
+        with Engine(first["dof"], first["m"], first["T"], first["nr"], batch=2, fused=fused) as e:
+            base_ptrs = None
+            for task, T in shapes:
+                p = synth.make_problem(task=task, T=T, batch=2, min_N=5, dense_residuals=True)
+                if p["nr"] != first["nr"]:
+                    p["nr"] = first["nr"]                         # the residual list does not change in a resize: pad it
+                    pad = lambda a, ax: np.concatenate([a, np.zeros(a.shape[:ax] + (first["nr"] - a.shape[ax],) + a.shape[ax + 1:])], axis=ax)
+                    p["r"] = pad(p["r"], 2); p["r_x"] = pad(p["r_x"], 2); p["r_u"] = pad(p["r_u"], 2)
+                    p["w_run"] = pad(p["w_run"], 0); p["w_term"] = pad(p["w_term"], 0)
+                e.resize(p["dof"], p["m"], p["T"])
+                got = run(e, p)
+                with Engine(p["dof"], p["m"], p["T"], p["nr"], batch=2, fused=fused) as f:
+                    want = run(f, p)
+                    assert e.backward_variant == f.backward_variant and e.forward_variant == f.forward_variant
+                for a, b in zip(got, want):
+                    assert np.array_equal(a, b), (task, fused)
+                ptrs = [ptr(e, w)[0] for w in (_lib.BUF_STEP_RECORDS, _lib.BUF_K, _lib.BUF_R_X)]
+                if task == "panda_reaching":
+                    base_ptrs = base_ptrs or ptrs
+                    assert ptrs == base_ptrs                      # back at the first shape: same allocations
+                elif task in ("pentabot", "acrobot"):
+                    assert ptrs == base_ptrs                      # smaller shapes live in the first shape's buffers
+            with pytest.raises(Exception):
+                e.resize(0, 1, 10)
+            e.resize(first["dof"], first["m"], first["T"])      # still usable after a refused resize
+            assert np.array_equal(run(e, first)[0], run(e, first)[0])

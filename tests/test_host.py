@@ -327,3 +327,18 @@ def test_free_joint_model_optimises_and_pruned_line_search_is_an_option():
     for row in pr["trace"]:
         tried = row["rollout_costs"][~np.isnan(row["rollout_costs"])]
         assert len(tried) >= 1 and (not row["accepted"] or row["new_cost"] == tried.min() or row["new_cost"] in tried)
+
+
+# ---- f3: iLQR_SVR's DoF importance (both branches) on the host ---------------------------------------------------------------
+@pytest.mark.parametrize("dof,m,T,s", [(7, 7, 60, 1), (10, 7, 45, 4), (6, 3, 30, 2), (2, 1, 20, 1)])
+def test_svr_dof_importance_host_both_branches(dof, m, T, s):
+    rng = np.random.default_rng(dof * 100 + m)
+    K = rng.standard_normal((T, 2 * dof, m)) * np.exp(rng.uniform(-3, 2, (1, 2 * dof, 1)))     # very different column scales
+    sums, rem = host.dof_importance(K, dof, s, svd=False, threshold=0.0)
+    assert np.array_equal(sums, orc.dof_importance(dof, m, T, s, K))
+    ref = orc.dof_importance_svd(dof, m, T, s, K)
+    got, _ = host.dof_importance(K, dof, s, svd=True)
+    assert np.max(np.abs(got - ref)) <= 1e-10 * np.max(np.abs(ref)), np.max(np.abs(got - ref))
+    thr = float(np.median(ref))
+    _, rem = host.dof_importance(K, dof, s, svd=True, threshold=thr)
+    assert list(rem) == [i for i in range(dof) if got[i] < thr]

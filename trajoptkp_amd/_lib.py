@@ -24,7 +24,7 @@ SYMBOLS = [
     "kpilqr_upload_states", "kpilqr_generate_keypoints", "kpilqr_get_keypoints",
     "kpilqr_filter_dynamics", "kpilqr_dof_importance",
     "kpilqr_comm_unique_id", "kpilqr_comm_init", "kpilqr_allreduce_linesearch",
-    "kpilqr_fd_slab_layout", "kpilqr_upload_fd_slab", "kpilqr_iterate_streamed",
+    "kpilqr_fd_slab_layout", "kpilqr_upload_fd_slab", "kpilqr_iterate_streamed", "kpilqr_resize",
 ]
 
 
@@ -120,6 +120,7 @@ def load():
     L.kpilqr_fd_slab_layout.argtypes = [vp, C.c_int, C.c_int, C.c_int, C.POINTER(FdLayout)]
     L.kpilqr_upload_fd_slab.argtypes = [vp, vp, C.c_int, C.c_int, C.c_int, C.c_double]
     L.kpilqr_iterate_streamed.argtypes = [vp, C.POINTER(StreamIO), C.c_int, C.c_int]
+    L.kpilqr_resize.argtypes = [vp, C.c_int, C.c_int, C.c_int]
     for s in SYMBOLS:
         getattr(L, s)          # raises AttributeError if the .so lacks a declared symbol
     _lib = L

@@ -42,7 +42,8 @@ struct Ctx {
     bool own_stream = false;
     std::string err;
 
-    // device buffers
+    // device buffers (cap[]: allocated bytes of the dimension-dependent ones, kpilqr_resize re-uses them)
+    size_t cap[18] = {0};
     double *rec = nullptr;        // [batch][T][stride]
     double *K = nullptr;          // [batch][T][n*m]
     double *k = nullptr;          // [batch][T][m]

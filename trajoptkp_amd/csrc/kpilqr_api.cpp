@@ -89,6 +89,98 @@ Ctx::Tuning read_tuning_from_env()
 }
 }  // namespace kpilqr
 
+// (Re)sizes every dimension-dependent device buffer of the context for c->d: a buffer is re-allocated only when it has to
+// GROW (capacities are remembered), so shrinking the state vector and growing it back -- what iLQR_SVR does between
+// optimisations -- re-uses the allocations.  Records, gains, residual and nominal-control buffers are zeroed.
+static int size_buffers(kpilqr_ctx *c)
+{
+    const kpilqr_dims *dims = &c->d;
+    c->n = 2 * dims->dof;
+    c->L = RecLayout(c->n, dims->m);
+    const size_t B = dims->batch, T = dims->T, n = c->n, m = dims->m, nr = dims->nr;
+    struct Want { void **p; size_t bytes; size_t *cap; bool zero; };
+    const Want want[] = {
+        {(void **)&c->rec, B * T * c->L.stride * 8, &c->cap[0], true},
+        {(void **)&c->K, B * T * n * m * 8, &c->cap[1], true},
+        {(void **)&c->k, B * T * m * 8, &c->cap[2], true},
+        {(void **)&c->r, B * (T + 1) * nr * 8, &c->cap[3], true},
+        {(void **)&c->r_x, B * (T + 1) * nr * n * 8, &c->cap[4], true},
+        {(void **)&c->r_u, B * (T + 1) * nr * m * 8, &c->cap[5], true},
+        {(void **)&c->w_run, nr * 8, &c->cap[6], false},
+        {(void **)&c->w_term, nr * 8, &c->cap[7], false},
+        {(void **)&c->u_nom, B * T * m * 8, &c->cap[8], true},
+        {(void **)&c->ctrl_lim, 2 * m * 8, &c->cap[9], false},
+        {(void **)&c->lambda, B * 8, &c->cap[10], false},
+        {(void **)&c->alphas, (size_t)dims->n_alpha * 8, &c->cap[11], false},
+        {(void **)&c->cost_pred, B * dims->n_alpha * 8, &c->cap[12], false},
+        {(void **)&c->delta_J, B * 8, &c->cap[13], false},
+        {(void **)&c->traj_cost, B * 8, &c->cap[14], false},
+        {(void **)&c->status, B * 4, &c->cap[15], true},
+        {(void **)&c->segmap, B * dims->dof * T * sizeof(int2), &c->cap[16], false},
+        {(void **)&c->kp_offsets, (B * dims->dof + 1) * 4, &c->cap[17], false},
+    };
+    for (const Want &w : want) {
+        if (w.bytes > *w.cap) {
+            if (*w.p) KP_HIP(c, hipFree(*w.p));
+            *w.p = nullptr; *w.cap = 0;
+            hipError_t e = hipMalloc(w.p, w.bytes ? w.bytes : 8);
+            if (e != hipSuccess) { c->err = std::string("hipMalloc failed: ") + hipGetErrorString(e); return KPILQR_ERR_ALLOC; }
+            *w.cap = w.bytes;
+        }
+        // records start zeroed so that padding / never-written columns are defined
+        if (w.zero) KP_HIP(c, hipMemsetAsync(*w.p, 0, w.bytes, c->stream));
+    }
+    c->rec_fd_base = c->rec;
+    c->fd_batch_total = dims->batch;
+    return KPILQR_OK;
+}
+
+// kernel families for c->d (names: kpilqr_backward_variant)
+static int select_variants(kpilqr_ctx *c)
+{
+    const kpilqr_dims *dims = &c->d;
+    c->fused = c->tiled_a4 = c->tiled_a6 = false;
+    const bool generic = (dims->flags & KPILQR_FLAG_GENERIC_KERNELS) != 0;
+    const bool force_tiled = (dims->flags & KPILQR_FLAG_TILED_KERNELS) != 0;
+    c->bwd_variant = (!generic && !force_tiled && backward_mfma_supported(c->n, dims->m)) ? "mfma_f64_t1"
+                   : (!generic && backward_tiled_supported(c->n, dims->m, c->tune.tiled_nt_min)) ? "mfma_f64_tiled" : "generic_lds";
+    c->fwd_variant = (!generic && !force_tiled && forward_mfma_supported(c->n, dims->m, dims->n_alpha)) ? "mfma_f64_t1"
+                   : (!generic && forward_tiled_supported(c->n, dims->m, dims->n_alpha, c->tune.tiled_nt_min)) ? "mfma_f64_tiled" : "generic_lds";
+    if ((dims->flags & KPILQR_FLAG_FUSED) && !generic && !force_tiled &&
+        fused_supported(c->n, dims->m, dims->nr, dims->dof, dims->T, c->L.stride, dims->n_alpha)) {
+        c->fused = true;
+        c->bwd_variant = c->fwd_variant = "mfma_f64_t1_fused";
+    }
+    // The same flag on a tiled shape (n + 2 > 16): parts of the fusion the tiled sweeps offer.
+    //  a4 (variant "..._a4"): A, B interpolated in registers from the key-point columns (tracker.h) -- k_interpolate and the
+    //     per-step reads of A, B disappear; needs canonical key-points like the one-tile fused sweeps.  Built, parity-green,
+    //     and NOT the default: a lone wave per SIMD is bound by instruction issue, and the per-lane list walk (4 NT + 4
+    //     values per lane: selects, un-contracted multiply-adds, loads, AGPR traffic for the tracker state) costs more than
+    //     the k_interpolate it removes (n = 62, T = 5000, B = 128, 26 % ragged key-points: interpolate 11.1 ms saved,
+    //     backward +11.8 ms, forward +10.4 ms; pushing n = 20, B = 64: 0.27 ms saved, +3.7 and +2.6 ms; DESIGN.md 4.4).
+    //     KPILQR_TILED_A4 = 1 turns it on.
+    //  a6 (variant "..._a6"): cost derivatives formed from the residuals inside the sweeps.  It replaces k_cost_derivs
+    //     (HBM-bound: n^2 doubles written per step) by NT*ceil(nr/4) + 6 MFMAs per wave-step of the latency-bound backward
+    //     sweep (+9 % at four tiles, whatever the batch): a gain from ~100 trajectories of a four-tile state up (n = 62,
+    //     B = 128, T = 5000: 74.4 -> 70.6 ms), a loss for two or three tiles at the batches measured.  KPILQR_TILED_A6 = 0 | 1.
+    if ((dims->flags & KPILQR_FLAG_FUSED) && !c->fused &&
+        strcmp(c->bwd_variant, "mfma_f64_tiled") == 0 && strcmp(c->fwd_variant, "mfma_f64_tiled") == 0) {
+        const bool can_a4 = tiled_a4_supported(c->n, dims->m, dims->dof, dims->T, c->L.stride);
+        const bool want_a4 = can_a4 && c->tune.tiled_a4 == 1;
+        const bool want_a6 = dims->nr <= 16 && (c->tune.tiled_a6 >= 0 ? c->tune.tiled_a6 != 0
+                                                : (tiled_tiles(c->n, c->tune.tiled_nt_min) == 4 && dims->batch >= 96));
+        c->tiled_a4 = want_a4; c->tiled_a6 = want_a6;
+        if (want_a4 && want_a6) c->bwd_variant = c->fwd_variant = "mfma_f64_tiled_a4a6";
+        else if (want_a4) c->bwd_variant = c->fwd_variant = "mfma_f64_tiled_a4";
+        else if (want_a6) c->bwd_variant = c->fwd_variant = "mfma_f64_tiled_a6";
+    }
+    if (strcmp(c->bwd_variant, "generic_lds") == 0 && backward_generic_lds_bytes(c->n, dims->m) > 160 * 1024) {
+        c->err = "state dimension too large for the generic backward kernel (LDS)";
+        return KPILQR_ERR_ARG;
+    }
+    return KPILQR_OK;
+}
+
 extern "C" {
 
 int kpilqr_version(void) { return KPILQR_VERSION; }
@@ -132,27 +224,12 @@ int kpilqr_create(const kpilqr_dims *dims, void *stream, kpilqr_ctx **out)
         c->own_stream = true;
     }
 
-    const size_t B = dims->batch, T = dims->T, n = c->n, m = dims->m, nr = dims->nr;
+    {
+        const int rcs = size_buffers(c);
+        if (rcs != KPILQR_OK) { const std::string msg = c->err; kpilqr_destroy(c); return set_err(nullptr, rcs, msg); }
+    }
     hipError_t rc = hipSuccess;
 #define TRY(x) do { if (rc == hipSuccess) rc = (x); } while (0)
-    TRY(dalloc(&c->rec, B * T * c->L.stride));
-    TRY(dalloc(&c->K, B * T * n * m));
-    TRY(dalloc(&c->k, B * T * m));
-    TRY(dalloc(&c->r, B * (T + 1) * nr));
-    TRY(dalloc(&c->r_x, B * (T + 1) * nr * n));
-    TRY(dalloc(&c->r_u, B * (T + 1) * nr * m));
-    TRY(dalloc(&c->w_run, nr));
-    TRY(dalloc(&c->w_term, nr));
-    TRY(dalloc(&c->u_nom, B * T * m));
-    TRY(dalloc(&c->ctrl_lim, 2 * m));
-    TRY(dalloc(&c->lambda, B));
-    TRY(dalloc(&c->alphas, (size_t)dims->n_alpha));
-    TRY(dalloc(&c->cost_pred, B * dims->n_alpha));
-    TRY(dalloc(&c->delta_J, B));
-    TRY(dalloc(&c->traj_cost, B));
-    TRY(dalloc(&c->status, B));
-    TRY(dalloc(&c->segmap, B * dims->dof * T));
-    TRY(dalloc(&c->kp_offsets, B * dims->dof + 1));
     TRY(dalloc(&c->nslots_dev, 1));
     TRY(dalloc(&c->err_flag, 1));
     TRY(hipHostMalloc((void **)&c->err_flag_host, sizeof(int), hipHostMallocDefault));
@@ -162,57 +239,11 @@ int kpilqr_create(const kpilqr_dims *dims, void *stream, kpilqr_ctx **out)
         kpilqr_destroy(c);
         return set_err(nullptr, KPILQR_ERR_ALLOC, msg);
     }
-    // records start zeroed so that padding / never-written columns are defined
-    (void)hipMemsetAsync(c->rec, 0, B * T * c->L.stride * sizeof(double), c->stream);
-    (void)hipMemsetAsync(c->K, 0, B * T * n * m * sizeof(double), c->stream);
-    (void)hipMemsetAsync(c->k, 0, B * T * m * sizeof(double), c->stream);
-    (void)hipMemsetAsync(c->r, 0, B * (T + 1) * nr * sizeof(double), c->stream);
-    (void)hipMemsetAsync(c->r_x, 0, B * (T + 1) * nr * n * sizeof(double), c->stream);
-    (void)hipMemsetAsync(c->r_u, 0, B * (T + 1) * nr * m * sizeof(double), c->stream);
-    (void)hipMemsetAsync(c->u_nom, 0, B * T * m * sizeof(double), c->stream);
-    (void)hipMemsetAsync(c->status, 0, B * sizeof(int), c->stream);
     (void)hipMemsetAsync(c->err_flag, 0, sizeof(int), c->stream);
     (void)hipMemsetAsync(c->nslots_dev, 0, sizeof(int), c->stream);
-    c->rec_fd_base = c->rec;
-    c->fd_batch_total = dims->batch;
-
-    const bool generic = (dims->flags & KPILQR_FLAG_GENERIC_KERNELS) != 0;
-    const bool force_tiled = (dims->flags & KPILQR_FLAG_TILED_KERNELS) != 0;
-    c->bwd_variant = (!generic && !force_tiled && backward_mfma_supported(c->n, dims->m)) ? "mfma_f64_t1"
-                   : (!generic && backward_tiled_supported(c->n, dims->m, c->tune.tiled_nt_min)) ? "mfma_f64_tiled" : "generic_lds";
-    c->fwd_variant = (!generic && !force_tiled && forward_mfma_supported(c->n, dims->m, dims->n_alpha)) ? "mfma_f64_t1"
-                   : (!generic && forward_tiled_supported(c->n, dims->m, dims->n_alpha, c->tune.tiled_nt_min)) ? "mfma_f64_tiled" : "generic_lds";
-    if ((dims->flags & KPILQR_FLAG_FUSED) && !generic && !force_tiled &&
-        fused_supported(c->n, dims->m, dims->nr, dims->dof, dims->T, c->L.stride, dims->n_alpha)) {
-        c->fused = true;
-        c->bwd_variant = c->fwd_variant = "mfma_f64_t1_fused";
-    }
-    // The same flag on a tiled shape (n + 2 > 16): parts of the fusion the tiled sweeps offer.
-    //  a4 (variant "..._a4"): A, B interpolated in registers from the key-point columns (tracker.h) -- k_interpolate and the
-    //     per-step reads of A, B disappear; needs canonical key-points like the one-tile fused sweeps.  Built, parity-green,
-    //     and NOT the default: a lone wave per SIMD is bound by instruction issue, and the per-lane list walk (4 NT + 4
-    //     values per lane: selects, un-contracted multiply-adds, loads, AGPR traffic for the tracker state) costs more than
-    //     the k_interpolate it removes (n = 62, T = 5000, B = 128, 26 % ragged key-points: interpolate 11.1 ms saved,
-    //     backward +11.8 ms, forward +10.4 ms; pushing n = 20, B = 64: 0.27 ms saved, +3.7 and +2.6 ms; DESIGN.md 4.4).
-    //     KPILQR_TILED_A4 = 1 turns it on.
-    //  a6 (variant "..._a6"): cost derivatives formed from the residuals inside the sweeps.  It replaces k_cost_derivs
-    //     (HBM-bound: n^2 doubles written per step) by NT*ceil(nr/4) + 6 MFMAs per wave-step of the latency-bound backward
-    //     sweep (+9 % at four tiles, whatever the batch): a gain from ~100 trajectories of a four-tile state up (n = 62,
-    //     B = 128, T = 5000: 74.4 -> 70.6 ms), a loss for two or three tiles at the batches measured.  KPILQR_TILED_A6 = 0 | 1.
-    if ((dims->flags & KPILQR_FLAG_FUSED) && !c->fused &&
-        strcmp(c->bwd_variant, "mfma_f64_tiled") == 0 && strcmp(c->fwd_variant, "mfma_f64_tiled") == 0) {
-        const bool can_a4 = tiled_a4_supported(c->n, dims->m, dims->dof, dims->T, c->L.stride);
-        const bool want_a4 = can_a4 && c->tune.tiled_a4 == 1;
-        const bool want_a6 = dims->nr <= 16 && (c->tune.tiled_a6 >= 0 ? c->tune.tiled_a6 != 0
-                                                : (tiled_tiles(c->n, c->tune.tiled_nt_min) == 4 && dims->batch >= 96));
-        c->tiled_a4 = want_a4; c->tiled_a6 = want_a6;
-        if (want_a4 && want_a6) c->bwd_variant = c->fwd_variant = "mfma_f64_tiled_a4a6";
-        else if (want_a4) c->bwd_variant = c->fwd_variant = "mfma_f64_tiled_a4";
-        else if (want_a6) c->bwd_variant = c->fwd_variant = "mfma_f64_tiled_a6";
-    }
-    if (strcmp(c->bwd_variant, "generic_lds") == 0 && backward_generic_lds_bytes(c->n, dims->m) > 160 * 1024) {
-        kpilqr_destroy(c);
-        return set_err(nullptr, KPILQR_ERR_ARG, "state dimension too large for the generic backward kernel (LDS)");
+    {
+        const int rcv = select_variants(c);
+        if (rcv != KPILQR_OK) { const std::string msg = c->err; kpilqr_destroy(c); return set_err(nullptr, rcv, msg); }
     }
     *out = c;
     return KPILQR_OK;
@@ -245,6 +276,36 @@ int kpilqr_get_dims(kpilqr_ctx *c, kpilqr_dims *out)
 {
     if (!c || !out) return KPILQR_ERR_ARG;
     *out = c->d;
+    return KPILQR_OK;
+}
+
+// iLQR_SVR::Resize (src/Optimiser/iLQR_SVR.cpp:38-193): the optimiser changes the size of its state vector between
+// optimisations.  Re-sizes the context in place; everything uploaded before (key-points, FD payload, residuals, nominal
+// controls, weights, limits, alphas, lambda) is forgotten, the kernel families are re-selected.
+int kpilqr_resize(kpilqr_ctx *c, int new_dof, int new_num_ctrl, int new_horizon)
+{
+    if (!c) return KPILQR_ERR_ARG;
+    KP_ENTER(c);
+    if (new_dof < 1 || new_num_ctrl < 1 || new_horizon < 2) return set_err(c, KPILQR_ERR_ARG, "dims out of range");
+    if (fd_difference_waves(2 * new_dof, new_num_ctrl) < 1)
+        return set_err(c, KPILQR_ERR_ARG, "state/control dimensions too large: one key-point's FD columns ((n+m)(n+1) doubles) exceed the CU's 160 KB of LDS");
+    KP_HIP(c, hipStreamSynchronize(c->stream));          // nothing in flight still uses the old layout
+    const kpilqr_dims old = c->d;
+    c->d.dof = new_dof; c->d.m = new_num_ctrl; c->d.T = new_horizon;
+    int rc = size_buffers(c);
+    if (rc == KPILQR_OK) rc = select_variants(c);
+    if (rc != KPILQR_OK) {                              // leave a usable context behind
+        const std::string msg = c->err;
+        c->d = old;
+        (void)size_buffers(c); (void)select_variants(c);
+        return set_err(c, rc, msg);
+    }
+    c->have_kp = c->kp_canonical = c->have_states = false;
+    c->njobs = c->nnom = c->nslots = 0;
+    if (c->X_states) { KP_HIP(c, hipFree(c->X_states)); c->X_states = nullptr; }
+    if (c->kp_mask) { KP_HIP(c, hipFree(c->kp_mask)); c->kp_mask = nullptr; }
+    if (c->kp_count) { KP_HIP(c, hipFree(c->kp_count)); c->kp_count = nullptr; }
+    if (c->kp_thr) { KP_HIP(c, hipFree(c->kp_thr)); c->kp_thr = nullptr; }
     return KPILQR_OK;
 }
 

@@ -84,6 +84,12 @@ class Engine:
         self._ck(self._L.kpilqr_sync(self._h))
         self._keep.clear()
 
+    def resize(self, dof, m, T):
+        """kpilqr_resize (iLQR_SVR::Resize): new state / control / horizon sizes in place, allocations re-used."""
+        self._ck(self._L.kpilqr_resize(self._h, int(dof), int(m), int(T)))
+        self.dof, self.n, self.m, self.T = int(dof), 2 * int(dof), int(m), int(T)
+        self._keep.clear()
+
     @property
     def backward_variant(self):
         return self._L.kpilqr_backward_variant(self._h).decode()

@@ -39,6 +39,7 @@ def load_host():
     H.kpilqr_host_task_file.argtypes = [C.c_char_p, C.c_int, C.c_int, C.c_int, vp, vp]
     H.kpilqr_host_save_summary.argtypes = [C.c_char_p, C.c_int, C.c_int, vp, vp]
     H.kpilqr_host_run_acrobot_batch.argtypes = [C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_double, vp, C.c_int, vp, C.c_int, vp, vp, vp]
+    H.kpilqr_host_dof_importance.argtypes = [vp, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_double, vp, vp]
     H.kpilqr_host_model_info.argtypes = [C.c_char_p, vp, vp, vp]
     H.kpilqr_host_model_op.argtypes = [C.c_char_p, C.c_int, vp, vp, vp, vp, C.c_double, C.c_int, vp, vp]
     H.kpilqr_host_model_fd.argtypes = [C.c_char_p, vp, vp, vp, C.c_int, vp, C.c_int, C.c_double, vp, vp, vp, vp, vp, vp, vp]
@@ -211,3 +212,13 @@ def optimise(model, T=100, max_iter=8, min_iter=2, options="", u_init=None):
         d["rollout_costs"] = w[12:12 + na].copy(); d["predicted"] = w[18:18 + na].copy()
         rows.append(d)
     return dict(iterations=it, cost_history=hist[~np.isnan(hist)], U=U, trace=rows)
+
+
+def dof_importance(K, dof, sampling_k_interval=1, svd=False, threshold=0.0):
+    """iLQR_SVR::LeastImportantDofs on gains K [T][n][m] (the ABI's layout): (sums [dof], indices below the threshold)."""
+    H = load_host()
+    Kc = np.ascontiguousarray(K, np.float64)
+    T, n, m = Kc.shape
+    sums = np.zeros(dof); rem = np.zeros(dof, np.int32)
+    cnt = H.kpilqr_host_dof_importance(_p(Kc), dof, m, T, int(sampling_k_interval), int(svd), float(threshold), _p(sums), _p(rem))
+    return sums, rem[:cnt].copy()

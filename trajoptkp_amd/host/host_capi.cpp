@@ -9,6 +9,7 @@
 #include "AcrobotModel.h"
 #include "FloatingBodyModel.h"
 #include "FileHandler.h"
+#include "SVR.h"
 #include "iLQR_GPU.h"
 #include "iLQR_GPU_Batch.h"
 
@@ -114,6 +115,21 @@ int kpilqr_host_run_acrobot_batch(int B, int T, int min_N, int max_iter, int min
     }
     if (stats) for (int i = 0; i < 8; i++) stats[i] = opt.linesearch_stats[i];
     return 0;
+}
+
+// iLQR_SVR::LeastImportantDofs on gains K [T][n][m] (column-major m x n per step, the ABI's host layout): sums [dof];
+// remove [dof] receives the indices below the threshold, their number is returned.
+int kpilqr_host_dof_importance(const double *K, int dof, int m, int T, int sampling_k_interval, int eigen_vector_method,
+                               double threshold, double *sums, int *remove)
+{
+    const int n = 2 * dof;
+    std::vector<MatrixXd> Km(T, MatrixXd(m, n));
+    for (int t = 0; t < T; t++) std::memcpy(Km[t].data(), K + (size_t)t * n * m, sizeof(double) * n * m);
+    const std::vector<double> s = DofImportance(Km, dof, sampling_k_interval, eigen_vector_method != 0);
+    for (int i = 0; i < dof; i++) sums[i] = s[i];
+    const std::vector<int> r = LeastImportantDofs(s, threshold);
+    for (size_t i = 0; i < r.size(); i++) remove[i] = r[i];
+    return (int)r.size();
 }
 
 // ---- stand-in models by name, for the oracle tests of the host finite differences (a1, a5) and of the control flow (a9) ----
