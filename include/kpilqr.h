@@ -118,9 +118,17 @@ int  kpilqr_upload_states(kpilqr_ctx *ctx, const double *X);
  * "set_interval" (:319-339), "adaptive_jerk" (:730-770 + :341-382) or "velocity_change" (:797-808 + :642-728)
  * on every trajectory; the lists become the context's key-points exactly as if given to
  * kpilqr_set_keypoints.  thresholds [dof] (jerk or velocity-change thresholds; NULL for set_interval), dt =
- * model time-step.  "iterative_error" interleaves host finite differences and stays on the host. */
+ * model time-step.  "iterative_error" interleaves host finite differences: its placement loop stays on the host and calls
+ * kpilqr_keypoint_error_test per bisection level. */
 int  kpilqr_generate_keypoints(kpilqr_ctx *ctx, const char *method, int min_N, int max_N,
                                const double *thresholds, double dt);
+/* The error test of "iterative_error" for one bisection level of the whole batch (KeypointGenerator::CheckDOFColumnError,
+ * src/KeyPointGenerator/KeyPointGenerator.cpp:550-640): intervals [n][4] = trajectory, DoF, start, end.  The host
+ * differences the DoF's columns at start, (start+end)/2 and end of every pending interval (kpilqr_upload_fd +
+ * kpilqr_fd_difference put them into the step records), this call says which intervals are good (1: keep, 0: split at the
+ * midpoint), the host bisects the others -- placement stays a host loop because it interleaves the simulator
+ * (GenerateKeyPointsIteratively :449-548), the arithmetic of a level runs here.  Synchronous. */
+int  kpilqr_keypoint_error_test(kpilqr_ctx *ctx, int n, const int *intervals, int min_N, double threshold, unsigned char *good);
 /* Reads the current per-DoF lists back (the host FD loop needs them): kp_offsets [batch*dof+1]; kp_times may be
  * NULL to query the size.  Returns the total number of entries (>= 0) or an error (< 0).  Synchronous. */
 int  kpilqr_get_keypoints(kpilqr_ctx *ctx, int *kp_offsets, int *kp_times, int times_capacity);

@@ -941,3 +941,47 @@ def test_resize_in_place_reuses_allocations_and_matches_fresh_contexts():
                 e.resize(0, 1, 10)
             e.resize(first["dof"], first["m"], first["T"])      # still usable after a refused resize
             assert np.array_equal(run(e, first)[0], run(e, first)[0])
+
+
+# ---- f2: the error test of iterative_error on the device (KeyPointGenerator.cpp:550-640) ------------------------------------
+@pytest.mark.parametrize("task,T,min_N,thr", [("panda_reaching", 400, 1, 3e-10), ("panda_reaching", 257, 5, 1e-9), ("high_dof_push", 300, 2, 1e-10)])
+def test_iterative_error_bisection_with_the_device_error_test(task, T, min_N, thr):
+    """GenerateKeyPointsIteratively (:449-548) driven level by level for a whole batch, the arithmetic of every level
+    (CheckDOFColumnError) done by kpilqr_keypoint_error_test on the columns in the step records: the key-point sets are
+    the oracle's (which bisects depth-first on the same dense A sequence), decision for decision."""
+    cfg = synth.TASKS[task]
+    dof, m, B = cfg["dof"], cfg["m"], 2
+    n = 2 * dof
+    dyn = [synth.dynamics_dense_smooth(np.random.default_rng(40 + b), dof, m, cfg["dt"], T) for b in range(B)]
+    A = np.stack([d[0] for d in dyn]); Bm = np.stack([d[1] for d in dyn])
+    with Engine(dof, m, T, cfg["nr"], batch=B) as e:
+        e.set_AB(A, Bm)                       # every column "differenced": the host FD of a level is not what is tested here
+        computed = set()
+        pending = [(b, i, 0, T - 1) for b in range(B) for i in range(dof)]
+        levels = 0
+        while pending:
+            levels += 1
+            iv = np.asarray(pending, np.int32)
+            good = e.keypoint_error_test(iv, min_N, thr)
+            nxt = []
+            for (b, i, s, en), g in zip(pending, good):
+                if en - s <= min_N:
+                    assert g
+                    continue
+                mid = (s + en) // 2
+                computed.update([(b, i, s), (b, i, mid), (b, i, en)])
+                if not g:
+                    nxt += [(b, i, s, mid), (b, i, mid, en)]
+            pending = nxt
+        assert levels > 3
+        from trajoptkp_amd.engine import KpilqrError
+        with pytest.raises(KpilqrError):
+            e.keypoint_error_test([[0, dof, 0, 5]], min_N, thr)
+    for b in range(B):
+        offs, cols = orc.kp_iterative_error(dof, T, min_N, thr, A[b])
+        want = {(b, int(i), t) for t in range(T) for i in cols[offs[t]:offs[t + 1]]}
+        got = {x for x in computed if x[0] == b}
+        # the reference's generator adds full rows 0 and T-1 whatever the bisection found
+        got |= {(b, i, 0) for i in range(dof)} | {(b, i, T - 1) for i in range(dof)}
+        assert got == want, (task, b, len(got), len(want))
+        assert 2 * dof < len(want) < T * dof

@@ -25,6 +25,7 @@ SYMBOLS = [
     "kpilqr_filter_dynamics", "kpilqr_dof_importance",
     "kpilqr_comm_unique_id", "kpilqr_comm_init", "kpilqr_allreduce_linesearch",
     "kpilqr_fd_slab_layout", "kpilqr_upload_fd_slab", "kpilqr_iterate_streamed", "kpilqr_resize",
+    "kpilqr_keypoint_error_test",
 ]
 
 
@@ -121,6 +122,7 @@ def load():
     L.kpilqr_upload_fd_slab.argtypes = [vp, vp, C.c_int, C.c_int, C.c_int, C.c_double]
     L.kpilqr_iterate_streamed.argtypes = [vp, C.POINTER(StreamIO), C.c_int, C.c_int]
     L.kpilqr_resize.argtypes = [vp, C.c_int, C.c_int, C.c_int]
+    L.kpilqr_keypoint_error_test.argtypes = [vp, C.c_int, vp, C.c_int, C.c_double, vp]
     for s in SYMBOLS:
         getattr(L, s)          # raises AttributeError if the .so lacks a declared symbol
     _lib = L

@@ -162,6 +162,7 @@ hipError_t launch_pack_linesearch(Ctx *c, double *dev8);
 // keypoints.hip
 hipError_t launch_generate_keypoints(Ctx *c, int method, int min_N, int max_N, double dt, const double *thr_dev,
                                      const double *X_dev, unsigned long long *mask_dev, int *count_dev);
+hipError_t launch_kp_error_test(Ctx *c, int n_iv, const int *iv_dev, int min_N, double threshold, unsigned char *good_dev);
 hipError_t launch_interpolate(Ctx *c);
 hipError_t launch_filter_dynamics(Ctx *c, int method, const double *coefs_dev, int ncoef);
 hipError_t launch_dof_importance(Ctx *c, int sampling, double *sums_dev);

@@ -150,4 +150,46 @@ hipError_t launch_generate_keypoints(Ctx *c, int method, int min_N, int max_N, d
     return hipGetLastError();
 }
 
+// ---- iterative_error: the error test of one bisection level, for the whole batch -------------------------------------------
+// KeypointGenerator::CheckDOFColumnError (src/KeyPointGenerator/KeyPointGenerator.cpp:550-640): an interval [s, e] of DoF i
+// is good when it is no longer than min_N (:562-564) or when the mean, over the velocity rows of the DoF's two A columns,
+// of the squared difference between the column at the midpoint and the mean of the columns at the ends stays below the
+// threshold (:608-639).  The three key-point columns are read from the step records (the host differenced them at
+// s, (s+e)/2 and e and k_fd_difference wrote them).  One thread per interval, the reference's summation order (compiled
+// without contraction): decisions are bit-identical with the oracle.
+__global__ void __launch_bounds__(256)
+k_kp_error_test(RecLayout L, int T, int batch, int dof, int n_iv, const int *__restrict__ iv, int min_N, double threshold,
+                const double *__restrict__ rec, unsigned char *__restrict__ good)
+{
+    const int k = blockIdx.x * blockDim.x + threadIdx.x;
+    if (k >= n_iv) return;
+    const int b = iv[4 * k], i = iv[4 * k + 1], s = iv[4 * k + 2], e = iv[4 * k + 3];
+    if ((unsigned)b >= (unsigned)batch || (unsigned)i >= (unsigned)dof || s < 0 || e >= T || e < s) { good[k] = 2; return; }   // bad argument
+    if (e - s <= min_N) { good[k] = 1; return; }
+    const int mid = (s + e) / 2, n = L.n;
+    const double *Rs = rec + ((size_t)b * T + s) * L.stride + L.off_A, *Rm = rec + ((size_t)b * T + mid) * L.stride + L.off_A,
+                 *Re = rec + ((size_t)b * T + e) * L.stride + L.off_A;
+    double error_sum = 0.0;
+    int counter = 0;
+    for (int cc = 0; cc < 2; cc++) {
+        const int col = cc == 0 ? i : i + dof;
+        for (int j = dof; j < 2 * dof; j++) {
+            const double approx = (Rs[j * n + col] + Re[j * n + col]) / 2;
+            const double d = Rm[j * n + col] - approx;
+            error_sum += d * d;
+            counter++;
+        }
+    }
+    const double average_error = counter > 0 ? error_sum / counter : 0.0;
+    good[k] = average_error < threshold ? 1 : 0;
+}
+
+hipError_t launch_kp_error_test(Ctx *c, int n_iv, const int *iv_dev, int min_N, double threshold, unsigned char *good_dev)
+{
+    if (n_iv == 0) return hipSuccess;
+    hipLaunchKernelGGL(k_kp_error_test, dim3((n_iv + 255) / 256), dim3(256), 0, c->stream, c->L, c->d.T, c->d.batch, c->d.dof, n_iv,
+                       iv_dev, min_N, threshold, c->rec, good_dev);
+    return hipGetLastError();
+}
+
 }  // namespace kpilqr

@@ -450,6 +450,24 @@ int kpilqr_generate_keypoints(kpilqr_ctx *c, const char *method, int min_N, int 
     return KPILQR_OK;
 }
 
+int kpilqr_keypoint_error_test(kpilqr_ctx *c, int n_iv, const int *intervals, int min_N, double threshold, unsigned char *good)
+{
+    if (!c || n_iv < 0 || (n_iv > 0 && (!intervals || !good))) return KPILQR_ERR_ARG;
+    KP_ENTER(c);
+    if (n_iv == 0) return KPILQR_OK;
+    const size_t iv_bytes = (size_t)n_iv * 4 * sizeof(int), off = (iv_bytes + 15) & ~(size_t)15;
+    int rc = ensure_stage(c, off + (size_t)n_iv);
+    if (rc) return rc;
+    int *iv_dev = (int *)c->stage;
+    unsigned char *good_dev = (unsigned char *)c->stage + off;
+    KP_HIP(c, hipMemcpyAsync(iv_dev, intervals, iv_bytes, hipMemcpyHostToDevice, c->stream));
+    KP_HIP(c, launch_kp_error_test(c, n_iv, iv_dev, min_N, threshold, good_dev));
+    KP_HIP(c, hipMemcpyAsync(good, good_dev, (size_t)n_iv, hipMemcpyDeviceToHost, c->stream));
+    KP_HIP(c, hipStreamSynchronize(c->stream));
+    for (int k = 0; k < n_iv; k++) if (good[k] > 1) return set_err(c, KPILQR_ERR_ARG, "kpilqr_keypoint_error_test: interval out of range");
+    return KPILQR_OK;
+}
+
 int kpilqr_get_keypoints(kpilqr_ctx *c, int *kp_offsets, int *kp_times, int times_capacity)
 {
     if (!c || !kp_offsets) return KPILQR_ERR_ARG;

@@ -140,6 +140,13 @@ class Engine:
         self._ck(self._L.kpilqr_get_keypoints(self._h, _ptr(offs), _ptr(times), len(times)))
         return offs, times[:total]
 
+    def keypoint_error_test(self, intervals, min_N, threshold):
+        """kpilqr_keypoint_error_test: intervals [n][4] = (trajectory, DoF, start, end) -> bool [n] (True: good)."""
+        iv = np.ascontiguousarray(intervals, np.int32).reshape(-1, 4)
+        good = np.zeros(len(iv), np.uint8)
+        self._ck(self._L.kpilqr_keypoint_error_test(self._h, len(iv), _ptr(iv), int(min_N), float(threshold), _ptr(good)))
+        return good.astype(bool)
+
     def upload_fd(self, job_b, job_t, job_col, job_mode, xplus, xminus, job_nom=None, xnom=None, eps=1e-6):
         nj = len(job_t)
         jb = np.ascontiguousarray(job_b, np.int32); jt = np.ascontiguousarray(job_t, np.int32)
