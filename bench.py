@@ -212,7 +212,8 @@ def roofline_of(p, p0, r, pmc=None):
     pairs = kp_pairs(p0)
     kb = 8 * T * (m * n + m)                                                        # gains out
     kb += 8 * (pairs[0] * 2 * n + pairs[1] * n) if a4 else 8 * T * (n * n + n * m)   # A, B: key-point columns or every step
-    kb += 8 * T * nr * (1 + n + m) if a6 else 8 * T * (n * n + n + m * m + m)         # residuals + Jacobians or l_*
+    ru0 = r["fused"] and not np.any(p0["r_u"])            # r_u never uploaded: the fused backward sweep does not read it
+    kb += 8 * T * nr * (1 + n + (0 if ru0 else m)) if a6 else 8 * T * (n * n + n + m * m + m)   # residuals + Jacobians or l_*
     flops = flops_a7(n, m) * T * B
     ach_tf = flops / t_bwd / 1e12
     traffic = None

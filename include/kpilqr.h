@@ -207,7 +207,9 @@ int  kpilqr_filter_dynamics(kpilqr_ctx *ctx, const char *method, const double *c
  * Residuals and their host-side FD Jacobians (Differentiator::ResidualDerivatives stays on the
  * host): r [batch][T+1][nr], r_x [batch][T+1][nr][n], r_u [batch][T+1][nr][m]; residual weights
  * w_run / w_term [nr] (struct residual, include/StdInclude.h:82-88).  Any pointer may be NULL to
- * keep what is already resident. */
+ * keep what is already resident.  The buffers start zeroed: a task whose residuals do not depend on the controls
+ * (r_u = 0: reaching, the pushing tasks) never passes r_u, and the fused sweeps then leave the control-residual
+ * products out (l_uu = l_u = 0 exactly). */
 int  kpilqr_upload_residuals(kpilqr_ctx *ctx, const double *r, const double *r_x, const double *r_u,
                              const double *w_run, const double *w_term);
 /* ModelTranslator::CostDerivativesFromResiduals (src/ModelTranslator/ModelTranslator.cpp:552-583)

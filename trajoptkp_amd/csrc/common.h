@@ -68,6 +68,7 @@ struct Ctx {
     bool fused = false;          // KPILQR_FLAG_FUSED and a supported shape
     bool tiled_a6 = false;       // KPILQR_FLAG_FUSED on a tiled shape: the cost derivatives (a6) are formed inside the sweeps
     bool tiled_a4 = false;       // KPILQR_FLAG_FUSED on a tiled shape: A, B are interpolated (a4) inside the sweeps
+    bool ru_zero = true;         // r_u was never written since create / resize (the buffer starts zeroed): r_u = 0 exactly
 
     // nominal states for on-device key-point placement (kpilqr_upload_states), allocated on first use
     double *X_states = nullptr;   // [batch][T][n]

@@ -124,7 +124,10 @@ template <int R> __device__ __forceinline__ void fset_reg(d4 &v, double x) { if 
 #define FPC_TILES 4
 #define FPC_BUF (FPC_TILES * 256)
 __device__ __forceinline__ d4 lds_tile4(const double *t, int lane);
-template <int N, int M, bool PC>
+// RU0: the context's r_u buffer was never written (a task without control residuals: r_u = 0, e.g. reaching,
+// src/ModelTranslator/Reaching.cpp:43-54), so [l_uu | l_u] = Ru' W [Ru | r] is exactly zero: the product and the r_u loads
+// are left out (4 of the step's 40 MFMAs).
+template <int N, int M, bool PC, bool RU0 = false>
 __device__ __forceinline__ void backward_fused_body(double *sh, const double *pcbuf, int *sflag, RecLayout L, FusedArgs F, int T,
                 const double *__restrict__ rec,
                 const double *__restrict__ lambda, int pd_stride, double *__restrict__ Kout, double *__restrict__ kout,
@@ -174,7 +177,7 @@ __device__ __forceinline__ void backward_fused_body(double *sh, const double *pc
         __amdgpu_buffer_rsrc_t rRu = frsrc(rub + (size_t)t * nr * m, nr * m * 8);
         s.Rx.x = fbld(rRx, oRx[0]); s.Rx.y = fbld(rRx, oRx[1]); s.Rx.z = fbld(rRx, oRx[2]); s.Rx.w = fbld(rRx, oRx[3]);
         s.R1.x = fbld(rR, oR1[0]); s.R1.y = fbld(rR, oR1[1]); s.R1.z = fbld(rR, oR1[2]); s.R1.w = fbld(rR, oR1[3]);
-        s.Ru.x = fbld(rRu, oRu[0]); s.Ru.y = fbld(rRu, oRu[1]); s.Ru.z = fbld(rRu, oRu[2]); s.Ru.w = fbld(rRu, oRu[3]);
+        if constexpr (!RU0) { s.Ru.x = fbld(rRu, oRu[0]); s.Ru.y = fbld(rRu, oRu[1]); s.Ru.z = fbld(rRu, oRu[2]); s.Ru.w = fbld(rRu, oRu[3]); }
     };
 
     // ---- column tracker, walking DOWN in time ----------------------------------------------------------
@@ -242,13 +245,18 @@ __device__ __forceinline__ void backward_fused_body(double *sh, const double *pc
         Fu.x = lerp_nc(sv[4], dt, av[4]); Fu.y = lerp_nc(sv[5], dt, av[5]);
         Fu.z = lerp_nc(sv[6], dt, av[6]); Fu.w = lerp_nc(sv[7], dt, av[7]);
         // ---- a6: Lzz, l_uu, l_u from the residuals --------------------------------------------------------
-        d4 Rz, Rur;
+        d4 Rz;
         Rz.x = bits_or(cur.Rx.x, cur.R1.x); Rz.y = bits_or(cur.Rx.y, cur.R1.y);
         Rz.z = bits_or(cur.Rx.z, cur.R1.z); Rz.w = bits_or(cur.Rx.w, cur.R1.w);
-        Rur.x = bits_or(cur.Ru.x, cur.R1.x); Rur.y = bits_or(cur.Ru.y, cur.R1.y);
-        Rur.z = bits_or(cur.Ru.z, cur.R1.z); Rur.w = bits_or(cur.Ru.w, cur.R1.w);
         Lzz = PR(Rz, Rz * W2, zero, ncr);
-        LU = PR(cur.Ru, Rur * W2, zero, ncr);
+        if constexpr (RU0) {
+            LU = zero;
+        } else {
+            d4 Rur;
+            Rur.x = bits_or(cur.Ru.x, cur.R1.x); Rur.y = bits_or(cur.Ru.y, cur.R1.y);
+            Rur.z = bits_or(cur.Ru.z, cur.R1.z); Rur.w = bits_or(cur.Ru.w, cur.R1.w);
+            LU = PR(cur.Ru, Rur * W2, zero, ncr);
+        }
         __builtin_amdgcn_sched_barrier(0);
         if (t > 0) load_res(t - 1, cur);
         __builtin_amdgcn_sched_barrier(0);
@@ -391,23 +399,23 @@ __device__ __forceinline__ void backward_fused_body(double *sh, const double *pc
     if (lane == 0) status[b] = fail;
 }
 
-template <int N, int M>
+template <int N, int M, bool RU0>
 __global__ void __launch_bounds__(64)
 k_backward_fused(RecLayout L, FusedArgs F, int T, const double *__restrict__ rec, const double *__restrict__ lambda,
                  int pd_stride, double *__restrict__ Kout, double *__restrict__ kout,
                  double *__restrict__ delta_J, int *__restrict__ status)
 {
     __shared__ __attribute__((aligned(16))) double sh[FLDS_TOTAL];
-    backward_fused_body<N, M, false>(sh, nullptr, nullptr, L, F, T, rec, lambda, pd_stride, Kout, kout, delta_J, status);
+    backward_fused_body<N, M, false, RU0>(sh, nullptr, nullptr, L, F, T, rec, lambda, pd_stride, Kout, kout, delta_J, status);
 }
-template <int N, int M>
+template <int N, int M, bool RU0>
 __global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(1, 1)))
 k_backward_fused_excl(RecLayout L, FusedArgs F, int T, const double *__restrict__ rec, const double *__restrict__ lambda,
                       int pd_stride, double *__restrict__ Kout, double *__restrict__ kout,
                       double *__restrict__ delta_J, int *__restrict__ status)
 {
     __shared__ __attribute__((aligned(16))) double sh[FLDS_TOTAL];
-    backward_fused_body<N, M, false>(sh, nullptr, nullptr, L, F, T, rec, lambda, pd_stride, Kout, kout, delta_J, status);
+    backward_fused_body<N, M, false, RU0>(sh, nullptr, nullptr, L, F, T, rec, lambda, pd_stride, Kout, kout, delta_J, status);
 }
 
 
@@ -897,7 +905,7 @@ k_backward_fusedpc_excl(RecLayout L, FusedArgs F, int T, int role_shift, const d
 // ---------------------------------------------------------------------------------------------------------
 // Forward pass.  The column tracker walks UP in time; its tiles (row = A row, col = A column) are turned into
 // the Y operands (row = contraction index) through a padded LDS transpose, off the Z dependency chain.
-template <int NCZ, int NCU>
+template <int NCZ, int NCU, bool RU0 = false>
 __device__ __forceinline__ void forward_fused_body(RecLayout L, FusedArgs F, int T, int n_alpha, const double *__restrict__ rec,
                const double *__restrict__ Kin, const double *__restrict__ kin,
                const double *__restrict__ u_nom, const double *__restrict__ ctrl_lim,
@@ -962,8 +970,10 @@ __device__ __forceinline__ void forward_fused_body(RecLayout L, FusedArgs F, int
         s.YkK.x = fbld(rK, oK[0]); s.YkK.y = fbld(rK, oK[1]); s.YkK.z = fbld(rK, oK[2]); s.YkK.w = fbld(rK, oK[3]);
         s.Ykk.x = fbld(rk, ok_[0]); s.Ykk.y = fbld(rk, ok_[1]); s.Ykk.z = fbld(rk, ok_[2]); s.Ykk.w = fbld(rk, ok_[3]);
         s.RxT.x = fbld(rRx, oRxT[0]); s.RxT.y = fbld(rRx, oRxT[1]); s.RxT.z = fbld(rRx, oRxT[2]); s.RxT.w = fbld(rRx, oRxT[3]);
-        s.RuT.x = fbld(rRu, oRuT[0]); s.RuT.y = NCU > 1 ? fbld(rRu, oRuT[1]) : 0.0;
-        s.RuT.z = NCU > 2 ? fbld(rRu, oRuT[2]) : 0.0; s.RuT.w = NCU > 3 ? fbld(rRu, oRuT[3]) : 0.0;
+        if constexpr (!RU0) {
+            s.RuT.x = fbld(rRu, oRuT[0]); s.RuT.y = NCU > 1 ? fbld(rRu, oRuT[1]) : 0.0;
+            s.RuT.z = NCU > 2 ? fbld(rRu, oRuT[2]) : 0.0; s.RuT.w = NCU > 3 ? fbld(rRu, oRuT[3]) : 0.0;
+        }
         s.rv.x = fbld(rR, oR[0]); s.rv.y = fbld(rR, oR[1]); s.rv.z = fbld(rR, oR[2]); s.rv.w = fbld(rR, oR[3]);
         s.ub.x = fbld(ru, oub[0]); s.ub.y = NCU > 1 ? fbld(ru, oub[1]) : 0.0;
         s.ub.z = NCU > 2 ? fbld(ru, oub[2]) : 0.0; s.ub.w = NCU > 3 ? fbld(ru, oub[3]) : 0.0;
@@ -1071,13 +1081,16 @@ __device__ __forceinline__ void forward_fused_body(RecLayout L, FusedArgs F, int
         cur.ub.z = NCU > 2 ? fbld(ru, oub[2]) : 0.0; cur.ub.w = NCU > 3 ? fbld(ru, oub[3]) : 0.0;
         __builtin_amdgcn_sched_barrier(0);
         Zn = PS<NCU>(Yb, dU, Zn);                      // + B du: the next state
-        const d4 Ju = PS<NCU>(cur.RuT, dU, zero);
+        d4 Ju = zero;                                  // RU0: r_u = 0, the control residual term vanishes
+        if constexpr (!RU0) Ju = PS<NCU>(cur.RuT, dU, zero);
         const d4 Jx = PR(cur.RxT, Z, zero, ncx);
         Z = Zn;
         __builtin_amdgcn_sched_barrier(0);
         cur.RxT.x = fbld(rRx, oRxT[0]); cur.RxT.y = fbld(rRx, oRxT[1]); cur.RxT.z = fbld(rRx, oRxT[2]); cur.RxT.w = fbld(rRx, oRxT[3]);
-        cur.RuT.x = fbld(rRu, oRuT[0]); cur.RuT.y = NCU > 1 ? fbld(rRu, oRuT[1]) : 0.0;
-        cur.RuT.z = NCU > 2 ? fbld(rRu, oRuT[2]) : 0.0; cur.RuT.w = NCU > 3 ? fbld(rRu, oRuT[3]) : 0.0;
+        if constexpr (!RU0) {
+            cur.RuT.x = fbld(rRu, oRuT[0]); cur.RuT.y = NCU > 1 ? fbld(rRu, oRuT[1]) : 0.0;
+            cur.RuT.z = NCU > 2 ? fbld(rRu, oRuT[2]) : 0.0; cur.RuT.w = NCU > 3 ? fbld(rRu, oRuT[3]) : 0.0;
+        }
         if (more) fetch_Y(Ya, Yb);                     // Y operands of step t+1 (staged during step t-1 ... see below)
         __builtin_amdgcn_sched_barrier(0);
         if (U_alpha && c < n_alpha) {
@@ -1107,21 +1120,21 @@ __device__ __forceinline__ void forward_fused_body(RecLayout L, FusedArgs F, int
     if (q == 0 && c < n_alpha) cost_pred[(size_t)b * n_alpha + c] = partial;
 }
 
-template <int NCZ, int NCU>
+template <int NCZ, int NCU, bool RU0>
 __global__ void __launch_bounds__(64)
 k_forward_fused(RecLayout L, FusedArgs F, int T, int n_alpha, const double *__restrict__ rec, const double *__restrict__ Kin,
                 const double *__restrict__ kin, const double *__restrict__ u_nom, const double *__restrict__ ctrl_lim,
                 const double *__restrict__ alphas, double *__restrict__ cost_pred, double *__restrict__ U_alpha)
 {
-    forward_fused_body<NCZ, NCU>(L, F, T, n_alpha, rec, Kin, kin, u_nom, ctrl_lim, alphas, cost_pred, U_alpha);
+    forward_fused_body<NCZ, NCU, RU0>(L, F, T, n_alpha, rec, Kin, kin, u_nom, ctrl_lim, alphas, cost_pred, U_alpha);
 }
-template <int NCZ, int NCU>
+template <int NCZ, int NCU, bool RU0>
 __global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(1, 1)))
 k_forward_fused_excl(RecLayout L, FusedArgs F, int T, int n_alpha, const double *__restrict__ rec, const double *__restrict__ Kin,
                      const double *__restrict__ kin, const double *__restrict__ u_nom, const double *__restrict__ ctrl_lim,
                      const double *__restrict__ alphas, double *__restrict__ cost_pred, double *__restrict__ U_alpha)
 {
-    forward_fused_body<NCZ, NCU>(L, F, T, n_alpha, rec, Kin, kin, u_nom, ctrl_lim, alphas, cost_pred, U_alpha);
+    forward_fused_body<NCZ, NCU, RU0>(L, F, T, n_alpha, rec, Kin, kin, u_nom, ctrl_lim, alphas, cost_pred, U_alpha);
 }
 
 // ---------------------------------------------------------------------------------------------------------
@@ -1425,19 +1438,21 @@ hipError_t launch_backward_fused(Ctx *c, int pd_stride)
 #undef LAUNCHPC
         return hipErrorInvalidValue;
     }
-#define LAUNCH(NN, MM)                                                                                       \
+#define LAUNCH2(NN, MM, RU)                                                                                   \
     do {                                                                                                     \
         if (excl)                                                                                            \
-            hipLaunchKernelGGL((k_backward_fused_excl<NN, MM>), grid, block, 0, c->stream, c->L, F, c->d.T,  \
+            hipLaunchKernelGGL((k_backward_fused_excl<NN, MM, RU>), grid, block, 0, c->stream, c->L, F, c->d.T,  \
                                c->rec, c->lambda, pd_stride, c->K, c->k, c->delta_J, c->status);             \
         else                                                                                                 \
-            hipLaunchKernelGGL((k_backward_fused<NN, MM>), grid, block, 0, c->stream, c->L, F, c->d.T,       \
+            hipLaunchKernelGGL((k_backward_fused<NN, MM, RU>), grid, block, 0, c->stream, c->L, F, c->d.T,   \
                                c->rec, c->lambda, pd_stride, c->K, c->k, c->delta_J, c->status);             \
     } while (0)
+#define LAUNCH(NN, MM) do { if (c->ru_zero) LAUNCH2(NN, MM, true); else LAUNCH2(NN, MM, false); } while (0)
 #define KP_X(NN, MM) if (n == NN && m == MM) { LAUNCH(NN, MM); return hipGetLastError(); }
     KP_T1_SHAPES(KP_X)
 #undef KP_X
 #undef LAUNCH
+#undef LAUNCH2
     return hipErrorInvalidValue;
 }
 
@@ -1475,17 +1490,21 @@ hipError_t launch_forward_fused(Ctx *c, double *U_alpha_dev)
 #undef LAUNCHSC
         return hipErrorInvalidValue;
     }
-#define LAUNCH(NCZ, NCU)                                                                                          \
+#define LAUNCH2(NCZ, NCU, RU)                                                                                     \
     do {                                                                                                          \
         if (excl)                                                                                                 \
-            hipLaunchKernelGGL((k_forward_fused_excl<NCZ, NCU>), grid, block, 0, c->stream, c->L, F, c->d.T,      \
+            hipLaunchKernelGGL((k_forward_fused_excl<NCZ, NCU, RU>), grid, block, 0, c->stream, c->L, F, c->d.T,  \
                                c->d.n_alpha, c->rec, c->K, c->k, c->u_nom, c->ctrl_lim, c->alphas, c->cost_pred,  \
                                U_alpha_dev);                                                                      \
         else                                                                                                      \
-            hipLaunchKernelGGL((k_forward_fused<NCZ, NCU>), grid, block, 0, c->stream, c->L, F, c->d.T,           \
+            hipLaunchKernelGGL((k_forward_fused<NCZ, NCU, RU>), grid, block, 0, c->stream, c->L, F, c->d.T,       \
                                c->d.n_alpha, c->rec, c->K, c->k, c->u_nom, c->ctrl_lim, c->alphas, c->cost_pred,  \
                                U_alpha_dev);                                                                      \
     } while (0)
+// (the r_u = 0 instantiation of the one-wave forward kernel measured SLOWER, 3.76 vs 3.22 ms at B = 1024: with the two
+// r_u loads and the Ju product gone the compiler's wait placement moves out of the latency shadow it sits in today --
+// DESIGN.md section 4.6 -- so the forward sweep always runs the dense form)
+#define LAUNCH(NCZ, NCU) LAUNCH2(NCZ, NCU, false)
 #define KP_X(NCZ, NCU) if (ncz == NCZ && ncu == NCU) { LAUNCH(NCZ, NCU); return hipGetLastError(); }
     KP_X(4, 2) KP_X(2, 1) KP_X(4, 1) KP_X(3, 1)
 #undef KP_X

@@ -302,6 +302,7 @@ int kpilqr_resize(kpilqr_ctx *c, int new_dof, int new_num_ctrl, int new_horizon)
     }
     c->have_kp = c->kp_canonical = c->have_states = false;
     c->njobs = c->nnom = c->nslots = 0;
+    c->ru_zero = true;                                   // size_buffers zeroed r_u
     if (c->X_states) { KP_HIP(c, hipFree(c->X_states)); c->X_states = nullptr; }
     if (c->kp_mask) { KP_HIP(c, hipFree(c->kp_mask)); c->kp_mask = nullptr; }
     if (c->kp_count) { KP_HIP(c, hipFree(c->kp_count)); c->kp_count = nullptr; }
@@ -636,7 +637,7 @@ int kpilqr_upload_residuals(kpilqr_ctx *c, const double *r, const double *r_x, c
     const size_t B = c->d.batch, T1 = c->d.T + 1, n = c->n, m = c->d.m, nr = c->d.nr;
     if (r) KP_HIP(c, hipMemcpyAsync(c->r, r, B * T1 * nr * 8, hipMemcpyHostToDevice, c->stream));
     if (r_x) KP_HIP(c, hipMemcpyAsync(c->r_x, r_x, B * T1 * nr * n * 8, hipMemcpyHostToDevice, c->stream));
-    if (r_u) KP_HIP(c, hipMemcpyAsync(c->r_u, r_u, B * T1 * nr * m * 8, hipMemcpyHostToDevice, c->stream));
+    if (r_u) { KP_HIP(c, hipMemcpyAsync(c->r_u, r_u, B * T1 * nr * m * 8, hipMemcpyHostToDevice, c->stream)); c->ru_zero = false; }
     if (w_run) KP_HIP(c, hipMemcpyAsync(c->w_run, w_run, nr * 8, hipMemcpyHostToDevice, c->stream));
     if (w_term) KP_HIP(c, hipMemcpyAsync(c->w_term, w_term, nr * 8, hipMemcpyHostToDevice, c->stream));
     return KPILQR_OK;
@@ -835,6 +836,7 @@ int kpilqr_iterate_streamed(kpilqr_ctx *c, const kpilqr_stream_io *io, int pd_ch
     if (nchunks > B) nchunks = B;
     if (io->fd_slab && (io->nslots < 1 || io->njobs < 1 || !io->traj_slot_first || (io->nnom > 0 && !io->traj_nom_first)))
         return set_err(c, KPILQR_ERR_ARG, "streamed FD payload needs the slot table and the per-trajectory slot / nominal-row offsets");
+    if (io->r_u) c->ru_zero = false;
     const void *hostp[] = {io->fd_slab, io->r, io->r_x, io->r_u, io->u_nom, io->lambda, io->K, io->k, io->cost_pred, io->delta_J, io->status};
     for (const void *p : hostp) if (!is_pinned(p)) return set_err(c, KPILQR_ERR_ARG, "kpilqr_iterate_streamed: host buffers must be pinned (kpilqr_host_alloc)");
     if (c->fused || c->tiled_a4) { int rc = check_fused(c); if (rc) return rc; }

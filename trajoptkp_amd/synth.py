@@ -345,6 +345,7 @@ def upload(engine, p, keypoints=True):
         engine.set_keypoints_rows(p["kp_rows"])
     engine.upload_fd(p["job_b"], p["job_t"], p["job_col"], p["job_mode"], p["xplus"], p["xminus"],
                      job_nom=p["job_nom"], xnom=p["xnom"], eps=p["eps"])
-    engine.upload_residuals(p["r"], p["r_x"], p["r_u"], p["w_run"], p["w_term"])
+    # a task without control residuals never uploads r_u (the context's buffer starts zeroed): include/kpilqr.h
+    engine.upload_residuals(p["r"], p["r_x"], p["r_u"] if np.any(p["r_u"]) else None, p["w_run"], p["w_term"])
     engine.upload_nominal(p["u_nom"], p["ctrl_lim"])
     engine.sync()
