@@ -1,0 +1,81 @@
+"""Turns the rocprofv3 CSVs of tools/collect_profiles.sh into the JSON summaries bench.py reads:
+profiles/<tag>_pmc_traffic.json (HBM bytes per launch: FETCH_SIZE x2 on gfx950 per /opt/skills/guides/MI355X_MICROARCH.md,
+WRITE_SIZE exact; both are reported in KB) and profiles/<tag>_pmc_counters.json (MFMA / VALU / LDS counters per launch and
+the per-trajectory-step figures derived from them), plus profiles/<tag>_kernel_stats.csv."""
+import csv
+import glob
+import json
+import os
+import shutil
+import sys
+
+out, tag = sys.argv[1], sys.argv[2]
+root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+T, B = 3000, 1024
+
+KEYS = {"k_backward_fused": "backward_fused", "k_forward_fused": "forward_fused", "k_fd_difference": "fd_difference"}
+
+
+def key_of(name):
+    for k, v in KEYS.items():
+        if k in name:
+            return v
+    return None
+
+
+def counters(passdir):
+    """-> {kernel key: {counter: mean per launch (summed over the device)}}"""
+    acc = {}
+    for f in glob.glob(os.path.join(out, passdir, "**", "*counter_collection.csv"), recursive=True):
+        per_dispatch = {}
+        for row in csv.DictReader(open(f)):
+            k = key_of(row["Kernel_Name"])
+            if k is None:
+                continue
+            d = per_dispatch.setdefault((k, row["Dispatch_Id"]), {})
+            d[row["Counter_Name"]] = d.get(row["Counter_Name"], 0.0) + float(row["Counter_Value"])
+        for (k, _), d in per_dispatch.items():
+            for cn, v in d.items():
+                acc.setdefault(k, {}).setdefault(cn, []).append(v)
+    return {k: {cn: sum(v) / len(v) for cn, v in d.items()} for k, d in acc.items()}, \
+           {k: len(next(iter(d.values()))) for k, d in acc.items()}
+
+
+fetch, nl = counters("pmc_fetch")
+write, _ = counters("pmc_write")
+traffic = {"note": "rocprofv3 --pmc FETCH_SIZE and --pmc WRITE_SIZE in SEPARATE passes over `python bench.py --no-cpu-baseline "
+                   "--no-secondary --steps 3 --warmup 1` (Panda reaching, B=1024, T=3000, fused sweeps); KB per launch, mean over launches. "
+                   "gfx950 correction (MI355X_MICROARCH.md, HBM): FETCH_SIZE counts 64 B per 128-B request -> x2 (calibrated in round 1 on a "
+                   "kernel with exactly known reads); WRITE_SIZE is exact.",
+           "workload": {"task": "panda_reaching", "T": T, "batch": B}, "kernels": {}}
+for k in fetch:
+    fk, wk = fetch[k].get("FETCH_SIZE", 0.0), write.get(k, {}).get("WRITE_SIZE", 0.0)
+    traffic["kernels"][k] = {"FETCH_SIZE_KB": fk, "WRITE_SIZE_KB": wk, "traffic_bytes": 1024.0 * (2.0 * fk + wk), "launches": nl.get(k)}
+json.dump(traffic, open(os.path.join(root, "profiles", f"{tag}_pmc_traffic.json"), "w"), indent=1)
+
+m3, _ = counters("pmc_m3")
+m4, _ = counters("pmc_m4")
+cnt = {"note": "rocprofv3 --pmc, two separate passes (SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CYCLES SQ_INSTS_VALU_MFMA_F64 SQ_INSTS_VALU; "
+               "SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_ANY) over the same command; mean per launch, "
+               "summed over the device.  Counters count per wave: / (T x B) gives the per-trajectory-step figures.",
+       "derived": {}, "kernels": {}}
+for k in m3:
+    d = dict(m3[k]); d.update(m4.get(k, {}))
+    cnt["kernels"][k] = d
+    if d.get("SQ_INSTS_VALU_MFMA_F64"):
+        mf = d["SQ_INSTS_VALU_MFMA_F64"]
+        cnt["derived"][k] = {"mfma_per_step_per_trajectory": mf / (T * B),
+                             "mfma_busy_cycles_per_instruction": d.get("SQ_VALU_MFMA_BUSY_CYCLES", 0.0) / mf,
+                             "valu_instructions_per_step_per_trajectory": d.get("SQ_INSTS_VALU", 0.0) / (T * B),
+                             "lds_bank_conflict_cycles": d.get("SQ_LDS_BANK_CONFLICT", 0.0)}
+json.dump(cnt, open(os.path.join(root, "profiles", f"{tag}_pmc_counters.json"), "w"), indent=1)
+
+for sub, name in (("stats", f"{tag}_kernel_stats.csv"), ("stats_generic", f"{tag}_generic_kernel_stats.csv")):
+    fs = glob.glob(os.path.join(out, sub, "**", "*kernel_stats.csv"), recursive=True)
+    if fs:
+        shutil.copy(fs[0], os.path.join(root, "profiles", name))
+for src, name in (("bench.json", f"{tag}_bench.json"), ("generic.json", f"{tag}_generic_bench.json")):
+    if os.path.exists(os.path.join(out, src)):
+        shutil.copy(os.path.join(out, src), os.path.join(root, "profiles", name))
+print(json.dumps(cnt["derived"], indent=1))
+print({k: v["traffic_bytes"] for k, v in traffic["kernels"].items()})

@@ -22,9 +22,33 @@ ThreadPool &Differentiator::pool()
 }
 
 // ---- staging ---------------------------------------------------------------------------------------------
+void FDStaging::plan(int total_jobs, int total_noms, int total_slots, int n_)
+{
+    size_t off[10];
+    layout(total_jobs, total_noms, total_slots, off);
+    if (off[9] > slab_cap || !slab) {
+        if (slab) { if (release) release(slab); else std::free(slab); }
+        slab_cap = off[9] + off[9] / 4 + 4096;
+        slab = (char *)(alloc ? alloc(slab_cap) : std::malloc(slab_cap));
+    }
+    n = n_;
+    xplus = (double *)(slab + off[0]); xminus = (double *)(slab + off[1]); xnom = (double *)(slab + off[2]);
+    job_b = (int *)(slab + off[3]); job_t = (int *)(slab + off[4]); job_col = (int *)(slab + off[5]);
+    job_nom = (int *)(slab + off[6]); slot_start = (int *)(slab + off[7]); job_mode = (unsigned char *)(slab + off[8]);
+    plan_jobs = total_jobs; plan_noms = total_noms; plan_slots = total_slots;
+    njobs = nnom = nslots = 0;
+    if (total_slots > 0) slot_start[total_slots] = total_jobs;
+}
+
 void FDStaging::free_all()
 {
     auto rel = [&](void *p) { if (p) { if (release) release(p); else std::free(p); } };
+    if (slab) {                     // slab mode: the arrays point into the slab
+        rel(slab); slab = nullptr; slab_cap = 0; slot_start = nullptr;
+        job_b = job_t = job_col = job_nom = nullptr; job_mode = nullptr; xplus = xminus = xnom = nullptr;
+        cap_jobs = cap_nom = 0; njobs = nnom = nslots = 0;
+        return;
+    }
     rel(job_b); rel(job_t); rel(job_col); rel(job_nom); rel(job_mode); rel(xplus); rel(xminus); rel(xnom);
     job_b = job_t = job_col = job_nom = nullptr; job_mode = nullptr; xplus = xminus = xnom = nullptr;
     cap_jobs = cap_nom = 0; njobs = nnom = 0;
@@ -264,6 +288,39 @@ void Differentiator::DynamicsDerivativesBatch(FDStaging &st, int b, const std::v
 // Differentiator::ResidualDerivatives (src/Differentiator/Differentiator.cpp:464-663), central differences: controls with
 // the reference's limit-aware one-sided fallback (:496-556), velocities through the state vector (:575-623), positions
 // through mj_integratePos on the tangent index (:626-656); the state is restored from the saved one after every column.
+void Differentiator::CountJobs(const std::vector<std::vector<int>> &keypoints, int &jobs, int &kps) const
+{
+    const int num_ctrl = model_translator->current_state_vector.num_ctrl;
+    jobs = kps = 0;
+    for (const std::vector<int> &cols : keypoints)
+        if (!cols.empty()) { kps++; jobs += jobs_of(cols, num_ctrl); }
+}
+
+void Differentiator::DynamicsDerivativesPlanned(FDStaging &st, int b, const std::vector<std::vector<int>> &keypoints, double eps)
+{
+    const stateVectorList &sv = model_translator->current_state_vector;
+    const int n = 2 * sv.dof;
+    std::vector<int> times, first;           // key-point times and the first job index of each
+    int total = st.njobs;
+    for (size_t t = 0; t < keypoints.size(); t++)
+        if (!keypoints[t].empty()) { times.push_back((int)t); first.push_back(total); total += jobs_of(keypoints[t], sv.num_ctrl); }
+    const int nom0 = st.nnom, slot0 = st.nslots;
+    if (total > st.plan_jobs || nom0 + (int)times.size() > st.plan_noms || slot0 + (int)times.size() > st.plan_slots || st.n != n) {
+        std::fprintf(stderr, "Differentiator: FD staging plan exceeded\n");
+        std::exit(1);
+    }
+    for (size_t it = 0; it < times.size(); it++) st.slot_start[slot0 + it] = first[it];
+    MuJoCo_helper->InitModelForFiniteDifferencing();
+    pool().parallel_for((int)times.size(), [&](int it, int tid) {
+        SliceSink sink{st, b, times[it], n, nom0 + it, first[it]};
+        fd_keypoint(*model_translator, *MuJoCo_helper, count_integrations, sink, keypoints[times[it]], times[it], tid, true, eps);
+    });
+    MuJoCo_helper->ResetModelAfterFiniteDifferencing();
+    st.njobs = total;
+    st.nnom = nom0 + (int)times.size();
+    st.nslots = slot0 + (int)times.size();
+}
+
 void Differentiator::ResidualDerivatives(double *r_x, double *r_u, int data_index, int tid, double eps)
 {
     const stateVectorList &sv = model_translator->current_state_vector;
