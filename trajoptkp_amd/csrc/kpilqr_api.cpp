@@ -156,8 +156,8 @@ static int select_variants(kpilqr_ctx *c)
     //     per-step reads of A, B disappear; needs canonical key-points like the one-tile fused sweeps.  Built, parity-green,
     //     and NOT the default: a lone wave per SIMD is bound by instruction issue, and the per-lane list walk (4 NT + 4
     //     values per lane: selects, un-contracted multiply-adds, loads, AGPR traffic for the tracker state) costs more than
-    //     the k_interpolate it removes (n = 62, T = 5000, B = 128, 26 % ragged key-points: interpolate 11.1 ms saved,
-    //     backward +11.8 ms, forward +10.4 ms; pushing n = 20, B = 64: 0.27 ms saved, +3.7 and +2.6 ms).
+    //     the k_interpolate it removes (n = 62, T = 5000, B = 128, 26 % ragged key-points: interpolate 11.2 ms saved,
+    //     backward +8.9 ms, forward +7.9 ms; pushing n = 20, B = 64: 0.28 ms saved, +2.3 and +1.9 ms).
     //     KPILQR_TILED_A4 = 1 turns it on.
     //  a6 (variant "..._a6"): cost derivatives formed from the residuals inside the sweeps.  It replaces k_cost_derivs
     //     (HBM-bound: n^2 doubles written per step) by NT*ceil(nr/4) + 6 MFMAs per wave-step of the latency-bound backward
