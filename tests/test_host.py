@@ -342,3 +342,20 @@ def test_svr_dof_importance_host_both_branches(dof, m, T, s):
     thr = float(np.median(ref))
     _, rem = host.dof_importance(K, dof, s, svd=True, threshold=thr)
     assert list(rem) == [i for i in range(dof) if got[i] < thr]
+
+
+# ---- the reference's own TestTasks rows as data fixtures for LoadTaskFromFile (FileHandler.cpp:471-578) --------------------
+@pytest.mark.parametrize("task,n_start", [("acrobot", 2), ("piston_block", 1), ("push_ncl", 13), ("walker_run", 9)])
+def test_load_task_from_the_references_test_task_files(task, n_start, golden_dir):
+    """tests/golden/TestTasks/<task>/{0,7}.csv are rows copied from the reference's TestTasks/ (data, not code): start state
+    (robot joints, then 6 numbers per rigid body) followed by the residual targets, a comma after every value."""
+    import os
+    for num in (0, 7):
+        path = os.path.join(golden_dir, "TestTasks", task, f"{num}.csv")
+        toks = [float(x) for x in open(path).read().strip().split(",") if x.strip()]
+        n_targets = len(toks) - n_start
+        assert n_targets > 0
+        got = host.load_task(path, n_start, n_targets)
+        assert got is not None
+        assert np.array_equal(got[0], toks[:n_start]) and np.array_equal(got[1], toks[n_start:])
+        assert host.load_task(path, n_start + 1, n_targets) is None        # wrong element count: refused (:519-523)
