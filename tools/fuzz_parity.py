@@ -1,5 +1,6 @@
 """Randomised parity sweep on the GPU box (not part of the test suite): random horizons, batch sizes, key-point
-intervals, regularisation, PD-check strides and one-sided FD fractions over every kernel family, each compared with
+intervals or ragged per-DoF key-point lists, regularisation, PD-check strides, one-sided FD fractions, residuals with and
+without control Jacobians, over every kernel family and every fusion form of the tiled sweeps (a4 / a6), each compared with
 the CPU oracle.  Usage: python tools/fuzz_parity.py [cases] [seed]"""
 import os, sys, time
 import numpy as np
@@ -29,17 +30,30 @@ for case in range(N):
     osf = float(rng.choice([0.0, 0.1, 0.5]))
     fused = bool(rng.integers(0, 2))
     form = str(rng.choice(["auto", "one"]))
-    for k in ("KPILQR_FUSED_WAVES", "KPILQR_FUSED_FWD_WAVES"):
+    for k in ("KPILQR_FUSED_WAVES", "KPILQR_FUSED_FWD_WAVES", "KPILQR_TILED_A4", "KPILQR_TILED_A6"):
         os.environ.pop(k, None)
     if form == "one":
         os.environ["KPILQR_FUSED_WAVES"] = "1"; os.environ["KPILQR_FUSED_FWD_WAVES"] = "1"
-    p = synth.make_problem(task=task, T=T, batch=batch, min_N=min_N, dense_residuals=bool(rng.integers(0, 2)),
-                           one_sided_frac=osf, lam=lam, config_id=int(rng.integers(1, 6)))
+    a4, a6 = str(rng.integers(0, 2)), str(rng.choice(["", "0", "1"]))
+    os.environ["KPILQR_TILED_A4"] = a4
+    if a6:
+        os.environ["KPILQR_TILED_A6"] = a6
+    dense_res = bool(rng.integers(0, 2))
+    if T >= 5 and rng.uniform() < 0.4:          # ragged per-DoF lists (bisection-shaped, very different densities per DoF)
+        dof = synth.TASKS[task]["dof"]
+        rows = [synth.bisect_keypoints(rng, dof, T, int(rng.integers(1, 4)), rng.uniform(0.0, 1.0, dof)) for _ in range(batch)]
+        p = synth.make_ragged_problem(task, T, rows, config_id=int(rng.integers(1, 6)), dense_residuals=dense_res, one_sided_frac=osf, lam=lam)
+        min_N = -1
+    else:
+        p = synth.make_problem(task=task, T=T, batch=batch, min_N=min_N, dense_residuals=dense_res,
+                               one_sided_frac=osf, lam=lam, config_id=int(rng.integers(1, 6)))
     with Engine(p["dof"], p["m"], T, p["nr"], batch=batch, fused=fused) as e:
         synth.upload(e, p)
         e.fd_difference()
         if "fused" not in e.backward_variant:
-            e.interpolate(); e.cost_derivs()
+            tail = e.backward_variant.rsplit("_", 1)[-1] if "tiled_" in e.backward_variant else ""
+            if "a4" not in tail: e.interpolate()
+            if "a6" not in tail: e.cost_derivs()
         st, dJ = e.backward(lam, pd)
         K, k = e.gains()
         cost, U = e.forward_linear(orc.alphas(6), want_U=True)
