@@ -141,7 +141,7 @@ int  kpilqr_get_keypoints(kpilqr_ctx *ctx, int *kp_offsets, int *kp_times, int t
  *   job_nom[j]           row of xnom holding the unperturbed next state (modes 1,2)
  *   xplus, xminus        [njobs][n] tangent-space next states; xnom [nnom][n]
  * One hipMemcpyAsync per array; with pinned host arrays (kpilqr_host_alloc) the call returns without waiting for them
- * (pageable arrays are waited for).  The slot table is built on the device and the indices are checked there (see
+ * (pageable arrays are waited for).  Jobs may come in any order; indices are checked on the device (see
  * kpilqr_upload_fd_slab): no host-side pass over the jobs. */
 int  kpilqr_upload_fd(kpilqr_ctx *ctx, int njobs, const int *job_b, const int *job_t,
                       const int *job_col, const unsigned char *job_mode, const int *job_nom,
@@ -149,37 +149,34 @@ int  kpilqr_upload_fd(kpilqr_ctx *ctx, int njobs, const int *job_b, const int *j
                       int nnom, const double *xnom, double eps);
 /* ---- asynchronous boundary: one pinned slab, no host-side loops, no stream synchronisation ---------------------------
  * The FD workers (Optimiser::WorkerComputeDerivatives, src/Optimiser/Optimiser.cpp:262-323, here
- * Differentiator::DynamicsDerivativesBatch) write their jobs straight into ONE pinned allocation laid out as below; the
- * upload is then a single hipMemcpyAsync into an identically laid-out device slab.  Jobs must be grouped by key-point
- * (consecutive jobs with the same (job_b, job_t) form a "slot"); slot_start [nslots+1] holds the first job of every slot
- * and njobs at the end -- the FD harness knows it for free.  nslots = 0: no table given (its region, njobs+1 ints, is
- * left unused) and the library builds it on the device.  Indices are range-checked ON THE DEVICE (a bad job is skipped);
- * a violation is reported by the next kpilqr_sync as KPILQR_ERR_ARG. */
+ * Differentiator::DynamicsDerivativesPlanned) write their jobs straight into ONE pinned allocation laid out as below; the
+ * upload is then a single hipMemcpyAsync into an identically laid-out device slab.  Jobs may come in any order.  Indices
+ * are range-checked ON THE DEVICE (a bad job is skipped); a violation is reported by the next kpilqr_sync as
+ * KPILQR_ERR_ARG. */
 typedef struct {
     size_t xplus, xminus, xnom;                 /* byte offsets of the double arrays [njobs][n], [njobs][n], [nnom][n] */
     size_t job_b, job_t, job_col, job_nom;      /* int arrays [njobs]                                                   */
-    size_t slot_start;                          /* int array [nslots+1] (njobs+1 when nslots = 0)                       */
     size_t job_mode;                            /* unsigned char array [njobs]                                          */
     size_t bytes;                               /* size of the slab                                                     */
 } kpilqr_fd_layout;
-int  kpilqr_fd_slab_layout(kpilqr_ctx *ctx, int njobs, int nnom, int nslots, kpilqr_fd_layout *out);
-int  kpilqr_upload_fd_slab(kpilqr_ctx *ctx, const void *slab, int njobs, int nnom, int nslots, double eps);
+int  kpilqr_fd_slab_layout(kpilqr_ctx *ctx, int njobs, int nnom, kpilqr_fd_layout *out);
+int  kpilqr_upload_fd_slab(kpilqr_ctx *ctx, const void *slab, int njobs, int nnom, double eps);
 
 /* One whole iteration for the batch, PIPELINED over chunks of trajectories: chunk c's uploads, its kernels and its
  * downloads run on their own stream, so H2D(c+1), kernels(c) and D2H(c-1) overlap (and so do consecutive calls: nothing
  * here waits for the previous iteration).  Every host pointer must be pinned (kpilqr_host_alloc); NULL inputs keep what
- * is resident, NULL outputs are not downloaded.  Jobs are sorted by trajectory; traj_slot_first / traj_nom_first
- * [batch+1] give the first slot / nominal row of every trajectory (jobs of trajectory b reference nominal rows in
+ * is resident, NULL outputs are not downloaded.  Jobs are sorted by trajectory; traj_job_first / traj_nom_first
+ * [batch+1] give the first job / nominal row of every trajectory (jobs of trajectory b reference nominal rows in
  * [traj_nom_first[b], traj_nom_first[b+1]) only).  Key-points, weights, control limits and alphas are set with the
  * ordinary calls beforehand.  Results are valid after kpilqr_sync.  nchunks = 0 lets the library choose (3: one chunk
  * per pipeline stream; the sweeps are latency-bound, so more chunks than streams only add their latency).  Uploads go
  * through the DMA engine, K and k come back through a copy kernel writing the pinned buffers: on this platform two DMA
  * directions do not overlap, a DMA upload and a kernel download do. */
 typedef struct {
-    const void *fd_slab;                        /* kpilqr_fd_slab_layout(njobs, nnom, nslots), nslots > 0; NULL: no new FD
-                                                   payload, the key-point columns already on the device are reused       */
-    int njobs, nnom, nslots;
-    const int *traj_slot_first, *traj_nom_first;/* [batch+1]                                                             */
+    const void *fd_slab;                        /* kpilqr_fd_slab_layout(njobs, nnom); NULL: no new FD payload, the
+                                                   key-point columns already on the device are reused                    */
+    int njobs, nnom;
+    const int *traj_job_first, *traj_nom_first; /* [batch+1]                                                             */
     double eps;
     const double *r, *r_x, *r_u;                /* [batch][T+1][nr], [..][nr][n], [..][nr][m]                            */
     const double *u_nom;                        /* [batch][T][m]                                                         */

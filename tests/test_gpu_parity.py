@@ -814,7 +814,7 @@ def test_fused_indefinite_quu_on_unchecked_steps(wave_form):
             assert relerr(K[b], o["K"]) < 1e-6 and relerr(k[b], o["k"]) < 1e-6, (lam, b, relerr(K[b], o["K"]))
 
 
-# ---- asynchronous boundary: pinned slab, device-side slot table / validation, chunk pipeline --------------------------
+# ---- asynchronous boundary: pinned slab, device-side validation, chunk pipeline --------------------------
 def _staged(p, fused):
     with Engine(p["dof"], p["m"], p["T"], p["nr"], batch=p["batch"], fused=fused) as e:
         synth.upload(e, p)
@@ -826,21 +826,19 @@ def _staged(p, fused):
 @pytest.mark.parametrize("task,T,batch,fused", [("panda_reaching", 200, 13, True), ("panda_reaching", 200, 13, False),
                                                 ("panda_pushing", 90, 5, False), ("acrobot", 100, 3, True)])
 def test_fd_slab_and_streamed_iteration_are_bit_identical(task, T, batch, fused):
-    """The one-slab upload (slot table from the caller, or built on the device) and the chunk-pipelined iteration give
-    the bytes of the array-by-array upload + kpilqr_iterate, whatever the number of chunks."""
+    """The one-slab upload and the chunk-pipelined iteration give the bytes of the array-by-array upload + kpilqr_iterate,
+    whatever the number of chunks."""
     p = synth.make_problem(task=task, T=T, batch=batch, min_N=5, dense_residuals=True, one_sided_frac=0.2)
     K0, k0, res0 = _staged(p, fused)
-    for with_slots in (True, False):
-        with Engine(p["dof"], p["m"], T, p["nr"], batch=batch, fused=fused) as e:
-            synth.upload(e, p)                                    # key-points, weights, limits, nominal controls, residuals
-            e.upload_fd([], [], [], [], np.zeros((0, p["n"])), np.zeros((0, p["n"])))     # forget the FD payload
-            s = e.fd_slab(p["job_b"], p["job_t"], p["job_col"], p["job_mode"], p["xplus"], p["xminus"], p["job_nom"], p["xnom"],
-                          with_slots=with_slots)
-            e.upload_fd_slab(s, p["eps"])
-            e.iterate(p["lam"], 100, orc.alphas(6))
-            res = e.results(); K, k = e.gains()
-        assert np.array_equal(K, K0) and np.array_equal(k, k0), (task, with_slots)
-        assert np.array_equal(res["cost_pred"], res0["cost_pred"]) and np.array_equal(res["delta_J"], res0["delta_J"])
+    with Engine(p["dof"], p["m"], T, p["nr"], batch=batch, fused=fused) as e:
+        synth.upload(e, p)                                    # key-points, weights, limits, nominal controls, residuals
+        e.upload_fd([], [], [], [], np.zeros((0, p["n"])), np.zeros((0, p["n"])))     # forget the FD payload
+        s = e.fd_slab(p["job_b"], p["job_t"], p["job_col"], p["job_mode"], p["xplus"], p["xminus"], p["job_nom"], p["xnom"])
+        e.upload_fd_slab(s, p["eps"])
+        e.iterate(p["lam"], 100, orc.alphas(6))
+        res = e.results(); K, k = e.gains()
+    assert np.array_equal(K, K0) and np.array_equal(k, k0), task
+    assert np.array_equal(res["cost_pred"], res0["cost_pred"]) and np.array_equal(res["delta_J"], res0["delta_J"])
     for nchunks in (1, 3, 4, 7, batch):
         with Engine(p["dof"], p["m"], T, p["nr"], batch=batch, fused=fused) as e:
             e.set_keypoints_rows(p["kp_rows"])

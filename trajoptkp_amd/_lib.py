@@ -36,12 +36,12 @@ class Dims(C.Structure):
 
 class FdLayout(C.Structure):
     _fields_ = [(k, C.c_size_t) for k in ("xplus", "xminus", "xnom", "job_b", "job_t", "job_col", "job_nom",
-                                          "slot_start", "job_mode", "bytes")]
+                                          "job_mode", "bytes")]
 
 
 class StreamIO(C.Structure):
-    _fields_ = [("fd_slab", C.c_void_p), ("njobs", C.c_int), ("nnom", C.c_int), ("nslots", C.c_int),
-                ("traj_slot_first", C.c_void_p), ("traj_nom_first", C.c_void_p), ("eps", C.c_double),
+    _fields_ = [("fd_slab", C.c_void_p), ("njobs", C.c_int), ("nnom", C.c_int),
+                ("traj_job_first", C.c_void_p), ("traj_nom_first", C.c_void_p), ("eps", C.c_double),
                 ("r", C.c_void_p), ("r_x", C.c_void_p), ("r_u", C.c_void_p), ("u_nom", C.c_void_p), ("lam", C.c_void_p),
                 ("K", C.c_void_p), ("k", C.c_void_p), ("cost_pred", C.c_void_p), ("delta_J", C.c_void_p),
                 ("status", C.c_void_p)]
@@ -118,8 +118,8 @@ def load():
     L.kpilqr_comm_unique_id.argtypes = [vp]
     L.kpilqr_comm_init.argtypes = [vp, C.c_int, C.c_int, vp]
     L.kpilqr_allreduce_linesearch.argtypes = [vp, vp]
-    L.kpilqr_fd_slab_layout.argtypes = [vp, C.c_int, C.c_int, C.c_int, C.POINTER(FdLayout)]
-    L.kpilqr_upload_fd_slab.argtypes = [vp, vp, C.c_int, C.c_int, C.c_int, C.c_double]
+    L.kpilqr_fd_slab_layout.argtypes = [vp, C.c_int, C.c_int, C.POINTER(FdLayout)]
+    L.kpilqr_upload_fd_slab.argtypes = [vp, vp, C.c_int, C.c_int, C.c_double]
     L.kpilqr_iterate_streamed.argtypes = [vp, C.POINTER(StreamIO), C.c_int, C.c_int]
     L.kpilqr_resize.argtypes = [vp, C.c_int, C.c_int, C.c_int]
     L.kpilqr_keypoint_error_test.argtypes = [vp, C.c_int, vp, C.c_int, C.c_double, vp]

@@ -12,9 +12,13 @@
 namespace kpilqr {
 
 // ---- device layout of one "step record" (all FP64), one per (trajectory b, time t) ----------
-// [ A (n x n) | B (n x m) | l_xx (n x n) | l_x (n) | l_uu (m x m) | l_u (m) ], every matrix
-// ROW-major so that the MFMA kernels' D-layout loads (lane -> one column, 4 consecutive rows per
-// instruction) read contiguous 4-row slabs.  Record stride is padded to 16 doubles (128 B).
+// [ A (n x n) | B (n x m) | l_xx (n x n) | l_x (n) | l_uu (m x m) | l_u (m) ].  A and B are COLUMN-major (as on the host):
+// the finite differences produce COLUMNS, so k_fd_difference writes every job as one contiguous run of n doubles whatever
+// the key-point pattern (with ragged per-DoF key-points a row-major record made every column n scattered 8-byte stores:
+// n = 62, 26 % ragged key-points: 12.9 ms -> see DESIGN.md section 4.1), the interpolation walkers read contiguous
+// runs, and the forward sweeps' A' operand is contiguous along lanes; the backward sweeps' tile loads become four
+// consecutive rows (32 B) per lane quad.  l_xx and l_uu are symmetric, row-major.  Record stride is padded to 16 doubles
+// (128 B).  a(row, col) / b(row, col): element offsets inside a record.
 struct RecLayout {
     int n, m;
     int off_A, off_B, off_lxx, off_lx, off_luu, off_lu;
@@ -31,6 +35,8 @@ struct RecLayout {
         rec = off_lu + m;
         stride = (rec + 15) & ~15;
     }
+    __host__ __device__ int a(int row, int col) const { return off_A + col * n + row; }
+    __host__ __device__ int b(int row, int col) const { return off_B + col * n + row; }
 };
 
 struct Ctx {
@@ -87,11 +93,6 @@ struct Ctx {
     char *fd_dev = nullptr;
     size_t fd_dev_cap = 0;                 // bytes
     int njobs = 0, nnom = 0;
-    int nslots = 0;                        // slot = run of consecutive jobs with one (b, t); < 0: the count lives in nslots_dev
-    int *slot_start = nullptr;             // [nslots+1] (device)
-    int *nslots_dev = nullptr;             // device int: slot count when the table was built on the device
-    int *slot_scratch = nullptr;           // per-1024-job block counts / offsets of the device slot build
-    size_t slot_scratch_cap = 0;           // ints
     int *job_b = nullptr, *job_t = nullptr, *job_col = nullptr, *job_nom = nullptr;
     unsigned char *job_mode = nullptr;
     double *xplus = nullptr, *xminus = nullptr, *xnom = nullptr;
@@ -149,10 +150,8 @@ Ctx::Tuning read_tuning_from_env();
 // ---- launchers (defined in the .hip files) --------------------------------------------------
 // elementwise.hip
 hipError_t launch_fd_difference(Ctx *c);
-hipError_t launch_build_slots(Ctx *c);
 hipError_t launch_copy_out(hipStream_t s, double *dst_host, const double *src_dev, size_t count);   // D2H by a kernel
-hipError_t launch_copy_in(hipStream_t s, void *dst_dev, const void *src_host, size_t bytes);        // H2D by a kernel       // slot table + count from job_b / job_t, on the device
-int fd_difference_waves(int n, int m);       // 0: the dims do not fit the kernel's LDS image
+hipError_t launch_copy_in(hipStream_t s, void *dst_dev, const void *src_host, size_t bytes);        // H2D by a kernel
 hipError_t launch_build_segmap(Ctx *c);
 // comm.cpp (RCCL opened lazily) and the pack kernel of elementwise.hip
 const char *comm_unique_id(char *id128);

@@ -14,219 +14,82 @@
 namespace kpilqr {
 
 // ---------------------------------------------------------------------------------------------
-// a2.  Jobs arrive grouped by key-point: a "slot" is a maximal run of consecutive jobs with the same
-// (trajectory, time).  One wavefront per slot: phase 1 streams the slot's x+/x- rows (contiguous in
-// job order) and parks the differenced columns in LDS; phase 2 streams them out in the row-major
-// order of the record's [A|B] block, so both the HBM reads and the HBM writes are coalesced.
-// Columns the slot does not hold are left untouched (ragged key-points).
-#define FD_WAVES 4
+// a2.  One job = one perturbed column: n values, contiguous in x+/x- AND -- A, B being column-major in the record --
+// contiguous at their destination.  The kernel is job-parallel: a lane owns one 16-byte pair of one job (n = 2 dof is
+// even), the flat (job, pair) index runs over the whole payload, so the reads of x+/x- are perfectly coalesced and every
+// job is one run of n doubles on the write side, whatever the key-point pattern (full rows of set_interval or the
+// ragged per-DoF lists of adaptive_jerk / iterative_error).  No LDS, no slot table.  Indices are validated here (a bad one
+// would be an out-of-bounds write): an invalid job is skipped and the context's error flag raised -- the host never
+// walks the job arrays.  Columns no job holds are left untouched.
 // error bits raised by the device-side checks (Ctx::err_flag, reported by kpilqr_sync)
 #define KP_ERRBIT_FD_INDEX 1        // FD job with trajectory / time / column / mode / nominal row out of range
-
-// The slot count is either known on the host (`nslots`, the caller handed the slot table over) or lives on the device
-// (`nslots_ptr`, written by k_slots_write): the blocks stride over the slots, so the launch never needs it on the host.
-// Indices are validated here (a bad one would be an out-of-bounds write): an invalid slot or job is skipped and the
-// context's error flag raised -- the host never walks the job arrays.
-__global__ void __launch_bounds__(64 * FD_WAVES)
-k_fd_difference(RecLayout L, int T, int batch, int nnom, int nslots, const int *__restrict__ nslots_ptr,
-                const int *__restrict__ slot_start,
+#define FD_UNROLL 4
+__global__ void __launch_bounds__(256)
+k_fd_difference(RecLayout L, int T, int batch, int nnom, long long npairs_total, unsigned long long np_magic,
                 const int *__restrict__ job_b, const int *__restrict__ job_t,
                 const int *__restrict__ job_col, const unsigned char *__restrict__ job_mode,
                 const int *__restrict__ job_nom,
                 const double *__restrict__ xplus, const double *__restrict__ xminus,
                 const double *__restrict__ xnom, double eps, double *__restrict__ rec, int *__restrict__ err_flag)
 {
-    extern __shared__ __attribute__((aligned(16))) double sh[];
-    const int n = L.n, m = L.m, ncol = n + m, ne = n * n + n * m;
-    const int nw = blockDim.x >> 6;                              // 1..FD_WAVES waves per block (LDS budget)
-    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
-    const int ns = nslots_ptr ? *nslots_ptr : nslots;
-    double *sv = sh + wave * (ncol * n + ncol);          // [col][row] values, then per-column job id + 1
-    int *present = (int *)(sv + ncol * n);
-    for (int base = blockIdx.x * nw; base < ns; base += gridDim.x * nw) {        // block-uniform trip count
-    const int slot = base + wave;
-    bool live = slot < ns;
-    int j0 = 0, nj = 0, sb = 0, st = 0;
-    if (live) {
-        j0 = slot_start[slot]; nj = slot_start[slot + 1] - j0;
-        sb = job_b[j0]; st = job_t[j0];
-        if (nj < 0 || (unsigned)sb >= (unsigned)batch || (unsigned)st >= (unsigned)T) {
-            if (lane == 0) atomicOr(err_flag, KP_ERRBIT_FD_INDEX);
-            live = false; nj = 0;
-        }
-    }
-    for (int cidx = lane; cidx < ncol; cidx += 64) present[cidx] = 0;
-    __syncthreads();
-    // eight elements per lane per trip as four 16-byte pairs (n = 2*dof is even, so a pair never straddles two jobs): the
-    // eight loads are issued before the first division, so a trip exposes one memory latency instead of eight (few waves
-    // are resident when the per-slot LDS image is large, n = 62)
-    const int npair = (nj * n) >> 1;
-    const double2 *xp2 = (const double2 *)(xplus + (size_t)j0 * n), *xm2 = (const double2 *)(xminus + (size_t)j0 * n);
-    for (int w0 = lane; w0 < npair; w0 += 4 * 64) {
-        double2 xp[4], xm[4];
-        int jobs_[4], rows_[4], modes_[4];
+    const int n = L.n, ncol = n + L.m, np = n >> 1;
+    const double2 *xp2 = (const double2 *)xplus, *xm2 = (const double2 *)xminus;
+    const long long stride = (long long)gridDim.x * blockDim.x;
+    for (long long w0 = (long long)blockIdx.x * blockDim.x + threadIdx.x; w0 < npairs_total; w0 += FD_UNROLL * stride) {
+        double2 xp[FD_UNROLL], xm[FD_UNROLL];
+        int job[FD_UNROLL], row[FD_UNROLL];
+        // the loads of a trip are issued before anything depends on them: one memory latency per trip, not FD_UNROLL
 #pragma unroll
-        for (int u = 0; u < 4; u++) {
-            const int w = w0 + 64 * u;
-            const bool ok = w < npair;
-            const int j = ok ? (2 * w) / n : 0;
-            rows_[u] = ok ? 2 * w - j * n : -1;
-            jobs_[u] = j0 + j;
+        for (int u = 0; u < FD_UNROLL; u++) {
+            const long long w = w0 + u * stride;
+            const bool ok = w < npairs_total;
+            // w / np by the multiply-high of ceil(2^64 / np) (exact for every w this kernel can see; np == 1: magic 0)
+            const long long q = np_magic ? (long long)__umul64hi((unsigned long long)w, np_magic) : w;
+            job[u] = ok ? (int)q : -1;
+            row[u] = ok ? 2 * (int)(w - q * np) : 0;
             xp[u] = ok ? xp2[w] : make_double2(0.0, 0.0);
             xm[u] = ok ? xm2[w] : make_double2(0.0, 0.0);
-            modes_[u] = ok ? job_mode[jobs_[u]] : 0;
         }
 #pragma unroll
-        for (int u = 0; u < 4; u++) {
-            if (rows_[u] < 0) continue;
-            const int job = jobs_[u], row = rows_[u], mode = modes_[u];
-            const int col = job_col[job];
-            if ((unsigned)col >= (unsigned)ncol || mode > 2) { atomicOr(err_flag, KP_ERRBIT_FD_INDEX); continue; }
+        for (int u = 0; u < FD_UNROLL; u++) {
+            const int j = job[u];
+            if (j < 0) continue;
+            const int sb = job_b[j], st = job_t[j], col = job_col[j], mode = job_mode[j];
+            if ((unsigned)sb >= (unsigned)batch || (unsigned)st >= (unsigned)T || (unsigned)col >= (unsigned)ncol || mode > 2) {
+                atomicOr(err_flag, KP_ERRBIT_FD_INDEX);
+                continue;
+            }
             double v0, v1;
             if (mode == 0) {
                 v0 = (xp[u].x - xm[u].x) / (2 * eps);
                 v1 = (xp[u].y - xm[u].y) / (2 * eps);
             } else {
-                const int nom = job_nom[job];
+                const int nom = job_nom[j];
                 if ((unsigned)nom >= (unsigned)nnom) { atomicOr(err_flag, KP_ERRBIT_FD_INDEX); continue; }
-                const double *x0 = xnom + (size_t)nom * n + row;
+                const double *x0 = xnom + (size_t)nom * n + row[u];
                 v0 = (mode == 1) ? (xp[u].x - x0[0]) / (eps) : (x0[0] - xm[u].x) / (eps);
                 v1 = (mode == 1) ? (xp[u].y - x0[1]) / (eps) : (x0[1] - xm[u].y) / (eps);
             }
-            sv[col * n + row] = v0;
-            sv[col * n + row + 1] = v1;
-            if (row == 0) present[col] = 1;
+            // column `col` of [A|B]: A column col at off_A + col*n, B column col-n at off_B + (col-n)*n = off_A + col*n
+            double *dst = rec + ((size_t)sb * T + st) * L.stride + L.off_A + (size_t)col * n + row[u];
+            *(double2 *)dst = make_double2(v0, v1);             // record stride, n and row are even: 16-byte aligned
         }
     }
-    __syncthreads();
-    if (live) {
-        double *R = rec + ((size_t)sb * T + st) * L.stride;
-        // A block: two adjacent columns of a row per lane (n is even and the record is 128-byte aligned: one 16-byte store
-        // when both columns are held by the slot); B block: one element per lane
-        for (int e2 = lane; e2 < (n * n) >> 1; e2 += 64) {
-            const int e = 2 * e2, row = e / n, col = e - row * n;
-            const bool p0 = present[col] != 0, p1 = present[col + 1] != 0;
-            const double v0 = sv[col * n + row], v1 = sv[(col + 1) * n + row];
-            if (p0 && p1) *(double2 *)(R + e) = make_double2(v0, v1);
-            else if (p0) R[e] = v0;
-            else if (p1) R[e + 1] = v1;
-        }
-        for (int e = n * n + lane; e < ne; e += 64) {
-            const int q = e - n * n, row = q / m, col = n + (q - row * m);
-            if (present[col]) R[e] = sv[col * n + row];
-        }
-    }
-    __syncthreads();                                            // the LDS image is reused by the next trip
-    }
-}
-
-// waves per block of k_fd_difference: as many slot images ((n+m)(n+1) doubles each) as fit in half of the CU's 160 KB of
-// LDS (two blocks resident), at most FD_WAVES; 0 = not even one image fits (kpilqr_create refuses such dims)
-int fd_difference_waves(int n, int m)
-{
-    const size_t per_wave = sizeof(double) * (size_t)(n + m) * (n + 1);
-    if (per_wave > 160 * 1024) return 0;
-    int w = (int)((80 * 1024) / per_wave);
-    if (w < 1) w = 1;
-    return w > FD_WAVES ? FD_WAVES : w;
 }
 
 hipError_t launch_fd_difference(Ctx *c)
 {
-    if (c->njobs == 0 || c->nslots == 0) return hipSuccess;
-    const int ncol = c->n + c->d.m;
-    const int nw = fd_difference_waves(c->n, c->d.m);
-    if (nw < 1) return hipErrorInvalidValue;
-    const size_t lds = sizeof(double) * nw * (ncol * c->n + ncol);
-    // slot count on the host: one trip per block; on the device (c->nslots < 0): a fixed grid that strides over the slots
-    const bool on_dev = c->nslots < 0;
-    int blocks = on_dev ? (c->n_simd / 4) * 8 : (c->nslots + nw - 1) / nw;
-    if (on_dev) { const int ub = (c->njobs + nw - 1) / nw; if (blocks > ub) blocks = ub; }
-    if (lds > 64 * 1024) {
-        hipError_t e = hipFuncSetAttribute((const void *)k_fd_difference, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-        if (e != hipSuccess) return e;
-    }
-    hipLaunchKernelGGL(k_fd_difference, dim3(blocks), dim3(64 * nw), lds, c->stream, c->L, c->d.T, c->fd_batch_total, c->nnom,
-                       on_dev ? 0 : c->nslots, on_dev ? c->nslots_dev : nullptr,
-                       c->slot_start, c->job_b, c->job_t, c->job_col, c->job_mode, c->job_nom, c->xplus,
-                       c->xminus, c->xnom, c->eps, c->rec_fd_base, c->err_flag);
-    return hipGetLastError();
-}
-
-// ---- slot table on the device: a slot starts at job j when j == 0 or (job_b, job_t) differs from job j-1 -----------------
-// count per block -> exclusive scan of the block counts (one block) -> each block writes its starts in order.
-#define SLOT_BLOCK 1024
-__device__ __forceinline__ bool slot_head(const int *job_b, const int *job_t, int j)
-{
-    return j == 0 || job_b[j] != job_b[j - 1] || job_t[j] != job_t[j - 1];
-}
-__global__ void __launch_bounds__(256)
-k_slots_count(int njobs, const int *__restrict__ job_b, const int *__restrict__ job_t, int *__restrict__ block_count)
-{
-    __shared__ int part[256];
-    const int j0 = blockIdx.x * SLOT_BLOCK;
-    int cnt = 0;
-    for (int i = threadIdx.x; i < SLOT_BLOCK; i += 256) { const int j = j0 + i; if (j < njobs && slot_head(job_b, job_t, j)) cnt++; }
-    part[threadIdx.x] = cnt;
-    __syncthreads();
-    for (int s = 128; s > 0; s >>= 1) { if (threadIdx.x < s) part[threadIdx.x] += part[threadIdx.x + s]; __syncthreads(); }
-    if (threadIdx.x == 0) block_count[blockIdx.x] = part[0];
-}
-__global__ void __launch_bounds__(1024)
-k_slots_scan(int nblocks, int njobs, int *__restrict__ block_count, int *__restrict__ nslots_out, int *__restrict__ slot_start)
-{
-    __shared__ int part[1024];
-    __shared__ int carry;
-    if (threadIdx.x == 0) carry = 0;
-    __syncthreads();
-    for (int base = 0; base < nblocks; base += 1024) {
-        const int i = base + threadIdx.x;
-        const int v = i < nblocks ? block_count[i] : 0;
-        part[threadIdx.x] = v;
-        __syncthreads();
-        for (int off = 1; off < 1024; off <<= 1) {               // Hillis-Steele inclusive scan
-            const int add = threadIdx.x >= off ? part[threadIdx.x - off] : 0;
-            __syncthreads();
-            part[threadIdx.x] += add;
-            __syncthreads();
-        }
-        if (i < nblocks) block_count[i] = carry + part[threadIdx.x] - v;      // exclusive offset of block i
-        __syncthreads();
-        if (threadIdx.x == 1023) carry += part[1023];
-        __syncthreads();
-    }
-    if (threadIdx.x == 0) { *nslots_out = carry; slot_start[carry] = njobs; }
-}
-__global__ void __launch_bounds__(256)
-k_slots_write(int njobs, const int *__restrict__ job_b, const int *__restrict__ job_t, const int *__restrict__ block_offset,
-              int *__restrict__ slot_start)
-{
-    __shared__ int part[256];
-    const int j0 = blockIdx.x * SLOT_BLOCK + threadIdx.x * 4;                // four consecutive jobs per thread
-    bool h[4];
-    int cnt = 0;
-#pragma unroll
-    for (int u = 0; u < 4; u++) { const int j = j0 + u; h[u] = j < njobs && slot_head(job_b, job_t, j); cnt += h[u]; }
-    part[threadIdx.x] = cnt;
-    __syncthreads();
-    for (int off = 1; off < 256; off <<= 1) {
-        const int add = threadIdx.x >= off ? part[threadIdx.x - off] : 0;
-        __syncthreads();
-        part[threadIdx.x] += add;
-        __syncthreads();
-    }
-    int at = block_offset[blockIdx.x] + part[threadIdx.x] - cnt;
-#pragma unroll
-    for (int u = 0; u < 4; u++) if (h[u]) slot_start[at++] = j0 + u;
-}
-
-hipError_t launch_build_slots(Ctx *c)
-{
     if (c->njobs == 0) return hipSuccess;
-    const int nb = (c->njobs + SLOT_BLOCK - 1) / SLOT_BLOCK;
-    hipLaunchKernelGGL(k_slots_count, dim3(nb), dim3(256), 0, c->stream, c->njobs, c->job_b, c->job_t, c->slot_scratch);
-    hipLaunchKernelGGL(k_slots_scan, dim3(1), dim3(1024), 0, c->stream, nb, c->njobs, c->slot_scratch, c->nslots_dev, c->slot_start);
-    hipLaunchKernelGGL(k_slots_write, dim3(nb), dim3(256), 0, c->stream, c->njobs, c->job_b, c->job_t, c->slot_scratch, c->slot_start);
+    const int np = c->n >> 1;
+    const long long npairs = (long long)c->njobs * np;
+    const unsigned long long magic = np > 1 ? ~0ULL / (unsigned)np + 1ULL : 0ULL;
+    // measured on the headline payload (90 M pairs): 16 blocks per CU 1.06 ms, 32: 0.92, 64 and beyond: 0.85 (5.1 TB/s);
+    // block-contiguous chunks instead of the grid stride 0.94-1.03, non-temporal loads 1.18
+    const long long want = (npairs + 256LL * FD_UNROLL - 1) / (256LL * FD_UNROLL);
+    const long long cap = (long long)(c->n_simd / 4) * 128;
+    const int blocks = (int)(want < cap ? (want < 1 ? 1 : want) : cap);
+    hipLaunchKernelGGL(k_fd_difference, dim3(blocks), dim3(256), 0, c->stream, c->L, c->d.T, c->fd_batch_total, c->nnom, npairs, magic,
+                       c->job_b, c->job_t, c->job_col, c->job_mode, c->job_nom, c->xplus, c->xminus, c->xnom, c->eps, c->rec_fd_base, c->err_flag);
     return hipGetLastError();
 }
 
@@ -293,45 +156,29 @@ k_interpolate(RecLayout L, int dof, int T, const int2 *__restrict__ segmap, doub
         ssm[w] = (tt < nt) ? sm[(size_t)i * T + t0 + tt] : make_int2(-1, -1);
     }
     __syncthreads();
-    // each thread owns two consecutive elements (16-byte stores); they belong to different DoFs
+    // each thread owns two consecutive elements (16-byte stores): two rows of ONE column (A, B are column-major and n is
+    // even), so both follow the key-point list of that column's DoF
     for (int e = 2 * threadIdx.x; e < ne; e += 2 * blockDim.x) {
-        int i0, i1;
-        {
-            const int ea = e, eb = e + 1;
-            if (ea < n * n) { const int col = ea % n; i0 = col < dof ? col : col - dof; }
-            else            { const int col = (ea - n * n) % m; i0 = col < dof ? col : -1; }
-            if (eb < n * n) { const int col = eb % n; i1 = col < dof ? col : col - dof; }
-            else            { const int col = (eb - n * n) % m; i1 = col < dof ? col : -1; }
-        }
-        int cs0 = -2, ce0 = -2, cs1 = -2, ce1 = -2;
-        double vs0 = 0.0, add0 = 0.0, vs1 = 0.0, add1 = 0.0;
+        const int col = e / n;                                   // 0..n-1: A column; n..n+m-1: B column col-n
+        const int i = col < dof ? col : col < n ? col - dof : (col - n < dof ? col - n : -1);
+        if (i < 0) continue;                                     // B column of an actuator beyond the DoFs: not interpolated
+        int cs = -2, ce = -2;
+        double2 vs = make_double2(0.0, 0.0), add = vs;
         for (int tt = 0; tt < nt; tt++) {
             const int t = t0 + tt;
-            const int2 s0 = i0 >= 0 ? ssm[i0 * INTERP_TT + tt] : make_int2(-1, -1);
-            const int2 s1 = i1 >= 0 ? ssm[i1 * INTERP_TT + tt] : make_int2(-1, -1);
-            if (s0.x >= 0 && (s0.x != cs0 || s0.y != ce0)) {
-                cs0 = s0.x; ce0 = s0.y;
-                vs0 = R[(size_t)cs0 * L.stride + e];
-                const double ve = R[(size_t)ce0 * L.stride + e];
-                add0 = (ve - vs0) / (double)(ce0 - cs0);
+            const int2 sg = ssm[i * INTERP_TT + tt];
+            if (sg.x < 0) continue;
+            if (sg.x != cs || sg.y != ce) {
+                cs = sg.x; ce = sg.y;
+                vs = *reinterpret_cast<const double2 *>(R + (size_t)cs * L.stride + e);     // record stride and e are even: 16-B aligned
+                const double2 ve = *reinterpret_cast<const double2 *>(R + (size_t)ce * L.stride + e);
+                add.x = (ve.x - vs.x) / (double)(ce - cs);
+                add.y = (ve.y - vs.y) / (double)(ce - cs);
             }
-            if (s1.x >= 0 && (s1.x != cs1 || s1.y != ce1)) {
-                cs1 = s1.x; ce1 = s1.y;
-                vs1 = R[(size_t)cs1 * L.stride + e + 1];
-                const double ve = R[(size_t)ce1 * L.stride + e + 1];
-                add1 = (ve - vs1) / (double)(ce1 - cs1);
-            }
-            double *dst = R + (size_t)t * L.stride + e;
-            if (s0.x >= 0 && s1.x >= 0) {
-                double2 v;
-                v.x = vs0 + ((double)(t - cs0) * add0);
-                v.y = vs1 + ((double)(t - cs1) * add1);
-                *reinterpret_cast<double2 *>(dst) = v;          // record stride and e are even: 16-B aligned
-            } else if (s0.x >= 0) {
-                dst[0] = vs0 + ((double)(t - cs0) * add0);
-            } else if (s1.x >= 0) {
-                dst[1] = vs1 + ((double)(t - cs1) * add1);
-            }
+            double2 v;
+            v.x = vs.x + ((double)(t - cs) * add.x);
+            v.y = vs.y + ((double)(t - cs) * add.y);
+            *reinterpret_cast<double2 *>(R + (size_t)t * L.stride + e) = v;
         }
     }
 }
@@ -588,9 +435,9 @@ hipError_t launch_trajectory_cost(Ctx *c)
 
 // ---------------------------------------------------------------------------------------------
 // Optimiser::FilterDynamicsMatrices (src/Optimiser/Optimiser.cpp:340-406): the velocity rows (dof..2dof-1) of A,
-// every column, filtered along time, in place.  One thread per matrix element walks the horizon (the rows form
-// one contiguous run of dof*n doubles per record, so a wavefront's loads and stores are coalesced); the
-// recurrences are the reference's, operation for operation (no contraction in this file).
+// every column, filtered along time, in place.  One thread per matrix element walks the horizon (column-major A: the
+// velocity rows of a column are one contiguous run of dof doubles per record); the recurrences are the reference's,
+// operation for operation (no contraction in this file).
 //   method 0: low-pass  y_k = ((1-a) y_{k-1}) + a ((x_k + x_{k-1})/2),  y_-1 = x_-1 = x_0        (:372-388)
 //   method 1: FIR       y_k = sum_c x_{k-c} coef_c over k-c >= 0, accumulated from 0 in c order    (:390-406)
 #define FIR_MAX 16
@@ -601,7 +448,8 @@ k_filter_dynamics(RecLayout L, int dof, int T, int method, const double *__restr
     const int b = blockIdx.y;
     const int e = blockIdx.x * blockDim.x + threadIdx.x;
     if (e >= ne) return;
-    double *p = rec + (size_t)b * T * L.stride + L.off_A + dof * n + e;
+    const int col = e / dof, row = dof + (e - col * dof);
+    double *p = rec + (size_t)b * T * L.stride + L.a(row, col);
     if (method == 0) {
         const double a = coefs[0];
         double yn1 = p[0], xn1 = yn1;
@@ -745,15 +593,15 @@ k_pack_AB(RecLayout L, long long nbt, const double *__restrict__ A, const double
         const long long bt = idx / ne;
         const int e = (int)(idx - bt * ne);
         double *R = rec + (size_t)bt * L.stride;
+        // host and record layouts agree (column-major per matrix): element for element
         if (e < n * n) {
             if (!A) continue;
-            const int row = e / n, col = e - row * n;
-            double *a = const_cast<double *>(A) + (size_t)bt * n * n + row + (size_t)col * n;
+            double *a = const_cast<double *>(A) + (size_t)bt * n * n + e;
             if (to_rec) R[L.off_A + e] = *a; else *a = R[L.off_A + e];
         } else {
             if (!B) continue;
-            const int q = e - n * n, row = q / m, col = q - row * m;
-            double *p = const_cast<double *>(B) + (size_t)bt * n * m + row + (size_t)col * n;
+            const int q = e - n * n;
+            double *p = const_cast<double *>(B) + (size_t)bt * n * m + q;
             if (to_rec) R[L.off_B + q] = *p; else *p = R[L.off_B + q];
         }
     }

@@ -65,9 +65,9 @@ __device__ __forceinline__ void forward_body(RecLayout L, int T, int n_alpha, co
         const int row = 4 * r + q;
         oK[r] = (row < n && c < m) ? 8 * (row * m + c) : OOB;            // K(i=c, p=row) at c + row*m
         ok_[r] = (row == n && c < m) ? 8 * c : OOB;                      // k(i=c)
-        oA[r] = (row < n && c < n) ? 8 * (L.off_A + c * n + row) : OOB;  // A(i=c, p=row)
+        oA[r] = (row < n && c < n) ? 8 * L.a(c, row) : OOB;  // A(i=c, p=row)
         oneA[r] = ((row == n && c == n) || (row == n + 1 && c == n + 1)) ? 1.0 : 0.0;
-        oB[r] = (row < m && c < n) ? 8 * (L.off_B + c * m + row) : OOB;  // B(i=c, p=row)
+        oB[r] = (row < m && c < n) ? 8 * L.b(c, row) : OOB;  // B(i=c, p=row)
         oLc[r] = (row < n && c < n) ? 8 * (L.off_lxx + row * n + c)
                : (row == n + 1 && c < n) ? 8 * (L.off_lx + c)
                : (c == n + 1 && row < n) ? 8 * (L.off_lx + row) : OOB;

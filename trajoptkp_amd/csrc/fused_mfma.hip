@@ -149,8 +149,8 @@ __device__ __forceinline__ void backward_fused_body(double *sh, const double *pc
 #pragma unroll
     for (int r = 0; r < 4; r++) {
         const int row = 4 * r + q;
-        co.a[r] = (row < n && c < n) ? 8 * (L.off_A + row * n + c) : OOBF;
-        co.b[r] = (row < n && c < m) ? 8 * (L.off_B + row * m + c) : OOBF;
+        co.a[r] = (row < n && c < n) ? 8 * L.a(row, c) : OOBF;
+        co.b[r] = (row < n && c < m) ? 8 * L.b(row, c) : OOBF;
         oRx[r] = (row < nr && c < n) ? 8 * (row * n + c) : OOBF;      // Rz(k=row, c) = r_x[k][c]
         oR1[r] = (row < nr && c == n) ? 8 * row : OOBF;               //            ... | r[k] in column n
         oRu[r] = (row < nr && c < m) ? 8 * (row * m + c) : OOBF;      // Ru(k=row, c) = r_u[k][c]
@@ -522,7 +522,7 @@ __device__ __forceinline__ void fused2_role_U(double *sh, RecLayout L, FusedArgs
 #pragma unroll
         for (int r = 0; r < 4; r++) {
             const int row = 4 * r + q;
-            tr.offs[r] = (row < n && c < m) ? 8 * (L.off_B + row * m + c) : OOBF;
+            tr.offs[r] = (row < n && c < m) ? 8 * L.b(row, c) : OOBF;
             oRu[r] = (row < nr && c < m) ? 8 * (row * m + c) : OOBF;
             oR1[r] = (row < nr && c == n) ? 8 * row : OOBF;
             w2run[r] = (row < nr) ? 2.0 * F.w_run[row] : 0.0;
@@ -682,8 +682,8 @@ __device__ __forceinline__ void fused2_role_Z(double *sh, RecLayout L, FusedArgs
 #pragma unroll
         for (int r = 0; r < 4; r++) {
             const int row = 4 * r + q;
-            tr.offs[r] = (row < n && c < n) ? 8 * (L.off_A + row * n + c) : OOBF;
-            tr.offs[4 + r] = (row < n && c < m) ? 8 * (L.off_B + row * m + c) : OOBF;
+            tr.offs[r] = (row < n && c < n) ? 8 * L.a(row, c) : OOBF;
+            tr.offs[4 + r] = (row < n && c < m) ? 8 * L.b(row, c) : OOBF;
             oRx[r] = (row < nr && c < n) ? 8 * (row * n + c) : OOBF;
             oR1[r] = (row < nr && c == n) ? 8 * row : OOBF;
             w2run[r] = (row < nr) ? 2.0 * F.w_run[row] : 0.0;
@@ -808,8 +808,8 @@ __device__ __forceinline__ void fusedpc_producer(double *pcbuf, int *sflag, RecL
 #pragma unroll
         for (int r = 0; r < 4; r++) {
             const int row = 4 * r + q;
-            tr.offs[r] = (row < n && c < n) ? 8 * (L.off_A + row * n + c) : OOBF;
-            tr.offs[4 + r] = (row < n && c < m) ? 8 * (L.off_B + row * m + c) : OOBF;
+            tr.offs[r] = (row < n && c < n) ? 8 * L.a(row, c) : OOBF;
+            tr.offs[4 + r] = (row < n && c < m) ? 8 * L.b(row, c) : OOBF;
             oRx[r] = (row < nr && c < n) ? 8 * (row * n + c) : OOBF;
             oR1[r] = (row < nr && c == n) ? 8 * row : OOBF;
             oRu[r] = (row < nr && c < m) ? 8 * (row * m + c) : OOBF;
@@ -925,8 +925,8 @@ __device__ __forceinline__ void forward_fused_body(RecLayout L, FusedArgs F, int
 #pragma unroll
     for (int r = 0; r < 4; r++) {
         const int row = 4 * r + q;
-        co.a[r] = (row < n && c < n) ? 8 * (L.off_A + row * n + c) : OOBF;
-        co.b[r] = (row < n && c < m) ? 8 * (L.off_B + row * m + c) : OOBF;
+        co.a[r] = (row < n && c < n) ? 8 * L.a(row, c) : OOBF;
+        co.b[r] = (row < n && c < m) ? 8 * L.b(row, c) : OOBF;
         oK[r] = (row < n && c < m) ? 8 * (row * m + c) : OOBF;
         ok_[r] = (row == n && c < m) ? 8 * c : OOBF;
         oRxT[r] = (row < n && c < nr) ? 8 * (c * n + row) : OOBF;     // RxT(p=row, k=c) = r_x[k][p]
@@ -1256,8 +1256,8 @@ __device__ __forceinline__ void forward_sc_cost(double *sh, RecLayout L, FusedAr
 #pragma unroll
     for (int r = 0; r < 4; r++) {
         const int row = 4 * r + q;
-        co.a[r] = (row < n && c < n) ? 8 * (L.off_A + row * n + c) : OOBF;
-        co.b[r] = (row < n && c < m) ? 8 * (L.off_B + row * m + c) : OOBF;
+        co.a[r] = (row < n && c < n) ? 8 * L.a(row, c) : OOBF;
+        co.b[r] = (row < n && c < m) ? 8 * L.b(row, c) : OOBF;
         oRxT[r] = (row < n && c < nr) ? 8 * (c * n + row) : OOBF;     // RxT(p=row, k=c) = r_x[k][p]
         oRuT[r] = (row < m && c < nr) ? 8 * (c * m + row) : OOBF;     // RuT(p=row, k=c) = r_u[k][p]
         oR[r] = (row < nr) ? 8 * row : OOBF;

@@ -129,42 +129,42 @@ k_backward_generic(RecLayout L, int T, const double *__restrict__ rec, const dou
     int fail = 0;
     for (int t = T - 1; t >= 0; t--) {
         const double *R = R0 + (size_t)t * L.stride;
-        const double *A = R + L.off_A, *B = R + L.off_B;       // row-major: A(r,c) = A[r*n+c], B(r,c) = B[r*m+c]
+        const double *A = R + L.off_A, *B = R + L.off_B;       // column-major: A(r,c) = A[c*n+r], B(r,c) = B[c*n+r]
         pd_counter++;
         // -- Q_x, Q_u, A'V_xx, B'V_xx --------------------------------------------------  :570-579
         for (int e = tid; e < n * n; e += NT) {
             const int i = e % n, j = e / n;
             double s = 0.0;
-            for (int p = 0; p < n; p++) s += A[p * n + i] * Vxx[p + j * n];
+            for (int p = 0; p < n; p++) s += A[i * n + p] * Vxx[p + j * n];
             AtV[i + j * n] = s;
         }
         for (int e = tid; e < m * n; e += NT) {
             const int i = e % m, j = e / m;
             double s = 0.0;
-            for (int p = 0; p < n; p++) s += B[p * m + i] * Vxx[p + j * n];
+            for (int p = 0; p < n; p++) s += B[i * n + p] * Vxx[p + j * n];
             BtV[i + j * m] = s;
         }
         for (int i = tid; i < n; i += NT) {
             double s = 0.0;
-            for (int p = 0; p < n; p++) s += A[p * n + i] * Vx[p];
+            for (int p = 0; p < n; p++) s += A[i * n + p] * Vx[p];
             Qx[i] = R[L.off_lx + i] + s;
         }
         for (int i = tid; i < m; i += NT) {
             double s = 0.0;
-            for (int p = 0; p < n; p++) s += B[p * m + i] * Vx[p];
+            for (int p = 0; p < n; p++) s += B[i * n + p] * Vx[p];
             Qu[i] = R[L.off_lu + i] + s;
         }
         __syncthreads();
         for (int e = tid; e < m * m; e += NT) {
             const int i = e % m, j = e / m;
             double s = 0.0;
-            for (int p = 0; p < n; p++) s += BtV[i + p * m] * B[p * m + j];
+            for (int p = 0; p < n; p++) s += BtV[i + p * m] * B[j * n + p];
             Quu[i + j * m] = R[L.off_luu + i * m + j] + s;
         }
         for (int e = tid; e < m * n; e += NT) {
             const int i = e % m, j = e / m;
             double s = 0.0;
-            for (int p = 0; p < n; p++) s += BtV[i + p * m] * A[p * n + j];
+            for (int p = 0; p < n; p++) s += BtV[i + p * m] * A[j * n + p];
             Qux[i + j * m] = s;
         }
         __syncthreads();
@@ -214,7 +214,7 @@ k_backward_generic(RecLayout L, int T, const double *__restrict__ rec, const dou
         for (int e = tid; e < n * n; e += NT) {
             const int i = e % n, j = e / n;
             double q = 0.0, s2 = 0.0, s3 = 0.0, s4 = 0.0;
-            for (int p = 0; p < n; p++) q += AtV[i + p * n] * A[p * n + j];
+            for (int p = 0; p < n; p++) q += AtV[i + p * n] * A[j * n + p];
             q = R[L.off_lxx + i * n + j] + q;
             for (int p = 0; p < m; p++) s2 += Kt[p + i * m] * G[p + j * m];
             for (int p = 0; p < m; p++) s3 += Kt[p + i * m] * Qux[p + j * m];
@@ -309,7 +309,7 @@ k_forward_generic(RecLayout L, int T, int n_alpha, const double *__restrict__ re
             for (int p = 0; p < n; p++) s += R[L.off_lxx + i * n + p] * dx[p];
             tv[i] = s;
             double s2 = 0.0;
-            for (int p = 0; p < n; p++) s2 += A[i * n + p] * dx[p];
+            for (int p = 0; p < n; p++) s2 += A[p * n + i] * dx[p];
             dxn[i] = s2;
         }
         __syncthreads();
@@ -320,7 +320,7 @@ k_forward_generic(RecLayout L, int T, int n_alpha, const double *__restrict__ re
         }
         for (int i = tid; i < n; i += NT) {
             double s = 0.0;
-            for (int p = 0; p < m; p++) s += B[i * m + p] * du[p];
+            for (int p = 0; p < m; p++) s += B[p * n + i] * du[p];
             dxn[i] = dxn[i] + s;
         }
         __syncthreads();

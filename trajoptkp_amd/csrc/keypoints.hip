@@ -174,8 +174,8 @@ k_kp_error_test(RecLayout L, int T, int batch, int dof, int n_iv, const int *__r
     for (int cc = 0; cc < 2; cc++) {
         const int col = cc == 0 ? i : i + dof;
         for (int j = dof; j < 2 * dof; j++) {
-            const double approx = (Rs[j * n + col] + Re[j * n + col]) / 2;
-            const double d = Rm[j * n + col] - approx;
+            const double approx = (Rs[col * n + j] + Re[col * n + j]) / 2;
+            const double d = Rm[col * n + j] - approx;
             error_sum += d * d;
             counter++;
         }

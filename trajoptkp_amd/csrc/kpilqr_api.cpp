@@ -200,8 +200,6 @@ int kpilqr_create(const kpilqr_dims *dims, void *stream, kpilqr_ctx **out)
                        std::string("no HIP device available (libkpilqr has no CPU fallback): ") +
                            (e != hipSuccess ? hipGetErrorString(e) : "device count 0"));
     if (dims->device < 0 || dims->device >= ndev) return set_err(nullptr, KPILQR_ERR_ARG, "device ordinal out of range");
-    if (fd_difference_waves(2 * dims->dof, dims->m) < 1)
-        return set_err(nullptr, KPILQR_ERR_ARG, "state/control dimensions too large: one key-point's FD columns ((n+m)(n+1) doubles) exceed the CU's 160 KB of LDS");
     if (hipSetDevice(dims->device) != hipSuccess) return set_err(nullptr, KPILQR_ERR_NO_DEVICE, "hipSetDevice failed");
 
     kpilqr_ctx *c = new (std::nothrow) kpilqr_ctx();
@@ -230,7 +228,6 @@ int kpilqr_create(const kpilqr_dims *dims, void *stream, kpilqr_ctx **out)
     }
     hipError_t rc = hipSuccess;
 #define TRY(x) do { if (rc == hipSuccess) rc = (x); } while (0)
-    TRY(dalloc(&c->nslots_dev, 1));
     TRY(dalloc(&c->err_flag, 1));
     TRY(hipHostMalloc((void **)&c->err_flag_host, sizeof(int), hipHostMallocDefault));
 #undef TRY
@@ -240,7 +237,6 @@ int kpilqr_create(const kpilqr_dims *dims, void *stream, kpilqr_ctx **out)
         return set_err(nullptr, KPILQR_ERR_ALLOC, msg);
     }
     (void)hipMemsetAsync(c->err_flag, 0, sizeof(int), c->stream);
-    (void)hipMemsetAsync(c->nslots_dev, 0, sizeof(int), c->stream);
     {
         const int rcv = select_variants(c);
         if (rcv != KPILQR_OK) { const std::string msg = c->err; kpilqr_destroy(c); return set_err(nullptr, rcv, msg); }
@@ -265,7 +261,7 @@ void kpilqr_destroy(kpilqr_ctx *c)
     void *ptrs[] = {c->rec, c->K, c->k, c->r, c->r_x, c->r_u, c->w_run, c->w_term, c->u_nom, c->ctrl_lim,
                     c->lambda, c->alphas, c->cost_pred, c->delta_J, c->traj_cost, c->status, c->segmap,
                     c->kp_offsets, c->kp_times, c->X_states, c->kp_thr, c->kp_mask, c->kp_count, c->ls8, c->fd_dev,
-                    c->stage, c->nslots_dev, c->slot_scratch, c->err_flag};
+                    c->stage, c->err_flag};
     for (void *p : ptrs) if (p) (void)hipFree(p);
     if (c->err_flag_host) (void)hipHostFree(c->err_flag_host);
     if (c->own_stream) (void)hipStreamDestroy(c->stream);
@@ -287,8 +283,6 @@ int kpilqr_resize(kpilqr_ctx *c, int new_dof, int new_num_ctrl, int new_horizon)
     if (!c) return KPILQR_ERR_ARG;
     KP_ENTER(c);
     if (new_dof < 1 || new_num_ctrl < 1 || new_horizon < 2) return set_err(c, KPILQR_ERR_ARG, "dims out of range");
-    if (fd_difference_waves(2 * new_dof, new_num_ctrl) < 1)
-        return set_err(c, KPILQR_ERR_ARG, "state/control dimensions too large: one key-point's FD columns ((n+m)(n+1) doubles) exceed the CU's 160 KB of LDS");
     KP_HIP(c, hipStreamSynchronize(c->stream));          // nothing in flight still uses the old layout
     const kpilqr_dims old = c->d;
     c->d.dof = new_dof; c->d.m = new_num_ctrl; c->d.T = new_horizon;
@@ -301,7 +295,7 @@ int kpilqr_resize(kpilqr_ctx *c, int new_dof, int new_num_ctrl, int new_horizon)
         return set_err(c, rc, msg);
     }
     c->have_kp = c->kp_canonical = c->have_states = false;
-    c->njobs = c->nnom = c->nslots = 0;
+    c->njobs = c->nnom = 0;
     c->ru_zero = true;                                   // size_buffers zeroed r_u
     if (c->X_states) { KP_HIP(c, hipFree(c->X_states)); c->X_states = nullptr; }
     if (c->kp_mask) { KP_HIP(c, hipFree(c->kp_mask)); c->kp_mask = nullptr; }
@@ -488,9 +482,9 @@ int kpilqr_get_keypoints(kpilqr_ctx *c, int *kp_offsets, int *kp_times, int time
 
 static size_t al16(size_t x) { return (x + 15) & ~(size_t)15; }
 
-static void fd_layout(int n, int njobs, int nnom, int nslots, kpilqr_fd_layout *L)
+static void fd_layout(int n, int njobs, int nnom, kpilqr_fd_layout *L)
 {
-    const size_t J = (size_t)njobs, N = (size_t)nnom, S = (size_t)(nslots > 0 ? nslots : njobs) + 1;
+    const size_t J = (size_t)njobs, N = (size_t)nnom;
     size_t o = 0;
     L->xplus = o; o = al16(o + J * n * sizeof(double));
     L->xminus = o; o = al16(o + J * n * sizeof(double));
@@ -499,22 +493,21 @@ static void fd_layout(int n, int njobs, int nnom, int nslots, kpilqr_fd_layout *
     L->job_t = o; o = al16(o + J * sizeof(int));
     L->job_col = o; o = al16(o + J * sizeof(int));
     L->job_nom = o; o = al16(o + J * sizeof(int));
-    L->slot_start = o; o = al16(o + S * sizeof(int));
     L->job_mode = o; o = al16(o + J);
     L->bytes = o;
 }
 
-int kpilqr_fd_slab_layout(kpilqr_ctx *c, int njobs, int nnom, int nslots, kpilqr_fd_layout *out)
+int kpilqr_fd_slab_layout(kpilqr_ctx *c, int njobs, int nnom, kpilqr_fd_layout *out)
 {
-    if (!c || !out || njobs < 0 || nnom < 0 || nslots < 0) return KPILQR_ERR_ARG;
-    fd_layout(c->n, njobs, nnom, nslots, out);
+    if (!c || !out || njobs < 0 || nnom < 0) return KPILQR_ERR_ARG;
+    fd_layout(c->n, njobs, nnom, out);
     return KPILQR_OK;
 }
 
-// device slab with the layout of (njobs, nnom, nslots); grows (with a stream sync) only when it has to
-static int fd_bind(kpilqr_ctx *c, int njobs, int nnom, int nslots, kpilqr_fd_layout *L)
+// device slab with the layout of (njobs, nnom); grows (with a stream sync) only when it has to
+static int fd_bind(kpilqr_ctx *c, int njobs, int nnom, kpilqr_fd_layout *L)
 {
-    fd_layout(c->n, njobs, nnom, nslots, L);
+    fd_layout(c->n, njobs, nnom, L);
     if (L->bytes > c->fd_dev_cap) {
         KP_HIP(c, hipStreamSynchronize(c->stream));
         if (c->fd_dev) KP_HIP(c, hipFree(c->fd_dev));
@@ -526,16 +519,8 @@ static int fd_bind(kpilqr_ctx *c, int njobs, int nnom, int nslots, kpilqr_fd_lay
     char *base = c->fd_dev;
     c->xplus = (double *)(base + L->xplus); c->xminus = (double *)(base + L->xminus); c->xnom = (double *)(base + L->xnom);
     c->job_b = (int *)(base + L->job_b); c->job_t = (int *)(base + L->job_t); c->job_col = (int *)(base + L->job_col);
-    c->job_nom = (int *)(base + L->job_nom); c->slot_start = (int *)(base + L->slot_start);
+    c->job_nom = (int *)(base + L->job_nom);
     c->job_mode = (unsigned char *)(base + L->job_mode);
-    const size_t nb = (size_t)njobs / 1024 + 2;
-    if (nslots <= 0 && nb > c->slot_scratch_cap) {
-        KP_HIP(c, hipStreamSynchronize(c->stream));
-        if (c->slot_scratch) KP_HIP(c, hipFree(c->slot_scratch));
-        c->slot_scratch = nullptr; c->slot_scratch_cap = 0;
-        KP_HIP(c, dalloc(&c->slot_scratch, nb + nb / 4));
-        c->slot_scratch_cap = nb + nb / 4;
-    }
     return KPILQR_OK;
 }
 
@@ -551,7 +536,7 @@ int kpilqr_upload_fd(kpilqr_ctx *c, int njobs, const int *job_b, const int *job_
     if (!(eps > 0.0)) return set_err(c, KPILQR_ERR_ARG, "eps must be positive");
     const int n = c->n;
     kpilqr_fd_layout L;
-    int rc = fd_bind(c, njobs, nnom, 0, &L);
+    int rc = fd_bind(c, njobs, nnom, &L);
     if (rc) return rc;
     const size_t J = njobs;
     if (njobs) {
@@ -567,8 +552,6 @@ int kpilqr_upload_fd(kpilqr_ctx *c, int njobs, const int *job_b, const int *job_
     }
     if (nnom) KP_HIP(c, hipMemcpyAsync(c->xnom, xnom, (size_t)nnom * n * sizeof(double), hipMemcpyHostToDevice, c->stream));
     c->njobs = njobs; c->nnom = nnom; c->eps = eps;
-    c->nslots = njobs ? -1 : 0;                      // the table and its length are produced on the device
-    KP_HIP(c, launch_build_slots(c));
     // pageable sources: the caller may free them on return, so wait for the copies; pinned ones are read in place
     if (!(is_pinned(job_b) && is_pinned(job_t) && is_pinned(job_col) && is_pinned(job_mode) && is_pinned(job_nom) &&
           is_pinned(xplus) && is_pinned(xminus) && is_pinned(xnom)))
@@ -576,19 +559,16 @@ int kpilqr_upload_fd(kpilqr_ctx *c, int njobs, const int *job_b, const int *job_
     return KPILQR_OK;
 }
 
-int kpilqr_upload_fd_slab(kpilqr_ctx *c, const void *slab, int njobs, int nnom, int nslots, double eps)
+int kpilqr_upload_fd_slab(kpilqr_ctx *c, const void *slab, int njobs, int nnom, double eps)
 {
-    if (!c || njobs < 0 || nnom < 0 || nslots < 0 || (njobs > 0 && !slab)) return KPILQR_ERR_ARG;
+    if (!c || njobs < 0 || nnom < 0 || (njobs > 0 && !slab)) return KPILQR_ERR_ARG;
     KP_ENTER(c);
     if (!(eps > 0.0)) return set_err(c, KPILQR_ERR_ARG, "eps must be positive");
-    if (nslots > njobs) return set_err(c, KPILQR_ERR_ARG, "more slots than jobs");
     kpilqr_fd_layout L;
-    int rc = fd_bind(c, njobs, nnom, nslots, &L);
+    int rc = fd_bind(c, njobs, nnom, &L);
     if (rc) return rc;
     if (njobs) KP_HIP(c, hipMemcpyAsync(c->fd_dev, slab, L.bytes, hipMemcpyHostToDevice, c->stream));   // the one DMA
     c->njobs = njobs; c->nnom = nnom; c->eps = eps;
-    if (nslots > 0 || njobs == 0) c->nslots = nslots;
-    else { c->nslots = -1; KP_HIP(c, launch_build_slots(c)); }
     if (!is_pinned(slab)) KP_HIP(c, hipStreamSynchronize(c->stream));
     return KPILQR_OK;
 }
@@ -834,8 +814,8 @@ int kpilqr_iterate_streamed(kpilqr_ctx *c, const kpilqr_stream_io *io, int pd_ch
     const int B = c->d.batch;
     if (nchunks < 1) nchunks = Ctx::kPipeStreams;          // 0: one chunk per pipeline stream
     if (nchunks > B) nchunks = B;
-    if (io->fd_slab && (io->nslots < 1 || io->njobs < 1 || !io->traj_slot_first || (io->nnom > 0 && !io->traj_nom_first)))
-        return set_err(c, KPILQR_ERR_ARG, "streamed FD payload needs the slot table and the per-trajectory slot / nominal-row offsets");
+    if (io->fd_slab && (io->njobs < 1 || !io->traj_job_first || (io->nnom > 0 && !io->traj_nom_first)))
+        return set_err(c, KPILQR_ERR_ARG, "streamed FD payload needs the per-trajectory job / nominal-row offsets");
     if (io->r_u) c->ru_zero = false;
     const void *hostp[] = {io->fd_slab, io->r, io->r_x, io->r_u, io->u_nom, io->lambda, io->K, io->k, io->cost_pred, io->delta_J, io->status};
     for (const void *p : hostp) if (!is_pinned(p)) return set_err(c, KPILQR_ERR_ARG, "kpilqr_iterate_streamed: host buffers must be pinned (kpilqr_host_alloc)");
@@ -860,20 +840,19 @@ int kpilqr_iterate_streamed(kpilqr_ctx *c, const kpilqr_stream_io *io, int pd_ch
     if (slab) {
         // (re)bind the device slab; a growth synchronises every stream first
         kpilqr_fd_layout probe;
-        fd_layout(n, io->njobs, io->nnom, io->nslots, &probe);
+        fd_layout(n, io->njobs, io->nnom, &probe);
         if (probe.bytes > c->fd_dev_cap) {
             rc = join_pipeline(c); if (rc) return rc;
             for (int i = 0; i < Ctx::kPipeStreams; i++) KP_HIP(c, hipStreamSynchronize(c->pipe_stream[i]));
         }
-        rc = fd_bind(c, io->njobs, io->nnom, io->nslots, &L);
+        rc = fd_bind(c, io->njobs, io->nnom, &L);
         if (rc) return rc;
-        c->njobs = io->njobs; c->nnom = io->nnom; c->nslots = io->nslots; c->eps = io->eps;
-        if (io->traj_slot_first[0] != 0 || io->traj_slot_first[B] != io->nslots)
-            return set_err(c, KPILQR_ERR_ARG, "traj_slot_first must run from 0 to nslots");
+        c->njobs = io->njobs; c->nnom = io->nnom; c->eps = io->eps;
+        if (io->traj_job_first[0] != 0 || io->traj_job_first[B] != io->njobs)
+            return set_err(c, KPILQR_ERR_ARG, "traj_job_first must run from 0 to njobs");
     }
     // order the chunk streams behind whatever the caller enqueued on the context's stream so far (key-points, weights ...)
     KP_HIP(c, hipEventRecord(c->pipe_in, c->stream));
-    const int *h_slot = slab ? (const int *)(slab + L.slot_start) : nullptr;
 
     for (int ch = 0; ch < nchunks; ch++) {
         const int b0 = (int)((long long)B * ch / nchunks), b1 = (int)((long long)B * (ch + 1) / nchunks), nb = b1 - b0;
@@ -885,9 +864,8 @@ int kpilqr_iterate_streamed(kpilqr_ctx *c, const kpilqr_stream_io *io, int pd_ch
         const size_t o = b0, cnt = nb;
         // ---- H2D of the chunk ------------------------------------------------------------------------------------
         if (slab) {
-            const int s0 = io->traj_slot_first[b0], s1 = io->traj_slot_first[b1];
-            const int j0 = s0 < io->nslots ? h_slot[s0] : io->njobs, j1 = s1 < io->nslots ? h_slot[s1] : io->njobs;
-            if (s1 < s0 || j1 < j0 || j1 > io->njobs) return set_err(c, KPILQR_ERR_ARG, "slot table / traj_slot_first not monotone");
+            const int j0 = io->traj_job_first[b0], j1 = io->traj_job_first[b1];
+            if (j1 < j0 || j0 < 0 || j1 > io->njobs) return set_err(c, KPILQR_ERR_ARG, "traj_job_first not monotone");
             const size_t J = (size_t)(j1 - j0), jo = (size_t)j0;
             if (J) {
                 KP_HIP(c, h2d(c->xplus + jo * n, slab + L.xplus + jo * n * 8, J * n * 8, s));
@@ -897,16 +875,17 @@ int kpilqr_iterate_streamed(kpilqr_ctx *c, const kpilqr_stream_io *io, int pd_ch
                 KP_HIP(c, h2d(c->job_col + jo, slab + L.job_col + jo * 4, J * 4, s));
                 KP_HIP(c, h2d(c->job_nom + jo, slab + L.job_nom + jo * 4, J * 4, s));
                 KP_HIP(c, h2d(c->job_mode + jo, slab + L.job_mode + jo, J, s));
-                KP_HIP(c, h2d(c->slot_start + s0, slab + L.slot_start + (size_t)s0 * 4, (size_t)(s1 - s0 + 1) * 4, s));
             }
             if (io->nnom > 0) {
                 const int q0 = io->traj_nom_first[b0], q1 = io->traj_nom_first[b1];
                 if (q1 < q0 || q1 > io->nnom) return set_err(c, KPILQR_ERR_ARG, "traj_nom_first not monotone");
                 if (q1 > q0) KP_HIP(c, h2d(c->xnom + (size_t)q0 * n, slab + L.xnom + (size_t)q0 * n * 8, (size_t)(q1 - q0) * n * 8, s));
             }
-            v.slot_start = c->slot_start + s0; v.nslots = s1 - s0; v.njobs = (int)J;
+            // the chunk's jobs: a contiguous range of the job arrays
+            v.job_b = c->job_b + jo; v.job_t = c->job_t + jo; v.job_col = c->job_col + jo; v.job_nom = c->job_nom + jo;
+            v.job_mode = c->job_mode + jo; v.xplus = c->xplus + jo * n; v.xminus = c->xminus + jo * n; v.njobs = (int)J;
         } else {
-            v.njobs = 0; v.nslots = 0;      // no new FD payload: the key-point columns already in the records are reused
+            v.njobs = 0;                    // no new FD payload: the key-point columns already in the records are reused
         }
         if (io->r) KP_HIP(c, h2d(v.r, io->r + o * (T + 1) * nr, cnt * (T + 1) * nr * 8, s));
         if (io->r_x) KP_HIP(c, h2d(v.r_x, io->r_x + o * (T + 1) * nr * n, cnt * (T + 1) * nr * n * 8, s));

@@ -133,9 +133,9 @@ __device__ __forceinline__ void backward_body(RecLayout L, int T, const double *
 #pragma unroll
     for (int r = 0; r < 4; r++) {
         const int row = 4 * r + q;
-        o.fz[r] = (row < n && c < n) ? 8 * (L.off_A + row * n + c) : OOB;
+        o.fz[r] = (row < n && c < n) ? 8 * L.a(row, c) : OOB;
         one[r] = (row == n && c == n) ? 1.0 : 0.0;
-        o.fu[r] = (row < n && c < m) ? 8 * (L.off_B + row * m + c) : OOB;
+        o.fu[r] = (row < n && c < m) ? 8 * L.b(row, c) : OOB;
         o.lzz[r] = (row < n && c < n) ? 8 * (L.off_lxx + row * n + c)
                  : (c == n && row < n) ? 8 * (L.off_lx + row)
                  : (row == n && c < n) ? 8 * (L.off_lx + c) : OOB;

@@ -84,7 +84,7 @@ __device__ __forceinline__ d4 ld_Fz(__amdgpu_buffer_rsrc_t rs, const TileSrc &S,
 #pragma unroll
     for (int r = 0; r < 4; r++) {
         const int row = 16 * ti + 4 * r + q, col = 16 * tj + c, n = S.n;
-        v[r] = tbld(rs, (row < n && col < n) ? 8 * (S.off_A + row * n + col) : OOBT);
+        v[r] = tbld(rs, (row < n && col < n) ? 8 * (S.off_A + col * n + row) : OOBT);
     }
     d4 o = {v[0], v[1], v[2], v[3]};
     return o;
@@ -95,7 +95,7 @@ __device__ __forceinline__ d4 ld_Fu(__amdgpu_buffer_rsrc_t rs, const TileSrc &S,
 #pragma unroll
     for (int r = 0; r < 4; r++) {
         const int row = 16 * ti + 4 * r + q;
-        v[r] = tbld(rs, (row < S.n && c < S.m) ? 8 * (S.off_B + row * S.m + c) : OOBT);
+        v[r] = tbld(rs, (row < S.n && c < S.m) ? 8 * (S.off_B + c * S.n + row) : OOBT);
     }
     d4 o = {v[0], v[1], v[2], v[3]};
     return o;
@@ -258,12 +258,12 @@ k_backward_tiled_col(RecLayout L, CostSrc CS, KpSrc KP, int T, const double *__r
 #pragma unroll
             for (int r = 0; r < 4; r++) {
                 const int row = 16 * k + 4 * r + q;
-                trA.offs[4 * k + r] = (hasA && row < n) ? 8 * (L.off_A + row * n + colA) : KP_OOB;
+                trA.offs[4 * k + r] = (hasA && row < n) ? 8 * L.a(row, colA) : KP_OOB;
             }
 #pragma unroll
         for (int r = 0; r < 4; r++) {
             const int row = 16 * w + 4 * r + q;
-            trB.offs[r] = (hasB && row < n) ? 8 * (L.off_B + row * m + c) : KP_OOB;
+            trB.offs[r] = (hasB && row < n) ? 8 * L.b(row, c) : KP_OOB;
         }
         trA.init(rT, KP.kp_offsets, KP.kp_times, hasA, (size_t)b * dof + (hasA ? kdA : 0), T, strideB);
         trB.init(rT, KP.kp_offsets, KP.kp_times, hasB, (size_t)b * dof + (hasB ? c : 0), T, strideB);
@@ -622,7 +622,7 @@ k_forward_tiled(RecLayout L, CostSrc CS, KpSrc KP, int T, int n_alpha, const dou
 #pragma unroll
         for (int r = 0; r < 4; r++) {
             const int pp = 16 * k + 4 * r + q;
-            oA[k][r] = (pp < n && o < n) ? 8 * (L.off_A + o * n + pp) : OOBT;
+            oA[k][r] = (pp < n && o < n) ? 8 * L.a(o, pp) : OOBT;
             oLc[k][r] = (pp < n && o < n) ? 8 * (L.off_lxx + pp * n + o)
                       : (pp == n + 1 && o < n) ? 8 * (L.off_lx + o)
                       : (o == n + 1 && pp < n) ? 8 * (L.off_lx + pp) : OOBT;
@@ -635,7 +635,7 @@ k_forward_tiled(RecLayout L, CostSrc CS, KpSrc KP, int T, int n_alpha, const dou
         const int pw = 16 * wi + row;                                   // this wave's slice of the state index
         oKw[r] = (pw < n && c < m) ? 8 * (pw * m + c) : OOBT;
         okw[r] = (pw == n && c < m) ? 8 * c : OOBT;
-        oB[r] = (row < m && o < n) ? 8 * (L.off_B + o * m + row) : OOBT;
+        oB[r] = (row < m && o < n) ? 8 * L.b(o, row) : OOBT;
         oLuu[r] = (row < m && c < m) ? 8 * (L.off_luu + row * m + c) : OOBT;
         olu[r] = (row < m) ? 8 * (L.off_lu + row) : OOBT;
         oub[r] = (row < m) ? 8 * row : OOBT;
@@ -732,12 +732,12 @@ k_forward_tiled(RecLayout L, CostSrc CS, KpSrc KP, int T, int n_alpha, const dou
 #pragma unroll
             for (int r = 0; r < 4; r++) {
                 const int row = 16 * k + 4 * r + q;
-                trA.offs[4 * k + r] = (hasA && row < n) ? 8 * (L.off_A + row * n + colA) : KP_OOB;
+                trA.offs[4 * k + r] = (hasA && row < n) ? 8 * L.a(row, colA) : KP_OOB;
             }
 #pragma unroll
         for (int r = 0; r < 4; r++) {
             const int row = 16 * wi + 4 * r + q;
-            trB.offs[r] = (hasB && row < n) ? 8 * (L.off_B + row * m + c) : KP_OOB;
+            trB.offs[r] = (hasB && row < n) ? 8 * L.b(row, c) : KP_OOB;
         }
         trA.init(rT, KP.kp_offsets, KP.kp_times, hasA, (size_t)b * dof + (hasA ? kdA : 0), T, strideB);
         trB.init(rT, KP.kp_offsets, KP.kp_times, hasB, (size_t)b * dof + (hasB ? c : 0), T, strideB);

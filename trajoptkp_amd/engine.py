@@ -170,18 +170,14 @@ class Engine:
         buf = (C.c_char * nbytes).from_address(p.value)
         return np.frombuffer(buf, dtype=dtype, count=int(np.prod(shape))).reshape(shape)
 
-    def fd_slab(self, job_b, job_t, job_col, job_mode, xplus, xminus, job_nom=None, xnom=None, with_slots=True):
-        """Packs FD jobs (grouped by key-point, sorted by trajectory) into ONE pinned slab in the layout of
+    def fd_slab(self, job_b, job_t, job_col, job_mode, xplus, xminus, job_nom=None, xnom=None):
+        """Packs FD jobs (sorted by trajectory for the chunk pipeline) into ONE pinned slab in the layout of
         kpilqr_fd_slab_layout.  Returns a dict for upload_fd_slab / iterate_streamed."""
         jb = np.asarray(job_b, np.int32); jt = np.asarray(job_t, np.int32)
         nj = len(jt)
         nnom = 0 if xnom is None else len(xnom)
-        head = np.ones(nj, bool)
-        head[1:] = (jb[1:] != jb[:-1]) | (jt[1:] != jt[:-1])
-        slot_start = np.concatenate([np.nonzero(head)[0], [nj]]).astype(np.int32)
-        nslots = len(slot_start) - 1 if with_slots else 0
         lay = _lib.FdLayout()
-        self._ck(self._L.kpilqr_fd_slab_layout(self._h, nj, nnom, nslots, C.byref(lay)))
+        self._ck(self._L.kpilqr_fd_slab_layout(self._h, nj, nnom, C.byref(lay)))
         slab = self.pinned(lay.bytes, np.uint8)
 
         def put(off, a, dt):
@@ -192,12 +188,9 @@ class Engine:
             put(lay.xnom, xnom, np.float64)
         put(lay.job_b, jb, np.int32); put(lay.job_t, jt, np.int32); put(lay.job_col, job_col, np.int32)
         put(lay.job_nom, np.zeros(nj, np.int32) if job_nom is None else job_nom, np.int32)
-        if with_slots:
-            put(lay.slot_start, slot_start, np.int32)
         put(lay.job_mode, job_mode, np.uint8)
         # per-trajectory offsets for the chunk pipeline
-        slot_b = jb[slot_start[:-1]]
-        tsf = self.pinned(self.batch + 1, np.int32); tsf[:] = np.searchsorted(slot_b, np.arange(self.batch + 1))
+        tjf = self.pinned(self.batch + 1, np.int32); tjf[:] = np.searchsorted(jb, np.arange(self.batch + 1))
         tnf = self.pinned(self.batch + 1, np.int32)
         if nnom and job_nom is not None:
             jn = np.asarray(job_nom, np.int64)
@@ -209,18 +202,18 @@ class Engine:
             tnf[:] = lo
         else:
             tnf[:] = 0
-        return dict(slab=slab, njobs=nj, nnom=nnom, nslots=nslots, traj_slot_first=tsf, traj_nom_first=tnf, layout=lay)
+        return dict(slab=slab, njobs=nj, nnom=nnom, traj_job_first=tjf, traj_nom_first=tnf, layout=lay)
 
     def upload_fd_slab(self, s, eps=1e-6):
-        self._ck(self._L.kpilqr_upload_fd_slab(self._h, _ptr(s["slab"]), s["njobs"], s["nnom"], s["nslots"], float(eps)))
+        self._ck(self._L.kpilqr_upload_fd_slab(self._h, _ptr(s["slab"]), s["njobs"], s["nnom"], float(eps)))
 
     def iterate_streamed(self, fd=None, eps=1e-6, r=None, r_x=None, r_u=None, u_nom=None, lam=None, K=None, k=None,
                          cost_pred=None, delta_J=None, status=None, pd_stride=100, nchunks=0):
         """kpilqr_iterate_streamed: every array must come from self.pinned(); asynchronous (sync() to wait)."""
         io = _lib.StreamIO()
         if fd is not None:
-            io.fd_slab = fd["slab"].ctypes.data; io.njobs = fd["njobs"]; io.nnom = fd["nnom"]; io.nslots = fd["nslots"]
-            io.traj_slot_first = fd["traj_slot_first"].ctypes.data; io.traj_nom_first = fd["traj_nom_first"].ctypes.data
+            io.fd_slab = fd["slab"].ctypes.data; io.njobs = fd["njobs"]; io.nnom = fd["nnom"]
+            io.traj_job_first = fd["traj_job_first"].ctypes.data; io.traj_nom_first = fd["traj_nom_first"].ctypes.data
         io.eps = float(eps)
         for name, a in (("r", r), ("r_x", r_x), ("r_u", r_u), ("u_nom", u_nom), ("lam", lam), ("K", K), ("k", k),
                         ("cost_pred", cost_pred), ("delta_J", delta_J), ("status", status)):

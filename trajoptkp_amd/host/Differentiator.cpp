@@ -22,31 +22,30 @@ ThreadPool &Differentiator::pool()
 }
 
 // ---- staging ---------------------------------------------------------------------------------------------
-void FDStaging::plan(int total_jobs, int total_noms, int total_slots, int n_)
+void FDStaging::plan(int total_jobs, int total_noms, int n_)
 {
-    size_t off[10];
-    layout(total_jobs, total_noms, total_slots, off);
-    if (off[9] > slab_cap || !slab) {
+    size_t off[9];
+    layout(total_jobs, total_noms, off);
+    if (off[8] > slab_cap || !slab) {
         if (slab) { if (release) release(slab); else std::free(slab); }
-        slab_cap = off[9] + off[9] / 4 + 4096;
+        slab_cap = off[8] + off[8] / 4 + 4096;
         slab = (char *)(alloc ? alloc(slab_cap) : std::malloc(slab_cap));
     }
     n = n_;
     xplus = (double *)(slab + off[0]); xminus = (double *)(slab + off[1]); xnom = (double *)(slab + off[2]);
     job_b = (int *)(slab + off[3]); job_t = (int *)(slab + off[4]); job_col = (int *)(slab + off[5]);
-    job_nom = (int *)(slab + off[6]); slot_start = (int *)(slab + off[7]); job_mode = (unsigned char *)(slab + off[8]);
-    plan_jobs = total_jobs; plan_noms = total_noms; plan_slots = total_slots;
-    njobs = nnom = nslots = 0;
-    if (total_slots > 0) slot_start[total_slots] = total_jobs;
+    job_nom = (int *)(slab + off[6]); job_mode = (unsigned char *)(slab + off[7]);
+    plan_jobs = total_jobs; plan_noms = total_noms;
+    njobs = nnom = 0;
 }
 
 void FDStaging::free_all()
 {
     auto rel = [&](void *p) { if (p) { if (release) release(p); else std::free(p); } };
     if (slab) {                     // slab mode: the arrays point into the slab
-        rel(slab); slab = nullptr; slab_cap = 0; slot_start = nullptr;
+        rel(slab); slab = nullptr; slab_cap = 0;
         job_b = job_t = job_col = job_nom = nullptr; job_mode = nullptr; xplus = xminus = xnom = nullptr;
-        cap_jobs = cap_nom = 0; njobs = nnom = nslots = 0;
+        cap_jobs = cap_nom = 0; njobs = nnom = 0;
         return;
     }
     rel(job_b); rel(job_t); rel(job_col); rel(job_nom); rel(job_mode); rel(xplus); rel(xminus); rel(xnom);
@@ -304,12 +303,11 @@ void Differentiator::DynamicsDerivativesPlanned(FDStaging &st, int b, const std:
     int total = st.njobs;
     for (size_t t = 0; t < keypoints.size(); t++)
         if (!keypoints[t].empty()) { times.push_back((int)t); first.push_back(total); total += jobs_of(keypoints[t], sv.num_ctrl); }
-    const int nom0 = st.nnom, slot0 = st.nslots;
-    if (total > st.plan_jobs || nom0 + (int)times.size() > st.plan_noms || slot0 + (int)times.size() > st.plan_slots || st.n != n) {
+    const int nom0 = st.nnom;
+    if (total > st.plan_jobs || nom0 + (int)times.size() > st.plan_noms || st.n != n) {
         std::fprintf(stderr, "Differentiator: FD staging plan exceeded\n");
         std::exit(1);
     }
-    for (size_t it = 0; it < times.size(); it++) st.slot_start[slot0 + it] = first[it];
     MuJoCo_helper->InitModelForFiniteDifferencing();
     pool().parallel_for((int)times.size(), [&](int it, int tid) {
         SliceSink sink{st, b, times[it], n, nom0 + it, first[it]};
@@ -318,7 +316,6 @@ void Differentiator::DynamicsDerivativesPlanned(FDStaging &st, int b, const std:
     MuJoCo_helper->ResetModelAfterFiniteDifferencing();
     st.njobs = total;
     st.nnom = nom0 + (int)times.size();
-    st.nslots = slot0 + (int)times.size();
 }
 
 void Differentiator::ResidualDerivatives(double *r_x, double *r_u, int data_index, int tid, double eps)

@@ -38,16 +38,15 @@ struct FDStaging {
     void reserve(size_t jobs, size_t noms, int n_);
     void free_all();
 
-    // SLAB mode (the optimisers use it): all arrays, plus the slot table (first job of every key-point), live in ONE
-    // pinned allocation laid out by `layout` = kpilqr_fd_slab_layout, so the upload is a single DMA
-    // (kpilqr_upload_fd_slab).  plan() sizes the slab for exactly the totals of the coming fill and resets the cursors;
-    // Differentiator::DynamicsDerivativesPlanned appends one trajectory's key-points at the cursors.
-    std::function<void(int njobs, int nnom, int nslots, size_t off[10])> layout;   // xplus, xminus, xnom, job_b, job_t, job_col, job_nom, slot_start, job_mode, bytes
+    // SLAB mode (the optimisers use it): all arrays live in ONE pinned allocation laid out by `layout` =
+    // kpilqr_fd_slab_layout, so the upload is a single DMA (kpilqr_upload_fd_slab).  plan() sizes the slab for exactly the
+    // totals of the coming fill and resets the cursors; Differentiator::DynamicsDerivativesPlanned appends one
+    // trajectory's key-points at the cursors.
+    std::function<void(int njobs, int nnom, size_t off[9])> layout;   // xplus, xminus, xnom, job_b, job_t, job_col, job_nom, job_mode, bytes
     char *slab = nullptr;
     size_t slab_cap = 0;
-    int *slot_start = nullptr;
-    int nslots = 0, plan_jobs = 0, plan_noms = 0, plan_slots = 0;
-    void plan(int total_jobs, int total_noms, int total_slots, int n_);
+    int plan_jobs = 0, plan_noms = 0;
+    void plan(int total_jobs, int total_noms, int n_);
 };
 
 class Differentiator {
@@ -71,7 +70,7 @@ public:
     void DynamicsDerivativesBatch(FDStaging &st, int b, const std::vector<std::vector<int>> &keypoints, double eps,
                                   bool append = false);
     // Slab mode: totals of a key-point set (jobs, key-points) for FDStaging::plan, and the fill of one trajectory at the
-    // staging's cursors (job order and contents exactly as DynamicsDerivativesBatch; also writes the slot table).
+    // staging's cursors (job order and contents exactly as DynamicsDerivativesBatch).
     void CountJobs(const std::vector<std::vector<int>> &keypoints, int &jobs, int &kps) const;
     void DynamicsDerivativesPlanned(FDStaging &st, int b, const std::vector<std::vector<int>> &keypoints, double eps);
     // Residual Jacobians of the saved states 0..T into r_x [T+1][nr][n], r_u [T+1][nr][m] on the pool; a task

@@ -56,11 +56,11 @@ void iLQR_GPU::Resize(int new_num_dofs, int new_num_ctrl, int new_horizon)
     // every host <-> device payload lives in pinned memory owned by the context
     staging.alloc = [this](size_t bytes) { void *p = nullptr; if (kpilqr_host_alloc(ctx, bytes, &p)) fatal("kpilqr_host_alloc", -4); return p; };
     staging.release = [this](void *p) { if (ctx) kpilqr_host_free(ctx, p); };
-    staging.layout = [this](int nj, int nn, int ns, size_t off[10]) {
+    staging.layout = [this](int nj, int nn, size_t off[9]) {
         kpilqr_fd_layout l;
-        if (kpilqr_fd_slab_layout(ctx, nj, nn, ns, &l)) fatal("kpilqr_fd_slab_layout", -1);
-        const size_t o[10] = {l.xplus, l.xminus, l.xnom, l.job_b, l.job_t, l.job_col, l.job_nom, l.slot_start, l.job_mode, l.bytes};
-        for (int i = 0; i < 10; i++) off[i] = o[i];
+        if (kpilqr_fd_slab_layout(ctx, nj, nn, &l)) fatal("kpilqr_fd_slab_layout", -1);
+        const size_t o[9] = {l.xplus, l.xminus, l.xnom, l.job_b, l.job_t, l.job_col, l.job_nom, l.job_mode, l.bytes};
+        for (int i = 0; i < 9; i++) off[i] = o[i];
     };
     auto pinned = [&](size_t count) { void *p = nullptr; if (kpilqr_host_alloc(ctx, std::max<size_t>(count, 1) * sizeof(double), &p)) fatal("kpilqr_host_alloc", -4); std::fill((double *)p, (double *)p + count, 0.0); return (double *)p; };
     host_r = pinned((size_t)(T + 1) * nr); host_rx = pinned((size_t)(T + 1) * nr * n); host_ru = pinned((size_t)(T + 1) * nr * m);
@@ -151,16 +151,16 @@ void iLQR_GPU::GenerateDerivatives()
     keypoint_generator->PerDofCSR(offs, times);
     int rc = kpilqr_set_keypoints(ctx, offs.data(), times.data());
     if (rc) fatal("kpilqr_set_keypoints", rc);
-    // FD at the key-points on the persistent pool, straight into ONE pinned slab (jobs, nominal rows, slot table):
+    // FD at the key-points on the persistent pool, straight into ONE pinned slab (jobs, nominal rows):
     // the upload is a single DMA and nothing on the host walks the jobs afterwards
     if ((rc = kpilqr_sync(ctx))) fatal("kpilqr_sync", rc);        // the previous upload has left the staging slab
     {
         int jobs = 0, kps = 0;
         activeDifferentiator->CountJobs(keypoint_generator->keypoints, jobs, kps);
-        staging.plan(jobs, kps, kps, n);
+        staging.plan(jobs, kps, n);
         activeDifferentiator->DynamicsDerivativesPlanned(staging, 0, keypoint_generator->keypoints, eps);
     }
-    rc = kpilqr_upload_fd_slab(ctx, staging.slab, staging.njobs, staging.nnom, staging.nslots, eps);
+    rc = kpilqr_upload_fd_slab(ctx, staging.slab, staging.njobs, staging.nnom, eps);
     if (rc) fatal("kpilqr_upload_fd_slab", rc);
     if ((rc = kpilqr_fd_difference(ctx))) fatal("kpilqr_fd_difference", rc);
     if (!fused_active && (rc = kpilqr_interpolate(ctx))) fatal("kpilqr_interpolate", rc);

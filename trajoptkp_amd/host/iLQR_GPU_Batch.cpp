@@ -27,11 +27,11 @@ iLQR_GPU_Batch::iLQR_GPU_Batch(std::vector<Problem> problems, int horizon, int d
     ctrl_lim.assign(lim.data(), lim.data() + 2 * m);
     staging.alloc = [this](size_t bytes) { void *p = nullptr; if (kpilqr_host_alloc(ctx, bytes, &p)) fatal("kpilqr_host_alloc", -4); return p; };
     staging.release = [this](void *p) { if (ctx) kpilqr_host_free(ctx, p); };
-    staging.layout = [this](int nj, int nn, int ns, size_t off[10]) {
+    staging.layout = [this](int nj, int nn, size_t off[9]) {
         kpilqr_fd_layout l;
-        if (kpilqr_fd_slab_layout(ctx, nj, nn, ns, &l)) fatal("kpilqr_fd_slab_layout", -1);
-        const size_t o[10] = {l.xplus, l.xminus, l.xnom, l.job_b, l.job_t, l.job_col, l.job_nom, l.slot_start, l.job_mode, l.bytes};
-        for (int i = 0; i < 10; i++) off[i] = o[i];
+        if (kpilqr_fd_slab_layout(ctx, nj, nn, &l)) fatal("kpilqr_fd_slab_layout", -1);
+        const size_t o[9] = {l.xplus, l.xminus, l.xnom, l.job_b, l.job_t, l.job_col, l.job_nom, l.job_mode, l.bytes};
+        for (int i = 0; i < 9; i++) off[i] = o[i];
     };
     auto pinned = [&](size_t count) { void *p = nullptr; if (kpilqr_host_alloc(ctx, std::max<size_t>(count, 1) * sizeof(double), &p)) fatal("kpilqr_host_alloc", -4); std::fill((double *)p, (double *)p + count, 0.0); return (double *)p; };
     host_r = pinned((size_t)B * (T + 1) * nr); host_rx = pinned((size_t)B * (T + 1) * nr * n); host_ru = pinned((size_t)B * (T + 1) * nr * m);
@@ -157,7 +157,7 @@ void iLQR_GPU_Batch::GenerateDerivatives(const std::vector<int> &who)
     }
     int tot_jobs = 0, tot_kps = 0;
     for (int b : who) { int j, k_; P[b].differentiator->CountJobs(S[b].kpgen->keypoints, j, k_); tot_jobs += j; tot_kps += k_; }
-    staging.plan(tot_jobs, tot_kps, tot_kps, n);
+    staging.plan(tot_jobs, tot_kps, n);
     // pass 2: FD of every trajectory on its own persistent pool, all into the ONE pinned slab, trajectories in order
     for (int b : who) {
         Traj &s = S[b];
@@ -175,7 +175,7 @@ void iLQR_GPU_Batch::GenerateDerivatives(const std::vector<int> &who)
         times.insert(times.end(), s.kp_times.begin(), s.kp_times.end());
     }
     if ((rc = kpilqr_set_keypoints(ctx, offs.data(), times.data()))) fatal("kpilqr_set_keypoints", rc);
-    rc = kpilqr_upload_fd_slab(ctx, staging.slab, staging.njobs, staging.nnom, staging.nslots, eps);
+    rc = kpilqr_upload_fd_slab(ctx, staging.slab, staging.njobs, staging.nnom, eps);
     if (rc) fatal("kpilqr_upload_fd_slab", rc);
     if ((rc = kpilqr_fd_difference(ctx))) fatal("kpilqr_fd_difference", rc);
     if (!fused_active && (rc = kpilqr_interpolate(ctx))) fatal("kpilqr_interpolate", rc);
