@@ -9,7 +9,8 @@ import os
 import subprocess
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "lib", "libkpilqr.so")
+# KPILQR_LIB: another build of the same library (kernel A/B runs, tools/build_variant.sh); the product default is in-tree
+LIB_PATH = os.environ.get("KPILQR_LIB") or os.path.join(_HERE, "lib", "libkpilqr.so")
 CSRC = os.path.join(_HERE, "csrc")
 
 # every symbol include/kpilqr.h declares (tests check the .so exports exactly these)

@@ -230,9 +230,11 @@ __device__ __forceinline__ void backward_fused_body(double *sh, const double *pc
             const double rinv = kp_rcp(den);
 #pragma unroll
             for (int i = 0; i < 8; i++) {
-                const double ev = sv[i];
-                sv[i] = pv[i];
-                av[i] = fdiv(ev - sv[i], den, rinv);
+                av[i] = fdiv(sv[i] - pv[i], den, rinv);
+                // a real move, in sv's own register: left to the compiler, sv is renamed onto pv's register, the loads below
+                // land somewhere else, and the two arrays are copied back and forth -- behind a wait for every memory
+                // operation in flight -- on EVERY step of the sweep instead of at the crossings
+                asm volatile("v_mov_b64 %0, %1" : "+v"(sv[i]) : "v"(pv[i]));
             }
             s = nb; idx--;
             nb = nb2;
