@@ -123,11 +123,16 @@ template <int R> __device__ __forceinline__ void fset_reg(d4 &v, double x) { if 
 // hand-offs inside the step are wave-local, and the only block barrier is the one that ends a step.
 #define FPC_TILES 4
 #define FPC_BUF (FPC_TILES * 256)
+// behind the two ring slots (offsets from the ring base): the side wave's V (in), Quz and Qzz (out) of the wave triple
+#define FPC_SIDE_V (2 * FPC_BUF)
+#define FPC_SIDE_QUZ (FPC_SIDE_V + 256)
+#define FPC_SIDE_QZZ (FPC_SIDE_QUZ + 256)
 __device__ __forceinline__ d4 lds_tile4(const double *t, int lane);
+__device__ __forceinline__ void lds_store4(double *t, int lane, const d4 &v);
 // RU0: the context's r_u buffer was never written (a task without control residuals: r_u = 0, e.g. reaching,
 // src/ModelTranslator/Reaching.cpp:43-54), so [l_uu | l_u] = Ru' W [Ru | r] is exactly zero: the product and the r_u loads
 // are left out (4 of the step's 40 MFMAs).
-template <int N, int M, bool PC, bool RU0 = false>
+template <int N, int M, bool PC, bool RU0 = false, bool SIDE = false>
 __device__ __forceinline__ void backward_fused_body(double *sh, const double *pcbuf, int *sflag, RecLayout L, FusedArgs F, int T,
                 const double *__restrict__ rec,
                 const double *__restrict__ lambda, int pd_stride, double *__restrict__ Kout, double *__restrict__ kout,
@@ -221,8 +226,13 @@ __device__ __forceinline__ void backward_fused_body(double *sh, const double *pc
         const bool term = (t == T - 1);
         if constexpr (PC) {
             const double *tb = pcbuf + (t & 1) * FPC_BUF;
-            Fz = lds_tile4(tb, lane); Fu = lds_tile4(tb + 256, lane);
-            Lzz = lds_tile4(tb + 512, lane); LU = lds_tile4(tb + 768, lane);
+            Fu = lds_tile4(tb + 256, lane); LU = lds_tile4(tb + 768, lane);
+            if constexpr (SIDE) {                     // Fz, Lzz are the side wave's operands; only V = Lzz of the last step is ours
+                Fz = zero; Lzz = zero;
+                if (term) Lzz = lds_tile4(tb + 512, lane);
+            } else {
+                Fz = lds_tile4(tb, lane); Lzz = lds_tile4(tb + 512, lane);
+            }
         } else {
         // ---- a4: this step's A and B columns --------------------------------------------------------------
         if (t < s) {                                   // per lane: crossed the start of the current segment
@@ -277,9 +287,14 @@ __device__ __forceinline__ void backward_fused_body(double *sh, const double *pc
         d4 Tu = PS<NCZ>(V, Fu, zero);
         d4 Quu = PS<NCZ>(Fu, Tu, Luu);
         // ---- Tz, Quz, Qzz --------------------------------------------------------------- :570-579
-        d4 Tz = PS<NCZ>(V, Fz, zero);
-        d4 Quz = PS<NCZ>(Fu, Tz, Luz);
-        d4 Qzz = PS<NCZ>(Fz, Tz, Lzz);
+        d4 Quz, Qzz;
+        if constexpr (SIDE) {
+            Quz = zero; Qzz = zero;                   // the side wave forms them meanwhile (fusedpc_side): read behind the refresh
+        } else {
+            d4 Tz = PS<NCZ>(V, Fz, zero);
+            Quz = PS<NCZ>(Fu, Tz, Luz);
+            Qzz = PS<NCZ>(Fz, Tz, Lzz);
+        }
         d4 Qr = Quu;                                  // Quu + lambda I
         Qr.x += 0.5 * lam2d[0]; Qr.y += 0.5 * lam2d[1]; Qr.z += 0.5 * lam2d[2]; Qr.w += 0.5 * lam2d[3];
 
@@ -292,11 +307,18 @@ __device__ __forceinline__ void backward_fused_body(double *sh, const double *pc
         d4 Xp = zero;
         bool done = false;
 #if KP_NS
-        if (haveX && !check_pd && kp_inverse_refresh<NCU>(Qr, Iu, Xinv, m)) {
+        const bool refreshed = haveX && !check_pd && kp_inverse_refresh<NCU>(Qr, Iu, Xinv, m);
+#else
+        const bool refreshed = false;
+#endif
+        if constexpr (SIDE) {                         // mid-step barrier of the triple: Quz, Qzz are published
+            __syncthreads();
+            Quz = lds_tile4(pcbuf + FPC_SIDE_QUZ, lane); Qzz = lds_tile4(pcbuf + FPC_SIDE_QZZ, lane);
+        }
+        if (refreshed) {
             Xp = PS<NCU>(Xinv, Quz, zero);                                 // Xinv' Quz = (Quu + lambda I)^-1 Quz
             done = true;
         }
-#endif
         if (!done) {
             sh[FLDS_Q + q * FMS + c] = Qr.x;
             if (NCU > 1) sh[FLDS_Q + (4 + q) * FMS + c] = Qr.y;
@@ -392,6 +414,7 @@ __device__ __forceinline__ void backward_fused_body(double *sh, const double *pc
         V.z = 0.5 * (acc.z + sh[FLDS_V + c * FVS + 8 + q]);
         V.w = 0.5 * (acc.w + sh[FLDS_V + c * FVS + 12 + q]);
         if (lane_nn) fset_reg<REG_NN>(V, 0.0);
+        if constexpr (SIDE) lds_store4(const_cast<double *>(pcbuf) + FPC_SIDE_V, lane, V);      // the side wave's V of the next step
         if (PC) __syncthreads();                       // end of step: the ring slot is free, the next one is full
         else wsync();
     }
@@ -794,7 +817,7 @@ k_backward_fused2(RecLayout L, FusedArgs F, int T, int role_shift, const double 
 // s_barrier per step: at the end of step t the consumer has read slot t&1 and the producer has filled slot (t-1)&1.
 // Two waves per SIMD at batch = #SIMDs: the producer's independent MFMAs and FP64 FMAs issue into the bubbles of the
 // consumer's dependent chain.
-template <int N, int M>
+template <int N, int M, bool TRIPLE = false>
 __device__ __forceinline__ void fusedpc_producer(double *pcbuf, int *sflag, RecLayout L, FusedArgs F, int T, const double *__restrict__ rec)
 {
     constexpr int n = N, m = M;
@@ -865,13 +888,45 @@ __device__ __forceinline__ void fusedpc_producer(double *pcbuf, int *sflag, RecL
             tr.advance(rT, F.kp_times, t - 1, T, strideB);
             publish(t - 1, Wr);
         }
+        if constexpr (TRIPLE) __syncthreads();             // the mid-step barrier of the consumer and the side wave
         __syncthreads();
         if (sflag[0]) break;
     }
 }
 
+// Third wave of the triple: everything of the step that hangs on V but not on the gains -- Tz = V Fz, Quz = Luz + Fu'Tz,
+// Qzz = Lzz + Fz'Tz (12 of the step's MFMAs) -- while the consumer runs Tu, Quu and the refresh of the inverse.  V comes
+// from the consumer through LDS at the end of the step before; Quz and Qzz go back at the mid-step barrier.  The consumer's
+// chain per step is then Tu | Quu | refresh | X | V' (20 MFMAs) with two barriers.
+template <int N, int M>
+__device__ __forceinline__ void fusedpc_side(double *pcbuf, int *sflag, int T)
+{
+    constexpr int NCZ = (N + 1 + 3) / 4;
+    constexpr int n = N;
+    const int lane = threadIdx.x & 63, c = lane & 15;
+    const u64 mask_n = (c == n) ? ~0ull : 0ull;
+    const d4 zero = {0.0, 0.0, 0.0, 0.0};
+    __syncthreads();                                   // the producer has published step T-1
+    for (int t = T - 1; t >= 0; t--) {
+        const double *tb = pcbuf + (t & 1) * FPC_BUF;
+        const d4 Fz = lds_tile4(tb, lane), Fu = lds_tile4(tb + 256, lane);
+        const d4 Lzz = lds_tile4(tb + 512, lane), LU = lds_tile4(tb + 768, lane);
+        const d4 V = (t == T - 1) ? Lzz : lds_tile4(pcbuf + FPC_SIDE_V, lane);          // V_xx = l_xx[T-1]   (iLQR.cpp:537-539)
+        d4 Luz;
+        Luz.x = bits_and(LU.x, mask_n); Luz.y = bits_and(LU.y, mask_n); Luz.z = bits_and(LU.z, mask_n); Luz.w = bits_and(LU.w, mask_n);
+        const d4 Tz = PS<NCZ>(V, Fz, zero);
+        const d4 Quz = PS<NCZ>(Fu, Tz, Luz);
+        const d4 Qzz = PS<NCZ>(Fz, Tz, Lzz);
+        lds_store4(pcbuf + FPC_SIDE_QUZ, lane, Quz);
+        lds_store4(pcbuf + FPC_SIDE_QZZ, lane, Qzz);
+        __syncthreads();                               // mid-step: the consumer takes Quz, Qzz
+        __syncthreads();                               // end of step: V of step t-1 is there, the next ring slot is full
+        if (sflag[0]) break;
+    }
+}
+
 #define FPC_RING FLDS_TOTAL
-#define FPC_FLAG (FPC_RING + 2 * FPC_BUF)
+#define FPC_FLAG (FPC_RING + 2 * FPC_BUF + 3 * 256)
 #define FPC_TOTAL (FPC_FLAG + 2)
 template <int N, int M>
 __device__ __forceinline__ void backward_fusedpc_block(RecLayout L, FusedArgs F, int T, int role_shift, const double *__restrict__ rec,
@@ -893,6 +948,23 @@ k_backward_fusedpc(RecLayout L, FusedArgs F, int T, int role_shift, const double
                    double *__restrict__ delta_J, int *__restrict__ status)
 {
     backward_fusedpc_block<N, M>(L, F, T, role_shift, rec, lambda, pd_stride, Kout, kout, delta_J, status);
+}
+// Wave TRIPLE per trajectory (batch <= #CUs): consumer | side | producer, one SIMD each of one CU.
+template <int N, int M>
+__global__ void __launch_bounds__(192) __attribute__((amdgpu_waves_per_eu(1, 1)))
+k_backward_fusedpc3(RecLayout L, FusedArgs F, int T, int role_shift, const double *__restrict__ rec, const double *__restrict__ lambda,
+                    int pd_stride, double *__restrict__ Kout, double *__restrict__ kout,
+                    double *__restrict__ delta_J, int *__restrict__ status)
+{
+    __shared__ __attribute__((aligned(16))) double sh[FPC_TOTAL];
+    const int role = (int)((__builtin_amdgcn_readfirstlane(threadIdx.x >> 6) + (blockIdx.x >> role_shift)) % 3);
+    if (role == 0)
+        backward_fused_body<N, M, true, false, true>(sh, sh + FPC_RING, (int *)(sh + FPC_FLAG), L, F, T, rec, lambda, pd_stride, Kout, kout,
+                                                     delta_J, status);
+    else if (role == 1)
+        fusedpc_side<N, M>(sh + FPC_RING, (int *)(sh + FPC_FLAG), T);
+    else
+        fusedpc_producer<N, M, true>(sh + FPC_RING, (int *)(sh + FPC_FLAG), L, F, T, rec);
 }
 // at most one wave per SIMD: while 2 x batch <= #SIMDs every wave of every pair gets a SIMD (and its FP64 unit) to itself
 template <int N, int M>
@@ -1417,8 +1489,10 @@ hipError_t launch_backward_fused(Ctx *c, int pd_stride)
     // Wave organisation of the backward sweep.  While every wave of a producer/consumer pair can have a SIMD to itself
     // (2 x batch <= #SIMDs) the pair is the fastest form (4.2 vs 5.8 ms per sweep, tools/small_batch_variants.sh);
     // beyond that the FP64 unit is shared and one wave per trajectory wins.
-    // KPILQR_FUSED_WAVES forces a form: 1 = one wave, 2 = control/state split, 3 = producer/consumer.
-    const int form = c->tune.fused_bwd_waves ? c->tune.fused_bwd_waves : (2 * c->d.batch <= c->n_simd ? 3 : 1);
+    // KPILQR_FUSED_WAVES forces a form: 1 = one wave, 2 = control/state split, 3 = producer/consumer, 4 = the triple
+    // consumer / side / producer (while batch <= #CUs: the three waves of a workgroup share a CU).
+    const int form = c->tune.fused_bwd_waves ? c->tune.fused_bwd_waves
+                   : (4 * c->d.batch <= c->n_simd ? 4 : 2 * c->d.batch <= c->n_simd ? 3 : 1);      // a triple needs three SIMDs of ONE CU
     const int role_shift = c->tune.role_shift;
     dim3 block2(128);
     if (form == 2) {
@@ -1426,6 +1500,13 @@ hipError_t launch_backward_fused(Ctx *c, int pd_stride)
         else if (n == 4 && m == 1) hipLaunchKernelGGL((k_backward_fused2<4, 1>), grid, block2, 0, c->stream, c->L, F, c->d.T, role_shift, c->rec, c->lambda, pd_stride, c->K, c->k, c->delta_J, c->status);
         else return hipErrorInvalidValue;
         return hipGetLastError();
+    }
+    if (form == 4) {
+        dim3 block3(192);
+#define KP_X(NN, MM) if (n == NN && m == MM) { hipLaunchKernelGGL((k_backward_fusedpc3<NN, MM>), grid, block3, 0, c->stream, c->L, F, c->d.T, role_shift, c->rec, c->lambda, pd_stride, c->K, c->k, c->delta_J, c->status); return hipGetLastError(); }
+        KP_T1_SHAPES(KP_X)
+#undef KP_X
+        return hipErrorInvalidValue;
     }
     if (form == 3) {
         const bool pexcl = 2 * c->d.batch <= c->n_simd;
