@@ -123,9 +123,8 @@ template <int R> __device__ __forceinline__ void fset_reg(d4 &v, double x) { if 
 // hand-offs inside the step are wave-local, and the only block barrier is the one that ends a step.
 #define FPC_TILES 4
 #define FPC_BUF (FPC_TILES * 256)
-// behind the two ring slots (offsets from the ring base): the side wave's V (in), Quz and Qzz (out) of the wave triple
-#define FPC_SIDE_V (2 * FPC_BUF)
-#define FPC_SIDE_QUZ (FPC_SIDE_V + 256)
+// behind the two ring slots (offsets from the ring base): the side wave's Quz and Qzz of the wave triple
+#define FPC_SIDE_QUZ (2 * FPC_BUF)
 #define FPC_SIDE_QZZ (FPC_SIDE_QUZ + 256)
 __device__ __forceinline__ d4 lds_tile4(const double *t, int lane);
 __device__ __forceinline__ void lds_store4(double *t, int lane, const d4 &v);
@@ -211,11 +210,12 @@ __device__ __forceinline__ void backward_fused_body(double *sh, const double *pc
         __syncthreads();                               // the producer has published step T-1
     }
     const d4 zero = {0.0, 0.0, 0.0, 0.0};
-    d4 V = zero;
+    d4 V = zero, accp = zero;                                  // accp (SIDE): V' of the step before, not yet symmetrised
+    (void)accp;
     d4 W2 = {w2term[0], w2term[1], w2term[2], w2term[3]};     // terminal weights at t = T-1, running after
     int pd_counter = 0, fail = 0;
     double dJ = 0.0;
-    d4 Xinv = zero, Iu;                          // running inverse of Quu + lambda I (KP_NS) and the identity of the u-block
+    d4 Xinv = zero, Xprev = zero, Iu;            // running inverse of Quu + lambda I (KP_NS), the one before it, the identity of the u-block
     bool haveX = false;
     Iu.x = (q == c && c < m) ? 1.0 : 0.0; Iu.y = (4 + q == c && c < m) ? 1.0 : 0.0;
     Iu.z = (8 + q == c && c < m) ? 1.0 : 0.0; Iu.w = (12 + q == c && c < m) ? 1.0 : 0.0;
@@ -230,6 +230,15 @@ __device__ __forceinline__ void backward_fused_body(double *sh, const double *pc
             if constexpr (SIDE) {                     // Fz, Lzz are the side wave's operands; only V = Lzz of the last step is ours
                 Fz = zero; Lzz = zero;
                 if (term) Lzz = lds_tile4(tb + 512, lane);
+                else {
+                    // (V' + V'')/2 of the step before: its transposed half is read here, behind the barrier that ended that
+                    // step, together with this step's tiles -- no write / wait / read round trip at the end of a step
+                    V.x = 0.5 * (accp.x + sh[FLDS_V + c * FVS + q]);
+                    V.y = 0.5 * (accp.y + sh[FLDS_V + c * FVS + 4 + q]);
+                    V.z = 0.5 * (accp.z + sh[FLDS_V + c * FVS + 8 + q]);
+                    V.w = 0.5 * (accp.w + sh[FLDS_V + c * FVS + 12 + q]);
+                    if (lane_nn) fset_reg<REG_NN>(V, 0.0);
+                }
             } else {
                 Fz = lds_tile4(tb, lane); Lzz = lds_tile4(tb + 512, lane);
             }
@@ -307,7 +316,7 @@ __device__ __forceinline__ void backward_fused_body(double *sh, const double *pc
         d4 Xp = zero;
         bool done = false;
 #if KP_NS
-        const bool refreshed = haveX && !check_pd && kp_inverse_refresh<NCU>(Qr, Iu, Xinv, m);
+        const bool refreshed = haveX && !check_pd && kp_inverse_refresh_p<NCU>(Qr, Iu, Xinv, Xprev, m);
 #else
         const bool refreshed = false;
 #endif
@@ -356,6 +365,7 @@ __device__ __forceinline__ void backward_fused_body(double *sh, const double *pc
                 for (int i = 0; i < M; i++)
                     if (q == (i & 3)) yr[i >> 2] = (c < m) ? y[i] : 0.0;
                 Xinv.x = yr[0]; Xinv.y = yr[1]; Xinv.z = yr[2]; Xinv.w = yr[3];
+                Xprev = Xinv;
                 haveX = true;
 #endif
             } else {
@@ -408,13 +418,16 @@ __device__ __forceinline__ void backward_fused_body(double *sh, const double *pc
         sh[FLDS_V + (4 + q) * FVS + c] = acc.y;
         sh[FLDS_V + (8 + q) * FVS + c] = acc.z;
         sh[FLDS_V + (12 + q) * FVS + c] = acc.w;
-        wsync();
-        V.x = 0.5 * (acc.x + sh[FLDS_V + c * FVS + q]);
-        V.y = 0.5 * (acc.y + sh[FLDS_V + c * FVS + 4 + q]);
-        V.z = 0.5 * (acc.z + sh[FLDS_V + c * FVS + 8 + q]);
-        V.w = 0.5 * (acc.w + sh[FLDS_V + c * FVS + 12 + q]);
-        if (lane_nn) fset_reg<REG_NN>(V, 0.0);
-        if constexpr (SIDE) lds_store4(const_cast<double *>(pcbuf) + FPC_SIDE_V, lane, V);      // the side wave's V of the next step
+        if constexpr (SIDE) {
+            accp = acc;                                // symmetrised at the top of the next step, by this wave and by the side wave
+        } else {
+            wsync();
+            V.x = 0.5 * (acc.x + sh[FLDS_V + c * FVS + q]);
+            V.y = 0.5 * (acc.y + sh[FLDS_V + c * FVS + 4 + q]);
+            V.z = 0.5 * (acc.z + sh[FLDS_V + c * FVS + 8 + q]);
+            V.w = 0.5 * (acc.w + sh[FLDS_V + c * FVS + 12 + q]);
+            if (lane_nn) fset_reg<REG_NN>(V, 0.0);
+        }
         if (PC) __syncthreads();                       // end of step: the ring slot is free, the next one is full
         else wsync();
     }
@@ -899,11 +912,13 @@ __device__ __forceinline__ void fusedpc_producer(double *pcbuf, int *sflag, RecL
 // from the consumer through LDS at the end of the step before; Quz and Qzz go back at the mid-step barrier.  The consumer's
 // chain per step is then Tu | Quu | refresh | X | V' (20 MFMAs) with two barriers.
 template <int N, int M>
-__device__ __forceinline__ void fusedpc_side(double *pcbuf, int *sflag, int T)
+__device__ __forceinline__ void fusedpc_side(const double *sh, double *pcbuf, int *sflag, int T)
 {
     constexpr int NCZ = (N + 1 + 3) / 4;
     constexpr int n = N;
-    const int lane = threadIdx.x & 63, c = lane & 15;
+    constexpr int REG_NN = n >> 2;
+    const int lane = threadIdx.x & 63, c = lane & 15, q = lane >> 4;
+    const bool lane_nn = (c == n) && (q == (n & 3));
     const u64 mask_n = (c == n) ? ~0ull : 0ull;
     const d4 zero = {0.0, 0.0, 0.0, 0.0};
     __syncthreads();                                   // the producer has published step T-1
@@ -911,7 +926,14 @@ __device__ __forceinline__ void fusedpc_side(double *pcbuf, int *sflag, int T)
         const double *tb = pcbuf + (t & 1) * FPC_BUF;
         const d4 Fz = lds_tile4(tb, lane), Fu = lds_tile4(tb + 256, lane);
         const d4 Lzz = lds_tile4(tb + 512, lane), LU = lds_tile4(tb + 768, lane);
-        const d4 V = (t == T - 1) ? Lzz : lds_tile4(pcbuf + FPC_SIDE_V, lane);          // V_xx = l_xx[T-1]   (iLQR.cpp:537-539)
+        d4 V = Lzz;                                    // V_xx = l_xx[T-1]   (iLQR.cpp:537-539)
+        if (t < T - 1) {                               // (V' + V'')/2 from the consumer's unsymmetrised image, as the consumer forms it
+            V.x = 0.5 * (sh[FLDS_V + (q) * FVS + c] + sh[FLDS_V + c * FVS + q]);
+            V.y = 0.5 * (sh[FLDS_V + (4 + q) * FVS + c] + sh[FLDS_V + c * FVS + 4 + q]);
+            V.z = 0.5 * (sh[FLDS_V + (8 + q) * FVS + c] + sh[FLDS_V + c * FVS + 8 + q]);
+            V.w = 0.5 * (sh[FLDS_V + (12 + q) * FVS + c] + sh[FLDS_V + c * FVS + 12 + q]);
+            if (lane_nn) fset_reg<REG_NN>(V, 0.0);
+        }
         d4 Luz;
         Luz.x = bits_and(LU.x, mask_n); Luz.y = bits_and(LU.y, mask_n); Luz.z = bits_and(LU.z, mask_n); Luz.w = bits_and(LU.w, mask_n);
         const d4 Tz = PS<NCZ>(V, Fz, zero);
@@ -926,7 +948,7 @@ __device__ __forceinline__ void fusedpc_side(double *pcbuf, int *sflag, int T)
 }
 
 #define FPC_RING FLDS_TOTAL
-#define FPC_FLAG (FPC_RING + 2 * FPC_BUF + 3 * 256)
+#define FPC_FLAG (FPC_RING + 2 * FPC_BUF + 2 * 256)
 #define FPC_TOTAL (FPC_FLAG + 2)
 template <int N, int M>
 __device__ __forceinline__ void backward_fusedpc_block(RecLayout L, FusedArgs F, int T, int role_shift, const double *__restrict__ rec,
@@ -962,7 +984,7 @@ k_backward_fusedpc3(RecLayout L, FusedArgs F, int T, int role_shift, const doubl
         backward_fused_body<N, M, true, false, true>(sh, sh + FPC_RING, (int *)(sh + FPC_FLAG), L, F, T, rec, lambda, pd_stride, Kout, kout,
                                                      delta_J, status);
     else if (role == 1)
-        fusedpc_side<N, M>(sh + FPC_RING, (int *)(sh + FPC_FLAG), T);
+        fusedpc_side<N, M>(sh, sh + FPC_RING, (int *)(sh + FPC_FLAG), T);
     else
         fusedpc_producer<N, M, true>(sh + FPC_RING, (int *)(sh + FPC_FLAG), L, F, T, rec);
 }
