@@ -51,6 +51,7 @@ struct Ctx {
     // device buffers (cap[]: allocated bytes of the dimension-dependent ones, kpilqr_resize re-uses them)
     size_t cap[18] = {0};
     double *rec = nullptr;        // [batch][T][stride]
+    int *kp_uniform = nullptr;    // device flag: every trajectory has one key-point list for all its DoFs (k_kp_uniform)
     double *K = nullptr;          // [batch][T][n*m]
     double *k = nullptr;          // [batch][T][m]
     double *r = nullptr;          // [batch][T+1][nr]

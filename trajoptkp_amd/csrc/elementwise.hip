@@ -123,8 +123,29 @@ k_build_segmap(int batch, int dof, int T, const int *__restrict__ offs, const in
     }
 }
 
+// *flag stays non-zero iff within every trajectory all DoFs have the same key-point list (what set_interval produces): the
+// fused forward sweep then interpolates its transposed operands directly (fused_mfma.hip, UNI).  Never read by the host.
+__global__ void __launch_bounds__(256)
+k_kp_uniform(int batch, int dof, const int *__restrict__ offs, const int *__restrict__ times, int *__restrict__ flag)
+{
+    const int b = blockIdx.x;
+    const int lo0 = offs[(size_t)b * dof], len0 = offs[(size_t)b * dof + 1] - lo0;
+    bool same = true;
+    for (int i = 1; i < dof; i++) {
+        const int lo = offs[(size_t)b * dof + i], len = offs[(size_t)b * dof + i + 1] - lo;
+        if (len != len0) { same = false; break; }
+        for (int j = threadIdx.x; j < len; j += blockDim.x) same = same && (times[lo + j] == times[lo0 + j]);
+    }
+    if (!same) atomicAnd(flag, 0);
+}
+
 hipError_t launch_build_segmap(Ctx *c)
 {
+    {
+        hipError_t e = hipMemsetAsync(c->kp_uniform, 1, sizeof(int), c->stream);        // any non-zero value: uniform until shown otherwise
+        if (e != hipSuccess) return e;
+        hipLaunchKernelGGL(k_kp_uniform, dim3(c->d.batch), dim3(256), 0, c->stream, c->d.batch, c->d.dof, c->kp_offsets, c->kp_times, c->kp_uniform);
+    }
     const long long total = (long long)c->d.batch * c->d.dof * c->d.T;
     int blocks = (int)((total + 255) / 256);
     if (blocks > 256 * 32) blocks = 256 * 32;

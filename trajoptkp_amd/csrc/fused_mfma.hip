@@ -1001,7 +1001,7 @@ k_backward_fusedpc_excl(RecLayout L, FusedArgs F, int T, int role_shift, const d
 // ---------------------------------------------------------------------------------------------------------
 // Forward pass.  The column tracker walks UP in time; its tiles (row = A row, col = A column) are turned into
 // the Y operands (row = contraction index) through a padded LDS transpose, off the Z dependency chain.
-template <int NCZ, int NCU, bool RU0 = false>
+template <int NCZ, int NCU, bool RU0 = false, bool UNI = false>
 __device__ __forceinline__ void forward_fused_body(RecLayout L, FusedArgs F, int T, int n_alpha, const double *__restrict__ rec,
                const double *__restrict__ Kin, const double *__restrict__ kin,
                const double *__restrict__ u_nom, const double *__restrict__ ctrl_lim,
@@ -1021,8 +1021,13 @@ __device__ __forceinline__ void forward_fused_body(RecLayout L, FusedArgs F, int
 #pragma unroll
     for (int r = 0; r < 4; r++) {
         const int row = 4 * r + q;
-        co.a[r] = (row < n && c < n) ? 8 * L.a(row, c) : OOBF;
-        co.b[r] = (row < n && c < m) ? 8 * L.b(row, c) : OOBF;
+        if (UNI) {                                   // the Y operands themselves: Ya(p = row, o = c) = A(o, p), Yb(p, o) = B(o, p)
+            co.a[r] = (row < n && c < n) ? 8 * L.a(c, row) : OOBF;
+            co.b[r] = (row < m && c < n) ? 8 * L.b(c, row) : OOBF;
+        } else {
+            co.a[r] = (row < n && c < n) ? 8 * L.a(row, c) : OOBF;
+            co.b[r] = (row < n && c < m) ? 8 * L.b(row, c) : OOBF;
+        }
         oK[r] = (row < n && c < m) ? 8 * (row * m + c) : OOBF;
         ok_[r] = (row == n && c < m) ? 8 * c : OOBF;
         oRxT[r] = (row < n && c < nr) ? 8 * (c * n + row) : OOBF;     // RxT(p=row, k=c) = r_x[k][p]
@@ -1076,7 +1081,11 @@ __device__ __forceinline__ void forward_fused_body(RecLayout L, FusedArgs F, int
     };
 
     // ---- column tracker, walking UP in time --------------------------------------------------------------
-    const int kd = (c < F.dof) ? c : c - F.dof;
+    // UNI: every DoF of the trajectory has the SAME key-point list (set_interval, and whatever else comes out uniform), so
+    // one list serves all four registers of a lane and the lanes interpolate the transposed operands Ya, Yb directly --
+    // lane (q, c) holds A(c, 4r+q): row c of A, a different COLUMN (DoF list) per register otherwise, which is why the
+    // general form interpolates column-wise and transposes through LDS
+    const int kd = UNI ? 0 : (c < F.dof) ? c : c - F.dof;
     const bool has = c < n;
     const int klo = has ? F.kp_offsets[(size_t)b * F.dof + kd] : 0;
     const int khi = has ? F.kp_offsets[(size_t)b * F.dof + kd + 1] : 0;
@@ -1135,9 +1144,18 @@ __device__ __forceinline__ void forward_fused_body(RecLayout L, FusedArgs F, int
     // Y operands: step t uses (Ya, Yb); during step t the tiles of step t+1 are fetched from LDS (staged during
     // step t-1) and those of step t+2 are staged.
     d4 Ya, Yb;
-    stage_cols(0);
-    fetch_Y(Ya, Yb);
-    if (T > 1) { advance(1); stage_cols(1); }
+    auto lerp_Y = [&](int t) {                // UNI: the operands of step t straight from the tracker
+        const double dt = (double)(t - s);
+        Ya.x = lerp_nc(sv[0], dt, av[0]); Ya.y = lerp_nc(sv[1], dt, av[1]); Ya.z = lerp_nc(sv[2], dt, av[2]); Ya.w = lerp_nc(sv[3], dt, av[3]);
+        Yb.x = lerp_nc(sv[4], dt, av[4]); Yb.y = NCU > 1 ? lerp_nc(sv[5], dt, av[5]) : 0.0;
+        Yb.z = NCU > 2 ? lerp_nc(sv[6], dt, av[6]) : 0.0; Yb.w = NCU > 3 ? lerp_nc(sv[7], dt, av[7]) : 0.0;
+    };
+    if (UNI) lerp_Y(0);
+    else {
+        stage_cols(0);
+        fetch_Y(Ya, Yb);
+        if (T > 1) { advance(1); stage_cols(1); }
+    }
 
     // single-buffered tiles: each is re-requested for step t+1 right behind its last use in step t
     Tiles cur = nxt;
@@ -1187,7 +1205,7 @@ __device__ __forceinline__ void forward_fused_body(RecLayout L, FusedArgs F, int
             cur.RuT.x = fbld(rRu, oRuT[0]); cur.RuT.y = NCU > 1 ? fbld(rRu, oRuT[1]) : 0.0;
             cur.RuT.z = NCU > 2 ? fbld(rRu, oRuT[2]) : 0.0; cur.RuT.w = NCU > 3 ? fbld(rRu, oRuT[3]) : 0.0;
         }
-        if (more) fetch_Y(Ya, Yb);                     // Y operands of step t+1 (staged during step t-1 ... see below)
+        if (!UNI && more) fetch_Y(Ya, Yb);             // Y operands of step t+1 (staged during step t-1 ... see below)
         __builtin_amdgcn_sched_barrier(0);
         if (U_alpha && c < n_alpha) {
             double *Ua = U_alpha + (((size_t)b * n_alpha + c) * T + t) * m;
@@ -1196,7 +1214,8 @@ __device__ __forceinline__ void forward_fused_body(RecLayout L, FusedArgs F, int
             for (int r = 0; r < NCU; r++) { const int row = 4 * r + q; if (row < m) Ua[row] = uv[r]; }
         }
         // a4 for step t+2 (column layout -> LDS): fills the latency of the products above
-        if (t + 2 < T) { advance(t + 2); stage_cols(t + 2); }
+        if (UNI) { if (more) { advance(t + 1); lerp_Y(t + 1); } }
+        else if (t + 2 < T) { advance(t + 2); stage_cols(t + 2); }
         // quadratic cost model on the residuals: sum_k w_k [Jx_k (2 r_k + Jx_k) + Ju_k (2 r_k + Ju_k)]
         if (t == T - 1) {                     // terminal weights at the last step (Optimiser.cpp:209-211)
 #pragma unroll
@@ -1216,21 +1235,28 @@ __device__ __forceinline__ void forward_fused_body(RecLayout L, FusedArgs F, int
     if (q == 0 && c < n_alpha) cost_pred[(size_t)b * n_alpha + c] = partial;
 }
 
-template <int NCZ, int NCU, bool RU0>
+// The one-wave forward sweep comes in two forms, launched back to back: UNI for key-point sets in which every DoF of a
+// trajectory has the same list (the device flag of k_kp_uniform says so), the general form otherwise.  Each looks at the
+// flag first and leaves if the set is not its kind, so the host never has to know.
+template <int NCZ, int NCU, bool RU0, bool UNI>
 __global__ void __launch_bounds__(64)
 k_forward_fused(RecLayout L, FusedArgs F, int T, int n_alpha, const double *__restrict__ rec, const double *__restrict__ Kin,
                 const double *__restrict__ kin, const double *__restrict__ u_nom, const double *__restrict__ ctrl_lim,
-                const double *__restrict__ alphas, double *__restrict__ cost_pred, double *__restrict__ U_alpha)
+                const double *__restrict__ alphas, double *__restrict__ cost_pred, double *__restrict__ U_alpha,
+                const int *__restrict__ kp_uniform)
 {
-    forward_fused_body<NCZ, NCU, RU0>(L, F, T, n_alpha, rec, Kin, kin, u_nom, ctrl_lim, alphas, cost_pred, U_alpha);
+    if ((*kp_uniform != 0) != UNI) return;
+    forward_fused_body<NCZ, NCU, RU0, UNI>(L, F, T, n_alpha, rec, Kin, kin, u_nom, ctrl_lim, alphas, cost_pred, U_alpha);
 }
-template <int NCZ, int NCU, bool RU0>
+template <int NCZ, int NCU, bool RU0, bool UNI>
 __global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(1, 1)))
 k_forward_fused_excl(RecLayout L, FusedArgs F, int T, int n_alpha, const double *__restrict__ rec, const double *__restrict__ Kin,
                      const double *__restrict__ kin, const double *__restrict__ u_nom, const double *__restrict__ ctrl_lim,
-                     const double *__restrict__ alphas, double *__restrict__ cost_pred, double *__restrict__ U_alpha)
+                     const double *__restrict__ alphas, double *__restrict__ cost_pred, double *__restrict__ U_alpha,
+                     const int *__restrict__ kp_uniform)
 {
-    forward_fused_body<NCZ, NCU, RU0>(L, F, T, n_alpha, rec, Kin, kin, u_nom, ctrl_lim, alphas, cost_pred, U_alpha);
+    if ((*kp_uniform != 0) != UNI) return;
+    forward_fused_body<NCZ, NCU, RU0, UNI>(L, F, T, n_alpha, rec, Kin, kin, u_nom, ctrl_lim, alphas, cost_pred, U_alpha);
 }
 
 // ---------------------------------------------------------------------------------------------------------
@@ -1595,17 +1621,19 @@ hipError_t launch_forward_fused(Ctx *c, double *U_alpha_dev)
 #undef LAUNCHSC
         return hipErrorInvalidValue;
     }
-#define LAUNCH2(NCZ, NCU, RU)                                                                                     \
+#define LAUNCH3(NCZ, NCU, RU, UNI)                                                                                \
     do {                                                                                                          \
         if (excl)                                                                                                 \
-            hipLaunchKernelGGL((k_forward_fused_excl<NCZ, NCU, RU>), grid, block, 0, c->stream, c->L, F, c->d.T,  \
+            hipLaunchKernelGGL((k_forward_fused_excl<NCZ, NCU, RU, UNI>), grid, block, 0, c->stream, c->L, F, c->d.T, \
                                c->d.n_alpha, c->rec, c->K, c->k, c->u_nom, c->ctrl_lim, c->alphas, c->cost_pred,  \
-                               U_alpha_dev);                                                                      \
+                               U_alpha_dev, c->kp_uniform);                                                       \
         else                                                                                                      \
-            hipLaunchKernelGGL((k_forward_fused<NCZ, NCU, RU>), grid, block, 0, c->stream, c->L, F, c->d.T,       \
+            hipLaunchKernelGGL((k_forward_fused<NCZ, NCU, RU, UNI>), grid, block, 0, c->stream, c->L, F, c->d.T,  \
                                c->d.n_alpha, c->rec, c->K, c->k, c->u_nom, c->ctrl_lim, c->alphas, c->cost_pred,  \
-                               U_alpha_dev);                                                                      \
+                               U_alpha_dev, c->kp_uniform);                                                       \
     } while (0)
+// both forms, back to back: the one whose kind of key-point set is not resident leaves at once (k_forward_fused)
+#define LAUNCH2(NCZ, NCU, RU) do { LAUNCH3(NCZ, NCU, RU, true); LAUNCH3(NCZ, NCU, RU, false); } while (0)
 // (the r_u = 0 instantiation of the one-wave forward kernel measured SLOWER, 3.76 vs 3.22 ms at B = 1024: with the two
 // r_u loads and the Ju product gone the compiler's wait placement moves out of the latency shadow it sits in today --
 // DESIGN.md section 4.6 -- so the forward sweep always runs the dense form)
@@ -1614,6 +1642,8 @@ hipError_t launch_forward_fused(Ctx *c, double *U_alpha_dev)
     KP_X(4, 2) KP_X(2, 1) KP_X(4, 1) KP_X(3, 1)
 #undef KP_X
 #undef LAUNCH
+#undef LAUNCH2
+#undef LAUNCH3
     return hipErrorInvalidValue;
 }
 

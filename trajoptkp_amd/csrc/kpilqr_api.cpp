@@ -229,6 +229,7 @@ int kpilqr_create(const kpilqr_dims *dims, void *stream, kpilqr_ctx **out)
     hipError_t rc = hipSuccess;
 #define TRY(x) do { if (rc == hipSuccess) rc = (x); } while (0)
     TRY(dalloc(&c->err_flag, 1));
+    TRY(dalloc(&c->kp_uniform, 1));
     TRY(hipHostMalloc((void **)&c->err_flag_host, sizeof(int), hipHostMallocDefault));
 #undef TRY
     if (rc != hipSuccess) {
@@ -237,6 +238,7 @@ int kpilqr_create(const kpilqr_dims *dims, void *stream, kpilqr_ctx **out)
         return set_err(nullptr, KPILQR_ERR_ALLOC, msg);
     }
     (void)hipMemsetAsync(c->err_flag, 0, sizeof(int), c->stream);
+    (void)hipMemsetAsync(c->kp_uniform, 0, sizeof(int), c->stream);
     {
         const int rcv = select_variants(c);
         if (rcv != KPILQR_OK) { const std::string msg = c->err; kpilqr_destroy(c); return set_err(nullptr, rcv, msg); }
@@ -261,7 +263,7 @@ void kpilqr_destroy(kpilqr_ctx *c)
     void *ptrs[] = {c->rec, c->K, c->k, c->r, c->r_x, c->r_u, c->w_run, c->w_term, c->u_nom, c->ctrl_lim,
                     c->lambda, c->alphas, c->cost_pred, c->delta_J, c->traj_cost, c->status, c->segmap,
                     c->kp_offsets, c->kp_times, c->X_states, c->kp_thr, c->kp_mask, c->kp_count, c->ls8, c->fd_dev,
-                    c->stage, c->err_flag};
+                    c->stage, c->err_flag, c->kp_uniform};
     for (void *p : ptrs) if (p) (void)hipFree(p);
     if (c->err_flag_host) (void)hipHostFree(c->err_flag_host);
     if (c->own_stream) (void)hipStreamDestroy(c->stream);
