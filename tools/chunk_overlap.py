@@ -13,10 +13,12 @@ T = 3000
 p = synth.tile_problem(synth.make_problem(task="panda_reaching", T=T, batch=16, min_N=5), B // 16)
 with Engine(p["dof"], p["m"], T, p["nr"], batch=B, fused=True) as e:
     synth.upload(e, p)
+    e.fd_difference(); e.backward(p["lam"], 100, fetch=False)          # lambda and alphas resident from here on
     e.forward_linear(orc.alphas(6), fetch=False); e.sync()
-    for mode in ("iterate", 1, 2, 3, 4):
+    for mode in ("iterate", 1, 2, 3, "iterate"):       # streamed modes without an FD payload skip fd_difference (records resident)
         def step():
             if mode == "iterate": e.iterate(None, 100, None)
+            elif mode == "stages": e.fd_difference(); e.backward(None, 100, fetch=False); e.forward_linear(None, fetch=False)
             else: e.iterate_streamed(nchunks=mode)
         for _ in range(3): step()
         e.sync(); t0 = time.perf_counter()
