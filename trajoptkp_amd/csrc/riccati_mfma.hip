@@ -167,7 +167,7 @@ __device__ __forceinline__ void backward_body(RecLayout L, int T, const double *
     double dJ = 0.0;
     int fail = 0;
     const d4 zero = {0.0, 0.0, 0.0, 0.0};
-    d4 Xinv = zero, Iu;                          // running inverse of Quu + lambda I and the identity of the u-block
+    d4 Xinv = zero, Xprev = zero, Iu;            // running inverse of Quu + lambda I, the one before it, the identity of the u-block
     bool haveX = false;
     Iu.x = (q == c && c < m) ? 1.0 : 0.0; Iu.y = (4 + q == c && c < m) ? 1.0 : 0.0;
     Iu.z = (8 + q == c && c < m) ? 1.0 : 0.0; Iu.w = (12 + q == c && c < m) ? 1.0 : 0.0;
@@ -201,7 +201,7 @@ __device__ __forceinline__ void backward_body(RecLayout L, int T, const double *
         //      (it gives the PD verdict of :587-595), and whenever the residual is too large to converge fast.
         d4 Xp = zero;
         bool done = false;
-        if (haveX && !check_pd && kp_inverse_refresh<NCU>(Qr, Iu, Xinv, m)) {
+        if (haveX && !check_pd && kp_inverse_refresh_p<NCU>(Qr, Iu, Xinv, Xprev, m)) {
             Xp = P<NCU>(Xinv, Quz, zero);                                  // Xinv' Quz = (Quu + lambda I)^-1 Quz
             done = true;
         }
@@ -239,6 +239,7 @@ __device__ __forceinline__ void backward_body(RecLayout L, int T, const double *
                 for (int i = 0; i < M; i++)
                     if (q == (i & 3)) yr[i >> 2] = (c < m) ? y[i] : 0.0;
                 Xinv.x = yr[0]; Xinv.y = yr[1]; Xinv.z = yr[2]; Xinv.w = yr[3];
+                Xprev = Xinv;
                 haveX = true;
             } else {
                 // Q_uu + lambda I is not PD and this is not a checked step: follow Eigen's pivoted
