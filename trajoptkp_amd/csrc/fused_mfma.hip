@@ -56,6 +56,12 @@ __device__ __forceinline__ double fbld(__amdgpu_buffer_rsrc_t r, int byte_off)
 {
     return __builtin_bit_cast(double, __builtin_amdgcn_raw_buffer_load_b64(r, byte_off, 0, 0));
 }
+// the same with a wave-uniform byte offset in the instruction's scalar operand: ONE descriptor per array and trajectory,
+// the step selected by an SGPR, instead of a descriptor rebuilt (64-bit address arithmetic, ~8 SALU) per array and step
+__device__ __forceinline__ double fblds(__amdgpu_buffer_rsrc_t r, int byte_off, int soff)
+{
+    return __builtin_bit_cast(double, __builtin_amdgcn_raw_buffer_load_b64(r, byte_off, soff, 0));
+}
 __device__ __forceinline__ __amdgpu_buffer_rsrc_t frsrc(const void *p, int bytes)
 {
     return __builtin_amdgcn_make_buffer_rsrc((void *)p, 0, bytes, 0x00020000);
@@ -1159,15 +1165,16 @@ __device__ __forceinline__ void forward_fused_body(RecLayout L, FusedArgs F, int
 
     // single-buffered tiles: each is re-requested for step t+1 right behind its last use in step t
     Tiles cur = nxt;
-    const __amdgpu_buffer_rsrc_t rNone = frsrc(Kin, 0);
+    // one descriptor per array for the whole trajectory; the step (t+1, or t again behind the last one: never used) goes
+    // into the loads' scalar offset
+    const __amdgpu_buffer_rsrc_t rK = frsrc(Kin + (size_t)b * T * m * n, T * m * n * 8), rk = frsrc(kin + (size_t)b * T * m, T * m * 8),
+                                 ru = frsrc(u_nom + (size_t)b * T * m, T * m * 8), rRx = frsrc(rxb, (T + 1) * nr * n * 8),
+                                 rRu = frsrc(rub, (T + 1) * nr * m * 8), rR = frsrc(rb, (T + 1) * nr * 8);
     for (int t = 0; t < T; t++) {
         const bool more = t + 1 < T;
-        __amdgpu_buffer_rsrc_t rK = more ? frsrc(Kin + ((size_t)b * T + t + 1) * m * n, m * n * 8) : rNone;
-        __amdgpu_buffer_rsrc_t rk = more ? frsrc(kin + ((size_t)b * T + t + 1) * m, m * 8) : rNone;
-        __amdgpu_buffer_rsrc_t ru = more ? frsrc(u_nom + ((size_t)b * T + t + 1) * m, m * 8) : rNone;
-        __amdgpu_buffer_rsrc_t rRx = more ? frsrc(rxb + (size_t)(t + 1) * nr * n, nr * n * 8) : rNone;
-        __amdgpu_buffer_rsrc_t rRu = more ? frsrc(rub + (size_t)(t + 1) * nr * m, nr * m * 8) : rNone;
-        __amdgpu_buffer_rsrc_t rR = more ? frsrc(rb + (size_t)(t + 1) * nr, nr * 8) : rNone;
+        const int tn = more ? t + 1 : t;
+        const int sK = tn * m * n * 8, sk = tn * m * 8, sRx = tn * nr * n * 8, sRu = tn * nr * m * 8, sR = tn * nr * 8;
+        (void)sRu;
         // Order of the step: every product is a dependent MFMA chain whose result is usable ~100 cycles after its last
         // issue, so independent work is placed behind each chain before its consumer:
         //   U chain | A dx chain | clamp (U ready) | B du | r_u du | r_x dx | a4 of step t+1 (VALU + LDS) | cost (Jx ready)
@@ -1175,8 +1182,8 @@ __device__ __forceinline__ void forward_fused_body(RecLayout L, FusedArgs F, int
         const d4 ub = cur.ub;
         d4 U = PS<NCZ>(Yk, Z, ub);                     // u_nom + K dx + alpha k   (:879)
         __builtin_amdgcn_sched_barrier(0);
-        cur.YkK.x = fbld(rK, oK[0]); cur.YkK.y = fbld(rK, oK[1]); cur.YkK.z = fbld(rK, oK[2]); cur.YkK.w = fbld(rK, oK[3]);
-        cur.Ykk.x = fbld(rk, ok_[0]); cur.Ykk.y = fbld(rk, ok_[1]); cur.Ykk.z = fbld(rk, ok_[2]); cur.Ykk.w = fbld(rk, ok_[3]);
+        cur.YkK.x = fblds(rK, oK[0], sK); cur.YkK.y = fblds(rK, oK[1], sK); cur.YkK.z = fblds(rK, oK[2], sK); cur.YkK.w = fblds(rK, oK[3], sK);
+        cur.Ykk.x = fblds(rk, ok_[0], sk); cur.Ykk.y = fblds(rk, ok_[1], sk); cur.Ykk.z = fblds(rk, ok_[2], sk); cur.Ykk.w = fblds(rk, ok_[3], sk);
         __builtin_amdgcn_sched_barrier(0);
         d4 Zn = PS<NCZ>(Ya, Z, zero);                  // A dx (does not need the controls)
         __builtin_amdgcn_sched_barrier(0);
@@ -1191,8 +1198,8 @@ __device__ __forceinline__ void forward_fused_body(RecLayout L, FusedArgs F, int
             if (NCU > 3) { u = U.w; if (u > hi[3]) u = hi[3]; if (u < lo[3]) u = lo[3]; U.w = u; dU.w = u - ub.w; }
         }
         __builtin_amdgcn_sched_barrier(0);
-        cur.ub.x = fbld(ru, oub[0]); cur.ub.y = NCU > 1 ? fbld(ru, oub[1]) : 0.0;
-        cur.ub.z = NCU > 2 ? fbld(ru, oub[2]) : 0.0; cur.ub.w = NCU > 3 ? fbld(ru, oub[3]) : 0.0;
+        cur.ub.x = fblds(ru, oub[0], sk); cur.ub.y = NCU > 1 ? fblds(ru, oub[1], sk) : 0.0;
+        cur.ub.z = NCU > 2 ? fblds(ru, oub[2], sk) : 0.0; cur.ub.w = NCU > 3 ? fblds(ru, oub[3], sk) : 0.0;
         __builtin_amdgcn_sched_barrier(0);
         Zn = PS<NCU>(Yb, dU, Zn);                      // + B du: the next state
         d4 Ju = zero;                                  // RU0: r_u = 0, the control residual term vanishes
@@ -1200,10 +1207,10 @@ __device__ __forceinline__ void forward_fused_body(RecLayout L, FusedArgs F, int
         const d4 Jx = PR(cur.RxT, Z, zero, ncx);
         Z = Zn;
         __builtin_amdgcn_sched_barrier(0);
-        cur.RxT.x = fbld(rRx, oRxT[0]); cur.RxT.y = fbld(rRx, oRxT[1]); cur.RxT.z = fbld(rRx, oRxT[2]); cur.RxT.w = fbld(rRx, oRxT[3]);
+        cur.RxT.x = fblds(rRx, oRxT[0], sRx); cur.RxT.y = fblds(rRx, oRxT[1], sRx); cur.RxT.z = fblds(rRx, oRxT[2], sRx); cur.RxT.w = fblds(rRx, oRxT[3], sRx);
         if constexpr (!RU0) {
-            cur.RuT.x = fbld(rRu, oRuT[0]); cur.RuT.y = NCU > 1 ? fbld(rRu, oRuT[1]) : 0.0;
-            cur.RuT.z = NCU > 2 ? fbld(rRu, oRuT[2]) : 0.0; cur.RuT.w = NCU > 3 ? fbld(rRu, oRuT[3]) : 0.0;
+            cur.RuT.x = fblds(rRu, oRuT[0], sRu); cur.RuT.y = NCU > 1 ? fblds(rRu, oRuT[1], sRu) : 0.0;
+            cur.RuT.z = NCU > 2 ? fblds(rRu, oRuT[2], sRu) : 0.0; cur.RuT.w = NCU > 3 ? fblds(rRu, oRuT[3], sRu) : 0.0;
         }
         if (!UNI && more) fetch_Y(Ya, Yb);             // Y operands of step t+1 (staged during step t-1 ... see below)
         __builtin_amdgcn_sched_barrier(0);
@@ -1227,7 +1234,7 @@ __device__ __forceinline__ void forward_fused_body(RecLayout L, FusedArgs F, int
                  + wcur[2] * (Jx.z * (r2.z + Jx.z) + Ju.z * (r2.z + Ju.z))
                  + wcur[3] * (Jx.w * (r2.w + Jx.w) + Ju.w * (r2.w + Ju.w));
         __builtin_amdgcn_sched_barrier(0);
-        cur.rv.x = fbld(rR, oR[0]); cur.rv.y = fbld(rR, oR[1]); cur.rv.z = fbld(rR, oR[2]); cur.rv.w = fbld(rR, oR[3]);
+        cur.rv.x = fblds(rR, oR[0], sR); cur.rv.y = fblds(rR, oR[1], sR); cur.rv.z = fblds(rR, oR[2], sR); cur.rv.w = fblds(rR, oR[3], sR);
         __builtin_amdgcn_sched_barrier(0);
     }
     partial += __shfl_xor(partial, 16);
