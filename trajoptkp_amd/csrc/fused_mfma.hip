@@ -1641,10 +1641,10 @@ hipError_t launch_forward_fused(Ctx *c, double *U_alpha_dev)
     } while (0)
 // both forms, back to back: the one whose kind of key-point set is not resident leaves at once (k_forward_fused)
 #define LAUNCH2(NCZ, NCU, RU) do { LAUNCH3(NCZ, NCU, RU, true); LAUNCH3(NCZ, NCU, RU, false); } while (0)
-// (the r_u = 0 instantiation of the one-wave forward kernel measured SLOWER, 3.76 vs 3.22 ms at B = 1024: with the two
-// r_u loads and the Ju product gone the compiler's wait placement moves out of the latency shadow it sits in today --
-// DESIGN.md section 4.6 -- so the forward sweep always runs the dense form)
-#define LAUNCH(NCZ, NCU) LAUNCH2(NCZ, NCU, false)
+// r_u never uploaded (ru_zero): the instantiation without the r_u loads and the Ju product.  Round-2 history: it measured
+// SLOWER at first (3.76 vs 3.22 ms at B = 1024: the compiler's wait placement left the latency shadow it sat in), and
+// faster once the uniform-key-point form and the per-trajectory descriptors had changed the loop (2.81 vs 3.03 ms).
+#define LAUNCH(NCZ, NCU) do { if (c->ru_zero) LAUNCH2(NCZ, NCU, true); else LAUNCH2(NCZ, NCU, false); } while (0)
 #define KP_X(NCZ, NCU) if (ncz == NCZ && ncu == NCU) { LAUNCH(NCZ, NCU); return hipGetLastError(); }
     KP_X(4, 2) KP_X(2, 1) KP_X(4, 1) KP_X(3, 1)
 #undef KP_X
