@@ -1022,7 +1022,7 @@ __device__ __forceinline__ void forward_fused_body(RecLayout L, FusedArgs F, int
     const int ncx = (n + 3) >> 2;
 
     ColOffs co;
-    int oK[4], ok_[4], oRxT[4], oRuT[4], oR[4], oub[4];
+    int oK[4], oRxT[4], oRuT[4], oR[4], oub[4];
     double lo[NCU], hi[NCU], wcur[4];
 #pragma unroll
     for (int r = 0; r < 4; r++) {
@@ -1035,7 +1035,6 @@ __device__ __forceinline__ void forward_fused_body(RecLayout L, FusedArgs F, int
             co.b[r] = (row < n && c < m) ? 8 * L.b(row, c) : OOBF;
         }
         oK[r] = (row < n && c < m) ? 8 * (row * m + c) : OOBF;
-        ok_[r] = (row == n && c < m) ? 8 * c : OOBF;
         oRxT[r] = (row < n && c < nr) ? 8 * (c * n + row) : OOBF;     // RxT(p=row, k=c) = r_x[k][p]
         oRuT[r] = (row < m && c < nr) ? 8 * (c * m + row) : OOBF;     // RuT(p=row, k=c) = r_u[k][p]
         oR[r] = (row < nr) ? 8 * row : OOBF;                          // r[k=row] (rows of Jx / Ju)
@@ -1046,6 +1045,8 @@ __device__ __forceinline__ void forward_fused_body(RecLayout L, FusedArgs F, int
         }
         wcur[r] = (row < nr) ? F.w_run[row] : 0.0;
     }
+    const int rn = n >> 2;                                                  // the register of row n (k)
+    const int okn = (q == (n & 3) && c < m) ? 8 * c : OOBF;
     const double my_alpha = (c < n_alpha) ? alphas[c] : 0.0;
     d4 Z;
     {
@@ -1066,7 +1067,7 @@ __device__ __forceinline__ void forward_fused_body(RecLayout L, FusedArgs F, int
     const double *rxb = F.r_x + (size_t)b * (T + 1) * nr * n;
     const double *rub = F.r_u + (size_t)b * (T + 1) * nr * m;
 
-    struct Tiles { d4 YkK, Ykk, RxT, RuT, rv, ub; };
+    struct Tiles { d4 YkK, RxT, RuT, rv, ub; double kk; };      // kk: this lane's element of k (row n of Yk lives in ONE register)
     auto load_tiles = [&](int t, Tiles &s) {
         __amdgpu_buffer_rsrc_t rK = frsrc(Kin + ((size_t)b * T + t) * m * n, m * n * 8);
         __amdgpu_buffer_rsrc_t rk = frsrc(kin + ((size_t)b * T + t) * m, m * 8);
@@ -1075,7 +1076,7 @@ __device__ __forceinline__ void forward_fused_body(RecLayout L, FusedArgs F, int
         __amdgpu_buffer_rsrc_t rRu = frsrc(rub + (size_t)t * nr * m, nr * m * 8);
         __amdgpu_buffer_rsrc_t rR = frsrc(rb + (size_t)t * nr, nr * 8);
         s.YkK.x = fbld(rK, oK[0]); s.YkK.y = fbld(rK, oK[1]); s.YkK.z = fbld(rK, oK[2]); s.YkK.w = fbld(rK, oK[3]);
-        s.Ykk.x = fbld(rk, ok_[0]); s.Ykk.y = fbld(rk, ok_[1]); s.Ykk.z = fbld(rk, ok_[2]); s.Ykk.w = fbld(rk, ok_[3]);
+        s.kk = fbld(rk, okn);
         s.RxT.x = fbld(rRx, oRxT[0]); s.RxT.y = fbld(rRx, oRxT[1]); s.RxT.z = fbld(rRx, oRxT[2]); s.RxT.w = fbld(rRx, oRxT[3]);
         if constexpr (!RU0) {
             s.RuT.x = fbld(rRu, oRuT[0]); s.RuT.y = NCU > 1 ? fbld(rRu, oRuT[1]) : 0.0;
@@ -1178,12 +1179,13 @@ __device__ __forceinline__ void forward_fused_body(RecLayout L, FusedArgs F, int
         // Order of the step: every product is a dependent MFMA chain whose result is usable ~100 cycles after its last
         // issue, so independent work is placed behind each chain before its consumer:
         //   U chain | A dx chain | clamp (U ready) | B du | r_u du | r_x dx | a4 of step t+1 (VALU + LDS) | cost (Jx ready)
-        const d4 Yk = cur.YkK + cur.Ykk;
+        d4 Yk = cur.YkK;                               // + k in row n (the lanes of the other rows hold 0): ONE load, not a tile of four
+        if (rn == 3) Yk.w += cur.kk; else if (rn == 2) Yk.z += cur.kk; else if (rn == 1) Yk.y += cur.kk; else Yk.x += cur.kk;
         const d4 ub = cur.ub;
         d4 U = PS<NCZ>(Yk, Z, ub);                     // u_nom + K dx + alpha k   (:879)
         __builtin_amdgcn_sched_barrier(0);
         cur.YkK.x = fblds(rK, oK[0], sK); cur.YkK.y = fblds(rK, oK[1], sK); cur.YkK.z = fblds(rK, oK[2], sK); cur.YkK.w = fblds(rK, oK[3], sK);
-        cur.Ykk.x = fblds(rk, ok_[0], sk); cur.Ykk.y = fblds(rk, ok_[1], sk); cur.Ykk.z = fblds(rk, ok_[2], sk); cur.Ykk.w = fblds(rk, ok_[3], sk);
+        cur.kk = fblds(rk, okn, sk);
         __builtin_amdgcn_sched_barrier(0);
         d4 Zn = PS<NCZ>(Ya, Z, zero);                  // A dx (does not need the controls)
         __builtin_amdgcn_sched_barrier(0);
