@@ -2,7 +2,7 @@
 profiles/<tag>_pmc_traffic.json (HBM bytes per launch: FETCH_SIZE x2 on gfx950 per /opt/skills/guides/MI355X_MICROARCH.md,
 WRITE_SIZE exact; both are reported in KB) and profiles/<tag>_pmc_counters.json (MFMA / VALU / LDS counters per launch and
 the per-trajectory-step figures derived from them), plus profiles/<tag>_kernel_stats.csv."""
-import csv
+import csv, re
 import glob
 import json
 import os
@@ -19,7 +19,7 @@ KEYS = {"k_backward_fused": "backward_fused", "k_forward_fused": "forward_fused"
 def key_of(name):
     # the one-wave forward sweep is launched in two forms (uniform key-point sets / general), one of which returns at
     # once: only the uniform form runs the bench workload (set_interval key-points)
-    if "k_forward_fused" in name and ", false, false>" in name:
+    if re.search(r"k_forward_fused(_excl)?<\d+, \d+, (true|false), false>", name):
         return None
     for k, v in KEYS.items():
         if k in name:
