@@ -795,6 +795,46 @@ def test_fused_long_horizon_ragged_keypoints(wave_form):
     check_fused(g, p)
 
 
+@pytest.mark.parametrize("mix", ["uniform", "mixed", "uniform_different_lists"])
+def test_fused_forward_uniform_keypoint_flag(monkeypatch, mix):
+    """The one-wave fused forward sweep has a form for key-point sets in which every DoF of a trajectory shares one list
+    (it interpolates the transposed operands directly) and a general form; a device flag picks between them.  All-uniform
+    batches (also with a DIFFERENT list per trajectory), and a batch where one trajectory is ragged (general form for all)."""
+    monkeypatch.setenv("KPILQR_FUSED_WAVES", "1")
+    monkeypatch.setenv("KPILQR_FUSED_FWD_WAVES", "1")
+    T, dof, B = 257, 7, 3
+    rng = np.random.default_rng(11)
+    rows = []
+    for b in range(B):
+        step = 5 if mix == "uniform" else 3 + 2 * b
+        offs = np.zeros(T + 1, np.int32); cols = []
+        for t in range(T):
+            offs[t] = len(cols)
+            if t == 0 or t == T - 1 or t % step == 0:
+                cols.extend(range(dof))
+            elif mix == "mixed" and b == B - 1:
+                cols.extend([i for i in range(dof) if rng.uniform() < 0.15 * (i + 1) / dof])
+        offs[T] = len(cols)
+        rows.append((offs, np.asarray(cols, np.int32)))
+    p = synth.make_ragged_problem("panda_reaching", T, rows, config_id=2, dense_residuals=(mix == "mixed"))
+    check_fused(run_fused(p), p)
+
+
+@pytest.mark.parametrize("batch", [256, 264])
+def test_fused_wave_forms_at_their_batch_limits(batch):
+    """The backward triple runs while batch <= #CUs (256), the producer / consumer pair beyond: the two batches either side
+    of the switch, a few trajectories of each against the oracle, replicas of a seed bit-identical."""
+    p0 = synth.make_problem(task="panda_reaching", T=60, batch=8, min_N=4, dense_residuals=True)
+    reps = (batch + 7) // 8
+    p = synth.tile_problem(p0, reps)
+    g = run_fused(p)
+    ref = [pipeline.run_trajectory(p0, b, want_U=True) for b in range(8)]
+    for b in (0, 7, 8 * (reps - 1) + 3):
+        o = ref[b % 8]
+        assert g["status"][b] == 0 and relerr(g["K"][b], o["K"]) < K_RTOL_TIGHT and relerr(g["cost_pred"][b], o["cost_pred"]) < 1e-9
+    assert np.array_equal(g["K"][3], g["K"][8 * (reps - 1) + 3])
+
+
 def test_fused_indefinite_quu_on_unchecked_steps(wave_form):
     """Q_uu + lambda I indefinite while no PD check is due (pd_stride > T): the reference inverts it anyway with
     Eigen's pivoted LDLT (iLQR.cpp:597-604).  The fused backward pass (running-inverse fast path, LDL' fallback,
