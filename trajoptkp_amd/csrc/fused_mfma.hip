@@ -19,6 +19,11 @@
 //     The forward pass scores a candidate with the same model written on the residuals:
 //         l_x'dx + dx'l_xx dx/2 = sum_k w_k Jx_k (2 r_k + Jx_k),   Jx = r_x dx      (likewise for du).
 //
+// Wave organisations (launch_backward_fused / launch_forward_fused pick by batch size):
+//   backward: one wave per trajectory (batch > #SIMDs/2) | producer / consumer pair | consumer / side / producer triple
+//             (batch <= #CUs) | control / state split (kept as a tested alternative);
+//   forward:  one wave -- in a form for uniform key-point sets (no LDS transpose) and a general one, chosen on the device --
+//             | state / cost pair | state / cost / staging triple.
 // Everything else (homogeneous form, LDL' solve, slow path, stores) is riccati_mfma.hip / forward_mfma.hip.
 // Per launch the kernels read Kp*(n^2+nm) + T*nr*(1+n+m) doubles instead of T*(2n^2+nm+n+m^2+m).
 #include <cstdlib>
