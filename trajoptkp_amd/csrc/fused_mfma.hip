@@ -324,10 +324,9 @@ __device__ __forceinline__ void backward_fused_body(double *sh, const double *pc
         //      1e-15) and X = Xinv Quz is one more product -- the reference, too, forms the explicit inverse and
         //      multiplies (iLQR.cpp:597-604).  The LDL' path below runs on the first step, on every checked step
         //      (it gives the PD verdict of :587-595), and whenever the residual is too large to converge fast.
-        d4 Xp = zero;
         bool done = false;
 #if KP_NS
-        const bool refreshed = haveX && !check_pd && kp_inverse_refresh_p<NCU>(Qr, Iu, Xinv, Xprev, m);
+        const bool refreshed = haveX && !check_pd && kp_inverse_refresh_n<NCU>(Qr, Iu, Xinv, Xprev, m);    // Xinv, Xprev: NEGATED inverses
 #else
         const bool refreshed = false;
 #endif
@@ -335,8 +334,9 @@ __device__ __forceinline__ void backward_fused_body(double *sh, const double *pc
             __syncthreads();
             Quz = lds_tile4(pcbuf + FPC_SIDE_QUZ, lane); Qzz = lds_tile4(pcbuf + FPC_SIDE_QZZ, lane);
         }
+        d4 Kp = zero;                                 // the gains -X
         if (refreshed) {
-            Xp = PS<NCU>(Xinv, Quz, zero);                                 // Xinv' Quz = (Quu + lambda I)^-1 Quz
+            Kp = PS<NCU>(Xinv, Quz, zero);                                 // -(Quu + lambda I)^-1 Quz: the gains, with their sign
             done = true;
         }
         if (!done) {
@@ -375,7 +375,7 @@ __device__ __forceinline__ void backward_fused_body(double *sh, const double *pc
 #pragma unroll
                 for (int i = 0; i < M; i++)
                     if (q == (i & 3)) yr[i >> 2] = (c < m) ? y[i] : 0.0;
-                Xinv.x = yr[0]; Xinv.y = yr[1]; Xinv.z = yr[2]; Xinv.w = yr[3];
+                Xinv.x = -yr[0]; Xinv.y = -yr[1]; Xinv.z = -yr[2]; Xinv.w = -yr[3];       // the running inverse is kept negated
                 Xprev = Xinv;
                 haveX = true;
 #endif
@@ -398,9 +398,8 @@ __device__ __forceinline__ void backward_fused_body(double *sh, const double *pc
 #pragma unroll
             for (int i = 0; i < M; i++)
                 if (q == (i & 3)) xr[i >> 2] = x[i];
-            Xp.x = xr[0]; Xp.y = xr[1]; Xp.z = xr[2]; Xp.w = xr[3];
+            Kp.x = -xr[0]; Kp.y = -xr[1]; Kp.z = -xr[2]; Kp.w = -xr[3];
         }
-        const d4 Kp = -Xp;
         {
             __amdgpu_buffer_rsrc_t rK = frsrc(Kout + ((size_t)b * T + t) * m * n, m * n * 8);
             __amdgpu_buffer_rsrc_t rk = frsrc(kout + ((size_t)b * T + t) * m, m * 8);
@@ -414,17 +413,17 @@ __device__ __forceinline__ void backward_fused_body(double *sh, const double *pc
         // delta_J += k'Q_u + k'Q_uu k = -lambda k'k (:612-613): lanes of column n keep the squares of their rows,
         // the four row groups are added once after the sweep
         if (c == n) {
-            dJ -= lam * (Xp.x * Xp.x);
-            if (NCU > 1) dJ -= lam * (Xp.y * Xp.y);
-            if (NCU > 2) dJ -= lam * (Xp.z * Xp.z);
-            if (NCU > 3) dJ -= lam * (Xp.w * Xp.w);
+            dJ -= lam * (Kp.x * Kp.x);
+            if (NCU > 1) dJ -= lam * (Kp.y * Kp.y);
+            if (NCU > 2) dJ -= lam * (Kp.z * Kp.z);
+            if (NCU > 3) dJ -= lam * (Kp.w * Kp.w);
         }
         // V' = Qzz + K'Quu K + K'Quz + Quz'K (:606-607) with K = -X, (Quu + lambda I) X = Quz:
-        //    = Qzz - X'(Quz + lambda X)     -- one product; G = (Quu + 2 lambda I)K' is never formed
+        //    = Qzz - X'(Quz + lambda X) = Qzz + K'(Quz - lambda K)   -- one product; G = (Quu + 2 lambda I)K' is never formed
         d4 G;
-        G.x = -__builtin_fma(lam, Xp.x, Quz.x); G.y = -__builtin_fma(lam, Xp.y, Quz.y);
-        G.z = -__builtin_fma(lam, Xp.z, Quz.z); G.w = -__builtin_fma(lam, Xp.w, Quz.w);
-        d4 acc = PS<NCU>(Xp, G, Qzz);
+        G.x = __builtin_fma(-lam, Kp.x, Quz.x); G.y = __builtin_fma(-lam, Kp.y, Quz.y);
+        G.z = __builtin_fma(-lam, Kp.z, Quz.z); G.w = __builtin_fma(-lam, Kp.w, Quz.w);
+        d4 acc = PS<NCU>(Kp, G, Qzz);
         sh[FLDS_V + (q) * FVS + c] = acc.x;
         sh[FLDS_V + (4 + q) * FVS + c] = acc.y;
         sh[FLDS_V + (8 + q) * FVS + c] = acc.z;

@@ -126,6 +126,39 @@ __device__ __forceinline__ bool kp_inverse_refresh_p(const d4 &Qr, const d4 &Iu,
     return true;
 }
 
+// The same on the NEGATED inverse N = -(Quu + lambda I)^-1 (what the fused backward sweep carries): the residual
+// R = I - Q X = I + Q N is the MFMA accumulator started at I -- no VALU between the products of the chain -- and the gains
+// K = -X = N Quz come out with their sign.  Everything else as kp_inverse_refresh_p (N (I + R + R^2), extrapolated start).
+template <int NCU>
+__device__ __forceinline__ bool kp_inverse_refresh_n(const d4 &Qr, const d4 &Iu, d4 &Ninv, d4 &Nprev, int m)
+{
+    d4 N0 = Ninv;
+    N0.x = __builtin_fma(2.0, Ninv.x, -Nprev.x);
+    if (NCU > 1) N0.y = __builtin_fma(2.0, Ninv.y, -Nprev.y);
+    if (NCU > 2) N0.z = __builtin_fma(2.0, Ninv.z, -Nprev.z);
+    if (NCU > 3) N0.w = __builtin_fma(2.0, Ninv.w, -Nprev.w);
+    d4 R = kp_P<NCU>(Qr, N0, Iu);                     // I + Q N0
+    d4 Y = kp_P<NCU>(N0, R, N0);
+    Y = kp_P<NCU>(Y, R, N0);
+    double rmax = fabs(R.x);
+    if (NCU > 1) rmax = fmax(rmax, fabs(R.y));
+    if (NCU > 2) rmax = fmax(rmax, fabs(R.z));
+    if (NCU > 3) rmax = fmax(rmax, fabs(R.w));
+    const double e = (double)m * rmax;
+    if (__builtin_amdgcn_ballot_w64(!(e < 2.0e-5)) != 0) {
+        if (__builtin_amdgcn_ballot_w64(!(e < 0.11)) != 0) return false;
+        const int iters = (__builtin_amdgcn_ballot_w64(e >= 1.3e-2) != 0) ? 3 : (__builtin_amdgcn_ballot_w64(e >= 1.7e-4) != 0) ? 2 : 1;
+        R = kp_P<NCU>(Qr, Y, Iu); Y = kp_P<NCU>(Y, R, Y);
+        if (iters > 1) {
+            R = kp_P<NCU>(Qr, Y, Iu); Y = kp_P<NCU>(Y, R, Y);
+            if (iters > 2) { R = kp_P<NCU>(Qr, Y, Iu); Y = kp_P<NCU>(Y, R, Y); }
+        }
+    }
+    Nprev = Ninv;
+    Ninv = Y;
+    return true;
+}
+
 // Unpivoted LDL' of an m x m SPD matrix, done redundantly by every lane from a broadcast image (`qel(i,j)` returns
 // element (i,j)): L (unit lower, strictly lower part stored) and the reciprocals of D.  Returns false when a pivot is
 // not positive -- the callers then report the PD failure (checked steps) or take the pivoted slow path.
