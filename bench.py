@@ -23,6 +23,7 @@ Rank 0 prints ONE JSON line.  Besides the contract's keys it carries
   pcie_inclusive  SURVEY 8(d): the same iteration with the FD payload / residuals re-uploaded and K,k downloaded every
                   iteration (kpilqr_iterate_streamed), full payload and resident-Jacobian form           (N=1 only)
   secondary_configs  BASELINE configs[1], [2], [4] with their own roofline objects                         (N=1 only)
+  strong_scaling_projection  configs[3] shards (512 / 256 / 128 trajectories) timed on this one GPU, x N     (N=1 only)
   materialising_pipeline, cpu_baseline (the CPU oracle = line-faithful port, timed on this box's host cores; N=1 only)
 """
 import argparse
@@ -438,6 +439,24 @@ def main():
                     except Exception as ex:
                         sec[key] = {"error": repr(ex)}
                 out["secondary_configs"] = sec
+                # ---- BASELINE configs[3] on ONE GPU: what a shard of the global batch of 1024 costs here.  A projection, labelled as
+                # one: N x (the rate of a 1024/N shard measured on this GPU); the driver's --gpus N runs measure the real thing.
+                proj = {}
+                for N_ in (2, 4, 8):
+                    try:
+                        Bs = 1024 // N_
+                        ps, ps0, ds = build_problem("set_interval", Bs, 3000, args.min_N, "panda_reaching")
+                        rs = time_config(torch, stream, local_rank, ps, 10, 2, True, False)
+                        rs["eng"].close()
+                        per = Bs * 10 / rs["elapsed"]
+                        proj[str(N_)] = {"batch_per_gpu": Bs, "ms_per_step": 1e3 * rs["elapsed"] / 10, "per_gpu_value": per,
+                                         "projected_value": N_ * per, "stage_ms": rs["stage_ms"]}
+                        del ps, ps0, rs
+                    except Exception as ex:
+                        proj[str(N_)] = {"error": repr(ex)}
+                out["strong_scaling_projection"] = {"note": "global batch 1024 over N GPUs, projected from shards timed on THIS GPU (no "
+                                                            "inter-GPU cost: the only collective is one 64-byte all-reduce per iteration)",
+                                                    "unit": "trajectory-iterations/s", "n_gpus": proj}
         if world == 1 and not args.no_cpu_baseline:
             try:
                 out["cpu_baseline"] = cpu_baseline(args.task, T, args.min_N)
