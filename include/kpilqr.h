@@ -115,7 +115,8 @@ int  kpilqr_set_keypoints(kpilqr_ctx *ctx, const int *kp_offsets, const int *kp_
  * X [batch][T][n]: the nominal trajectory states (positions then velocities), as Optimiser::X_old. */
 int  kpilqr_upload_states(kpilqr_ctx *ctx, const double *X);
 /* KeypointGenerator::GenerateKeyPoints (src/KeyPointGenerator/KeyPointGenerator.cpp:76-135) for method
- * "set_interval" (:319-339), "adaptive_jerk" (:730-770 + :341-382) or "velocity_change" (:797-808 + :642-728)
+ * "set_interval" (:319-339), "adaptive_jerk" (:730-770 + :341-382), "adaptive_accel" (:772-795 + :341-382, dispatch
+ * :98-101; thresholds = jerk_thresholds, which the placement reads for either profile) or "velocity_change" (:797-808 + :642-728)
  * on every trajectory; the lists become the context's key-points exactly as if given to
  * kpilqr_set_keypoints.  thresholds [dof] (jerk or velocity-change thresholds; NULL for set_interval), dt =
  * model time-step.  "iterative_error" interleaves host finite differences: its placement loop stays on the host and calls

@@ -63,6 +63,38 @@ int orc_kp_set_interval(int dof, int T, int min_N, int *offs, int *cols)
     return cnt;
 }
 
+/* GenerateAccellerationProfile :772-795 + GenerateKeyPointsAdaptive :341-382 (dispatch :98-101).  The profile is the
+ * SIGNED velocity difference of consecutive steps (no division by dt, no abs), horizon-1 entries; the placement compares it
+ * with jerk_thresholds (GenerateKeyPointsAdaptive reads that member whatever the profile, :360). */
+int orc_kp_adaptive_accel(int dof, int T, int min_N, int max_N, const double *thr,
+                          const double *X, int *offs, int *cols)
+{
+    const int n = 2 * dof;
+    double *acc = (double *)calloc((size_t)T * dof, sizeof(double));
+    for (int t = 0; t < T - 1; t++) {                                /* :783 */
+        const double *s1 = X + (size_t)t * n, *s2 = s1 + n;
+        for (int j = 0; j < dof; j++) acc[(size_t)t * dof + j] = s2[j + dof] - s1[j + dof];   /* :785-788 */
+    }
+    int cnt = 0;
+    int *last = (int *)calloc((size_t)dof, sizeof(int));
+    offs[0] = 0;
+    for (int i = 0; i < dof; i++) cols[cnt++] = i;                   /* :347 */
+    for (int t = 1; t < T - 1; t++) {
+        offs[t] = cnt;
+        for (int j = 0; j < dof; j++) {
+            if ((t - last[j]) >= min_N) {                            /* :359 */
+                if (acc[(size_t)t * dof + j] > thr[j]) { cols[cnt++] = j; last[j] = t; }
+            }
+            if ((t - last[j]) >= max_N) { cols[cnt++] = j; last[j] = t; }   /* :365 */
+        }
+    }
+    offs[T - 1] = cnt;
+    for (int i = 0; i < dof; i++) cols[cnt++] = i;                   /* :381 */
+    offs[T] = cnt;
+    free(acc); free(last);
+    return cnt;
+}
+
 /* GenerateJerkProfile :730-770 + GenerateKeyPointsAdaptive :341-382 */
 int orc_kp_adaptive_jerk(int dof, int T, int min_N, int max_N, const double *thr,
                          double dt, const double *X, int *offs, int *cols)

@@ -48,6 +48,8 @@ int orc_kp_set_interval(int dof, int T, int min_N, int *offs, int *cols);       
 /* X: trajectory states, T entries of n=2*dof doubles (positions then velocities). */
 int orc_kp_adaptive_jerk(int dof, int T, int min_N, int max_N, const double *jerk_thresholds,
                          double dt, const double *X, int *offs, int *cols);          /* :730-770,341-382 */
+int orc_kp_adaptive_accel(int dof, int T, int min_N, int max_N, const double *jerk_thresholds,
+                          const double *X, int *offs, int *cols);                     /* :772-795,341-382 */
 int orc_kp_velocity_change(int dof, int T, int min_N, int max_N, const double *vel_thresholds,
                            const double *X, int *offs, int *cols);                   /* :642-728,797-808 */
 /* iterative_error on a GIVEN dense A sequence (the reference interleaves MuJoCo FD here;

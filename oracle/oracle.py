@@ -49,6 +49,8 @@ def lib(path=None):
     L.orc_kp_set_interval.restype = C.c_int
     L.orc_kp_adaptive_jerk.argtypes = [C.c_int, C.c_int, C.c_int, C.c_int, _d, C.c_double, _d, _i, _i]
     L.orc_kp_adaptive_jerk.restype = C.c_int
+    L.orc_kp_adaptive_accel.argtypes = [C.c_int, C.c_int, C.c_int, C.c_int, _d, _d, _i, _i]
+    L.orc_kp_adaptive_accel.restype = C.c_int
     L.orc_kp_velocity_change.argtypes = [C.c_int, C.c_int, C.c_int, C.c_int, _d, _d, _i, _i]
     L.orc_kp_velocity_change.restype = C.c_int
     L.orc_kp_iterative_error.argtypes = [C.c_int, C.c_int, C.c_int, C.c_double, _d, _i, _i]
@@ -151,6 +153,12 @@ def kp_set_interval(dof, T, min_N):
 def kp_adaptive_jerk(dof, T, min_N, max_N, thr, dt, X):
     offs, cols = _kp_out(dof, T, extra=T * dof)
     cnt = lib().orc_kp_adaptive_jerk(dof, T, min_N, max_N, _c(thr), dt, _c(X), offs, cols)
+    return offs, cols[:cnt].copy()
+
+
+def kp_adaptive_accel(dof, T, min_N, max_N, thr, X):
+    offs, cols = _kp_out(dof, T, extra=T * dof)
+    cnt = lib().orc_kp_adaptive_accel(dof, T, min_N, max_N, _c(thr), _c(X), offs, cols)
     return offs, cols[:cnt].copy()
 
 

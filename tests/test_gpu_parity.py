@@ -593,7 +593,7 @@ def _kp_states(rng, dof, T):
     return np.concatenate([q, v], axis=1)
 
 
-@pytest.mark.parametrize("method", ["set_interval", "adaptive_jerk", "velocity_change"])
+@pytest.mark.parametrize("method", ["set_interval", "adaptive_jerk", "adaptive_accel", "velocity_change"])
 @pytest.mark.parametrize("shape", [(7, 300, 3), (2, 100, 2), (10, 65, 2), (31, 129, 1), (7, 2, 2), (7, 3000, 2)])
 def test_device_keypoint_generation_matches_oracle(method, shape):
     from trajoptkp_amd.engine import rows_to_dof_csr
@@ -601,13 +601,16 @@ def test_device_keypoint_generation_matches_oracle(method, shape):
     rng = np.random.default_rng(dof * 1000 + T)
     X = np.stack([_kp_states(rng, dof, T) if T > 8 else rng.standard_normal((T, 2 * dof)) for _ in range(B)])
     min_N, max_N = int(rng.integers(1, 5)), int(rng.integers(5, 40))
-    thr = rng.uniform(50.0, 4000.0, dof) if method == "adaptive_jerk" else rng.uniform(0.5, 20.0, dof)
+    thr = rng.uniform(50.0, 4000.0, dof) if method == "adaptive_jerk" else rng.uniform(0.005, 0.2, dof) if method == "adaptive_accel" \
+        else rng.uniform(0.5, 20.0, dof)
     rows = []
     for b in range(B):
         if method == "set_interval":
             rows.append(orc.kp_set_interval(dof, T, min_N))
         elif method == "adaptive_jerk":
             rows.append(orc.kp_adaptive_jerk(dof, T, min_N, max_N, thr, 0.01, X[b]))
+        elif method == "adaptive_accel":
+            rows.append(orc.kp_adaptive_accel(dof, T, min_N, max_N, thr, X[b]))
         else:
             rows.append(orc.kp_velocity_change(dof, T, min_N, max_N, thr, X[b]))
     o_ref, t_ref = rows_to_dof_csr(rows, dof, T)

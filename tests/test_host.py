@@ -36,6 +36,19 @@ def test_adaptive_jerk_matches_oracle(seed):
 
 
 @pytest.mark.parametrize("seed", range(6))
+def test_adaptive_accel_matches_oracle(seed):
+    rng = np.random.default_rng(300 + seed)
+    dof, T = int(rng.integers(1, 8)), int(rng.integers(20, 300))
+    X = _states(rng, dof, T)
+    thr = rng.uniform(0.001, 0.05, dof)
+    min_N, max_N = int(rng.integers(1, 4)), int(rng.integers(4, 30))
+    o, c, _ = host.keypoints("adaptive_accel", dof, T, min_N, max_N, thr, dt=0.01, X=X)
+    oo, oc = orc.kp_adaptive_accel(dof, T, min_N, max_N, thr, X)
+    assert np.array_equal(o, oo) and np.array_equal(c, oc)
+    assert len(oc) > 2 * dof                      # the thresholds bite: more than the two enforced rows
+
+
+@pytest.mark.parametrize("seed", range(6))
 def test_velocity_change_matches_oracle(seed):
     rng = np.random.default_rng(100 + seed)
     dof, T = int(rng.integers(1, 8)), int(rng.integers(20, 300))

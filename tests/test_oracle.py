@@ -98,6 +98,25 @@ def test_keypoints_adaptive_jerk_structure():
     _assert_keypoints(orc.kp_rows(offs, cols), 2, 100, 5)
 
 
+def test_keypoints_adaptive_accel_structure():
+    """adaptive_accel (KeyPointGenerator.cpp:98-101, 772-795): the reference's tests hold no case for it; the same structural
+    asserts as keypoints.adaptive_jerk (rows 0 / T-1 full, max gap <= max_N) plus the definition of the profile: a key-point
+    inside the horizon sits where v[t+1] - v[t] exceeds the threshold (signed) or where max_N forces one."""
+    X = _free_fall_states()
+    thr = np.array([0.01, 0.01])
+    offs, cols = orc.kp_adaptive_accel(2, 100, 1, 5, thr, X)
+    rows = orc.kp_rows(offs, cols)
+    _assert_keypoints(rows, 2, 100, 5)
+    acc = X[1:, 2:] - X[:-1, 2:]
+    last = [0, 0]
+    for t in range(1, 99):
+        for j in range(2):
+            expect = (t - last[j] >= 1 and acc[t, j] > thr[j]) or (t - last[j] >= 5)
+            assert (j in rows[t]) == expect, (t, j)
+            if expect:
+                last[j] = t
+
+
 def test_keypoints_velocity_change_structure():
     """keypoints.velocity_change, src/tests/Keypoints_Test.cpp:161-202 (min_N 1, max_N 5)."""
     X = _free_fall_states()

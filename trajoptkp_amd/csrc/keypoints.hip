@@ -1,6 +1,6 @@
 // keypoints.hip -- key-point placement on the device for a whole batch:
 // KeypointGenerator::GenerateKeyPointsSetInterval (src/KeyPointGenerator/KeyPointGenerator.cpp:319-339),
-// GenerateJerkProfile + GenerateKeyPointsAdaptive (:730-770, :341-382) and GenerateVelocityProfile +
+// GenerateJerkProfile / GenerateAccellerationProfile + GenerateKeyPointsAdaptive (:730-770 / :772-795, :341-382) and GenerateVelocityProfile +
 // GenerateKeyPointsVelocityChange (:797-808, :642-728), producing the context's per-DoF CSR lists directly
 // (what kpilqr_set_keypoints would have been given).  The placement of one DoF never looks at another DoF,
 // so one thread owns one (trajectory, DoF) list and walks the horizon; the states of 64 steps at a time are
@@ -16,7 +16,7 @@ namespace kpilqr {
 
 #define KP_CHUNK 64
 
-// method: 0 set_interval, 1 adaptive_jerk, 2 velocity_change
+// method: 0 set_interval, 1 adaptive_jerk, 2 velocity_change, 3 adaptive_accel
 __global__ void __launch_bounds__(64)
 k_kp_flags(int method, int dof, int T, int min_N, int max_N, double dt, const double *__restrict__ thr,
            const double *__restrict__ X, unsigned long long *__restrict__ mask, int *__restrict__ count)
@@ -56,10 +56,13 @@ k_kp_flags(int method, int dof, int T, int min_N, int max_N, double dt, const do
                     }
                 } else if (method == 0) {
                     key = (t % min_N) == 0;                                 // :328-338
-                } else if (method == 1) {
+                } else if (method == 1 || method == 3) {
                     // jerk[t] from the velocities of steps t, t+1, t+2; the last two rows of the profile are 0 (:757-761)
                     double jerk = 0.0;
-                    if (t < T - 2) {
+                    if (method == 3) {
+                        // adaptive_accel (:98-101): the profile is the signed velocity difference v[t+1] - v[t] (:785-788)
+                        jerk = sx[(tt + 2) * dof + j] - sx[(tt + 1) * dof + j];
+                    } else if (t < T - 2) {
                         const double v1 = sx[(tt + 1) * dof + j], v2 = sx[(tt + 2) * dof + j], v3 = sx[(tt + 3) * dof + j];
                         const double a1 = (v2 - v1) / dt;                  // :748
                         const double a2 = (v3 - v2) / dt;                  // :749

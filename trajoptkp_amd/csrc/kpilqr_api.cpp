@@ -418,11 +418,12 @@ int kpilqr_generate_keypoints(kpilqr_ctx *c, const char *method, int min_N, int 
     if (strcmp(method, "set_interval") == 0) mth = 0;
     else if (strcmp(method, "adaptive_jerk") == 0) mth = 1;
     else if (strcmp(method, "velocity_change") == 0) mth = 2;
-    else return set_err(c, KPILQR_ERR_ARG, "kpilqr_generate_keypoints: method must be set_interval, adaptive_jerk or velocity_change "
+    else if (strcmp(method, "adaptive_accel") == 0) mth = 3;
+    else return set_err(c, KPILQR_ERR_ARG, "kpilqr_generate_keypoints: method must be set_interval, adaptive_jerk, adaptive_accel or velocity_change "
                                            "(iterative_error interleaves host finite differences and stays on the host)");
     if (min_N < 1 || max_N < 1) return set_err(c, KPILQR_ERR_ARG, "min_N and max_N must be >= 1");
     if (c->d.dof > 64) return set_err(c, KPILQR_ERR_ARG, "on-device key-point placement supports dof <= 64");
-    if (mth != 0 && (!thresholds || !(dt > 0.0))) return set_err(c, KPILQR_ERR_ARG, "thresholds and a positive dt are required");
+    if (mth != 0 && (!thresholds || (mth == 1 && !(dt > 0.0)))) return set_err(c, KPILQR_ERR_ARG, "thresholds (and, for adaptive_jerk, a positive dt) are required");
     if (mth != 0 && !c->have_states) return set_err(c, KPILQR_ERR_STATE, "kpilqr_generate_keypoints before kpilqr_upload_states");
     const size_t nlists = (size_t)c->d.batch * c->d.dof, T = c->d.T, nchunks = (T + 63) / 64;
     if (!c->kp_thr) KP_HIP(c, hipMalloc((void **)&c->kp_thr, sizeof(double) * c->d.dof));

@@ -26,7 +26,8 @@ void KeypointGenerator::GenerateKeyPoints(const std::vector<MatrixXd> &X, double
     keypoints.clear();
     const std::string &name = current_keypoint_method.name;
     if (name == "set_interval") SetInterval();
-    else if (name == "adaptive_jerk") Adaptive(X, dt);
+    else if (name == "adaptive_jerk") Adaptive(X, dt, false);
+    else if (name == "adaptive_accel") Adaptive(X, dt, true);
     else if (name == "velocity_change") VelocityChange(X);
     else if (name == "iterative_error") {
         if (!fd) { std::fprintf(stderr, "ERROR: iterative_error needs a column FD callback\n"); std::exit(1); }
@@ -49,8 +50,10 @@ void KeypointGenerator::SetInterval()
     keypoints[horizon - 1] = full;
 }
 
-// jerk profile |d2(qdot)/dt2| (:730-770) thresholded per DoF with min_N / max_N spacing (:341-382)
-void KeypointGenerator::Adaptive(const std::vector<MatrixXd> &X, double dt)
+// jerk profile |d2(qdot)/dt2| (:730-770) -- or, for "adaptive_accel", the signed velocity difference of consecutive steps
+// (GenerateAccellerationProfile :772-795: no division by dt, no abs) -- thresholded per DoF with min_N / max_N spacing
+// (:341-382; the placement reads jerk_thresholds for either profile, :360)
+void KeypointGenerator::Adaptive(const std::vector<MatrixXd> &X, double dt, bool accel)
 {
     const keypoint_method &km = current_keypoint_method;
     std::vector<int> full(dof);
@@ -60,13 +63,15 @@ void KeypointGenerator::Adaptive(const std::vector<MatrixXd> &X, double dt)
     std::vector<int> last(dof, 0);
     for (int t = 1; t + 1 < horizon; t++) {
         for (int j = 0; j < dof; j++) {
-            double jerk = 0.0;
-            if (t < horizon - 2) {
+            double profile = 0.0;
+            if (accel) {
+                profile = X[t + 1](j + dof) - X[t](j + dof);
+            } else if (t < horizon - 2) {
                 const double a1 = (X[t + 1](j + dof) - X[t](j + dof)) / dt;
                 const double a2 = (X[t + 2](j + dof) - X[t + 1](j + dof)) / dt;
-                jerk = std::fabs((a2 - a1) / dt);
+                profile = std::fabs((a2 - a1) / dt);
             }
-            if (t - last[j] >= km.min_N && jerk > km.jerk_thresholds[j]) { keypoints[t].push_back(j); last[j] = t; }
+            if (t - last[j] >= km.min_N && profile > km.jerk_thresholds[j]) { keypoints[t].push_back(j); last[j] = t; }
             if (t - last[j] >= km.max_N) { keypoints[t].push_back(j); last[j] = t; }
         }
     }

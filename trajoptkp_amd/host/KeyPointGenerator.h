@@ -33,7 +33,7 @@ public:
 
 private:
     void SetInterval();
-    void Adaptive(const std::vector<MatrixXd> &X, double dt);
+    void Adaptive(const std::vector<MatrixXd> &X, double dt, bool accel);
     void VelocityChange(const std::vector<MatrixXd> &X);
     void IterativeError(const ColumnFD &fd);
     void UpdatePercentages();

@@ -13,7 +13,7 @@ struct residual {
 };
 
 struct keypoint_method {
-    std::string name = "set_interval";   // set_interval | adaptive_jerk | velocity_change | iterative_error
+    std::string name = "set_interval";   // set_interval | adaptive_jerk | adaptive_accel | velocity_change | iterative_error
     int min_N = 1;
     int max_N = 1;
     std::vector<double> jerk_thresholds;

@@ -245,7 +245,7 @@ int kpilqr_host_optimise(const char *model, int T, int max_iter, int min_iter, c
     Model M;
     if (!make_model(model, 8, M)) return -1;
     const std::string opt = options ? options : "";
-    for (const char *km : {"set_interval", "adaptive_jerk", "velocity_change", "iterative_error"})
+    for (const char *km : {"set_interval", "adaptive_jerk", "adaptive_accel", "velocity_change", "iterative_error"})
         if (opt.find(std::string("+") + km) != std::string::npos) M.mt->keypoint_method = km;
     *M.sim->master_reset_data = *M.sim->main_data;
     auto diff = std::make_shared<Differentiator>(M.mt, M.sim);
