@@ -100,15 +100,111 @@ def cpu_baseline(task, T, min_N, reps_per_thread=60):
 
 
 # ---- problems ---------------------------------------------------------------------------------------------------------
-def build_problem(kind, B, T, min_N, task):
-    """Returns (problem dict tiled to B trajectories, the unique-seed problem, description)."""
+_BIG = ("xplus", "xminus", "xnom", "r", "r_x", "r_u", "u_nom")
+
+
+def _shared(shape, dtype=np.float64):
+    """numpy array in anonymous shared memory: forked workers fill their slice in place (nothing is pickled back)."""
+    import mmap
+    nbytes = max(int(np.prod(shape)) * np.dtype(dtype).itemsize, 1)
+    return np.frombuffer(mmap.mmap(-1, nbytes), dtype=dtype, count=int(np.prod(shape))).reshape(shape)
+
+
+_FILL = None
+
+
+def _fill_entry(lo):
+    return _FILL(lo)
+
+
+def distinct_problem(task, T, B, min_N, first_b=0, workers=None, cache=None):
+    """B trajectories with B DISTINCT seeds (synth.seed_for(2, first_b + b)): what a batch of MPC replans / initial
+    conditions looks like.  Generated by forked workers, a few seeds each, straight into shared arrays; must run BEFORE
+    anything initialises HIP in this process (fork).  cache: a directory -- the big arrays are kept there as .npy files and
+    memory-mapped by later runs (the rocprofv3 passes of tools/collect_profiles.sh, whose preloaded profiler has initialised
+    the GPU before this script starts, must not fork)."""
+    import multiprocessing as mp
+    from trajoptkp_amd import synth
+    global _FILL
+    workers = workers or max(1, min(16, len(os.sched_getaffinity(0)) // max(1, int(os.environ.get("LOCAL_WORLD_SIZE", "1")))))
+    if B <= 2:
+        return synth.make_problem(task=task, T=T, batch=B, min_N=min_N, first_b=first_b)
+    stem = os.path.join(cache, f"{task}_T{T}_B{B}_N{min_N}_b{first_b}_") if cache else None
+    if stem and all(os.path.exists(stem + k + ".npy") for k in _BIG):
+        out = {k: np.load(stem + k + ".npy", mmap_mode="r") for k in _BIG}
+        return _assemble(synth.make_problem(task=task, T=T, batch=1, min_N=min_N, first_b=first_b), out, B)
+    probe = synth.make_problem(task=task, T=T, batch=1, min_N=min_N, first_b=first_b)
+    nj, nn = len(probe["job_b"]), len(probe["xnom"])
+    out = {k: _shared((B * probe[k].shape[0],) + probe[k].shape[1:]) for k in _BIG}
+    chunk = max(1, min(16, (B + 2 * workers - 1) // (2 * workers)))
+
+    def fill(lo):
+        hi = min(lo + chunk, B)
+        q = synth.make_problem(task=task, T=T, batch=hi - lo, min_N=min_N, first_b=first_b + lo)
+        for k in _BIG:
+            per = probe[k].shape[0]
+            out[k][lo * per:hi * per] = q[k]
+        return lo
+
+    if workers == 1 or os.environ.get("KPILQR_BENCH_NOFORK"):
+        for lo in range(0, B, chunk):
+            fill(lo)
+    else:
+        _FILL = fill
+        with mp.get_context("fork").Pool(workers) as pool:
+            pool.map(_fill_entry, list(range(0, B, chunk)))
+        _FILL = None
+    if stem:
+        os.makedirs(cache, exist_ok=True)
+        for k in _BIG:
+            np.save(stem + k + ".npy.tmp.npy", out[k]); os.replace(stem + k + ".npy.tmp.npy", stem + k + ".npy")
+    return _assemble(probe, out, B)
+
+
+def _assemble(probe, out, B):
+    nj, nn = len(probe["job_b"]), len(probe["xnom"])
+    p = {k: v for k, v in probe.items() if k not in ("A_kp", "B_kp")}
+    p["batch"] = B
+    for k in _BIG:
+        p[k] = out[k]
+    p["job_b"] = np.repeat(np.arange(B, dtype=np.int32), nj)
+    for k in ("job_t", "job_col", "job_mode"):
+        p[k] = np.tile(probe[k], B)
+    p["job_nom"] = (np.tile(probe["job_nom"], B) + np.repeat(np.arange(B, dtype=np.int32) * nn, nj)).astype(np.int32)
+    p["kp_rows"] = probe["kp_rows"] * B
+    return p
+
+
+def slice_problem(p, B):
+    """The first B trajectories of a problem whose jobs are ordered by trajectory (shards of the headline batch)."""
+    B0 = p["batch"]
+    if B == B0:
+        return p
+    nj, nn = len(p["job_b"]) // B0, len(p["xnom"]) // B0
+    q = dict(p)
+    q["batch"] = B
+    for k in ("job_b", "job_t", "job_col", "job_mode", "job_nom", "xplus", "xminus"):
+        q[k] = p[k][:B * nj]
+    q["xnom"] = p["xnom"][:B * nn]
+    for k in ("r", "r_x", "r_u", "u_nom"):
+        q[k] = p[k][:B]
+    q["kp_rows"] = p["kp_rows"][:B]
+    return q
+
+
+def build_problem(kind, B, T, min_N, task, first_b=0, distinct=True, cache=None):
+    """Returns (problem of B trajectories, the problem of its first few trajectories for the oracle check, description)."""
     from trajoptkp_amd import synth
     if kind == "set_interval":
+        if distinct:
+            p = distinct_problem(task, T, B, min_N, first_b, cache=cache)
+            p0 = synth.make_problem(task=task, T=T, batch=min(8, B), min_N=min_N, first_b=first_b)
+            return p, p0, f"{task} T={T} set_interval({min_N}), {B} distinct seeds"
         uniq = min(8, B)
         if B % uniq:
             uniq = 1
-        p0 = synth.make_problem(task=task, T=T, batch=uniq, min_N=min_N)
-        desc = f"{task} T={T} set_interval({min_N})"
+        p0 = synth.make_problem(task=task, T=T, batch=uniq, min_N=min_N, first_b=first_b)
+        desc = f"{task} T={T} set_interval({min_N}), {uniq} distinct seeds tiled"
     elif kind == "adaptive_jerk":          # BASELINE configs[2]: contact trajectory, jerk thresholds 10 (joints) / 1 (body)
         from trajoptkp_amd import host        # the product's own KeypointGenerator (host C++) places the key-points
         uniq = min(8, B)
@@ -118,7 +214,7 @@ def build_problem(kind, B, T, min_N, task):
                                X=synth.contact_trajectory(np.random.default_rng(synth.seed_for(3, b) + 17), dof, T, dt))[:2]
                 for b in range(uniq)]
         p0 = synth.make_ragged_problem(task, T, rows, config_id=3, dense_residuals=True)
-        desc = f"{task} T={T} adaptive_jerk(min_N=1,max_N=100) ragged key-points"
+        desc = f"{task} T={T} adaptive_jerk(min_N=1,max_N=100) ragged key-points, {uniq} distinct seeds tiled"
     elif kind == "iterative_error":        # BASELINE configs[4]: bisection on a dense synthetic A sequence
         from trajoptkp_amd import host
         uniq = min(2, B)
@@ -128,7 +224,7 @@ def build_problem(kind, B, T, min_N, task):
             A, Bm = synth.dynamics_dense_smooth(np.random.default_rng(synth.seed_for(5, b) + 77), dof, m, dt, T)
             rows.append(host.keypoints("iterative_error", dof, T, 1, 1, iterative_error_threshold=1e-11, dt=dt, A=A)[:2]); dyn.append((A, Bm))
         p0 = synth.make_ragged_problem(task, T, rows, dyn=dyn, config_id=5, dense_residuals=True)
-        desc = f"{task} T={T} iterative_error(1e-11) ragged key-points (emulated on a dense synthetic A sequence)"
+        desc = f"{task} T={T} iterative_error(1e-11) ragged key-points (emulated on a dense synthetic A sequence), {uniq} distinct seeds tiled"
     else:
         raise ValueError(kind)
     uniq = p0["batch"]
@@ -201,6 +297,50 @@ def time_config(torch, stream, dev, p, steps, warmup, fused, generic, world=1, d
                 variants={"backward": eng.backward_variant, "forward": eng.forward_variant})
 
 
+LAMBDAS = (1e-4, 1e-3, 1e-2, 0.1, 1.0, 10.0)        # the reference's range [min_lambda, max_lambda] (Optimiser.h:239-242)
+
+
+def lambda_sweep(torch, stream, dev, p, fused, steps=5):
+    """The two sweeps of the headline batch at every regularisation of the reference's schedule and on a MIXED batch
+    (trajectory b at LAMBDAS[b % 6]): the running inverse's refresh count, the LDL' re-seeds and the pivoted slow path are
+    data-dependent and a launch lasts as long as its slowest wave.  Reports stage times, the number of valid backward
+    passes and (when the library offers kpilqr_backward_stats) the per-step histogram of what the refresh did."""
+    from trajoptkp_amd import Engine, synth
+    B = p["batch"]
+    eng = Engine(p["dof"], p["m"], p["T"], p["nr"], batch=B, device=dev, stream=stream.cuda_stream, fused=fused)
+    synth.upload(eng, p)
+    alphas = np.array([(i / 6.0) ** 2 for i in range(1, 7)])
+    eng.fd_difference()
+    eng.forward_linear(alphas, fetch=False)
+    rows = {}
+    cases = [(f"{lam:g}", np.full(B, lam)) for lam in LAMBDAS] + [("mixed", np.array([LAMBDAS[b % 6] for b in range(B)]))]
+    for name, lam in cases:
+        eng.backward(lam, 100, fetch=False); eng.forward_linear(None, fetch=False)     # uploads lambda; warm-up
+        eng.sync()
+        ev = [[torch.cuda.Event(enable_timing=True) for _ in range(3)] for _ in range(steps)]
+        for s_ in range(steps):
+            ev[s_][0].record(stream); eng.backward(None, 100, fetch=False)
+            ev[s_][1].record(stream); eng.forward_linear(None, fetch=False)
+            ev[s_][2].record(stream)
+        torch.cuda.synchronize()
+        bw = float(np.mean([e[0].elapsed_time(e[1]) for e in ev])); fw = float(np.mean([e[1].elapsed_time(e[2]) for e in ev]))
+        st = eng.results()["status"]
+        row = {"stage_ms": {"backward": bw, "forward": fw}, "valid_backward_passes": int((st == 0).sum()), "batch": B}
+        if hasattr(eng, "backward_stats"):
+            try:
+                h = eng.backward_stats(100)                                  # [B][6] step counts per trajectory
+                ok = st == 0
+                tot = h[ok].sum(0).astype(float)
+                row["refresh_histogram"] = {"fraction_of_steps": {k: float(v / max(tot.sum(), 1.0)) for k, v in zip(
+                    ("third_order_only", "plus_1_second_order", "plus_2_second_order", "plus_3_second_order", "ldl_factorisation", "pivoted_slow_path"), tot)},
+                    "slowest_trajectory_extra_refresh_steps": int((h[:, 1] + 2 * h[:, 2] + 3 * h[:, 3]).max())}
+            except Exception as ex:
+                row["refresh_histogram"] = {"error": repr(ex)}
+        rows[name] = row
+    eng.close()
+    return rows
+
+
 def roofline_of(p, p0, r, pmc=None):
     """roofline object of the backward sweep of a timed configuration."""
     n, m, nr, T, B = p["n"], p["m"], p["nr"], p["T"], p["batch"]
@@ -234,12 +374,16 @@ def roofline_of(p, p0, r, pmc=None):
         hbm["traffic_GBps"] = traffic / t_bwd / 1e9
         hbm["traffic_frac_of_hbm_peak"] = traffic / t_bwd / 1e9 / HBM_PEAK_GBS
     return {"bound": "mfma", "kernel": f"backward ({r['variants']['backward']})", "achieved": ach_tf, "peak": FP64_PEAK_TFLOPS,
-            "unit": "TFLOP/s", "frac": ach_tf / FP64_PEAK_TFLOPS, "traffic": traffic, "avg_launch_ms": r["stage_ms"]["backward"],
+            "unit": "TFLOP/s", "frac": ach_tf / FP64_PEAK_TFLOPS, "traffic": traffic,
+            "traffic_source": (None if traffic is None else f"profiles/{pmc.get('_file', '?')}: separate rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE "
+                               "passes of this command (tools/collect_profiles.sh), NOT measured in this run"),
+            "avg_launch_ms": r["stage_ms"]["backward"],
             "algorithmic_flops_per_launch": flops, "flops_per_trajectory_step": flops_a7(n, m), "hbm": hbm}
 
 
-def parity_check(p0, eng, n_check):
-    """K, k, delta_J, cost_pred of the first n_check unique seeds against the CPU oracle (the timed engine's last results)."""
+def parity_check(p0, eng, n_check, tiled=False):
+    """K, k, delta_J, cost_pred of the first n_check trajectories against the CPU oracle (the timed engine's last results);
+    tiled: the batch is p0 replicated, and every replica must carry its seed's bytes."""
     from oracle import pipeline
     K, k = eng.gains()
     res = eng.results()
@@ -255,7 +399,7 @@ def parity_check(p0, eng, n_check):
         if o["status"] != 0 or res["status"][b] != 0:
             out["status_mismatch"] = True
     uniq = p0["batch"]
-    reps = K.shape[0] // uniq
+    reps = K.shape[0] // uniq if tiled else 1
     if reps > 1:        # every replica of a seed must carry its seed's bytes
         Kr = K.reshape(reps, uniq, -1)
         out["replicas_bit_identical"] = bool(np.array_equal(Kr, np.broadcast_to(Kr[0], Kr.shape)))
@@ -281,6 +425,27 @@ def pcie_inclusive(batch, steps=4):
     return out
 
 
+def launch_ranks(n, argv):
+    """`python bench.py --gpus N` without a launcher: start the N ranks ourselves, exactly as the driver would
+    (`python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 ...`), as a CHILD process --
+    this process has not touched the GPU and never will -- pass rank 0's JSON line through and exit with the child's code.
+    With fewer GPUs than ranks (rehearsal on a one-GPU box) the ranks share devices: RCCL refuses a communicator with two
+    ranks on one device, so the rehearsal's collective runs over gloo and the line says so (`rccl_ranks` = 0)."""
+    import socket
+    import subprocess
+    import torch
+    ndev = torch.cuda.device_count()          # does not initialise HIP
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    if ndev < n:
+        env.setdefault("KPILQR_DIST_BACKEND", "gloo")
+        print(f"bench.py: {n} ranks on {ndev} GPU(s): rehearsal, ranks share devices, collective over gloo", file=sys.stderr)
+    sock = socket.socket(); sock.bind(("127.0.0.1", 0)); port = sock.getsockname()[1]; sock.close()
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={n}", "--master-addr", "127.0.0.1",
+           "--master-port", str(port), os.path.abspath(__file__)] + argv
+    return subprocess.call(cmd, env=env)
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -298,14 +463,41 @@ def main():
     ap.add_argument("--no-secondary", action="store_true", help="skip every side measurement (materialising pipeline, pcie_inclusive, secondary configs, weak line)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--pcie-batch", type=int, default=256)
+    ap.add_argument("--workload-cache", default=None, help="directory for the generated workload (.npy, memory-mapped by later runs: profiler passes)")
+    ap.add_argument("--tiled-seeds", action="store_true", help="8 distinct seeds tiled to the batch (round-1/2 workload) instead of one seed per trajectory")
     args = ap.parse_args()
 
-    import torch
-    from trajoptkp_amd import distributed as kd
-
+    if "WORLD_SIZE" not in os.environ and args.gpus > 1:
+        sys.exit(launch_ranks(args.gpus, sys.argv[1:]))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
+    if world != args.gpus:
+        print(f"bench.py: --gpus {args.gpus} but the launcher started {world} rank(s) (WORLD_SIZE)", file=sys.stderr)
+        sys.exit(2)
+
+    from trajoptkp_amd import distributed as kd
+    weak = args.weak or (args.batch is not None and world > 1)
+    if weak:
+        B_local = args.batch or 1024
+        global_batch = B_local * world
+        lo = rank * B_local
+    else:
+        global_batch = args.batch if (args.batch is not None and world == 1) else args.global_batch
+        lo, hi = kd.shard_range(global_batch, rank, world)          # contiguous block of the global batch
+        B_local = hi - lo
+    T = args.T
+    # The workload is generated BEFORE this process touches the GPU: the distinct seeds are made by forked workers.
+    # Every rank makes the seeds of its own shard (trajectory lo + b has seed seed_for(2, lo + b), whatever N is).
+    t_gen = time.perf_counter()
+    p, p0, desc = build_problem(args.keypoints, B_local, T, args.min_N, args.task, first_b=lo, distinct=not args.tiled_seeds,
+                                cache=args.workload_cache or os.environ.get("KPILQR_WORKLOAD_CACHE"))
+    pw = None
+    if world > 1 and not weak and not args.no_secondary:            # the weak-scaling line beside the strong one
+        pw = build_problem(args.keypoints, args.global_batch, T, args.min_N, args.task, distinct=False)[0]   # 8 seeds tiled: a side line
+    t_gen = time.perf_counter() - t_gen
+
+    import torch
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs an MI355X: no HIP device visible (there is no CPU fallback)")
     local_rank = local_rank % torch.cuda.device_count()     # the modulo only matters when rehearsing N>1 ranks on a 1-GPU box
@@ -319,34 +511,24 @@ def main():
         else:
             dist.init_process_group(backend)
 
-    weak = args.weak or (args.batch is not None and world > 1)
-    if weak:
-        B_local = args.batch or 1024
-        global_batch = B_local * world
-    else:
-        global_batch = args.batch if (args.batch is not None and world == 1) else args.global_batch
-        lo, hi = kd.shard_range(global_batch, rank, world)          # contiguous block of the global batch
-        B_local = hi - lo
-    T = args.T
     # a dedicated (non-null) HIP stream shared by torch and the engine: kernels, HIP events and the RCCL all-reduce
     # are all ordered on it
     stream = torch.cuda.Stream()
     torch.cuda.set_stream(stream)
     fused = not args.unfused and not args.generic
 
-    p, p0, desc = build_problem(args.keypoints, B_local, T, args.min_N, args.task)
     r = time_config(torch, stream, local_rank, p, args.steps, args.warmup, fused, args.generic, world, dist)
     eng = r["eng"]
     res = eng.results()
     n_ok = int((res["status"] == 0).sum())
-    parity = parity_check(p0, eng, min(p0["batch"], 8)) if rank == 0 else None
+    tiled = args.tiled_seeds or args.keypoints != "set_interval"
+    parity = parity_check(p0, eng, min(p0["batch"], 8), tiled) if rank == 0 else None
     eng.close()
 
     side = world == 1 and not args.no_secondary
     weak_line = None
-    if world > 1 and not weak and not args.no_secondary:
+    if pw is not None:
         # the same job with 1024 trajectories PER GPU, for the weak-scaling curve beside the strong one
-        pw, pw0, _ = build_problem(args.keypoints, args.global_batch, T, args.min_N, args.task)
         rw = time_config(torch, stream, local_rank, pw, max(3, args.steps // 2), 2, fused, args.generic, world, dist)
         rw["eng"].close()
         weak_line = {"batch_per_gpu": args.global_batch, "global_batch": args.global_batch * world, "steps": max(3, args.steps // 2),
@@ -356,9 +538,10 @@ def main():
     if rank == 0:
         value = global_batch * args.steps / r["elapsed"]
         pmc = None
-        for name in ("r02_pmc_traffic.json", "r01_pmc_traffic.json"):
+        for name in ("r03_pmc_traffic.json", "r02_pmc_traffic.json", "r01_pmc_traffic.json"):
             try:
                 pmc = json.load(open(os.path.join(ROOT, "profiles", name)))
+                pmc["_file"] = name
                 break
             except Exception:
                 pmc = None
@@ -370,11 +553,16 @@ def main():
             "value": value, "unit": "trajectory-iterations/s", "n_gpus": world, "steps": args.steps,
             "warmup": args.warmup, "ms_per_step": 1e3 * r["elapsed"] / args.steps, "higher_is_better": True,
             "scaling": "weak" if weak else "strong", "vs_baseline": None, "dtype": "f64", "data": "synthetic",
-            "config": {"workload": f"{desc}, global batch {global_batch} sharded over {world} GPU(s) ({B_local} on rank 0; "
-                                   f"{p0['batch']} distinct seeds tiled), 6 alphas, lambda={p['lam']}"
+            "config": {"workload": f"{desc} per rank, global batch {global_batch} sharded over {world} GPU(s) ({B_local} on rank 0), "
+                                   f"6 alphas, lambda={p['lam']}"
                                    + (", fused sweeps (a4+a6 inside a7/a8)" if r["fused"] else ""),
                        "batch_per_gpu": B_local, "global_batch": global_batch, "horizon": T, "kernels": r["variants"],
-                       "valid_backward_passes_rank0": n_ok, "parallelism": f"traj-shard x{world}"},
+                       "valid_backward_passes_rank0": n_ok, "parallelism": f"traj-shard x{world}",
+                       "workload_generation_s": t_gen},
+            "rccl_ranks": (dist.get_world_size() if (world > 1 and dist.get_backend() == "nccl") else (1 if world == 1 else 0)),
+            "collective": ("none (one rank)" if world == 1 else
+                           f"one all-reduce of 8 doubles per iteration over torch.distributed '{dist.get_backend()}'"
+                           + (" (= RCCL)" if dist.get_backend() == "nccl" else " (REHEARSAL: ranks share GPUs, RCCL needs one device per rank)")),
             "batch_iterations_per_s": args.steps / r["elapsed"],
             "stage_ms": r["stage_ms"],
             "roofline": roof,
@@ -389,7 +577,7 @@ def main():
         try:
             if r["fused"] and args.task == "panda_reaching" and not args.generic:
                 cnt = None
-                for name in ("r02_pmc_counters.json", "r01_pmc_counters.json"):
+                for name in ("r03_pmc_counters.json", "r02_pmc_counters.json", "r01_pmc_counters.json"):
                     try:
                         cnt = json.load(open(os.path.join(ROOT, "profiles", name)))["derived"]["backward_fused"]; break
                     except Exception:
@@ -398,7 +586,7 @@ def main():
                 ach_tf = issued / (r["stage_ms"]["backward"] * 1e-3) / 1e12
                 out["roofline"]["issued_mfma"] = {"TFLOPs": ach_tf, "frac_of_fp64_peak": ach_tf / FP64_PEAK_TFLOPS,
                                                   "mfma_16x16x4_per_trajectory_step": cnt["mfma_per_step_per_trajectory"],
-                                                  "source": name}
+                                                  "source": f"profiles/{name} (a separate rocprofv3 --pmc pass, not measured in this run)"}
         except Exception:
             pass
         if weak_line is not None:
@@ -413,6 +601,12 @@ def main():
                                                  "ms_per_step": 1e3 * r2["elapsed"] / k2, "kernels": r2["variants"], "stage_ms": r2["stage_ms"],
                                                  "stage_algorithmic_GBps": {k: ab[k] * B_local / (r2["stage_ms"][k] * 1e-3) / 1e9 for k in r2["stages"]},
                                                  "roofline": roofline_of(p, p0, r2)}
+            # ---- the regularisation range and a mixed batch ------------------------------------------------------------
+            if args.task == "panda_reaching" and not args.generic:
+                try:
+                    out["lambda_sweep"] = lambda_sweep(torch, stream, local_rank, p, fused)
+                except Exception as ex:
+                    out["lambda_sweep"] = {"error": repr(ex)}
             # ---- PCIe-inclusive rate -------------------------------------------------------------------
             if args.task == "panda_reaching" and args.keypoints == "set_interval":
                 try:
@@ -429,7 +623,7 @@ def main():
                     try:
                         ps, ps0, ds = build_problem(kind, Bs, Ts, 5, task)
                         rs = time_config(torch, stream, local_rank, ps, ks, 1, True, False)
-                        pc = parity_check(ps0, rs["eng"], min(ps0["batch"], 2))
+                        pc = parity_check(ps0, rs["eng"], min(ps0["batch"], 2), tiled=kind != "set_interval")
                         rs["eng"].close()
                         sec[key] = {"workload": ds + f", batch={Bs}", "value": Bs * ks / rs["elapsed"], "unit": "trajectory-iterations/s",
                                     "steps": ks, "ms_per_step": 1e3 * rs["elapsed"] / ks, "kernels": rs["variants"], "stage_ms": rs["stage_ms"],
@@ -444,14 +638,14 @@ def main():
                 proj = {}
                 for N_ in (2, 4, 8):
                     try:
-                        Bs = 1024 // N_
-                        ps, ps0, ds = build_problem("set_interval", Bs, 3000, args.min_N, "panda_reaching")
+                        Bs = B_local // N_
+                        ps = slice_problem(p, Bs)                       # the first 1024/N of the headline batch's trajectories
                         rs = time_config(torch, stream, local_rank, ps, 10, 2, True, False)
                         rs["eng"].close()
                         per = Bs * 10 / rs["elapsed"]
                         proj[str(N_)] = {"batch_per_gpu": Bs, "ms_per_step": 1e3 * rs["elapsed"] / 10, "per_gpu_value": per,
                                          "projected_value": N_ * per, "stage_ms": rs["stage_ms"]}
-                        del ps, ps0, rs
+                        del ps, rs
                     except Exception as ex:
                         proj[str(N_)] = {"error": repr(ex)}
                 out["strong_scaling_projection"] = {"note": "global batch 1024 over N GPUs, projected from shards timed on THIS GPU (no "

@@ -172,7 +172,11 @@ int  kpilqr_upload_fd_slab(kpilqr_ctx *ctx, const void *slab, int njobs, int nno
  * ordinary calls beforehand.  Results are valid after kpilqr_sync.  nchunks = 0 lets the library choose (3: one chunk
  * per pipeline stream; the sweeps are latency-bound, so more chunks than streams only add their latency).  Uploads go
  * through the DMA engine, K and k come back through a copy kernel writing the pinned buffers: on this platform two DMA
- * directions do not overlap, a DMA upload and a kernel download do. */
+ * directions do not overlap, a DMA upload and a kernel download do.
+ * Consecutive calls overlap without a wait as long as (njobs, nnom, traj_job_first, traj_nom_first) stay the same -- the
+ * usual case: same key-points, new payload.  When they differ from the iteration still in flight the call first orders
+ * itself behind that whole iteration (the device slab is re-laid-out, so chunks could otherwise overwrite ranges another
+ * chunk stream is still reading).  All offsets are validated before anything is enqueued. */
 typedef struct {
     const void *fd_slab;                        /* kpilqr_fd_slab_layout(njobs, nnom); NULL: no new FD payload, the
                                                    key-point columns already on the device are reused                    */

@@ -116,6 +116,7 @@ struct Ctx {
     hipEvent_t pipe_in = nullptr;
     bool pipe_ready = false, pipe_dirty = false;
     int pipe_chunks = 0;
+    unsigned long long pipe_sig = 0;       // hash of (njobs, nnom, traj_job_first, traj_nom_first) of the streamed iteration in flight
 
     // staging for debug hooks / U_alpha
     double *stage = nullptr;

@@ -322,19 +322,27 @@ int kpilqr_host_free(kpilqr_ctx *c, void *pinned)
     return KPILQR_OK;
 }
 
-int kpilqr_sync(kpilqr_ctx *c)
+// Waits for the context's stream and reports what the device-side argument checks raised since the last report.  Used by
+// kpilqr_sync and by every other entry point that synchronises (blocking downloads): a caller that never calls kpilqr_sync
+// still sees a skipped FD job.
+static int sync_and_report(kpilqr_ctx *c)
 {
-    if (!c) return KPILQR_ERR_ARG;
-    KP_ENTER(c);
     KP_HIP(c, hipMemcpyAsync(c->err_flag_host, c->err_flag, sizeof(int), hipMemcpyDeviceToHost, c->stream));
     KP_HIP(c, hipStreamSynchronize(c->stream));
-    if (*c->err_flag_host) {                     // raised by a device-side argument check since the last sync
+    if (*c->err_flag_host) {
         const int bits = *c->err_flag_host;
         KP_HIP(c, hipMemsetAsync(c->err_flag, 0, sizeof(int), c->stream));
         return set_err(c, KPILQR_ERR_ARG, (bits & 1) ? "FD job index out of range (trajectory, time, column, mode or nominal row): the job was skipped"
                                                      : "device-side argument check failed");
     }
     return KPILQR_OK;
+}
+
+int kpilqr_sync(kpilqr_ctx *c)
+{
+    if (!c) return KPILQR_ERR_ARG;
+    KP_ENTER(c);
+    return sync_and_report(c);
 }
 
 int kpilqr_device_ptr(kpilqr_ctx *c, int which, void **dptr, size_t *bytes)
@@ -349,7 +357,10 @@ int kpilqr_device_ptr(kpilqr_ctx *c, int which, void **dptr, size_t *bytes)
     case KPILQR_BUF_k: p = c->k; sz = B * T * m * 8; break;
     case KPILQR_BUF_RESIDUALS: p = c->r; sz = B * (T + 1) * nr * 8; break;
     case KPILQR_BUF_R_X: p = c->r_x; sz = B * (T + 1) * nr * n * 8; break;
-    case KPILQR_BUF_R_U: p = c->r_u; sz = B * (T + 1) * nr * m * 8; break;
+    case KPILQR_BUF_R_U:
+        // a writable pointer leaves the library: from here on r_u may be non-zero without kpilqr_upload_residuals having
+        // seen it, so the r_u-free instantiations of the fused sweeps (Ctx::ru_zero) are off for this context
+        p = c->r_u; sz = B * (T + 1) * nr * m * 8; c->ru_zero = false; break;
     case KPILQR_BUF_U_NOM: p = c->u_nom; sz = B * T * m * 8; break;
     case KPILQR_BUF_FD_XPLUS: p = c->xplus; sz = (size_t)c->njobs * n * 8; break;
     case KPILQR_BUF_FD_XMINUS: p = c->xminus; sz = (size_t)c->njobs * n * 8; break;
@@ -461,7 +472,7 @@ int kpilqr_keypoint_error_test(kpilqr_ctx *c, int n_iv, const int *intervals, in
     KP_HIP(c, hipMemcpyAsync(iv_dev, intervals, iv_bytes, hipMemcpyHostToDevice, c->stream));
     KP_HIP(c, launch_kp_error_test(c, n_iv, iv_dev, min_N, threshold, good_dev));
     KP_HIP(c, hipMemcpyAsync(good, good_dev, (size_t)n_iv, hipMemcpyDeviceToHost, c->stream));
-    KP_HIP(c, hipStreamSynchronize(c->stream));
+    { const int rcs = sync_and_report(c); if (rcs) return rcs; }
     for (int k = 0; k < n_iv; k++) if (good[k] > 1) return set_err(c, KPILQR_ERR_ARG, "kpilqr_keypoint_error_test: interval out of range");
     return KPILQR_OK;
 }
@@ -547,9 +558,10 @@ int kpilqr_upload_fd(kpilqr_ctx *c, int njobs, const int *job_b, const int *job_
         KP_HIP(c, hipMemcpyAsync(c->job_t, job_t, J * sizeof(int), hipMemcpyHostToDevice, c->stream));
         KP_HIP(c, hipMemcpyAsync(c->job_col, job_col, J * sizeof(int), hipMemcpyHostToDevice, c->stream));
         KP_HIP(c, hipMemcpyAsync(c->job_mode, job_mode, J, hipMemcpyHostToDevice, c->stream));
-        // no nominal rows given: one-sided jobs then fail the device-side range check (nnom = 0) and are reported
+        // no nominal rows given: every job_nom becomes -1, so a one-sided job (mode 1, 2) fails the device-side range check
+        // whatever nnom is, is skipped and reported by the next synchronising call
         if (job_nom) KP_HIP(c, hipMemcpyAsync(c->job_nom, job_nom, J * sizeof(int), hipMemcpyHostToDevice, c->stream));
-        else KP_HIP(c, hipMemsetAsync(c->job_nom, 0, J * sizeof(int), c->stream));
+        else KP_HIP(c, hipMemsetAsync(c->job_nom, 0xff, J * sizeof(int), c->stream));
         KP_HIP(c, hipMemcpyAsync(c->xplus, xplus, J * n * sizeof(double), hipMemcpyHostToDevice, c->stream));
         KP_HIP(c, hipMemcpyAsync(c->xminus, xminus, J * n * sizeof(double), hipMemcpyHostToDevice, c->stream));
     }
@@ -841,21 +853,44 @@ int kpilqr_iterate_streamed(kpilqr_ctx *c, const kpilqr_stream_io *io, int pd_ch
     kpilqr_fd_layout L{};
     const char *slab = (const char *)io->fd_slab;
     if (slab) {
-        // (re)bind the device slab; a growth synchronises every stream first
-        kpilqr_fd_layout probe;
-        fd_layout(n, io->njobs, io->nnom, &probe);
-        if (probe.bytes > c->fd_dev_cap) {
-            rc = join_pipeline(c); if (rc) return rc;
-            for (int i = 0; i < Ctx::kPipeStreams; i++) KP_HIP(c, hipStreamSynchronize(c->pipe_stream[i]));
-        }
-        rc = fd_bind(c, io->njobs, io->nnom, &L);
-        if (rc) return rc;
-        c->njobs = io->njobs; c->nnom = io->nnom; c->eps = io->eps;
+        // ---- validate EVERYTHING before a single operation is enqueued or the context is changed --------------------
         if (io->traj_job_first[0] != 0 || io->traj_job_first[B] != io->njobs)
             return set_err(c, KPILQR_ERR_ARG, "traj_job_first must run from 0 to njobs");
+        unsigned long long sig = 1469598103934665603ULL;           // FNV-1a over what decides where a chunk's payload lands
+        auto mix = [&](unsigned long long v) { sig = (sig ^ v) * 1099511628211ULL; };
+        mix((unsigned)io->njobs); mix((unsigned)io->nnom);
+        for (int b = 0; b <= B; b++) {
+            const int j = io->traj_job_first[b];
+            if (j < 0 || j > io->njobs || (b > 0 && j < io->traj_job_first[b - 1]))
+                return set_err(c, KPILQR_ERR_ARG, "traj_job_first not monotone in [0, njobs]");
+            mix((unsigned)j);
+            if (io->nnom > 0) {
+                const int q = io->traj_nom_first[b];
+                if (q < 0 || q > io->nnom || (b > 0 && q < io->traj_nom_first[b - 1]))
+                    return set_err(c, KPILQR_ERR_ARG, "traj_nom_first not monotone in [0, nnom]");
+                mix((unsigned)q);
+            }
+        }
+        // The device slab is laid out from (njobs, nnom) and a chunk's payload lands at its trajectories' job / nominal
+        // ranges.  Same-stream order protects a chunk's ranges from the NEXT iteration's uploads only while those ranges
+        // are the same; when the layout or the per-trajectory offsets differ from the iteration still in flight, the
+        // new uploads could overwrite regions another chunk stream is still differencing -- so the pipeline is joined
+        // first (every chunk stream then starts behind everything enqueued so far, through pipe_in below).
+        kpilqr_fd_layout probe;
+        fd_layout(n, io->njobs, io->nnom, &probe);
+        if (c->pipe_dirty && (sig != c->pipe_sig || probe.bytes > c->fd_dev_cap)) { rc = join_pipeline(c); if (rc) return rc; }
+        if (probe.bytes > c->fd_dev_cap)                           // a growth frees the old slab: nothing may still read it
+            for (int i = 0; i < Ctx::kPipeStreams; i++) KP_HIP(c, hipStreamSynchronize(c->pipe_stream[i]));
+        rc = fd_bind(c, io->njobs, io->nnom, &L);
+        if (rc) return rc;
+        c->pipe_sig = sig;
+        c->njobs = io->njobs; c->nnom = io->nnom; c->eps = io->eps;
     }
     // order the chunk streams behind whatever the caller enqueued on the context's stream so far (key-points, weights ...)
     KP_HIP(c, hipEventRecord(c->pipe_in, c->stream));
+    // from here on chunk streams hold work: every exit path, errors included, leaves the pipeline marked for joining, so a
+    // later kpilqr_sync / kpilqr_destroy waits for the DMAs that read the caller's buffers
+    c->pipe_dirty = true;
 
     for (int ch = 0; ch < nchunks; ch++) {
         const int b0 = (int)((long long)B * ch / nchunks), b1 = (int)((long long)B * (ch + 1) / nchunks), nb = b1 - b0;
@@ -868,7 +903,6 @@ int kpilqr_iterate_streamed(kpilqr_ctx *c, const kpilqr_stream_io *io, int pd_ch
         // ---- H2D of the chunk ------------------------------------------------------------------------------------
         if (slab) {
             const int j0 = io->traj_job_first[b0], j1 = io->traj_job_first[b1];
-            if (j1 < j0 || j0 < 0 || j1 > io->njobs) return set_err(c, KPILQR_ERR_ARG, "traj_job_first not monotone");
             const size_t J = (size_t)(j1 - j0), jo = (size_t)j0;
             if (J) {
                 KP_HIP(c, h2d(c->xplus + jo * n, slab + L.xplus + jo * n * 8, J * n * 8, s));
@@ -881,7 +915,6 @@ int kpilqr_iterate_streamed(kpilqr_ctx *c, const kpilqr_stream_io *io, int pd_ch
             }
             if (io->nnom > 0) {
                 const int q0 = io->traj_nom_first[b0], q1 = io->traj_nom_first[b1];
-                if (q1 < q0 || q1 > io->nnom) return set_err(c, KPILQR_ERR_ARG, "traj_nom_first not monotone");
                 if (q1 > q0) KP_HIP(c, h2d(c->xnom + (size_t)q0 * n, slab + L.xnom + (size_t)q0 * n * 8, (size_t)(q1 - q0) * n * 8, s));
             }
             // the chunk's jobs: a contiguous range of the job arrays
@@ -918,7 +951,6 @@ int kpilqr_iterate_streamed(kpilqr_ctx *c, const kpilqr_stream_io *io, int pd_ch
         if (io->delta_J) KP_HIP(c, hipMemcpyAsync(io->delta_J + o, v.delta_J, cnt * 8, hipMemcpyDeviceToHost, s));
         if (io->status) KP_HIP(c, hipMemcpyAsync(io->status + o, v.status, cnt * 4, hipMemcpyDeviceToHost, s));
     }
-    c->pipe_dirty = true;
     return KPILQR_OK;
 }
 
@@ -979,8 +1011,7 @@ int kpilqr_get_AB(kpilqr_ctx *c, double *A, double *B)
     KP_HIP(c, launch_unpack_AB(c, A ? dA : nullptr, B ? dB : nullptr));
     if (A) KP_HIP(c, hipMemcpyAsync(A, dA, szA, hipMemcpyDeviceToHost, c->stream));
     if (B) KP_HIP(c, hipMemcpyAsync(B, dB, szB, hipMemcpyDeviceToHost, c->stream));
-    KP_HIP(c, hipStreamSynchronize(c->stream));
-    return KPILQR_OK;
+    return sync_and_report(c);
 }
 
 int kpilqr_set_cost_derivs(kpilqr_ctx *c, const double *l_x, const double *l_xx, const double *l_u, const double *l_uu)
@@ -1017,8 +1048,7 @@ int kpilqr_get_cost_derivs(kpilqr_ctx *c, double *l_x, double *l_xx, double *l_u
     if (l_xx) KP_HIP(c, hipMemcpyAsync(l_xx, d2, s2, hipMemcpyDeviceToHost, c->stream));
     if (l_u) KP_HIP(c, hipMemcpyAsync(l_u, d3, s3, hipMemcpyDeviceToHost, c->stream));
     if (l_uu) KP_HIP(c, hipMemcpyAsync(l_uu, d4, s4, hipMemcpyDeviceToHost, c->stream));
-    KP_HIP(c, hipStreamSynchronize(c->stream));
-    return KPILQR_OK;
+    return sync_and_report(c);
 }
 
 const char *kpilqr_backward_variant(kpilqr_ctx *c) { return c ? c->bwd_variant : ""; }

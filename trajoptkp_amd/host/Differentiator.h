@@ -47,6 +47,7 @@ struct FDStaging {
     size_t slab_cap = 0;
     int plan_jobs = 0, plan_noms = 0;
     void plan(int total_jobs, int total_noms, int n_);
+    bool complete() const { return njobs == plan_jobs && nnom == plan_noms; }   // every planned job and nominal row was filled
 };
 
 class Differentiator {

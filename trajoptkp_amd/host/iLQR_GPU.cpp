@@ -160,6 +160,9 @@ void iLQR_GPU::GenerateDerivatives()
         staging.plan(jobs, kps, n);
         activeDifferentiator->DynamicsDerivativesPlanned(staging, 0, keypoint_generator->keypoints, eps);
     }
+    // the slab's array offsets were computed from the PLANNED totals: an under-filled plan would make the device read
+    // x-, xnom and the job arrays at the wrong offsets
+    if (!staging.complete()) { std::fprintf(stderr, "FD staging: %d of %d jobs, %d of %d nominal rows filled\n", staging.njobs, staging.plan_jobs, staging.nnom, staging.plan_noms); std::exit(1); }
     rc = kpilqr_upload_fd_slab(ctx, staging.slab, staging.njobs, staging.nnom, eps);
     if (rc) fatal("kpilqr_upload_fd_slab", rc);
     if ((rc = kpilqr_fd_difference(ctx))) fatal("kpilqr_fd_difference", rc);

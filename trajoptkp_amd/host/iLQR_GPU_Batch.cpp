@@ -175,6 +175,9 @@ void iLQR_GPU_Batch::GenerateDerivatives(const std::vector<int> &who)
         times.insert(times.end(), s.kp_times.begin(), s.kp_times.end());
     }
     if ((rc = kpilqr_set_keypoints(ctx, offs.data(), times.data()))) fatal("kpilqr_set_keypoints", rc);
+    // the slab's array offsets were computed from the PLANNED totals: an under-filled plan would make the device read
+    // x-, xnom and the job arrays at the wrong offsets
+    if (!staging.complete()) { std::fprintf(stderr, "FD staging: %d of %d jobs, %d of %d nominal rows filled\n", staging.njobs, staging.plan_jobs, staging.nnom, staging.plan_noms); std::exit(1); }
     rc = kpilqr_upload_fd_slab(ctx, staging.slab, staging.njobs, staging.nnom, eps);
     if (rc) fatal("kpilqr_upload_fd_slab", rc);
     if ((rc = kpilqr_fd_difference(ctx))) fatal("kpilqr_fd_difference", rc);
