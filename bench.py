@@ -443,7 +443,12 @@ def launch_ranks(n, argv):
     sock = socket.socket(); sock.bind(("127.0.0.1", 0)); port = sock.getsockname()[1]; sock.close()
     cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={n}", "--master-addr", "127.0.0.1",
            "--master-port", str(port), os.path.abspath(__file__)] + argv
-    return subprocess.call(cmd, env=env)
+    # rank 0's JSON line goes to stdout, whatever else the ranks print there (gloo's connection banner in a rehearsal) to stderr
+    child = subprocess.Popen(cmd, env=env, stdout=subprocess.PIPE, text=True)
+    for line in child.stdout:
+        (sys.stdout if line.lstrip().startswith("{") else sys.stderr).write(line)
+        sys.stdout.flush()
+    return child.wait()
 
 
 def main():

@@ -107,6 +107,7 @@ def test_streamed_iterations_with_a_changing_slab_layout(fused):
             e.iterate_streamed(fd=s, eps=p["eps"], lam=lam, K=K, k=k, cost_pred=cp, status=st, nchunks=3, **pin)     # no wait in between
             outs.append((K, k, cp, st))
         e.sync()
+        outs = [tuple(np.array(a) for a in o) for o in outs]       # the pinned buffers are freed with the engine
     for (K, k, cp, st), (K0, k0, res0) in zip(outs, want):
         assert np.all(st == 0)
         assert np.array_equal(K, K0) and np.array_equal(k, k0)
