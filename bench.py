@@ -238,7 +238,7 @@ def kp_pairs(p0):
             float(np.mean([int(np.count_nonzero(np.asarray(c) < p0["m"])) for (_, c) in p0["kp_rows"]])))
 
 
-def time_config(torch, stream, dev, p, steps, warmup, fused, generic, world=1, dist=None):
+def time_config(torch, stream, dev, p, steps, warmup, fused, generic, world=1, dist=None, kp_ordered=True):
     """Times `steps` iterations of problem p on the engine; returns timings and the live engine."""
     from trajoptkp_amd import Engine, synth
     from trajoptkp_amd import distributed as kd
@@ -248,14 +248,18 @@ def time_config(torch, stream, dev, p, steps, warmup, fused, generic, world=1, d
     is_fused = "fused" in eng.backward_variant
     tail = eng.backward_variant.rsplit("_", 1)[-1] if "tiled_" in eng.backward_variant else ""
     a4, a6 = "a4" in tail, "a6" in tail          # tiled shapes: which of a4 / a6 run inside the sweeps
-    synth.upload(eng, p)
+    # Fused sweeps: the FD payload is resident KEY-POINT ORDERED (kpilqr_upload_fd_kp) and there is no differencing stage at
+    # all -- with one wave per trajectory the backward sweep differences x+ / x- itself at every segment crossing (every timed
+    # step does: nothing marks the column store valid), smaller batches run the streaming differencing kernel inside the
+    # "backward" stage.  Materialising / tiled contexts: job lists and kpilqr_fd_difference, as before.
+    synth.upload(eng, p, kp_ordered=is_fused and kp_ordered)
     lam = np.full(B, p["lam"])
     alphas = np.array([(i / 6.0) ** 2 for i in range(1, 7)])
-    stages = ("fd_difference",) + (() if (is_fused or a4) else ("interpolate",)) + (() if (is_fused or a6) else ("cost_derivs",)) \
+    stages = (() if is_fused else ("fd_difference",)) + (() if (is_fused or a4) else ("interpolate",)) + (() if (is_fused or a6) else ("cost_derivs",)) \
         + ("backward", "forward")
     calls = {"fd_difference": eng.fd_difference, "interpolate": eng.interpolate, "cost_derivs": eng.cost_derivs,
              "backward": lambda: eng.backward(None, 100, fetch=False), "forward": lambda: eng.forward_linear(None, fetch=False)}
-    eng.fd_difference()
+    if "fd_difference" in stages: eng.fd_difference()
     if "interpolate" in stages: eng.interpolate()
     if "cost_derivs" in stages: eng.cost_derivs()
     eng.backward(lam, 100, fetch=False)               # uploads lambda / alphas once
@@ -293,7 +297,8 @@ def time_config(torch, stream, dev, p, steps, warmup, fused, generic, world=1, d
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
         elapsed = float(tt.item())
     stage_ms = {name: float(np.mean([evs[s][i][0].elapsed_time(evs[s][i][1]) for s in range(steps)])) for i, name in enumerate(stages)}
-    return dict(eng=eng, elapsed=elapsed, stage_ms=stage_ms, stages=stages, fused=is_fused,
+    raw = is_fused and kp_ordered and (2 * B > 1024 or os.environ.get("KPILQR_FUSED_WAVES") == "1") and os.environ.get("KPILQR_FUSED_RAW") != "0"
+    return dict(eng=eng, elapsed=elapsed, stage_ms=stage_ms, stages=stages, fused=is_fused, raw=raw, kp_ordered=is_fused and kp_ordered,
                 variants={"backward": eng.backward_variant, "forward": eng.forward_variant})
 
 
@@ -308,9 +313,10 @@ def lambda_sweep(torch, stream, dev, p, fused, steps=5):
     from trajoptkp_amd import Engine, synth
     B = p["batch"]
     eng = Engine(p["dof"], p["m"], p["T"], p["nr"], batch=B, device=dev, stream=stream.cuda_stream, fused=fused)
-    synth.upload(eng, p)
+    synth.upload(eng, p, kp_ordered="fused" in eng.backward_variant)
     alphas = np.array([(i / 6.0) ** 2 for i in range(1, 7)])
-    eng.fd_difference()
+    if "fused" not in eng.backward_variant:
+        eng.fd_difference()
     eng.forward_linear(alphas, fetch=False)
     rows = {}
     cases = [(f"{lam:g}", np.full(B, lam)) for lam in LAMBDAS] + [("mixed", np.array([LAMBDAS[b % 6] for b in range(B)]))]
@@ -352,7 +358,9 @@ def roofline_of(p, p0, r, pmc=None):
     a4, a6 = r["fused"] or "a4" in tail, r["fused"] or "a6" in tail
     pairs = kp_pairs(p0)
     kb = 8 * T * (m * n + m)                                                        # gains out
-    kb += 8 * (pairs[0] * 2 * n + pairs[1] * n) if a4 else 8 * T * (n * n + n * m)   # A, B: key-point columns or every step
+    cols = 8 * (pairs[0] * 2 * n + pairs[1] * n)                                    # the key-point columns of a trajectory
+    # A, B: key-point columns (the raw sweep reads x+ and x- and writes the differenced column: 3x) or every step
+    kb += (3 * cols + pairs[0] if r.get("raw") else cols) if a4 else 8 * T * (n * n + n * m)
     ru0 = r["fused"] and not np.any(p0["r_u"])            # r_u never uploaded: the fused backward sweep does not read it
     kb += 8 * T * nr * (1 + n + (0 if ru0 else m)) if a6 else 8 * T * (n * n + n + m * m + m)   # residuals + Jacobians or l_*
     flops = flops_a7(n, m) * T * B
@@ -560,7 +568,9 @@ def main():
             "scaling": "weak" if weak else "strong", "vs_baseline": None, "dtype": "f64", "data": "synthetic",
             "config": {"workload": f"{desc} per rank, global batch {global_batch} sharded over {world} GPU(s) ({B_local} on rank 0), "
                                    f"6 alphas, lambda={p['lam']}"
-                                   + (", fused sweeps (a4+a6 inside a7/a8)" if r["fused"] else ""),
+                                   + (", fused sweeps (a4+a6 inside a7/a8)" if r["fused"] else "")
+                                   + (", key-point ordered FD payload differenced inside the backward sweep (no fd_difference stage)" if r.get("raw") else
+                                      ", key-point ordered FD payload" if r.get("kp_ordered") else ""),
                        "batch_per_gpu": B_local, "global_batch": global_batch, "horizon": T, "kernels": r["variants"],
                        "valid_backward_passes_rank0": n_ok, "parallelism": f"traj-shard x{world}",
                        "workload_generation_s": t_gen},

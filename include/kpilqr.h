@@ -31,7 +31,7 @@
 extern "C" {
 #endif
 
-#define KPILQR_VERSION 200   /* 0.2.0 */
+#define KPILQR_VERSION 300   /* 0.3.0 */
 
 typedef struct kpilqr_ctx kpilqr_ctx;
 
@@ -72,7 +72,8 @@ enum {
 
 /* which device buffer kpilqr_device_ptr returns */
 enum {
-    KPILQR_BUF_STEP_RECORDS = 0, /* [batch][T][rec] : A|B|l_xx|l_x|l_uu|l_u per step  */
+    KPILQR_BUF_STEP_RECORDS = 0, /* [batch][T][rec] : A|B|l_xx|l_x|l_uu|l_u per step; a FUSED
+                                    context has none until this (or a materialising call) asks for them */
     KPILQR_BUF_K = 1,            /* [batch][T][n][m]  (column-major m x n, as Eigen)             */
     KPILQR_BUF_k = 2,            /* [batch][T][m]                                                */
     KPILQR_BUF_RESIDUALS = 3,    /* [batch][T+1][nr]                                             */
@@ -163,6 +164,30 @@ typedef struct {
 int  kpilqr_fd_slab_layout(kpilqr_ctx *ctx, int njobs, int nnom, kpilqr_fd_layout *out);
 int  kpilqr_upload_fd_slab(kpilqr_ctx *ctx, const void *slab, int njobs, int nnom, double eps);
 
+/* ---- key-point ordered FD payload: no job lists at all -------------------------------------------------------------------
+ * The same FD results laid out BY the key-point lists the context holds (kpilqr_set_keypoints / kpilqr_generate_keypoints +
+ * kpilqr_get_keypoints): CSR entry e = position in kp_times, i.e. (trajectory b, DoF d, key-point time t = kp_times[e]),
+ * and three slots per entry,
+ *     kind 0: qpos_d perturbed  -> column d       of A      (Differentiator.cpp:328-428)
+ *     kind 1: qvel_d perturbed  -> column d + dof of A      (:226-325)
+ *     kind 2: ctrl_d perturbed  -> column d       of B      (:81-223; only d < num_ctrl, other kind-2 slots are ignored)
+ *   xplus  [entries][3][n]   next state after the + perturbation  (a backward-only difference: the unperturbed next state)
+ *   xminus [entries][3][n]   next state after the - perturbation  (a forward-only difference:  the unperturbed next state)
+ *   mode   [entries]         bit k set: kind k is one-sided -> (xplus - xminus) / eps, else (xplus - xminus) / (2 eps)
+ * so the host FD loop writes every perturbed next state straight to its slot, nothing carries indices, and the library
+ * never walks or sorts anything.  On a KPILQR_FLAG_FUSED context with one wavefront per trajectory (batch > #SIMDs / 2) there
+ * is then NO differencing kernel either: the backward sweep reads the slots of a key-point when it reaches it, forms the
+ * column (the arithmetic of Differentiator.cpp:166-222,441-457, bit for bit what kpilqr_fd_difference gives) and keeps it
+ * for the forward sweep.  Every other context accepts the payload too (it is differenced by a streaming kernel first).
+ * The payload refers to the CURRENT key-points: upload it after them; new key-points invalidate it.  `entries` must be
+ * kp_offsets[batch*dof].  One hipMemcpyAsync; with a pinned slab the call does not wait. */
+typedef struct {
+    size_t xplus, xminus, mode;                 /* byte offsets of the arrays inside the slab */
+    size_t bytes;
+} kpilqr_fdkp_layout;
+int  kpilqr_fd_kp_layout(kpilqr_ctx *ctx, int entries, kpilqr_fdkp_layout *out);
+int  kpilqr_upload_fd_kp(kpilqr_ctx *ctx, const void *slab, int entries, double eps);
+
 /* One whole iteration for the batch, PIPELINED over chunks of trajectories: chunk c's uploads, its kernels and its
  * downloads run on their own stream, so H2D(c+1), kernels(c) and D2H(c-1) overlap (and so do consecutive calls: nothing
  * here waits for the previous iteration).  Every host pointer must be pinned (kpilqr_host_alloc); NULL inputs keep what
@@ -189,6 +214,9 @@ typedef struct {
     double *K, *k;                              /* out: [batch][T][n][m], [batch][T][m]                                  */
     double *cost_pred, *delta_J;                /* out: [batch][n_alpha], [batch]                                        */
     int *status;                                /* out: [batch]                                                          */
+    const void *fd_kp_slab;                     /* key-point ordered payload (kpilqr_fd_kp_layout) instead of fd_slab; the
+                                                   chunks' ranges follow from the key-points, no offset arrays needed     */
+    int entries;                                /* kp_offsets[batch*dof]                                                 */
 } kpilqr_stream_io;
 int  kpilqr_iterate_streamed(kpilqr_ctx *ctx, const kpilqr_stream_io *io, int pd_check_stride, int nchunks);
 

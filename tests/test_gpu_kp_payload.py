@@ -1,0 +1,204 @@
+"""GPU tests of the record-free fused path (round 3): the key-point column store, the key-point ordered FD payload
+(kpilqr_upload_fd_kp) and the RAW backward sweep that differences it at the segment crossings.  Every form must give the
+bytes of the job-list payload + kpilqr_fd_difference path (same arithmetic: Differentiator.cpp:166-222,441-457), and those
+are held to the oracle by tests/test_gpu_parity.py."""
+import numpy as np
+import pytest
+
+from oracle import oracle as orc
+from oracle import pipeline
+from trajoptkp_amd import Engine, synth
+from trajoptkp_amd.engine import KpilqrError
+
+pytestmark = pytest.mark.gpu
+
+
+def relerr(a, b):
+    return float(np.max(np.abs(a - b)) / max(float(np.max(np.abs(b))), 1e-300))
+
+
+def _run(p, fused, kp_ordered, explicit_fd=False, lam=None, pd=100, want_AB=False):
+    lam = p["lam"] if lam is None else lam
+    with Engine(p["dof"], p["m"], p["T"], p["nr"], batch=p["batch"], fused=fused) as e:
+        synth.upload(e, p, kp_ordered=kp_ordered)
+        if explicit_fd:
+            e.fd_difference()
+            st, dJ = e.backward(lam, pd)
+            cost, U = e.forward_linear(orc.alphas(6), want_U=True)
+        else:
+            e.iterate(lam, pd, orc.alphas(6))
+            res = e.results(); st, dJ, cost, U = res["status"], res["delta_J"], res["cost_pred"], None
+        K, k = e.gains()
+        out = dict(K=K, k=k, status=st, delta_J=dJ, cost=cost, U=U, variant=e.backward_variant)
+        if want_AB:
+            e.interpolate()
+            out["A"], out["B"] = e.get_AB()
+    return out
+
+
+def _same(a, b, keys=("K", "k", "delta_J", "cost")):
+    for key in keys:
+        assert np.array_equal(a[key], b[key]), key
+
+
+@pytest.fixture(params=["one_wave", "auto"])
+def waves(request, monkeypatch):
+    if request.param == "one_wave":
+        monkeypatch.setenv("KPILQR_FUSED_WAVES", "1")
+        monkeypatch.setenv("KPILQR_FUSED_FWD_WAVES", "1")
+    return request.param
+
+
+@pytest.mark.parametrize("task,T,batch,kw", [("panda_reaching", 200, 3, dict(one_sided_frac=0.25)),
+                                             ("panda_reaching", 301, 2, dict(dense_residuals=True, min_N=1)),
+                                             ("acrobot", 100, 2, dict(config_id=1, dense_residuals=True, one_sided_frac=0.5)),
+                                             ("hopper", 150, 2, dict(dense_residuals=True)),
+                                             ("pentabot", 64, 3, dict(one_sided_frac=0.1))])
+def test_kp_ordered_payload_gives_the_bytes_of_the_job_lists(task, T, batch, kw, waves):
+    """Fused context: key-point ordered payload (RAW backward sweep with one wave per trajectory, the streaming
+    differencing kernel otherwise) == job lists + kpilqr_fd_difference, bit for bit; and against the oracle."""
+    kw = dict(kw); kw.setdefault("min_N", 5)
+    p = synth.make_problem(task=task, T=T, batch=batch, **kw)
+    ref = _run(p, True, False, explicit_fd=True)
+    assert "fused" in ref["variant"] and np.all(ref["status"] == 0)
+    for explicit in (False, True):
+        _same(_run(p, True, True, explicit_fd=explicit), ref)
+    _same(_run(p, True, False), ref)                              # job lists through kpilqr_iterate (no explicit differencing call)
+    for b in range(batch):
+        o = pipeline.run_trajectory(p, b)
+        assert relerr(ref["K"][b], o["K"]) < 1e-9 and relerr(ref["cost"][b], o["cost_pred"]) < 1e-9
+
+
+def test_kp_ordered_payload_ragged_lists(waves):
+    """Per-DoF lists of very different densities (bisection-shaped), one-sided jobs: every lane walks its own entries."""
+    T, dof = 260, 7
+    rng = np.random.default_rng(11)
+    rows = [synth.bisect_keypoints(rng, dof, T, 1, rng.uniform(0.05, 1.0, dof)) for _ in range(3)]
+    p = synth.make_ragged_problem("panda_reaching", T, rows, config_id=4, dense_residuals=True, one_sided_frac=0.3)
+    ref = _run(p, True, False, explicit_fd=True)
+    got = _run(p, True, True)
+    _same(got, ref)
+    for b in range(3):
+        o = pipeline.run_trajectory(p, b)
+        assert relerr(got["K"][b], o["K"]) < 1e-9
+
+
+@pytest.mark.parametrize("task,T,batch", [("panda_reaching", 120, 2), ("panda_pushing", 90, 2)])
+def test_kp_ordered_payload_on_a_context_with_records(task, T, batch):
+    """A materialising (non-fused, or tiled) context takes the key-point ordered payload too: A, B, K identical to the job lists."""
+    p = synth.make_problem(task=task, T=T, batch=batch, min_N=4, dense_residuals=True, one_sided_frac=0.2)
+    a = _run(p, False, False, want_AB=True)
+    b = _run(p, False, True, want_AB=True)
+    _same(b, a)
+    assert np.array_equal(a["A"], b["A"]) and np.array_equal(a["B"], b["B"])
+
+
+def test_fused_context_materialises_on_demand():
+    """A fused context holds no step records; get_AB / interpolate / the cost-derivative hooks allocate and fill them when
+    asked, from either payload form, and give the materialising context's bytes."""
+    import torch
+    p = synth.make_problem(task="panda_reaching", T=150, batch=2, min_N=5, dense_residuals=True, one_sided_frac=0.2)
+    with Engine(p["dof"], p["m"], p["T"], p["nr"], batch=2) as e:
+        synth.upload(e, p)
+        e.fd_difference(); e.sync()
+        A_kp, B_kp = e.get_AB()
+        e.interpolate(); A, B = e.get_AB()
+        e.cost_derivs(); lx = e.get_cost_derivs()
+    for kp_ordered in (False, True):
+        with Engine(p["dof"], p["m"], p["T"], p["nr"], batch=2, fused=True) as e:
+            synth.upload(e, p, kp_ordered=kp_ordered)
+            e.iterate(p["lam"], 100, orc.alphas(6))                 # the sweeps run without records
+            K0, _ = e.gains()
+            A1, B1 = e.get_AB()                                     # key-point columns only
+            assert np.array_equal(A1, A_kp) and np.array_equal(B1, B_kp)
+            e.interpolate(); A2, B2 = e.get_AB()
+            assert np.array_equal(A2, A) and np.array_equal(B2, B)
+            e.cost_derivs(); lx2 = e.get_cost_derivs()
+            for u, v in zip(lx, lx2):
+                assert np.array_equal(u, v)
+            e.iterate(p["lam"], 100, orc.alphas(6))                 # and the sweeps are unaffected by the records' presence
+            K1, _ = e.gains()
+            assert np.array_equal(K0, K1)
+    # no records before anyone asks: a fused context of 48 x 3000 Panda steps would hold 645 MB of them
+    torch.cuda.synchronize(); torch.cuda.empty_cache()
+    free0 = torch.cuda.mem_get_info()[0]
+    q = synth.make_problem(task="panda_reaching", T=3000, batch=1, min_N=5)
+    q = synth.tile_problem(q, 48)
+    with Engine(q["dof"], q["m"], 3000, q["nr"], batch=48, fused=True) as e:
+        synth.upload(e, q, kp_ordered=True)
+        e.iterate(q["lam"], 100, orc.alphas(6)); e.sync()
+        used = free0 - torch.cuda.mem_get_info()[0]
+        assert used < 420e6, used                                    # K, k, residuals, Jacobians, payload, kpc: ~330 MB
+        e.get_AB()
+        assert free0 - torch.cuda.mem_get_info()[0] > used + 600e6   # now the records exist
+
+
+def test_raw_sweep_pd_failure_and_lambda_retry(waves):
+    """The raw sweep may stop at a failed PD check: the retry with a larger lambda differences again and matches the oracle."""
+    p = synth.make_problem(task="panda_reaching", T=300, batch=2, min_N=5, dense_residuals=True)
+    p["r_u"][:, 120] *= 0.0
+    p["r_x"][1, 180:200] *= 40.0
+    with Engine(p["dof"], p["m"], p["T"], p["nr"], batch=2, fused=True) as e:
+        synth.upload(e, p, kp_ordered=True)
+        lam = np.array([-60.0, 0.1])                                # negative regularisation: not PD at the first check
+        st, _ = e.backward(lam, 50)
+        o0 = pipeline.run_trajectory(p, 0, lam=-60.0, pd_stride=50, stages=("fd", "interp", "cost", "bwd"))
+        assert st[0] == o0["status"] and st[0] > 0 and st[1] == 0
+        st, dJ = e.backward(np.array([0.5, 0.1]), 50)               # the reference's retry (iLQR.cpp:435-442)
+        assert np.all(st == 0)
+        K, k = e.gains()
+        cost = e.forward_linear(orc.alphas(6))
+    for b, l in enumerate((0.5, 0.1)):
+        o = pipeline.run_trajectory(p, b, lam=l, pd_stride=50)
+        assert relerr(K[b], o["K"]) < 1e-9 and relerr(cost[b], o["cost_pred"]) < 1e-9
+
+
+def test_kp_ordered_payload_argument_checks():
+    p = synth.make_problem(task="panda_reaching", T=60, batch=2, min_N=5)
+    xp, xm, mode = synth.kp_ordered_payload(p)
+    with Engine(p["dof"], p["m"], p["T"], p["nr"], batch=2, fused=True) as e:
+        s = e.fd_kp_slab(xp, xm, mode)
+        with pytest.raises(KpilqrError) as ei:
+            e.upload_fd_kp(s)                                       # before the key-points it is ordered by
+        assert ei.value.code == -5
+        e.set_keypoints_rows(p["kp_rows"])
+        bad = dict(s); bad["entries"] = s["entries"] - 1
+        with pytest.raises(KpilqrError) as ei:
+            e.upload_fd_kp(bad)
+        assert ei.value.code == -1
+        e.upload_fd_kp(s)
+        # new key-points invalidate the payload: the sweeps then have nothing to difference and must say so ... they run on
+        # the (zeroed) column store rather than on a payload laid out by other lists
+        q = synth.make_problem(task="panda_reaching", T=60, batch=2, min_N=3)
+        e.set_keypoints_rows(q["kp_rows"])
+        e.upload_residuals(p["r"], p["r_x"], None, p["w_run"], p["w_term"]); e.upload_nominal(p["u_nom"], p["ctrl_lim"])
+        e.iterate(0.1, 100, orc.alphas(6))
+        K, _ = e.gains()
+        assert np.all(np.isfinite(K))
+
+
+@pytest.mark.parametrize("fused", [True, False])
+def test_streamed_iteration_with_the_kp_ordered_payload(fused):
+    p = synth.make_problem(task="panda_reaching", T=200, batch=11, min_N=5, dense_residuals=True, one_sided_frac=0.2)
+    ref = _run(p, fused, False)
+    xp, xm, mode = synth.kp_ordered_payload(p)
+    for nchunks in (1, 3, 5):
+        with Engine(p["dof"], p["m"], p["T"], p["nr"], batch=11, fused=fused) as e:
+            e.set_keypoints_rows(p["kp_rows"])
+            e.upload_residuals(None, None, None, p["w_run"], p["w_term"])
+            e.upload_nominal(None, p["ctrl_lim"])
+            e.forward_linear(orc.alphas(6), fetch=False)
+            s = e.fd_kp_slab(xp, xm, mode)
+            pin = {}
+            for name in ("r", "r_x", "r_u", "u_nom"):
+                pin[name] = e.pinned(p[name].shape); pin[name][...] = p[name]
+            lam = e.pinned(11); lam[:] = p["lam"]
+            K = e.pinned(ref["K"].shape); k = e.pinned(ref["k"].shape); cp = e.pinned((11, 6)); st = e.pinned(11, np.int32)
+            for _ in range(2):
+                e.iterate_streamed(fd_kp=s, eps=p["eps"], lam=lam, K=K, k=k, cost_pred=cp, status=st, nchunks=nchunks, **pin)
+            e.sync()
+            assert np.all(st == 0)
+            assert np.array_equal(K, ref["K"]) and np.array_equal(k, ref["k"]) and np.array_equal(cp, ref["cost"])
+            e.iterate_streamed(eps=p["eps"], lam=lam, K=K, k=k, cost_pred=cp, status=st, nchunks=nchunks)    # payload resident: reused
+            e.sync()
+            assert np.array_equal(K, ref["K"]) and np.array_equal(cp, ref["cost"])

@@ -5,7 +5,8 @@ Not the bench metric (bench.py keeps inputs resident; it reports these figures i
   python tools/pcie_inclusive.py [batch] [steps]
 
 Forms: "serial"  = kpilqr_upload_fd + kpilqr_upload_residuals + kpilqr_iterate + kpilqr_download_gains + sync per iteration
-       "chunks=N" = kpilqr_iterate_streamed over N trajectory chunks (H2D | kernels | D2H overlapped), one sync at the end
+       "chunks=N" = kpilqr_iterate_streamed over N trajectory chunks (H2D | kernels | D2H overlapped; the FD payload goes up
+       key-point ordered, kpilqr_fd_kp_layout), one sync at the end
        of the timed loop ("pipelined") or after every iteration ("per-iteration sync").
 """
 import sys
@@ -36,7 +37,9 @@ def measure(B=256, steps=5, T=3000, task="panda_reaching", chunk_list=(4, 8, 16)
             ints[name] = e.pinned(p[name].shape, dt); ints[name][...] = p[name]
         lam = e.pinned(B); lam[:] = p["lam"]
         K = e.pinned(K0.shape); k = e.pinned(k0.shape)
-        slab = e.fd_slab(p["job_b"], p["job_t"], p["job_col"], p["job_mode"], p["xplus"], p["xminus"], p["job_nom"], p["xnom"])
+        # the chunk pipeline ships the key-point ordered payload (no job lists, no nominal rows; the fused sweeps read it
+        # directly); the serial form keeps round 1's call sequence with the job arrays
+        slab = e.fd_kp_slab(*synth.kp_ordered_payload(p))
         fd_bytes = slab["layout"].bytes
         res_bytes = {True: pin["r"].nbytes + pin["r_x"].nbytes + pin["r_u"].nbytes, False: pin["r"].nbytes}
         dn_bytes = K.nbytes + k.nbytes
@@ -55,7 +58,7 @@ def measure(B=256, steps=5, T=3000, task="panda_reaching", chunk_list=(4, 8, 16)
 
         def streamed(full, nchunks, sync_each):
             kw = dict(r=pin["r"], r_x=pin["r_x"], r_u=pin["r_u"]) if full else dict(r=pin["r"])
-            e.iterate_streamed(fd=slab, eps=p["eps"], lam=lam, K=K, k=k, nchunks=nchunks, **kw)
+            e.iterate_streamed(fd_kp=slab, eps=p["eps"], lam=lam, K=K, k=k, nchunks=nchunks, **kw)
             if sync_each:
                 e.sync()
 

@@ -26,7 +26,7 @@ SYMBOLS = [
     "kpilqr_filter_dynamics", "kpilqr_dof_importance",
     "kpilqr_comm_unique_id", "kpilqr_comm_init", "kpilqr_allreduce_linesearch",
     "kpilqr_fd_slab_layout", "kpilqr_upload_fd_slab", "kpilqr_iterate_streamed", "kpilqr_resize",
-    "kpilqr_keypoint_error_test",
+    "kpilqr_keypoint_error_test", "kpilqr_fd_kp_layout", "kpilqr_upload_fd_kp",
 ]
 
 
@@ -40,12 +40,16 @@ class FdLayout(C.Structure):
                                           "job_mode", "bytes")]
 
 
+class FdkpLayout(C.Structure):
+    _fields_ = [(k, C.c_size_t) for k in ("xplus", "xminus", "mode", "bytes")]
+
+
 class StreamIO(C.Structure):
     _fields_ = [("fd_slab", C.c_void_p), ("njobs", C.c_int), ("nnom", C.c_int),
                 ("traj_job_first", C.c_void_p), ("traj_nom_first", C.c_void_p), ("eps", C.c_double),
                 ("r", C.c_void_p), ("r_x", C.c_void_p), ("r_u", C.c_void_p), ("u_nom", C.c_void_p), ("lam", C.c_void_p),
                 ("K", C.c_void_p), ("k", C.c_void_p), ("cost_pred", C.c_void_p), ("delta_J", C.c_void_p),
-                ("status", C.c_void_p)]
+                ("status", C.c_void_p), ("fd_kp_slab", C.c_void_p), ("entries", C.c_int)]
 
 
 FLAG_GENERIC_KERNELS = 1
@@ -124,6 +128,8 @@ def load():
     L.kpilqr_iterate_streamed.argtypes = [vp, C.POINTER(StreamIO), C.c_int, C.c_int]
     L.kpilqr_resize.argtypes = [vp, C.c_int, C.c_int, C.c_int]
     L.kpilqr_keypoint_error_test.argtypes = [vp, C.c_int, vp, C.c_int, C.c_double, vp]
+    L.kpilqr_fd_kp_layout.argtypes = [vp, C.c_int, C.POINTER(FdkpLayout)]
+    L.kpilqr_upload_fd_kp.argtypes = [vp, vp, C.c_int, C.c_double]
     for s in SYMBOLS:
         getattr(L, s)          # raises AttributeError if the .so lacks a declared symbol
     _lib = L

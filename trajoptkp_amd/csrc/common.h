@@ -77,6 +77,34 @@ struct Ctx {
     bool tiled_a4 = false;       // KPILQR_FLAG_FUSED on a tiled shape: A, B are interpolated (a4) inside the sweeps
     bool ru_zero = true;         // r_u was never written since create / resize (the buffer starts zeroed): r_u = 0 exactly
 
+    // ---- fused contexts: the key-point column store (no step records) ---------------------------------------------------
+    // A fused (one-tile) context does not allocate step records: its sweeps read the differenced key-point columns from
+    //   kpc [entry][3][n],  entry = position in the per-DoF CSR (kp_offsets / kp_times),
+    //                       kind 0: position column (A col d), 1: velocity column (A col d + dof), 2: control column (B col d, d < m)
+    // i.e. 3n doubles per (trajectory, DoF, key-point) instead of a whole record per (trajectory, step).  The records are
+    // allocated on demand when something asks for the materialised sequence (kpilqr_interpolate, get_AB, the error test ...).
+    double *kpc = nullptr;
+    size_t kpc_cap = 0;          // bytes
+    bool kpc_valid = false;      // kpc holds ALL differenced columns of the resident FD payload for the current key-points
+    bool kpc_touched = false;    // a raw backward sweep has (re)written kpc from the resident payload since it was uploaded
+    int *kp_entry = nullptr;     // [batch*dof][T]: CSR entry of (list, t), or -1        (built with the segment map)
+    int *kp_entry_list = nullptr;// [entries]: list (= b*dof + d) of a CSR entry
+    size_t kp_entry_cap = 0, kp_entry_list_cap = 0;   // ints
+    bool entry_tables_valid = false;
+    bool have_rec = false;       // step records allocated (always on a non-fused context; on demand on a fused one)
+    bool rec_synced = false;     // fused context: the records hold the key-point columns of the resident payload
+    int kp_total_host = -1;      // number of CSR entries when the host knows it (kpilqr_set_keypoints), else -1
+    int *kp_traj_first_host = nullptr;                // [batch+1] first CSR entry of every trajectory (host copy), or null
+    // FD payload resident on the device: 0 none, 1 job lists (kpilqr_upload_fd / _slab), 2 key-point ordered (kpilqr_upload_fd_kp)
+    int fd_kind = 0;
+    // key-point ordered payload: x+ [entry][3][n], x- [entry][3][n], mode [entry][3] in ONE device slab
+    char *fdk_dev = nullptr;
+    size_t fdk_dev_cap = 0;
+    double *kx_plus = nullptr, *kx_minus = nullptr;
+    unsigned char *k_mode = nullptr;
+    int fdk_entries = 0;         // entries of the resident key-point ordered payload (a view: of its trajectories)
+    int fdk_first = 0;           // first entry of a view's trajectories (0 for the context itself)
+
     // nominal states for on-device key-point placement (kpilqr_upload_states), allocated on first use
     double *X_states = nullptr;   // [batch][T][n]
     double *kp_thr = nullptr;     // [dof]
@@ -134,6 +162,7 @@ struct Ctx {
         int tiled_nt_min = 0;      // KPILQR_TILED_NT_MIN: run the tiled kernels with more tiles than needed
         int tiled_a6 = -1;         // KPILQR_TILED_A6: -1 auto, 0 | 1
         int tiled_a4 = -1;         // KPILQR_TILED_A4: -1 auto, 0 | 1 (a4 inside the tiled sweeps)
+        int fused_raw = -1;        // KPILQR_FUSED_RAW: 0 never difference inside the backward sweep (diagnostic), else auto
         int pipe_copy = -1;        // KPILQR_PIPE_COPY: chunk pipeline copies by kernel: bit 0 uploads, bit 1 downloads (-1 auto)
     } tune;
 };
@@ -151,7 +180,11 @@ Ctx::Tuning read_tuning_from_env();
 
 // ---- launchers (defined in the .hip files) --------------------------------------------------
 // elementwise.hip
-hipError_t launch_fd_difference(Ctx *c);
+hipError_t launch_fd_difference(Ctx *c);                 // job lists -> step records
+hipError_t launch_fd_difference_kpc(Ctx *c);             // job lists -> key-point column store
+hipError_t launch_fd_kp_difference(Ctx *c);              // key-point ordered payload -> key-point column store
+hipError_t launch_kpc_to_records(Ctx *c);                // key-point column store -> step records
+hipError_t launch_build_entry_tables(Ctx *c);            // kp_entry, kp_entry_list from the CSR lists
 hipError_t launch_copy_out(hipStream_t s, double *dst_host, const double *src_dev, size_t count);   // D2H by a kernel
 hipError_t launch_copy_in(hipStream_t s, void *dst_dev, const void *src_host, size_t bytes);        // H2D by a kernel
 hipError_t launch_build_segmap(Ctx *c);
@@ -197,7 +230,8 @@ hipError_t launch_forward_tiled(Ctx *c, double *U_alpha_dev);
 bool tiled_a4_supported(int n, int m, int dof, int T, int stride);
 // fused_mfma.hip: a4 + a6 evaluated inside the sweeps (n+2 <= 16)
 bool fused_supported(int n, int m, int nr, int dof, int T, int stride, int n_alpha);
-hipError_t launch_backward_fused(Ctx *c, int pd_stride);
+int backward_fused_form(const Ctx *c);
+hipError_t launch_backward_fused(Ctx *c, int pd_stride, bool raw);
 hipError_t launch_forward_fused(Ctx *c, double *U_alpha_dev);
 
 }  // namespace kpilqr

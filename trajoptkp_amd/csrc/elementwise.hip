@@ -94,6 +94,182 @@ hipError_t launch_fd_difference(Ctx *c)
 }
 
 // ---------------------------------------------------------------------------------------------
+// Fused contexts keep no step records: their sweeps read the differenced key-point columns from the key-point column
+// store kpc [entry][3][n] (common.h).  Three ways fill it:
+//   k_fd_difference_kpc   job lists (any order) -> kpc; (trajectory, DoF, t) -> entry through the kp_entry table
+//   k_fd_kp_difference    key-point ordered payload (x+ / x- / mode already in entry order) -> kpc, a pure stream
+//   the raw backward sweep of fused_mfma.hip differences the key-point ordered payload itself and leaves kpc behind
+// and k_kpc_to_records scatters kpc into (lazily allocated) step records when the materialised sequence is asked for.
+// The arithmetic is k_fd_difference's: (x+ - x-) / (2 eps), one-sided (x+ - xnom) / eps, (xnom - x-) / eps.
+__global__ void __launch_bounds__(256)
+k_fd_difference_kpc(int n, int m, int dof, int T, int batch, int nnom, long long npairs_total, unsigned long long np_magic,
+                    const int *__restrict__ job_b, const int *__restrict__ job_t,
+                    const int *__restrict__ job_col, const unsigned char *__restrict__ job_mode,
+                    const int *__restrict__ job_nom,
+                    const double *__restrict__ xplus, const double *__restrict__ xminus,
+                    const double *__restrict__ xnom, double eps, const int *__restrict__ kp_entry,
+                    double *__restrict__ kpc, int *__restrict__ err_flag)
+{
+    const int ncol = n + m, np = n >> 1;
+    const double2 *xp2 = (const double2 *)xplus, *xm2 = (const double2 *)xminus;
+    const long long stride = (long long)gridDim.x * blockDim.x;
+    for (long long w0 = (long long)blockIdx.x * blockDim.x + threadIdx.x; w0 < npairs_total; w0 += FD_UNROLL * stride) {
+        double2 xp[FD_UNROLL], xm[FD_UNROLL];
+        int job[FD_UNROLL], row[FD_UNROLL];
+#pragma unroll
+        for (int u = 0; u < FD_UNROLL; u++) {
+            const long long w = w0 + u * stride;
+            const bool ok = w < npairs_total;
+            const long long q = np_magic ? (long long)__umul64hi((unsigned long long)w, np_magic) : w;
+            job[u] = ok ? (int)q : -1;
+            row[u] = ok ? 2 * (int)(w - q * np) : 0;
+            xp[u] = ok ? xp2[w] : make_double2(0.0, 0.0);
+            xm[u] = ok ? xm2[w] : make_double2(0.0, 0.0);
+        }
+#pragma unroll
+        for (int u = 0; u < FD_UNROLL; u++) {
+            const int j = job[u];
+            if (j < 0) continue;
+            const int sb = job_b[j], st = job_t[j], col = job_col[j], mode = job_mode[j];
+            if ((unsigned)sb >= (unsigned)batch || (unsigned)st >= (unsigned)T || (unsigned)col >= (unsigned)ncol || mode > 2) {
+                atomicOr(err_flag, KP_ERRBIT_FD_INDEX);
+                continue;
+            }
+            double v0, v1;
+            if (mode == 0) {
+                v0 = (xp[u].x - xm[u].x) / (2 * eps);
+                v1 = (xp[u].y - xm[u].y) / (2 * eps);
+            } else {
+                const int nom = job_nom[j];
+                if ((unsigned)nom >= (unsigned)nnom) { atomicOr(err_flag, KP_ERRBIT_FD_INDEX); continue; }
+                const double *x0 = xnom + (size_t)nom * n + row[u];
+                v0 = (mode == 1) ? (xp[u].x - x0[0]) / (eps) : (x0[0] - xm[u].x) / (eps);
+                v1 = (mode == 1) ? (xp[u].y - x0[1]) / (eps) : (x0[1] - xm[u].y) / (eps);
+            }
+            // column col: DoF and kind; a job at a step that is not a key-point of its DoF has no slot (the materialising
+            // path keeps such columns in the records, the sweeps never look at them)
+            const int kind = col < dof ? 0 : col < n ? 1 : 2;
+            const int d = kind == 0 ? col : kind == 1 ? col - dof : col - n;
+            if (d >= dof) continue;                                   // a control without a DoF list of its own (m > dof): not a fused shape
+            const int e = kp_entry[((size_t)sb * dof + d) * T + st];
+            if (e < 0) continue;
+            double *dst = kpc + ((size_t)e * 3 + kind) * n + row[u];
+            *(double2 *)dst = make_double2(v0, v1);
+        }
+    }
+}
+
+hipError_t launch_fd_difference_kpc(Ctx *c)
+{
+    if (c->njobs == 0) return hipSuccess;
+    const int np = c->n >> 1;
+    const long long npairs = (long long)c->njobs * np;
+    const unsigned long long magic = np > 1 ? ~0ULL / (unsigned)np + 1ULL : 0ULL;
+    const long long want = (npairs + 256LL * FD_UNROLL - 1) / (256LL * FD_UNROLL);
+    const long long cap = (long long)(c->n_simd / 4) * 128;
+    const int blocks = (int)(want < cap ? (want < 1 ? 1 : want) : cap);
+    hipLaunchKernelGGL(k_fd_difference_kpc, dim3(blocks), dim3(256), 0, c->stream, c->n, c->d.m, c->d.dof, c->d.T, c->fd_batch_total, c->nnom,
+                       npairs, magic, c->job_b, c->job_t, c->job_col, c->job_mode, c->job_nom, c->xplus, c->xminus, c->xnom, c->eps,
+                       c->kp_entry, c->kpc, c->err_flag);
+    return hipGetLastError();
+}
+
+// key-point ordered payload -> kpc: slot s = entry * 3 + kind holds x+ / x- rows of n doubles; bit `kind` of the entry's mode
+// byte says one-sided (the host has put the nominal next state into the x- or x+ slot: / eps), else central: / (2 eps)
+__global__ void __launch_bounds__(256)
+k_fd_kp_difference(int n, long long npairs_total, unsigned long long np_magic, const double *__restrict__ xplus,
+                   const double *__restrict__ xminus, const unsigned char *__restrict__ mode, double eps, double *__restrict__ kpc)
+{
+    const double2 *xp2 = (const double2 *)xplus, *xm2 = (const double2 *)xminus;
+    double2 *out = (double2 *)kpc;
+    const long long stride = (long long)gridDim.x * blockDim.x;
+    for (long long w = (long long)blockIdx.x * blockDim.x + threadIdx.x; w < npairs_total; w += stride) {
+        const long long slot = np_magic ? (long long)__umul64hi((unsigned long long)w, np_magic) : w;
+        const long long e = slot / 3;
+        const double2 a = xp2[w], b = xm2[w];
+        const double den = ((mode[e] >> (int)(slot - 3 * e)) & 1) ? eps : 2 * eps;
+        out[w] = make_double2((a.x - b.x) / den, (a.y - b.y) / den);
+    }
+}
+
+hipError_t launch_fd_kp_difference(Ctx *c)
+{
+    // a view of a trajectory range (kpilqr_iterate_streamed) differences its own entries: [fdk_first, fdk_first + fdk_entries)
+    if (c->fdk_entries == 0) return hipSuccess;
+    const int np = c->n >> 1;
+    const long long npairs = (long long)c->fdk_entries * 3 * np;
+    const unsigned long long magic = np > 1 ? ~0ULL / (unsigned)np + 1ULL : 0ULL;
+    const long long want = (npairs + 256LL * 4 - 1) / (256LL * 4);
+    const long long cap = (long long)(c->n_simd / 4) * 128;
+    const int blocks = (int)(want < cap ? (want < 1 ? 1 : want) : cap);
+    const size_t o = (size_t)c->fdk_first * 3;
+    hipLaunchKernelGGL(k_fd_kp_difference, dim3(blocks), dim3(256), 0, c->stream, c->n, npairs, magic, c->kx_plus + o * c->n,
+                       c->kx_minus + o * c->n, c->k_mode + c->fdk_first, c->eps, c->kpc + o * c->n);
+    return hipGetLastError();
+}
+
+// kpc -> step records (the key-point columns k_fd_difference would have written): one lane per 16-byte pair of a slot
+__global__ void __launch_bounds__(256)
+k_kpc_to_records(RecLayout L, int dof, int T, long long npairs_total, unsigned long long np_magic, const int *__restrict__ kp_times,
+                 const int *__restrict__ kp_entry_list, const double *__restrict__ kpc, double *__restrict__ rec)
+{
+    const int n = L.n, m = L.m, np = n >> 1;
+    const double2 *in = (const double2 *)kpc;
+    const long long stride = (long long)gridDim.x * blockDim.x;
+    for (long long w = (long long)blockIdx.x * blockDim.x + threadIdx.x; w < npairs_total; w += stride) {
+        const long long slot = np_magic ? (long long)__umul64hi((unsigned long long)w, np_magic) : w;
+        const int row = 2 * (int)(w - slot * np);
+        const int e = (int)(slot / 3), kind = (int)(slot - (long long)e * 3);
+        const int list = kp_entry_list[e], t = kp_times[e];
+        const int b = list / dof, d = list - b * dof;
+        if (kind == 2 && d >= m) continue;
+        const int col = kind == 0 ? d : kind == 1 ? d + dof : n + d;
+        double *dst = rec + ((size_t)b * T + t) * L.stride + L.off_A + (size_t)col * n + row;
+        *(double2 *)dst = in[w];
+    }
+}
+
+// entries [e0, e0 + ne) of the context's lists (a view: its own trajectories)
+hipError_t launch_kpc_to_records(Ctx *c)
+{
+    if (c->fdk_entries == 0) return hipSuccess;
+    const int np = c->n >> 1;
+    const long long npairs = (long long)c->fdk_entries * 3 * np;
+    const unsigned long long magic = np > 1 ? ~0ULL / (unsigned)np + 1ULL : 0ULL;
+    const long long want = (npairs + 1023) / 1024;
+    const long long cap = (long long)(c->n_simd / 4) * 64;
+    const int blocks = (int)(want < cap ? (want < 1 ? 1 : want) : cap);
+    const size_t o = (size_t)c->fdk_first * 3;
+    hipLaunchKernelGGL(k_kpc_to_records, dim3(blocks), dim3(256), 0, c->stream, c->L, c->d.dof, c->d.T, npairs, magic, c->kp_times + c->fdk_first,
+                       c->kp_entry_list + c->fdk_first, c->kpc + o * c->n, c->rec_fd_base);
+    return hipGetLastError();
+}
+
+// kp_entry [list][t] (CSR entry of a key-point, -1 elsewhere) and kp_entry_list [entry] -> list, from the CSR lists
+__global__ void __launch_bounds__(256)
+k_build_entry_tables(int T, const int *__restrict__ offs, const int *__restrict__ times, int *__restrict__ kp_entry,
+                     int *__restrict__ kp_entry_list)
+{
+    const int l = blockIdx.x;
+    const int lo = offs[l], hi = offs[l + 1];
+    int *row = kp_entry + (size_t)l * T;
+    for (int t = threadIdx.x; t < T; t += blockDim.x) row[t] = -1;
+    __syncthreads();
+    for (int e = lo + threadIdx.x; e < hi; e += blockDim.x) {
+        const int t = times[e];
+        if ((unsigned)t < (unsigned)T) row[t] = e;
+        kp_entry_list[e] = l;
+    }
+}
+
+hipError_t launch_build_entry_tables(Ctx *c)
+{
+    hipLaunchKernelGGL(k_build_entry_tables, dim3(c->d.batch * c->d.dof), dim3(256), 0, c->stream, c->d.T, c->kp_offsets, c->kp_times,
+                       c->kp_entry, c->kp_entry_list);
+    return hipGetLastError();
+}
+
+// ---------------------------------------------------------------------------------------------
 // Key-point CSR (per trajectory, per DoF: sorted times) -> dense (start,end) map per (b, dof, t):
 // the pair of consecutive key-points strictly around t, or (-1,-1) when t is itself a key-point
 // of that DoF or lies outside the DoF's first/last key-point (the reference leaves those alone).

@@ -1,7 +1,11 @@
 // fused_mfma.hip -- the "never materialise A, B, l_*" form of the backward (a7) and forward (a8) passes
 // for n+2 <= 16: the interpolation of the dynamics Jacobians (a4) and the
-// Gauss-Newton cost derivatives (a6) are evaluated INSIDE the two sweeps, from the key-point columns that
-// k_fd_difference left in the step records and from the residuals / residual Jacobians.
+// Gauss-Newton cost derivatives (a6) are evaluated INSIDE the two sweeps, from the differenced key-point columns in the
+// key-point column store kpc [entry][3][n] (common.h: 3n doubles per (trajectory, DoF, key-point), no step records) and
+// from the residuals / residual Jacobians.  The one-wave backward sweep also has a RAW form that differences the
+// key-point ordered FD payload (x+ / x- in entry order, kpilqr_upload_fd_kp) itself at the segment crossings -- the
+// arithmetic of Differentiator.cpp:166-222,441-457 -- and leaves kpc behind for the forward sweep: no differencing kernel,
+// no intermediate pass over the payload.
 //
 //   * a4 (KeypointGenerator::InterpolateDerivatives, src/KeyPointGenerator/KeyPointGenerator.cpp:840-954):
 //     in the MFMA "D" layout lane (c,q) holds rows 4r+q of COLUMN c of A (and of B), and the reference
@@ -99,12 +103,30 @@ struct FusedArgs {
     const int *kp_offsets, *kp_times;              // per (b, dof) CSR of key-point time indices
     const double *r, *r_x, *r_u, *w_run, *w_term;  // [b][T+1][nr], [..][nr][n], [..][nr][m], [nr], [nr]
     int dof, nr;
+    double *kpc;                                   // key-point column store [entry][3][n] (read; written by the raw backward sweep)
+    const double *xp, *xm;                         // key-point ordered FD payload [entry][3][n] (raw backward sweep only)
+    const unsigned char *mode;                     // [entry]: bit k set = kind k is a one-sided difference (/ eps, not / 2 eps)
+    double eps, rinv_eps, rinv_2eps;               // the host's correctly rounded 1/eps, 1/(2 eps): with them fdiv IS the IEEE quotient
 };
 
 // ---- column tracker: lane (c,q) interpolates rows 4r+q of column c of A and of B ------------------------
-// col[0..3] = A(4r+q, c), col[4..7] = B(4r+q, c) (c < m).  The whole trajectory's records sit behind one
-// buffer descriptor; a lane with nothing to load carries an out-of-range offset and reads 0.
+// col[0..3] = A(4r+q, c), col[4..7] = B(4r+q, c) (c < m).  The whole trajectory's key-point columns -- entries
+// [E0, E0 + NE) of kpc, 3n doubles each: position column | velocity column | control column of the entry's DoF -- sit
+// behind one buffer descriptor; tk is the entry RELATIVE to E0 (anything outside [0, NE) reads zeros), and a lane with
+// nothing to load carries an out-of-range offset and reads 0.
 struct ColOffs { int a[4], b[4]; };
+
+// offsets of lane (c, q) inside an entry: rows 4r+q of A column c (the position column of DoF c, or the velocity column of
+// DoF c - dof) and of B column c
+__device__ __forceinline__ void col_offsets(ColOffs &co, int n, int m, int dof, int c, int q)
+{
+#pragma unroll
+    for (int r = 0; r < 4; r++) {
+        const int row = 4 * r + q;
+        co.a[r] = (row < n && c < n) ? 8 * ((c < dof ? 0 : n) + row) : OOBF;
+        co.b[r] = (row < n && c < m) ? 8 * (2 * n + row) : OOBF;
+    }
+}
 
 __device__ __forceinline__ void load_col(__amdgpu_buffer_rsrc_t rT, const ColOffs &o, int tk, int T, int strideB, double *col)
 {
@@ -142,9 +164,12 @@ __device__ __forceinline__ void lds_store4(double *t, int lane, const d4 &v);
 // RU0: the context's r_u buffer was never written (a task without control residuals: r_u = 0, e.g. reaching,
 // src/ModelTranslator/Reaching.cpp:43-54), so [l_uu | l_u] = Ru' W [Ru | r] is exactly zero: the product and the r_u loads
 // are left out (4 of the step's 40 MFMAs).
-template <int N, int M, bool PC, bool RU0 = false, bool SIDE = false>
+// RAW (one wave per trajectory only): the sweep reads the key-point ordered FD payload (F.xp, F.xm, F.mode) instead of kpc,
+// differences every column when it becomes a segment start -- (x+ - x-) / (2 eps), or / eps for a one-sided job, with
+// the host's correctly rounded reciprocals, i.e. the bytes k_fd_kp_difference would write -- and stores it to kpc, which
+// the forward sweep then reads.
+template <int N, int M, bool PC, bool RU0 = false, bool SIDE = false, bool RAW = false>
 __device__ __forceinline__ void backward_fused_body(double *sh, const double *pcbuf, int *sflag, RecLayout L, FusedArgs F, int T,
-                const double *__restrict__ rec,
                 const double *__restrict__ lambda, int pd_stride, double *__restrict__ Kout, double *__restrict__ kout,
                 double *__restrict__ delta_J, int *__restrict__ status)
 {
@@ -156,16 +181,15 @@ __device__ __forceinline__ void backward_fused_body(double *sh, const double *pc
     const int b = blockIdx.x;
     const double lam = lambda[b];
     const int nr = F.nr, ncr = (nr + 3) >> 2;
-    const int strideB = L.stride * 8;
+    constexpr int strideB = 3 * N * 8;                            // bytes of one key-point entry: three columns
 
     ColOffs co;
+    col_offsets(co, n, m, F.dof, c, q);
     double w2run[4], w2term[4], lam2d[4];
     int oRx[4], oR1[4], oRu[4], oKst[4], okst[4];
 #pragma unroll
     for (int r = 0; r < 4; r++) {
         const int row = 4 * r + q;
-        co.a[r] = (row < n && c < n) ? 8 * L.a(row, c) : OOBF;
-        co.b[r] = (row < n && c < m) ? 8 * L.b(row, c) : OOBF;
         oRx[r] = (row < nr && c < n) ? 8 * (row * n + c) : OOBF;      // Rz(k=row, c) = r_x[k][c]
         oR1[r] = (row < nr && c == n) ? 8 * row : OOBF;               //            ... | r[k] in column n
         oRu[r] = (row < nr && c < m) ? 8 * (row * m + c) : OOBF;      // Ru(k=row, c) = r_u[k][c]
@@ -179,8 +203,9 @@ __device__ __forceinline__ void backward_fused_body(double *sh, const double *pc
     const bool lane_nn = (c == n) && (q == (n & 3));
     constexpr int REG_NN = n >> 2;
 
-    const double *R0 = rec + (size_t)b * T * L.stride;
-    __amdgpu_buffer_rsrc_t rT = frsrc(R0, T * strideB);
+    // this trajectory's key-point entries [E0, E0 + NE): one descriptor over its slice of kpc (and of the raw payload)
+    const int E0 = F.kp_offsets[(size_t)b * F.dof], NE = F.kp_offsets[(size_t)(b + 1) * F.dof] - E0;
+    __amdgpu_buffer_rsrc_t rT = frsrc(F.kpc + (size_t)E0 * 3 * n, NE * strideB);
     const double *rb = F.r + (size_t)b * (T + 1) * nr;
     const double *rxb = F.r_x + (size_t)b * (T + 1) * nr * n;
     const double *rub = F.r_u + (size_t)b * (T + 1) * nr * m;
@@ -205,10 +230,46 @@ __device__ __forceinline__ void backward_fused_body(double *sh, const double *pc
     int nb = (has && idx - 1 >= lo) ? F.kp_times[idx - 1] : -1;
     int nb2 = (has && idx - 2 >= lo) ? F.kp_times[idx - 2] : -1;
     double sv[8], av[8], pv[8];
+    // RAW: the prefetched column of the next segment start waits as x+ (in pv) and x- (pm) until the crossing differences it
+    double pm[8];
+    int pmode = 0;
+    __amdgpu_buffer_rsrc_t rP = rT, rM = rT, rMo = rT;
+    const int bitA = (c < F.dof) ? 1 : 2;                         // mode bit of this lane's A column (position / velocity job)
+    auto load_raw = [&](int e_rel, double *xp_, double *xm_, int &mo) {
+        load_col(rP, co, e_rel, NE, strideB, xp_);
+        load_col(rM, co, e_rel, NE, strideB, xm_);
+        mo = __builtin_amdgcn_raw_buffer_load_b8(rMo, ((unsigned)e_rel < (unsigned)NE && c < n) ? e_rel : OOBF, 0, 0);
+    };
+    auto difference = [&](double *xp_, const double *xm_, int mo, int e_rel) {      // xp_ <- the differenced column, also to kpc
+        const bool oa = (mo & bitA) != 0, ob = (mo & 4) != 0;
+        const double dA = oa ? F.eps : 2 * F.eps, rA = oa ? F.rinv_eps : F.rinv_2eps;
+        const double dB = ob ? F.eps : 2 * F.eps, rB = ob ? F.rinv_eps : F.rinv_2eps;
+        const bool ok = (unsigned)e_rel < (unsigned)NE;
+        const int base = ok ? e_rel * strideB : 0;
+#pragma unroll
+        for (int i = 0; i < 4; i++) {
+            xp_[i] = fdiv(xp_[i] - xm_[i], dA, rA);
+            xp_[4 + i] = fdiv(xp_[4 + i] - xm_[4 + i], dB, rB);
+            __builtin_amdgcn_raw_buffer_store_b64(__builtin_bit_cast(u32x2f, xp_[i]), rT, (ok && co.a[i] != OOBF) ? base + co.a[i] : OOBF, 0, 0);
+            __builtin_amdgcn_raw_buffer_store_b64(__builtin_bit_cast(u32x2f, xp_[4 + i]), rT, (ok && co.b[i] != OOBF) ? base + co.b[i] : OOBF, 0, 0);
+        }
+    };
+    (void)pm; (void)pmode; (void)bitA;
     ResTiles cur;
     if constexpr (!PC) {
-        load_col(rT, co, s, T, strideB, sv);
-        load_col(rT, co, nb, T, strideB, pv);
+        const int e_s = has ? idx - E0 : -1, e_nb = (has && idx - 1 >= lo) ? idx - 1 - E0 : -1;
+        if constexpr (RAW) {
+            rP = frsrc(F.xp + (size_t)E0 * 3 * n, NE * strideB);
+            rM = frsrc(F.xm + (size_t)E0 * 3 * n, NE * strideB);
+            rMo = frsrc(F.mode + E0, NE);
+            int mo0;
+            load_raw(e_s, sv, pm, mo0);
+            difference(sv, pm, mo0, e_s);
+            load_raw(e_nb, pv, pm, pmode);
+        } else {
+            load_col(rT, co, e_s, NE, strideB, sv);
+            load_col(rT, co, e_nb, NE, strideB, pv);
+        }
 #pragma unroll
         for (int i = 0; i < 8; i++) av[i] = 0.0;
         // Fz(n,n) = 1: lane c == n walks no list (never crosses), so its constant start value carries the 1
@@ -258,6 +319,7 @@ __device__ __forceinline__ void backward_fused_body(double *sh, const double *pc
         if (t < s) {                                   // per lane: crossed the start of the current segment
             const double den = (double)(s - nb);
             const double rinv = kp_rcp(den);
+            if constexpr (RAW) difference(pv, pm, pmode, idx - 1 - E0);      // the prefetched x+ / x- become the column
 #pragma unroll
             for (int i = 0; i < 8; i++) {
                 av[i] = fdiv(sv[i] - pv[i], den, rinv);
@@ -269,7 +331,9 @@ __device__ __forceinline__ void backward_fused_body(double *sh, const double *pc
             s = nb; idx--;
             nb = nb2;
             nb2 = (idx - 2 >= lo) ? F.kp_times[idx - 2] : -1;
-            load_col(rT, co, nb, T, strideB, pv);
+            const int e_nb = (idx - 1 >= lo) ? idx - 1 - E0 : -1;
+            if constexpr (RAW) load_raw(e_nb, pv, pm, pmode);
+            else load_col(rT, co, e_nb, NE, strideB, pv);
         }
         const double dt = (double)(t - s);
         Fz.x = lerp_nc(sv[0], dt, av[0]); Fz.y = lerp_nc(sv[1], dt, av[1]);
@@ -447,23 +511,23 @@ __device__ __forceinline__ void backward_fused_body(double *sh, const double *pc
     if (lane == 0) status[b] = fail;
 }
 
-template <int N, int M, bool RU0>
+template <int N, int M, bool RU0, bool RAW>
 __global__ void __launch_bounds__(64)
-k_backward_fused(RecLayout L, FusedArgs F, int T, const double *__restrict__ rec, const double *__restrict__ lambda,
+k_backward_fused(RecLayout L, FusedArgs F, int T, const double *__restrict__ lambda,
                  int pd_stride, double *__restrict__ Kout, double *__restrict__ kout,
                  double *__restrict__ delta_J, int *__restrict__ status)
 {
     __shared__ __attribute__((aligned(16))) double sh[FLDS_TOTAL];
-    backward_fused_body<N, M, false, RU0>(sh, nullptr, nullptr, L, F, T, rec, lambda, pd_stride, Kout, kout, delta_J, status);
+    backward_fused_body<N, M, false, RU0, false, RAW>(sh, nullptr, nullptr, L, F, T, lambda, pd_stride, Kout, kout, delta_J, status);
 }
-template <int N, int M, bool RU0>
+template <int N, int M, bool RU0, bool RAW>
 __global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(1, 1)))
-k_backward_fused_excl(RecLayout L, FusedArgs F, int T, const double *__restrict__ rec, const double *__restrict__ lambda,
+k_backward_fused_excl(RecLayout L, FusedArgs F, int T, const double *__restrict__ lambda,
                       int pd_stride, double *__restrict__ Kout, double *__restrict__ kout,
                       double *__restrict__ delta_J, int *__restrict__ status)
 {
     __shared__ __attribute__((aligned(16))) double sh[FLDS_TOTAL];
-    backward_fused_body<N, M, false, RU0>(sh, nullptr, nullptr, L, F, T, rec, lambda, pd_stride, Kout, kout, delta_J, status);
+    backward_fused_body<N, M, false, RU0, false, RAW>(sh, nullptr, nullptr, L, F, T, lambda, pd_stride, Kout, kout, delta_J, status);
 }
 
 
@@ -514,20 +578,23 @@ struct DownTracker {
     int offs[NV];
     int lo, idx, s, nb, nb2;
     double sv[NV], av[NV], pv[NV];
-    __device__ __forceinline__ void init(__amdgpu_buffer_rsrc_t rT, const int *kp_offsets, const int *kp_times, bool has, size_t list, int T, int strideB)
+    // rT: the trajectory's slice of kpc, entries [E0, E0 + NE) of strideB bytes each (see load_col)
+    int E0, NE;
+    __device__ __forceinline__ void init(__amdgpu_buffer_rsrc_t rT, const int *kp_offsets, const int *kp_times, bool has, size_t list, int E0_, int NE_, int strideB)
     {
+        E0 = E0_; NE = NE_;
         lo = has ? kp_offsets[list] : 0;
         const int hi = has ? kp_offsets[list + 1] : 0;
         idx = hi - 1;
         s = has ? kp_times[idx] : -1;
         nb = (has && idx - 1 >= lo) ? kp_times[idx - 1] : -1;
         nb2 = (has && idx - 2 >= lo) ? kp_times[idx - 2] : -1;
-        load_vals<NV>(rT, offs, s, T, strideB, sv);
-        load_vals<NV>(rT, offs, nb, T, strideB, pv);
+        load_vals<NV>(rT, offs, has ? idx - E0 : -1, NE, strideB, sv);
+        load_vals<NV>(rT, offs, (has && idx - 1 >= lo) ? idx - 1 - E0 : -1, NE, strideB, pv);
 #pragma unroll
         for (int i = 0; i < NV; i++) av[i] = 0.0;
     }
-    __device__ __forceinline__ void advance(__amdgpu_buffer_rsrc_t rT, const int *kp_times, int t, int T, int strideB)
+    __device__ __forceinline__ void advance(__amdgpu_buffer_rsrc_t rT, const int *kp_times, int t, int strideB)
     {
         if (t < s) {                                 // per lane: crossed the start of the current segment
             const double den = (double)(s - nb);
@@ -541,7 +608,7 @@ struct DownTracker {
             s = nb; idx--;
             nb = nb2;
             nb2 = (idx - 2 >= lo) ? kp_times[idx - 2] : -1;
-            load_vals<NV>(rT, offs, nb, T, strideB, pv);
+            load_vals<NV>(rT, offs, (idx - 1 >= lo) ? idx - 1 - E0 : -1, NE, strideB, pv);
         }
     }
     __device__ __forceinline__ double value(int i, double dt) const { return lerp_nc(sv[i], dt, av[i]); }
@@ -549,7 +616,7 @@ struct DownTracker {
 
 // ---- wave U: control side ------------------------------------------------------------------------------------
 template <int N, int M>
-__device__ __forceinline__ void fused2_role_U(double *sh, RecLayout L, FusedArgs F, int T, const double *__restrict__ rec, double lam,
+__device__ __forceinline__ void fused2_role_U(double *sh, RecLayout L, FusedArgs F, int T, double lam,
                                               int pd_stride, double *__restrict__ Kout, double *__restrict__ kout,
                                               double *__restrict__ delta_J, int *__restrict__ status)
 {
@@ -559,7 +626,7 @@ __device__ __forceinline__ void fused2_role_U(double *sh, RecLayout L, FusedArgs
     const int lane = threadIdx.x & 63, c = lane & 15, q = lane >> 4;
     const int b = blockIdx.x;
     const int nr = F.nr, ncr = (nr + 3) >> 2;
-    const int strideB = L.stride * 8;
+    const int strideB = 3 * L.n * 8;                               // bytes of one key-point entry of kpc: three columns
     int *sflag = (int *)(sh + F2_FLAG);
     DownTracker<4> tr;                           // B rows of column c (c < m), key-point list of DoF c
     int oRu[4], oR1[4], oKst[4], okst[4];
@@ -570,7 +637,7 @@ __device__ __forceinline__ void fused2_role_U(double *sh, RecLayout L, FusedArgs
 #pragma unroll
         for (int r = 0; r < 4; r++) {
             const int row = 4 * r + q;
-            tr.offs[r] = (row < n && c < m) ? 8 * L.b(row, c) : OOBF;
+            tr.offs[r] = (row < n && c < m) ? 8 * (2 * n + row) : OOBF;
             oRu[r] = (row < nr && c < m) ? 8 * (row * m + c) : OOBF;
             oR1[r] = (row < nr && c == n) ? 8 * row : OOBF;
             w2run[r] = (row < nr) ? 2.0 * F.w_run[row] : 0.0;
@@ -585,8 +652,8 @@ __device__ __forceinline__ void fused2_role_U(double *sh, RecLayout L, FusedArgs
     const u64 mask_n = (c == n) ? ~0ull : 0ull, mask_u = (c < m) ? ~0ull : 0ull;
     const bool lane_nn = (c == n) && (q == (n & 3));
     const d4 zero = {0.0, 0.0, 0.0, 0.0};
-    const double *R0 = rec + (size_t)b * T * L.stride;
-    __amdgpu_buffer_rsrc_t rT = frsrc(R0, T * strideB);
+    const int E0 = F.kp_offsets[(size_t)b * F.dof], NE = F.kp_offsets[(size_t)(b + 1) * F.dof] - E0;      // this trajectory's key-point entries
+    __amdgpu_buffer_rsrc_t rT = frsrc(F.kpc + (size_t)E0 * 3 * L.n, NE * strideB);
     const double *rb = F.r + (size_t)b * (T + 1) * nr;
     const double *rub = F.r_u + (size_t)b * (T + 1) * nr * m;
     d4 Ru, R1;
@@ -607,7 +674,7 @@ __device__ __forceinline__ void fused2_role_U(double *sh, RecLayout L, FusedArgs
         Luz.x = bits_and(LU.x, mask_n); Luz.y = bits_and(LU.y, mask_n); Luz.z = bits_and(LU.z, mask_n); Luz.w = bits_and(LU.w, mask_n);
         lds_store4(sh + F2_L, lane, Luz);
     };
-    tr.init(rT, F.kp_offsets, F.kp_times, c < m, (size_t)b * F.dof + c, T, strideB);
+    tr.init(rT, F.kp_offsets, F.kp_times, c < m, (size_t)b * F.dof + c, E0, NE, strideB);
     d4 Fu;
     auto lerp_Fu = [&](int t) {
         const double dt = (double)(t - tr.s);
@@ -697,7 +764,7 @@ __device__ __forceinline__ void fused2_role_U(double *sh, RecLayout L, FusedArgs
         __syncthreads();
         // ---- phase 3 (off the critical path): next step's B columns and [l_uu | l_u] -----------------------------
         if (t > 0) {
-            tr.advance(rT, F.kp_times, t - 1, T, strideB);
+            tr.advance(rT, F.kp_times, t - 1, strideB);
             lerp_Fu(t - 1);
             LU = cost_tile(Wr);
             load_res(t - 2);
@@ -711,7 +778,7 @@ __device__ __forceinline__ void fused2_role_U(double *sh, RecLayout L, FusedArgs
 
 // ---- wave Z: state side ---------------------------------------------------------------------------------------
 template <int N, int M>
-__device__ __forceinline__ void fused2_role_Z(double *sh, RecLayout L, FusedArgs F, int T, const double *__restrict__ rec, int pd_stride)
+__device__ __forceinline__ void fused2_role_Z(double *sh, RecLayout L, FusedArgs F, int T, int pd_stride)
 {
     constexpr int NCZ = (N + 1 + 3) / 4;
     constexpr int NCU = (M + 3) / 4;
@@ -719,7 +786,7 @@ __device__ __forceinline__ void fused2_role_Z(double *sh, RecLayout L, FusedArgs
     const int lane = threadIdx.x & 63, c = lane & 15, q = lane >> 4;
     const int b = blockIdx.x;
     const int nr = F.nr, ncr = (nr + 3) >> 2;
-    const int strideB = L.stride * 8;
+    const int strideB = 3 * L.n * 8;                               // bytes of one key-point entry of kpc: three columns
     const int *sflag = (const int *)(sh + F2_FLAG);
     DownTracker<8> tr;                           // A rows then B rows of column c
     int oRx[4], oR1[4];
@@ -730,8 +797,8 @@ __device__ __forceinline__ void fused2_role_Z(double *sh, RecLayout L, FusedArgs
 #pragma unroll
         for (int r = 0; r < 4; r++) {
             const int row = 4 * r + q;
-            tr.offs[r] = (row < n && c < n) ? 8 * L.a(row, c) : OOBF;
-            tr.offs[4 + r] = (row < n && c < m) ? 8 * L.b(row, c) : OOBF;
+            tr.offs[r] = (row < n && c < n) ? 8 * ((c < F.dof ? 0 : n) + row) : OOBF;
+            tr.offs[4 + r] = (row < n && c < m) ? 8 * (2 * n + row) : OOBF;
             oRx[r] = (row < nr && c < n) ? 8 * (row * n + c) : OOBF;
             oR1[r] = (row < nr && c == n) ? 8 * row : OOBF;
             w2run[r] = (row < nr) ? 2.0 * F.w_run[row] : 0.0;
@@ -743,8 +810,8 @@ __device__ __forceinline__ void fused2_role_Z(double *sh, RecLayout L, FusedArgs
     const bool lane_nn = (c == n) && (q == (n & 3));
     constexpr int REG_NN = n >> 2;
     const d4 zero = {0.0, 0.0, 0.0, 0.0};
-    const double *R0 = rec + (size_t)b * T * L.stride;
-    __amdgpu_buffer_rsrc_t rT = frsrc(R0, T * strideB);
+    const int E0 = F.kp_offsets[(size_t)b * F.dof], NE = F.kp_offsets[(size_t)(b + 1) * F.dof] - E0;      // this trajectory's key-point entries
+    __amdgpu_buffer_rsrc_t rT = frsrc(F.kpc + (size_t)E0 * 3 * L.n, NE * strideB);
     const double *rb = F.r + (size_t)b * (T + 1) * nr;
     const double *rxb = F.r_x + (size_t)b * (T + 1) * nr * n;
     d4 Rx, R1;
@@ -761,7 +828,7 @@ __device__ __forceinline__ void fused2_role_Z(double *sh, RecLayout L, FusedArgs
         return PR(Rz, Rz * W2, zero, ncr);
     };
     const int kd = (c < F.dof) ? c : c - F.dof;
-    tr.init(rT, F.kp_offsets, F.kp_times, c < n, (size_t)b * F.dof + kd, T, strideB);
+    tr.init(rT, F.kp_offsets, F.kp_times, c < n, (size_t)b * F.dof + kd, E0, NE, strideB);
 #pragma unroll
     for (int r = 0; r < 4; r++) if (c == n && 4 * r + q == n) tr.sv[r] = 1.0;       // Fz(n,n) = 1
     d4 Fz, Fu;
@@ -795,7 +862,7 @@ __device__ __forceinline__ void fused2_role_Z(double *sh, RecLayout L, FusedArgs
         if (sflag[0]) break;
         // ---- phase 2 (off the critical path): next step's A,B columns and Lzz -----------------------------------
         if (t > 0) {
-            tr.advance(rT, F.kp_times, t - 1, T, strideB);
+            tr.advance(rT, F.kp_times, t - 1, strideB);
             lerp_F(t - 1);
             Lzz = cost_tile(Wr);
             load_res(t - 2);
@@ -820,7 +887,7 @@ __device__ __forceinline__ void fused2_role_Z(double *sh, RecLayout L, FusedArgs
 
 template <int N, int M>
 __global__ void __launch_bounds__(128) __attribute__((amdgpu_waves_per_eu(2, 2)))
-k_backward_fused2(RecLayout L, FusedArgs F, int T, int role_shift, const double *__restrict__ rec, const double *__restrict__ lambda,
+k_backward_fused2(RecLayout L, FusedArgs F, int T, int role_shift, const double *__restrict__ lambda,
                   int pd_stride, double *__restrict__ Kout, double *__restrict__ kout,
                   double *__restrict__ delta_J, int *__restrict__ status)
 {
@@ -828,8 +895,8 @@ k_backward_fused2(RecLayout L, FusedArgs F, int T, int role_shift, const double 
     // The role is wave-uniform and the compiler must know it (readfirstlane): scalar branches, SGPR descriptors.
     // Which wave plays which role can alternate with the block index (role_shift) to mix U and Z waves on a SIMD.
     const bool isU = ((__builtin_amdgcn_readfirstlane(threadIdx.x >> 6) ^ (blockIdx.x >> role_shift)) & 1) == 0;
-    if (isU) fused2_role_U<N, M>(sh, L, F, T, rec, lambda[blockIdx.x], pd_stride, Kout, kout, delta_J, status);
-    else     fused2_role_Z<N, M>(sh, L, F, T, rec, pd_stride);
+    if (isU) fused2_role_U<N, M>(sh, L, F, T, lambda[blockIdx.x], pd_stride, Kout, kout, delta_J, status);
+    else     fused2_role_Z<N, M>(sh, L, F, T, pd_stride);
 }
 
 // ---------------------------------------------------------------------------------------------------------
@@ -841,13 +908,13 @@ k_backward_fused2(RecLayout L, FusedArgs F, int T, int role_shift, const double 
 // Two waves per SIMD at batch = #SIMDs: the producer's independent MFMAs and FP64 FMAs issue into the bubbles of the
 // consumer's dependent chain.
 template <int N, int M, bool TRIPLE = false>
-__device__ __forceinline__ void fusedpc_producer(double *pcbuf, int *sflag, RecLayout L, FusedArgs F, int T, const double *__restrict__ rec)
+__device__ __forceinline__ void fusedpc_producer(double *pcbuf, int *sflag, RecLayout L, FusedArgs F, int T)
 {
     constexpr int n = N, m = M;
     const int lane = threadIdx.x & 63, c = lane & 15, q = lane >> 4;
     const int b = blockIdx.x;
     const int nr = F.nr, ncr = (nr + 3) >> 2;
-    const int strideB = L.stride * 8;
+    const int strideB = 3 * L.n * 8;                               // bytes of one key-point entry of kpc: three columns
     DownTracker<8> tr;                           // A rows then B rows of column c
     int oRx[4], oR1[4], oRu[4];
     d4 Wt, Wr;
@@ -856,8 +923,8 @@ __device__ __forceinline__ void fusedpc_producer(double *pcbuf, int *sflag, RecL
 #pragma unroll
         for (int r = 0; r < 4; r++) {
             const int row = 4 * r + q;
-            tr.offs[r] = (row < n && c < n) ? 8 * L.a(row, c) : OOBF;
-            tr.offs[4 + r] = (row < n && c < m) ? 8 * L.b(row, c) : OOBF;
+            tr.offs[r] = (row < n && c < n) ? 8 * ((c < F.dof ? 0 : n) + row) : OOBF;
+            tr.offs[4 + r] = (row < n && c < m) ? 8 * (2 * n + row) : OOBF;
             oRx[r] = (row < nr && c < n) ? 8 * (row * n + c) : OOBF;
             oR1[r] = (row < nr && c == n) ? 8 * row : OOBF;
             oRu[r] = (row < nr && c < m) ? 8 * (row * m + c) : OOBF;
@@ -868,8 +935,8 @@ __device__ __forceinline__ void fusedpc_producer(double *pcbuf, int *sflag, RecL
         Wr.x = wr[0]; Wr.y = wr[1]; Wr.z = wr[2]; Wr.w = wr[3];
     }
     const d4 zero = {0.0, 0.0, 0.0, 0.0};
-    const double *R0 = rec + (size_t)b * T * L.stride;
-    __amdgpu_buffer_rsrc_t rT = frsrc(R0, T * strideB);
+    const int E0 = F.kp_offsets[(size_t)b * F.dof], NE = F.kp_offsets[(size_t)(b + 1) * F.dof] - E0;      // this trajectory's key-point entries
+    __amdgpu_buffer_rsrc_t rT = frsrc(F.kpc + (size_t)E0 * 3 * L.n, NE * strideB);
     const double *rb = F.r + (size_t)b * (T + 1) * nr;
     const double *rxb = F.r_x + (size_t)b * (T + 1) * nr * n;
     const double *rub = F.r_u + (size_t)b * (T + 1) * nr * m;
@@ -885,7 +952,7 @@ __device__ __forceinline__ void fusedpc_producer(double *pcbuf, int *sflag, RecL
         Ru.x = fbld(rU, oRu[0]); Ru.y = fbld(rU, oRu[1]); Ru.z = fbld(rU, oRu[2]); Ru.w = fbld(rU, oRu[3]);
     };
     const int kd = (c < F.dof) ? c : c - F.dof;
-    tr.init(rT, F.kp_offsets, F.kp_times, c < n, (size_t)b * F.dof + kd, T, strideB);
+    tr.init(rT, F.kp_offsets, F.kp_times, c < n, (size_t)b * F.dof + kd, E0, NE, strideB);
 #pragma unroll
     for (int r = 0; r < 4; r++) if (c == n && 4 * r + q == n) tr.sv[r] = 1.0;       // Fz(n,n) = 1
     auto publish = [&](int t, const d4 &W2) {
@@ -908,7 +975,7 @@ __device__ __forceinline__ void fusedpc_producer(double *pcbuf, int *sflag, RecL
     __syncthreads();
     for (int t = T - 1; t >= 0; t--) {
         if (t > 0) {
-            tr.advance(rT, F.kp_times, t - 1, T, strideB);
+            tr.advance(rT, F.kp_times, t - 1, strideB);
             publish(t - 1, Wr);
         }
         if constexpr (TRIPLE) __syncthreads();             // the mid-step barrier of the consumer and the side wave
@@ -961,59 +1028,57 @@ __device__ __forceinline__ void fusedpc_side(const double *sh, double *pcbuf, in
 #define FPC_FLAG (FPC_RING + 2 * FPC_BUF + 2 * 256)
 #define FPC_TOTAL (FPC_FLAG + 2)
 template <int N, int M>
-__device__ __forceinline__ void backward_fusedpc_block(RecLayout L, FusedArgs F, int T, int role_shift, const double *__restrict__ rec,
-                   const double *__restrict__ lambda, int pd_stride, double *__restrict__ Kout, double *__restrict__ kout,
+__device__ __forceinline__ void backward_fusedpc_block(RecLayout L, FusedArgs F, int T, int role_shift, const double *__restrict__ lambda, int pd_stride, double *__restrict__ Kout, double *__restrict__ kout,
                    double *__restrict__ delta_J, int *__restrict__ status)
 {
     __shared__ __attribute__((aligned(16))) double sh[FPC_TOTAL];
     const bool consumer = ((__builtin_amdgcn_readfirstlane(threadIdx.x >> 6) ^ (blockIdx.x >> role_shift)) & 1) == 0;
     if (consumer)
-        backward_fused_body<N, M, true>(sh, sh + FPC_RING, (int *)(sh + FPC_FLAG), L, F, T, rec, lambda, pd_stride, Kout, kout,
+        backward_fused_body<N, M, true>(sh, sh + FPC_RING, (int *)(sh + FPC_FLAG), L, F, T, lambda, pd_stride, Kout, kout,
                                         delta_J, status);
     else
-        fusedpc_producer<N, M>(sh + FPC_RING, (int *)(sh + FPC_FLAG), L, F, T, rec);
+        fusedpc_producer<N, M>(sh + FPC_RING, (int *)(sh + FPC_FLAG), L, F, T);
 }
 template <int N, int M>
 __global__ void __launch_bounds__(128) __attribute__((amdgpu_waves_per_eu(2, 2)))
-k_backward_fusedpc(RecLayout L, FusedArgs F, int T, int role_shift, const double *__restrict__ rec, const double *__restrict__ lambda,
+k_backward_fusedpc(RecLayout L, FusedArgs F, int T, int role_shift, const double *__restrict__ lambda,
                    int pd_stride, double *__restrict__ Kout, double *__restrict__ kout,
                    double *__restrict__ delta_J, int *__restrict__ status)
 {
-    backward_fusedpc_block<N, M>(L, F, T, role_shift, rec, lambda, pd_stride, Kout, kout, delta_J, status);
+    backward_fusedpc_block<N, M>(L, F, T, role_shift, lambda, pd_stride, Kout, kout, delta_J, status);
 }
 // Wave TRIPLE per trajectory (batch <= #CUs): consumer | side | producer, one SIMD each of one CU.
 template <int N, int M>
 __global__ void __launch_bounds__(192) __attribute__((amdgpu_waves_per_eu(1, 1)))
-k_backward_fusedpc3(RecLayout L, FusedArgs F, int T, int role_shift, const double *__restrict__ rec, const double *__restrict__ lambda,
+k_backward_fusedpc3(RecLayout L, FusedArgs F, int T, int role_shift, const double *__restrict__ lambda,
                     int pd_stride, double *__restrict__ Kout, double *__restrict__ kout,
                     double *__restrict__ delta_J, int *__restrict__ status)
 {
     __shared__ __attribute__((aligned(16))) double sh[FPC_TOTAL];
     const int role = (int)((__builtin_amdgcn_readfirstlane(threadIdx.x >> 6) + (blockIdx.x >> role_shift)) % 3);
     if (role == 0)
-        backward_fused_body<N, M, true, false, true>(sh, sh + FPC_RING, (int *)(sh + FPC_FLAG), L, F, T, rec, lambda, pd_stride, Kout, kout,
+        backward_fused_body<N, M, true, false, true>(sh, sh + FPC_RING, (int *)(sh + FPC_FLAG), L, F, T, lambda, pd_stride, Kout, kout,
                                                      delta_J, status);
     else if (role == 1)
         fusedpc_side<N, M>(sh, sh + FPC_RING, (int *)(sh + FPC_FLAG), T);
     else
-        fusedpc_producer<N, M, true>(sh + FPC_RING, (int *)(sh + FPC_FLAG), L, F, T, rec);
+        fusedpc_producer<N, M, true>(sh + FPC_RING, (int *)(sh + FPC_FLAG), L, F, T);
 }
 // at most one wave per SIMD: while 2 x batch <= #SIMDs every wave of every pair gets a SIMD (and its FP64 unit) to itself
 template <int N, int M>
 __global__ void __launch_bounds__(128) __attribute__((amdgpu_waves_per_eu(1, 1)))
-k_backward_fusedpc_excl(RecLayout L, FusedArgs F, int T, int role_shift, const double *__restrict__ rec, const double *__restrict__ lambda,
+k_backward_fusedpc_excl(RecLayout L, FusedArgs F, int T, int role_shift, const double *__restrict__ lambda,
                         int pd_stride, double *__restrict__ Kout, double *__restrict__ kout,
                         double *__restrict__ delta_J, int *__restrict__ status)
 {
-    backward_fusedpc_block<N, M>(L, F, T, role_shift, rec, lambda, pd_stride, Kout, kout, delta_J, status);
+    backward_fusedpc_block<N, M>(L, F, T, role_shift, lambda, pd_stride, Kout, kout, delta_J, status);
 }
 
 // ---------------------------------------------------------------------------------------------------------
 // Forward pass.  The column tracker walks UP in time; its tiles (row = A row, col = A column) are turned into
 // the Y operands (row = contraction index) through a padded LDS transpose, off the Z dependency chain.
 template <int NCZ, int NCU, bool RU0 = false, bool UNI = false>
-__device__ __forceinline__ void forward_fused_body(RecLayout L, FusedArgs F, int T, int n_alpha, const double *__restrict__ rec,
-               const double *__restrict__ Kin, const double *__restrict__ kin,
+__device__ __forceinline__ void forward_fused_body(RecLayout L, FusedArgs F, int T, int n_alpha, const double *__restrict__ Kin, const double *__restrict__ kin,
                const double *__restrict__ u_nom, const double *__restrict__ ctrl_lim,
                const double *__restrict__ alphas, double *__restrict__ cost_pred, double *__restrict__ U_alpha)
 {
@@ -1022,21 +1087,25 @@ __device__ __forceinline__ void forward_fused_body(RecLayout L, FusedArgs F, int
     const int lane = threadIdx.x, c = lane & 15, q = lane >> 4;
     const int b = blockIdx.x;
     const int nr = F.nr;
-    const int strideB = L.stride * 8;
+    const int strideB = 3 * L.n * 8;                               // bytes of one key-point entry of kpc: three columns
     const int ncx = (n + 3) >> 2;
 
+    // this trajectory's key-point entries [E0, E0 + NE) of kpc; KpU: entries per DoF list when all lists are the same (UNI)
+    const int E0 = F.kp_offsets[(size_t)b * F.dof], NE = F.kp_offsets[(size_t)(b + 1) * F.dof] - E0;
+    const int KpU = F.kp_offsets[(size_t)b * F.dof + 1] - E0;
     ColOffs co;
+    if (!UNI) col_offsets(co, n, m, F.dof, c, q);
     int oK[4], oRxT[4], oRuT[4], oR[4], oub[4];
     double lo[NCU], hi[NCU], wcur[4];
 #pragma unroll
     for (int r = 0; r < 4; r++) {
         const int row = 4 * r + q;
-        if (UNI) {                                   // the Y operands themselves: Ya(p = row, o = c) = A(o, p), Yb(p, o) = B(o, p)
-            co.a[r] = (row < n && c < n) ? 8 * L.a(c, row) : OOBF;
-            co.b[r] = (row < m && c < n) ? 8 * L.b(c, row) : OOBF;
-        } else {
-            co.a[r] = (row < n && c < n) ? 8 * L.a(row, c) : OOBF;
-            co.b[r] = (row < n && c < m) ? 8 * L.b(row, c) : OOBF;
+        if (UNI) {
+            // the Y operands themselves: Ya(p = row, o = c) = A(o, p), Yb(p, o) = B(o, p) -- element c of column `row`, whose
+            // DoF list starts (row mod dof) * KpU entries into the trajectory's slice (equal lists: the same position in each)
+            const int d = row < F.dof ? row : row - F.dof;
+            co.a[r] = (row < n && c < n) ? 8 * ((d * KpU * 3 + (row < F.dof ? 0 : 1)) * n + c) : OOBF;
+            co.b[r] = (row < m && c < n) ? 8 * ((row * KpU * 3 + 2) * n + c) : OOBF;
         }
         oK[r] = (row < n && c < m) ? 8 * (row * m + c) : OOBF;
         oRxT[r] = (row < n && c < nr) ? 8 * (c * n + row) : OOBF;     // RxT(p=row, k=c) = r_x[k][p]
@@ -1065,8 +1134,7 @@ __device__ __forceinline__ void forward_fused_body(RecLayout L, FusedArgs F, int
     const d4 zero = {0.0, 0.0, 0.0, 0.0};
     double partial = 0.0;
 
-    const double *R0 = rec + (size_t)b * T * L.stride;
-    __amdgpu_buffer_rsrc_t rT = frsrc(R0, T * strideB);
+    __amdgpu_buffer_rsrc_t rT = frsrc(F.kpc + (size_t)E0 * 3 * L.n, NE * strideB);
     const double *rb = F.r + (size_t)b * (T + 1) * nr;
     const double *rxb = F.r_x + (size_t)b * (T + 1) * nr * n;
     const double *rub = F.r_u + (size_t)b * (T + 1) * nr * m;
@@ -1108,8 +1176,8 @@ __device__ __forceinline__ void forward_fused_body(RecLayout L, FusedArgs F, int
     // not needed yet: the end column is requested at the crossing and the slope formed one step later
     // (`pend`), so no second prefetch buffer is held.
     double sv[8], ev[8], av[8];
-    load_col(rT, co, has ? s : BIGT, T, strideB, sv);
-    load_col(rT, co, e, T, strideB, ev);
+    load_col(rT, co, has ? idx - E0 : -1, NE, strideB, sv);
+    load_col(rT, co, (has && idx + 1 < khi) ? idx + 1 - E0 : -1, NE, strideB, ev);
     bool pend = true;
 #pragma unroll
     for (int i = 0; i < 8; i++) av[i] = 0.0;
@@ -1147,7 +1215,7 @@ __device__ __forceinline__ void forward_fused_body(RecLayout L, FusedArgs F, int
 #pragma unroll
             for (int i = 0; i < 8; i++) { sv[i] = ev[i]; av[i] = 0.0; }
             s = e; e = nb; idx++;
-            load_col(rT, co, e, T, strideB, ev);
+            load_col(rT, co, (idx + 1 < khi) ? idx + 1 - E0 : -1, NE, strideB, ev);
             nb = (idx + 2 < khi) ? F.kp_times[idx + 2] : BIGT;
             pend = true;
         }
@@ -1253,23 +1321,23 @@ __device__ __forceinline__ void forward_fused_body(RecLayout L, FusedArgs F, int
 // flag first and leaves if the set is not its kind, so the host never has to know.
 template <int NCZ, int NCU, bool RU0, bool UNI>
 __global__ void __launch_bounds__(64)
-k_forward_fused(RecLayout L, FusedArgs F, int T, int n_alpha, const double *__restrict__ rec, const double *__restrict__ Kin,
+k_forward_fused(RecLayout L, FusedArgs F, int T, int n_alpha, const double *__restrict__ Kin,
                 const double *__restrict__ kin, const double *__restrict__ u_nom, const double *__restrict__ ctrl_lim,
                 const double *__restrict__ alphas, double *__restrict__ cost_pred, double *__restrict__ U_alpha,
                 const int *__restrict__ kp_uniform)
 {
     if ((*kp_uniform != 0) != UNI) return;
-    forward_fused_body<NCZ, NCU, RU0, UNI>(L, F, T, n_alpha, rec, Kin, kin, u_nom, ctrl_lim, alphas, cost_pred, U_alpha);
+    forward_fused_body<NCZ, NCU, RU0, UNI>(L, F, T, n_alpha, Kin, kin, u_nom, ctrl_lim, alphas, cost_pred, U_alpha);
 }
 template <int NCZ, int NCU, bool RU0, bool UNI>
 __global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(1, 1)))
-k_forward_fused_excl(RecLayout L, FusedArgs F, int T, int n_alpha, const double *__restrict__ rec, const double *__restrict__ Kin,
+k_forward_fused_excl(RecLayout L, FusedArgs F, int T, int n_alpha, const double *__restrict__ Kin,
                      const double *__restrict__ kin, const double *__restrict__ u_nom, const double *__restrict__ ctrl_lim,
                      const double *__restrict__ alphas, double *__restrict__ cost_pred, double *__restrict__ U_alpha,
                      const int *__restrict__ kp_uniform)
 {
     if ((*kp_uniform != 0) != UNI) return;
-    forward_fused_body<NCZ, NCU, RU0, UNI>(L, F, T, n_alpha, rec, Kin, kin, u_nom, ctrl_lim, alphas, cost_pred, U_alpha);
+    forward_fused_body<NCZ, NCU, RU0, UNI>(L, F, T, n_alpha, Kin, kin, u_nom, ctrl_lim, alphas, cost_pred, U_alpha);
 }
 
 // ---------------------------------------------------------------------------------------------------------
@@ -1376,23 +1444,21 @@ __device__ __forceinline__ void forward_sc_state(double *sh, RecLayout L, int T,
 
 // ROLE 0: score and stage (second wave of the pair); 1: score only; 2: stage the A, B columns only (third wave of the triple)
 template <int NCZ, int NCU, int ROLE = 0>
-__device__ __forceinline__ void forward_sc_cost(double *sh, RecLayout L, FusedArgs F, int T, int n_alpha, const double *__restrict__ rec,
-               double *__restrict__ cost_pred)
+__device__ __forceinline__ void forward_sc_cost(double *sh, RecLayout L, FusedArgs F, int T, int n_alpha, double *__restrict__ cost_pred)
 {
     const int n = L.n, m = L.m;
     const int lane = threadIdx.x & 63, c = lane & 15, q = lane >> 4;
     const int b = blockIdx.x;
     const int nr = F.nr;
-    const int strideB = L.stride * 8;
+    const int strideB = 3 * L.n * 8;                               // bytes of one key-point entry of kpc: three columns
     const int ncx = (n + 3) >> 2;
     ColOffs co;
+    col_offsets(co, n, m, F.dof, c, q);
     int oRxT[4], oRuT[4], oR[4];
     double wcur[4], wterm[4];
 #pragma unroll
     for (int r = 0; r < 4; r++) {
         const int row = 4 * r + q;
-        co.a[r] = (row < n && c < n) ? 8 * L.a(row, c) : OOBF;
-        co.b[r] = (row < n && c < m) ? 8 * L.b(row, c) : OOBF;
         oRxT[r] = (row < n && c < nr) ? 8 * (c * n + row) : OOBF;     // RxT(p=row, k=c) = r_x[k][p]
         oRuT[r] = (row < m && c < nr) ? 8 * (c * m + row) : OOBF;     // RuT(p=row, k=c) = r_u[k][p]
         oR[r] = (row < nr) ? 8 * row : OOBF;
@@ -1402,8 +1468,8 @@ __device__ __forceinline__ void forward_sc_cost(double *sh, RecLayout L, FusedAr
     }
     const d4 zero = {0.0, 0.0, 0.0, 0.0};
     double partial = 0.0;
-    const double *R0 = rec + (size_t)b * T * L.stride;
-    __amdgpu_buffer_rsrc_t rT = frsrc(R0, T * strideB);
+    const int E0 = F.kp_offsets[(size_t)b * F.dof], NE = F.kp_offsets[(size_t)(b + 1) * F.dof] - E0;      // this trajectory's key-point entries
+    __amdgpu_buffer_rsrc_t rT = frsrc(F.kpc + (size_t)E0 * 3 * L.n, NE * strideB);
     const double *rb = F.r + (size_t)b * (T + 1) * nr;
     const double *rxb = F.r_x + (size_t)b * (T + 1) * nr * n;
     const double *rub = F.r_u + (size_t)b * (T + 1) * nr * m;
@@ -1430,8 +1496,8 @@ __device__ __forceinline__ void forward_sc_cost(double *sh, RecLayout L, FusedAr
     int nb = (has && idx + 2 < khi) ? F.kp_times[idx + 2] : BIGT;
     double sv[8], ev[8], av[8];
     if (ROLE != 1) {
-        load_col(rT, co, has ? s : BIGT, T, strideB, sv);
-        load_col(rT, co, e, T, strideB, ev);
+        load_col(rT, co, has ? idx - E0 : -1, NE, strideB, sv);
+        load_col(rT, co, (has && idx + 1 < khi) ? idx + 1 - E0 : -1, NE, strideB, ev);
     }
     bool pend = true;
 #pragma unroll
@@ -1458,7 +1524,7 @@ __device__ __forceinline__ void forward_sc_cost(double *sh, RecLayout L, FusedAr
 #pragma unroll
             for (int i = 0; i < 8; i++) { sv[i] = ev[i]; av[i] = 0.0; }
             s = e; e = nb; idx++;
-            load_col(rT, co, e, T, strideB, ev);
+            load_col(rT, co, (idx + 1 < khi) ? idx + 1 - E0 : -1, NE, strideB, ev);
             nb = (idx + 2 < khi) ? F.kp_times[idx + 2] : BIGT;
             pend = true;
         }
@@ -1505,43 +1571,55 @@ __device__ __forceinline__ void forward_sc_cost(double *sh, RecLayout L, FusedAr
 
 template <int NCZ, int NCU>
 __global__ void __launch_bounds__(128) __attribute__((amdgpu_waves_per_eu(1, 1)))
-k_forward_fused_sc(RecLayout L, FusedArgs F, int T, int n_alpha, const double *__restrict__ rec, const double *__restrict__ Kin,
+k_forward_fused_sc(RecLayout L, FusedArgs F, int T, int n_alpha, const double *__restrict__ Kin,
                    const double *__restrict__ kin, const double *__restrict__ u_nom, const double *__restrict__ ctrl_lim,
                    const double *__restrict__ alphas, double *__restrict__ cost_pred, double *__restrict__ U_alpha)
 {
     __shared__ __attribute__((aligned(16))) double sh[FSC_TOTAL];
     const bool state = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6) == 0;
     if (state) forward_sc_state<NCZ, NCU>(sh, L, T, n_alpha, Kin, kin, u_nom, ctrl_lim, alphas, U_alpha);
-    else       forward_sc_cost<NCZ, NCU>(sh, L, F, T, n_alpha, rec, cost_pred);
+    else       forward_sc_cost<NCZ, NCU>(sh, L, F, T, n_alpha, cost_pred);
 }
 
 // state + cost + staging waves (4 x batch <= #SIMDs: one 3-wave workgroup per CU): the cost wave of the pair is the longer
 // one (1 360 vs 1 130 cycles per step); its a4 half goes to a third wave
 template <int NCZ, int NCU>
 __global__ void __launch_bounds__(192) __attribute__((amdgpu_waves_per_eu(1, 1)))
-k_forward_fused_sc3(RecLayout L, FusedArgs F, int T, int n_alpha, const double *__restrict__ rec, const double *__restrict__ Kin,
+k_forward_fused_sc3(RecLayout L, FusedArgs F, int T, int n_alpha, const double *__restrict__ Kin,
                     const double *__restrict__ kin, const double *__restrict__ u_nom, const double *__restrict__ ctrl_lim,
                     const double *__restrict__ alphas, double *__restrict__ cost_pred, double *__restrict__ U_alpha)
 {
     __shared__ __attribute__((aligned(16))) double sh[FSC_TOTAL];
     const int role = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     if (role == 0) forward_sc_state<NCZ, NCU>(sh, L, T, n_alpha, Kin, kin, u_nom, ctrl_lim, alphas, U_alpha);
-    else if (role == 1) forward_sc_cost<NCZ, NCU, 1>(sh, L, F, T, n_alpha, rec, cost_pred);
-    else forward_sc_cost<NCZ, NCU, 2>(sh, L, F, T, n_alpha, rec, cost_pred);
+    else if (role == 1) forward_sc_cost<NCZ, NCU, 1>(sh, L, F, T, n_alpha, cost_pred);
+    else forward_sc_cost<NCZ, NCU, 2>(sh, L, F, T, n_alpha, cost_pred);
 }
 
 bool fused_supported(int n, int m, int nr, int dof, int T, int stride, int n_alpha)
 {
-    return kp_t1_shape(n, m) && nr >= 1 && nr <= 16 && m <= dof && n_alpha <= 16 && (long long)T * stride * 8 < 0x7ffffff0LL;
+    (void)stride;
+    // one trajectory's slice of the key-point column store (at most T entries per DoF, 3n doubles each) behind one descriptor
+    return kp_t1_shape(n, m) && nr >= 1 && nr <= 16 && m <= dof && n_alpha <= 16 && (long long)T * dof * 3 * n * 8 < 0x7ffffff0LL;
 }
 
 static FusedArgs fused_args(const Ctx *c)
 {
-    FusedArgs F = {c->kp_offsets, c->kp_times, c->r, c->r_x, c->r_u, c->w_run, c->w_term, c->d.dof, c->d.nr};
+    FusedArgs F = {c->kp_offsets, c->kp_times, c->r, c->r_x, c->r_u, c->w_run, c->w_term, c->d.dof, c->d.nr,
+                   c->kpc, c->kx_plus, c->kx_minus, c->k_mode, c->eps, 1.0 / c->eps, 1.0 / (2 * c->eps)};
     return F;
 }
 
-hipError_t launch_backward_fused(Ctx *c, int pd_stride)
+// Which wave organisation launch_backward_fused will pick: 1 one wave per trajectory, 2 control/state split, 3 producer /
+// consumer pair, 4 consumer / side / producer triple.  Only form 1 has the RAW instantiation.
+int backward_fused_form(const Ctx *c)
+{
+    return c->tune.fused_bwd_waves ? c->tune.fused_bwd_waves
+         : (4 * c->d.batch <= c->n_simd ? 4 : 2 * c->d.batch <= c->n_simd ? 3 : 1);      // a triple needs three SIMDs of ONE CU
+}
+
+// raw: difference the key-point ordered payload inside the sweep (one-wave form only; the caller checks backward_fused_form)
+hipError_t launch_backward_fused(Ctx *c, int pd_stride, bool raw)
 {
     const int n = c->n, m = c->d.m;
     dim3 grid(c->d.batch), block(64);
@@ -1552,19 +1630,19 @@ hipError_t launch_backward_fused(Ctx *c, int pd_stride)
     // beyond that the FP64 unit is shared and one wave per trajectory wins.
     // KPILQR_FUSED_WAVES forces a form: 1 = one wave, 2 = control/state split, 3 = producer/consumer, 4 = the triple
     // consumer / side / producer (while batch <= #CUs: the three waves of a workgroup share a CU).
-    const int form = c->tune.fused_bwd_waves ? c->tune.fused_bwd_waves
-                   : (4 * c->d.batch <= c->n_simd ? 4 : 2 * c->d.batch <= c->n_simd ? 3 : 1);      // a triple needs three SIMDs of ONE CU
+    const int form = backward_fused_form(c);
+    if (raw && form != 1) return hipErrorInvalidValue;
     const int role_shift = c->tune.role_shift;
     dim3 block2(128);
     if (form == 2) {
-        if (n == 14 && m == 7) hipLaunchKernelGGL((k_backward_fused2<14, 7>), grid, block2, 0, c->stream, c->L, F, c->d.T, role_shift, c->rec, c->lambda, pd_stride, c->K, c->k, c->delta_J, c->status);
-        else if (n == 4 && m == 1) hipLaunchKernelGGL((k_backward_fused2<4, 1>), grid, block2, 0, c->stream, c->L, F, c->d.T, role_shift, c->rec, c->lambda, pd_stride, c->K, c->k, c->delta_J, c->status);
+        if (n == 14 && m == 7) hipLaunchKernelGGL((k_backward_fused2<14, 7>), grid, block2, 0, c->stream, c->L, F, c->d.T, role_shift, c->lambda, pd_stride, c->K, c->k, c->delta_J, c->status);
+        else if (n == 4 && m == 1) hipLaunchKernelGGL((k_backward_fused2<4, 1>), grid, block2, 0, c->stream, c->L, F, c->d.T, role_shift, c->lambda, pd_stride, c->K, c->k, c->delta_J, c->status);
         else return hipErrorInvalidValue;
         return hipGetLastError();
     }
     if (form == 4) {
         dim3 block3(192);
-#define KP_X(NN, MM) if (n == NN && m == MM) { hipLaunchKernelGGL((k_backward_fusedpc3<NN, MM>), grid, block3, 0, c->stream, c->L, F, c->d.T, role_shift, c->rec, c->lambda, pd_stride, c->K, c->k, c->delta_J, c->status); return hipGetLastError(); }
+#define KP_X(NN, MM) if (n == NN && m == MM) { hipLaunchKernelGGL((k_backward_fusedpc3<NN, MM>), grid, block3, 0, c->stream, c->L, F, c->d.T, role_shift, c->lambda, pd_stride, c->K, c->k, c->delta_J, c->status); return hipGetLastError(); }
         KP_T1_SHAPES(KP_X)
 #undef KP_X
         return hipErrorInvalidValue;
@@ -1573,8 +1651,8 @@ hipError_t launch_backward_fused(Ctx *c, int pd_stride)
         const bool pexcl = 2 * c->d.batch <= c->n_simd;
 #define LAUNCHPC(NN, MM)                                                                                              \
         do {                                                                                                          \
-            if (pexcl) hipLaunchKernelGGL((k_backward_fusedpc_excl<NN, MM>), grid, block2, 0, c->stream, c->L, F, c->d.T, role_shift, c->rec, c->lambda, pd_stride, c->K, c->k, c->delta_J, c->status); \
-            else hipLaunchKernelGGL((k_backward_fusedpc<NN, MM>), grid, block2, 0, c->stream, c->L, F, c->d.T, role_shift, c->rec, c->lambda, pd_stride, c->K, c->k, c->delta_J, c->status); \
+            if (pexcl) hipLaunchKernelGGL((k_backward_fusedpc_excl<NN, MM>), grid, block2, 0, c->stream, c->L, F, c->d.T, role_shift, c->lambda, pd_stride, c->K, c->k, c->delta_J, c->status); \
+            else hipLaunchKernelGGL((k_backward_fusedpc<NN, MM>), grid, block2, 0, c->stream, c->L, F, c->d.T, role_shift, c->lambda, pd_stride, c->K, c->k, c->delta_J, c->status); \
         } while (0)
 #define KP_X(NN, MM) if (n == NN && m == MM) { LAUNCHPC(NN, MM); return hipGetLastError(); }
         KP_T1_SHAPES(KP_X)
@@ -1582,21 +1660,23 @@ hipError_t launch_backward_fused(Ctx *c, int pd_stride)
 #undef LAUNCHPC
         return hipErrorInvalidValue;
     }
-#define LAUNCH2(NN, MM, RU)                                                                                   \
+#define LAUNCH3(NN, MM, RU, RW)                                                                               \
     do {                                                                                                     \
         if (excl)                                                                                            \
-            hipLaunchKernelGGL((k_backward_fused_excl<NN, MM, RU>), grid, block, 0, c->stream, c->L, F, c->d.T,  \
-                               c->rec, c->lambda, pd_stride, c->K, c->k, c->delta_J, c->status);             \
+            hipLaunchKernelGGL((k_backward_fused_excl<NN, MM, RU, RW>), grid, block, 0, c->stream, c->L, F, c->d.T,  \
+                               c->lambda, pd_stride, c->K, c->k, c->delta_J, c->status);             \
         else                                                                                                 \
-            hipLaunchKernelGGL((k_backward_fused<NN, MM, RU>), grid, block, 0, c->stream, c->L, F, c->d.T,   \
-                               c->rec, c->lambda, pd_stride, c->K, c->k, c->delta_J, c->status);             \
+            hipLaunchKernelGGL((k_backward_fused<NN, MM, RU, RW>), grid, block, 0, c->stream, c->L, F, c->d.T,   \
+                               c->lambda, pd_stride, c->K, c->k, c->delta_J, c->status);             \
     } while (0)
+#define LAUNCH2(NN, MM, RU) do { if (raw) LAUNCH3(NN, MM, RU, true); else LAUNCH3(NN, MM, RU, false); } while (0)
 #define LAUNCH(NN, MM) do { if (c->ru_zero) LAUNCH2(NN, MM, true); else LAUNCH2(NN, MM, false); } while (0)
 #define KP_X(NN, MM) if (n == NN && m == MM) { LAUNCH(NN, MM); return hipGetLastError(); }
     KP_T1_SHAPES(KP_X)
 #undef KP_X
 #undef LAUNCH
 #undef LAUNCH2
+#undef LAUNCH3
     return hipErrorInvalidValue;
 }
 
@@ -1614,7 +1694,7 @@ hipError_t launch_forward_fused(Ctx *c, double *U_alpha_dev)
         dim3 block3(192);
 #define LAUNCHSC3(NCZ, NCU)                                                                                             \
         if (ncz == NCZ && ncu == NCU) {                                                                                 \
-            hipLaunchKernelGGL((k_forward_fused_sc3<NCZ, NCU>), grid, block3, 0, c->stream, c->L, F, c->d.T, c->d.n_alpha, c->rec, \
+            hipLaunchKernelGGL((k_forward_fused_sc3<NCZ, NCU>), grid, block3, 0, c->stream, c->L, F, c->d.T, c->d.n_alpha, \
                                c->K, c->k, c->u_nom, c->ctrl_lim, c->alphas, c->cost_pred, U_alpha_dev);                \
             return hipGetLastError();                                                                                   \
         }
@@ -1626,7 +1706,7 @@ hipError_t launch_forward_fused(Ctx *c, double *U_alpha_dev)
         dim3 block2(128);
 #define LAUNCHSC(NCZ, NCU)                                                                                              \
         if (ncz == NCZ && ncu == NCU) {                                                                                 \
-            hipLaunchKernelGGL((k_forward_fused_sc<NCZ, NCU>), grid, block2, 0, c->stream, c->L, F, c->d.T, c->d.n_alpha, c->rec, \
+            hipLaunchKernelGGL((k_forward_fused_sc<NCZ, NCU>), grid, block2, 0, c->stream, c->L, F, c->d.T, c->d.n_alpha, \
                                c->K, c->k, c->u_nom, c->ctrl_lim, c->alphas, c->cost_pred, U_alpha_dev);                \
             return hipGetLastError();                                                                                   \
         }
@@ -1638,11 +1718,11 @@ hipError_t launch_forward_fused(Ctx *c, double *U_alpha_dev)
     do {                                                                                                          \
         if (excl)                                                                                                 \
             hipLaunchKernelGGL((k_forward_fused_excl<NCZ, NCU, RU, UNI>), grid, block, 0, c->stream, c->L, F, c->d.T, \
-                               c->d.n_alpha, c->rec, c->K, c->k, c->u_nom, c->ctrl_lim, c->alphas, c->cost_pred,  \
+                               c->d.n_alpha, c->K, c->k, c->u_nom, c->ctrl_lim, c->alphas, c->cost_pred,  \
                                U_alpha_dev, c->kp_uniform);                                                       \
         else                                                                                                      \
             hipLaunchKernelGGL((k_forward_fused<NCZ, NCU, RU, UNI>), grid, block, 0, c->stream, c->L, F, c->d.T,  \
-                               c->d.n_alpha, c->rec, c->K, c->k, c->u_nom, c->ctrl_lim, c->alphas, c->cost_pred,  \
+                               c->d.n_alpha, c->K, c->k, c->u_nom, c->ctrl_lim, c->alphas, c->cost_pred,  \
                                U_alpha_dev, c->kp_uniform);                                                       \
     } while (0)
 // both forms, back to back: the one whose kind of key-point set is not resident leaves at once (k_forward_fused)

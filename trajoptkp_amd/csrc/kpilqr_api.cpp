@@ -85,6 +85,7 @@ Ctx::Tuning read_tuning_from_env()
     t.tiled_a6 = env_int("KPILQR_TILED_A6", -1);
     t.tiled_a4 = env_int("KPILQR_TILED_A4", -1);
     t.pipe_copy = env_int("KPILQR_PIPE_COPY", -1);
+    t.fused_raw = env_int("KPILQR_FUSED_RAW", -1);
     return t;
 }
 }  // namespace kpilqr
@@ -100,7 +101,8 @@ static int size_buffers(kpilqr_ctx *c)
     const size_t B = dims->batch, T = dims->T, n = c->n, m = dims->m, nr = dims->nr;
     struct Want { void **p; size_t bytes; size_t *cap; bool zero; };
     const Want want[] = {
-        {(void **)&c->rec, B * T * c->L.stride * 8, &c->cap[0], true},
+        // a fused (one-tile) context keeps key-point columns only (Ctx::kpc); its records appear on demand (ensure_records)
+        {(void **)&c->rec, c->fused ? 0 : B * T * c->L.stride * 8, &c->cap[0], true},
         {(void **)&c->K, B * T * n * m * 8, &c->cap[1], true},
         {(void **)&c->k, B * T * m * 8, &c->cap[2], true},
         {(void **)&c->r, B * (T + 1) * nr * 8, &c->cap[3], true},
@@ -128,11 +130,113 @@ static int size_buffers(kpilqr_ctx *c)
             *w.cap = w.bytes;
         }
         // records start zeroed so that padding / never-written columns are defined
-        if (w.zero) KP_HIP(c, hipMemsetAsync(*w.p, 0, w.bytes, c->stream));
+        if (w.zero && w.bytes) KP_HIP(c, hipMemsetAsync(*w.p, 0, w.bytes, c->stream));
     }
+    c->have_rec = !c->fused;
     c->rec_fd_base = c->rec;
     c->fd_batch_total = dims->batch;
     return KPILQR_OK;
+}
+
+// ---- fused contexts: key-point column store, entry tables, records on demand ----------------------------------------------
+static int grow_dev(kpilqr_ctx *c, void **p, size_t *cap, size_t bytes, bool zero)
+{
+    if (bytes > *cap) {
+        KP_HIP(c, hipStreamSynchronize(c->stream));              // nothing in flight still uses the old allocation
+        if (*p) KP_HIP(c, hipFree(*p));
+        *p = nullptr; *cap = 0;
+        hipError_t e = hipMalloc(p, bytes ? bytes : 8);
+        if (e != hipSuccess) { c->err = std::string("hipMalloc failed: ") + hipGetErrorString(e); return KPILQR_ERR_ALLOC; }
+        *cap = bytes;
+        if (zero) KP_HIP(c, hipMemsetAsync(*p, 0, bytes, c->stream));
+        return 1;                                                // re-allocated: the old contents are gone
+    }
+    return KPILQR_OK;
+}
+
+// kpc for the current key-point capacity: 3n doubles per CSR entry
+static int ensure_kpc(kpilqr_ctx *c)
+{
+    const int rc = grow_dev(c, (void **)&c->kpc, &c->kpc_cap, c->kp_cap * 3 * (size_t)c->n * 8, true);
+    if (rc < 0) return rc;
+    if (rc > 0) c->kpc_valid = c->kpc_touched = false;
+    return KPILQR_OK;
+}
+
+// kp_entry [list][t] and kp_entry_list [entry] for the current lists
+static int ensure_entry_tables(kpilqr_ctx *c)
+{
+    if (c->entry_tables_valid) return KPILQR_OK;
+    int rc = grow_dev(c, (void **)&c->kp_entry, &c->kp_entry_cap, (size_t)c->d.batch * c->d.dof * c->d.T * sizeof(int), false);
+    if (rc < 0) return rc;
+    rc = grow_dev(c, (void **)&c->kp_entry_list, &c->kp_entry_list_cap, (c->kp_cap ? c->kp_cap : 1) * sizeof(int), false);
+    if (rc < 0) return rc;
+    KP_HIP(c, launch_build_entry_tables(c));
+    c->entry_tables_valid = true;
+    return KPILQR_OK;
+}
+
+// The resident FD payload differenced into kpc (explicitly: the raw backward sweep does the same on the fly)
+static int difference_to_kpc(kpilqr_ctx *c)
+{
+    if (c->fd_kind == 0 || !c->have_kp) return KPILQR_OK;
+    int rc = ensure_kpc(c);
+    if (rc) return rc;
+    if (c->fd_kind == 1) {
+        rc = ensure_entry_tables(c);
+        if (rc) return rc;
+        KP_HIP(c, launch_fd_difference_kpc(c));
+    } else {
+        KP_HIP(c, launch_fd_kp_difference(c));
+    }
+    c->kpc_valid = true;
+    return KPILQR_OK;
+}
+
+// The key-point columns of the resident FD payload written into the step records (what kpilqr_fd_difference means on a
+// context that has records)
+static int records_from_payload(kpilqr_ctx *c)
+{
+    if (c->fd_kind == 1) { KP_HIP(c, launch_fd_difference(c)); return KPILQR_OK; }
+    if (c->fd_kind == 2) {
+        if (!c->have_kp) return KPILQR_OK;
+        int rc = KPILQR_OK;
+        if (!c->kpc_valid) rc = difference_to_kpc(c);
+        if (rc) return rc;
+        rc = ensure_entry_tables(c);
+        if (rc) return rc;
+        KP_HIP(c, launch_kpc_to_records(c));
+    }
+    return KPILQR_OK;
+}
+
+// A fused context has no step records until something asks for the materialised sequence (kpilqr_interpolate, get_AB /
+// set_AB, the cost-derivative hooks, the key-point error test, KPILQR_BUF_STEP_RECORDS): then they are allocated, zeroed
+// and given the key-point columns of the resident payload.
+static int ensure_records(kpilqr_ctx *c)
+{
+    if (!c->have_rec) {
+        const size_t bytes = (size_t)c->d.batch * c->d.T * c->L.stride * 8;
+        const int rc = grow_dev(c, (void **)&c->rec, &c->cap[0], bytes, false);
+        if (rc < 0) return rc;
+        KP_HIP(c, hipMemsetAsync(c->rec, 0, bytes, c->stream));
+        c->rec_fd_base = c->rec;
+        c->have_rec = true;
+        c->rec_synced = false;
+    }
+    if (!c->rec_synced) {
+        const int rc = records_from_payload(c);
+        if (rc) return rc;
+        c->rec_synced = true;
+    }
+    return KPILQR_OK;
+}
+
+// a new FD payload or new key-points: whatever was derived from the old ones is stale
+static void payload_changed(kpilqr_ctx *c)
+{
+    c->kpc_valid = c->kpc_touched = false;
+    c->rec_synced = false;
 }
 
 // kernel families for c->d (names: kpilqr_backward_variant)
@@ -223,7 +327,8 @@ int kpilqr_create(const kpilqr_dims *dims, void *stream, kpilqr_ctx **out)
     }
 
     {
-        const int rcs = size_buffers(c);
+        int rcs = select_variants(c);                        // first: a fused context allocates no step records
+        if (rcs == KPILQR_OK) rcs = size_buffers(c);
         if (rcs != KPILQR_OK) { const std::string msg = c->err; kpilqr_destroy(c); return set_err(nullptr, rcs, msg); }
     }
     hipError_t rc = hipSuccess;
@@ -239,10 +344,6 @@ int kpilqr_create(const kpilqr_dims *dims, void *stream, kpilqr_ctx **out)
     }
     (void)hipMemsetAsync(c->err_flag, 0, sizeof(int), c->stream);
     (void)hipMemsetAsync(c->kp_uniform, 0, sizeof(int), c->stream);
-    {
-        const int rcv = select_variants(c);
-        if (rcv != KPILQR_OK) { const std::string msg = c->err; kpilqr_destroy(c); return set_err(nullptr, rcv, msg); }
-    }
     *out = c;
     return KPILQR_OK;
 }
@@ -263,9 +364,10 @@ void kpilqr_destroy(kpilqr_ctx *c)
     void *ptrs[] = {c->rec, c->K, c->k, c->r, c->r_x, c->r_u, c->w_run, c->w_term, c->u_nom, c->ctrl_lim,
                     c->lambda, c->alphas, c->cost_pred, c->delta_J, c->traj_cost, c->status, c->segmap,
                     c->kp_offsets, c->kp_times, c->X_states, c->kp_thr, c->kp_mask, c->kp_count, c->ls8, c->fd_dev,
-                    c->stage, c->err_flag, c->kp_uniform};
+                    c->stage, c->err_flag, c->kp_uniform, c->kpc, c->kp_entry, c->kp_entry_list, c->fdk_dev};
     for (void *p : ptrs) if (p) (void)hipFree(p);
     if (c->err_flag_host) (void)hipHostFree(c->err_flag_host);
+    if (c->kp_traj_first_host) free(c->kp_traj_first_host);
     if (c->own_stream) (void)hipStreamDestroy(c->stream);
     delete c;
 }
@@ -288,16 +390,21 @@ int kpilqr_resize(kpilqr_ctx *c, int new_dof, int new_num_ctrl, int new_horizon)
     KP_HIP(c, hipStreamSynchronize(c->stream));          // nothing in flight still uses the old layout
     const kpilqr_dims old = c->d;
     c->d.dof = new_dof; c->d.m = new_num_ctrl; c->d.T = new_horizon;
-    int rc = size_buffers(c);
-    if (rc == KPILQR_OK) rc = select_variants(c);
+    c->n = 2 * new_dof; c->L = RecLayout(c->n, new_num_ctrl);
+    int rc = select_variants(c);
+    if (rc == KPILQR_OK) rc = size_buffers(c);
     if (rc != KPILQR_OK) {                              // leave a usable context behind
         const std::string msg = c->err;
         c->d = old;
-        (void)size_buffers(c); (void)select_variants(c);
+        c->n = 2 * old.dof; c->L = RecLayout(c->n, old.m);
+        (void)select_variants(c); (void)size_buffers(c);
         return set_err(c, rc, msg);
     }
     c->have_kp = c->kp_canonical = c->have_states = false;
     c->njobs = c->nnom = 0;
+    c->fd_kind = 0; c->fdk_entries = 0; c->entry_tables_valid = false; c->kp_total_host = -1;
+    if (c->kp_traj_first_host) { free(c->kp_traj_first_host); c->kp_traj_first_host = nullptr; }
+    payload_changed(c);
     c->ru_zero = true;                                   // size_buffers zeroed r_u
     if (c->X_states) { KP_HIP(c, hipFree(c->X_states)); c->X_states = nullptr; }
     if (c->kp_mask) { KP_HIP(c, hipFree(c->kp_mask)); c->kp_mask = nullptr; }
@@ -352,7 +459,7 @@ int kpilqr_device_ptr(kpilqr_ctx *c, int which, void **dptr, size_t *bytes)
     const size_t B = c->d.batch, T = c->d.T, n = c->n, m = c->d.m, nr = c->d.nr;
     void *p = nullptr; size_t sz = 0;
     switch (which) {
-    case KPILQR_BUF_STEP_RECORDS: p = c->rec; sz = B * T * c->L.stride * 8; break;
+    case KPILQR_BUF_STEP_RECORDS: { const int rcr = ensure_records(c); if (rcr) return rcr; } p = c->rec; sz = B * T * c->L.stride * 8; break;
     case KPILQR_BUF_K: p = c->K; sz = B * T * n * m * 8; break;
     case KPILQR_BUF_k: p = c->k; sz = B * T * m * 8; break;
     case KPILQR_BUF_RESIDUALS: p = c->r; sz = B * (T + 1) * nr * 8; break;
@@ -404,6 +511,15 @@ int kpilqr_set_keypoints(kpilqr_ctx *c, const int *kp_offsets, const int *kp_tim
     // pageable host arrays: make the copies complete before returning control (pinned ones are read in place)
     if (!(is_pinned(kp_offsets) && is_pinned(kp_times))) KP_HIP(c, hipStreamSynchronize(c->stream));
     c->have_kp = true;
+    // host copy of the first CSR entry of every trajectory (chunking of a key-point ordered payload), and everything that
+    // was derived from the old lists is stale; a key-point ordered payload is laid out BY the lists: it has to follow them
+    c->kp_total_host = total;
+    if (!c->kp_traj_first_host) c->kp_traj_first_host = (int *)malloc(sizeof(int) * ((size_t)c->d.batch + 1));
+    if (!c->kp_traj_first_host) return set_err(c, KPILQR_ERR_ALLOC, "host allocation failed");
+    for (int b = 0; b <= c->d.batch; b++) c->kp_traj_first_host[b] = kp_offsets[(size_t)b * c->d.dof];
+    c->entry_tables_valid = false;
+    if (c->fd_kind == 2) { c->fd_kind = 0; c->fdk_entries = 0; }
+    payload_changed(c);
     return KPILQR_OK;
 }
 
@@ -456,6 +572,11 @@ int kpilqr_generate_keypoints(kpilqr_ctx *c, const char *method, int min_N, int 
     KP_HIP(c, launch_build_segmap(c));
     c->have_kp = true;
     c->kp_canonical = true;      // rows 0 and T-1 are always full and the lists are strictly increasing by construction
+    c->kp_total_host = -1;       // the lists exist on the device only (kpilqr_get_keypoints brings them to the host)
+    if (c->kp_traj_first_host) { free(c->kp_traj_first_host); c->kp_traj_first_host = nullptr; }
+    c->entry_tables_valid = false;
+    if (c->fd_kind == 2) { c->fd_kind = 0; c->fdk_entries = 0; }
+    payload_changed(c);
     return KPILQR_OK;
 }
 
@@ -466,6 +587,8 @@ int kpilqr_keypoint_error_test(kpilqr_ctx *c, int n_iv, const int *intervals, in
     if (n_iv == 0) return KPILQR_OK;
     const size_t iv_bytes = (size_t)n_iv * 4 * sizeof(int), off = (iv_bytes + 15) & ~(size_t)15;
     int rc = ensure_stage(c, off + (size_t)n_iv);
+    if (rc) return rc;
+    rc = ensure_records(c);                  // a fused context: records on demand, with the resident payload's columns
     if (rc) return rc;
     int *iv_dev = (int *)c->stage;
     unsigned char *good_dev = (unsigned char *)c->stage + off;
@@ -486,6 +609,9 @@ int kpilqr_get_keypoints(kpilqr_ctx *c, int *kp_offsets, int *kp_times, int time
     KP_HIP(c, hipMemcpyAsync(kp_offsets, c->kp_offsets, (nlists + 1) * sizeof(int), hipMemcpyDeviceToHost, c->stream));
     KP_HIP(c, hipStreamSynchronize(c->stream));
     const int total = kp_offsets[nlists];
+    c->kp_total_host = total;
+    if (!c->kp_traj_first_host) c->kp_traj_first_host = (int *)malloc(sizeof(int) * ((size_t)c->d.batch + 1));
+    if (c->kp_traj_first_host) for (int b = 0; b <= c->d.batch; b++) c->kp_traj_first_host[b] = kp_offsets[(size_t)b * c->d.dof];
     if (kp_times) {
         if (total > times_capacity) return set_err(c, KPILQR_ERR_ARG, "kp_times capacity too small");
         KP_HIP(c, hipMemcpyAsync(kp_times, c->kp_times, (size_t)total * sizeof(int), hipMemcpyDeviceToHost, c->stream));
@@ -567,6 +693,7 @@ int kpilqr_upload_fd(kpilqr_ctx *c, int njobs, const int *job_b, const int *job_
     }
     if (nnom) KP_HIP(c, hipMemcpyAsync(c->xnom, xnom, (size_t)nnom * n * sizeof(double), hipMemcpyHostToDevice, c->stream));
     c->njobs = njobs; c->nnom = nnom; c->eps = eps;
+    c->fd_kind = 1; payload_changed(c);
     // pageable sources: the caller may free them on return, so wait for the copies; pinned ones are read in place
     if (!(is_pinned(job_b) && is_pinned(job_t) && is_pinned(job_col) && is_pinned(job_mode) && is_pinned(job_nom) &&
           is_pinned(xplus) && is_pinned(xminus) && is_pinned(xnom)))
@@ -584,6 +711,55 @@ int kpilqr_upload_fd_slab(kpilqr_ctx *c, const void *slab, int njobs, int nnom, 
     if (rc) return rc;
     if (njobs) KP_HIP(c, hipMemcpyAsync(c->fd_dev, slab, L.bytes, hipMemcpyHostToDevice, c->stream));   // the one DMA
     c->njobs = njobs; c->nnom = nnom; c->eps = eps;
+    c->fd_kind = 1; payload_changed(c);
+    if (!is_pinned(slab)) KP_HIP(c, hipStreamSynchronize(c->stream));
+    return KPILQR_OK;
+}
+
+// ---- key-point ordered FD payload ---------------------------------------------------------------------------------------
+static void fdkp_layout(int n, int entries, kpilqr_fdkp_layout *L)
+{
+    const size_t E = (size_t)entries;
+    size_t o = 0;
+    L->xplus = o; o = al16(o + E * 3 * n * sizeof(double));
+    L->xminus = o; o = al16(o + E * 3 * n * sizeof(double));
+    L->mode = o; o = al16(o + E);
+    L->bytes = o;
+}
+
+int kpilqr_fd_kp_layout(kpilqr_ctx *c, int entries, kpilqr_fdkp_layout *out)
+{
+    if (!c || !out || entries < 0) return KPILQR_ERR_ARG;
+    fdkp_layout(c->n, entries, out);
+    return KPILQR_OK;
+}
+
+// device slab of the key-point ordered payload for `entries` entries; grows (after a stream sync) only when it has to
+static int fdk_bind(kpilqr_ctx *c, int entries, kpilqr_fdkp_layout *L)
+{
+    fdkp_layout(c->n, entries, L);
+    const int rc = grow_dev(c, (void **)&c->fdk_dev, &c->fdk_dev_cap, L->bytes + L->bytes / 8 + 4096, false);
+    if (rc < 0) return rc;
+    c->kx_plus = (double *)(c->fdk_dev + L->xplus); c->kx_minus = (double *)(c->fdk_dev + L->xminus);
+    c->k_mode = (unsigned char *)(c->fdk_dev + L->mode);
+    return KPILQR_OK;
+}
+
+int kpilqr_upload_fd_kp(kpilqr_ctx *c, const void *slab, int entries, double eps)
+{
+    if (!c || entries < 0 || (entries > 0 && !slab)) return KPILQR_ERR_ARG;
+    KP_ENTER(c);
+    if (!(eps > 0.0)) return set_err(c, KPILQR_ERR_ARG, "eps must be positive");
+    if (!c->have_kp) return set_err(c, KPILQR_ERR_STATE, "kpilqr_upload_fd_kp before the key-points it is ordered by (kpilqr_set_keypoints / kpilqr_generate_keypoints)");
+    if (c->kp_total_host >= 0 && entries != c->kp_total_host)
+        return set_err(c, KPILQR_ERR_ARG, "kpilqr_upload_fd_kp: `entries` is not the number of key-point entries (kp_offsets[batch*dof])");
+    if ((size_t)entries > c->kp_cap) return set_err(c, KPILQR_ERR_ARG, "kpilqr_upload_fd_kp: more entries than key-points");
+    kpilqr_fdkp_layout L;
+    int rc = fdk_bind(c, entries, &L);
+    if (rc) return rc;
+    if (entries) KP_HIP(c, hipMemcpyAsync(c->fdk_dev, slab, L.bytes, hipMemcpyHostToDevice, c->stream));   // the one DMA
+    c->fdk_entries = entries; c->fdk_first = 0; c->eps = eps;
+    c->fd_kind = 2; payload_changed(c);
     if (!is_pinned(slab)) KP_HIP(c, hipStreamSynchronize(c->stream));
     return KPILQR_OK;
 }
@@ -592,8 +768,14 @@ int kpilqr_fd_difference(kpilqr_ctx *c)
 {
     if (!c) return KPILQR_ERR_ARG;
     KP_ENTER(c);
-    KP_HIP(c, launch_fd_difference(c));
-    return KPILQR_OK;
+    if (c->fused) {
+        // the sweeps read the key-point column store; the records, if something has asked for them, follow
+        int rc = difference_to_kpc(c);
+        if (rc) return rc;
+        if (c->have_rec) { rc = records_from_payload(c); if (rc) return rc; c->rec_synced = true; }
+        return KPILQR_OK;
+    }
+    return records_from_payload(c);
 }
 
 int kpilqr_interpolate(kpilqr_ctx *c)
@@ -601,6 +783,7 @@ int kpilqr_interpolate(kpilqr_ctx *c)
     if (!c) return KPILQR_ERR_ARG;
     KP_ENTER(c);
     if (!c->have_kp) return set_err(c, KPILQR_ERR_STATE, "kpilqr_interpolate before kpilqr_set_keypoints");
+    if (c->fused) { const int rc = ensure_records(c); if (rc) return rc; }
     KP_HIP(c, launch_interpolate(c));
     return KPILQR_OK;
 }
@@ -642,6 +825,7 @@ int kpilqr_cost_derivs(kpilqr_ctx *c)
 {
     if (!c) return KPILQR_ERR_ARG;
     KP_ENTER(c);
+    if (c->fused) { const int rc = ensure_records(c); if (rc) return rc; }
     KP_HIP(c, launch_cost_derivs(c));
     return KPILQR_OK;
 }
@@ -670,7 +854,19 @@ static int run_backward(kpilqr_ctx *c, int pd_stride)
     if (c->fused) {
         int rc = check_fused(c);
         if (rc) return rc;
-        KP_HIP(c, launch_backward_fused(c, pd_stride));
+        rc = ensure_kpc(c);
+        if (rc) return rc;
+        // Key-point ordered payload, one wave per trajectory: the RAW sweep differences the payload itself and leaves kpc
+        // behind for the forward sweep -- no differencing kernel.  (It may stop at a failed PD check, so it never marks
+        // kpc valid: another backward pass on the same payload differences again.)  Otherwise the payload is differenced
+        // into kpc first, once, and the sweeps read kpc.
+        if (!c->kpc_valid && c->fd_kind == 2 && backward_fused_form(c) == 1 && c->tune.fused_raw != 0) {
+            KP_HIP(c, launch_backward_fused(c, pd_stride, true));
+            c->kpc_touched = true;
+            return KPILQR_OK;
+        }
+        if (!c->kpc_valid) { rc = difference_to_kpc(c); if (rc) return rc; }
+        KP_HIP(c, launch_backward_fused(c, pd_stride, false));
         return KPILQR_OK;
     }
     if (strcmp(c->bwd_variant, "mfma_f64_t1") == 0) KP_HIP(c, launch_backward_mfma(c, pd_stride));
@@ -744,6 +940,10 @@ static int run_forward(kpilqr_ctx *c, double *U_dev)
     if (c->fused) {
         int rc = check_fused(c);
         if (rc) return rc;
+        rc = ensure_kpc(c);
+        if (rc) return rc;
+        // kpc: differenced explicitly, or left behind by the raw backward sweep of this payload
+        if (!c->kpc_valid && !c->kpc_touched) { rc = difference_to_kpc(c); if (rc) return rc; }
         KP_HIP(c, launch_forward_fused(c, U_dev));
         return KPILQR_OK;
     }
@@ -781,8 +981,8 @@ int kpilqr_iterate(kpilqr_ctx *c, const double *lambda, int pd_check_stride, con
     if (pd_check_stride < 1) return set_err(c, KPILQR_ERR_ARG, "pd_check_stride must be >= 1");
     if (lambda) KP_HIP(c, hipMemcpyAsync(c->lambda, lambda, (size_t)c->d.batch * 8, hipMemcpyHostToDevice, c->stream));
     if (alphas) KP_HIP(c, hipMemcpyAsync(c->alphas, alphas, (size_t)c->d.n_alpha * 8, hipMemcpyHostToDevice, c->stream));
-    KP_HIP(c, launch_fd_difference(c));
-    if (!c->fused) {              // the fused sweeps interpolate A,B and form l_* themselves
+    if (!c->fused) {              // the fused sweeps difference (or read kpc), interpolate A, B and form l_* themselves
+        { const int rcp = records_from_payload(c); if (rcp) return rcp; }
         if (!c->tiled_a4) KP_HIP(c, launch_interpolate(c));      // tiled + flag: A, B interpolated inside the sweeps
         if (!c->tiled_a6) KP_HIP(c, launch_cost_derivs(c));      // tiled + flag: l_* are formed inside the sweeps
     }
@@ -812,7 +1012,8 @@ static void make_view(const kpilqr_ctx *c, int b0, int nb, hipStream_t s, kpilqr
     *v = *c;
     const size_t T = c->d.T, n = c->n, m = c->d.m, nr = c->d.nr, na = c->d.n_alpha, dof = c->d.dof, o = (size_t)b0;
     v->d.batch = nb; v->stream = s; v->own_stream = false;
-    v->rec += o * T * c->L.stride; v->K += o * T * n * m; v->k += o * T * m;
+    if (v->rec) v->rec += o * T * c->L.stride;
+    v->K += o * T * n * m; v->k += o * T * m;
     v->r += o * (T + 1) * nr; v->r_x += o * (T + 1) * nr * n; v->r_u += o * (T + 1) * nr * m;
     v->u_nom += o * T * m; v->lambda += o; v->cost_pred += o * na; v->delta_J += o; v->traj_cost += o; v->status += o;
     v->segmap += o * dof * T; v->kp_offsets += o * dof;
@@ -831,8 +1032,14 @@ int kpilqr_iterate_streamed(kpilqr_ctx *c, const kpilqr_stream_io *io, int pd_ch
     if (nchunks > B) nchunks = B;
     if (io->fd_slab && (io->njobs < 1 || !io->traj_job_first || (io->nnom > 0 && !io->traj_nom_first)))
         return set_err(c, KPILQR_ERR_ARG, "streamed FD payload needs the per-trajectory job / nominal-row offsets");
+    if (io->fd_slab && io->fd_kp_slab) return set_err(c, KPILQR_ERR_ARG, "one FD payload per iteration: job lists OR key-point ordered");
+    if (io->fd_kp_slab) {
+        if (!c->kp_traj_first_host || c->kp_total_host < 0)
+            return set_err(c, KPILQR_ERR_STATE, "streamed key-point ordered payload: the lists must be known to the host (kpilqr_set_keypoints, or kpilqr_get_keypoints after generating them)");
+        if (io->entries != c->kp_total_host) return set_err(c, KPILQR_ERR_ARG, "fd_kp_slab: `entries` is not the number of key-point entries");
+    }
     if (io->r_u) c->ru_zero = false;
-    const void *hostp[] = {io->fd_slab, io->r, io->r_x, io->r_u, io->u_nom, io->lambda, io->K, io->k, io->cost_pred, io->delta_J, io->status};
+    const void *hostp[] = {io->fd_kp_slab, io->fd_slab, io->r, io->r_x, io->r_u, io->u_nom, io->lambda, io->K, io->k, io->cost_pred, io->delta_J, io->status};
     for (const void *p : hostp) if (!is_pinned(p)) return set_err(c, KPILQR_ERR_ARG, "kpilqr_iterate_streamed: host buffers must be pinned (kpilqr_host_alloc)");
     if (c->fused || c->tiled_a4) { int rc = check_fused(c); if (rc) return rc; }
     int rc = pipe_setup(c);
@@ -886,12 +1093,36 @@ int kpilqr_iterate_streamed(kpilqr_ctx *c, const kpilqr_stream_io *io, int pd_ch
         c->pipe_sig = sig;
         c->njobs = io->njobs; c->nnom = io->nnom; c->eps = io->eps;
     }
+    kpilqr_fdkp_layout LK{};
+    const char *kslab = (const char *)io->fd_kp_slab;
+    if (kslab) {
+        // a chunk's payload lands at its trajectories' entry range, which only the key-points decide: same-stream order
+        // protects it from the next iteration's uploads (new key-points go through KP_ENTER, which joins the pipeline)
+        kpilqr_fdkp_layout probe;
+        fdkp_layout(n, io->entries, &probe);
+        if (probe.bytes + probe.bytes / 8 + 4096 > c->fdk_dev_cap && c->pipe_ready) {
+            rc = join_pipeline(c); if (rc) return rc;
+            for (int i = 0; i < Ctx::kPipeStreams; i++) KP_HIP(c, hipStreamSynchronize(c->pipe_stream[i]));
+        }
+        rc = fdk_bind(c, io->entries, &LK);
+        if (rc) return rc;
+        c->fdk_entries = io->entries; c->fdk_first = 0; c->eps = io->eps;
+    }
+    if (slab) c->fd_kind = 1;
+    if (kslab) c->fd_kind = 2;
+    if (slab || kslab) payload_changed(c);
+    // allocations and tables the chunks need are made HERE, on the context: a view never allocates
+    if (c->fused || c->fd_kind == 2) {
+        rc = ensure_kpc(c); if (rc) return rc;
+        rc = ensure_entry_tables(c); if (rc) return rc;
+    }
     // order the chunk streams behind whatever the caller enqueued on the context's stream so far (key-points, weights ...)
     KP_HIP(c, hipEventRecord(c->pipe_in, c->stream));
     // from here on chunk streams hold work: every exit path, errors included, leaves the pipeline marked for joining, so a
     // later kpilqr_sync / kpilqr_destroy waits for the DMAs that read the caller's buffers
     c->pipe_dirty = true;
 
+    bool vflags_valid = c->kpc_valid, vflags_touched = c->kpc_touched;
     for (int ch = 0; ch < nchunks; ch++) {
         const int b0 = (int)((long long)B * ch / nchunks), b1 = (int)((long long)B * (ch + 1) / nchunks), nb = b1 - b0;
         if (nb <= 0) continue;
@@ -920,8 +1151,21 @@ int kpilqr_iterate_streamed(kpilqr_ctx *c, const kpilqr_stream_io *io, int pd_ch
             // the chunk's jobs: a contiguous range of the job arrays
             v.job_b = c->job_b + jo; v.job_t = c->job_t + jo; v.job_col = c->job_col + jo; v.job_nom = c->job_nom + jo;
             v.job_mode = c->job_mode + jo; v.xplus = c->xplus + jo * n; v.xminus = c->xminus + jo * n; v.njobs = (int)J;
+        } else if (kslab) {
+            const int e0 = c->kp_traj_first_host[b0], e1 = c->kp_traj_first_host[b1];
+            const size_t E = (size_t)(e1 - e0), eo = (size_t)e0, row = (size_t)3 * n * 8;
+            if (E) {
+                KP_HIP(c, h2d((char *)c->kx_plus + eo * row, kslab + LK.xplus + eo * row, E * row, s));
+                KP_HIP(c, h2d((char *)c->kx_minus + eo * row, kslab + LK.xminus + eo * row, E * row, s));
+                KP_HIP(c, h2d(c->k_mode + eo, kslab + LK.mode + eo, E, s));
+            }
+            v.fdk_first = e0; v.fdk_entries = (int)E;      // the chunk's entries
         } else {
-            v.njobs = 0;                    // no new FD payload: the key-point columns already in the records are reused
+            // no new FD payload: what was differenced before is reused (kpc / the records' key-point columns)
+            v.njobs = 0;
+            if (c->fd_kind == 2 && c->kp_traj_first_host) {
+                v.fdk_first = c->kp_traj_first_host[b0]; v.fdk_entries = c->kp_traj_first_host[b1] - v.fdk_first;
+            }
         }
         if (io->r) KP_HIP(c, h2d(v.r, io->r + o * (T + 1) * nr, cnt * (T + 1) * nr * 8, s));
         if (io->r_x) KP_HIP(c, h2d(v.r_x, io->r_x + o * (T + 1) * nr * n, cnt * (T + 1) * nr * n * 8, s));
@@ -929,8 +1173,8 @@ int kpilqr_iterate_streamed(kpilqr_ctx *c, const kpilqr_stream_io *io, int pd_ch
         if (io->u_nom) KP_HIP(c, h2d(v.u_nom, io->u_nom + o * T * m, cnt * T * m * 8, s));
         if (io->lambda) KP_HIP(c, h2d(v.lambda, io->lambda + o, cnt * 8, s));
         // ---- kernels of the chunk --------------------------------------------------------------------------------
-        KP_HIP(c, launch_fd_difference(&v));
         if (!c->fused) {
+            if (slab || kslab) { rc = records_from_payload(&v); if (rc) { c->err = v.err; return rc; } }
             if (!c->tiled_a4) KP_HIP(c, launch_interpolate(&v));
             if (!c->tiled_a6) KP_HIP(c, launch_cost_derivs(&v));
         }
@@ -938,6 +1182,7 @@ int kpilqr_iterate_streamed(kpilqr_ctx *c, const kpilqr_stream_io *io, int pd_ch
         if (rc) { c->err = v.err; return rc; }
         rc = run_forward(&v, nullptr);
         if (rc) { c->err = v.err; return rc; }
+        vflags_valid = v.kpc_valid; vflags_touched = v.kpc_touched;
         // ---- D2H of the chunk ------------------------------------------------------------------------------------
         // K, k by a copy kernel: it overlaps with the SDMA uploads of the next chunks (two SDMA directions do not)
         if (k_down) {
@@ -951,6 +1196,7 @@ int kpilqr_iterate_streamed(kpilqr_ctx *c, const kpilqr_stream_io *io, int pd_ch
         if (io->delta_J) KP_HIP(c, hipMemcpyAsync(io->delta_J + o, v.delta_J, cnt * 8, hipMemcpyDeviceToHost, s));
         if (io->status) KP_HIP(c, hipMemcpyAsync(io->status + o, v.status, cnt * 4, hipMemcpyDeviceToHost, s));
     }
+    c->kpc_valid = vflags_valid; c->kpc_touched = vflags_touched;       // what every chunk did to its slice of kpc
     return KPILQR_OK;
 }
 
@@ -987,6 +1233,7 @@ int kpilqr_set_AB(kpilqr_ctx *c, const double *A, const double *B)
 {
     if (!c) return KPILQR_ERR_ARG;
     KP_ENTER(c);
+    if (c->fused) { const int rcr = ensure_records(c); if (rcr) return rcr; }
     const size_t BT = (size_t)c->d.batch * c->d.T, n = c->n, m = c->d.m;
     const size_t szA = BT * n * n * 8, szB = BT * n * m * 8;
     int rc = ensure_stage(c, szA + szB);
@@ -1003,6 +1250,7 @@ int kpilqr_get_AB(kpilqr_ctx *c, double *A, double *B)
 {
     if (!c) return KPILQR_ERR_ARG;
     KP_ENTER(c);
+    if (c->fused) { const int rcr = ensure_records(c); if (rcr) return rcr; }
     const size_t BT = (size_t)c->d.batch * c->d.T, n = c->n, m = c->d.m;
     const size_t szA = BT * n * n * 8, szB = BT * n * m * 8;
     int rc = ensure_stage(c, szA + szB);
@@ -1018,6 +1266,7 @@ int kpilqr_set_cost_derivs(kpilqr_ctx *c, const double *l_x, const double *l_xx,
 {
     if (!c) return KPILQR_ERR_ARG;
     KP_ENTER(c);
+    if (c->fused) { const int rcr = ensure_records(c); if (rcr) return rcr; }
     const size_t BT = (size_t)c->d.batch * c->d.T, n = c->n, m = c->d.m;
     const size_t s1 = BT * n * 8, s2 = BT * n * n * 8, s3 = BT * m * 8, s4 = BT * m * m * 8;
     int rc = ensure_stage(c, s1 + s2 + s3 + s4);
@@ -1037,6 +1286,7 @@ int kpilqr_get_cost_derivs(kpilqr_ctx *c, double *l_x, double *l_xx, double *l_u
 {
     if (!c) return KPILQR_ERR_ARG;
     KP_ENTER(c);
+    if (c->fused) { const int rcr = ensure_records(c); if (rcr) return rcr; }
     const size_t BT = (size_t)c->d.batch * c->d.T, n = c->n, m = c->d.m;
     const size_t s1 = BT * n * 8, s2 = BT * n * n * 8, s3 = BT * m * 8, s4 = BT * m * m * 8;
     int rc = ensure_stage(c, s1 + s2 + s3 + s4);

@@ -204,16 +204,36 @@ class Engine:
             tnf[:] = 0
         return dict(slab=slab, njobs=nj, nnom=nnom, traj_job_first=tjf, traj_nom_first=tnf, layout=lay)
 
+    def fd_kp_slab(self, xplus, xminus, mode, pinned=True):
+        """Key-point ordered payload (kpilqr_fd_kp_layout): xplus / xminus [entries][3][n], mode [entries] (bit k: kind k is
+        one-sided), packed into ONE slab -- pinned (the asynchronous boundary) or, for a one-off upload of a large resident
+        payload, pageable.  Returns a dict for upload_fd_kp / iterate_streamed(fd_kp=...)."""
+        ent = int(np.shape(mode)[0])
+        lay = _lib.FdkpLayout()
+        self._ck(self._L.kpilqr_fd_kp_layout(self._h, ent, C.byref(lay)))
+        slab = self.pinned(lay.bytes, np.uint8) if pinned else np.zeros(max(lay.bytes, 1), np.uint8)
+        for off, a, dt in ((lay.xplus, xplus, np.float64), (lay.xminus, xminus, np.float64), (lay.mode, mode, np.uint8)):
+            a = np.ascontiguousarray(a, dt)
+            if dt is np.float64 and a.shape != (ent, 3, self.n):
+                raise ValueError(f"expected shape {(ent, 3, self.n)}, got {a.shape}")
+            slab[off:off + a.nbytes] = a.view(np.uint8).reshape(-1)
+        return dict(slab=slab, entries=ent, layout=lay)
+
+    def upload_fd_kp(self, s, eps=1e-6):
+        self._ck(self._L.kpilqr_upload_fd_kp(self._h, _ptr(s["slab"]), s["entries"], float(eps)))
+
     def upload_fd_slab(self, s, eps=1e-6):
         self._ck(self._L.kpilqr_upload_fd_slab(self._h, _ptr(s["slab"]), s["njobs"], s["nnom"], float(eps)))
 
-    def iterate_streamed(self, fd=None, eps=1e-6, r=None, r_x=None, r_u=None, u_nom=None, lam=None, K=None, k=None,
+    def iterate_streamed(self, fd=None, fd_kp=None, eps=1e-6, r=None, r_x=None, r_u=None, u_nom=None, lam=None, K=None, k=None,
                          cost_pred=None, delta_J=None, status=None, pd_stride=100, nchunks=0):
         """kpilqr_iterate_streamed: every array must come from self.pinned(); asynchronous (sync() to wait)."""
         io = _lib.StreamIO()
         if fd is not None:
             io.fd_slab = fd["slab"].ctypes.data; io.njobs = fd["njobs"]; io.nnom = fd["nnom"]
             io.traj_job_first = fd["traj_job_first"].ctypes.data; io.traj_nom_first = fd["traj_nom_first"].ctypes.data
+        if fd_kp is not None:
+            io.fd_kp_slab = fd_kp["slab"].ctypes.data; io.entries = fd_kp["entries"]
         io.eps = float(eps)
         for name, a in (("r", r), ("r_x", r_x), ("r_u", r_u), ("u_nom", u_nom), ("lam", lam), ("K", K), ("k", k),
                         ("cost_pred", cost_pred), ("delta_J", delta_J), ("status", status)):

@@ -339,12 +339,45 @@ def tile_problem(p, reps):
     return q
 
 
-def upload(engine, p, keypoints=True):
-    """Push a problem dict into an Engine (everything the GPU path needs to run one iteration)."""
+def kp_ordered_payload(p):
+    """The FD job lists of a problem re-laid-out BY its key-point lists -- the payload of kpilqr_upload_fd_kp
+    (include/kpilqr.h): xplus / xminus [entries][3][n] and mode [entries], entry = position in the per-DoF CSR, kind 0 / 1 / 2
+    = position / velocity / control column of the entry's DoF.  A one-sided job carries the nominal next state in the slot
+    of the side that was not perturbed, and its bit in the entry's mode byte.  Jobs at steps that are not key-points of
+    their DoF have no slot and are dropped; slots no job fills stay zero."""
+    from .engine import rows_to_dof_csr
+    dof, n, m, T, B = p["dof"], p["n"], p["m"], p["T"], p["batch"]
+    offs, times = rows_to_dof_csr(p["kp_rows"], dof, T)
+    E = int(offs[-1])
+    entry_of = np.full((B * dof, T), -1, np.int64)
+    lists = np.repeat(np.arange(B * dof), np.diff(offs))
+    entry_of[lists, times] = np.arange(E)
+    col = p["job_col"].astype(np.int64)
+    kind = np.where(col < dof, 0, np.where(col < n, 1, 2))
+    d = np.where(kind == 0, col, np.where(kind == 1, col - dof, col - n))
+    e = entry_of[p["job_b"].astype(np.int64) * dof + d, p["job_t"]]
+    ok = e >= 0
+    e, kind, jm = e[ok], kind[ok], p["job_mode"][ok]
+    xp = np.zeros((E, 3, n)); xm = np.zeros((E, 3, n)); mode = np.zeros(E, np.uint8)
+    xnom_rows = p["xnom"][p["job_nom"][ok]] if len(p["xnom"]) else np.zeros((len(e), n))
+    xp[e, kind] = np.where((jm == 2)[:, None], xnom_rows, p["xplus"][ok])
+    xm[e, kind] = np.where((jm == 1)[:, None], xnom_rows, p["xminus"][ok])
+    np.bitwise_or.at(mode, e, ((jm != 0).astype(np.uint8) << kind.astype(np.uint8)))
+    return xp, xm, mode
+
+
+def upload(engine, p, keypoints=True, kp_ordered=False):
+    """Push a problem dict into an Engine (everything the GPU path needs to run one iteration).  kp_ordered: the FD
+    payload goes up key-point ordered (kpilqr_upload_fd_kp) instead of as job lists."""
     if keypoints:
         engine.set_keypoints_rows(p["kp_rows"])
-    engine.upload_fd(p["job_b"], p["job_t"], p["job_col"], p["job_mode"], p["xplus"], p["xminus"],
-                     job_nom=p["job_nom"], xnom=p["xnom"], eps=p["eps"])
+    if kp_ordered:
+        # a large resident payload goes up once from pageable memory (the call waits for it); small ones through a pinned slab
+        big = p["xplus"].nbytes > (256 << 20)
+        engine.upload_fd_kp(engine.fd_kp_slab(*kp_ordered_payload(p), pinned=not big), eps=p["eps"])
+    else:
+        engine.upload_fd(p["job_b"], p["job_t"], p["job_col"], p["job_mode"], p["xplus"], p["xminus"],
+                         job_nom=p["job_nom"], xnom=p["xnom"], eps=p["eps"])
     # a task without control residuals never uploads r_u (the context's buffer starts zeroed): include/kpilqr.h
     engine.upload_residuals(p["r"], p["r_x"], p["r_u"] if np.any(p["r_u"]) else None, p["w_run"], p["w_term"])
     engine.upload_nominal(p["u_nom"], p["ctrl_lim"])
