@@ -171,19 +171,22 @@ int  kpilqr_upload_fd_slab(kpilqr_ctx *ctx, const void *slab, int njobs, int nno
  *     kind 0: qpos_d perturbed  -> column d       of A      (Differentiator.cpp:328-428)
  *     kind 1: qvel_d perturbed  -> column d + dof of A      (:226-325)
  *     kind 2: ctrl_d perturbed  -> column d       of B      (:81-223; only d < num_ctrl, other kind-2 slots are ignored)
- *   xplus  [entries][3][n]   next state after the + perturbation  (a backward-only difference: the unperturbed next state)
- *   xminus [entries][3][n]   next state after the - perturbation  (a forward-only difference:  the unperturbed next state)
- *   mode   [entries]         bit k set: kind k is one-sided -> (xplus - xminus) / eps, else (xplus - xminus) / (2 eps)
- * so the host FD loop writes every perturbed next state straight to its slot, nothing carries indices, and the library
- * never walks or sorts anything.  On a KPILQR_FLAG_FUSED context with one wavefront per trajectory (batch > #SIMDs / 2) there
+ * One RECORD per entry, `entry_stride` = (6n + 2) * 8 bytes, records back to back in CSR order:
+ *   double xplus [3][n]      next state after the + perturbation  (a backward-only difference: the unperturbed next state)
+ *   double xminus[3][n]      next state after the - perturbation  (a forward-only difference:  the unperturbed next state)
+ *   int32  mode              bit k set: kind k is one-sided -> (xplus - xminus) / eps, else (xplus - xminus) / (2 eps)
+ *   int32  pad[3]
+ * so the host FD loop writes every perturbed next state straight to its slot, nothing carries indices, the library never
+ * walks or sorts anything, and a trajectory's (or a chunk of trajectories') payload is one contiguous range.  On a KPILQR_FLAG_FUSED context with one wavefront per trajectory (batch > #SIMDs / 2) there
  * is then NO differencing kernel either: the backward sweep reads the slots of a key-point when it reaches it, forms the
  * column (the arithmetic of Differentiator.cpp:166-222,441-457, bit for bit what kpilqr_fd_difference gives) and keeps it
  * for the forward sweep.  Every other context accepts the payload too (it is differenced by a streaming kernel first).
  * The payload refers to the CURRENT key-points: upload it after them; new key-points invalidate it.  `entries` must be
  * kp_offsets[batch*dof].  One hipMemcpyAsync; with a pinned slab the call does not wait. */
 typedef struct {
-    size_t xplus, xminus, mode;                 /* byte offsets of the arrays inside the slab */
-    size_t bytes;
+    size_t entry_stride;                        /* bytes of one entry record: (6n + 2) * 8                       */
+    size_t xplus, xminus, mode;                 /* byte offsets inside a record: 0, 3n * 8, 6n * 8 (an int32)    */
+    size_t bytes;                               /* entries * entry_stride                                        */
 } kpilqr_fdkp_layout;
 int  kpilqr_fd_kp_layout(kpilqr_ctx *ctx, int entries, kpilqr_fdkp_layout *out);
 int  kpilqr_upload_fd_kp(kpilqr_ctx *ctx, const void *slab, int entries, double eps);

@@ -45,10 +45,10 @@ def draw_case(rng, case):
 
 def run_case(c, worst=None):
     """Runs one case on the GPU and against the oracle; returns the kernel-variant string.  Raises AssertionError."""
-    saved = {k: os.environ.get(k) for k in ENV_KEYS}
+    saved = {key: os.environ.get(key) for key in ENV_KEYS}
     try:
-        for k in ENV_KEYS:
-            os.environ.pop(k, None)
+        for key in ENV_KEYS:
+            os.environ.pop(key, None)
         if c["form"] == "one":
             os.environ["KPILQR_FUSED_WAVES"] = "1"; os.environ["KPILQR_FUSED_FWD_WAVES"] = "1"
         os.environ["KPILQR_TILED_A4"] = c["a4"]
@@ -73,9 +73,9 @@ def run_case(c, worst=None):
             cost, U = e.forward_linear(orc.alphas(6), want_U=True)
             var = e.backward_variant + "/" + e.forward_variant + ("/" + c["form"] if "fused" in e.backward_variant else "")
     finally:
-        for k, v in saved.items():
-            if v is None: os.environ.pop(k, None)
-            else: os.environ[k] = v
+        for key, val in saved.items():
+            if val is None: os.environ.pop(key, None)
+            else: os.environ[key] = val
     for b in range(batch):
         o = pipeline.run_trajectory(p, b, lam=lam, pd_stride=pd, want_U=True)
         assert st[b] == o["status"], (c["case"], c["task"], T, st[b], o["status"])

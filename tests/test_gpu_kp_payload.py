@@ -128,7 +128,7 @@ def test_fused_context_materialises_on_demand():
         synth.upload(e, q, kp_ordered=True)
         e.iterate(q["lam"], 100, orc.alphas(6)); e.sync()
         used = free0 - torch.cuda.mem_get_info()[0]
-        assert used < 420e6, used                                    # K, k, residuals, Jacobians, payload, kpc: ~330 MB
+        assert used < 800e6, used                                    # K, k, residuals + Jacobians (355 MB), payload, kpc: ~735 MB
         e.get_AB()
         assert free0 - torch.cuda.mem_get_info()[0] > used + 600e6   # now the records exist
 

@@ -3,6 +3,6 @@
 for v in "$@"; do
   if [ "$v" = default ]; then unset KPILQR_LIB; else export KPILQR_LIB=$PWD/trajoptkp_amd/lib/variants/$v/libkpilqr.so; fi
   python tools/ab_check.py 2>&1 | tail -1
-  python bench.py --no-secondary --no-cpu-baseline --steps 10 --warmup 2 2>/dev/null | python -c "
+  python bench.py --workload-cache /tmp/kpwl --no-secondary --no-cpu-baseline --steps 10 --warmup 2 2>/dev/null | python -c "
 import json,sys; d=json.loads(sys.stdin.read().strip().splitlines()[-1]); print('$v', round(d['value']), d['stage_ms'], d['parity_check']['max_rel_err_K'])"
 done

@@ -41,7 +41,7 @@ class FdLayout(C.Structure):
 
 
 class FdkpLayout(C.Structure):
-    _fields_ = [(k, C.c_size_t) for k in ("xplus", "xminus", "mode", "bytes")]
+    _fields_ = [(k, C.c_size_t) for k in ("entry_stride", "xplus", "xminus", "mode", "bytes")]
 
 
 class StreamIO(C.Structure):

@@ -97,11 +97,10 @@ struct Ctx {
     int *kp_traj_first_host = nullptr;                // [batch+1] first CSR entry of every trajectory (host copy), or null
     // FD payload resident on the device: 0 none, 1 job lists (kpilqr_upload_fd / _slab), 2 key-point ordered (kpilqr_upload_fd_kp)
     int fd_kind = 0;
-    // key-point ordered payload: x+ [entry][3][n], x- [entry][3][n], mode [entry][3] in ONE device slab
+    // key-point ordered payload: one record per CSR entry, [x+ (3n) | x- (3n) | int32 mode, pad] = fdk_stride() bytes
     char *fdk_dev = nullptr;
     size_t fdk_dev_cap = 0;
-    double *kx_plus = nullptr, *kx_minus = nullptr;
-    unsigned char *k_mode = nullptr;
+    size_t fdk_stride() const { return (size_t)(6 * n + 2) * 8; }
     int fdk_entries = 0;         // entries of the resident key-point ordered payload (a view: of its trajectories)
     int fdk_first = 0;           // first entry of a view's trajectories (0 for the context itself)
 
@@ -162,6 +161,7 @@ struct Ctx {
         int tiled_nt_min = 0;      // KPILQR_TILED_NT_MIN: run the tiled kernels with more tiles than needed
         int tiled_a6 = -1;         // KPILQR_TILED_A6: -1 auto, 0 | 1
         int tiled_a4 = -1;         // KPILQR_TILED_A4: -1 auto, 0 | 1 (a4 inside the tiled sweeps)
+        int fused_uni = -1;        // KPILQR_FUSED_UNI: 0 never take the uniform-key-point form of the one-wave backward sweep (diagnostic)
         int fused_raw = -1;        // KPILQR_FUSED_RAW: 0 never difference inside the backward sweep (diagnostic), else auto
         int pipe_copy = -1;        // KPILQR_PIPE_COPY: chunk pipeline copies by kernel: bit 0 uploads, bit 1 downloads (-1 auto)
     } tune;

@@ -174,21 +174,24 @@ hipError_t launch_fd_difference_kpc(Ctx *c)
     return hipGetLastError();
 }
 
-// key-point ordered payload -> kpc: slot s = entry * 3 + kind holds x+ / x- rows of n doubles; bit `kind` of the entry's mode
-// byte says one-sided (the host has put the nominal next state into the x- or x+ slot: / eps), else central: / (2 eps)
+// key-point ordered payload -> kpc.  One record per CSR entry, [x+ (3n) | x- (3n) | int32 mode, pad]; a lane owns one
+// 16-byte pair of the 3n doubles of an entry; bit `kind` of the entry's mode says one-sided (the host has put the nominal
+// next state into the x- or x+ slot: / eps), else central: / (2 eps)
 __global__ void __launch_bounds__(256)
-k_fd_kp_difference(int n, long long npairs_total, unsigned long long np_magic, const double *__restrict__ xplus,
-                   const double *__restrict__ xminus, const unsigned char *__restrict__ mode, double eps, double *__restrict__ kpc)
+k_fd_kp_difference(int n, long long npairs_total, unsigned long long magic, const double2 *__restrict__ rec, double eps,
+                   double2 *__restrict__ kpc)
 {
-    const double2 *xp2 = (const double2 *)xplus, *xm2 = (const double2 *)xminus;
-    double2 *out = (double2 *)kpc;
+    const int pe = 3 * (n >> 1);                     // pairs per entry
+    const int s2 = 3 * n + 1;                        // record stride in double2
     const long long stride = (long long)gridDim.x * blockDim.x;
     for (long long w = (long long)blockIdx.x * blockDim.x + threadIdx.x; w < npairs_total; w += stride) {
-        const long long slot = np_magic ? (long long)__umul64hi((unsigned long long)w, np_magic) : w;
-        const long long e = slot / 3;
-        const double2 a = xp2[w], b = xm2[w];
-        const double den = ((mode[e] >> (int)(slot - 3 * e)) & 1) ? eps : 2 * eps;
-        out[w] = make_double2((a.x - b.x) / den, (a.y - b.y) / den);
+        const long long e = magic ? (long long)__umul64hi((unsigned long long)w, magic) : w;      // w / pe
+        const int p = (int)(w - e * pe);
+        const double2 *r = rec + e * s2;
+        const double2 a = r[p], b = r[pe + p];
+        const int mode = ((const int *)(r + 2 * pe))[0];
+        const double den = ((mode >> (p / (n >> 1))) & 1) ? eps : 2 * eps;
+        kpc[w] = make_double2((a.x - b.x) / den, (a.y - b.y) / den);
     }
 }
 
@@ -196,15 +199,15 @@ hipError_t launch_fd_kp_difference(Ctx *c)
 {
     // a view of a trajectory range (kpilqr_iterate_streamed) differences its own entries: [fdk_first, fdk_first + fdk_entries)
     if (c->fdk_entries == 0) return hipSuccess;
-    const int np = c->n >> 1;
-    const long long npairs = (long long)c->fdk_entries * 3 * np;
-    const unsigned long long magic = np > 1 ? ~0ULL / (unsigned)np + 1ULL : 0ULL;
+    const int pe = 3 * (c->n >> 1);
+    const long long npairs = (long long)c->fdk_entries * pe;
+    const unsigned long long magic = pe > 1 ? ~0ULL / (unsigned)pe + 1ULL : 0ULL;
     const long long want = (npairs + 256LL * 4 - 1) / (256LL * 4);
     const long long cap = (long long)(c->n_simd / 4) * 128;
     const int blocks = (int)(want < cap ? (want < 1 ? 1 : want) : cap);
-    const size_t o = (size_t)c->fdk_first * 3;
-    hipLaunchKernelGGL(k_fd_kp_difference, dim3(blocks), dim3(256), 0, c->stream, c->n, npairs, magic, c->kx_plus + o * c->n,
-                       c->kx_minus + o * c->n, c->k_mode + c->fdk_first, c->eps, c->kpc + o * c->n);
+    hipLaunchKernelGGL(k_fd_kp_difference, dim3(blocks), dim3(256), 0, c->stream, c->n, npairs, magic,
+                       (const double2 *)(c->fdk_dev + (size_t)c->fdk_first * c->fdk_stride()), c->eps,
+                       (double2 *)(c->kpc + (size_t)c->fdk_first * 3 * c->n));
     return hipGetLastError();
 }
 

@@ -43,6 +43,10 @@ typedef unsigned long long u64;
 #define KP_NS 1
 #endif
 #define BIGT 0x3fffffff
+// An offset no trajectory's slice of kpc reaches (fused_supported keeps a slice below 1 GB): a lane / register / entry with
+// nothing to load adds it instead of selecting -- BIGOFF and BIGOFF + BIGOFF are both out of range of the descriptor and do
+// not wrap, so the load returns 0 (the store is dropped) without a compare-and-select per access.
+#define BIGOFF 0x40000000
 
 template <int NC>
 __device__ __forceinline__ d4 PS(const d4 &Y, const d4 &X, d4 acc)
@@ -104,9 +108,10 @@ struct FusedArgs {
     const double *r, *r_x, *r_u, *w_run, *w_term;  // [b][T+1][nr], [..][nr][n], [..][nr][m], [nr], [nr]
     int dof, nr;
     double *kpc;                                   // key-point column store [entry][3][n] (read; written by the raw backward sweep)
-    const double *xp, *xm;                         // key-point ordered FD payload [entry][3][n] (raw backward sweep only)
-    const unsigned char *mode;                     // [entry]: bit k set = kind k is a one-sided difference (/ eps, not / 2 eps)
-    double eps, rinv_eps, rinv_2eps;               // the host's correctly rounded 1/eps, 1/(2 eps): with them fdiv IS the IEEE quotient
+    const char *fdk;                               // key-point ordered FD payload (raw backward sweep only): one record per entry,
+                                                   // [x+ (3n) | x- (3n) | int32 mode: bit k = kind k is one-sided | pad] = (6n + 2) * 8 bytes
+    double eps2, rinv_2eps;                        // 2 eps and the host's correctly rounded 1 / (2 eps): with it fdiv IS the IEEE
+                                                   // quotient (eps and 1/eps are exact halves / doubles of them)
 };
 
 // ---- column tracker: lane (c,q) interpolates rows 4r+q of column c of A and of B ------------------------
@@ -123,20 +128,74 @@ __device__ __forceinline__ void col_offsets(ColOffs &co, int n, int m, int dof, 
 #pragma unroll
     for (int r = 0; r < 4; r++) {
         const int row = 4 * r + q;
-        co.a[r] = (row < n && c < n) ? 8 * ((c < dof ? 0 : n) + row) : OOBF;
-        co.b[r] = (row < n && c < m) ? 8 * (2 * n + row) : OOBF;
+        co.a[r] = (row < n && c < n) ? 8 * ((c < dof ? 0 : n) + row) : BIGOFF;
+        co.b[r] = (row < n && c < m) ? 8 * (2 * n + row) : BIGOFF;
     }
 }
 
 __device__ __forceinline__ void load_col(__amdgpu_buffer_rsrc_t rT, const ColOffs &o, int tk, int T, int strideB, double *col)
 {
-    const bool ok = (unsigned)tk < (unsigned)T;
-    const int base = ok ? tk * strideB : 0;
+    const int base = ((unsigned)tk < (unsigned)T) ? tk * strideB : BIGOFF;
 #pragma unroll
     for (int r = 0; r < 4; r++) {
-        col[r] = fbld(rT, (ok && o.a[r] != OOBF) ? base + o.a[r] : OOBF);
-        col[4 + r] = fbld(rT, (ok && o.b[r] != OOBF) ? base + o.b[r] : OOBF);
+        col[r] = fbld(rT, base + o.a[r]);
+        col[4 + r] = fbld(rT, base + o.b[r]);
     }
+}
+
+// The same for a lane whose four registers are rows q, 4+q, 8+q, 12+q of ONE column (the column layout of the backward
+// sweep): one offset per column and lane, the rows in the loads' immediate field.  Registers 4r+3 < N are valid in every
+// lane that holds the column at all; the one partial register (N % 4 rows) has a per-lane offset of its own; registers
+// beyond the column are zero without a load.
+struct ColOffsN { int a, al, b, bl; };
+template <int N>
+__device__ __forceinline__ void col_offsets_n(ColOffsN &co, int m, int dof, int c, int q)
+{
+    constexpr int NF = N / 4;
+    co.a = (c < N) ? 8 * ((c < dof ? 0 : N) + q) : BIGOFF;
+    co.b = (c < m) ? 8 * (2 * N + q) : BIGOFF;
+    co.al = (c < N && 4 * NF + q < N) ? 8 * ((c < dof ? 0 : N) + 4 * NF + q) : BIGOFF;
+    co.bl = (c < m && 4 * NF + q < N) ? 8 * (2 * N + 4 * NF + q) : BIGOFF;
+}
+template <int N>
+__device__ __forceinline__ void load_col_n(__amdgpu_buffer_rsrc_t rT, const ColOffsN &o, int base, double *col)
+{
+    constexpr int NF = N / 4;
+    const int va = base + o.a, vb = base + o.b;
+#pragma unroll
+    for (int r = 0; r < 4; r++) {
+        col[r] = r < NF ? fbld(rT, va + 32 * r) : (r == NF && (N & 3)) ? fbld(rT, base + o.al) : 0.0;
+        col[4 + r] = r < NF ? fbld(rT, vb + 32 * r) : (r == NF && (N & 3)) ? fbld(rT, base + o.bl) : 0.0;
+    }
+}
+template <int N>
+__device__ __forceinline__ void store_col_n(__amdgpu_buffer_rsrc_t rT, const ColOffsN &o, int base, const double *col)
+{
+    constexpr int NF = N / 4;
+    const int va = base + o.a, vb = base + o.b;
+#pragma unroll
+    for (int r = 0; r < 4; r++) {
+        if (r < NF) {
+            __builtin_amdgcn_raw_buffer_store_b64(__builtin_bit_cast(u32x2f, col[r]), rT, va + 32 * r, 0, 0);
+            __builtin_amdgcn_raw_buffer_store_b64(__builtin_bit_cast(u32x2f, col[4 + r]), rT, vb + 32 * r, 0, 0);
+        } else if (r == NF && (N & 3)) {
+            __builtin_amdgcn_raw_buffer_store_b64(__builtin_bit_cast(u32x2f, col[r]), rT, base + o.al, 0, 0);
+            __builtin_amdgcn_raw_buffer_store_b64(__builtin_bit_cast(u32x2f, col[4 + r]), rT, base + o.bl, 0, 0);
+        }
+    }
+}
+
+// Every kernel of this file takes (RecLayout L, FusedArgs F, ...) first, so F sits at a fixed place of the kernel-argument
+// segment.  Scalars that only a segment CROSSING needs (descriptors of the key-point stores, the key-point times, eps) are
+// re-read from there inside the crossing -- scalar loads, every few steps -- instead of staying live across the hot loop,
+// where the register allocator would park them in VGPR lanes and pay a v_readlane / v_writelane (a VALU slot each) per use.
+static_assert(sizeof(RecLayout) == 40 && alignof(FusedArgs) == 8, "kernel-argument layout assumed by kernarg_fused()");
+typedef const __attribute__((address_space(4))) FusedArgs *KArgF;
+__device__ __forceinline__ KArgF kernarg_fused()
+{
+    const __attribute__((address_space(4))) char *ka = (const __attribute__((address_space(4))) char *)__builtin_amdgcn_kernarg_segment_ptr();
+    asm volatile("" : "+s"(ka));                 // opaque: the loads below cannot be hoisted out of the loop that holds the call
+    return (KArgF)(ka + 40);
 }
 
 // LDS map of the backward kernel (doubles) -- as riccati_mfma.hip
@@ -168,7 +227,14 @@ __device__ __forceinline__ void lds_store4(double *t, int lane, const d4 &v);
 // differences every column when it becomes a segment start -- (x+ - x-) / (2 eps), or / eps for a one-sided job, with
 // the host's correctly rounded reciprocals, i.e. the bytes k_fd_kp_difference would write -- and stores it to kpc, which
 // the forward sweep then reads.
-template <int N, int M, bool PC, bool RU0 = false, bool SIDE = false, bool RAW = false>
+// UNI (one wave per trajectory only): every DoF of the trajectory has the SAME key-point list (set_interval -- the reference's
+// default -- and whatever else comes out uniform; the device flag of k_kp_uniform says so).  Segment start, end and position
+// are then wave-uniform scalars, the sweep is a loop over SEGMENTS with the crossing in straight-line code at its top and the
+// first step of the segment peeled behind it, and the loads of a crossing have a whole Riccati chain to land before anything
+// waits for them.  (In the general form the crossing sits in a per-lane branch, behind which the compiler has to wait for
+// every memory operation in flight at the next load-dependent instruction: ~1 us of HBM latency per crossing, 7.5 against
+// 4.5 ms per sweep with a key-point at every step.)
+template <int N, int M, bool PC, bool RU0 = false, bool SIDE = false, bool RAW = false, bool UNI = false>
 __device__ __forceinline__ void backward_fused_body(double *sh, const double *pcbuf, int *sflag, RecLayout L, FusedArgs F, int T,
                 const double *__restrict__ lambda, int pd_stride, double *__restrict__ Kout, double *__restrict__ kout,
                 double *__restrict__ delta_J, int *__restrict__ status)
@@ -183,8 +249,8 @@ __device__ __forceinline__ void backward_fused_body(double *sh, const double *pc
     const int nr = F.nr, ncr = (nr + 3) >> 2;
     constexpr int strideB = 3 * N * 8;                            // bytes of one key-point entry: three columns
 
-    ColOffs co;
-    col_offsets(co, n, m, F.dof, c, q);
+    ColOffsN co;
+    col_offsets_n<N>(co, m, F.dof, c, q);
     double w2run[4], w2term[4], lam2d[4];
     int oRx[4], oR1[4], oRu[4], oKst[4], okst[4];
 #pragma unroll
@@ -227,48 +293,85 @@ __device__ __forceinline__ void backward_fused_body(double *sh, const double *pc
     const int hi = has ? F.kp_offsets[(size_t)b * F.dof + kd + 1] : 0;
     int idx = hi - 1;
     int s = has ? F.kp_times[idx] : -1;                       // == T-1 for canonical key-points
-    int nb = (has && idx - 1 >= lo) ? F.kp_times[idx - 1] : -1;
-    int nb2 = (has && idx - 2 >= lo) ? F.kp_times[idx - 2] : -1;
+    int nb = (has && idx - 1 >= lo) ? F.kp_times[idx - 1] : -1;      // the time of the next segment start, one crossing ahead
     double sv[8], av[8], pv[8];
     // RAW: the prefetched column of the next segment start waits as x+ (in pv) and x- (pm) until the crossing differences it
     double pm[8];
     int pmode = 0;
-    __amdgpu_buffer_rsrc_t rP = rT, rM = rT, rMo = rT;
+    // the raw payload: ONE descriptor over the trajectory's records; x- sits 3n doubles behind x+ and the mode word behind both,
+    // so they are the same per-lane offsets plus an immediate
+    constexpr int strideR = (6 * N + 2) * 8, offM = 3 * N * 8, offMode = 6 * N * 8;
+    __amdgpu_buffer_rsrc_t rP = rT;
     const int bitA = (c < F.dof) ? 1 : 2;                         // mode bit of this lane's A column (position / velocity job)
+    auto ebase = [&](int e_rel) { return ((unsigned)e_rel < (unsigned)NE) ? e_rel * strideB : BIGOFF; };
     auto load_raw = [&](int e_rel, double *xp_, double *xm_, int &mo) {
-        load_col(rP, co, e_rel, NE, strideB, xp_);
-        load_col(rM, co, e_rel, NE, strideB, xm_);
-        mo = __builtin_amdgcn_raw_buffer_load_b8(rMo, ((unsigned)e_rel < (unsigned)NE && c < n) ? e_rel : OOBF, 0, 0);
+        const int base = ((unsigned)e_rel < (unsigned)NE) ? e_rel * strideR : BIGOFF;
+        load_col_n<N>(rP, co, base, xp_);
+        load_col_n<N>(rP, co, base + offM, xm_);
+        mo = __builtin_amdgcn_raw_buffer_load_b32(rP, base + ((c < n) ? offMode : BIGOFF), 0, 0);
     };
+    double eps2 = F.eps2, rinv2 = F.rinv_2eps;
     auto difference = [&](double *xp_, const double *xm_, int mo, int e_rel) {      // xp_ <- the differenced column, also to kpc
-        const bool oa = (mo & bitA) != 0, ob = (mo & 4) != 0;
-        const double dA = oa ? F.eps : 2 * F.eps, rA = oa ? F.rinv_eps : F.rinv_2eps;
-        const double dB = ob ? F.eps : 2 * F.eps, rB = ob ? F.rinv_eps : F.rinv_2eps;
-        const bool ok = (unsigned)e_rel < (unsigned)NE;
-        const int base = ok ? e_rel * strideB : 0;
+        // central differences are the rule (a control at its limit is the exception, Differentiator.cpp:94-143): one
+        // wave-uniform test keeps the per-lane denominator selects off the usual path
+        if (__builtin_amdgcn_ballot_w64(mo != 0) == 0) {
 #pragma unroll
-        for (int i = 0; i < 4; i++) {
-            xp_[i] = fdiv(xp_[i] - xm_[i], dA, rA);
-            xp_[4 + i] = fdiv(xp_[4 + i] - xm_[4 + i], dB, rB);
-            __builtin_amdgcn_raw_buffer_store_b64(__builtin_bit_cast(u32x2f, xp_[i]), rT, (ok && co.a[i] != OOBF) ? base + co.a[i] : OOBF, 0, 0);
-            __builtin_amdgcn_raw_buffer_store_b64(__builtin_bit_cast(u32x2f, xp_[4 + i]), rT, (ok && co.b[i] != OOBF) ? base + co.b[i] : OOBF, 0, 0);
+            for (int i = 0; i < 8; i++) xp_[i] = fdiv(xp_[i] - xm_[i], eps2, rinv2);
+        } else {
+            const bool oa = (mo & bitA) != 0, ob = (mo & 4) != 0;
+            const double dA = oa ? 0.5 * eps2 : eps2, rA = oa ? 2.0 * rinv2 : rinv2;     // exact halves / doubles
+            const double dB = ob ? 0.5 * eps2 : eps2, rB = ob ? 2.0 * rinv2 : rinv2;
+#pragma unroll
+            for (int i = 0; i < 4; i++) {
+                xp_[i] = fdiv(xp_[i] - xm_[i], dA, rA);
+                xp_[4 + i] = fdiv(xp_[4 + i] - xm_[4 + i], dB, rB);
+            }
         }
+        store_col_n<N>(rT, co, ebase(e_rel), xp_);
     };
     (void)pm; (void)pmode; (void)bitA;
     ResTiles cur;
-    if constexpr (!PC) {
+    // UNI: lane offsets of the lane's own DoF list (kd * KpU entries into the slice), the position in the soffset operand
+    const int KpU = F.kp_offsets[(size_t)b * F.dof + 1] - E0;
+    ColOffsN cu = co, cr = co;                                 // kpc / raw payload
+    auto shift = [&](int v, int by) { return v == BIGOFF ? BIGOFF : v + by; };
+    if constexpr (UNI) {
+        cu.a = shift(co.a, kd * KpU * strideB); cu.al = shift(co.al, kd * KpU * strideB);
+        cu.b = shift(co.b, kd * KpU * strideB); cu.bl = shift(co.bl, kd * KpU * strideB);
+        cr.a = shift(co.a, kd * KpU * strideR); cr.al = shift(co.al, kd * KpU * strideR);
+        cr.b = shift(co.b, kd * KpU * strideR); cr.bl = shift(co.bl, kd * KpU * strideR);
+    }
+    int up = KpU - 1;                                          // UNI: position (in every list) of the current segment's start
+    int us = T, unb = T - 1, unb_v = T - 1;                    // UNI: its time, and the time of the next start (uniform; unb_v: as loaded)
+    (void)up; (void)us; (void)unb; (void)unb_v; (void)cu; (void)cr;
+    if constexpr (!PC && UNI) {
+        // both columns of the first crossing are the last key-point's (slope 0 over the virtual segment [T-1, T])
+        if constexpr (RAW) {
+            rP = frsrc(F.fdk + (size_t)E0 * strideR, NE * strideR);
+            load_col_n<N>(rP, cr, up * strideR, pv);
+            load_col_n<N>(rP, cr, up * strideR + offM, pm);
+            pmode = __builtin_amdgcn_raw_buffer_load_b32(rP, up * strideR + kd * KpU * strideR + ((c < n) ? offMode : BIGOFF), 0, 0);
+#pragma unroll
+            for (int i = 0; i < 8; i++) sv[i] = 0.0;
+        } else {
+            load_col_n<N>(rT, cu, up * strideB, pv);
+#pragma unroll
+            for (int i = 0; i < 8; i++) sv[i] = pv[i];
+        }
+#pragma unroll
+        for (int i = 0; i < 8; i++) av[i] = 0.0;
+        load_res(T - 1, cur);
+    } else if constexpr (!PC) {
         const int e_s = has ? idx - E0 : -1, e_nb = (has && idx - 1 >= lo) ? idx - 1 - E0 : -1;
         if constexpr (RAW) {
-            rP = frsrc(F.xp + (size_t)E0 * 3 * n, NE * strideB);
-            rM = frsrc(F.xm + (size_t)E0 * 3 * n, NE * strideB);
-            rMo = frsrc(F.mode + E0, NE);
+            rP = frsrc(F.fdk + (size_t)E0 * strideR, NE * strideR);
             int mo0;
             load_raw(e_s, sv, pm, mo0);
             difference(sv, pm, mo0, e_s);
             load_raw(e_nb, pv, pm, pmode);
         } else {
-            load_col(rT, co, e_s, NE, strideB, sv);
-            load_col(rT, co, e_nb, NE, strideB, pv);
+            load_col_n<N>(rT, co, ebase(e_s), sv);
+            load_col_n<N>(rT, co, ebase(e_nb), pv);
         }
 #pragma unroll
         for (int i = 0; i < 8; i++) av[i] = 0.0;
@@ -293,7 +396,15 @@ __device__ __forceinline__ void backward_fused_body(double *sh, const double *pc
     Iu.z = (8 + q == c && c < m) ? 1.0 : 0.0; Iu.w = (12 + q == c && c < m) ? 1.0 : 0.0;
     (void)haveX; (void)Iu;
 
-    for (int t = T - 1; t >= 0; t--) {
+    // one step of the sweep; false: the PD check of this step failed (the sweep ends)
+#ifdef KP_CYC
+    unsigned long long cyc_cross = 0, cyc_peel = 0, cyc_inner = 0, cyc_a = 0;
+    const unsigned long long cyc_all0 = __builtin_readcyclecounter();
+#endif
+    auto step = [&](int t) __attribute__((always_inline)) -> bool {
+#ifdef KP_CYC
+        const unsigned long long cyc_s0 = __builtin_readcyclecounter();
+#endif
         d4 Fz, Fu, Lzz, LU;
         const bool term = (t == T - 1);
         if constexpr (PC) {
@@ -316,7 +427,12 @@ __device__ __forceinline__ void backward_fused_body(double *sh, const double *pc
             }
         } else {
         // ---- a4: this step's A and B columns --------------------------------------------------------------
+        if constexpr (!UNI)
         if (t < s) {                                   // per lane: crossed the start of the current segment
+            const KArgF Fk = kernarg_fused();          // crossing-only scalars, from the kernel-argument segment
+            rT = frsrc(Fk->kpc + (size_t)E0 * 3 * n, NE * strideB);
+            if constexpr (RAW) { rP = frsrc(Fk->fdk + (size_t)E0 * strideR, NE * strideR); eps2 = Fk->eps2; rinv2 = Fk->rinv_2eps; }
+            const int *kpt = Fk->kp_times;
             const double den = (double)(s - nb);
             const double rinv = kp_rcp(den);
             if constexpr (RAW) difference(pv, pm, pmode, idx - 1 - E0);      // the prefetched x+ / x- become the column
@@ -328,14 +444,18 @@ __device__ __forceinline__ void backward_fused_body(double *sh, const double *pc
                 // operation in flight -- on EVERY step of the sweep instead of at the crossings
                 asm volatile("v_mov_b64 %0, %1" : "+v"(sv[i]) : "v"(pv[i]));
             }
-            s = nb; idx--;
-            nb = nb2;
-            nb2 = (idx - 2 >= lo) ? F.kp_times[idx - 2] : -1;
+            idx--;
+#ifdef KP_EXP_NOTIMELOAD
+            { const int gap = s - nb; s = nb; nb = (idx - 1 >= lo) ? nb - gap : -1; }
+#else
+            s = nb;
+            nb = (idx - 1 >= lo) ? kpt[idx - 1] : -1;
+#endif
             const int e_nb = (idx - 1 >= lo) ? idx - 1 - E0 : -1;
             if constexpr (RAW) load_raw(e_nb, pv, pm, pmode);
-            else load_col(rT, co, e_nb, NE, strideB, pv);
+            else load_col_n<N>(rT, co, ebase(e_nb), pv);
         }
-        const double dt = (double)(t - s);
+        const double dt = UNI ? (double)(t - us) : (double)(t - s);
         Fz.x = lerp_nc(sv[0], dt, av[0]); Fz.y = lerp_nc(sv[1], dt, av[1]);
         Fz.z = lerp_nc(sv[2], dt, av[2]); Fz.w = lerp_nc(sv[3], dt, av[3]);
         Fu.x = lerp_nc(sv[4], dt, av[4]); Fu.y = lerp_nc(sv[5], dt, av[5]);
@@ -356,6 +476,9 @@ __device__ __forceinline__ void backward_fused_body(double *sh, const double *pc
         __builtin_amdgcn_sched_barrier(0);
         if (t > 0) load_res(t - 1, cur);
         __builtin_amdgcn_sched_barrier(0);
+#ifdef KP_CYC
+        cyc_a += __builtin_readcyclecounter() - cyc_s0;
+#endif
         }
         d4 Luu, Luz;
         Luu.x = bits_and(LU.x, mask_u); Luu.y = bits_and(LU.y, mask_u); Luu.z = bits_and(LU.z, mask_u); Luu.w = bits_and(LU.w, mask_u);
@@ -420,7 +543,7 @@ __device__ __forceinline__ void backward_fused_body(double *sh, const double *pc
                 if (!pos) {
                     fail = t + 1;
                     if (PC) { if (lane == 0) sflag[0] = fail; __syncthreads(); }      // the producer leaves with us
-                    break;
+                    return false;
                 }
                 pd_counter = 0;
             }
@@ -504,30 +627,112 @@ __device__ __forceinline__ void backward_fused_body(double *sh, const double *pc
         }
         if (PC) __syncthreads();                       // end of step: the ring slot is free, the next one is full
         else wsync();
+        return true;
+    };
+    if constexpr (UNI && !PC) {
+        // segments from the top: [k_p, k_p+1) with k_KpU := T.  The crossing -- slope of the new segment from the column
+        // prefetched a segment ago, the next column requested (raw: x+ / x- differenced and kept for the forward sweep) --
+        // is straight-line code; the segment's first step is peeled behind it so that the wait for its residual tiles
+        // (requested BEFORE the crossing's loads) can leave those in flight.
+        bool ok = true;
+        for (; up >= 0 && ok; up--) {
+#ifdef KP_CYC
+            const unsigned long long cyc0 = __builtin_readcyclecounter();
+#endif
+            const KArgF Fk = kernarg_fused();                      // crossing-only scalars, from the kernel-argument segment
+            rT = frsrc(Fk->kpc + (size_t)E0 * 3 * n, NE * strideB);
+            if constexpr (RAW) { rP = frsrc(Fk->fdk + (size_t)E0 * strideR, NE * strideR); eps2 = Fk->eps2; rinv2 = Fk->rinv_2eps; }
+            // the time of the new segment's start was requested a crossing ago, BEHIND that crossing's column loads: memory
+            // operations return in order, and the wait for the residual tiles of the peeled step ("all but the youngest
+            // loads") would otherwise have to sit out this load's latency too (measured: +840 cycles on every peeled step)
+            unb = __builtin_amdgcn_readfirstlane(unb_v);
+            const int gap = us - unb;                              // steps of the new segment (k_p+1 - k_p; 1 for the first)
+            const double den = (double)gap, rinv = kp_rcp(den);
+            if constexpr (RAW) {
+                if (__builtin_amdgcn_ballot_w64(pmode != 0) == 0) {
+#pragma unroll
+                    for (int i = 0; i < 8; i++) pv[i] = fdiv(pv[i] - pm[i], eps2, rinv2);
+                } else {
+                    const bool oa = (pmode & bitA) != 0, ob = (pmode & 4) != 0;
+                    const double dA = oa ? 0.5 * eps2 : eps2, rA = oa ? 2.0 * rinv2 : rinv2;     // exact halves / doubles
+                    const double dB = ob ? 0.5 * eps2 : eps2, rB = ob ? 2.0 * rinv2 : rinv2;
+#pragma unroll
+                    for (int i = 0; i < 4; i++) { pv[i] = fdiv(pv[i] - pm[i], dA, rA); pv[4 + i] = fdiv(pv[4 + i] - pm[4 + i], dB, rB); }
+                }
+                store_col_n<N>(rT, cu, up * strideB, pv);
+                if (up == KpU - 1) {
+#pragma unroll
+                    for (int i = 0; i < 8; i++) sv[i] = pv[i];
+                }
+            }
+#pragma unroll
+            for (int i = 0; i < 8; i++) { av[i] = fdiv(sv[i] - pv[i], den, rinv); sv[i] = pv[i]; }
+            if (c == n) {                                          // Fz(n,n) = 1 rides in the idle lane's constant start value
+#pragma unroll
+                for (int r = 0; r < 4; r++) if (4 * r + q == n) { sv[r] = 1.0; av[r] = 0.0; }
+            }
+            const int t_hi = us - 1;
+            us = unb;
+            const int pn = up > 0 ? up - 1 : 0;                    // the next start (position 0 again at the bottom: never used)
+            if constexpr (RAW) {
+                load_col_n<N>(rP, cr, pn * strideR, pv);
+                load_col_n<N>(rP, cr, pn * strideR + offM, pm);
+                pmode = __builtin_amdgcn_raw_buffer_load_b32(rP, pn * strideR + kd * KpU * strideR + ((c < n) ? offMode : BIGOFF), 0, 0);
+            } else {
+                load_col_n<N>(rT, cu, pn * strideB, pv);
+            }
+            __builtin_amdgcn_sched_barrier(0);
+            unb_v = Fk->kp_times[E0 + pn];                         // behind the column loads (see above)
+            __builtin_amdgcn_sched_barrier(0);
+#ifdef KP_CYC
+            const unsigned long long cyc1 = __builtin_readcyclecounter();
+            cyc_cross += cyc1 - cyc0;
+#endif
+            ok = step(t_hi);                                       // peeled: straight-line behind the crossing
+#ifdef KP_CYC
+            const unsigned long long cyc2 = __builtin_readcyclecounter();
+            cyc_peel += cyc2 - cyc1;
+#endif
+            for (int t = t_hi - 1; t >= us && ok; t--) ok = step(t);
+#ifdef KP_CYC
+            cyc_inner += __builtin_readcyclecounter() - cyc2;
+#endif
+        }
+    } else {
+        for (int t = T - 1; t >= 0; t--) if (!step(t)) break;
     }
     dJ += __shfl_xor(dJ, 16);
     dJ += __shfl_xor(dJ, 32);
     if (lane_nn) delta_J[b] = dJ;
+#ifdef KP_CYC
+    if (lane_nn) { delta_J[b] = (double)cyc_cross; Kout[(size_t)b * T * m * n] = (double)cyc_peel; Kout[(size_t)b * T * m * n + 1] = (double)cyc_inner;
+                   Kout[(size_t)b * T * m * n + 2] = (double)(__builtin_readcyclecounter() - cyc_all0); Kout[(size_t)b * T * m * n + 3] = (double)cyc_a; }
+#endif
     if (lane == 0) status[b] = fail;
 }
 
-template <int N, int M, bool RU0, bool RAW>
+// The one-wave backward sweep comes in two forms, launched back to back like the forward sweep's: UNI for key-point sets in
+// which every DoF of a trajectory has the same list, the general form otherwise; each looks at the device flag first and
+// leaves if the set is not its kind.
+template <int N, int M, bool RU0, bool RAW, bool UNI>
 __global__ void __launch_bounds__(64)
 k_backward_fused(RecLayout L, FusedArgs F, int T, const double *__restrict__ lambda,
                  int pd_stride, double *__restrict__ Kout, double *__restrict__ kout,
-                 double *__restrict__ delta_J, int *__restrict__ status)
+                 double *__restrict__ delta_J, int *__restrict__ status, const int *__restrict__ kp_uniform)
 {
     __shared__ __attribute__((aligned(16))) double sh[FLDS_TOTAL];
-    backward_fused_body<N, M, false, RU0, false, RAW>(sh, nullptr, nullptr, L, F, T, lambda, pd_stride, Kout, kout, delta_J, status);
+    if ((*kp_uniform != 0) != UNI) return;
+    backward_fused_body<N, M, false, RU0, false, RAW, UNI>(sh, nullptr, nullptr, L, F, T, lambda, pd_stride, Kout, kout, delta_J, status);
 }
-template <int N, int M, bool RU0, bool RAW>
+template <int N, int M, bool RU0, bool RAW, bool UNI>
 __global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(1, 1)))
 k_backward_fused_excl(RecLayout L, FusedArgs F, int T, const double *__restrict__ lambda,
                       int pd_stride, double *__restrict__ Kout, double *__restrict__ kout,
-                      double *__restrict__ delta_J, int *__restrict__ status)
+                      double *__restrict__ delta_J, int *__restrict__ status, const int *__restrict__ kp_uniform)
 {
     __shared__ __attribute__((aligned(16))) double sh[FLDS_TOTAL];
-    backward_fused_body<N, M, false, RU0, false, RAW>(sh, nullptr, nullptr, L, F, T, lambda, pd_stride, Kout, kout, delta_J, status);
+    if ((*kp_uniform != 0) != UNI) return;
+    backward_fused_body<N, M, false, RU0, false, RAW, UNI>(sh, nullptr, nullptr, L, F, T, lambda, pd_stride, Kout, kout, delta_J, status);
 }
 
 
@@ -545,10 +750,9 @@ k_backward_fused_excl(RecLayout L, FusedArgs F, int T, const double *__restrict_
 template <int NV>
 __device__ __forceinline__ void load_vals(__amdgpu_buffer_rsrc_t rT, const int *offs, int tk, int T, int strideB, double *out)
 {
-    const bool ok = (unsigned)tk < (unsigned)T;
-    const int base = ok ? tk * strideB : 0;
+    const int base = ((unsigned)tk < (unsigned)T) ? tk * strideB : BIGOFF;
 #pragma unroll
-    for (int r = 0; r < NV; r++) out[r] = fbld(rT, (ok && offs[r] != OOBF) ? base + offs[r] : OOBF);
+    for (int r = 0; r < NV; r++) out[r] = fbld(rT, base + offs[r]);
 }
 
 #define F2_Q 0                                   // Quu + lambda I, row-major stride 16 (U private)
@@ -637,7 +841,7 @@ __device__ __forceinline__ void fused2_role_U(double *sh, RecLayout L, FusedArgs
 #pragma unroll
         for (int r = 0; r < 4; r++) {
             const int row = 4 * r + q;
-            tr.offs[r] = (row < n && c < m) ? 8 * (2 * n + row) : OOBF;
+            tr.offs[r] = (row < n && c < m) ? 8 * (2 * n + row) : BIGOFF;
             oRu[r] = (row < nr && c < m) ? 8 * (row * m + c) : OOBF;
             oR1[r] = (row < nr && c == n) ? 8 * row : OOBF;
             w2run[r] = (row < nr) ? 2.0 * F.w_run[row] : 0.0;
@@ -797,8 +1001,8 @@ __device__ __forceinline__ void fused2_role_Z(double *sh, RecLayout L, FusedArgs
 #pragma unroll
         for (int r = 0; r < 4; r++) {
             const int row = 4 * r + q;
-            tr.offs[r] = (row < n && c < n) ? 8 * ((c < F.dof ? 0 : n) + row) : OOBF;
-            tr.offs[4 + r] = (row < n && c < m) ? 8 * (2 * n + row) : OOBF;
+            tr.offs[r] = (row < n && c < n) ? 8 * ((c < F.dof ? 0 : n) + row) : BIGOFF;
+            tr.offs[4 + r] = (row < n && c < m) ? 8 * (2 * n + row) : BIGOFF;
             oRx[r] = (row < nr && c < n) ? 8 * (row * n + c) : OOBF;
             oR1[r] = (row < nr && c == n) ? 8 * row : OOBF;
             w2run[r] = (row < nr) ? 2.0 * F.w_run[row] : 0.0;
@@ -923,8 +1127,8 @@ __device__ __forceinline__ void fusedpc_producer(double *pcbuf, int *sflag, RecL
 #pragma unroll
         for (int r = 0; r < 4; r++) {
             const int row = 4 * r + q;
-            tr.offs[r] = (row < n && c < n) ? 8 * ((c < F.dof ? 0 : n) + row) : OOBF;
-            tr.offs[4 + r] = (row < n && c < m) ? 8 * (2 * n + row) : OOBF;
+            tr.offs[r] = (row < n && c < n) ? 8 * ((c < F.dof ? 0 : n) + row) : BIGOFF;
+            tr.offs[4 + r] = (row < n && c < m) ? 8 * (2 * n + row) : BIGOFF;
             oRx[r] = (row < nr && c < n) ? 8 * (row * n + c) : OOBF;
             oR1[r] = (row < nr && c == n) ? 8 * row : OOBF;
             oRu[r] = (row < nr && c < m) ? 8 * (row * m + c) : OOBF;
@@ -1104,8 +1308,8 @@ __device__ __forceinline__ void forward_fused_body(RecLayout L, FusedArgs F, int
             // the Y operands themselves: Ya(p = row, o = c) = A(o, p), Yb(p, o) = B(o, p) -- element c of column `row`, whose
             // DoF list starts (row mod dof) * KpU entries into the trajectory's slice (equal lists: the same position in each)
             const int d = row < F.dof ? row : row - F.dof;
-            co.a[r] = (row < n && c < n) ? 8 * ((d * KpU * 3 + (row < F.dof ? 0 : 1)) * n + c) : OOBF;
-            co.b[r] = (row < m && c < n) ? 8 * ((row * KpU * 3 + 2) * n + c) : OOBF;
+            co.a[r] = (row < n && c < n) ? 8 * ((d * KpU * 3 + (row < F.dof ? 0 : 1)) * n + c) : BIGOFF;
+            co.b[r] = (row < m && c < n) ? 8 * ((row * KpU * 3 + 2) * n + c) : BIGOFF;
         }
         oK[r] = (row < n && c < m) ? 8 * (row * m + c) : OOBF;
         oRxT[r] = (row < n && c < nr) ? 8 * (c * n + row) : OOBF;     // RxT(p=row, k=c) = r_x[k][p]
@@ -1600,13 +1804,13 @@ bool fused_supported(int n, int m, int nr, int dof, int T, int stride, int n_alp
 {
     (void)stride;
     // one trajectory's slice of the key-point column store (at most T entries per DoF, 3n doubles each) behind one descriptor
-    return kp_t1_shape(n, m) && nr >= 1 && nr <= 16 && m <= dof && n_alpha <= 16 && (long long)T * dof * 3 * n * 8 < 0x7ffffff0LL;
+    return kp_t1_shape(n, m) && nr >= 1 && nr <= 16 && m <= dof && n_alpha <= 16 && (long long)T * dof * (6 * n + 2) * 8 < (long long)BIGOFF;
 }
 
 static FusedArgs fused_args(const Ctx *c)
 {
     FusedArgs F = {c->kp_offsets, c->kp_times, c->r, c->r_x, c->r_u, c->w_run, c->w_term, c->d.dof, c->d.nr,
-                   c->kpc, c->kx_plus, c->kx_minus, c->k_mode, c->eps, 1.0 / c->eps, 1.0 / (2 * c->eps)};
+                   c->kpc, c->fdk_dev, 2 * c->eps, 1.0 / (2 * c->eps)};
     return F;
 }
 
@@ -1660,15 +1864,17 @@ hipError_t launch_backward_fused(Ctx *c, int pd_stride, bool raw)
 #undef LAUNCHPC
         return hipErrorInvalidValue;
     }
-#define LAUNCH3(NN, MM, RU, RW)                                                                               \
+#define LAUNCH4(NN, MM, RU, RW, UN)                                                                           \
     do {                                                                                                     \
         if (excl)                                                                                            \
-            hipLaunchKernelGGL((k_backward_fused_excl<NN, MM, RU, RW>), grid, block, 0, c->stream, c->L, F, c->d.T,  \
-                               c->lambda, pd_stride, c->K, c->k, c->delta_J, c->status);             \
+            hipLaunchKernelGGL((k_backward_fused_excl<NN, MM, RU, RW, UN>), grid, block, 0, c->stream, c->L, F, c->d.T,  \
+                               c->lambda, pd_stride, c->K, c->k, c->delta_J, c->status, c->kp_uniform);      \
         else                                                                                                 \
-            hipLaunchKernelGGL((k_backward_fused<NN, MM, RU, RW>), grid, block, 0, c->stream, c->L, F, c->d.T,   \
-                               c->lambda, pd_stride, c->K, c->k, c->delta_J, c->status);             \
+            hipLaunchKernelGGL((k_backward_fused<NN, MM, RU, RW, UN>), grid, block, 0, c->stream, c->L, F, c->d.T,   \
+                               c->lambda, pd_stride, c->K, c->k, c->delta_J, c->status, c->kp_uniform);      \
     } while (0)
+// both forms, back to back: the one whose kind of key-point set is not resident leaves at once
+#define LAUNCH3(NN, MM, RU, RW) do { if (c->tune.fused_uni != 0) LAUNCH4(NN, MM, RU, RW, true); LAUNCH4(NN, MM, RU, RW, false); } while (0)
 #define LAUNCH2(NN, MM, RU) do { if (raw) LAUNCH3(NN, MM, RU, true); else LAUNCH3(NN, MM, RU, false); } while (0)
 #define LAUNCH(NN, MM) do { if (c->ru_zero) LAUNCH2(NN, MM, true); else LAUNCH2(NN, MM, false); } while (0)
 #define KP_X(NN, MM) if (n == NN && m == MM) { LAUNCH(NN, MM); return hipGetLastError(); }
@@ -1677,6 +1883,7 @@ hipError_t launch_backward_fused(Ctx *c, int pd_stride, bool raw)
 #undef LAUNCH
 #undef LAUNCH2
 #undef LAUNCH3
+#undef LAUNCH4
     return hipErrorInvalidValue;
 }
 

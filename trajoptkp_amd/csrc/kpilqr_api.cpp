@@ -86,6 +86,7 @@ Ctx::Tuning read_tuning_from_env()
     t.tiled_a4 = env_int("KPILQR_TILED_A4", -1);
     t.pipe_copy = env_int("KPILQR_PIPE_COPY", -1);
     t.fused_raw = env_int("KPILQR_FUSED_RAW", -1);
+    t.fused_uni = env_int("KPILQR_FUSED_UNI", -1);
     return t;
 }
 }  // namespace kpilqr
@@ -719,12 +720,9 @@ int kpilqr_upload_fd_slab(kpilqr_ctx *c, const void *slab, int njobs, int nnom, 
 // ---- key-point ordered FD payload ---------------------------------------------------------------------------------------
 static void fdkp_layout(int n, int entries, kpilqr_fdkp_layout *L)
 {
-    const size_t E = (size_t)entries;
-    size_t o = 0;
-    L->xplus = o; o = al16(o + E * 3 * n * sizeof(double));
-    L->xminus = o; o = al16(o + E * 3 * n * sizeof(double));
-    L->mode = o; o = al16(o + E);
-    L->bytes = o;
+    L->entry_stride = (size_t)(6 * n + 2) * 8;
+    L->xplus = 0; L->xminus = (size_t)3 * n * 8; L->mode = (size_t)6 * n * 8;
+    L->bytes = (size_t)entries * L->entry_stride;
 }
 
 int kpilqr_fd_kp_layout(kpilqr_ctx *c, int entries, kpilqr_fdkp_layout *out)
@@ -740,8 +738,6 @@ static int fdk_bind(kpilqr_ctx *c, int entries, kpilqr_fdkp_layout *L)
     fdkp_layout(c->n, entries, L);
     const int rc = grow_dev(c, (void **)&c->fdk_dev, &c->fdk_dev_cap, L->bytes + L->bytes / 8 + 4096, false);
     if (rc < 0) return rc;
-    c->kx_plus = (double *)(c->fdk_dev + L->xplus); c->kx_minus = (double *)(c->fdk_dev + L->xminus);
-    c->k_mode = (unsigned char *)(c->fdk_dev + L->mode);
     return KPILQR_OK;
 }
 
@@ -1153,12 +1149,8 @@ int kpilqr_iterate_streamed(kpilqr_ctx *c, const kpilqr_stream_io *io, int pd_ch
             v.job_mode = c->job_mode + jo; v.xplus = c->xplus + jo * n; v.xminus = c->xminus + jo * n; v.njobs = (int)J;
         } else if (kslab) {
             const int e0 = c->kp_traj_first_host[b0], e1 = c->kp_traj_first_host[b1];
-            const size_t E = (size_t)(e1 - e0), eo = (size_t)e0, row = (size_t)3 * n * 8;
-            if (E) {
-                KP_HIP(c, h2d((char *)c->kx_plus + eo * row, kslab + LK.xplus + eo * row, E * row, s));
-                KP_HIP(c, h2d((char *)c->kx_minus + eo * row, kslab + LK.xminus + eo * row, E * row, s));
-                KP_HIP(c, h2d(c->k_mode + eo, kslab + LK.mode + eo, E, s));
-            }
+            const size_t E = (size_t)(e1 - e0), eo = (size_t)e0;
+            if (E) KP_HIP(c, h2d(c->fdk_dev + eo * LK.entry_stride, kslab + eo * LK.entry_stride, E * LK.entry_stride, s));   // the chunk: ONE range
             v.fdk_first = e0; v.fdk_entries = (int)E;      // the chunk's entries
         } else {
             // no new FD payload: what was differenced before is reused (kpc / the records' key-point columns)

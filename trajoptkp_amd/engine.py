@@ -212,11 +212,15 @@ class Engine:
         lay = _lib.FdkpLayout()
         self._ck(self._L.kpilqr_fd_kp_layout(self._h, ent, C.byref(lay)))
         slab = self.pinned(lay.bytes, np.uint8) if pinned else np.zeros(max(lay.bytes, 1), np.uint8)
-        for off, a, dt in ((lay.xplus, xplus, np.float64), (lay.xminus, xminus, np.float64), (lay.mode, mode, np.uint8)):
-            a = np.ascontiguousarray(a, dt)
-            if dt is np.float64 and a.shape != (ent, 3, self.n):
+        n3 = 3 * self.n
+        rec = slab[:ent * lay.entry_stride].view(np.float64).reshape(ent, lay.entry_stride // 8)     # one record per entry
+        for off, a in ((lay.xplus, xplus), (lay.xminus, xminus)):
+            a = np.ascontiguousarray(a, np.float64)
+            if a.shape != (ent, 3, self.n):
                 raise ValueError(f"expected shape {(ent, 3, self.n)}, got {a.shape}")
-            slab[off:off + a.nbytes] = a.view(np.uint8).reshape(-1)
+            rec[:, off // 8:off // 8 + n3] = a.reshape(ent, n3)
+        rec[:, lay.mode // 8:] = 0.0
+        rec[:, lay.mode // 8:lay.mode // 8 + 1].view(np.int32)[:, 0] = np.asarray(mode, np.int32)
         return dict(slab=slab, entries=ent, layout=lay)
 
     def upload_fd_kp(self, s, eps=1e-6):
