@@ -31,6 +31,7 @@
 // Everything else (homogeneous form, LDL' solve, slow path, stores) is riccati_mfma.hip / forward_mfma.hip.
 // Per launch the kernels read Kp*(n^2+nm) + T*nr*(1+n+m) doubles instead of T*(2n^2+nm+n+m^2+m).
 #include <cstdlib>
+#include <type_traits>
 #include "mfma_common.h"
 
 namespace kpilqr {
@@ -1447,8 +1448,17 @@ __device__ __forceinline__ void forward_fused_body(RecLayout L, FusedArgs F, int
     const __amdgpu_buffer_rsrc_t rK = frsrc(Kin + (size_t)b * T * m * n, T * m * n * 8), rk = frsrc(kin + (size_t)b * T * m, T * m * 8),
                                  ru = frsrc(u_nom + (size_t)b * T * m, T * m * 8), rRx = frsrc(rxb, (T + 1) * nr * n * 8),
                                  rRu = frsrc(rub, (T + 1) * nr * m * 8), rR = frsrc(rb, (T + 1) * nr * 8);
-    for (int t = 0; t < T; t++) {
-        const bool more = t + 1 < T;
+    // UNI: the uniform tracker of the segment loop below (positions and times are wave-uniform scalars)
+    int up = 0, uks = 0, uke = 0, ukn_v = 0;            // segment's start position, its start / end time, the time after that (as loaded)
+    double ev2[8];                                       // the column after the next one (requested a segment ahead)
+    double wterm[4] = {0.0, 0.0, 0.0, 0.0};
+    (void)up; (void)uks; (void)uke; (void)ukn_v; (void)ev2; (void)wterm;
+    // MODE 0: the general form (per-lane tracker, crossing inside the step); UNI: 1 a step inside a segment, 2 the last step of a
+    // segment (the crossing into the next one, in straight-line code, sits where the general form advances its tracker),
+    // 3 the final step t = T-1 (terminal weights, nothing left to request)
+    auto step = [&](int t, auto mode_tag) __attribute__((always_inline)) {
+        constexpr int MODE = decltype(mode_tag)::value;
+        const bool more = MODE == 3 ? false : MODE != 0 ? true : t + 1 < T;
         const int tn = more ? t + 1 : t;
         const int sK = tn * m * n * 8, sk = tn * m * 8, sRx = tn * nr * n * 8, sRu = tn * nr * m * 8, sR = tn * nr * 8;
         (void)sRu;
@@ -1499,12 +1509,45 @@ __device__ __forceinline__ void forward_fused_body(RecLayout L, FusedArgs F, int
             for (int r = 0; r < NCU; r++) { const int row = 4 * r + q; if (row < m) Ua[row] = uv[r]; }
         }
         // a4 for step t+2 (column layout -> LDS): fills the latency of the products above
-        if (UNI) { if (more) { advance(t + 1); lerp_Y(t + 1); } }
-        else if (t + 2 < T) { advance(t + 2); stage_cols(t + 2); }
-        // quadratic cost model on the residuals: sum_k w_k [Jx_k (2 r_k + Jx_k) + Ju_k (2 r_k + Ju_k)]
-        if (t == T - 1) {                     // terminal weights at the last step (Optimiser.cpp:209-211)
+        if constexpr (MODE == 0) {
+            if (UNI) { if (more) { advance(t + 1); lerp_Y(t + 1); } }
+            else if (t + 2 < T) { advance(t + 2); stage_cols(t + 2); }
+        } else if constexpr (MODE == 1) {
+            const double dt = (double)(t + 1 - uks);                       // the next step lies in the same segment
+            Ya.x = lerp_nc(sv[0], dt, av[0]); Ya.y = lerp_nc(sv[1], dt, av[1]); Ya.z = lerp_nc(sv[2], dt, av[2]); Ya.w = lerp_nc(sv[3], dt, av[3]);
+            Yb.x = lerp_nc(sv[4], dt, av[4]); Yb.y = NCU > 1 ? lerp_nc(sv[5], dt, av[5]) : 0.0;
+            Yb.z = NCU > 2 ? lerp_nc(sv[6], dt, av[6]) : 0.0; Yb.w = NCU > 3 ? lerp_nc(sv[7], dt, av[7]) : 0.0;
+        } else if constexpr (MODE == 2) {
+            // crossing into segment up + 1: its start column (ev) and end column (ev2) were requested one and two segments
+            // ago; the column after those and its time are requested now, the time BEHIND the columns (loads return in
+            // order: a wait that leaves "the youngest loads" in flight must not have to sit out the time's latency)
+            const int kn = __builtin_amdgcn_readfirstlane(ukn_v);
+            uks = uke; uke = kn; up++;
+            const int gap = uke - uks;
+            const double den = (double)(gap > 0 ? gap : 1), rinv = kp_rcp(den);
 #pragma unroll
-            for (int r = 0; r < 4; r++) wcur[r] = (4 * r + q < nr) ? F.w_term[4 * r + q] : 0.0;   // (hoisting these loads out of the loop measured 0.9 ms slower)
+            for (int i = 0; i < 8; i++) { sv[i] = ev[i]; ev[i] = ev2[i]; av[i] = fdiv(ev[i] - sv[i], den, rinv); }
+            if (c == n || c == n + 1) {                                    // the identity rows of Ya: lanes c >= n walk no list
+#pragma unroll
+                for (int r = 0; r < 4; r++) if (4 * r + q == c) { sv[r] = 1.0; ev[r] = 1.0; av[r] = 0.0; }
+            }
+            const int pn = up + 2 < KpU ? up + 2 : KpU - 1;
+            load_col(rT, co, pn, NE, strideB, ev2);
+            __builtin_amdgcn_sched_barrier(0);
+            ukn_v = F.kp_times[E0 + pn];
+            __builtin_amdgcn_sched_barrier(0);
+            Ya.x = sv[0]; Ya.y = sv[1]; Ya.z = sv[2]; Ya.w = sv[3];        // the next step IS the key-point: dt = 0
+            Yb.x = sv[4]; Yb.y = NCU > 1 ? sv[5] : 0.0; Yb.z = NCU > 2 ? sv[6] : 0.0; Yb.w = NCU > 3 ? sv[7] : 0.0;
+        }
+        // quadratic cost model on the residuals: sum_k w_k [Jx_k (2 r_k + Jx_k) + Ju_k (2 r_k + Ju_k)]
+        if constexpr (MODE == 0) {
+            if (t == T - 1) {                     // terminal weights at the last step (Optimiser.cpp:209-211)
+#pragma unroll
+                for (int r = 0; r < 4; r++) wcur[r] = (4 * r + q < nr) ? F.w_term[4 * r + q] : 0.0;   // (hoisting these loads out of the loop measured 0.9 ms slower)
+            }
+        } else if constexpr (MODE == 3) {
+#pragma unroll
+            for (int r = 0; r < 4; r++) wcur[r] = wterm[r];
         }
         const d4 r2 = cur.rv + cur.rv;
         partial += wcur[0] * (Jx.x * (r2.x + Jx.x) + Ju.x * (r2.x + Ju.x))
@@ -1514,6 +1557,36 @@ __device__ __forceinline__ void forward_fused_body(RecLayout L, FusedArgs F, int
         __builtin_amdgcn_sched_barrier(0);
         cur.rv.x = fblds(rR, oR[0], sR); cur.rv.y = fblds(rR, oR[1], sR); cur.rv.z = fblds(rR, oR[2], sR); cur.rv.w = fblds(rR, oR[3], sR);
         __builtin_amdgcn_sched_barrier(0);
+    };
+    if constexpr (UNI) {
+        // Segments from the bottom: segment p = steps k_p .. k_p+1 - 1; the last key-point T-1 is a segment of its own (the
+        // final step).  On entry of the loop: sv = column(k_0), ev = column(k_1), ev2 = column(k_2) in flight, av = slope of
+        // segment 0, Y(0) = sv.  (The per-lane tracker above did the loads of sv and ev; it is not used any further.)
+#pragma unroll
+        for (int r = 0; r < 4; r++) wterm[r] = (4 * r + q < nr) ? F.w_term[4 * r + q] : 0.0;
+        uks = __builtin_amdgcn_readfirstlane(F.kp_times[E0]);
+        uke = __builtin_amdgcn_readfirstlane(F.kp_times[E0 + (KpU > 1 ? 1 : 0)]);
+        {
+            const int p2 = KpU > 2 ? 2 : KpU - 1;
+            load_col(rT, co, p2, NE, strideB, ev2);
+            ukn_v = F.kp_times[E0 + p2];
+            const int gap = uke - uks;
+            const double den = (double)(gap > 0 ? gap : 1), rinv = kp_rcp(den);
+#pragma unroll
+            for (int i = 0; i < 8; i++) av[i] = fdiv(ev[i] - sv[i], den, rinv);
+            if (c == n || c == n + 1) {
+#pragma unroll
+                for (int r = 0; r < 4; r++) if (4 * r + q == c) { ev[r] = 1.0; av[r] = 0.0; }
+            }
+        }
+        for (int seg = 0; seg < KpU - 1; seg++) {       // (the crossing inside step<2> moves up, uks, uke on)
+            const int t_last = uke - 1;
+            for (int t = uks; t < t_last; t++) step(t, std::integral_constant<int, 1>{});
+            step(t_last, std::integral_constant<int, 2>{});
+        }
+        step(T - 1, std::integral_constant<int, 3>{});
+    } else {
+        for (int t = 0; t < T; t++) step(t, std::integral_constant<int, 0>{});
     }
     partial += __shfl_xor(partial, 16);
     partial += __shfl_xor(partial, 32);
