@@ -1481,9 +1481,9 @@ __device__ __forceinline__ void forward_fused_body(RecLayout L, FusedArgs F, int
             // rows >= 4*NCU of U hold no control (exact zeros): only the first NCU registers are clamped (:883-889)
             dU = zero;
             u = U.x; if (u > hi[0]) u = hi[0]; if (u < lo[0]) u = lo[0]; U.x = u; dU.x = u - ub.x;
-            if (NCU > 1) { u = U.y; if (u > hi[1]) u = hi[1]; if (u < lo[1]) u = lo[1]; U.y = u; dU.y = u - ub.y; }
-            if (NCU > 2) { u = U.z; if (u > hi[2]) u = hi[2]; if (u < lo[2]) u = lo[2]; U.z = u; dU.z = u - ub.z; }
-            if (NCU > 3) { u = U.w; if (u > hi[3]) u = hi[3]; if (u < lo[3]) u = lo[3]; U.w = u; dU.w = u - ub.w; }
+            if constexpr (NCU > 1) { u = U.y; if (u > hi[1]) u = hi[1]; if (u < lo[1]) u = lo[1]; U.y = u; dU.y = u - ub.y; }
+            if constexpr (NCU > 2) { u = U.z; if (u > hi[2]) u = hi[2]; if (u < lo[2]) u = lo[2]; U.z = u; dU.z = u - ub.z; }
+            if constexpr (NCU > 3) { u = U.w; if (u > hi[3]) u = hi[3]; if (u < lo[3]) u = lo[3]; U.w = u; dU.w = u - ub.w; }
         }
         __builtin_amdgcn_sched_barrier(0);
         cur.ub.x = fblds(ru, oub[0], sk); cur.ub.y = NCU > 1 ? fblds(ru, oub[1], sk) : 0.0;
