@@ -372,3 +372,22 @@ def test_load_task_from_the_references_test_task_files(task, n_start, golden_dir
         assert got is not None
         assert np.array_equal(got[0], toks[:n_start]) and np.array_equal(got[1], toks[n_start:])
         assert host.load_task(path, n_start + 1, n_targets) is None        # wrong element count: refused (:519-523)
+
+
+@pytest.mark.parametrize("model,stagger", [("acrobot", 0), ("acrobot", 1), ("floating_body", 0), ("floating_body", 2)])
+def test_keypoint_ordered_fill_matches_the_job_lists(model, stagger):
+    """The FD workers writing straight into the entry records of kpilqr_upload_fd_kp (Differentiator::DynamicsDerivativesKp)
+    produce exactly the jobs of the job-list fill, slot by slot: x+ / x- rows, the nominal next state in the unstepped side of
+    a one-sided control column (controls at their limits), the mode bits; uniform and ragged per-DoF key-point lists; hinge
+    and free-joint (tangent-space position rows) models.  No GPU."""
+    mdl = host.Model(model)
+    T, nu = 60, mdl.nu
+    rng = np.random.default_rng(7)
+    lim = np.asarray(mdl.limits).reshape(nu, 2)
+    u = rng.uniform(lim[:, 0], lim[:, 1], (T, nu)) * 0.2
+    u[10:20] = lim[:, 1]                       # at the upper limit: backward-only control columns
+    u[30:35] = lim[:, 0]                       # at the lower limit: forward-only
+    r = host.fd_kp_check(model, T, 5, stagger, u)
+    assert r["mismatches"] == 0, r
+    assert r["one_sided"] > 0 and r["jobs"] > 0 and r["entries"] > 0
+

@@ -41,6 +41,7 @@ def load_host():
     H.kpilqr_host_run_acrobot_batch.argtypes = [C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_double, vp, C.c_int, vp, C.c_int, vp, vp, vp]
     H.kpilqr_host_dof_importance.argtypes = [vp, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_double, vp, vp]
     H.kpilqr_host_model_info.argtypes = [C.c_char_p, vp, vp, vp]
+    H.kpilqr_host_fd_kp_check.argtypes = [C.c_char_p, C.c_int, C.c_int, C.c_int, vp, vp]
     H.kpilqr_host_model_op.argtypes = [C.c_char_p, C.c_int, vp, vp, vp, vp, C.c_double, C.c_int, vp, vp]
     H.kpilqr_host_model_fd.argtypes = [C.c_char_p, vp, vp, vp, C.c_int, vp, C.c_int, C.c_double, vp, vp, vp, vp, vp, vp, vp]
     H.kpilqr_host_optimise.argtypes = [C.c_char_p, C.c_int, C.c_int, C.c_int, C.c_char_p, vp, vp, C.c_int, vp, vp]
@@ -74,6 +75,18 @@ def run_acrobot(T=100, min_N=5, max_iter=5, min_iter=2, method="set_interval", t
         raise RuntimeError(f"kpilqr_host_run_acrobot failed: {it}")
     return dict(iterations=it, cost_history=hist[:it + 1].copy(), U=U, K0=K0,
                 timings_ms=dict(derivs=tm[0], backward=tm[1], forward=tm[2], total=tm[3]))
+
+
+def fd_kp_check(model, T, min_N, stagger, u):
+    """Differentiator::DynamicsDerivativesKp (key-point ordered payload) against the job-list fill on a rolled-out trajectory
+    of a stand-in model; -> dict(mismatches, jobs, one_sided, entries)."""
+    H = load_host()
+    u = np.ascontiguousarray(u, np.float64)
+    stats = np.zeros(3, np.int32)
+    bad = H.kpilqr_host_fd_kp_check(model.encode(), int(T), int(min_N), int(stagger), _p(u), _p(stats))
+    if bad < 0:
+        raise RuntimeError(f"kpilqr_host_fd_kp_check failed: {bad}")
+    return dict(mismatches=bad, jobs=int(stats[0]), one_sided=int(stats[1]), entries=int(stats[2]))
 
 
 def fd_bench(T=3000, reps=5, mode=1, fd_threads=16):

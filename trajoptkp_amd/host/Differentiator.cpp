@@ -217,7 +217,51 @@ struct SliceSink {
         at++;
     }
 };
+// Key-point ordered payload (include/kpilqr.h, kpilqr_fd_kp_layout): one record per CSR entry (trajectory, DoF, key-point),
+// [x+ (3n) | x- (3n) | int32 mode, pad]; the perturbed next states of DoF i at this key-point go straight to the three
+// slots of entry entry_of[i] -- position kind 0, velocity kind 1, control kind 2 -- a one-sided job with the unperturbed
+// next state in the slot of the side that was not stepped and its bit in the mode word.  The three kinds of an entry are
+// written by the one worker that owns the key-point, so the mode word needs no atomics (it is zeroed with the plan).
+struct KpSink {
+    char *slab; size_t stride; int n, dof; const int *entry_of;      // entry_of[i]: CSR entry of DoF i at this key-point time
+    MatrixXd xnom;
+    void nominal(const MatrixXd &x) { xnom = x; }
+    void job(int col, int mode, const MatrixXd &xp, const MatrixXd &xm)
+    {
+        const int kind = col < dof ? 0 : col < n ? 1 : 2;
+        const int i = kind == 0 ? col : kind == 1 ? col - dof : col - n;
+        double *rec = (double *)(slab + (size_t)entry_of[i] * stride);
+        std::memcpy(rec + (size_t)kind * n, (mode == 2 ? xnom : xp).data(), sizeof(double) * n);
+        std::memcpy(rec + (size_t)(3 + kind) * n, (mode == 1 ? xnom : xm).data(), sizeof(double) * n);
+        if (mode != 0) *(int *)(rec + (size_t)6 * n) |= 1 << kind;
+    }
+};
 }  // namespace
+
+// Key-point ordered fill of one trajectory: offs / times = its per-DoF CSR (KeypointGenerator::PerDofCSR), entry0 = the CSR
+// position of its first entry in the batch's lists.  Every entry's record must belong to [slab, slab + entries * stride).
+void Differentiator::DynamicsDerivativesKp(char *slab, size_t stride, int entry0, const std::vector<int> &offs,
+                                           const std::vector<int> &times, const std::vector<std::vector<int>> &keypoints, double eps)
+{
+    const stateVectorList &sv = model_translator->current_state_vector;
+    const int dof = sv.dof, n = 2 * dof, T = (int)keypoints.size();
+    std::vector<int> entry_of((size_t)T * dof, -1);            // [t][i]
+    for (int i = 0; i < dof; i++)
+        for (int e = offs[i]; e < offs[i + 1]; e++) entry_of[(size_t)times[e] * dof + i] = entry0 + e;
+    for (int e = offs[0]; e < offs[dof]; e++) {                // zero the mode words (and the pad) of this trajectory's records
+        double *rec = (double *)(slab + (size_t)(entry0 + e) * stride);
+        rec[6 * n] = 0.0; rec[6 * n + 1] = 0.0;
+    }
+    std::vector<int> kts;
+    for (int t = 0; t < T; t++) if (!keypoints[t].empty()) kts.push_back(t);
+    MuJoCo_helper->InitModelForFiniteDifferencing();
+    pool().parallel_for((int)kts.size(), [&](int it, int tid) {
+        const int t = kts[it];
+        KpSink sink{slab, stride, n, dof, entry_of.data() + (size_t)t * dof, MatrixXd()};
+        fd_keypoint(*model_translator, *MuJoCo_helper, count_integrations, sink, keypoints[t], t, tid, true, eps);
+    });
+    MuJoCo_helper->ResetModelAfterFiniteDifferencing();
+}
 
 void Differentiator::DynamicsDerivatives(FDJobs &jobs, int b, const std::vector<int> &cols, int data_index, int tid,
                                          bool central_diff, double eps)

@@ -74,6 +74,11 @@ public:
     // staging's cursors (job order and contents exactly as DynamicsDerivativesBatch).
     void CountJobs(const std::vector<std::vector<int>> &keypoints, int &jobs, int &kps) const;
     void DynamicsDerivativesPlanned(FDStaging &st, int b, const std::vector<std::vector<int>> &keypoints, double eps);
+    // Key-point ordered payload (kpilqr_fd_kp_layout: one record of `stride` bytes per CSR entry): the FD workers write every
+    // perturbed next state straight into its slot of the trajectory's records; offs / times = the trajectory's per-DoF CSR,
+    // entry0 = the position of its first entry in the batch's lists.  No job arrays, no nominal rows, nothing to walk.
+    void DynamicsDerivativesKp(char *slab, size_t stride, int entry0, const std::vector<int> &offs, const std::vector<int> &times,
+                               const std::vector<std::vector<int>> &keypoints, double eps);
     // Residual Jacobians of the saved states 0..T into r_x [T+1][nr][n], r_u [T+1][nr][m] on the pool; a task
     // that knows them in closed form (ModelTranslator::ResidualJacobians) skips the differencing altogether.
     void ResidualDerivativesAll(double *r_x, double *r_u, int T, double eps);

@@ -235,6 +235,58 @@ int kpilqr_host_model_fd(const char *model, const double *qpos, const double *qv
     return jobs.njobs();
 }
 
+// The key-point ordered fill (Differentiator::DynamicsDerivativesKp, the payload of kpilqr_upload_fd_kp) against the job-list
+// fill (DynamicsDerivativesBatch) on one rolled-out trajectory of a stand-in model: controls u [T][nu] (some at their limits
+// make one-sided columns), key-points every min_N steps for DoF i shifted by i*stagger (ragged per-DoF lists), no GPU.
+// stats[0] = jobs, [1] = one-sided jobs, [2] = entries.  Returns the number of slots that differ from the job they came from
+// (x+ / x- rows, with the nominal next state in the unstepped side of a one-sided job, and the mode bits), or < 0.
+int kpilqr_host_fd_kp_check(const char *model, int T, int min_N, int stagger, const double *u, int *stats)
+{
+    Model M;
+    if (!make_model(model, 8, M)) return -1;
+    const stateVectorList &sv = M.mt->current_state_vector;
+    const int dof = sv.dof, n = 2 * dof, nu = sv.num_ctrl;
+    SimData *d = M.sim->main_data;
+    for (int t = 0; t < T; t++) {                                  // roll out, saving the states the FD loops start from
+        for (int i = 0; i < nu; i++) d->ctrl[i] = u[(size_t)t * nu + i];
+        M.sim->AppendSystemStateToEnd(d);
+        M.sim->ForwardSimulator(d);
+    }
+    std::vector<std::vector<int>> kp(T);
+    for (int t = 0; t < T; t++)
+        for (int i = 0; i < dof; i++)
+            if (t == 0 || t == T - 1 || (t + i * stagger) % min_N == 0) kp[t].push_back(i);
+    KeypointGenerator gen(dof, T);
+    gen.keypoints = kp;
+    std::vector<int> offs, times;
+    gen.PerDofCSR(offs, times);
+    const int entries = offs[dof];
+    Differentiator diff(M.mt, M.sim);
+    FDStaging st;
+    diff.DynamicsDerivativesBatch(st, 0, kp, 1e-6);
+    const size_t stride = (size_t)(6 * n + 2) * 8;
+    std::vector<char> slab((size_t)entries * stride, (char)0x5a);  // poisoned: every slot must be written
+    diff.DynamicsDerivativesKp(slab.data(), stride, 0, offs, times, kp, 1e-6);
+    std::vector<int> entry_of((size_t)T * dof, -1);
+    for (int i = 0; i < dof; i++) for (int e = offs[i]; e < offs[i + 1]; e++) entry_of[(size_t)times[e] * dof + i] = e;
+    int bad = 0, one_sided = 0;
+    std::vector<int> mode_seen(entries, 0);
+    for (int j = 0; j < st.njobs; j++) {
+        const int col = st.job_col[j], kind = col < dof ? 0 : col < n ? 1 : 2, i = kind == 0 ? col : kind == 1 ? col - dof : col - n;
+        const int e = entry_of[(size_t)st.job_t[j] * dof + i], mode = st.job_mode[j];
+        if (e < 0) { bad++; continue; }
+        const double *rec = (const double *)(slab.data() + (size_t)e * stride);
+        const double *P = mode == 2 ? st.xnom + (size_t)st.job_nom[j] * n : st.xplus + (size_t)j * n;
+        const double *Mn = mode == 1 ? st.xnom + (size_t)st.job_nom[j] * n : st.xminus + (size_t)j * n;
+        if (std::memcmp(rec + (size_t)kind * n, P, sizeof(double) * n) != 0) bad++;
+        if (std::memcmp(rec + (size_t)(3 + kind) * n, Mn, sizeof(double) * n) != 0) bad++;
+        if (mode) { one_sided++; mode_seen[e] |= 1 << kind; }
+    }
+    for (int e = 0; e < entries; e++) if (*(const int *)(slab.data() + (size_t)e * stride + (size_t)6 * n * 8) != mode_seen[e]) bad++;
+    stats[0] = st.njobs; stats[1] = one_sided; stats[2] = entries;
+    return bad;
+}
+
 // Optimise() of a stand-in model on the GPU engine with the per-iteration decisions written out for the a9 parity test:
 // trace [max_iter][24] = derivatives, lambda_in, backward_passes, lambda_exit, lambda_after_backward, old_cost, new_cost,
 // best, accepted, converged, lambda_out, n_alpha, rollout_costs[6], predicted[6].  options: "+pruned" (GPU-ordered line

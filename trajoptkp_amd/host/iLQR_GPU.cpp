@@ -34,6 +34,8 @@ void iLQR_GPU::free_pinned()
     staging.free_all();
     double **all[] = {&host_r, &host_rx, &host_ru, &host_unom, &host_K, &host_k};
     for (double **p : all) { if (*p && ctx) kpilqr_host_free(ctx, *p); *p = nullptr; }
+    if (kp_slab && ctx) kpilqr_host_free(ctx, kp_slab);
+    kp_slab = nullptr; kp_slab_bytes = 0;
 }
 
 iLQR_GPU::~iLQR_GPU()
@@ -151,9 +153,24 @@ void iLQR_GPU::GenerateDerivatives()
     keypoint_generator->PerDofCSR(offs, times);
     int rc = kpilqr_set_keypoints(ctx, offs.data(), times.data());
     if (rc) fatal("kpilqr_set_keypoints", rc);
+    if ((rc = kpilqr_sync(ctx))) fatal("kpilqr_sync", rc);        // the previous upload has left the staging slab
+    if (fused_active) {
+        // Fused sweeps: the payload goes up KEY-POINT ORDERED -- the FD workers write every perturbed next state straight into
+        // its slot of the entry records (kpilqr_fd_kp_layout), one DMA, no job lists; the sweeps read the records (or the
+        // column store differenced from them) directly
+        const int entries = offs[dof];
+        kpilqr_fdkp_layout lay;
+        if ((rc = kpilqr_fd_kp_layout(ctx, entries, &lay))) fatal("kpilqr_fd_kp_layout", rc);
+        if (lay.bytes > kp_slab_bytes) {
+            if (kp_slab) kpilqr_host_free(ctx, kp_slab);
+            kp_slab_bytes = lay.bytes + lay.bytes / 4 + 4096;
+            if ((rc = kpilqr_host_alloc(ctx, kp_slab_bytes, (void **)&kp_slab))) fatal("kpilqr_host_alloc", rc);
+        }
+        activeDifferentiator->DynamicsDerivativesKp(kp_slab, lay.entry_stride, 0, offs, times, keypoint_generator->keypoints, eps);
+        if ((rc = kpilqr_upload_fd_kp(ctx, kp_slab, entries, eps))) fatal("kpilqr_upload_fd_kp", rc);
+    } else {
     // FD at the key-points on the persistent pool, straight into ONE pinned slab (jobs, nominal rows):
     // the upload is a single DMA and nothing on the host walks the jobs afterwards
-    if ((rc = kpilqr_sync(ctx))) fatal("kpilqr_sync", rc);        // the previous upload has left the staging slab
     {
         int jobs = 0, kps = 0;
         activeDifferentiator->CountJobs(keypoint_generator->keypoints, jobs, kps);
@@ -165,6 +182,7 @@ void iLQR_GPU::GenerateDerivatives()
     if (!staging.complete()) { std::fprintf(stderr, "FD staging: %d of %d jobs, %d of %d nominal rows filled\n", staging.njobs, staging.plan_jobs, staging.nnom, staging.plan_noms); std::exit(1); }
     rc = kpilqr_upload_fd_slab(ctx, staging.slab, staging.njobs, staging.nnom, eps);
     if (rc) fatal("kpilqr_upload_fd_slab", rc);
+    }
     if ((rc = kpilqr_fd_difference(ctx))) fatal("kpilqr_fd_difference", rc);
     if (!fused_active && (rc = kpilqr_interpolate(ctx))) fatal("kpilqr_interpolate", rc);
     if (filteringMethod != "none") {                              // Optimiser.cpp:105-107

@@ -68,6 +68,8 @@ private:
     std::vector<double> alphas, w_run, w_term, ctrl_lim;
     // pinned staging (kpilqr_host_alloc): FD jobs, residuals + Jacobians, nominal controls, gains
     FDStaging staging;
+    char *kp_slab = nullptr;                 // key-point ordered FD payload (fused sweeps): one pinned slab of entry records
+    size_t kp_slab_bytes = 0;
     double *host_r = nullptr, *host_rx = nullptr, *host_ru = nullptr, *host_unom = nullptr, *host_K = nullptr, *host_k = nullptr;
     void free_pinned();
     bool fused_active = false, recreate_ctx = false;
