@@ -260,6 +260,13 @@ int  kpilqr_trajectory_cost(kpilqr_ctx *ctx, double *cost /*[batch]*/);
  * (results stay on the device, KPILQR_BUF_STATUS / KPILQR_BUF_DELTA_J). */
 int  kpilqr_backward(kpilqr_ctx *ctx, const double *lambda, int pd_check_stride,
                      int *status, double *delta_J);
+/* Diagnostic: the backward pass of a KPILQR_FLAG_FUSED context with counters.  The explicit inverse the reference forms at
+ * every step (iLQR.cpp:597-600) is carried along the sweep and refreshed on the matrix core; how much work a step needs is
+ * data dependent (and a launch lasts as long as its slowest wavefront).  hist [batch][6] = steps whose inverse came from:
+ * [0] the third-order refresh alone, [1..3] that plus 1 / 2 / 3 second-order steps, [4] the LDL' factorisation (first step,
+ * every pd_check_stride-th step, re-seeds), [5] Eigen's pivoted LDLT restated (indefinite Q_uu + lambda I on an unchecked
+ * step).  K, k, delta_J, status as kpilqr_backward; lambda as last given.  Synchronous. */
+int  kpilqr_backward_stats(kpilqr_ctx *ctx, int pd_check_stride, int *hist);
 /* K [batch][T][n][m] (column-major m x n), k [batch][T][m]; either may be NULL. */
 int  kpilqr_download_gains(kpilqr_ctx *ctx, double *K, double *k);
 

@@ -202,3 +202,22 @@ def test_streamed_iteration_with_the_kp_ordered_payload(fused):
             e.iterate_streamed(eps=p["eps"], lam=lam, K=K, k=k, cost_pred=cp, status=st, nchunks=nchunks)    # payload resident: reused
             e.sync()
             assert np.array_equal(K, ref["K"]) and np.array_equal(cp, ref["cost"])
+
+
+def test_backward_stats_histogram():
+    """kpilqr_backward_stats: every step of every trajectory is counted once, the gains are those of kpilqr_backward, and a
+    small lambda needs more refresh work than a large one."""
+    p = synth.make_problem(task="panda_reaching", T=600, batch=3, min_N=5)
+    with Engine(p["dof"], p["m"], p["T"], p["nr"], batch=3, fused=True) as e:
+        synth.upload(e, p, kp_ordered=True)
+        extra = {}
+        for lam in (1e-4, 10.0):
+            st, dJ = e.backward(lam, 100)
+            K0, k0 = e.gains()
+            h = e.backward_stats(100)
+            K1, k1 = e.gains()
+            assert np.all(st == 0) and np.all(h.sum(1) == p["T"]), h
+            assert np.all(h[:, 4] >= p["T"] // 100) and np.all(h[:, 5] == 0)      # the checked steps factorise; nothing indefinite
+            assert relerr(K1, K0) < 1e-12 and relerr(k1, k0) < 1e-12
+            extra[lam] = int((h[:, 1] + 2 * h[:, 2] + 3 * h[:, 3]).sum())
+        assert extra[1e-4] >= extra[10.0]

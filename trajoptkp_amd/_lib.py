@@ -26,7 +26,7 @@ SYMBOLS = [
     "kpilqr_filter_dynamics", "kpilqr_dof_importance",
     "kpilqr_comm_unique_id", "kpilqr_comm_init", "kpilqr_allreduce_linesearch",
     "kpilqr_fd_slab_layout", "kpilqr_upload_fd_slab", "kpilqr_iterate_streamed", "kpilqr_resize",
-    "kpilqr_keypoint_error_test", "kpilqr_fd_kp_layout", "kpilqr_upload_fd_kp",
+    "kpilqr_keypoint_error_test", "kpilqr_fd_kp_layout", "kpilqr_upload_fd_kp", "kpilqr_backward_stats",
 ]
 
 
@@ -130,6 +130,7 @@ def load():
     L.kpilqr_keypoint_error_test.argtypes = [vp, C.c_int, vp, C.c_int, C.c_double, vp]
     L.kpilqr_fd_kp_layout.argtypes = [vp, C.c_int, C.POINTER(FdkpLayout)]
     L.kpilqr_upload_fd_kp.argtypes = [vp, vp, C.c_int, C.c_double]
+    L.kpilqr_backward_stats.argtypes = [vp, C.c_int, vp]
     for s in SYMBOLS:
         getattr(L, s)          # raises AttributeError if the .so lacks a declared symbol
     _lib = L

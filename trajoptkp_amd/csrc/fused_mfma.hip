@@ -235,11 +235,16 @@ __device__ __forceinline__ void lds_store4(double *t, int lane, const d4 &v);
 // waits for them.  (In the general form the crossing sits in a per-lane branch, behind which the compiler has to wait for
 // every memory operation in flight at the next load-dependent instruction: ~1 us of HBM latency per crossing, 7.5 against
 // 4.5 ms per sweep with a key-point at every step.)
-template <int N, int M, bool PC, bool RU0 = false, bool SIDE = false, bool RAW = false, bool UNI = false>
+// STATS (diagnostic instantiation, kpilqr_backward_stats): counts per trajectory what every step did to obtain
+// (Quu + lambda I)^-1 -- hist[0] third-order refresh only, [1..3] plus that many second-order steps, [4] LDL' factorisation
+// (first step, checked steps, re-seeds), [5] the pivoted slow path -- into hist [batch][6].
+template <int N, int M, bool PC, bool RU0 = false, bool SIDE = false, bool RAW = false, bool UNI = false, bool STATS = false>
 __device__ __forceinline__ void backward_fused_body(double *sh, const double *pcbuf, int *sflag, RecLayout L, FusedArgs F, int T,
                 const double *__restrict__ lambda, int pd_stride, double *__restrict__ Kout, double *__restrict__ kout,
-                double *__restrict__ delta_J, int *__restrict__ status)
+                double *__restrict__ delta_J, int *__restrict__ status, int *__restrict__ hist = nullptr)
 {
+    int hcnt[6] = {0, 0, 0, 0, 0, 0};
+    (void)hcnt;
     constexpr int NCZ = (N + 1 + 3) / 4;
     constexpr int NCU = (M + 3) / 4;
     constexpr int n = N, m = M;
@@ -514,7 +519,9 @@ __device__ __forceinline__ void backward_fused_body(double *sh, const double *pc
         //      (it gives the PD verdict of :587-595), and whenever the residual is too large to converge fast.
         bool done = false;
 #if KP_NS
-        const bool refreshed = haveX && !check_pd && kp_inverse_refresh_n<NCU>(Qr, Iu, Xinv, Xprev, m);    // Xinv, Xprev: NEGATED inverses
+        int ns_steps = 0;
+        const bool refreshed = haveX && !check_pd && kp_inverse_refresh_n<NCU>(Qr, Iu, Xinv, Xprev, m, STATS ? &ns_steps : nullptr);    // Xinv, Xprev: NEGATED inverses
+        if constexpr (STATS) { if (refreshed) hcnt[ns_steps < 0 ? 0 : ns_steps > 3 ? 3 : ns_steps]++; }
 #else
         const bool refreshed = false;
 #endif
@@ -567,7 +574,9 @@ __device__ __forceinline__ void backward_fused_body(double *sh, const double *pc
                 Xprev = Xinv;
                 haveX = true;
 #endif
+                if constexpr (STATS) hcnt[4]++;
             } else {
+                if constexpr (STATS) hcnt[5]++;
                 double *wa = sh + FLDS_SLOW, *wx = wa + 256, *wt = wx + 256;
                 int *tr = (int *)(wt + 16);
                 if (lane == 0) kp_slow_ldlt_inverse(L.m, sh + FLDS_Q, FMS, wa, wx, wt, tr);
@@ -710,6 +719,19 @@ __device__ __forceinline__ void backward_fused_body(double *sh, const double *pc
                    Kout[(size_t)b * T * m * n + 2] = (double)(__builtin_readcyclecounter() - cyc_all0); Kout[(size_t)b * T * m * n + 3] = (double)cyc_a; }
 #endif
     if (lane == 0) status[b] = fail;
+    if constexpr (STATS) {
+        if (lane == 0) for (int i = 0; i < 6; i++) hist[(size_t)b * 6 + i] = hcnt[i];
+    }
+}
+
+template <int N, int M>
+__global__ void __launch_bounds__(64)
+k_backward_fused_stats(RecLayout L, FusedArgs F, int T, const double *__restrict__ lambda,
+                       int pd_stride, double *__restrict__ Kout, double *__restrict__ kout,
+                       double *__restrict__ delta_J, int *__restrict__ status, int *__restrict__ hist)
+{
+    __shared__ __attribute__((aligned(16))) double sh[FLDS_TOTAL];
+    backward_fused_body<N, M, false, false, false, false, false, true>(sh, nullptr, nullptr, L, F, T, lambda, pd_stride, Kout, kout, delta_J, status, hist);
 }
 
 // The one-wave backward sweep comes in two forms, launched back to back like the forward sweep's: UNI for key-point sets in
@@ -1957,6 +1979,17 @@ hipError_t launch_backward_fused(Ctx *c, int pd_stride, bool raw)
 #undef LAUNCH2
 #undef LAUNCH3
 #undef LAUNCH4
+    return hipErrorInvalidValue;
+}
+
+// diagnostic: the one-wave sweep (general form, reads kpc) with the refresh histogram
+hipError_t launch_backward_fused_stats(Ctx *c, int pd_stride, int *hist_dev)
+{
+    const int n = c->n, m = c->d.m;
+    const FusedArgs F = fused_args(c);
+#define KP_X(NN, MM) if (n == NN && m == MM) { hipLaunchKernelGGL((k_backward_fused_stats<NN, MM>), dim3(c->d.batch), dim3(64), 0, c->stream, c->L, F, c->d.T, c->lambda, pd_stride, c->K, c->k, c->delta_J, c->status, hist_dev); return hipGetLastError(); }
+    KP_T1_SHAPES(KP_X)
+#undef KP_X
     return hipErrorInvalidValue;
 }
 

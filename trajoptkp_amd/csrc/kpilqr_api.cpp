@@ -884,6 +884,29 @@ int kpilqr_backward(kpilqr_ctx *c, const double *lambda, int pd_check_stride, in
     return KPILQR_OK;
 }
 
+// Diagnostic (bench's lambda sweep): the backward pass of a fused context in its instrumented form.  hist [batch][6] = number
+// of steps whose (Quu + lambda I)^-1 came from: the third-order Newton-Schulz refresh alone, that plus 1 / 2 / 3 second-order
+// steps, the LDL' factorisation (first step, checked steps, re-seeds), the pivoted slow path.  Gains, delta_J and status
+// are written as by kpilqr_backward.  Uses the lambda already resident.  Synchronous.
+int kpilqr_backward_stats(kpilqr_ctx *c, int pd_check_stride, int *hist)
+{
+    if (!c || !hist) return KPILQR_ERR_ARG;
+    KP_ENTER(c);
+    if (!c->fused) return set_err(c, KPILQR_ERR_STATE, "kpilqr_backward_stats: fused contexts only");
+    if (pd_check_stride < 1) return set_err(c, KPILQR_ERR_ARG, "pd_check_stride must be >= 1");
+    int rc = check_fused(c);
+    if (rc) return rc;
+    rc = ensure_kpc(c);
+    if (rc) return rc;
+    if (!c->kpc_valid) { rc = difference_to_kpc(c); if (rc) return rc; }
+    const size_t bytes = (size_t)c->d.batch * 6 * sizeof(int);
+    rc = ensure_stage(c, bytes);
+    if (rc) return rc;
+    KP_HIP(c, launch_backward_fused_stats(c, pd_check_stride, (int *)c->stage));
+    KP_HIP(c, hipMemcpyAsync(hist, c->stage, bytes, hipMemcpyDeviceToHost, c->stream));
+    return sync_and_report(c);
+}
+
 int kpilqr_download_gains(kpilqr_ctx *c, double *K, double *k)
 {
     if (!c) return KPILQR_ERR_ARG;

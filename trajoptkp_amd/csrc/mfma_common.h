@@ -129,9 +129,11 @@ __device__ __forceinline__ bool kp_inverse_refresh_p(const d4 &Qr, const d4 &Iu,
 // The same on the NEGATED inverse N = -(Quu + lambda I)^-1 (what the fused backward sweep carries): the residual
 // R = I - Q X = I + Q N is the MFMA accumulator started at I -- no VALU between the products of the chain -- and the gains
 // K = -X = N Quz come out with their sign.  Everything else as kp_inverse_refresh_p (N (I + R + R^2), extrapolated start).
+// steps (optional): the number of second-order steps that followed the third-order one (0..3; -1 when it gave up).
 template <int NCU>
-__device__ __forceinline__ bool kp_inverse_refresh_n(const d4 &Qr, const d4 &Iu, d4 &Ninv, d4 &Nprev, int m)
+__device__ __forceinline__ bool kp_inverse_refresh_n(const d4 &Qr, const d4 &Iu, d4 &Ninv, d4 &Nprev, int m, int *steps = nullptr)
 {
+    if (steps) *steps = 0;
     d4 N0 = Ninv;
     N0.x = __builtin_fma(2.0, Ninv.x, -Nprev.x);
     if (NCU > 1) N0.y = __builtin_fma(2.0, Ninv.y, -Nprev.y);
@@ -146,8 +148,9 @@ __device__ __forceinline__ bool kp_inverse_refresh_n(const d4 &Qr, const d4 &Iu,
     if (NCU > 3) rmax = fmax(rmax, fabs(R.w));
     const double e = (double)m * rmax;
     if (__builtin_amdgcn_ballot_w64(!(e < 2.0e-5)) != 0) {
-        if (__builtin_amdgcn_ballot_w64(!(e < 0.11)) != 0) return false;
+        if (__builtin_amdgcn_ballot_w64(!(e < 0.11)) != 0) { if (steps) *steps = -1; return false; }
         const int iters = (__builtin_amdgcn_ballot_w64(e >= 1.3e-2) != 0) ? 3 : (__builtin_amdgcn_ballot_w64(e >= 1.7e-4) != 0) ? 2 : 1;
+        if (steps) *steps = iters;
         R = kp_P<NCU>(Qr, Y, Iu); Y = kp_P<NCU>(Y, R, Y);
         if (iters > 1) {
             R = kp_P<NCU>(Qr, Y, Iu); Y = kp_P<NCU>(Y, R, Y);

@@ -296,6 +296,12 @@ class Engine:
         self.sync()
         return status, dJ
 
+    def backward_stats(self, pd_stride=100):
+        """kpilqr_backward_stats: the instrumented backward sweep of a fused context -> hist [batch][6] (see include/kpilqr.h)."""
+        h = np.zeros((self.batch, 6), np.int32)
+        self._ck(self._L.kpilqr_backward_stats(self._h, int(pd_stride), _ptr(h)))
+        return h
+
     def gains(self):
         K = np.zeros((self.batch, self.T, self.n, self.m)); k = np.zeros((self.batch, self.T, self.m))
         self._ck(self._L.kpilqr_download_gains(self._h, _ptr(K), _ptr(k)))
