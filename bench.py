@@ -634,9 +634,12 @@ def main():
                 for key, (kind, task, Ts, Bs, ks) in {
                         "configs[1] panda_reaching T=3000 batch=1": ("set_interval", "panda_reaching", 3000, 1, 10),
                         "configs[2] panda_pushing T=3000 adaptive_jerk batch=64": ("adaptive_jerk", "panda_pushing", 3000, 64, 5),
-                        "configs[4] high_dof_push n=62 T=5000 iterative_error batch=128 (one GPU's share of 1024)": ("iterative_error", "high_dof_push", 5000, 128, 3)}.items():
+                        "configs[4] high_dof_push n=62 T=5000 iterative_error batch=128 (one GPU's share of 1024)": ("iterative_error", "high_dof_push", 5000, 128, 3),
+                        # not a BASELINE config: the reference's humanoid (TaskConfigs/locomotion/humanoid.yaml, 21 actuators) on the
+                        # wide-control tiled sweeps (tiled_wide.hip) instead of the VALU / LDS kernels
+                        "humanoid n=54 m=21 T=1500 set_interval batch=64": ("set_interval", "humanoid", 1500, 64, 3)}.items():
                     try:
-                        ps, ps0, ds = build_problem(kind, Bs, Ts, 5, task)
+                        ps, ps0, ds = build_problem(kind, Bs, Ts, 5, task, distinct=False)
                         rs = time_config(torch, stream, local_rank, ps, ks, 1, True, False)
                         pc = parity_check(ps0, rs["eng"], min(ps0["batch"], 2), tiled=kind != "set_interval")
                         rs["eng"].close()

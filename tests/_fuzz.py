@@ -11,7 +11,8 @@ from oracle import oracle as orc
 from oracle import pipeline
 from trajoptkp_amd import Engine, synth
 
-TASKS = ["panda_reaching", "acrobot", "hopper", "pentabot", "panda_pushing", "walker", "arm8", "arm5x2", "high_dof_push"]
+TASKS = ["panda_reaching", "acrobot", "hopper", "pentabot", "panda_pushing", "walker", "arm8", "arm5x2", "high_dof_push",
+         "quadruped", "humanoid_fixed"]
 ENV_KEYS = ("KPILQR_FUSED_WAVES", "KPILQR_FUSED_FWD_WAVES", "KPILQR_TILED_A4", "KPILQR_TILED_A6")
 TOL = 1e-8
 
@@ -23,7 +24,7 @@ def relerr(a, b):
 def draw_case(rng, case):
     """Parameters of case number `case` (consumes the generator in a fixed order, so a seed names a sweep)."""
     task = TASKS[case % len(TASKS)]
-    big = task == "high_dof_push"
+    big = task in ("high_dof_push", "humanoid_fixed", "quadruped")
     c = dict(case=case, task=task)
     c["T"] = int(rng.choice([2, 3, 5, 17, 64, 129, 300] if big else [2, 3, 5, 17, 64, 129, 300, 777, 1500]))
     c["batch"] = int(rng.integers(1, 4))

@@ -11,7 +11,7 @@ import _fuzz
 
 pytestmark = pytest.mark.gpu
 
-FUZZ_SEED, FUZZ_CASES, FUZZ_SLICES = 20261004, 216, 8       # 216 = 24 rounds over the nine task shapes
+FUZZ_SEED, FUZZ_CASES, FUZZ_SLICES = 20261004, 220, 10      # 220 = 20 rounds over the eleven task shapes
 
 
 @pytest.mark.parametrize("part", range(FUZZ_SLICES))

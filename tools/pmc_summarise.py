@@ -21,6 +21,9 @@ def key_of(name):
     # once: only the uniform form runs the bench workload (set_interval key-points)
     if re.search(r"k_forward_fused(_excl)?<\d+, \d+, (true|false), false>", name):
         return None
+    # the same for the one-wave backward sweep since round 3 (<N, M, RU0, RAW, UNI>: UNI = false leaves at once here)
+    if re.search(r"k_backward_fused(_excl)?<\d+, \d+, (true|false), (true|false), false>", name):
+        return None
     for k, v in KEYS.items():
         if k in name:
             return v
@@ -48,7 +51,7 @@ def counters(passdir):
 fetch, nl = counters("pmc_fetch")
 write, _ = counters("pmc_write")
 traffic = {"note": "rocprofv3 --pmc FETCH_SIZE and --pmc WRITE_SIZE in SEPARATE passes over `python bench.py --no-cpu-baseline "
-                   "--no-secondary --steps 3 --warmup 1` (Panda reaching, B=1024, T=3000, fused sweeps); KB per launch, mean over launches. "
+                   "--no-secondary --steps 3 --warmup 1` (Panda reaching, B=1024 distinct seeds, T=3000, fused sweeps, key-point ordered FD payload differenced inside the backward sweep); KB per launch, mean over launches. "
                    "gfx950 correction (MI355X_MICROARCH.md, HBM): FETCH_SIZE counts 64 B per 128-B request -> x2 (calibrated in round 1 on a "
                    "kernel with exactly known reads); WRITE_SIZE is exact.",
            "workload": {"task": "panda_reaching", "T": T, "batch": B}, "kernels": {}}

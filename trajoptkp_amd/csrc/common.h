@@ -228,6 +228,11 @@ size_t backward_tiled_lds_bytes(int nt);
 bool forward_tiled_supported(int n, int m, int n_alpha, int nt_min);
 hipError_t launch_forward_tiled(Ctx *c, double *U_alpha_dev);
 bool tiled_a4_supported(int n, int m, int dof, int T, int stride);
+// tiled_wide.hip: the same sweeps with the control block over up to two tiles (8 < m <= 32 backward, 16 < m <= 32 forward)
+bool backward_wide_supported(int n, int m, int nt_min);
+hipError_t launch_backward_wide(Ctx *c, int pd_stride);
+bool forward_wide_supported(int n, int m, int n_alpha, int nt_min);
+hipError_t launch_forward_wide(Ctx *c, double *U_alpha_dev);
 // fused_mfma.hip: a4 + a6 evaluated inside the sweeps (n+2 <= 16)
 bool fused_supported(int n, int m, int nr, int dof, int T, int stride, int n_alpha);
 int backward_fused_form(const Ctx *c);

@@ -248,9 +248,11 @@ static int select_variants(kpilqr_ctx *c)
     const bool generic = (dims->flags & KPILQR_FLAG_GENERIC_KERNELS) != 0;
     const bool force_tiled = (dims->flags & KPILQR_FLAG_TILED_KERNELS) != 0;
     c->bwd_variant = (!generic && !force_tiled && backward_mfma_supported(c->n, dims->m)) ? "mfma_f64_t1"
-                   : (!generic && backward_tiled_supported(c->n, dims->m, c->tune.tiled_nt_min)) ? "mfma_f64_tiled" : "generic_lds";
+                   : (!generic && backward_tiled_supported(c->n, dims->m, c->tune.tiled_nt_min)) ? "mfma_f64_tiled"
+                   : (!generic && backward_wide_supported(c->n, dims->m, c->tune.tiled_nt_min)) ? "mfma_f64_wide" : "generic_lds";
     c->fwd_variant = (!generic && !force_tiled && forward_mfma_supported(c->n, dims->m, dims->n_alpha)) ? "mfma_f64_t1"
-                   : (!generic && forward_tiled_supported(c->n, dims->m, dims->n_alpha, c->tune.tiled_nt_min)) ? "mfma_f64_tiled" : "generic_lds";
+                   : (!generic && forward_tiled_supported(c->n, dims->m, dims->n_alpha, c->tune.tiled_nt_min)) ? "mfma_f64_tiled"
+                   : (!generic && forward_wide_supported(c->n, dims->m, dims->n_alpha, c->tune.tiled_nt_min)) ? "mfma_f64_wide" : "generic_lds";
     if ((dims->flags & KPILQR_FLAG_FUSED) && !generic && !force_tiled &&
         fused_supported(c->n, dims->m, dims->nr, dims->dof, dims->T, c->L.stride, dims->n_alpha)) {
         c->fused = true;
@@ -867,6 +869,7 @@ static int run_backward(kpilqr_ctx *c, int pd_stride)
     }
     if (strcmp(c->bwd_variant, "mfma_f64_t1") == 0) KP_HIP(c, launch_backward_mfma(c, pd_stride));
     else if (strncmp(c->bwd_variant, "mfma_f64_tiled", 14) == 0) KP_HIP(c, launch_backward_tiled(c, pd_stride));
+    else if (strcmp(c->bwd_variant, "mfma_f64_wide") == 0) KP_HIP(c, launch_backward_wide(c, pd_stride));
     else KP_HIP(c, launch_backward_generic(c, pd_stride));
     return KPILQR_OK;
 }
@@ -968,6 +971,7 @@ static int run_forward(kpilqr_ctx *c, double *U_dev)
     }
     if (strcmp(c->fwd_variant, "mfma_f64_t1") == 0) KP_HIP(c, launch_forward_mfma(c, U_dev));
     else if (strncmp(c->fwd_variant, "mfma_f64_tiled", 14) == 0) KP_HIP(c, launch_forward_tiled(c, U_dev));
+    else if (strcmp(c->fwd_variant, "mfma_f64_wide") == 0) KP_HIP(c, launch_forward_wide(c, U_dev));
     else KP_HIP(c, launch_forward_generic(c, U_dev));
     return KPILQR_OK;
 }

@@ -36,6 +36,15 @@ TASKS = {
     # an under-actuated 5-joint arm with 2 motors: a shape with no instantiation of its own (tiled catch-all)
     "arm5x2": dict(dof=5, m=2, nr=3, dt=0.01, lim=[5.0] * 2,
                    w_run=[1.0, 0.1, 0.01], w_term=[100.0, 1.0, 0.1]),
+    # TaskConfigs/locomotion/humanoid.yaml:14-15: 21 actuators, 27 DoFs with the free root (n = 54: four state tiles, two
+    # control tiles); weights synthetic.  humanoid_fixed: the same without the root (n = 42: three tiles)
+    "humanoid": dict(dof=27, m=21, nr=8, dt=0.005, lim=[1.0] * 21,
+                     w_run=[1.0, 0.5, 0.5, 0.1, 0.1, 0.01, 0.01, 0.01], w_term=[100.0, 50.0, 50.0, 1.0, 1.0, 0.1, 0.1, 0.1]),
+    "humanoid_fixed": dict(dof=21, m=21, nr=6, dt=0.005, lim=[1.0] * 21,
+                           w_run=[1.0, 0.5, 0.1, 0.1, 0.01, 0.01], w_term=[100.0, 50.0, 1.0, 1.0, 0.1, 0.1]),
+    # a 12-actuator quadruped (9 < num_ctrl <= 16: one control tile, wide backward kernel)
+    "quadruped": dict(dof=18, m=12, nr=6, dt=0.005, lim=[1.0] * 12,
+                      w_run=[1.0, 0.5, 0.1, 0.1, 0.01, 0.01], w_term=[100.0, 50.0, 1.0, 1.0, 0.1, 0.1]),
     # a fully actuated 8-joint arm: num_ctrl = 8, the largest the padded tiled backward kernel takes
     "arm8": dict(dof=8, m=8, nr=6, dt=0.008, lim=[50.0] * 8,
                  w_run=[1.0, 0.5, 0.1, 0.1, 0.01, 0.01], w_term=[100.0, 50.0, 1.0, 1.0, 0.1, 0.1]),
