@@ -1310,12 +1310,16 @@ __device__ __forceinline__ void forward_fused_body(RecLayout L, FusedArgs F, int
                const double *__restrict__ alphas, double *__restrict__ cost_pred, double *__restrict__ U_alpha)
 {
     __shared__ __attribute__((aligned(16))) double shA[16 * 17], shB[16 * 17];
-    const int n = L.n, m = L.m;
+    // The chunk counts name the shape (KP_T1_SHAPES: (14,7) -> <4,2>, (4,1) -> <2,1>, (12,3) -> <4,1>, (10,3) -> <3,1>; the
+    // launcher dispatches nothing else), so n and m are compile-time constants here as in the backward sweep: the row of k in
+    // the gain operand, the chunk count of r_x dx and the row masks cost no selects or scalar branches per step.
+    constexpr int n = (NCZ == 4 && NCU == 2) ? 14 : (NCZ == 2) ? 4 : (NCZ == 4) ? 12 : 10;
+    constexpr int m = (NCZ == 4 && NCU == 2) ? 7 : (NCZ == 2) ? 1 : 3;
     const int lane = threadIdx.x, c = lane & 15, q = lane >> 4;
     const int b = blockIdx.x;
     const int nr = F.nr;
-    const int strideB = 3 * L.n * 8;                               // bytes of one key-point entry of kpc: three columns
-    const int ncx = (n + 3) >> 2;
+    constexpr int strideB = 3 * n * 8;                             // bytes of one key-point entry of kpc: three columns
+    constexpr int ncx = (n + 3) >> 2;
 
     // this trajectory's key-point entries [E0, E0 + NE) of kpc; KpU: entries per DoF list when all lists are the same (UNI)
     const int E0 = F.kp_offsets[(size_t)b * F.dof], NE = F.kp_offsets[(size_t)(b + 1) * F.dof] - E0;
@@ -1345,7 +1349,7 @@ __device__ __forceinline__ void forward_fused_body(RecLayout L, FusedArgs F, int
         }
         wcur[r] = (row < nr) ? F.w_run[row] : 0.0;
     }
-    const int rn = n >> 2;                                                  // the register of row n (k)
+    constexpr int rn = n >> 2;                                              // the register of row n (k)
     const int okn = (q == (n & 3) && c < m) ? 8 * c : OOBF;
     const double my_alpha = (c < n_alpha) ? alphas[c] : 0.0;
     d4 Z;
@@ -1488,7 +1492,7 @@ __device__ __forceinline__ void forward_fused_body(RecLayout L, FusedArgs F, int
         // issue, so independent work is placed behind each chain before its consumer:
         //   U chain | A dx chain | clamp (U ready) | B du | r_u du | r_x dx | a4 of step t+1 (VALU + LDS) | cost (Jx ready)
         d4 Yk = cur.YkK;                               // + k in row n (the lanes of the other rows hold 0): ONE load, not a tile of four
-        if (rn == 3) Yk.w += cur.kk; else if (rn == 2) Yk.z += cur.kk; else if (rn == 1) Yk.y += cur.kk; else Yk.x += cur.kk;
+        if constexpr (rn == 3) Yk.w += cur.kk; else if constexpr (rn == 2) Yk.z += cur.kk; else if constexpr (rn == 1) Yk.y += cur.kk; else Yk.x += cur.kk;
         const d4 ub = cur.ub;
         d4 U = PS<NCZ>(Yk, Z, ub);                     // u_nom + K dx + alpha k   (:879)
         __builtin_amdgcn_sched_barrier(0);
@@ -1514,7 +1518,7 @@ __device__ __forceinline__ void forward_fused_body(RecLayout L, FusedArgs F, int
         Zn = PS<NCU>(Yb, dU, Zn);                      // + B du: the next state
         d4 Ju = zero;                                  // RU0: r_u = 0, the control residual term vanishes
         if constexpr (!RU0) Ju = PS<NCU>(cur.RuT, dU, zero);
-        const d4 Jx = PR(cur.RxT, Z, zero, ncx);
+                const d4 Jx = PS<ncx>(cur.RxT, Z, zero);
         Z = Zn;
         __builtin_amdgcn_sched_barrier(0);
         cur.RxT.x = fblds(rRx, oRxT[0], sRx); cur.RxT.y = fblds(rRx, oRxT[1], sRx); cur.RxT.z = fblds(rRx, oRxT[2], sRx); cur.RxT.w = fblds(rRx, oRxT[3], sRx);
