@@ -2,27 +2,29 @@
 """bench.py -- iLQR iterations/sec on the keypoint-iLQR hot path (BASELINE.json metric).
 
 One "step" = one whole GPU-side iLQR iteration for every trajectory of the batch:
-    fd_difference (a2) -> interpolate (a4) -> cost_derivs (a6) -> backward pass (a7, one pass at a valid lambda)
+    FD differencing (a2) -> interpolation (a4) -> cost derivatives (a6) -> backward pass (a7, one pass at a valid lambda)
     -> linearised forward pass over the 6 line-search alphas (a8)
-By default a4 and a6 run INSIDE the two sweeps (KPILQR_FLAG_FUSED: three launches per iteration, A/B/l_* never written
-to HBM); `--unfused` times the materialising five-kernel pipeline.  All inputs (host FD results, residuals and their
-Jacobians, nominal controls) are resident in HBM when the timed region starts.
+By default (KPILQR_FLAG_FUSED) that is TWO launches: the backward sweep differences the key-point ordered FD payload at its
+segment crossings and evaluates a4 and a6 inside, the forward sweep reads the columns it leaves behind (A, B, l_* never
+written to HBM, no step records); `--unfused` times the materialising five-kernel pipeline.  All inputs (host FD results,
+residuals and their Jacobians, nominal controls) are resident in HBM when the timed region starts.
 
 Workload: BASELINE configs[3] -- Franka Panda 7-DoF reaching, T=3000, set-interval key-points every 5 steps, a GLOBAL
-batch of 1024 independent trajectories (MPC replans) sharded in contiguous blocks over the N ranks (`--global-batch`,
-strong scaling: N=1 runs all 1024 on one GPU).  `--weak` keeps `--batch` trajectories PER GPU instead.
+batch of 1024 independent trajectories (MPC replans) with 1024 DISTINCT seeds, sharded in contiguous blocks over the N ranks
+(`--global-batch`, strong scaling: N=1 runs all 1024 on one GPU).  `--weak` keeps `--batch` trajectories PER GPU instead.
 
-    python bench.py --gpus N --steps K --warmup W
+    python bench.py --gpus N --steps K --warmup W        (N > 1 without a launcher: starts the N ranks itself)
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...
 
 Rank 0 prints ONE JSON line.  Besides the contract's keys it carries
   roofline        dominant kernel (backward sweep): the binding resource is the SIMD's FP64 matrix pipe, so `bound` is
                   "mfma" (algorithmic a7 flops / HIP-event launch time vs the FP64 MFMA peak); `hbm` inside it gives the
                   HBM fractions (the kernel's own compulsory bytes, the PMC traffic, and SURVEY 8(d)'s riccati figure)
-  parity_check    K, k, predicted costs of the unique seeds against the CPU oracle (outside the timed region)
+  parity_check    K, k, predicted costs of the first seeds against the CPU oracle (outside the timed region)
+  lambda_sweep    both sweeps over the reference's regularisation range and on a mixed batch, with the refresh histogram
   pcie_inclusive  SURVEY 8(d): the same iteration with the FD payload / residuals re-uploaded and K,k downloaded every
                   iteration (kpilqr_iterate_streamed), full payload and resident-Jacobian form           (N=1 only)
-  secondary_configs  BASELINE configs[1], [2], [4] with their own roofline objects                         (N=1 only)
+  secondary_configs  BASELINE configs[1], [2], [4] (and the humanoid shape) with their own roofline objects (N=1 only)
   strong_scaling_projection  configs[3] shards (512 / 256 / 128 trajectories) timed on this one GPU, x N     (N=1 only)
   materialising_pipeline, cpu_baseline (the CPU oracle = line-faithful port, timed on this box's host cores; N=1 only)
 """

@@ -50,11 +50,13 @@ typedef struct {
 #define KPILQR_FLAG_TILED_KERNELS   2   /* prefer the LDS-tiled MFMA kernels even when one tile would do */
 #define KPILQR_FLAG_FUSED           4   /* n+2 <= 16 only: kpilqr_backward / kpilqr_forward_linear / kpilqr_iterate
                                            evaluate the interpolation (a4) and the cost derivatives (a6) inside the
-                                           sweeps, from the key-point columns written by kpilqr_fd_difference and the
-                                           uploaded residuals; A, B, l_* are then NOT materialised for every step
-                                           (kpilqr_interpolate / kpilqr_cost_derivs still do that on request, and the
-                                           set_AB / set_cost_derivs hooks do not feed the fused sweeps).  Needs
-                                           canonical key-points: per DoF strictly increasing, first 0, last T-1.
+                                           sweeps, from the differenced key-point columns (a compact column store; with
+                                           the key-point ordered payload of kpilqr_upload_fd_kp and one wavefront per
+                                           trajectory the backward sweep even does the differencing itself) and the
+                                           uploaded residuals; A, B, l_* are then NOT materialised and the context holds
+                                           NO step records (kpilqr_interpolate / kpilqr_cost_derivs / get_AB allocate and
+                                           fill them on request; the set_AB / set_cost_derivs hooks do not feed the fused
+                                           sweeps).  Needs canonical key-points: per DoF strictly increasing, first 0, last T-1.
                                            Faster at every batch size (Panda, T=3000: 170 vs 142 iterations/s for one
                                            trajectory, 102k vs 68k at batch 1024).  On a tiled shape (n+2 > 16) the
                                            library may form only the cost derivatives inside the sweeps (variant
