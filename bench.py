@@ -622,6 +622,13 @@ def main():
             if args.task == "panda_reaching" and not args.generic:
                 try:
                     out["lambda_sweep"] = lambda_sweep(torch, stream, local_rank, p, fused)
+                    if r.get("raw"):
+                        # the kernel as launched also differences the FD payload (a2); the same sweep on a column store that
+                        # is already differenced (what the lambda sweep times) is the a7 kernel proper
+                        ms = out["lambda_sweep"][f"{p['lam']:g}"]["stage_ms"]["backward"]
+                        tf = out["roofline"]["algorithmic_flops_per_launch"] / (ms * 1e-3) / 1e12
+                        out["roofline"]["sweep_on_differenced_columns"] = {"avg_launch_ms": ms, "achieved": tf, "frac": tf / FP64_PEAK_TFLOPS,
+                                                                           "note": "k_backward_fused_excl<..., RAW = false>: no differencing inside"}
                 except Exception as ex:
                     out["lambda_sweep"] = {"error": repr(ex)}
             # ---- PCIe-inclusive rate -------------------------------------------------------------------
@@ -630,6 +637,11 @@ def main():
                     out["pcie_inclusive"] = pcie_inclusive(args.pcie_batch)
                 except Exception as ex:
                     out["pcie_inclusive"] = {"error": repr(ex)}
+                if B_local >= 1024 and args.pcie_batch != 1024:     # the headline batch too (13 GB of pinned host memory)
+                    try:
+                        out["pcie_inclusive_b1024"] = pcie_inclusive(1024, steps=2)
+                    except Exception as ex:
+                        out["pcie_inclusive_b1024"] = {"error": repr(ex)}
             # ---- BASELINE configs[1], [2], [4] ----------------------------------------------------------------------
             if args.task == "panda_reaching" and args.keypoints == "set_interval" and T == 3000 and not args.generic and not args.unfused:
                 sec = {}
