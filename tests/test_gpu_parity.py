@@ -541,12 +541,15 @@ def test_fused_ragged_keypoints_and_dense_keypoints(wave_form):
     check_fused(run_fused(p), p)
 
 
-@pytest.mark.parametrize("T", [1, 2, 3, 7])
+@pytest.mark.parametrize("T", [1, 2, 3, 4, 5, 6, 7, 9, 13])
 def test_fused_tiny_horizons(T, wave_form):
+    """Horizons around the depth of the forward sweep's request pipeline (four register sets: every remainder of T mod 4,
+    horizons shorter than the pipeline), with and without control residuals, key-points every 5 and every 2 steps."""
     if T == 1:
         pytest.skip("the reference's key-point generators need T >= 2")
-    p = synth.make_problem(task="panda_reaching", T=T, batch=2, min_N=5, dense_residuals=True)
-    check_fused(run_fused(p), p)
+    for dense, mn in ((True, 5), (False, 2)):
+        p = synth.make_problem(task="panda_reaching", T=T, batch=2, min_N=mn, dense_residuals=dense)
+        check_fused(run_fused(p), p)
 
 
 def test_fused_full_size_panda_T3000(wave_form):

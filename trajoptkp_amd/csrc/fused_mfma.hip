@@ -49,6 +49,20 @@ typedef unsigned long long u64;
 // not wrap, so the load returns 0 (the store is dropped) without a compare-and-select per access.
 #define BIGOFF 0x40000000
 
+// Latency probe (-DKP_PROBE_SAMEB, tools/build_variant.sh): every workgroup of the one-wave sweeps works on one of eight
+// trajectories, so all of its loads hit in cache -- the sweep time that is left is what the memory system does NOT account for
+// (results are only meaningful for a batch that repeats 8 problems, synth.tile_problem).
+#ifndef KP_FWD_SETS
+#define KP_FWD_SETS 4              // register sets of the one-wave forward sweep (requests run this many steps ahead)
+#endif
+#ifndef KP_PROBE_BWD
+#define KP_PROBE_BWD 0
+#endif
+#ifdef KP_PROBE_SAMEB
+#define KP_BLOCK_TRAJ ((int)(blockIdx.x & 7))
+#else
+#define KP_BLOCK_TRAJ ((int)blockIdx.x)
+#endif
 template <int NC>
 __device__ __forceinline__ d4 PS(const d4 &Y, const d4 &X, d4 acc)
 {
@@ -250,8 +264,10 @@ __device__ __forceinline__ void backward_fused_body(double *sh, const double *pc
     constexpr int n = N, m = M;
     auto wsync = [&]() { if (PC) __builtin_amdgcn_wave_barrier(); else __syncthreads(); };
     const int lane = threadIdx.x & 63, c = lane & 15, q = lane >> 4;
-    const int b = blockIdx.x;
+    const int b = KP_BLOCK_TRAJ;
     const double lam = lambda[b];
+    // (probe builds, -DKP_PROBE_BWD=bits: 1 residual loads, 2 key-point stores, 4 gain stores go to one of eight trajectories)
+    const int bR = (KP_PROBE_BWD & 1) ? (int)(blockIdx.x & 7) : b, bP = (KP_PROBE_BWD & 2) ? (int)(blockIdx.x & 7) : b, bS = (KP_PROBE_BWD & 4) ? (int)(blockIdx.x & 7) : b;
     const int nr = F.nr, ncr = (nr + 3) >> 2;
     constexpr int strideB = 3 * N * 8;                            // bytes of one key-point entry: three columns
 
@@ -276,11 +292,11 @@ __device__ __forceinline__ void backward_fused_body(double *sh, const double *pc
     constexpr int REG_NN = n >> 2;
 
     // this trajectory's key-point entries [E0, E0 + NE): one descriptor over its slice of kpc (and of the raw payload)
-    const int E0 = F.kp_offsets[(size_t)b * F.dof], NE = F.kp_offsets[(size_t)(b + 1) * F.dof] - E0;
+    const int E0 = F.kp_offsets[(size_t)bP * F.dof], NE = F.kp_offsets[(size_t)(bP + 1) * F.dof] - E0;
     __amdgpu_buffer_rsrc_t rT = frsrc(F.kpc + (size_t)E0 * 3 * n, NE * strideB);
-    const double *rb = F.r + (size_t)b * (T + 1) * nr;
-    const double *rxb = F.r_x + (size_t)b * (T + 1) * nr * n;
-    const double *rub = F.r_u + (size_t)b * (T + 1) * nr * m;
+    const double *rb = F.r + (size_t)bR * (T + 1) * nr;
+    const double *rxb = F.r_x + (size_t)bR * (T + 1) * nr * n;
+    const double *rub = F.r_u + (size_t)bR * (T + 1) * nr * m;
 
     struct ResTiles { d4 Rx, R1, Ru; };
     auto load_res = [&](int t, ResTiles &s) {
@@ -295,8 +311,8 @@ __device__ __forceinline__ void backward_fused_body(double *sh, const double *pc
     // ---- column tracker, walking DOWN in time ----------------------------------------------------------
     const int kd = (c < F.dof) ? c : c - F.dof;
     const bool has = !PC && c < n;
-    const int lo = has ? F.kp_offsets[(size_t)b * F.dof + kd] : 0;
-    const int hi = has ? F.kp_offsets[(size_t)b * F.dof + kd + 1] : 0;
+    const int lo = has ? F.kp_offsets[(size_t)bP * F.dof + kd] : 0;
+    const int hi = has ? F.kp_offsets[(size_t)bP * F.dof + kd + 1] : 0;
     int idx = hi - 1;
     int s = has ? F.kp_times[idx] : -1;                       // == T-1 for canonical key-points
     int nb = (has && idx - 1 >= lo) ? F.kp_times[idx - 1] : -1;      // the time of the next segment start, one crossing ahead
@@ -338,7 +354,7 @@ __device__ __forceinline__ void backward_fused_body(double *sh, const double *pc
     (void)pm; (void)pmode; (void)bitA;
     ResTiles cur;
     // UNI: lane offsets of the lane's own DoF list (kd * KpU entries into the slice), the position in the soffset operand
-    const int KpU = F.kp_offsets[(size_t)b * F.dof + 1] - E0;
+    const int KpU = F.kp_offsets[(size_t)bP * F.dof + 1] - E0;
     ColOffsN cu = co, cr = co;                                 // kpc / raw payload
     auto shift = [&](int v, int by) { return v == BIGOFF ? BIGOFF : v + by; };
     if constexpr (UNI) {
@@ -598,8 +614,8 @@ __device__ __forceinline__ void backward_fused_body(double *sh, const double *pc
             Kp.x = -xr[0]; Kp.y = -xr[1]; Kp.z = -xr[2]; Kp.w = -xr[3];
         }
         {
-            __amdgpu_buffer_rsrc_t rK = frsrc(Kout + ((size_t)b * T + t) * m * n, m * n * 8);
-            __amdgpu_buffer_rsrc_t rk = frsrc(kout + ((size_t)b * T + t) * m, m * 8);
+            __amdgpu_buffer_rsrc_t rK = frsrc(Kout + ((size_t)bS * T + t) * m * n, m * n * 8);
+            __amdgpu_buffer_rsrc_t rk = frsrc(kout + ((size_t)bS * T + t) * m, m * 8);
             const double kv[4] = {Kp.x, Kp.y, Kp.z, Kp.w};
 #pragma unroll
             for (int r = 0; r < NCU; r++) {
@@ -1304,6 +1320,31 @@ k_backward_fusedpc_excl(RecLayout L, FusedArgs F, int T, int role_shift, const d
 // ---------------------------------------------------------------------------------------------------------
 // Forward pass.  The column tracker walks UP in time; its tiles (row = A row, col = A column) are turned into
 // the Y operands (row = contraction index) through a padded LDS transpose, off the Z dependency chain.
+// The time loop of the forward sweep by register set: NS consecutive steps with compile-time set indices, and what is left
+// below a full group at the end (MODE 1 ends in the final step, mode 3, at t = T-1; MODE 0 has no final step of its own).
+template <int K, int NS, int MODE, class StepF>
+__device__ __forceinline__ void fwd_steps(StepF &step, int t)
+{
+    step(t, std::integral_constant<int, MODE>{}, std::integral_constant<int, K>{});
+    if constexpr (K + 1 < NS) fwd_steps<K + 1, NS, MODE>(step, t + 1);
+}
+template <int K, int NS, int MODE, class StepF>
+__device__ __forceinline__ void fwd_tail(StepF &step, int t, int T)
+{
+    if constexpr (MODE == 0) {
+        if (t < T) {
+            step(t, std::integral_constant<int, 0>{}, std::integral_constant<int, K>{});
+            if constexpr (K + 1 < NS) fwd_tail<K + 1, NS, 0>(step, t + 1, T);
+        }
+    } else {
+        if (K + 1 == NS || t == T - 1) step(T - 1, std::integral_constant<int, 3>{}, std::integral_constant<int, K>{});
+        else {
+            step(t, std::integral_constant<int, MODE>{}, std::integral_constant<int, K>{});
+            if constexpr (K + 1 < NS) fwd_tail<K + 1, NS, MODE>(step, t + 1, T);
+        }
+    }
+}
+
 template <int NCZ, int NCU, bool RU0 = false, bool UNI = false>
 __device__ __forceinline__ void forward_fused_body(RecLayout L, FusedArgs F, int T, int n_alpha, const double *__restrict__ Kin, const double *__restrict__ kin,
                const double *__restrict__ u_nom, const double *__restrict__ ctrl_lim,
@@ -1316,7 +1357,7 @@ __device__ __forceinline__ void forward_fused_body(RecLayout L, FusedArgs F, int
     constexpr int n = (NCZ == 4 && NCU == 2) ? 14 : (NCZ == 2) ? 4 : (NCZ == 4) ? 12 : 10;
     constexpr int m = (NCZ == 4 && NCU == 2) ? 7 : (NCZ == 2) ? 1 : 3;
     const int lane = threadIdx.x, c = lane & 15, q = lane >> 4;
-    const int b = blockIdx.x;
+    const int b = KP_BLOCK_TRAJ;
     const int nr = F.nr;
     constexpr int strideB = 3 * n * 8;                             // bytes of one key-point entry of kpc: three columns
     constexpr int ncx = (n + 3) >> 2;
@@ -1416,8 +1457,14 @@ __device__ __forceinline__ void forward_fused_body(RecLayout L, FusedArgs F, int
 #pragma unroll
     for (int r = 0; r < 4; r++) if ((c == n || c == n + 1) && 4 * r + q == c) sv[r] = 1.0;
 
-    Tiles nxt;
-    load_tiles(0, nxt);          // step 0
+    // Two register sets: S0 holds the tiles of the even steps, S1 those of the odd ones; step t re-requests ITS set for step
+    // t+2 right behind each tile's last use.  A wavefront's loads return in order and a step is shorter than a trip to HBM
+    // (the sweep ran at one memory latency per step with a single set: 2.66 ms at B = 128 where its arithmetic needs 2.13,
+    // -DKP_PROBE_SAMEB), so the requests have to be two steps ahead of their use.
+    constexpr int NS = KP_FWD_SETS;
+    Tiles S[NS];
+#pragma unroll
+    for (int k = 0; k < NS; k++) load_tiles(k < T ? k : T - 1, S[k]);
 
     // One wavefront per workgroup: LDS accesses of the wave execute in order, so the write -> transposed read
     // pairs below need no barrier.  The Y operands of step t+1 are produced during step t (off the Z chain).
@@ -1467,8 +1514,6 @@ __device__ __forceinline__ void forward_fused_body(RecLayout L, FusedArgs F, int
         if (T > 1) { advance(1); stage_cols(1); }
     }
 
-    // single-buffered tiles: each is re-requested for step t+1 right behind its last use in step t
-    Tiles cur = nxt;
     // one descriptor per array for the whole trajectory; the step (t+1, or t again behind the last one: never used) goes
     // into the loads' scalar offset
     const __amdgpu_buffer_rsrc_t rK = frsrc(Kin + (size_t)b * T * m * n, T * m * n * 8), rk = frsrc(kin + (size_t)b * T * m, T * m * 8),
@@ -1479,13 +1524,18 @@ __device__ __forceinline__ void forward_fused_body(RecLayout L, FusedArgs F, int
     double ev2[8];                                       // the column after the next one (requested a segment ahead)
     double wterm[4] = {0.0, 0.0, 0.0, 0.0};
     (void)up; (void)uks; (void)uke; (void)ukn_v; (void)ev2; (void)wterm;
-    // MODE 0: the general form (per-lane tracker, crossing inside the step); UNI: 1 a step inside a segment, 2 the last step of a
-    // segment (the crossing into the next one, in straight-line code, sits where the general form advances its tracker),
-    // 3 the final step t = T-1 (terminal weights, nothing left to request)
-    auto step = [&](int t, auto mode_tag) __attribute__((always_inline)) {
+    // MODE 0: the general form (per-lane tracker, crossing inside the step); UNI: 1 a step below T-1 -- when it is the last one
+    // of its segment, the crossing into the next segment sits behind a wave-uniform scalar branch where the general form advances
+    // its per-lane tracker; 3 the final step t = T-1 (terminal weights, nothing left to request).
+    // The tile requests stay OUTSIDE every branch and the loop has one body (a pair of steps): a request in flight across a
+    // join of paths that each issued it ends in register copies at the join, and a copy waits for the load (a form with the
+    // crossing step peeled into straight-line code had `s_waitcnt vmcnt(0)` plus 16 moves at the end of every segment).
+    // PAR: the parity of t (which register set the step works on)
+    auto step = [&](int t, auto mode_tag, auto par_tag) __attribute__((always_inline)) {
         constexpr int MODE = decltype(mode_tag)::value;
+        Tiles &cur = S[decltype(par_tag)::value];
         const bool more = MODE == 3 ? false : MODE != 0 ? true : t + 1 < T;
-        const int tn = more ? t + 1 : t;
+        const int tn = MODE == 3 ? t : (t + NS < T ? t + NS : T - 1);       // (behind the last steps: a valid address, never used)
         const int sK = tn * m * n * 8, sk = tn * m * 8, sRx = tn * nr * n * 8, sRu = tn * nr * m * 8, sR = tn * nr * 8;
         (void)sRu;
         // Order of the step: every product is a dependent MFMA chain whose result is usable ~100 cycles after its last
@@ -1539,31 +1589,30 @@ __device__ __forceinline__ void forward_fused_body(RecLayout L, FusedArgs F, int
             if (UNI) { if (more) { advance(t + 1); lerp_Y(t + 1); } }
             else if (t + 2 < T) { advance(t + 2); stage_cols(t + 2); }
         } else if constexpr (MODE == 1) {
-            const double dt = (double)(t + 1 - uks);                       // the next step lies in the same segment
+            if (t + 1 == uke) {
+                // crossing into segment up + 1: its start column (ev) and end column (ev2) were requested one and two segments
+                // ago; the column after those and its time are requested now, the time BEHIND the columns (loads return in
+                // order: a wait that leaves "the youngest loads" in flight must not have to sit out the time's latency)
+                const int kn = __builtin_amdgcn_readfirstlane(ukn_v);
+                uks = uke; uke = kn; up++;
+                const int gap = uke - uks;
+                const double den = (double)(gap > 0 ? gap : 1), rinv = kp_rcp(den);
+#pragma unroll
+                for (int i = 0; i < 8; i++) { sv[i] = ev[i]; ev[i] = ev2[i]; av[i] = fdiv(ev[i] - sv[i], den, rinv); }
+                if (c == n || c == n + 1) {                                // the identity rows of Ya: lanes c >= n walk no list
+#pragma unroll
+                    for (int r = 0; r < 4; r++) if (4 * r + q == c) { sv[r] = 1.0; ev[r] = 1.0; av[r] = 0.0; }
+                }
+                const int pn = up + 2 < KpU ? up + 2 : KpU - 1;
+                load_col(rT, co, pn, NE, strideB, ev2);
+                __builtin_amdgcn_sched_barrier(0);
+                ukn_v = F.kp_times[E0 + pn];
+                __builtin_amdgcn_sched_barrier(0);
+            }
+            const double dt = (double)(t + 1 - uks);                       // 0 behind a crossing: the next step IS the key-point
             Ya.x = lerp_nc(sv[0], dt, av[0]); Ya.y = lerp_nc(sv[1], dt, av[1]); Ya.z = lerp_nc(sv[2], dt, av[2]); Ya.w = lerp_nc(sv[3], dt, av[3]);
             Yb.x = lerp_nc(sv[4], dt, av[4]); Yb.y = NCU > 1 ? lerp_nc(sv[5], dt, av[5]) : 0.0;
             Yb.z = NCU > 2 ? lerp_nc(sv[6], dt, av[6]) : 0.0; Yb.w = NCU > 3 ? lerp_nc(sv[7], dt, av[7]) : 0.0;
-        } else if constexpr (MODE == 2) {
-            // crossing into segment up + 1: its start column (ev) and end column (ev2) were requested one and two segments
-            // ago; the column after those and its time are requested now, the time BEHIND the columns (loads return in
-            // order: a wait that leaves "the youngest loads" in flight must not have to sit out the time's latency)
-            const int kn = __builtin_amdgcn_readfirstlane(ukn_v);
-            uks = uke; uke = kn; up++;
-            const int gap = uke - uks;
-            const double den = (double)(gap > 0 ? gap : 1), rinv = kp_rcp(den);
-#pragma unroll
-            for (int i = 0; i < 8; i++) { sv[i] = ev[i]; ev[i] = ev2[i]; av[i] = fdiv(ev[i] - sv[i], den, rinv); }
-            if (c == n || c == n + 1) {                                    // the identity rows of Ya: lanes c >= n walk no list
-#pragma unroll
-                for (int r = 0; r < 4; r++) if (4 * r + q == c) { sv[r] = 1.0; ev[r] = 1.0; av[r] = 0.0; }
-            }
-            const int pn = up + 2 < KpU ? up + 2 : KpU - 1;
-            load_col(rT, co, pn, NE, strideB, ev2);
-            __builtin_amdgcn_sched_barrier(0);
-            ukn_v = F.kp_times[E0 + pn];
-            __builtin_amdgcn_sched_barrier(0);
-            Ya.x = sv[0]; Ya.y = sv[1]; Ya.z = sv[2]; Ya.w = sv[3];        // the next step IS the key-point: dt = 0
-            Yb.x = sv[4]; Yb.y = NCU > 1 ? sv[5] : 0.0; Yb.z = NCU > 2 ? sv[6] : 0.0; Yb.w = NCU > 3 ? sv[7] : 0.0;
         }
         // quadratic cost model on the residuals: sum_k w_k [Jx_k (2 r_k + Jx_k) + Ju_k (2 r_k + Ju_k)]
         if constexpr (MODE == 0) {
@@ -1605,14 +1654,13 @@ __device__ __forceinline__ void forward_fused_body(RecLayout L, FusedArgs F, int
                 for (int r = 0; r < 4; r++) if (4 * r + q == c) { ev[r] = 1.0; av[r] = 0.0; }
             }
         }
-        for (int seg = 0; seg < KpU - 1; seg++) {       // (the crossing inside step<2> moves up, uks, uke on)
-            const int t_last = uke - 1;
-            for (int t = uks; t < t_last; t++) step(t, std::integral_constant<int, 1>{});
-            step(t_last, std::integral_constant<int, 2>{});
-        }
-        step(T - 1, std::integral_constant<int, 3>{});
+        int t = 0;
+        for (; t + NS < T; t += NS) fwd_steps<0, NS, 1>(step, t);         // (the crossing inside a step moves up, uks, uke on)
+        fwd_tail<0, NS, 1>(step, t, T);
     } else {
-        for (int t = 0; t < T; t++) step(t, std::integral_constant<int, 0>{});
+        int t = 0;
+        for (; t + NS <= T; t += NS) fwd_steps<0, NS, 0>(step, t);
+        fwd_tail<0, NS, 0>(step, t, T);
     }
     partial += __shfl_xor(partial, 16);
     partial += __shfl_xor(partial, 32);
@@ -2003,9 +2051,11 @@ hipError_t launch_forward_fused(Ctx *c, double *U_alpha_dev)
     dim3 grid(c->d.batch), block(64);
     const bool excl = c->d.batch <= c->n_simd;
     const FusedArgs F = fused_args(c);
-    // state / cost wave pair while each wave gets its own SIMD (KPILQR_FUSED_FWD_WAVES = 1 | 2 forces a form)
-    const int form = c->tune.fused_fwd_waves ? c->tune.fused_fwd_waves
-                   : (4 * c->d.batch <= c->n_simd ? 3 : 2 * c->d.batch <= c->n_simd ? 2 : 1);
+    // One wave per trajectory with its tile requests four steps ahead (forward_fused_body) from 64 trajectories up: 1.83 ms
+    // per sweep at B = 64 ... 512 against 1.89 ... 2.49 ms for the state / cost wave groups, which keep a single step of
+    // requests in flight; below that the state / cost / cost triple's shorter step wins (B = 1, 8: 1.63 against 1.83 ms).
+    // KPILQR_FUSED_FWD_WAVES = 1 | 2 | 3 forces a form.
+    const int form = c->tune.fused_fwd_waves ? c->tune.fused_fwd_waves : (32 * c->d.batch <= c->n_simd ? 3 : 1);
     const int ncz = (n + 2 + 3) / 4, ncu = (m + 3) / 4;       // tile chunks of [dx; alpha; 1] and of the controls
     if (form == 3) {
         dim3 block3(192);
