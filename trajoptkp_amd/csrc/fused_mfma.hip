@@ -55,6 +55,9 @@ typedef unsigned long long u64;
 #ifndef KP_FWD_SETS
 #define KP_FWD_SETS 4              // register sets of the one-wave forward sweep (requests run this many steps ahead)
 #endif
+#ifndef KP_BWD_LATE_STORE
+#define KP_BWD_LATE_STORE 1
+#endif
 #ifndef KP_PROBE_BWD
 #define KP_PROBE_BWD 0
 #endif
@@ -418,6 +421,24 @@ __device__ __forceinline__ void backward_fused_body(double *sh, const double *pc
     Iu.z = (8 + q == c && c < m) ? 1.0 : 0.0; Iu.w = (12 + q == c && c < m) ? 1.0 : 0.0;
     (void)haveX; (void)Iu;
 
+    // The gains of a step leave the wave one step late (one-wave forms), in front of the next residual requests: a wait
+    // for those requests also waits for every store issued behind them (the counter is shared and in order), and stores
+    // issued at the end of a step are acknowledged by a loaded memory system long after the requests have come back --
+    // the wait at the top of every step sat out that acknowledgement.  In front of the requests the stores are a step old
+    // when anything waits for them.
+    d4 Kst = zero;
+    int tst = -1;
+    (void)Kst; (void)tst;
+    auto store_gains = [&](int t, const d4 &Kp) {
+        __amdgpu_buffer_rsrc_t rK = frsrc(Kout + ((size_t)bS * T + t) * m * n, m * n * 8);
+        __amdgpu_buffer_rsrc_t rk = frsrc(kout + ((size_t)bS * T + t) * m, m * 8);
+        const double kv[4] = {Kp.x, Kp.y, Kp.z, Kp.w};
+#pragma unroll
+        for (int r = 0; r < NCU; r++) {
+            __builtin_amdgcn_raw_buffer_store_b64(__builtin_bit_cast(u32x2f, kv[r]), rK, oKst[r], 0, 0);
+            __builtin_amdgcn_raw_buffer_store_b64(__builtin_bit_cast(u32x2f, kv[r]), rk, okst[r], 0, 0);
+        }
+    };
     // one step of the sweep; false: the PD check of this step failed (the sweep ends)
 #ifdef KP_CYC
     unsigned long long cyc_cross = 0, cyc_peel = 0, cyc_inner = 0, cyc_a = 0;
@@ -496,6 +517,7 @@ __device__ __forceinline__ void backward_fused_body(double *sh, const double *pc
             LU = PR(cur.Ru, Rur * W2, zero, ncr);
         }
         __builtin_amdgcn_sched_barrier(0);
+        if constexpr (KP_BWD_LATE_STORE) { if (tst >= 0) store_gains(tst, Kst); }      // the step above, IN FRONT of the requests
         if (t > 0) load_res(t - 1, cur);
         __builtin_amdgcn_sched_barrier(0);
 #ifdef KP_CYC
@@ -613,16 +635,8 @@ __device__ __forceinline__ void backward_fused_body(double *sh, const double *pc
                 if (q == (i & 3)) xr[i >> 2] = x[i];
             Kp.x = -xr[0]; Kp.y = -xr[1]; Kp.z = -xr[2]; Kp.w = -xr[3];
         }
-        {
-            __amdgpu_buffer_rsrc_t rK = frsrc(Kout + ((size_t)bS * T + t) * m * n, m * n * 8);
-            __amdgpu_buffer_rsrc_t rk = frsrc(kout + ((size_t)bS * T + t) * m, m * 8);
-            const double kv[4] = {Kp.x, Kp.y, Kp.z, Kp.w};
-#pragma unroll
-            for (int r = 0; r < NCU; r++) {
-                __builtin_amdgcn_raw_buffer_store_b64(__builtin_bit_cast(u32x2f, kv[r]), rK, oKst[r], 0, 0);
-                __builtin_amdgcn_raw_buffer_store_b64(__builtin_bit_cast(u32x2f, kv[r]), rk, okst[r], 0, 0);
-            }
-        }
+        if constexpr (KP_BWD_LATE_STORE && !PC) { Kst = Kp; tst = t; }
+        else store_gains(t, Kp);
         // delta_J += k'Q_u + k'Q_uu k = -lambda k'k (:612-613): lanes of column n keep the squares of their rows,
         // the four row groups are added once after the sweep
         if (c == n) {
@@ -727,6 +741,7 @@ __device__ __forceinline__ void backward_fused_body(double *sh, const double *pc
     } else {
         for (int t = T - 1; t >= 0; t--) if (!step(t)) break;
     }
+    if constexpr (KP_BWD_LATE_STORE && !PC) { if (tst >= 0) store_gains(tst, Kst); }      // the last completed step
     dJ += __shfl_xor(dJ, 16);
     dJ += __shfl_xor(dJ, 32);
     if (lane_nn) delta_J[b] = dJ;
