@@ -182,7 +182,7 @@ Ctx::Tuning read_tuning_from_env();
 // elementwise.hip
 hipError_t launch_fd_difference(Ctx *c);                 // job lists -> step records
 hipError_t launch_fd_difference_kpc(Ctx *c);             // job lists -> key-point column store
-hipError_t launch_fd_kp_difference(Ctx *c);              // key-point ordered payload -> key-point column store
+hipError_t launch_fd_kp_difference(Ctx *c, bool only_if_ragged = false);   // key-point ordered payload -> key-point column store (only_if_ragged: leaves at once when the device flag kp_uniform is set)
 hipError_t launch_kpc_to_records(Ctx *c);                // key-point column store -> step records
 hipError_t launch_build_entry_tables(Ctx *c);            // kp_entry, kp_entry_list from the CSR lists
 hipError_t launch_copy_out(hipStream_t s, double *dst_host, const double *src_dev, size_t count);   // D2H by a kernel

@@ -179,8 +179,10 @@ hipError_t launch_fd_difference_kpc(Ctx *c)
 // next state into the x- or x+ slot: / eps), else central: / (2 eps)
 __global__ void __launch_bounds__(256)
 k_fd_kp_difference(int n, long long npairs_total, unsigned long long magic, const double2 *__restrict__ rec, double eps,
-                   double2 *__restrict__ kpc)
+                   double2 *__restrict__ kpc, const int *__restrict__ skip_if_uniform)
 {
+    // launched beside the raw backward sweep, which differences UNIFORM key-point sets itself: then this kernel leaves at once
+    if (skip_if_uniform && *skip_if_uniform != 0) return;
     const int pe = 3 * (n >> 1);                     // pairs per entry
     const int s2 = 3 * n + 1;                        // record stride in double2
     const long long stride = (long long)gridDim.x * blockDim.x;
@@ -195,7 +197,7 @@ k_fd_kp_difference(int n, long long npairs_total, unsigned long long magic, cons
     }
 }
 
-hipError_t launch_fd_kp_difference(Ctx *c)
+hipError_t launch_fd_kp_difference(Ctx *c, bool only_if_ragged)
 {
     // a view of a trajectory range (kpilqr_iterate_streamed) differences its own entries: [fdk_first, fdk_first + fdk_entries)
     if (c->fdk_entries == 0) return hipSuccess;
@@ -207,7 +209,7 @@ hipError_t launch_fd_kp_difference(Ctx *c)
     const int blocks = (int)(want < cap ? (want < 1 ? 1 : want) : cap);
     hipLaunchKernelGGL(k_fd_kp_difference, dim3(blocks), dim3(256), 0, c->stream, c->n, npairs, magic,
                        (const double2 *)(c->fdk_dev + (size_t)c->fdk_first * c->fdk_stride()), c->eps,
-                       (double2 *)(c->kpc + (size_t)c->fdk_first * 3 * c->n));
+                       (double2 *)(c->kpc + (size_t)c->fdk_first * 3 * c->n), only_if_ragged ? c->kp_uniform : (const int *)nullptr);
     return hipGetLastError();
 }
 

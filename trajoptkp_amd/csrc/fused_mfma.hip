@@ -58,6 +58,12 @@ typedef unsigned long long u64;
 #ifndef KP_BWD_LATE_STORE
 #define KP_BWD_LATE_STORE 1
 #endif
+#ifndef KP_BWD_LATE_KPC
+#define KP_BWD_LATE_KPC 1
+#endif
+#ifndef KP_WSYNC_LIGHT
+#define KP_WSYNC_LIGHT 1
+#endif
 #ifndef KP_PROBE_BWD
 #define KP_PROBE_BWD 0
 #endif
@@ -265,7 +271,16 @@ __device__ __forceinline__ void backward_fused_body(double *sh, const double *pc
     constexpr int NCZ = (N + 1 + 3) / 4;
     constexpr int NCU = (M + 3) / 4;
     constexpr int n = N, m = M;
+    // one wavefront per workgroup (or the consumer wave of a group): its LDS operations execute in order, so a write ->
+    // transposed read pair needs the compiler's ordering only (4.94 -> 4.87 ms against __syncthreads() in the one-wave forms).
+    // (Tried: the transposed half requested at the end of a step and averaged in front of the next step's first Riccati
+    // product, so that the LDS round trip runs under that step's a4 / a6 -- 7.73 ms: eight more live registers across the
+    // top of the step.)
+#if KP_WSYNC_LIGHT
+    auto wsync = [&]() { __builtin_amdgcn_wave_barrier(); };
+#else
     auto wsync = [&]() { if (PC) __builtin_amdgcn_wave_barrier(); else __syncthreads(); };
+#endif
     const int lane = threadIdx.x & 63, c = lane & 15, q = lane >> 4;
     const int b = KP_BLOCK_TRAJ;
     const double lam = lambda[b];
@@ -336,7 +351,7 @@ __device__ __forceinline__ void backward_fused_body(double *sh, const double *pc
         mo = __builtin_amdgcn_raw_buffer_load_b32(rP, base + ((c < n) ? offMode : BIGOFF), 0, 0);
     };
     double eps2 = F.eps2, rinv2 = F.rinv_2eps;
-    auto difference = [&](double *xp_, const double *xm_, int mo, int e_rel) {      // xp_ <- the differenced column, also to kpc
+    auto difference_arith = [&](double *xp_, const double *xm_, int mo) {           // xp_ <- the differenced column
         // central differences are the rule (a control at its limit is the exception, Differentiator.cpp:94-143): one
         // wave-uniform test keeps the per-lane denominator selects off the usual path
         if (__builtin_amdgcn_ballot_w64(mo != 0) == 0) {
@@ -352,6 +367,9 @@ __device__ __forceinline__ void backward_fused_body(double *sh, const double *pc
                 xp_[4 + i] = fdiv(xp_[4 + i] - xm_[4 + i], dB, rB);
             }
         }
+    };
+    auto difference = [&](double *xp_, const double *xm_, int mo, int e_rel) {      // ... and out to kpc
+        difference_arith(xp_, xm_, mo);
         store_col_n<N>(rT, co, ebase(e_rel), xp_);
     };
     (void)pm; (void)pmode; (void)bitA;
@@ -427,8 +445,8 @@ __device__ __forceinline__ void backward_fused_body(double *sh, const double *pc
     // the wait at the top of every step sat out that acknowledgement.  In front of the requests the stores are a step old
     // when anything waits for them.
     d4 Kst = zero;
-    int tst = -1;
-    (void)Kst; (void)tst;
+    int tst = -1, kst_pos = -1;
+    (void)Kst; (void)tst; (void)kst_pos;
     auto store_gains = [&](int t, const d4 &Kp) {
         __amdgpu_buffer_rsrc_t rK = frsrc(Kout + ((size_t)bS * T + t) * m * n, m * n * 8);
         __amdgpu_buffer_rsrc_t rk = frsrc(kout + ((size_t)bS * T + t) * m, m * 8);
@@ -470,33 +488,31 @@ __device__ __forceinline__ void backward_fused_body(double *sh, const double *pc
             }
         } else {
         // ---- a4: this step's A and B columns --------------------------------------------------------------
-        if constexpr (!UNI)
-        if (t < s) {                                   // per lane: crossed the start of the current segment
-            const KArgF Fk = kernarg_fused();          // crossing-only scalars, from the kernel-argument segment
-            rT = frsrc(Fk->kpc + (size_t)E0 * 3 * n, NE * strideB);
-            if constexpr (RAW) { rP = frsrc(Fk->fdk + (size_t)E0 * strideR, NE * strideR); eps2 = Fk->eps2; rinv2 = Fk->rinv_2eps; }
-            const int *kpt = Fk->kp_times;
-            const double den = (double)(s - nb);
-            const double rinv = kp_rcp(den);
-            if constexpr (RAW) difference(pv, pm, pmode, idx - 1 - E0);      // the prefetched x+ / x- become the column
+        // General form (per-lane lists): a lane that has crossed the start of its segment takes the column prefetched a
+        // crossing ago as the new start and forms the slope -- arithmetic only up here.  Everything of the crossing that is
+        // a memory operation (the differenced column out to kpc, the next column and its time in) waits for `late_cross`
+        // below, BEHIND the wait for this step's residual tiles: in front of it the wait, which the compiler has to place
+        // conservatively behind a divergent branch, drained the requests the branch had just issued -- a trip to HBM on
+        // every step on which any lane crossed (ragged key-point sets: most steps; 8.7 -> ... ms).
+        bool cross = false;
+        if constexpr (!UNI) {
+            cross = t < s;
+            if (cross) {
+                if constexpr (RAW) { const KArgF Fk = kernarg_fused(); eps2 = Fk->eps2; rinv2 = Fk->rinv_2eps; }
+                const double den = (double)(s - nb);
+                const double rinv = kp_rcp(den);
+                if constexpr (RAW) difference_arith(pv, pm, pmode);      // the prefetched x+ / x- become the column
 #pragma unroll
-            for (int i = 0; i < 8; i++) {
-                av[i] = fdiv(sv[i] - pv[i], den, rinv);
-                // a real move, in sv's own register: left to the compiler, sv is renamed onto pv's register, the loads below
-                // land somewhere else, and the two arrays are copied back and forth -- behind a wait for every memory
-                // operation in flight -- on EVERY step of the sweep instead of at the crossings
-                asm volatile("v_mov_b64 %0, %1" : "+v"(sv[i]) : "v"(pv[i]));
+                for (int i = 0; i < 8; i++) {
+                    av[i] = fdiv(sv[i] - pv[i], den, rinv);
+                    // a real move, in sv's own register: left to the compiler, sv is renamed onto pv's register, the loads below
+                    // land somewhere else, and the two arrays are copied back and forth -- behind a wait for every memory
+                    // operation in flight -- on EVERY step of the sweep instead of at the crossings
+                    asm volatile("v_mov_b64 %0, %1" : "+v"(sv[i]) : "v"(pv[i]));
+                }
+                idx--;
+                s = nb;
             }
-            idx--;
-#ifdef KP_EXP_NOTIMELOAD
-            { const int gap = s - nb; s = nb; nb = (idx - 1 >= lo) ? nb - gap : -1; }
-#else
-            s = nb;
-            nb = (idx - 1 >= lo) ? kpt[idx - 1] : -1;
-#endif
-            const int e_nb = (idx - 1 >= lo) ? idx - 1 - E0 : -1;
-            if constexpr (RAW) load_raw(e_nb, pv, pm, pmode);
-            else load_col_n<N>(rT, co, ebase(e_nb), pv);
         }
         const double dt = UNI ? (double)(t - us) : (double)(t - s);
         Fz.x = lerp_nc(sv[0], dt, av[0]); Fz.y = lerp_nc(sv[1], dt, av[1]);
@@ -518,6 +534,25 @@ __device__ __forceinline__ void backward_fused_body(double *sh, const double *pc
         }
         __builtin_amdgcn_sched_barrier(0);
         if constexpr (KP_BWD_LATE_STORE) { if (tst >= 0) store_gains(tst, Kst); }      // the step above, IN FRONT of the requests
+        if constexpr (!UNI) {
+            if (cross) {                               // late_cross: the memory operations of the crossing at the top of this step
+                const KArgF Fk = kernarg_fused();      // crossing-only scalars, from the kernel-argument segment
+                rT = frsrc(Fk->kpc + (size_t)E0 * 3 * n, NE * strideB);
+                if constexpr (RAW) {
+                    rP = frsrc(Fk->fdk + (size_t)E0 * strideR, NE * strideR);
+                    store_col_n<N>(rT, co, ebase(idx - E0), sv);          // the column that has just become the start value
+                }
+                nb = (idx - 1 >= lo) ? Fk->kp_times[idx - 1] : -1;
+                const int e_nb = (idx - 1 >= lo) ? idx - 1 - E0 : -1;
+                if constexpr (RAW) load_raw(e_nb, pv, pm, pmode);
+                else load_col_n<N>(rT, co, ebase(e_nb), pv);
+            }
+        }
+        if constexpr (RAW && UNI) {
+            // the differenced column of the crossing above (it is the segment's start value now): like the gains it leaves
+            // behind the wait for this step's tiles -- in front of it, the wait sat out the stores' acknowledgement
+            if (kst_pos >= 0) { store_col_n<N>(rT, cu, kst_pos * strideB, sv); kst_pos = -1; }
+        }
         if (t > 0) load_res(t - 1, cur);
         __builtin_amdgcn_sched_barrier(0);
 #ifdef KP_CYC
@@ -699,7 +734,8 @@ __device__ __forceinline__ void backward_fused_body(double *sh, const double *pc
 #pragma unroll
                     for (int i = 0; i < 4; i++) { pv[i] = fdiv(pv[i] - pm[i], dA, rA); pv[4 + i] = fdiv(pv[4 + i] - pm[4 + i], dB, rB); }
                 }
-                store_col_n<N>(rT, cu, up * strideB, pv);
+                kst_pos = KP_BWD_LATE_KPC ? up : -1;                 // stored from sv behind the tile wait of the step below
+                if constexpr (!KP_BWD_LATE_KPC) store_col_n<N>(rT, cu, up * strideB, pv);
                 if (up == KpU - 1) {
 #pragma unroll
                     for (int i = 0; i < 8; i++) sv[i] = pv[i];
@@ -1170,7 +1206,7 @@ __device__ __forceinline__ void fusedpc_producer(double *pcbuf, int *sflag, RecL
 {
     constexpr int n = N, m = M;
     const int lane = threadIdx.x & 63, c = lane & 15, q = lane >> 4;
-    const int b = blockIdx.x;
+    const int b = KP_BLOCK_TRAJ;
     const int nr = F.nr, ncr = (nr + 3) >> 2;
     const int strideB = 3 * L.n * 8;                               // bytes of one key-point entry of kpc: three columns
     DownTracker<8> tr;                           // A rows then B rows of column c
@@ -2035,9 +2071,22 @@ hipError_t launch_backward_fused(Ctx *c, int pd_stride, bool raw)
             hipLaunchKernelGGL((k_backward_fused<NN, MM, RU, RW, UN>), grid, block, 0, c->stream, c->L, F, c->d.T,   \
                                c->lambda, pd_stride, c->K, c->k, c->delta_J, c->status, c->kp_uniform);      \
     } while (0)
-// both forms, back to back: the one whose kind of key-point set is not resident leaves at once
+// both forms, back to back: the one whose kind of key-point set is not resident leaves at once.  raw: only UNIFORM sets are
+// differenced inside the sweep; for per-DoF lists a lane's crossing is a divergent branch that every lane of the wave pays for
+// (17 loads, 8 stores on most steps), and the streaming kernel + the plain general sweep are faster (iterative-error lists with
+// a key-point on 99 % of the steps: 8.7 + 2.2 against 11.9 ms) -- k_fd_kp_difference is launched in between and looks at the
+// same device flag.  (KPILQR_FUSED_UNI=0, diagnostic: the general raw form for every set.)
 #define LAUNCH3(NN, MM, RU, RW) do { if (c->tune.fused_uni != 0) LAUNCH4(NN, MM, RU, RW, true); LAUNCH4(NN, MM, RU, RW, false); } while (0)
-#define LAUNCH2(NN, MM, RU) do { if (raw) LAUNCH3(NN, MM, RU, true); else LAUNCH3(NN, MM, RU, false); } while (0)
+#define LAUNCH2(NN, MM, RU)                                                                                             \
+    do {                                                                                                                \
+        if (raw && c->tune.fused_uni != 0) {                                                                            \
+            LAUNCH4(NN, MM, RU, true, true);                                                                            \
+            hipError_t e_ = launch_fd_kp_difference(c, true);                                                           \
+            if (e_ != hipSuccess) return e_;                                                                            \
+            LAUNCH4(NN, MM, RU, false, false);                                                                          \
+        } else if (raw) LAUNCH3(NN, MM, RU, true);                                                                      \
+        else LAUNCH3(NN, MM, RU, false);                                                                                \
+    } while (0)
 #define LAUNCH(NN, MM) do { if (c->ru_zero) LAUNCH2(NN, MM, true); else LAUNCH2(NN, MM, false); } while (0)
 #define KP_X(NN, MM) if (n == NN && m == MM) { LAUNCH(NN, MM); return hipGetLastError(); }
     KP_T1_SHAPES(KP_X)
