@@ -16,6 +16,12 @@
 #include "mfma_common.h"
 #include "tracker.h"
 
+// latency probe (-DKP_PROBE_SAMEB): every workgroup works on one of two trajectories, everything hits in cache
+#ifdef KP_PROBE_SAMEB
+#define KP_TILED_TRAJ ((int)(blockIdx.x & 1))
+#else
+#define KP_TILED_TRAJ ((int)blockIdx.x)
+#endif
 namespace kpilqr {
 
 typedef unsigned int u32x2t __attribute__((ext_vector_type(2)));
@@ -197,7 +203,7 @@ k_backward_tiled_col(RecLayout L, CostSrc CS, KpSrc KP, int T, const double *__r
     const int n = L.n, m = PAD ? L.m : M, nz = n + 1;
     const int lane = threadIdx.x & 63, c = lane & 15, q = lane >> 4;
     const int w = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);    // this wave's column tile (wave-uniform)
-    const int b = blockIdx.x;
+    const int b = KP_TILED_TRAJ;
     const double lam = lambda[b];
     double *bufV = sh;                               // V' (NT x NT tiles, tile (i,j) at i*NT+j)
     double *bufF = bufV + NZZ * TILE;                // Fz
@@ -606,7 +612,7 @@ k_forward_tiled(RecLayout L, CostSrc CS, KpSrc KP, int T, int n_alpha, const dou
     const int n = L.n, m = L.m, nz2 = n + 2;
     const int lane = threadIdx.x & 63, c = lane & 15, q = lane >> 4;
     const int wi = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);   // this wave's row tile (wave-uniform)
-    const int b = blockIdx.x;
+    const int b = KP_TILED_TRAJ;
     const int ncu = (m + 3) >> 2;
     auto nchunk = [&](int kt) { const int rows = nz2 - 16 * kt; return rows >= 16 ? 4 : (rows + 3) / 4; };
     const int ncl = nchunk(NT - 1);

@@ -60,6 +60,8 @@ iLQR_GPU_Batch::~iLQR_GPU_Batch()
     if (!ctx) return;
     kpilqr_sync(ctx);
     staging.free_all();
+    if (kp_slab) kpilqr_host_free(ctx, kp_slab);
+    kp_slab = nullptr;
     double **all[] = {&host_r, &host_rx, &host_ru, &host_unom, &host_K, &host_k};
     for (double **p : all) { if (*p) kpilqr_host_free(ctx, *p); *p = nullptr; }
     kpilqr_destroy(ctx);
@@ -155,18 +157,6 @@ void iLQR_GPU_Batch::GenerateDerivatives(const std::vector<int> &who)
         s.kpgen->GenerateKeyPoints(Xk, P[b].MuJoCo_helper->ReturnModelTimeStep(), col_fd);
         s.kpgen->PerDofCSR(s.kp_offsets, s.kp_times);
     }
-    int tot_jobs = 0, tot_kps = 0;
-    for (int b : who) { int j, k_; P[b].differentiator->CountJobs(S[b].kpgen->keypoints, j, k_); tot_jobs += j; tot_kps += k_; }
-    staging.plan(tot_jobs, tot_kps, n);
-    // pass 2: FD of every trajectory on its own persistent pool, all into the ONE pinned slab, trajectories in order
-    for (int b : who) {
-        Traj &s = S[b];
-        Differentiator &diff = *P[b].differentiator;
-        diff.DynamicsDerivativesPlanned(staging, b, s.kpgen->keypoints, eps);
-        for (int t = 0; t <= T; t++)
-            for (int i = 0; i < nr; i++) host_r[((size_t)b * (T + 1) + t) * nr + i] = s.residuals[t](i);
-        diff.ResidualDerivativesAll(host_rx + (size_t)b * (T + 1) * nr * n, host_ru + (size_t)b * (T + 1) * nr * m, T, eps);
-    }
     // key-points of the whole batch (unchanged lists are re-sent as they are)
     std::vector<int> offs(1, 0), times;
     for (int b = 0; b < B; b++) {
@@ -174,12 +164,46 @@ void iLQR_GPU_Batch::GenerateDerivatives(const std::vector<int> &who)
         for (int i = 0; i < dof; i++) offs.push_back(offs.back() + (s.kp_offsets[i + 1] - s.kp_offsets[i]));
         times.insert(times.end(), s.kp_times.begin(), s.kp_times.end());
     }
+    // Fused sweeps take the payload KEY-POINT ORDERED (one record per CSR entry, written in place by the FD workers, no job
+    // lists: iLQR_GPU.cpp) when every record of the batch is valid afterwards: all trajectories regenerate, or the others'
+    // records still sit where the slab of the previous call left them (the batch CSR has not moved).
+    const bool kp_ordered = fused_active && ((int)who.size() == B || (!kp_slab_offs.empty() && kp_slab_offs == offs));
+    kpilqr_fdkp_layout lay = {};
+    if (kp_ordered) {
+        if ((rc = kpilqr_fd_kp_layout(ctx, offs.back(), &lay))) fatal("kpilqr_fd_kp_layout", rc);
+        if (lay.bytes > kp_slab_bytes) {                       // (a grown slab is refilled completely: who is everybody then)
+            if ((int)who.size() != B) fatal("key-point slab grew under a partial regeneration", -1);
+            if (kp_slab) kpilqr_host_free(ctx, kp_slab);
+            kp_slab_bytes = lay.bytes + lay.bytes / 4 + 4096;
+            if ((rc = kpilqr_host_alloc(ctx, kp_slab_bytes, (void **)&kp_slab))) fatal("kpilqr_host_alloc", rc);
+        }
+    } else {
+        int tot_jobs = 0, tot_kps = 0;
+        for (int b : who) { int j, k_; P[b].differentiator->CountJobs(S[b].kpgen->keypoints, j, k_); tot_jobs += j; tot_kps += k_; }
+        staging.plan(tot_jobs, tot_kps, n);
+        kp_slab_offs.clear();                                  // the job-list payload replaces the records on the device
+    }
+    // pass 2: FD of every trajectory on its own persistent pool, all into the ONE pinned slab, trajectories in order
+    for (int b : who) {
+        Traj &s = S[b];
+        Differentiator &diff = *P[b].differentiator;
+        if (kp_ordered) diff.DynamicsDerivativesKp(kp_slab, lay.entry_stride, offs[(size_t)b * dof], s.kp_offsets, s.kp_times, s.kpgen->keypoints, eps);
+        else diff.DynamicsDerivativesPlanned(staging, b, s.kpgen->keypoints, eps);
+        for (int t = 0; t <= T; t++)
+            for (int i = 0; i < nr; i++) host_r[((size_t)b * (T + 1) + t) * nr + i] = s.residuals[t](i);
+        diff.ResidualDerivativesAll(host_rx + (size_t)b * (T + 1) * nr * n, host_ru + (size_t)b * (T + 1) * nr * m, T, eps);
+    }
     if ((rc = kpilqr_set_keypoints(ctx, offs.data(), times.data()))) fatal("kpilqr_set_keypoints", rc);
-    // the slab's array offsets were computed from the PLANNED totals: an under-filled plan would make the device read
-    // x-, xnom and the job arrays at the wrong offsets
-    if (!staging.complete()) { std::fprintf(stderr, "FD staging: %d of %d jobs, %d of %d nominal rows filled\n", staging.njobs, staging.plan_jobs, staging.nnom, staging.plan_noms); std::exit(1); }
-    rc = kpilqr_upload_fd_slab(ctx, staging.slab, staging.njobs, staging.nnom, eps);
-    if (rc) fatal("kpilqr_upload_fd_slab", rc);
+    if (kp_ordered) {
+        if ((rc = kpilqr_upload_fd_kp(ctx, kp_slab, offs.back(), eps))) fatal("kpilqr_upload_fd_kp", rc);
+        kp_slab_offs = offs;
+    } else {
+        // the slab's array offsets were computed from the PLANNED totals: an under-filled plan would make the device read
+        // x-, xnom and the job arrays at the wrong offsets
+        if (!staging.complete()) { std::fprintf(stderr, "FD staging: %d of %d jobs, %d of %d nominal rows filled\n", staging.njobs, staging.plan_jobs, staging.nnom, staging.plan_noms); std::exit(1); }
+        rc = kpilqr_upload_fd_slab(ctx, staging.slab, staging.njobs, staging.nnom, eps);
+        if (rc) fatal("kpilqr_upload_fd_slab", rc);
+    }
     if ((rc = kpilqr_fd_difference(ctx))) fatal("kpilqr_fd_difference", rc);
     if (!fused_active && (rc = kpilqr_interpolate(ctx))) fatal("kpilqr_interpolate", rc);
     if ((rc = kpilqr_upload_residuals(ctx, host_r, host_rx, host_ru, w_run.data(), w_term.data()))) fatal("kpilqr_upload_residuals", rc);

@@ -65,5 +65,10 @@ private:
     bool fused_active = false;
     std::vector<double> alphas, w_run, w_term, ctrl_lim;
     FDStaging staging;
+    // fused sweeps: the key-point ordered FD payload (kpilqr_upload_fd_kp) of the whole batch in one pinned slab, kept between
+    // iterations so that a partial regeneration refills only its trajectories' records while the entry layout stays the same
+    char *kp_slab = nullptr;
+    size_t kp_slab_bytes = 0;
+    std::vector<int> kp_slab_offs;          // the batch CSR the slab's records were laid out for (empty: no valid slab)
     double *host_r = nullptr, *host_rx = nullptr, *host_ru = nullptr, *host_unom = nullptr, *host_K = nullptr, *host_k = nullptr;
 };
