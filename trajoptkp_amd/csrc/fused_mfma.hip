@@ -553,7 +553,10 @@ __device__ __forceinline__ void backward_fused_body(double *sh, const double *pc
             // behind the wait for this step's tiles -- in front of it, the wait sat out the stores' acknowledgement
             if (kst_pos >= 0) { store_col_n<N>(rT, cu, kst_pos * strideB, sv); kst_pos = -1; }
         }
-        if (t > 0) load_res(t - 1, cur);
+        // (general form: unconditional -- with the request behind a branch there is a path from the crossing's requests to the
+        // next crossing without a tile request in between, and the compiler's wait for the crossing's columns drains the tiles)
+        if constexpr (UNI) { if (t > 0) load_res(t - 1, cur); }
+        else load_res(t > 0 ? t - 1 : 0, cur);
         __builtin_amdgcn_sched_barrier(0);
 #ifdef KP_CYC
         cyc_a += __builtin_readcyclecounter() - cyc_s0;
