@@ -58,12 +58,6 @@ typedef unsigned long long u64;
 #ifndef KP_BWD_LATE_STORE
 #define KP_BWD_LATE_STORE 1
 #endif
-#ifndef KP_BWD_LATE_KPC
-#define KP_BWD_LATE_KPC 1
-#endif
-#ifndef KP_WSYNC_LIGHT
-#define KP_WSYNC_LIGHT 1
-#endif
 #ifndef KP_PROBE_BWD
 #define KP_PROBE_BWD 0
 #endif
@@ -276,11 +270,7 @@ __device__ __forceinline__ void backward_fused_body(double *sh, const double *pc
     // (Tried: the transposed half requested at the end of a step and averaged in front of the next step's first Riccati
     // product, so that the LDS round trip runs under that step's a4 / a6 -- 7.73 ms: eight more live registers across the
     // top of the step.)
-#if KP_WSYNC_LIGHT
     auto wsync = [&]() { __builtin_amdgcn_wave_barrier(); };
-#else
-    auto wsync = [&]() { if (PC) __builtin_amdgcn_wave_barrier(); else __syncthreads(); };
-#endif
     const int lane = threadIdx.x & 63, c = lane & 15, q = lane >> 4;
     const int b = KP_BLOCK_TRAJ;
     const double lam = lambda[b];
@@ -737,8 +727,7 @@ __device__ __forceinline__ void backward_fused_body(double *sh, const double *pc
 #pragma unroll
                     for (int i = 0; i < 4; i++) { pv[i] = fdiv(pv[i] - pm[i], dA, rA); pv[4 + i] = fdiv(pv[4 + i] - pm[4 + i], dB, rB); }
                 }
-                kst_pos = KP_BWD_LATE_KPC ? up : -1;                 // stored from sv behind the tile wait of the step below
-                if constexpr (!KP_BWD_LATE_KPC) store_col_n<N>(rT, cu, up * strideB, pv);
+                kst_pos = up;                                      // stored from sv behind the tile wait of the step below
                 if (up == KpU - 1) {
 #pragma unroll
                     for (int i = 0; i < 8; i++) sv[i] = pv[i];
