@@ -452,12 +452,14 @@ __device__ __forceinline__ void backward_fused_body(double *sh, const double *pc
     unsigned long long cyc_cross = 0, cyc_peel = 0, cyc_inner = 0, cyc_a = 0;
     const unsigned long long cyc_all0 = __builtin_readcyclecounter();
 #endif
-    auto step = [&](int t) __attribute__((always_inline)) -> bool {
+    // may_be_first: whether this call site can see the terminal step t = T-1 (only the first step of a sweep can: the call
+    // sites inside the loops say no, and the selects of the terminal value function and weights leave the hot path)
+    auto step = [&](int t, auto may_be_first) __attribute__((always_inline)) -> bool {
 #ifdef KP_CYC
         const unsigned long long cyc_s0 = __builtin_readcyclecounter();
 #endif
         d4 Fz, Fu, Lzz, LU;
-        const bool term = (t == T - 1);
+        const bool term = decltype(may_be_first)::value && (t == T - 1);
         if constexpr (PC) {
             const double *tb = pcbuf + (t & 1) * FPC_BUF;
             Fu = lds_tile4(tb + 256, lane); LU = lds_tile4(tb + 768, lane);
@@ -667,12 +669,11 @@ __device__ __forceinline__ void backward_fused_body(double *sh, const double *pc
         else store_gains(t, Kp);
         // delta_J += k'Q_u + k'Q_uu k = -lambda k'k (:612-613): lanes of column n keep the squares of their rows,
         // the four row groups are added once after the sweep
-        if (c == n) {
-            dJ -= lam * (Kp.x * Kp.x);
-            if (NCU > 1) dJ -= lam * (Kp.y * Kp.y);
-            if (NCU > 2) dJ -= lam * (Kp.z * Kp.z);
-            if (NCU > 3) dJ -= lam * (Kp.w * Kp.w);
-        }
+        // (every lane accumulates; only the lanes of column n are read behind the sweep)
+        dJ -= lam * (Kp.x * Kp.x);
+        if (NCU > 1) dJ -= lam * (Kp.y * Kp.y);
+        if (NCU > 2) dJ -= lam * (Kp.z * Kp.z);
+        if (NCU > 3) dJ -= lam * (Kp.w * Kp.w);
         // V' = Qzz + K'Quu K + K'Quz + Quz'K (:606-607) with K = -X, (Quu + lambda I) X = Quz:
         //    = Qzz - X'(Quz + lambda X) = Qzz + K'(Quz - lambda K)   -- one product; G = (Quu + 2 lambda I)K' is never formed
         d4 G;
@@ -698,6 +699,9 @@ __device__ __forceinline__ void backward_fused_body(double *sh, const double *pc
         return true;
     };
     if constexpr (UNI && !PC) {
+        // (Tried: ONE loop over the steps with the crossing's arithmetic behind a uniform branch at the top of the step and its
+        // memory operations behind the tile wait, as in the forward sweep and in the general form -- 5.64 against 4.81 ms, also
+        // with a key-point every 20 steps (5.20 against 4.41): the loop as a whole came out slower, not the crossing.)
         // segments from the top: [k_p, k_p+1) with k_KpU := T.  The crossing -- slope of the new segment from the column
         // prefetched a segment ago, the next column requested (raw: x+ / x- differenced and kept for the forward sweep) --
         // is straight-line code; the segment's first step is peeled behind it so that the wait for its residual tiles
@@ -756,18 +760,19 @@ __device__ __forceinline__ void backward_fused_body(double *sh, const double *pc
             const unsigned long long cyc1 = __builtin_readcyclecounter();
             cyc_cross += cyc1 - cyc0;
 #endif
-            ok = step(t_hi);                                       // peeled: straight-line behind the crossing
+            ok = step(t_hi, std::true_type{});                     // peeled: straight-line behind the crossing
 #ifdef KP_CYC
             const unsigned long long cyc2 = __builtin_readcyclecounter();
             cyc_peel += cyc2 - cyc1;
 #endif
-            for (int t = t_hi - 1; t >= us && ok; t--) ok = step(t);
+            for (int t = t_hi - 1; t >= us && ok; t--) ok = step(t, std::false_type{});
 #ifdef KP_CYC
             cyc_inner += __builtin_readcyclecounter() - cyc2;
 #endif
         }
     } else {
-        for (int t = T - 1; t >= 0; t--) if (!step(t)) break;
+        if (step(T - 1, std::true_type{}))
+            for (int t = T - 2; t >= 0; t--) if (!step(t, std::false_type{})) break;
     }
     if constexpr (KP_BWD_LATE_STORE && !PC) { if (tst >= 0) store_gains(tst, Kst); }      // the last completed step
     dJ += __shfl_xor(dJ, 16);
@@ -1668,10 +1673,14 @@ __device__ __forceinline__ void forward_fused_body(RecLayout L, FusedArgs F, int
             for (int r = 0; r < 4; r++) wcur[r] = wterm[r];
         }
         const d4 r2 = cur.rv + cur.rv;
-        partial += wcur[0] * (Jx.x * (r2.x + Jx.x) + Ju.x * (r2.x + Ju.x))
-                 + wcur[1] * (Jx.y * (r2.y + Jx.y) + Ju.y * (r2.y + Ju.y))
-                 + wcur[2] * (Jx.z * (r2.z + Jx.z) + Ju.z * (r2.z + Ju.z))
-                 + wcur[3] * (Jx.w * (r2.w + Jx.w) + Ju.w * (r2.w + Ju.w));
+        if constexpr (RU0)                             // Ju = 0 exactly: its term adds a signed zero
+            partial += wcur[0] * (Jx.x * (r2.x + Jx.x)) + wcur[1] * (Jx.y * (r2.y + Jx.y))
+                     + wcur[2] * (Jx.z * (r2.z + Jx.z)) + wcur[3] * (Jx.w * (r2.w + Jx.w));
+        else
+            partial += wcur[0] * (Jx.x * (r2.x + Jx.x) + Ju.x * (r2.x + Ju.x))
+                     + wcur[1] * (Jx.y * (r2.y + Jx.y) + Ju.y * (r2.y + Ju.y))
+                     + wcur[2] * (Jx.z * (r2.z + Jx.z) + Ju.z * (r2.z + Ju.z))
+                     + wcur[3] * (Jx.w * (r2.w + Jx.w) + Ju.w * (r2.w + Ju.w));
         __builtin_amdgcn_sched_barrier(0);
         cur.rv.x = fblds(rR, oR[0], sR); cur.rv.y = fblds(rR, oR[1], sR); cur.rv.z = fblds(rR, oR[2], sR); cur.rv.w = fblds(rR, oR[3], sR);
         __builtin_amdgcn_sched_barrier(0);
