@@ -307,10 +307,15 @@ __device__ __forceinline__ void backward_fused_body(double *sh, const double *pc
     const double *rub = F.r_u + (size_t)bR * (T + 1) * nr * m;
 
     struct ResTiles { d4 Rx, R1, Ru; };
+    // The sweep asks for the steps in order (T-1, T-2, ...), so the three residual arrays and the two gain arrays are walked
+    // with running pointers: a subtraction per array and step instead of a 64-bit (trajectory, step) product (-24 scalar
+    // instructions per step, 4.84 -> 4.77 ms).  `t` only says whether there IS a step t (the general form asks once more at the bottom).
+    const double *pRx = rxb + (size_t)(T - 1) * nr * n, *pR = rb + (size_t)(T - 1) * nr, *pRu = rub + (size_t)(T - 1) * nr * m;
     auto load_res = [&](int t, ResTiles &s) {
-        __amdgpu_buffer_rsrc_t rRx = frsrc(rxb + (size_t)t * nr * n, nr * n * 8);
-        __amdgpu_buffer_rsrc_t rR = frsrc(rb + (size_t)t * nr, nr * 8);
-        __amdgpu_buffer_rsrc_t rRu = frsrc(rub + (size_t)t * nr * m, nr * m * 8);
+        __amdgpu_buffer_rsrc_t rRx = frsrc(pRx, nr * n * 8);
+        __amdgpu_buffer_rsrc_t rR = frsrc(pR, nr * 8);
+        __amdgpu_buffer_rsrc_t rRu = frsrc(pRu, nr * m * 8);
+        if (t > 0) { pRx -= nr * n; pR -= nr; pRu -= nr * m; }       // (behind step 0: stay on it)
         s.Rx.x = fbld(rRx, oRx[0]); s.Rx.y = fbld(rRx, oRx[1]); s.Rx.z = fbld(rRx, oRx[2]); s.Rx.w = fbld(rRx, oRx[3]);
         s.R1.x = fbld(rR, oR1[0]); s.R1.y = fbld(rR, oR1[1]); s.R1.z = fbld(rR, oR1[2]); s.R1.w = fbld(rR, oR1[3]);
         if constexpr (!RU0) { s.Ru.x = fbld(rRu, oRu[0]); s.Ru.y = fbld(rRu, oRu[1]); s.Ru.z = fbld(rRu, oRu[2]); s.Ru.w = fbld(rRu, oRu[3]); }
@@ -437,9 +442,12 @@ __device__ __forceinline__ void backward_fused_body(double *sh, const double *pc
     d4 Kst = zero;
     int tst = -1, kst_pos = -1;
     (void)Kst; (void)tst; (void)kst_pos;
+    double *pK = Kout + ((size_t)bS * T + T - 1) * m * n, *pk = kout + ((size_t)bS * T + T - 1) * m;
     auto store_gains = [&](int t, const d4 &Kp) {
-        __amdgpu_buffer_rsrc_t rK = frsrc(Kout + ((size_t)bS * T + t) * m * n, m * n * 8);
-        __amdgpu_buffer_rsrc_t rk = frsrc(kout + ((size_t)bS * T + t) * m, m * 8);
+        (void)t;                                       // the steps are stored in order, T-1 first
+        __amdgpu_buffer_rsrc_t rK = frsrc(pK, m * n * 8);
+        __amdgpu_buffer_rsrc_t rk = frsrc(pk, m * 8);
+        pK -= m * n; pk -= m;
         const double kv[4] = {Kp.x, Kp.y, Kp.z, Kp.w};
 #pragma unroll
         for (int r = 0; r < NCU; r++) {
