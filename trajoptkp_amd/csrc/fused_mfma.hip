@@ -468,6 +468,8 @@ __device__ __forceinline__ void backward_fused_body(double *sh, const double *pc
 #endif
         d4 Fz, Fu, Lzz, LU;
         const bool term = decltype(may_be_first)::value && (t == T - 1);
+        bool cross = false;                            // general form: this lane has crossed the start of its segment
+        (void)cross;
         if constexpr (PC) {
             const double *tb = pcbuf + (t & 1) * FPC_BUF;
             Fu = lds_tile4(tb + 256, lane); LU = lds_tile4(tb + 768, lane);
@@ -494,7 +496,6 @@ __device__ __forceinline__ void backward_fused_body(double *sh, const double *pc
         // below, BEHIND the wait for this step's residual tiles: in front of it the wait, which the compiler has to place
         // conservatively behind a divergent branch, drained the requests the branch had just issued -- a trip to HBM on
         // every step on which any lane crossed (ragged key-point sets: most steps; 8.7 -> ... ms).
-        bool cross = false;
         if constexpr (!UNI) {
             cross = t < s;
             if (cross) {
