@@ -154,3 +154,16 @@ def test_ragged_lists_on_two_and_three_tiles(task, T, batch, fused):
     assert variant.startswith("mfma_f64_tiled"), variant
     for b in range(batch):
         check_against_oracle(p, b, K, k, res)
+
+
+def test_every_trajectory_of_a_distinct_seed_batch_matches_the_oracle():
+    """tools/full_batch_parity.py at a reduced size (256 distinct seeds, T=1000; the committed run is 1024 x 3000,
+    profiles/r03_full_batch_parity.txt): K, k, predicted costs, delta_J and status of EVERY trajectory against the oracle, for
+    the raw backward sweep and for the differencing kernel + plain sweep.  A process of its own: the oracle workers are
+    forked before anything touches the GPU."""
+    import subprocess, sys, os
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    r = subprocess.run([sys.executable, os.path.join(root, "tools", "full_batch_parity.py"), "256", "1000"], cwd=root,
+                       capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]
+    assert "all trajectories within 1e-9 of the oracle" in r.stdout
