@@ -432,6 +432,12 @@ def pcie_inclusive(batch, steps=4):
         a, b, c = pick(payload, "chunks=3 pipelined"), pick(payload, "chunks=3 per-iteration"), pick(payload, "serial")
         out[key] = {"value": a["traj_it_per_s"], "ms_per_iteration": a["ms_per_iteration"], "h2d_GB": a["h2d_GB"], "d2h_GB": a["d2h_GB"],
                     "link_GBps": a["link_GBps"], "synced_value": b["traj_it_per_s"], "serial_value": c["traj_it_per_s"]}
+    # the same with the key-point columns differenced on the host (kpilqr_upload_kp_columns): half the FD bytes, bit-identical K
+    for key, payload in (("full_payload_host_differenced_columns", "columns + full residual payload"),
+                         ("resident_jacobians_host_differenced_columns", "columns + resident Jacobians")):
+        a = pick(payload, "chunks=3 pipelined")
+        out[key] = {"value": a["traj_it_per_s"], "ms_per_iteration": a["ms_per_iteration"], "h2d_GB": a["h2d_GB"], "d2h_GB": a["d2h_GB"],
+                    "link_GBps": a["link_GBps"]}
     return out
 
 

@@ -31,7 +31,7 @@
 extern "C" {
 #endif
 
-#define KPILQR_VERSION 300   /* 0.3.0 */
+#define KPILQR_VERSION 301   /* 0.3.1 */
 
 typedef struct kpilqr_ctx kpilqr_ctx;
 
@@ -193,6 +193,14 @@ typedef struct {
 int  kpilqr_fd_kp_layout(kpilqr_ctx *ctx, int entries, kpilqr_fdkp_layout *out);
 int  kpilqr_upload_fd_kp(kpilqr_ctx *ctx, const void *slab, int entries, double eps);
 
+/* The key-point columns themselves, for a host that has already differenced (the reference's own place for a2,
+ * Differentiator.cpp:166-222,441-457, or analytic derivatives): columns [entries][3][n] in CSR entry order, kinds as above
+ * (column d of A, column d + dof of A, column d of B; kind-2 slots of DoFs >= num_ctrl are ignored) -- the layout of the
+ * library's key-point column store, uploaded straight into it: 3n doubles per entry instead of the 6n + 2 of the FD payload,
+ * and no differencing on the device.  With the IEEE quotients (x+ - x-) / (2 eps) the gains are bit for bit those of
+ * kpilqr_upload_fd_kp.  Refers to the CURRENT key-points like the FD payloads; replaces them. */
+int  kpilqr_upload_kp_columns(kpilqr_ctx *ctx, const double *columns, int entries);
+
 /* One whole iteration for the batch, PIPELINED over chunks of trajectories: chunk c's uploads, its kernels and its
  * downloads run on their own stream, so H2D(c+1), kernels(c) and D2H(c-1) overlap (and so do consecutive calls: nothing
  * here waits for the previous iteration).  Every host pointer must be pinned (kpilqr_host_alloc); NULL inputs keep what
@@ -222,6 +230,8 @@ typedef struct {
     const void *fd_kp_slab;                     /* key-point ordered payload (kpilqr_fd_kp_layout) instead of fd_slab; the
                                                    chunks' ranges follow from the key-points, no offset arrays needed     */
     int entries;                                /* kp_offsets[batch*dof]                                                 */
+    const double *kp_columns;                   /* the key-point columns (kpilqr_upload_kp_columns) instead of an FD payload:
+                                                   [entries][3][n]; version >= 301                                        */
 } kpilqr_stream_io;
 int  kpilqr_iterate_streamed(kpilqr_ctx *ctx, const kpilqr_stream_io *io, int pd_check_stride, int nchunks);
 

@@ -40,7 +40,7 @@ def test_header_compiles_as_plain_c(tmp_path):
 
 
 def test_version():
-    assert trajoptkp_amd.load().kpilqr_version() == 300
+    assert trajoptkp_amd.load().kpilqr_version() == 301
 
 
 def _no_gpu():

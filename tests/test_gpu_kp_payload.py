@@ -221,3 +221,38 @@ def test_backward_stats_histogram():
             assert relerr(K1, K0) < 1e-12 and relerr(k1, k0) < 1e-12
             extra[lam] = int((h[:, 1] + 2 * h[:, 2] + 3 * h[:, 3]).sum())
         assert extra[1e-4] >= extra[10.0]
+
+
+@pytest.mark.parametrize("fused", [True, False])
+def test_host_differenced_columns_give_the_bytes_of_the_fd_payload(fused, waves):
+    """kpilqr_upload_kp_columns: the key-point columns differenced on the host (IEEE quotients) and uploaded straight into the
+    column store == the key-point ordered FD payload differenced on the device, bit for bit -- gains, costs, and the
+    materialised A, B -- on fused and materialising contexts, one-sided jobs included; and through the chunk pipeline."""
+    def stages(e, p):
+        if not fused:
+            e.fd_difference(); e.interpolate(); e.cost_derivs()
+        st, dJ = e.backward(p["lam"], 100)
+        cost = e.forward_linear(orc.alphas(6))
+        K, k = e.gains()
+        e.interpolate()
+        A, B = e.get_AB()
+        return dict(K=K, k=k, delta_J=dJ, cost=cost, A=A, B=B)
+
+    for p in (synth.make_problem(task="panda_reaching", T=160, batch=3, min_N=4, one_sided_frac=0.3, dense_residuals=True),
+              synth.make_problem(task="acrobot", T=90, batch=2, min_N=1, config_id=1)):
+        xp, xm, mode = synth.kp_ordered_payload(p)
+        with Engine(p["dof"], p["m"], p["T"], p["nr"], batch=p["batch"], fused=fused) as e:
+            synth.upload(e, p, kp_ordered=True)
+            ref = stages(e, p)
+        assert np.any(ref["K"] != 0)
+        with Engine(p["dof"], p["m"], p["T"], p["nr"], batch=p["batch"], fused=fused) as e:
+            synth.upload(e, p, kp_ordered=True)            # key-points, residuals, nominal ... and a payload that is replaced:
+            e.upload_kp_columns(e.kp_columns(xp, xm, mode, eps=p["eps"]))
+            _same(stages(e, p), ref, keys=("K", "k", "delta_J", "cost", "A", "B"))
+            # the same columns through kpilqr_iterate_streamed, two chunks
+            cols = e.kp_columns(xp, xm, mode, eps=p["eps"])
+            Kp = e.pinned(ref["K"].shape); kp_ = e.pinned(ref["k"].shape); cp = e.pinned((p["batch"], 6)); jp = e.pinned((p["batch"],))
+            lam = e.pinned((p["batch"],)); lam[:] = p["lam"]
+            e.iterate_streamed(kp_cols=cols, lam=lam, K=Kp, k=kp_, cost_pred=cp, delta_J=jp, nchunks=2)
+            e.sync()
+            _same(dict(K=np.array(Kp), k=np.array(kp_), delta_J=np.array(jp), cost=np.array(cp)), ref)

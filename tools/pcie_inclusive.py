@@ -39,8 +39,12 @@ def measure(B=256, steps=5, T=3000, task="panda_reaching", chunk_list=(4, 8, 16)
         K = e.pinned(K0.shape); k = e.pinned(k0.shape)
         # the chunk pipeline ships the key-point ordered payload (no job lists, no nominal rows; the fused sweeps read it
         # directly); the serial form keeps round 1's call sequence with the job arrays
-        slab = e.fd_kp_slab(*synth.kp_ordered_payload(p))
+        kp_payload = synth.kp_ordered_payload(p)
+        slab = e.fd_kp_slab(*kp_payload)
         fd_bytes = slab["layout"].bytes
+        # ... or the key-point columns a host has differenced itself (kpilqr_upload_kp_columns): 3n doubles per entry
+        cols = e.kp_columns(*kp_payload, eps=p["eps"])
+        col_bytes = cols["entries"] * 3 * p["n"] * 8
         res_bytes = {True: pin["r"].nbytes + pin["r_x"].nbytes + pin["r_u"].nbytes, False: pin["r"].nbytes}
         dn_bytes = K.nbytes + k.nbytes
         from trajoptkp_amd.engine import _ptr
@@ -56,9 +60,10 @@ def measure(B=256, steps=5, T=3000, task="panda_reaching", chunk_list=(4, 8, 16)
             e._ck(e._L.kpilqr_download_gains(e._h, _ptr(K), _ptr(k)))
             e.sync()
 
-        def streamed(full, nchunks, sync_each):
+        def streamed(full, nchunks, sync_each, columns=False):
             kw = dict(r=pin["r"], r_x=pin["r_x"], r_u=pin["r_u"]) if full else dict(r=pin["r"])
-            e.iterate_streamed(fd_kp=slab, eps=p["eps"], lam=lam, K=K, k=k, nchunks=nchunks, **kw)
+            kw.update(dict(kp_cols=cols) if columns else dict(fd_kp=slab))
+            e.iterate_streamed(eps=p["eps"], lam=lam, K=K, k=k, nchunks=nchunks, **kw)
             if sync_each:
                 e.sync()
 
@@ -82,6 +87,13 @@ def measure(B=256, steps=5, T=3000, task="panda_reaching", chunk_list=(4, 8, 16)
                     dt = timed(streamed, full, nc, sync_each)
                     assert np.array_equal(K, K0) and np.array_equal(k, k0), "streamed K differs from the staged path"
                     rows.append((label, f"chunks={nc} " + ("per-iteration sync" if sync_each else "pipelined"), dt, up))
+        # the host-differenced columns as the payload (pipelined form of the first chunk count)
+        for full in (True, False):
+            K[...] = 0
+            dt = timed(streamed, full, chunk_list[0], False, True)
+            assert np.array_equal(K, K0) and np.array_equal(k, k0), "streamed K differs from the staged path (key-point columns)"
+            rows.append(("columns + " + ("full residual payload" if full else "resident Jacobians"), f"chunks={chunk_list[0]} pipelined", dt,
+                         col_bytes + res_bytes[full]))
         e.iterate(lam); e.sync()
         t0 = time.perf_counter()
         for _ in range(steps):
@@ -94,7 +106,7 @@ def measure(B=256, steps=5, T=3000, task="panda_reaching", chunk_list=(4, 8, 16)
     if not quiet:
         print(f"B={B} resident: {1e3 * dt_res:8.2f} ms/batch-iteration = {B / dt_res:9.1f} trajectory-iterations/s")
         for r in out["rows"]:
-            print(f"B={B} {r['payload']:18s} {r['form']:32s}: {r['ms_per_iteration']:8.2f} ms = {r['traj_it_per_s']:9.1f} traj-it/s"
+            print(f"B={B} {r['payload']:36s} {r['form']:32s}: {r['ms_per_iteration']:8.2f} ms = {r['traj_it_per_s']:9.1f} traj-it/s"
                   f"  (H2D {r['h2d_GB']:.2f} GB + D2H {r['d2h_GB']:.2f} GB -> {r['link_GBps']:.1f} GB/s)", flush=True)
     return out
 

@@ -27,6 +27,7 @@ SYMBOLS = [
     "kpilqr_comm_unique_id", "kpilqr_comm_init", "kpilqr_allreduce_linesearch",
     "kpilqr_fd_slab_layout", "kpilqr_upload_fd_slab", "kpilqr_iterate_streamed", "kpilqr_resize",
     "kpilqr_keypoint_error_test", "kpilqr_fd_kp_layout", "kpilqr_upload_fd_kp", "kpilqr_backward_stats",
+    "kpilqr_upload_kp_columns",
 ]
 
 
@@ -49,7 +50,7 @@ class StreamIO(C.Structure):
                 ("traj_job_first", C.c_void_p), ("traj_nom_first", C.c_void_p), ("eps", C.c_double),
                 ("r", C.c_void_p), ("r_x", C.c_void_p), ("r_u", C.c_void_p), ("u_nom", C.c_void_p), ("lam", C.c_void_p),
                 ("K", C.c_void_p), ("k", C.c_void_p), ("cost_pred", C.c_void_p), ("delta_J", C.c_void_p),
-                ("status", C.c_void_p), ("fd_kp_slab", C.c_void_p), ("entries", C.c_int)]
+                ("status", C.c_void_p), ("fd_kp_slab", C.c_void_p), ("entries", C.c_int), ("kp_columns", C.c_void_p)]
 
 
 FLAG_GENERIC_KERNELS = 1
@@ -131,6 +132,7 @@ def load():
     L.kpilqr_fd_kp_layout.argtypes = [vp, C.c_int, C.POINTER(FdkpLayout)]
     L.kpilqr_upload_fd_kp.argtypes = [vp, vp, C.c_int, C.c_double]
     L.kpilqr_backward_stats.argtypes = [vp, C.c_int, vp]
+    L.kpilqr_upload_kp_columns.argtypes = [vp, vp, C.c_int]
     for s in SYMBOLS:
         getattr(L, s)          # raises AttributeError if the .so lacks a declared symbol
     _lib = L

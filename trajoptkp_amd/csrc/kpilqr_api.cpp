@@ -181,6 +181,10 @@ static int ensure_entry_tables(kpilqr_ctx *c)
 static int difference_to_kpc(kpilqr_ctx *c)
 {
     if (c->fd_kind == 0 || !c->have_kp) return KPILQR_OK;
+    if (c->fd_kind == 3) {                       // the columns ARE the payload
+        if (!c->kpc_valid) return set_err(c, KPILQR_ERR_STATE, "the key-point columns are gone (new key-points): upload them again");
+        return KPILQR_OK;
+    }
     int rc = ensure_kpc(c);
     if (rc) return rc;
     if (c->fd_kind == 1) {
@@ -199,7 +203,7 @@ static int difference_to_kpc(kpilqr_ctx *c)
 static int records_from_payload(kpilqr_ctx *c)
 {
     if (c->fd_kind == 1) { KP_HIP(c, launch_fd_difference(c)); return KPILQR_OK; }
-    if (c->fd_kind == 2) {
+    if (c->fd_kind == 2 || c->fd_kind == 3) {
         if (!c->have_kp) return KPILQR_OK;
         int rc = KPILQR_OK;
         if (!c->kpc_valid) rc = difference_to_kpc(c);
@@ -521,7 +525,7 @@ int kpilqr_set_keypoints(kpilqr_ctx *c, const int *kp_offsets, const int *kp_tim
     if (!c->kp_traj_first_host) return set_err(c, KPILQR_ERR_ALLOC, "host allocation failed");
     for (int b = 0; b <= c->d.batch; b++) c->kp_traj_first_host[b] = kp_offsets[(size_t)b * c->d.dof];
     c->entry_tables_valid = false;
-    if (c->fd_kind == 2) { c->fd_kind = 0; c->fdk_entries = 0; }
+    if (c->fd_kind == 2 || c->fd_kind == 3) { c->fd_kind = 0; c->fdk_entries = 0; }
     payload_changed(c);
     return KPILQR_OK;
 }
@@ -578,7 +582,7 @@ int kpilqr_generate_keypoints(kpilqr_ctx *c, const char *method, int min_N, int 
     c->kp_total_host = -1;       // the lists exist on the device only (kpilqr_get_keypoints brings them to the host)
     if (c->kp_traj_first_host) { free(c->kp_traj_first_host); c->kp_traj_first_host = nullptr; }
     c->entry_tables_valid = false;
-    if (c->fd_kind == 2) { c->fd_kind = 0; c->fdk_entries = 0; }
+    if (c->fd_kind == 2 || c->fd_kind == 3) { c->fd_kind = 0; c->fdk_entries = 0; }
     payload_changed(c);
     return KPILQR_OK;
 }
@@ -759,6 +763,25 @@ int kpilqr_upload_fd_kp(kpilqr_ctx *c, const void *slab, int entries, double eps
     c->fdk_entries = entries; c->fdk_first = 0; c->eps = eps;
     c->fd_kind = 2; payload_changed(c);
     if (!is_pinned(slab)) KP_HIP(c, hipStreamSynchronize(c->stream));
+    return KPILQR_OK;
+}
+
+// The differenced key-point columns as the payload (fd_kind 3): straight into the column store
+int kpilqr_upload_kp_columns(kpilqr_ctx *c, const double *columns, int entries)
+{
+    if (!c || entries < 0 || (entries > 0 && !columns)) return KPILQR_ERR_ARG;
+    KP_ENTER(c);
+    if (!c->have_kp) return set_err(c, KPILQR_ERR_STATE, "kpilqr_upload_kp_columns before the key-points it is ordered by (kpilqr_set_keypoints / kpilqr_generate_keypoints)");
+    if (c->kp_total_host >= 0 && entries != c->kp_total_host)
+        return set_err(c, KPILQR_ERR_ARG, "kpilqr_upload_kp_columns: `entries` is not the number of key-point entries (kp_offsets[batch*dof])");
+    if ((size_t)entries > c->kp_cap) return set_err(c, KPILQR_ERR_ARG, "kpilqr_upload_kp_columns: more entries than key-points");
+    int rc = ensure_kpc(c);
+    if (rc) return rc;
+    if (entries) KP_HIP(c, hipMemcpyAsync(c->kpc, columns, (size_t)entries * 3 * c->n * 8, hipMemcpyHostToDevice, c->stream));
+    c->fd_kind = 3; c->fdk_entries = entries; c->fdk_first = 0;      // (the entry range, as for the key-point ordered payload)
+    payload_changed(c);
+    c->kpc_valid = true;
+    if (!is_pinned(columns)) KP_HIP(c, hipStreamSynchronize(c->stream));
     return KPILQR_OK;
 }
 
@@ -1055,14 +1078,15 @@ int kpilqr_iterate_streamed(kpilqr_ctx *c, const kpilqr_stream_io *io, int pd_ch
     if (nchunks > B) nchunks = B;
     if (io->fd_slab && (io->njobs < 1 || !io->traj_job_first || (io->nnom > 0 && !io->traj_nom_first)))
         return set_err(c, KPILQR_ERR_ARG, "streamed FD payload needs the per-trajectory job / nominal-row offsets");
-    if (io->fd_slab && io->fd_kp_slab) return set_err(c, KPILQR_ERR_ARG, "one FD payload per iteration: job lists OR key-point ordered");
-    if (io->fd_kp_slab) {
+    if ((io->fd_slab != nullptr) + (io->fd_kp_slab != nullptr) + (io->kp_columns != nullptr) > 1)
+        return set_err(c, KPILQR_ERR_ARG, "one FD payload per iteration: job lists OR key-point ordered OR key-point columns");
+    if (io->fd_kp_slab || io->kp_columns) {
         if (!c->kp_traj_first_host || c->kp_total_host < 0)
             return set_err(c, KPILQR_ERR_STATE, "streamed key-point ordered payload: the lists must be known to the host (kpilqr_set_keypoints, or kpilqr_get_keypoints after generating them)");
-        if (io->entries != c->kp_total_host) return set_err(c, KPILQR_ERR_ARG, "fd_kp_slab: `entries` is not the number of key-point entries");
+        if (io->entries != c->kp_total_host) return set_err(c, KPILQR_ERR_ARG, "fd_kp_slab / kp_columns: `entries` is not the number of key-point entries");
     }
     if (io->r_u) c->ru_zero = false;
-    const void *hostp[] = {io->fd_kp_slab, io->fd_slab, io->r, io->r_x, io->r_u, io->u_nom, io->lambda, io->K, io->k, io->cost_pred, io->delta_J, io->status};
+    const void *hostp[] = {io->kp_columns, io->fd_kp_slab, io->fd_slab, io->r, io->r_x, io->r_u, io->u_nom, io->lambda, io->K, io->k, io->cost_pred, io->delta_J, io->status};
     for (const void *p : hostp) if (!is_pinned(p)) return set_err(c, KPILQR_ERR_ARG, "kpilqr_iterate_streamed: host buffers must be pinned (kpilqr_host_alloc)");
     if (c->fused || c->tiled_a4) { int rc = check_fused(c); if (rc) return rc; }
     int rc = pipe_setup(c);
@@ -1131,11 +1155,13 @@ int kpilqr_iterate_streamed(kpilqr_ctx *c, const kpilqr_stream_io *io, int pd_ch
         if (rc) return rc;
         c->fdk_entries = io->entries; c->fdk_first = 0; c->eps = io->eps;
     }
+    const double *kcols = io->kp_columns;
     if (slab) c->fd_kind = 1;
     if (kslab) c->fd_kind = 2;
-    if (slab || kslab) payload_changed(c);
+    if (kcols) { c->fd_kind = 3; c->fdk_entries = io->entries; c->fdk_first = 0; }
+    if (slab || kslab || kcols) payload_changed(c);
     // allocations and tables the chunks need are made HERE, on the context: a view never allocates
-    if (c->fused || c->fd_kind == 2) {
+    if (c->fused || c->fd_kind == 2 || c->fd_kind == 3) {
         rc = ensure_kpc(c); if (rc) return rc;
         rc = ensure_entry_tables(c); if (rc) return rc;
     }
@@ -1179,10 +1205,17 @@ int kpilqr_iterate_streamed(kpilqr_ctx *c, const kpilqr_stream_io *io, int pd_ch
             const size_t E = (size_t)(e1 - e0), eo = (size_t)e0;
             if (E) KP_HIP(c, h2d(c->fdk_dev + eo * LK.entry_stride, kslab + eo * LK.entry_stride, E * LK.entry_stride, s));   // the chunk: ONE range
             v.fdk_first = e0; v.fdk_entries = (int)E;      // the chunk's entries
+        } else if (kcols) {
+            // the chunk's columns, straight into its range of the column store
+            const int e0 = c->kp_traj_first_host[b0], e1 = c->kp_traj_first_host[b1];
+            const size_t E = (size_t)(e1 - e0), eo = (size_t)e0 * 3 * n;
+            if (E) KP_HIP(c, h2d(c->kpc + eo, kcols + eo, E * 3 * n * 8, s));
+            v.njobs = 0; v.fdk_first = e0; v.fdk_entries = (int)E;
+            v.kpc_valid = true;
         } else {
             // no new FD payload: what was differenced before is reused (kpc / the records' key-point columns)
             v.njobs = 0;
-            if (c->fd_kind == 2 && c->kp_traj_first_host) {
+            if ((c->fd_kind == 2 || c->fd_kind == 3) && c->kp_traj_first_host) {
                 v.fdk_first = c->kp_traj_first_host[b0]; v.fdk_entries = c->kp_traj_first_host[b1] - v.fdk_first;
             }
         }
@@ -1193,7 +1226,7 @@ int kpilqr_iterate_streamed(kpilqr_ctx *c, const kpilqr_stream_io *io, int pd_ch
         if (io->lambda) KP_HIP(c, h2d(v.lambda, io->lambda + o, cnt * 8, s));
         // ---- kernels of the chunk --------------------------------------------------------------------------------
         if (!c->fused) {
-            if (slab || kslab) { rc = records_from_payload(&v); if (rc) { c->err = v.err; return rc; } }
+            if (slab || kslab || kcols) { rc = records_from_payload(&v); if (rc) { c->err = v.err; return rc; } }
             if (!c->tiled_a4) KP_HIP(c, launch_interpolate(&v));
             if (!c->tiled_a6) KP_HIP(c, launch_cost_derivs(&v));
         }

@@ -226,10 +226,24 @@ class Engine:
     def upload_fd_kp(self, s, eps=1e-6):
         self._ck(self._L.kpilqr_upload_fd_kp(self._h, _ptr(s["slab"]), s["entries"], float(eps)))
 
+    def kp_columns(self, xplus, xminus, mode, eps=1e-6, pinned=True):
+        """The key-point columns differenced ON THE HOST from the arrays of fd_kp_slab (IEEE quotients: bit for bit what
+        the device forms from the same payload): [entries][3][n] for upload_kp_columns / iterate_streamed(kp_cols=...)."""
+        ent = int(np.shape(mode)[0])
+        xp = np.ascontiguousarray(xplus, np.float64).reshape(ent, 3, self.n)
+        xm = np.ascontiguousarray(xminus, np.float64).reshape(ent, 3, self.n)
+        den = np.where((np.asarray(mode, np.int32)[:, None] >> np.arange(3)[None, :]) & 1, float(eps), 2.0 * float(eps))   # [entries][kind]
+        cols = self.pinned(max(ent * 3 * self.n, 1)) if pinned else np.zeros(max(ent * 3 * self.n, 1))
+        cols[:ent * 3 * self.n].reshape(ent, 3, self.n)[...] = (xp - xm) / den[:, :, None]
+        return dict(cols=cols, entries=ent)
+
+    def upload_kp_columns(self, s):
+        self._ck(self._L.kpilqr_upload_kp_columns(self._h, _ptr(s["cols"]), s["entries"]))
+
     def upload_fd_slab(self, s, eps=1e-6):
         self._ck(self._L.kpilqr_upload_fd_slab(self._h, _ptr(s["slab"]), s["njobs"], s["nnom"], float(eps)))
 
-    def iterate_streamed(self, fd=None, fd_kp=None, eps=1e-6, r=None, r_x=None, r_u=None, u_nom=None, lam=None, K=None, k=None,
+    def iterate_streamed(self, fd=None, fd_kp=None, kp_cols=None, eps=1e-6, r=None, r_x=None, r_u=None, u_nom=None, lam=None, K=None, k=None,
                          cost_pred=None, delta_J=None, status=None, pd_stride=100, nchunks=0):
         """kpilqr_iterate_streamed: every array must come from self.pinned(); asynchronous (sync() to wait)."""
         io = _lib.StreamIO()
@@ -238,6 +252,8 @@ class Engine:
             io.traj_job_first = fd["traj_job_first"].ctypes.data; io.traj_nom_first = fd["traj_nom_first"].ctypes.data
         if fd_kp is not None:
             io.fd_kp_slab = fd_kp["slab"].ctypes.data; io.entries = fd_kp["entries"]
+        if kp_cols is not None:
+            io.kp_columns = kp_cols["cols"].ctypes.data; io.entries = kp_cols["entries"]
         io.eps = float(eps)
         for name, a in (("r", r), ("r_x", r_x), ("r_u", r_u), ("u_nom", u_nom), ("lam", lam), ("K", K), ("k", k),
                         ("cost_pred", cost_pred), ("delta_J", delta_J), ("status", status)):
