@@ -121,6 +121,10 @@ def test_acrobot_fused_unfused_and_analytic_residual_jacobians_agree():
     assert np.allclose(base["cost_history"], unf["cost_history"], rtol=1e-7)
     assert np.allclose(base["cost_history"], ana["cost_history"], rtol=1e-5)
     assert np.allclose(base["K0"], unf["K0"], rtol=1e-6, atol=1e-9)
+    # a2 on the host (iLQR_GPU::host_differencing -> kpilqr_upload_kp_columns): the same bytes as differencing on the device
+    col = host.run_acrobot(T=100, min_N=5, max_iter=6, min_iter=2, method="set_interval+fused+columns", torque_weight=1e-3)
+    assert col["iterations"] == base["iterations"]
+    assert np.array_equal(col["cost_history"], base["cost_history"]) and np.array_equal(col["K0"], base["K0"])
     # a filtering task (Optimiser::FilterDynamicsMatrices) runs on the materialising pipeline and still optimises
     for f in ("low_pass", "FIR"):
         r = host.run_acrobot(T=100, min_N=5, max_iter=6, min_iter=2, method=f"set_interval+{f}", torque_weight=1e-3)

@@ -76,6 +76,7 @@ int kpilqr_host_run_acrobot(int T, int min_N, int max_iter, int min_iter, const 
     if (!opt.ok()) return -2;
     if (unfused) opt.SetFused(false);
     if (fused) opt.SetFused(true);
+    opt.host_differencing = keypoint_method_full.find("+columns") != std::string::npos;
     if (lowpass || fir) { opt.filteringMethod = lowpass ? "low_pass" : "FIR"; opt.SetFused(false); }
     std::vector<MatrixXd> U0(T, MatrixXd(1, 1));
     std::vector<MatrixXd> U = opt.Optimise(sim->main_data, U0, max_iter, min_iter, T);

@@ -36,6 +36,8 @@ void iLQR_GPU::free_pinned()
     for (double **p : all) { if (*p && ctx) kpilqr_host_free(ctx, *p); *p = nullptr; }
     if (kp_slab && ctx) kpilqr_host_free(ctx, kp_slab);
     kp_slab = nullptr; kp_slab_bytes = 0;
+    if (kp_cols && ctx) kpilqr_host_free(ctx, kp_cols);
+    kp_cols = nullptr; kp_cols_count = 0;
 }
 
 iLQR_GPU::~iLQR_GPU()
@@ -167,7 +169,26 @@ void iLQR_GPU::GenerateDerivatives()
             if ((rc = kpilqr_host_alloc(ctx, kp_slab_bytes, (void **)&kp_slab))) fatal("kpilqr_host_alloc", rc);
         }
         activeDifferentiator->DynamicsDerivativesKp(kp_slab, lay.entry_stride, 0, offs, times, keypoint_generator->keypoints, eps);
-        if ((rc = kpilqr_upload_fd_kp(ctx, kp_slab, entries, eps))) fatal("kpilqr_upload_fd_kp", rc);
+        if (host_differencing) {
+            // a2 on the host: (x+ - x-) / (2 eps), or / eps for a one-sided job (bit `kind` of the entry's mode word), then the
+            // columns go up as they are
+            const size_t per = (size_t)3 * n, want = (size_t)entries * per;
+            if (want > kp_cols_count) {
+                if (kp_cols) kpilqr_host_free(ctx, kp_cols);
+                kp_cols_count = want + want / 4 + 64;
+                if ((rc = kpilqr_host_alloc(ctx, kp_cols_count * sizeof(double), (void **)&kp_cols))) fatal("kpilqr_host_alloc", rc);
+            }
+            for (int e = 0; e < entries; e++) {
+                const char *rec = kp_slab + (size_t)e * lay.entry_stride;
+                const double *xp = (const double *)(rec + lay.xplus), *xm = (const double *)(rec + lay.xminus);
+                const int mode = *(const int *)(rec + lay.mode);
+                for (int kind = 0; kind < 3; kind++) {
+                    const double den = ((mode >> kind) & 1) ? eps : 2 * eps;
+                    for (int r = 0; r < n; r++) kp_cols[(size_t)e * per + (size_t)kind * n + r] = (xp[kind * n + r] - xm[kind * n + r]) / den;
+                }
+            }
+            if ((rc = kpilqr_upload_kp_columns(ctx, kp_cols, entries))) fatal("kpilqr_upload_kp_columns", rc);
+        } else if ((rc = kpilqr_upload_fd_kp(ctx, kp_slab, entries, eps))) fatal("kpilqr_upload_fd_kp", rc);
     } else {
     // FD at the key-points on the persistent pool, straight into ONE pinned slab (jobs, nominal rows):
     // the upload is a single DMA and nothing on the host walks the jobs afterwards

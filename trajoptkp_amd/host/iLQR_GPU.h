@@ -28,6 +28,9 @@ public:
     // inside the sweeps.  For one trajectory the sweeps run as wave pairs (producer/consumer backward, state/cost
     // forward: DESIGN.md section 4.6) -- 5.9 ms per iteration at T=3000 against 7.0 ms materialising.
     bool use_fused = true;
+    // Fused sweeps: difference the FD results on the HOST, as the reference does (Differentiator.cpp:166-222,441-457), and
+    // upload the key-point columns (kpilqr_upload_kp_columns: half the bytes of x+ / x-, the same gains bit for bit)
+    bool host_differencing = false;
     void SetFused(bool on) { if (on != use_fused) { use_fused = on; recreate_ctx = true; Resize(dof, num_ctrl, horizon_length); } }
     std::string BackwardVariant() const { return ctx ? kpilqr_backward_variant(ctx) : ""; }
 
@@ -70,6 +73,8 @@ private:
     FDStaging staging;
     char *kp_slab = nullptr;                 // key-point ordered FD payload (fused sweeps): one pinned slab of entry records
     size_t kp_slab_bytes = 0;
+    double *kp_cols = nullptr;               // host_differencing: the differenced columns [entries][3][n], pinned
+    size_t kp_cols_count = 0;
     double *host_r = nullptr, *host_rx = nullptr, *host_ru = nullptr, *host_unom = nullptr, *host_K = nullptr, *host_k = nullptr;
     void free_pinned();
     bool fused_active = false, recreate_ctx = false;
