@@ -495,7 +495,7 @@ __device__ __forceinline__ void backward_fused_body(double *sh, const double *pc
         // a memory operation (the differenced column out to kpc, the next column and its time in) waits for `late_cross`
         // below, BEHIND the wait for this step's residual tiles: in front of it the wait, which the compiler has to place
         // conservatively behind a divergent branch, drained the requests the branch had just issued -- a trip to HBM on
-        // every step on which any lane crossed (ragged key-point sets: most steps; 8.7 -> ... ms).
+        // every step on which any lane crossed (ragged key-point sets: most steps; 8.89 -> 8.32 and 9.61 -> 8.72 ms on two such sets).
         if constexpr (!UNI) {
             cross = t < s;
             if (cross) {
