@@ -2125,11 +2125,11 @@ hipError_t launch_forward_fused(Ctx *c, double *U_alpha_dev)
     dim3 grid(c->d.batch), block(64);
     const bool excl = c->d.batch <= c->n_simd;
     const FusedArgs F = fused_args(c);
-    // One wave per trajectory with its tile requests four steps ahead (forward_fused_body) from 64 trajectories up: 1.83 ms
-    // per sweep at B = 64 ... 512 against 1.89 ... 2.49 ms for the state / cost wave groups, which keep a single step of
-    // requests in flight; below that the state / cost / cost triple's shorter step wins (B = 1, 8: 1.63 against 1.83 ms).
+    // One wave per trajectory with its tile requests four steps ahead (forward_fused_body) from 26 trajectories up: 1.79 ms
+    // per sweep at B = 32 ... 512 against 1.85 ... 2.49 ms for the state / cost wave groups, which keep a single step of
+    // requests in flight; below that the state / cost / cost triple's shorter step wins (B = 1 ... 24: 1.63 ... 1.75 against 1.79 ms).
     // KPILQR_FUSED_FWD_WAVES = 1 | 2 | 3 forces a form.
-    const int form = c->tune.fused_fwd_waves ? c->tune.fused_fwd_waves : (32 * c->d.batch <= c->n_simd ? 3 : 1);
+    const int form = c->tune.fused_fwd_waves ? c->tune.fused_fwd_waves : (40 * c->d.batch <= c->n_simd ? 3 : 1);
     const int ncz = (n + 2 + 3) / 4, ncu = (m + 3) / 4;       // tile chunks of [dx; alpha; 1] and of the controls
     if (form == 3) {
         dim3 block3(192);
