@@ -250,14 +250,18 @@ def time_config(torch, stream, dev, p, steps, warmup, fused, generic, world=1, d
     is_fused = "fused" in eng.backward_variant
     tail = eng.backward_variant.rsplit("_", 1)[-1] if "tiled_" in eng.backward_variant else ""
     a4, a6 = "a4" in tail, "a6" in tail          # tiled shapes: which of a4 / a6 run inside the sweeps
-    # Fused sweeps: the FD payload is resident KEY-POINT ORDERED (kpilqr_upload_fd_kp) and there is no differencing stage at
-    # all -- with one wave per trajectory the backward sweep differences x+ / x- itself at every segment crossing (every timed
-    # step does: nothing marks the column store valid), smaller batches run the streaming differencing kernel inside the
-    # "backward" stage.  Materialising / tiled contexts: job lists and kpilqr_fd_difference, as before.
+    # Fused sweeps: the FD payload is resident KEY-POINT ORDERED (kpilqr_upload_fd_kp).  With one wave per trajectory the backward
+    # sweep differences x+ / x- itself at every segment crossing (every timed step does: nothing marks the column store valid)
+    # and there is no differencing stage; smaller batches -- a GPU's share at N > 1 -- difference with the streaming kernel as
+    # a stage of every timed step.  Materialising / tiled contexts: job lists and kpilqr_fd_difference, as before.
     synth.upload(eng, p, kp_ordered=is_fused and kp_ordered)
     lam = np.full(B, p["lam"])
     alphas = np.array([(i / 6.0) ** 2 for i in range(1, 7)])
-    stages = (() if is_fused else ("fd_difference",)) + (() if (is_fused or a4) else ("interpolate",)) + (() if (is_fused or a6) else ("cost_derivs",)) \
+    # raw: the library's own choice (one wave per trajectory beyond #SIMDs / 2 trajectories) -- the backward pass differences the
+    # payload itself on EVERY call.  Otherwise the differencing is a stage of its own in every timed step (kpilqr_fd_difference:
+    # the streaming kernel; a backward pass alone would find the column store of the unchanged payload still valid and skip it).
+    raw = is_fused and kp_ordered and (2 * B > 1024 or os.environ.get("KPILQR_FUSED_WAVES") == "1") and os.environ.get("KPILQR_FUSED_RAW") != "0"
+    stages = (() if raw else ("fd_difference",)) + (() if (is_fused or a4) else ("interpolate",)) + (() if (is_fused or a6) else ("cost_derivs",)) \
         + ("backward", "forward")
     calls = {"fd_difference": eng.fd_difference, "interpolate": eng.interpolate, "cost_derivs": eng.cost_derivs,
              "backward": lambda: eng.backward(None, 100, fetch=False), "forward": lambda: eng.forward_linear(None, fetch=False)}
@@ -299,7 +303,6 @@ def time_config(torch, stream, dev, p, steps, warmup, fused, generic, world=1, d
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
         elapsed = float(tt.item())
     stage_ms = {name: float(np.mean([evs[s][i][0].elapsed_time(evs[s][i][1]) for s in range(steps)])) for i, name in enumerate(stages)}
-    raw = is_fused and kp_ordered and (2 * B > 1024 or os.environ.get("KPILQR_FUSED_WAVES") == "1") and os.environ.get("KPILQR_FUSED_RAW") != "0"
     return dict(eng=eng, elapsed=elapsed, stage_ms=stage_ms, stages=stages, fused=is_fused, raw=raw, kp_ordered=is_fused and kp_ordered,
                 variants={"backward": eng.backward_variant, "forward": eng.forward_variant})
 
