@@ -250,17 +250,19 @@ def time_config(torch, stream, dev, p, steps, warmup, fused, generic, world=1, d
     is_fused = "fused" in eng.backward_variant
     tail = eng.backward_variant.rsplit("_", 1)[-1] if "tiled_" in eng.backward_variant else ""
     a4, a6 = "a4" in tail, "a6" in tail          # tiled shapes: which of a4 / a6 run inside the sweeps
-    # Fused sweeps: the FD payload is resident KEY-POINT ORDERED (kpilqr_upload_fd_kp).  With one wave per trajectory the backward
-    # sweep differences x+ / x- itself at every segment crossing (every timed step does: nothing marks the column store valid)
-    # and there is no differencing stage; smaller batches -- a GPU's share at N > 1 -- difference with the streaming kernel as
-    # a stage of every timed step.  Materialising / tiled contexts: job lists and kpilqr_fd_difference, as before.
+    # Fused sweeps: the FD payload is resident KEY-POINT ORDERED (kpilqr_upload_fd_kp); beyond 256 trajectories the backward pass
+    # differences x+ / x- itself at every segment crossing, on every timed step, and there is no differencing stage; below, and on
+    # materialising / tiled contexts (job lists), kpilqr_fd_difference is a stage of every timed step.
     synth.upload(eng, p, kp_ordered=is_fused and kp_ordered)
     lam = np.full(B, p["lam"])
     alphas = np.array([(i / 6.0) ** 2 for i in range(1, 7)])
-    # raw: the library's own choice (one wave per trajectory beyond #SIMDs / 2 trajectories) -- the backward pass differences the
-    # payload itself on EVERY call.  Otherwise the differencing is a stage of its own in every timed step (kpilqr_fd_difference:
-    # the streaming kernel; a backward pass alone would find the column store of the unchanged payload still valid and skip it).
-    raw = is_fused and kp_ordered and (2 * B > 1024 or os.environ.get("KPILQR_FUSED_WAVES") == "1") and os.environ.get("KPILQR_FUSED_RAW") != "0"
+    # raw: the library's own choice for a key-point ordered payload on a fused context beyond #SIMDs / 4 trajectories -- the backward
+    # pass differences the payload itself on EVERY call (in the sweep with one wave per trajectory, in the producer wave of the
+    # pair; nothing marks the column store valid).  Otherwise (the triple, below that) the differencing is a stage of its own in
+    # every timed step (kpilqr_fd_difference: a backward pass alone would find the column store of the unchanged payload still
+    # valid and skip it).
+    raw = is_fused and kp_ordered and (4 * B > 1024 or os.environ.get("KPILQR_FUSED_WAVES") in ("1", "3")) \
+        and os.environ.get("KPILQR_FUSED_WAVES") not in ("2", "4") and os.environ.get("KPILQR_FUSED_RAW") != "0"
     stages = (() if raw else ("fd_difference",)) + (() if (is_fused or a4) else ("interpolate",)) + (() if (is_fused or a6) else ("cost_derivs",)) \
         + ("backward", "forward")
     calls = {"fd_difference": eng.fd_difference, "interpolate": eng.interpolate, "cost_derivs": eng.cost_derivs,

@@ -914,6 +914,81 @@ struct DownTracker {
     __device__ __forceinline__ double value(int i, double dt) const { return lerp_nc(sv[i], dt, av[i]); }
 };
 
+// The same walking the KEY-POINT ORDERED FD PAYLOAD (producer wave of the pair / triple, RAWP): the prefetched x+ / x- of the
+// next segment start are differenced when the lane reaches it -- (x+ - x-) / (2 eps), / eps for a one-sided job: the arithmetic
+// and the bytes of k_fd_kp_difference -- and the column goes out to kpc for the forward sweep.  The producer is a step ahead of the
+// consumer and not the longer wave: the differencing costs the sweep nothing (a streaming kernel in front of it: 0.09 ... 0.41 ms
+// at 128 ... 512 trajectories).  Values 0..3 of a lane belong to its A column (kind 0 / 1), 4..7 to its B column (kind 2).
+struct DownTrackerRaw {
+    static constexpr int NV = 8;
+    int offs[NV];
+    int lo, idx, s, nb, nb2, pmode, bitA;
+    double sv[NV], av[NV], pv[NV], pm[NV];
+    int E0, NE, strideR, offM, offMode, strideB;
+    bool has;
+    __device__ __forceinline__ void load_raw(__amdgpu_buffer_rsrc_t rP, int e_rel, double *xp, double *xm, int &mo) const
+    {
+        const int base = ((unsigned)e_rel < (unsigned)NE) ? e_rel * strideR : BIGOFF;
+#pragma unroll
+        for (int r = 0; r < NV; r++) { xp[r] = fbld(rP, base + offs[r]); xm[r] = fbld(rP, base + offM + offs[r]); }
+        mo = __builtin_amdgcn_raw_buffer_load_b32(rP, base + (has ? offMode : BIGOFF), 0, 0);
+    }
+    __device__ __forceinline__ void diff(double *xp, const double *xm, int mo, double eps2, double rinv2) const
+    {
+        const bool oa = (mo & bitA) != 0, ob = (mo & 4) != 0;
+        const double dA = oa ? 0.5 * eps2 : eps2, rA = oa ? 2.0 * rinv2 : rinv2;     // exact halves / doubles
+        const double dB = ob ? 0.5 * eps2 : eps2, rB = ob ? 2.0 * rinv2 : rinv2;
+#pragma unroll
+        for (int i = 0; i < 4; i++) { xp[i] = fdiv(xp[i] - xm[i], dA, rA); xp[4 + i] = fdiv(xp[4 + i] - xm[4 + i], dB, rB); }
+    }
+    __device__ __forceinline__ void store(__amdgpu_buffer_rsrc_t rT, int e_rel, const double *x) const
+    {
+        const int base = ((unsigned)e_rel < (unsigned)NE) ? e_rel * strideB : BIGOFF;
+#pragma unroll
+        for (int r = 0; r < NV; r++) __builtin_amdgcn_raw_buffer_store_b64(__builtin_bit_cast(u32x2f, x[r]), rT, base + offs[r], 0, 0);
+    }
+    __device__ __forceinline__ void init(__amdgpu_buffer_rsrc_t rT, __amdgpu_buffer_rsrc_t rP, const int *kp_offsets, const int *kp_times, bool has_,
+                                         size_t list, int E0_, int NE_, int n, bool pos_col, double eps2, double rinv2)
+    {
+        E0 = E0_; NE = NE_; has = has_;
+        strideB = 3 * n * 8; strideR = (6 * n + 2) * 8; offM = 3 * n * 8; offMode = 6 * n * 8;
+        bitA = pos_col ? 1 : 2;
+        lo = has ? kp_offsets[list] : 0;
+        const int hi = has ? kp_offsets[list + 1] : 0;
+        idx = hi - 1;
+        s = has ? kp_times[idx] : -1;
+        nb = (has && idx - 1 >= lo) ? kp_times[idx - 1] : -1;
+        nb2 = (has && idx - 2 >= lo) ? kp_times[idx - 2] : -1;
+        int mo0;
+        load_raw(rP, has ? idx - E0 : -1, sv, pm, mo0);
+        diff(sv, pm, mo0, eps2, rinv2);
+        store(rT, has ? idx - E0 : -1, sv);
+        load_raw(rP, (has && idx - 1 >= lo) ? idx - 1 - E0 : -1, pv, pm, pmode);
+#pragma unroll
+        for (int i = 0; i < NV; i++) av[i] = 0.0;
+    }
+    __device__ __forceinline__ void advance(__amdgpu_buffer_rsrc_t rT, __amdgpu_buffer_rsrc_t rP, const int *kp_times, int t, double eps2, double rinv2)
+    {
+        if (t < s) {                                 // per lane: crossed the start of the current segment
+            const double den = (double)(s - nb);
+            const double rinv = kp_rcp(den);
+            diff(pv, pm, pmode, eps2, rinv2);
+            store(rT, idx - 1 - E0, pv);
+#pragma unroll
+            for (int i = 0; i < NV; i++) {
+                const double ev = sv[i];
+                sv[i] = pv[i];
+                av[i] = fdiv(ev - sv[i], den, rinv);
+            }
+            s = nb; idx--;
+            nb = nb2;
+            nb2 = (idx - 2 >= lo) ? kp_times[idx - 2] : -1;
+            load_raw(rP, (idx - 1 >= lo) ? idx - 1 - E0 : -1, pv, pm, pmode);
+        }
+    }
+    __device__ __forceinline__ double value(int i, double dt) const { return lerp_nc(sv[i], dt, av[i]); }
+};
+
 // ---- wave U: control side ------------------------------------------------------------------------------------
 template <int N, int M>
 __device__ __forceinline__ void fused2_role_U(double *sh, RecLayout L, FusedArgs F, int T, double lam,
@@ -1207,7 +1282,7 @@ k_backward_fused2(RecLayout L, FusedArgs F, int T, int role_shift, const double 
 // s_barrier per step: at the end of step t the consumer has read slot t&1 and the producer has filled slot (t-1)&1.
 // Two waves per SIMD at batch = #SIMDs: the producer's independent MFMAs and FP64 FMAs issue into the bubbles of the
 // consumer's dependent chain.
-template <int N, int M, bool TRIPLE = false>
+template <int N, int M, bool TRIPLE = false, bool RAWP = false>
 __device__ __forceinline__ void fusedpc_producer(double *pcbuf, int *sflag, RecLayout L, FusedArgs F, int T)
 {
     constexpr int n = N, m = M;
@@ -1215,7 +1290,7 @@ __device__ __forceinline__ void fusedpc_producer(double *pcbuf, int *sflag, RecL
     const int b = KP_BLOCK_TRAJ;
     const int nr = F.nr, ncr = (nr + 3) >> 2;
     const int strideB = 3 * L.n * 8;                               // bytes of one key-point entry of kpc: three columns
-    DownTracker<8> tr;                           // A rows then B rows of column c
+    typename std::conditional<RAWP, DownTrackerRaw, DownTracker<8>>::type tr;       // A rows then B rows of column c
     int oRx[4], oR1[4], oRu[4];
     d4 Wt, Wr;
     {
@@ -1252,7 +1327,14 @@ __device__ __forceinline__ void fusedpc_producer(double *pcbuf, int *sflag, RecL
         Ru.x = fbld(rU, oRu[0]); Ru.y = fbld(rU, oRu[1]); Ru.z = fbld(rU, oRu[2]); Ru.w = fbld(rU, oRu[3]);
     };
     const int kd = (c < F.dof) ? c : c - F.dof;
-    tr.init(rT, F.kp_offsets, F.kp_times, c < n, (size_t)b * F.dof + kd, E0, NE, strideB);
+    __amdgpu_buffer_rsrc_t rP = rT;
+    if constexpr (RAWP) {
+        rP = frsrc(F.fdk + (size_t)E0 * (6 * n + 2) * 8, NE * (6 * n + 2) * 8);
+        tr.init(rT, rP, F.kp_offsets, F.kp_times, c < n, (size_t)b * F.dof + kd, E0, NE, n, c < F.dof, F.eps2, F.rinv_2eps);
+    } else {
+        tr.init(rT, F.kp_offsets, F.kp_times, c < n, (size_t)b * F.dof + kd, E0, NE, strideB);
+    }
+    (void)rP;
 #pragma unroll
     for (int r = 0; r < 4; r++) if (c == n && 4 * r + q == n) tr.sv[r] = 1.0;       // Fz(n,n) = 1
     auto publish = [&](int t, const d4 &W2) {
@@ -1275,7 +1357,8 @@ __device__ __forceinline__ void fusedpc_producer(double *pcbuf, int *sflag, RecL
     __syncthreads();
     for (int t = T - 1; t >= 0; t--) {
         if (t > 0) {
-            tr.advance(rT, F.kp_times, t - 1, strideB);
+            if constexpr (RAWP) tr.advance(rT, rP, F.kp_times, t - 1, F.eps2, F.rinv_2eps);
+            else tr.advance(rT, F.kp_times, t - 1, strideB);
             publish(t - 1, Wr);
         }
         if constexpr (TRIPLE) __syncthreads();             // the mid-step barrier of the consumer and the side wave
@@ -1327,7 +1410,9 @@ __device__ __forceinline__ void fusedpc_side(const double *sh, double *pcbuf, in
 #define FPC_RING FLDS_TOTAL
 #define FPC_FLAG (FPC_RING + 2 * FPC_BUF + 2 * 256)
 #define FPC_TOTAL (FPC_FLAG + 2)
-template <int N, int M>
+// guard: -1 run, 1 run only when the device flag says the key-point set is uniform, 0 only when it is not (the raw producer is
+// launched for uniform sets; per-DoF lists go through k_fd_kp_difference and the plain producer, launched behind it)
+template <int N, int M, bool RAWP>
 __device__ __forceinline__ void backward_fusedpc_block(RecLayout L, FusedArgs F, int T, int role_shift, const double *__restrict__ lambda, int pd_stride, double *__restrict__ Kout, double *__restrict__ kout,
                    double *__restrict__ delta_J, int *__restrict__ status)
 {
@@ -1337,24 +1422,26 @@ __device__ __forceinline__ void backward_fusedpc_block(RecLayout L, FusedArgs F,
         backward_fused_body<N, M, true>(sh, sh + FPC_RING, (int *)(sh + FPC_FLAG), L, F, T, lambda, pd_stride, Kout, kout,
                                         delta_J, status);
     else
-        fusedpc_producer<N, M>(sh + FPC_RING, (int *)(sh + FPC_FLAG), L, F, T);
+        fusedpc_producer<N, M, false, RAWP>(sh + FPC_RING, (int *)(sh + FPC_FLAG), L, F, T);
 }
-template <int N, int M>
+template <int N, int M, bool RAWP>
 __global__ void __launch_bounds__(128) __attribute__((amdgpu_waves_per_eu(2, 2)))
 k_backward_fusedpc(RecLayout L, FusedArgs F, int T, int role_shift, const double *__restrict__ lambda,
                    int pd_stride, double *__restrict__ Kout, double *__restrict__ kout,
-                   double *__restrict__ delta_J, int *__restrict__ status)
+                   double *__restrict__ delta_J, int *__restrict__ status, const int *__restrict__ kp_uniform, int guard)
 {
-    backward_fusedpc_block<N, M>(L, F, T, role_shift, lambda, pd_stride, Kout, kout, delta_J, status);
+    if (guard >= 0 && (*kp_uniform != 0) != (guard != 0)) return;
+    backward_fusedpc_block<N, M, RAWP>(L, F, T, role_shift, lambda, pd_stride, Kout, kout, delta_J, status);
 }
 // Wave TRIPLE per trajectory (batch <= #CUs): consumer | side | producer, one SIMD each of one CU.
-template <int N, int M>
+template <int N, int M, bool RAWP>
 __global__ void __launch_bounds__(192) __attribute__((amdgpu_waves_per_eu(1, 1)))
 k_backward_fusedpc3(RecLayout L, FusedArgs F, int T, int role_shift, const double *__restrict__ lambda,
                     int pd_stride, double *__restrict__ Kout, double *__restrict__ kout,
-                    double *__restrict__ delta_J, int *__restrict__ status)
+                    double *__restrict__ delta_J, int *__restrict__ status, const int *__restrict__ kp_uniform, int guard)
 {
     __shared__ __attribute__((aligned(16))) double sh[FPC_TOTAL];
+    if (guard >= 0 && (*kp_uniform != 0) != (guard != 0)) return;
     const int role = (int)((__builtin_amdgcn_readfirstlane(threadIdx.x >> 6) + (blockIdx.x >> role_shift)) % 3);
     if (role == 0)
         backward_fused_body<N, M, true, false, true>(sh, sh + FPC_RING, (int *)(sh + FPC_FLAG), L, F, T, lambda, pd_stride, Kout, kout,
@@ -1362,16 +1449,17 @@ k_backward_fusedpc3(RecLayout L, FusedArgs F, int T, int role_shift, const doubl
     else if (role == 1)
         fusedpc_side<N, M>(sh, sh + FPC_RING, (int *)(sh + FPC_FLAG), T);
     else
-        fusedpc_producer<N, M, true>(sh + FPC_RING, (int *)(sh + FPC_FLAG), L, F, T);
+        fusedpc_producer<N, M, true, RAWP>(sh + FPC_RING, (int *)(sh + FPC_FLAG), L, F, T);
 }
 // at most one wave per SIMD: while 2 x batch <= #SIMDs every wave of every pair gets a SIMD (and its FP64 unit) to itself
-template <int N, int M>
+template <int N, int M, bool RAWP>
 __global__ void __launch_bounds__(128) __attribute__((amdgpu_waves_per_eu(1, 1)))
 k_backward_fusedpc_excl(RecLayout L, FusedArgs F, int T, int role_shift, const double *__restrict__ lambda,
                         int pd_stride, double *__restrict__ Kout, double *__restrict__ kout,
-                        double *__restrict__ delta_J, int *__restrict__ status)
+                        double *__restrict__ delta_J, int *__restrict__ status, const int *__restrict__ kp_uniform, int guard)
 {
-    backward_fusedpc_block<N, M>(L, F, T, role_shift, lambda, pd_stride, Kout, kout, delta_J, status);
+    if (guard >= 0 && (*kp_uniform != 0) != (guard != 0)) return;
+    backward_fusedpc_block<N, M, RAWP>(L, F, T, role_shift, lambda, pd_stride, Kout, kout, delta_J, status);
 }
 
 // ---------------------------------------------------------------------------------------------------------
@@ -2043,7 +2131,7 @@ hipError_t launch_backward_fused(Ctx *c, int pd_stride, bool raw)
     // KPILQR_FUSED_WAVES forces a form: 1 = one wave, 2 = control/state split, 3 = producer/consumer, 4 = the triple
     // consumer / side / producer (while batch <= #CUs: the three waves of a workgroup share a CU).
     const int form = backward_fused_form(c);
-    if (raw && form != 1) return hipErrorInvalidValue;
+    if (raw && form != 1 && form != 3) return hipErrorInvalidValue;
     const int role_shift = c->tune.role_shift;
     dim3 block2(128);
     if (form == 2) {
@@ -2052,21 +2140,35 @@ hipError_t launch_backward_fused(Ctx *c, int pd_stride, bool raw)
         else return hipErrorInvalidValue;
         return hipGetLastError();
     }
+    // (the triple keeps the streaming differencing kernel in front of it: with the payload differenced in its producer wave that
+    // wave is late at every crossing and the consumer waits -- 5.13 against 5.07 ms per iteration at B = 128, 4.80 against 4.64 at B = 1)
     if (form == 4) {
         dim3 block3(192);
-#define KP_X(NN, MM) if (n == NN && m == MM) { hipLaunchKernelGGL((k_backward_fusedpc3<NN, MM>), grid, block3, 0, c->stream, c->L, F, c->d.T, role_shift, c->lambda, pd_stride, c->K, c->k, c->delta_J, c->status); return hipGetLastError(); }
+#define KP_X(NN, MM) if (n == NN && m == MM) { hipLaunchKernelGGL((k_backward_fusedpc3<NN, MM, false>), grid, block3, 0, c->stream, c->L, F, c->d.T, role_shift, c->lambda, pd_stride, c->K, c->k, c->delta_J, c->status, c->kp_uniform, -1); return hipGetLastError(); }
         KP_T1_SHAPES(KP_X)
 #undef KP_X
         return hipErrorInvalidValue;
     }
+    // raw (pair, 256 < batch <= 512): the producer wave differences the key-point ordered payload of UNIFORM sets itself (5.82
+    // against 6.03 ms per iteration at B = 512); per-DoF lists take k_fd_kp_difference and the plain producer -- all three
+    // launched, the device flag decides (as for one wave per trajectory)
     if (form == 3) {
         const bool pexcl = 2 * c->d.batch <= c->n_simd;
-#define LAUNCHPC(NN, MM)                                                                                              \
+#define LAUNCHPC(NN, MM, RW, GUARD)                                                                                   \
         do {                                                                                                          \
-            if (pexcl) hipLaunchKernelGGL((k_backward_fusedpc_excl<NN, MM>), grid, block2, 0, c->stream, c->L, F, c->d.T, role_shift, c->lambda, pd_stride, c->K, c->k, c->delta_J, c->status); \
-            else hipLaunchKernelGGL((k_backward_fusedpc<NN, MM>), grid, block2, 0, c->stream, c->L, F, c->d.T, role_shift, c->lambda, pd_stride, c->K, c->k, c->delta_J, c->status); \
+            if (pexcl) hipLaunchKernelGGL((k_backward_fusedpc_excl<NN, MM, RW>), grid, block2, 0, c->stream, c->L, F, c->d.T, role_shift, c->lambda, pd_stride, c->K, c->k, c->delta_J, c->status, c->kp_uniform, GUARD); \
+            else hipLaunchKernelGGL((k_backward_fusedpc<NN, MM, RW>), grid, block2, 0, c->stream, c->L, F, c->d.T, role_shift, c->lambda, pd_stride, c->K, c->k, c->delta_J, c->status, c->kp_uniform, GUARD); \
         } while (0)
-#define KP_X(NN, MM) if (n == NN && m == MM) { LAUNCHPC(NN, MM); return hipGetLastError(); }
+#define KP_X(NN, MM)                                                                                   \
+        if (n == NN && m == MM) {                                                                      \
+            if (raw) {                                                                                 \
+                LAUNCHPC(NN, MM, true, 1);                                                             \
+                hipError_t e_ = launch_fd_kp_difference(c, true);                                      \
+                if (e_ != hipSuccess) return e_;                                                       \
+                LAUNCHPC(NN, MM, false, 0);                                                            \
+            } else LAUNCHPC(NN, MM, false, -1);                                                        \
+            return hipGetLastError();                                                                  \
+        }
         KP_T1_SHAPES(KP_X)
 #undef KP_X
 #undef LAUNCHPC

@@ -877,11 +877,13 @@ static int run_backward(kpilqr_ctx *c, int pd_stride)
         if (rc) return rc;
         rc = ensure_kpc(c);
         if (rc) return rc;
-        // Key-point ordered payload, one wave per trajectory: the RAW sweep differences the payload itself and leaves kpc
+        // Key-point ordered payload, one wave per trajectory or the producer / consumer pair: the sweep (its producer wave)
+        // differences the payload itself and leaves kpc
         // behind for the forward sweep -- no differencing kernel.  (It may stop at a failed PD check, so it never marks
         // kpc valid: another backward pass on the same payload differences again.)  Otherwise the payload is differenced
         // into kpc first, once, and the sweeps read kpc.
-        if (!c->kpc_valid && c->fd_kind == 2 && backward_fused_form(c) == 1 && c->tune.fused_raw != 0) {
+        const int bform = backward_fused_form(c);
+        if (!c->kpc_valid && c->fd_kind == 2 && (bform == 1 || bform == 3) && c->tune.fused_raw != 0) {
             KP_HIP(c, launch_backward_fused(c, pd_stride, true));
             c->kpc_touched = true;
             return KPILQR_OK;
