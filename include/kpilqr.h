@@ -179,7 +179,7 @@ int  kpilqr_upload_fd_slab(kpilqr_ctx *ctx, const void *slab, int njobs, int nno
  *   int32  mode              bit k set: kind k is one-sided -> (xplus - xminus) / eps, else (xplus - xminus) / (2 eps)
  *   int32  pad[3]
  * so the host FD loop writes every perturbed next state straight to its slot, nothing carries indices, the library never
- * walks or sorts anything, and a trajectory's (or a chunk of trajectories') payload is one contiguous range.  On a KPILQR_FLAG_FUSED context with one wavefront per trajectory (batch > #SIMDs / 2) there
+ * walks or sorts anything, and a trajectory's (or a chunk of trajectories') payload is one contiguous range.  On a KPILQR_FLAG_FUSED context with more than #SIMDs / 4 trajectories (one wavefront per trajectory, or the producer / consumer pair) there
  * is then NO differencing kernel either: the backward sweep reads the slots of a key-point when it reaches it, forms the
  * column (the arithmetic of Differentiator.cpp:166-222,441-457, bit for bit what kpilqr_fd_difference gives) and keeps it
  * for the forward sweep.  Every other context accepts the payload too (it is differenced by a streaming kernel first).
