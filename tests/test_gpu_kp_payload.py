@@ -41,11 +41,16 @@ def _same(a, b, keys=("K", "k", "delta_J", "cost")):
         assert np.array_equal(a[key], b[key]), key
 
 
-@pytest.fixture(params=["one_wave", "auto"])
+@pytest.fixture(params=["one_wave", "auto", "pair"])
 def waves(request, monkeypatch):
+    """one_wave: the raw backward sweep; auto: small batches -> the triple behind the streaming differencing kernel; pair: the
+    producer / consumer pair, whose producer wave differences the payload (the form of 256 < batch <= 512)."""
     if request.param == "one_wave":
         monkeypatch.setenv("KPILQR_FUSED_WAVES", "1")
         monkeypatch.setenv("KPILQR_FUSED_FWD_WAVES", "1")
+    elif request.param == "pair":
+        monkeypatch.setenv("KPILQR_FUSED_WAVES", "3")
+        monkeypatch.setenv("KPILQR_ROLE_SHIFT", "0")
     return request.param
 
 
