@@ -925,7 +925,7 @@ struct DownTrackerRaw {
     int lo, idx, s, nb, nb2, pmode, bitA;
     double sv[NV], av[NV], pv[NV], pm[NV];
     int E0, NE, strideR, offM, offMode, strideB;
-    bool has;
+    bool has, fresh;                             // fresh: pv / pm still hold x+ / x- (not differenced yet)
     __device__ __forceinline__ void load_raw(__amdgpu_buffer_rsrc_t rP, int e_rel, double *xp, double *xm, int &mo) const
     {
         const int base = ((unsigned)e_rel < (unsigned)NE) ? e_rel * strideR : BIGOFF;
@@ -964,16 +964,26 @@ struct DownTrackerRaw {
         diff(sv, pm, mo0, eps2, rinv2);
         store(rT, has ? idx - E0 : -1, sv);
         load_raw(rP, (has && idx - 1 >= lo) ? idx - 1 - E0 : -1, pv, pm, pmode);
+        fresh = has && idx - 1 >= lo;                // (nothing below the list's first key-point: nothing to difference or store)
 #pragma unroll
         for (int i = 0; i < NV; i++) av[i] = 0.0;
+    }
+    // the prefetched x+ / x- differenced (and stored) as soon as they have arrived -- a step behind their request, on a step
+    // that has time for it -- so that the crossing itself is left with the slopes and the next requests
+    __device__ __forceinline__ void settle(__amdgpu_buffer_rsrc_t rT, double eps2, double rinv2)
+    {
+        if (fresh) {
+            diff(pv, pm, pmode, eps2, rinv2);
+            store(rT, idx - 1 - E0, pv);
+            fresh = false;
+        }
     }
     __device__ __forceinline__ void advance(__amdgpu_buffer_rsrc_t rT, __amdgpu_buffer_rsrc_t rP, const int *kp_times, int t, double eps2, double rinv2)
     {
         if (t < s) {                                 // per lane: crossed the start of the current segment
             const double den = (double)(s - nb);
             const double rinv = kp_rcp(den);
-            diff(pv, pm, pmode, eps2, rinv2);
-            store(rT, idx - 1 - E0, pv);
+            settle(rT, eps2, rinv2);                 // (consecutive key-points: not settled yet)
 #pragma unroll
             for (int i = 0; i < NV; i++) {
                 const double ev = sv[i];
@@ -984,6 +994,7 @@ struct DownTrackerRaw {
             nb = nb2;
             nb2 = (idx - 2 >= lo) ? kp_times[idx - 2] : -1;
             load_raw(rP, (idx - 1 >= lo) ? idx - 1 - E0 : -1, pv, pm, pmode);
+            fresh = idx - 1 >= lo;
         }
     }
     __device__ __forceinline__ double value(int i, double dt) const { return lerp_nc(sv[i], dt, av[i]); }
@@ -1357,7 +1368,7 @@ __device__ __forceinline__ void fusedpc_producer(double *pcbuf, int *sflag, RecL
     __syncthreads();
     for (int t = T - 1; t >= 0; t--) {
         if (t > 0) {
-            if constexpr (RAWP) tr.advance(rT, rP, F.kp_times, t - 1, F.eps2, F.rinv_2eps);
+            if constexpr (RAWP) { tr.settle(rT, F.eps2, F.rinv_2eps); tr.advance(rT, rP, F.kp_times, t - 1, F.eps2, F.rinv_2eps); }
             else tr.advance(rT, F.kp_times, t - 1, strideB);
             publish(t - 1, Wr);
         }
@@ -2140,8 +2151,9 @@ hipError_t launch_backward_fused(Ctx *c, int pd_stride, bool raw)
         else return hipErrorInvalidValue;
         return hipGetLastError();
     }
-    // (the triple keeps the streaming differencing kernel in front of it: with the payload differenced in its producer wave that
-    // wave is late at every crossing and the consumer waits -- 5.13 against 5.07 ms per iteration at B = 128, 4.80 against 4.64 at B = 1)
+    // (the triple keeps the streaming differencing kernel in front of it: with the payload differenced in its producer wave the
+    // consumer waits for that wave -- 5.13 against 5.05 ms per iteration at B = 128, 4.81 against 4.64 at B = 1, also with the
+    // differencing moved off the crossing step)
     if (form == 4) {
         dim3 block3(192);
 #define KP_X(NN, MM) if (n == NN && m == MM) { hipLaunchKernelGGL((k_backward_fusedpc3<NN, MM, false>), grid, block3, 0, c->stream, c->L, F, c->d.T, role_shift, c->lambda, pd_stride, c->K, c->k, c->delta_J, c->status, c->kp_uniform, -1); return hipGetLastError(); }
@@ -2149,7 +2161,7 @@ hipError_t launch_backward_fused(Ctx *c, int pd_stride, bool raw)
 #undef KP_X
         return hipErrorInvalidValue;
     }
-    // raw (pair, 256 < batch <= 512): the producer wave differences the key-point ordered payload of UNIFORM sets itself (5.82
+    // raw (pair, 256 < batch <= 512): the producer wave differences the key-point ordered payload of UNIFORM sets itself (5.73
     // against 6.03 ms per iteration at B = 512); per-DoF lists take k_fd_kp_difference and the plain producer -- all three
     // launched, the device flag decides (as for one wave per trajectory)
     if (form == 3) {
