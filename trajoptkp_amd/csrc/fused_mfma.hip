@@ -58,6 +58,9 @@ typedef unsigned long long u64;
 #ifndef KP_BWD_LATE_STORE
 #define KP_BWD_LATE_STORE 1
 #endif
+#ifndef KP_PROD_SPLIT
+#define KP_PROD_SPLIT 1
+#endif
 #ifndef KP_PROBE_BWD
 #define KP_PROBE_BWD 0
 #endif
@@ -911,6 +914,33 @@ struct DownTracker {
             load_vals<NV>(rT, offs, (idx - 1 >= lo) ? idx - 1 - E0 : -1, NE, strideB, pv);
         }
     }
+    // advance() in two halves (producer wave of the pair / triple): the arithmetic of a crossing, and -- behind the wave's wait for
+    // its residual tiles -- the request of the next column (a wait placed behind the divergent branch is conservative and would
+    // sit out requests issued in front of it)
+    bool need = false;
+    __device__ __forceinline__ void cross(int t)
+    {
+        need = t < s;
+        if (need) {
+            const double den = (double)(s - nb);
+            const double rinv = kp_rcp(den);
+#pragma unroll
+            for (int i = 0; i < NV; i++) {
+                const double ev = sv[i];
+                sv[i] = pv[i];
+                av[i] = fdiv(ev - sv[i], den, rinv);
+            }
+            s = nb; idx--;
+            nb = nb2;
+        }
+    }
+    __device__ __forceinline__ void request(__amdgpu_buffer_rsrc_t rT, const int *kp_times, int strideB)
+    {
+        if (need) {
+            nb2 = (idx - 2 >= lo) ? kp_times[idx - 2] : -1;
+            load_vals<NV>(rT, offs, (idx - 1 >= lo) ? idx - 1 - E0 : -1, NE, strideB, pv);
+        }
+    }
     __device__ __forceinline__ double value(int i, double dt) const { return lerp_nc(sv[i], dt, av[i]); }
 };
 
@@ -992,6 +1022,32 @@ struct DownTrackerRaw {
             }
             s = nb; idx--;
             nb = nb2;
+            nb2 = (idx - 2 >= lo) ? kp_times[idx - 2] : -1;
+            load_raw(rP, (idx - 1 >= lo) ? idx - 1 - E0 : -1, pv, pm, pmode);
+            fresh = idx - 1 >= lo;
+        }
+    }
+    bool need = false;
+    __device__ __forceinline__ void cross(__amdgpu_buffer_rsrc_t rT, int t, double eps2, double rinv2)
+    {
+        need = t < s;
+        if (need) {
+            const double den = (double)(s - nb);
+            const double rinv = kp_rcp(den);
+            settle(rT, eps2, rinv2);
+#pragma unroll
+            for (int i = 0; i < NV; i++) {
+                const double ev = sv[i];
+                sv[i] = pv[i];
+                av[i] = fdiv(ev - sv[i], den, rinv);
+            }
+            s = nb; idx--;
+            nb = nb2;
+        }
+    }
+    __device__ __forceinline__ void request(__amdgpu_buffer_rsrc_t rP, const int *kp_times)
+    {
+        if (need) {
             nb2 = (idx - 2 >= lo) ? kp_times[idx - 2] : -1;
             load_raw(rP, (idx - 1 >= lo) ? idx - 1 - E0 : -1, pv, pm, pmode);
             fresh = idx - 1 >= lo;
@@ -1368,9 +1424,17 @@ __device__ __forceinline__ void fusedpc_producer(double *pcbuf, int *sflag, RecL
     __syncthreads();
     for (int t = T - 1; t >= 0; t--) {
         if (t > 0) {
+#if KP_PROD_SPLIT
+            if constexpr (RAWP) { tr.settle(rT, F.eps2, F.rinv_2eps); tr.cross(rT, t - 1, F.eps2, F.rinv_2eps); }
+            else tr.cross(t - 1);
+            publish(t - 1, Wr);
+            if constexpr (RAWP) tr.request(rP, F.kp_times);
+            else tr.request(rT, F.kp_times, strideB);
+#else
             if constexpr (RAWP) { tr.settle(rT, F.eps2, F.rinv_2eps); tr.advance(rT, rP, F.kp_times, t - 1, F.eps2, F.rinv_2eps); }
             else tr.advance(rT, F.kp_times, t - 1, strideB);
             publish(t - 1, Wr);
+#endif
         }
         if constexpr (TRIPLE) __syncthreads();             // the mid-step barrier of the consumer and the side wave
         __syncthreads();
