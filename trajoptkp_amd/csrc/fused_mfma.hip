@@ -59,7 +59,7 @@ typedef unsigned long long u64;
 #define KP_BWD_LATE_STORE 1
 #endif
 #ifndef KP_PROD_SPLIT
-#define KP_PROD_SPLIT 1
+#define KP_PROD_SPLIT 1             // 0: the producer wave requests the next key-point column in front of its publish (round-3 A/B)
 #endif
 #ifndef KP_PROBE_BWD
 #define KP_PROBE_BWD 0
