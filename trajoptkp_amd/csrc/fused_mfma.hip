@@ -58,6 +58,9 @@ typedef unsigned long long u64;
 #ifndef KP_BWD_LATE_STORE
 #define KP_BWD_LATE_STORE 1
 #endif
+#ifndef KP_FSC_SETS
+#define KP_FSC_SETS 4              // tile sets of the forward state / cost wave groups
+#endif
 #ifndef KP_PROD_SPLIT
 #define KP_PROD_SPLIT 1             // 0: the producer wave requests the next key-point column in front of its publish (round-3 A/B)
 #endif
@@ -1422,23 +1425,28 @@ __device__ __forceinline__ void fusedpc_producer(double *pcbuf, int *sflag, RecL
     if (lane == 0) sflag[0] = 0;
     publish(T - 1, Wt);                                   // terminal weights   (iLQR.cpp:537-539)
     __syncthreads();
-    for (int t = T - 1; t >= 0; t--) {
-        if (t > 0) {
+    // (no `if (t > 0)` around the body: requests behind a condition make the waits that follow conservative; the last step,
+    // t = 0, has nothing left to produce and is the two barriers behind the loop)
+    bool stop = false;
+    for (int t = T - 1; t > 0; t--) {
 #if KP_PROD_SPLIT
-            if constexpr (RAWP) { tr.settle(rT, F.eps2, F.rinv_2eps); tr.cross(rT, t - 1, F.eps2, F.rinv_2eps); }
-            else tr.cross(t - 1);
-            publish(t - 1, Wr);
-            if constexpr (RAWP) tr.request(rP, F.kp_times);
-            else tr.request(rT, F.kp_times, strideB);
+        if constexpr (RAWP) { tr.settle(rT, F.eps2, F.rinv_2eps); tr.cross(rT, t - 1, F.eps2, F.rinv_2eps); }
+        else tr.cross(t - 1);
+        publish(t - 1, Wr);
+        if constexpr (RAWP) tr.request(rP, F.kp_times);
+        else tr.request(rT, F.kp_times, strideB);
 #else
-            if constexpr (RAWP) { tr.settle(rT, F.eps2, F.rinv_2eps); tr.advance(rT, rP, F.kp_times, t - 1, F.eps2, F.rinv_2eps); }
-            else tr.advance(rT, F.kp_times, t - 1, strideB);
-            publish(t - 1, Wr);
+        if constexpr (RAWP) { tr.settle(rT, F.eps2, F.rinv_2eps); tr.advance(rT, rP, F.kp_times, t - 1, F.eps2, F.rinv_2eps); }
+        else tr.advance(rT, F.kp_times, t - 1, strideB);
+        publish(t - 1, Wr);
 #endif
-        }
         if constexpr (TRIPLE) __syncthreads();             // the mid-step barrier of the consumer and the side wave
         __syncthreads();
-        if (sflag[0]) break;
+        if (sflag[0]) { stop = true; break; }
+    }
+    if (!stop) {
+        if constexpr (TRIPLE) __syncthreads();
+        __syncthreads();
     }
 }
 
@@ -1959,8 +1967,9 @@ __device__ __forceinline__ void forward_sc_state(double *sh, RecLayout L, int T,
         Z.x = zr[0]; Z.y = zr[1]; Z.z = zr[2]; Z.w = zr[3];
     }
     const d4 zero = {0.0, 0.0, 0.0, 0.0};
-    // two alternating tile sets (even / odd steps): each is re-requested for step t+2 right behind its use in step t, so a
-    // load has two whole steps to land -- the short S step leaves less cover than the one-wave kernel has
+    // KP_FSC_SETS tile sets (step t works on set t mod KP_FSC_SETS): each is re-requested for step t + KP_FSC_SETS right behind
+    // its use in step t.  The time loop is a body of KP_FSC_SETS steps WITHOUT conditions (the steps below a full group are
+    // peeled behind it): a request inside `if (t + 1 < T)` makes every later wait conservative
     struct STiles { d4 YkK, Ykk, ub; };
     const __amdgpu_buffer_rsrc_t rNone = frsrc(Kin, 0);
     auto request = [&](int t, STiles &s_) {
@@ -1984,7 +1993,7 @@ __device__ __forceinline__ void forward_sc_state(double *sh, RecLayout L, int T,
         const d4 ub = s_.ub;
         d4 U = PS<NCZ>(Yk, Z, ub);                     // u_nom + K dx + alpha k   (:879)
         __builtin_amdgcn_sched_barrier(0);
-        request(t + 2, s_);
+        request(t + KP_FSC_SETS, s_);
         __builtin_amdgcn_sched_barrier(0);
         d4 Zn = PS<NCZ>(Ya, Z, zero);                  // A dx
         d4 dU = zero;
@@ -2007,14 +2016,17 @@ __device__ __forceinline__ void forward_sc_state(double *sh, RecLayout L, int T,
         }
         __syncthreads();
     };
-    STiles ta, tb;
-    request(0, ta);
-    request(1, tb);
+    STiles S[KP_FSC_SETS];
+#pragma unroll
+    for (int k = 0; k < KP_FSC_SETS; k++) request(k, S[k]);
     __syncthreads();                                   // Y(0) is staged
-    for (int t = 0; t < T; t += 2) {
-        step(t, ta);
-        if (t + 1 < T) step(t + 1, tb);
+    int t = 0;
+    for (; t + KP_FSC_SETS <= T; t += KP_FSC_SETS) {
+#pragma unroll
+        for (int k = 0; k < KP_FSC_SETS; k++) step(t + k, S[k]);
     }
+#pragma unroll
+    for (int k = 0; k < KP_FSC_SETS - 1; k++) if (t + k < T) step(t + k, S[k]);
 }
 
 // ROLE 0: score and stage (second wave of the pair); 1: score only; 2: stage the A, B columns only (third wave of the triple)
@@ -2115,7 +2127,7 @@ __device__ __forceinline__ void forward_sc_cost(double *sh, RecLayout L, FusedAr
             const d4 Jx = PR(s_.RxT, Zt, zero, ncx);
             const d4 r2 = s_.rv + s_.rv;
             __builtin_amdgcn_sched_barrier(0);
-            request(tt + 2, s_);
+            request(tt + KP_FSC_SETS, s_);
             __builtin_amdgcn_sched_barrier(0);
             if (tt == T - 1) {                // terminal weights at the last step (Optimiser.cpp:209-211)
 #pragma unroll
@@ -2130,15 +2142,21 @@ __device__ __forceinline__ void forward_sc_cost(double *sh, RecLayout L, FusedAr
         if (ROLE != 1 && t + 1 < T) { advance(t + 1); stage_cols(t + 1); }
         if (t < T) __syncthreads();
     };
-    CTiles ta, tb;                                     // ta: even steps, tb: odd steps
-    if (ROLE != 2) { request(0, ta); request(1, tb); }
+    CTiles S[KP_FSC_SETS];                             // set k: the steps congruent k mod KP_FSC_SETS
+    if (ROLE != 2) {
+#pragma unroll
+        for (int k = 0; k < KP_FSC_SETS; k++) request(k, S[k]);
+    }
     if (ROLE != 1) stage_cols(0);
     __syncthreads();
-    iter(0, tb);
-    for (int t = 1; t <= T; t += 2) {
-        iter(t, ta);                                   // scores the even step t-1
-        if (t + 1 <= T) iter(t + 1, tb);               // scores the odd step t
+    iter(0, S[KP_FSC_SETS - 1]);                       // (scores nothing: stages the columns of step 1)
+    int t = 1;
+    for (; t + KP_FSC_SETS - 1 <= T; t += KP_FSC_SETS) {   // iteration t scores step t-1, whose tiles are in set (t-1) mod KP_FSC_SETS
+#pragma unroll
+        for (int k = 0; k < KP_FSC_SETS; k++) iter(t + k, S[k]);
     }
+#pragma unroll
+    for (int k = 0; k < KP_FSC_SETS - 1; k++) if (t + k <= T) iter(t + k, S[k]);
     partial += __shfl_xor(partial, 16);
     partial += __shfl_xor(partial, 32);
     if (ROLE != 2 && q == 0 && c < n_alpha) cost_pred[(size_t)b * n_alpha + c] = partial;
@@ -2303,11 +2321,11 @@ hipError_t launch_forward_fused(Ctx *c, double *U_alpha_dev)
     dim3 grid(c->d.batch), block(64);
     const bool excl = c->d.batch <= c->n_simd;
     const FusedArgs F = fused_args(c);
-    // One wave per trajectory with its tile requests four steps ahead (forward_fused_body) from 26 trajectories up: 1.79 ms
-    // per sweep at B = 32 ... 512 against 1.85 ... 2.49 ms for the state / cost wave groups, which keep a single step of
-    // requests in flight; below that the state / cost / cost triple's shorter step wins (B = 1 ... 24: 1.63 ... 1.75 against 1.79 ms).
+    // While a trajectory can have three SIMDs of a CU (4 x batch <= #SIMDs) the state / cost / staging triple runs it: 1.58 ms per
+    // sweep at B = 1, 1.74 ... 1.76 at B = 128 ... 256 (four tile sets per wave, a time loop without conditions) against 1.80 for
+    // one wave per trajectory with its tile requests four steps ahead, which takes over beyond.
     // KPILQR_FUSED_FWD_WAVES = 1 | 2 | 3 forces a form.
-    const int form = c->tune.fused_fwd_waves ? c->tune.fused_fwd_waves : (40 * c->d.batch <= c->n_simd ? 3 : 1);
+    const int form = c->tune.fused_fwd_waves ? c->tune.fused_fwd_waves : (4 * c->d.batch <= c->n_simd ? 3 : 1);
     const int ncz = (n + 2 + 3) / 4, ncu = (m + 3) / 4;       // tile chunks of [dx; alpha; 1] and of the controls
     if (form == 3) {
         dim3 block3(192);
