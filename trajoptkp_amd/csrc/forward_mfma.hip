@@ -111,17 +111,19 @@ __device__ __forceinline__ void forward_body(RecLayout L, int T, int n_alpha, co
         s.ub.x = bld(ru, oub[0]); s.ub.y = NCU > 1 ? bld(ru, oub[1]) : 0.0;
         s.ub.z = NCU > 2 ? bld(ru, oub[2]) : 0.0; s.ub.w = NCU > 3 ? bld(ru, oub[3]) : 0.0;
     };
-    Tiles nxt;
-    load_tiles(0, nxt);
-
-    for (int t = 0; t < T; t++) {
-        // consume the loads issued one step ago, then request the next step's at once
-        const Tiles cur = nxt;
+    // Two tile sets (even / odd steps), each re-requested for step t+2 as soon as step t has taken its copy; the time loop is a
+    // body of two steps without conditions (a request behind `if (t + 1 < T)` makes the waits that follow conservative), the
+    // odd last step peeled.  24 loads per step: a third set would not fit the 6-bit counter.
+    Tiles S[2];
+    load_tiles(0, S[0]);
+    load_tiles(T > 1 ? 1 : 0, S[1]);
+    auto step = [&](int t, Tiles &set) __attribute__((always_inline)) {
+        const Tiles cur = set;
         const d4 Yk = cur.YkK + cur.Ykk;
         d4 Ya = cur.Ya;
         Ya.x += oneA[0]; Ya.y += oneA[1]; Ya.z += oneA[2]; Ya.w += oneA[3];
         const d4 Yb = cur.Yb, Lc = cur.Lc, Luu = cur.Luu, lu = cur.lu, ub = cur.ub;
-        if (t + 1 < T) load_tiles(t + 1, nxt);
+        load_tiles(t + 2 < T ? t + 2 : T - 1, set);           // (behind the last steps: a valid record, never used)
         __builtin_amdgcn_sched_barrier(0);     // keep the prefetch AHEAD of this step's compute
 
         // Order of the step: every product is a dependent MFMA chain whose result is usable ~100 cycles after its last
@@ -151,7 +153,10 @@ __device__ __forceinline__ void forward_body(RecLayout L, int T, int n_alpha, co
                  + dU.z * (0.5 * Wu.z + lu.z) + dU.w * (0.5 * Wu.w + lu.w);
         partial += 0.5 * (Z.x * Wz.x + Z.y * Wz.y + Z.z * Wz.z + Z.w * Wz.w);
         Z = Zn;
-    }
+    };
+    int t = 0;
+    for (; t + 2 <= T; t += 2) { step(t, S[0]); step(t + 1, S[1]); }
+    if (t < T) step(t, S[0]);
     // column sums: lanes c, c+16, c+32, c+48
     partial += __shfl_xor(partial, 16);
     partial += __shfl_xor(partial, 32);
