@@ -540,7 +540,9 @@ __device__ __forceinline__ void backward_fused_body(double *sh, const double *pc
             LU = PR(cur.Ru, Rur * W2, zero, ncr);
         }
         __builtin_amdgcn_sched_barrier(0);
-        if constexpr (KP_BWD_LATE_STORE) { if (tst >= 0) store_gains(tst, Kst); }      // the step above, IN FRONT of the requests
+        // the step above, IN FRONT of the requests.  (The test is false only at the first step; compiling it out of the loops'
+        // call sites was measured and is 0.04 ms SLOWER at B=1024 -- the scheduler's placement of the stores changes.)
+        if constexpr (KP_BWD_LATE_STORE) { if (tst >= 0) store_gains(tst, Kst); }
         if constexpr (!UNI) {
             if (cross) {                               // late_cross: the memory operations of the crossing at the top of this step
                 const KArgF Fk = kernarg_fused();      // crossing-only scalars, from the kernel-argument segment
@@ -560,10 +562,10 @@ __device__ __forceinline__ void backward_fused_body(double *sh, const double *pc
             // behind the wait for this step's tiles -- in front of it, the wait sat out the stores' acknowledgement
             if (kst_pos >= 0) { store_col_n<N>(rT, cu, kst_pos * strideB, sv); kst_pos = -1; }
         }
-        // (general form: unconditional -- with the request behind a branch there is a path from the crossing's requests to the
-        // next crossing without a tile request in between, and the compiler's wait for the crossing's columns drains the tiles)
-        if constexpr (UNI) { if (t > 0) load_res(t - 1, cur); }
-        else load_res(t > 0 ? t - 1 : 0, cur);
+        // (unconditional: a request behind `if (t > 0)` costs a scalar branch per step and makes the compiler's later waits
+        // conservative -- in the general form its wait for the crossing's columns drained the tiles; 4.76 -> 4.70 ms in the
+        // uniform form.  Behind step 0 the request repeats step 0's tiles, never used.)
+        load_res(t > 0 ? t - 1 : 0, cur);
         __builtin_amdgcn_sched_barrier(0);
 #ifdef KP_CYC
         cyc_a += __builtin_readcyclecounter() - cyc_s0;
