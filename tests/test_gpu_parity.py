@@ -861,6 +861,29 @@ def test_fused_indefinite_quu_on_unchecked_steps(wave_form):
             assert relerr(K[b], o["K"]) < 1e-6 and relerr(k[b], o["k"]) < 1e-6, (lam, b, relerr(K[b], o["K"]))
 
 
+@pytest.mark.parametrize("task,T", [("panda_pushing", 20), ("walker", 24), ("light_clutter_push", 20)])
+@pytest.mark.parametrize("uw", ["1", "0"])
+def test_tiled_indefinite_quu_on_unchecked_steps(task, T, uw, monkeypatch):
+    """The same on the tiled backward kernels: with the u-wave (two and three tiles: the inverse of the pivoted slow path
+    reaches the column waves as a tile) and without it (every wave solves for its own columns).  Short horizons: with an
+    indefinite Q_uu the recursion amplifies rounding differences (at T=48 either kernel is 1e-2 from the oracle at lambda=1e-4)."""
+    monkeypatch.setenv("KPILQR_TILED_UW", uw)
+    p = synth.make_problem(task=task, T=T, batch=2, min_N=4, dense_residuals=True)
+    assert np.any(p["r_u"] != 0)
+    p["w_run"] = -np.abs(p["w_run"]) - 1.0               # negative control-residual weights: l_uu indefinite
+    for lam in (1e-4, 0.3):
+        with Engine(p["dof"], p["m"], p["T"], p["nr"], batch=2) as e:
+            assert e.backward_variant == "mfma_f64_tiled"
+            synth.upload(e, p)
+            e.fd_difference(); e.interpolate(); e.cost_derivs()
+            st, _ = e.backward(lam, 1000)
+            K, k = e.gains()
+        for b in range(2):
+            o = pipeline.run_trajectory(p, b, lam=lam, pd_stride=1000, stages=("fd", "interp", "cost", "bwd"))
+            assert st[b] == 0 and o["status"] == 0
+            assert relerr(K[b], o["K"]) < 1e-6 and relerr(k[b], o["k"]) < 1e-6, (lam, b, relerr(K[b], o["K"]))
+
+
 # ---- asynchronous boundary: pinned slab, device-side validation, chunk pipeline --------------------------
 def _staged(p, fused):
     with Engine(p["dof"], p["m"], p["T"], p["nr"], batch=p["batch"], fused=fused) as e:

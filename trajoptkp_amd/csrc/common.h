@@ -160,6 +160,7 @@ struct Ctx {
         int role_shift = 9;        // KPILQR_ROLE_SHIFT (wave-pair role placement probe)
         int tiled_nt_min = 0;      // KPILQR_TILED_NT_MIN: run the tiled kernels with more tiles than needed
         int tiled_a6 = -1;         // KPILQR_TILED_A6: -1 auto, 0 | 1
+        int tiled_uw = -1;         // KPILQR_TILED_UW: 0 = no u-wave in the tiled backward sweep (NT <= 3, materialised tiles)
         int tiled_a4 = -1;         // KPILQR_TILED_A4: -1 auto, 0 | 1 (a4 inside the tiled sweeps)
         int fused_uni = -1;        // KPILQR_FUSED_UNI: 0 never take the uniform-key-point form of the one-wave backward sweep (diagnostic)
         int fused_raw = -1;        // KPILQR_FUSED_RAW: 0 never difference inside the backward sweep (diagnostic), else auto

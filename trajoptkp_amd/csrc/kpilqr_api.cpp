@@ -84,6 +84,7 @@ Ctx::Tuning read_tuning_from_env()
     t.tiled_nt_min = env_int("KPILQR_TILED_NT_MIN", 0);
     t.tiled_a6 = env_int("KPILQR_TILED_A6", -1);
     t.tiled_a4 = env_int("KPILQR_TILED_A4", -1);
+    t.tiled_uw = env_int("KPILQR_TILED_UW", -1);
     t.pipe_copy = env_int("KPILQR_PIPE_COPY", -1);
     t.fused_raw = env_int("KPILQR_FUSED_RAW", -1);
     t.fused_uni = env_int("KPILQR_FUSED_UNI", -1);

@@ -558,6 +558,378 @@ bool backward_tiled_supported(int n, int m, int nt_min)
     return nt >= 2 && nt <= 4 && m >= 1 && m <= 8 && backward_tiled_lds_bytes(nt) <= 160 * 1024;
 }
 
+// ---------------------------------------------------------------------------------------------
+// The same sweep with one more wavefront per trajectory, the "u-wave" (materialised A, B and cost tiles; NT <= 3, so that
+// the NT+1 waves still have a SIMD each).  In k_backward_tiled_col every wave repeats, behind the products, the chain
+// Quu -> refresh of the running inverse (or LDL') -> X, which is a third of an n=20 step (2 260 of 7 830 cycles) and
+// depends on nothing but V' Fu.  Here wave NT forms Tu = V'Fu (all row tiles), Quu = l_uu + Fu'Tu and the inverse WHILE the
+// column waves form Tz, Quz, Qzz; they meet at the second barrier, behind which a column wave only multiplies
+// X(w) = Xinv Quz(w).  The PD verdict (:587-595) and the LDL' fallbacks are the u-wave's alone and reach the others as a flag
+// and as an inverse tile: on factorised steps X is Xinv Quz too (Xinv = the per-lane solves of the identity columns).
+//   (F of the step above: V' complete)                                                                   | barrier
+//   B  column wave w: Tz(:,w) = V'Fz(:,w) from registers, Fz(:,w), Fu(w) -> LDS  ||  u-wave: Tu = V'Fu    | barrier
+//   C  column wave w: Quz(w), Qzz(:,w)               ||  u-wave: Quu, refresh / LDL' -> Xinv, flag       | barrier
+//   D  X(w) = Xinv Quz(w), K / k stores, G(w)                                                            | barrier
+//   E, F as above (the u-wave only keeps the barrier count)
+// The u-wave reads Fu from global memory itself (its slots of the per-step requests), so its chain -- the critical path of the
+// step -- starts at the first barrier and not behind the column waves' staging.
+// NCL = 4-row chunks of the last row tile that hold rows of z (compile-time here: a run-time count puts every chunk of the last
+// tile behind its own branch, and the basic blocks that leaves keep the scheduler from interleaving independent MFMA chains).
+template <int M, int NT, int NCL>
+__global__ void __launch_bounds__(64 * (NT + 1))
+k_backward_tiled_uw(RecLayout L, int T, const double *__restrict__ rec, const double *__restrict__ lambda,
+                    int pd_stride, double *__restrict__ Kout, double *__restrict__ kout,
+                    double *__restrict__ delta_J, int *__restrict__ status)
+{
+    extern __shared__ __attribute__((aligned(16))) double sh[];
+    constexpr int NCU = (M + 3) / 4;
+    constexpr int NZZ = NT * NT;
+    constexpr bool PAD = (M == 8);
+    const int n = L.n, m = PAD ? L.m : M;
+    const int lane = threadIdx.x & 63, c = lane & 15, q = lane >> 4;
+    const int w = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);    // column tile of this wave; NT: the u-wave
+    const bool uw = (w == NT);
+    const int b = KP_TILED_TRAJ;
+    const double lam = lambda[b];
+    double *bufV = sh;
+    double *bufF = bufV + NZZ * TILE;
+    double *bufT = bufF + NZZ * TILE;
+    double *bufFu = bufT + NZZ * TPAD;
+    double *bufQuz = bufFu + NT * TILE;              // (unused here: Quz(w) stays in its wave)
+    double *bufX = bufQuz + NT * TILE;
+    double *bufG = bufX + NT * TILE;
+    double *sQ = bufG + NT * TILE;                   // the u-wave's image of Quu + lambda I
+    double *bufXi = sQ + TILE;                       // the inverse, u-wave -> column waves
+    int *sFlag = (int *)(bufXi + TILE);              // PD verdict of the step (0 | t+1)
+    double *sRow = bufT;                             // slow-path work area of the u-wave (phase BC: bufT is free between F and E)
+    TileSrc S = {n, m, L.off_A, L.off_B, L.off_lxx, L.off_lx, L.off_luu, L.off_lu};
+    auto nck = [](int kt) { return kt < NT - 1 ? 4 : NCL; };        // chunks of row tile kt
+    auto comp = [](const d4 &v, int r) { return r == 0 ? v.x : r == 1 ? v.y : r == 2 ? v.z : v.w; };
+
+    const double *R0 = rec + (size_t)b * T * L.stride;
+    const int rec_bytes = L.rec * 8;
+    const d4 zero = {0.0, 0.0, 0.0, 0.0};
+    const int tn = n >> 4, cn = n & 15;
+    const bool lane_nn = (c == cn) && (q == (cn & 3));
+    const int reg_nn = cn >> 2;
+    d4 nn_keep;
+    nn_keep.x = (lane_nn && reg_nn == 0) ? 0.0 : 1.0; nn_keep.y = (lane_nn && reg_nn == 1) ? 0.0 : 1.0;
+    nn_keep.z = (lane_nn && reg_nn == 2) ? 0.0 : 1.0; nn_keep.w = (lane_nn && reg_nn == 3) ? 0.0 : 1.0;
+    const d4 nn_one = 1.0 - nn_keep;
+    double lam2d[4];
+#pragma unroll
+    for (int r = 0; r < 4; r++) lam2d[r] = (4 * r + q == c && c < m) ? 2.0 * lam : 0.0;
+    auto rsrc_of = [&](int t) { return __builtin_amdgcn_make_buffer_rsrc((void *)(R0 + (size_t)t * L.stride), 0, rec_bytes, 0x00020000); };
+    auto ld4 = [&](__amdgpu_buffer_rsrc_t rs, const int (&o)[4]) { d4 v = {tbld(rs, o[0]), tbld(rs, o[1]), tbld(rs, o[2]), tbld(rs, o[3])}; return v; };
+    // V'(i,k)' Y(k) summed over the row tiles k, for every output tile i: NT independent accumulation chains issued interleaved.
+    // (More, shallower chains -- one per (k,i), halves of Fu'Tu, split products in the refresh -- measured no gain: at one FP64 MFMA
+    // per 64 cycles the u-wave's 18 products are issue-bound, not chain-bound; nor did a third-order refresh, with or without the
+    // extrapolated first guess of kp_inverse_refresh_p: 7.2 / 8.4 against 6.8 ms on the pushing workload.)
+    auto VtY = [&](const d4 (&Y)[NT], d4 (&Tq)[NT]) {
+#pragma unroll
+        for (int i = 0; i < NT; i++) Tq[i] = zero;
+#pragma unroll
+        for (int k = 0; k < NT; k++) {
+            d4 Vk[NT];
+#pragma unroll
+            for (int i = 0; i < NT; i++) Vk[i] = lds_tile(bufV + (k * NT + i) * TILE, lane);
+#pragma unroll
+            for (int r = 0; r < nck(k); r++)
+#pragma unroll
+                for (int i = 0; i < NT; i++) Tq[i] = MFMA(comp(Vk[i], r), comp(Y[k], r), Tq[i]);
+        }
+    };
+    int pd_counter = 0, fail = 0;
+    double dJ = 0.0;
+#ifdef KP_CYC_UW
+    long long cy[12] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0}, c0 = __builtin_readcyclecounter(), c1;
+#define CYC(i) { c1 = __builtin_readcyclecounter(); cy[i] += c1 - c0; c0 = c1; }
+#else
+#define CYC(i)
+#endif
+    // The two roles run their own time loops (no joins of the two paths inside a step: a join behind a request copies the
+    // requested registers and waits for every load on the spot) and meet at the five barriers of a step.
+    if (uw) {
+        // ================================================ u-wave ======================================================
+        // sources, one step ahead: Fu (NT row tiles, consumed right behind the first barrier) and l_uu (consumed behind the second)
+        int oFu[NT][4], oLuu[4];
+#pragma unroll
+        for (int r = 0; r < 4; r++) {
+            const int rowu = 4 * r + q;
+#pragma unroll
+            for (int k = 0; k < NT; k++) {
+                const int row = 16 * k + 4 * r + q;
+                oFu[k][r] = (row < n && c < m) ? 8 * (S.off_B + c * n + row) : OOBT;
+            }
+            oLuu[r] = (rowu < m && c < m) ? 8 * (S.off_luu + rowu * m + c) : OOBT;
+        }
+        d4 pFu[NT], pLuu;
+        {
+            __amdgpu_buffer_rsrc_t rs = rsrc_of(T - 1);
+#pragma unroll
+            for (int k = 0; k < NT; k++) pFu[k] = ld4(rs, oFu[k]);
+            pLuu = ld4(rs, oLuu);
+        }
+        d4 Xinv = zero, Iu;                      // running inverse of Quu + lambda I, identity of the u-block
+        bool haveX = false;
+        Iu.x = (q == c && c < m) ? 1.0 : 0.0; Iu.y = (4 + q == c && c < m) ? 1.0 : 0.0;
+        Iu.z = (8 + q == c && c < m) ? 1.0 : 0.0; Iu.w = (12 + q == c && c < m) ? 1.0 : 0.0;
+        for (int t = T - 1; t >= 0; t--) {
+            pd_counter++;
+            const bool check_pd = pd_counter >= pd_stride;
+            __amdgpu_buffer_rsrc_t rn = t > 0 ? rsrc_of(t - 1) : __builtin_amdgcn_make_buffer_rsrc((void *)R0, 0, 0, 0x00020000);
+            CYC(0)
+            __syncthreads();                                       // V' of the step above is complete
+            CYC(1)
+            // Quu = l_uu + sum_i Fu(i)' (V'Fu)(i);  (V'Fu)(i) = sum_k V'(k,i)' Fu(k) by the symmetry of V'
+            d4 Tu[NT], Qp[NT];
+            VtY(pFu, Tu);
+#pragma unroll
+            for (int i = 0; i < NT; i++) Qp[i] = zero;
+#pragma unroll
+            for (int r = 0; r < 4; r++)
+#pragma unroll
+                for (int i = 0; i < NT; i++)
+                    if (r < nck(i)) Qp[i] = MFMA(comp(pFu[i], r), comp(Tu[i], r), Qp[i]);
+            __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+            for (int k = 0; k < NT; k++) pFu[k] = ld4(rn, oFu[k]);
+            __builtin_amdgcn_sched_barrier(0);
+            CYC(7)
+            __syncthreads();                                       // (the column waves' Fz, Fu are in LDS: not used here)
+            CYC(9)
+            d4 Qr = pLuu;
+#pragma unroll
+            for (int i = 0; i < NT; i++) Qr = Qr + Qp[i];
+            pLuu = ld4(rn, oLuu);
+            Qr.x += 0.5 * lam2d[0]; Qr.y += 0.5 * lam2d[1]; Qr.z += 0.5 * lam2d[2]; Qr.w += 0.5 * lam2d[3];
+            // running inverse refreshed by Newton-Schulz steps on the matrix core; LDL' on the first step, on checked
+            // steps (PD verdict) and when the residual is too large to converge fast (as in k_backward_tiled_col)
+            if (!(haveX && !check_pd && kp_inverse_refresh<NCU>(Qr, Iu, Xinv, m))) {
+                lds_store(sQ, lane, Qr);
+                auto qel = [&](int i, int j) {
+                    if (PAD && (i >= m || j >= m)) return (i == j) ? 1.0 : 0.0;
+                    return sQ[(i >> 2) * 64 + j + 16 * (i & 3)];
+                };
+                double Lm[M][M], rd[M];
+                const bool pos = kp_ldl_factor<M>([&](int i, int j) { return qel(i, j); }, Lm, rd);
+                if (check_pd && !pos) fail = t + 1;                // CheckMatrixPD every pd_stride steps   :587-595
+                double yr[4] = {0.0, 0.0, 0.0, 0.0};
+                if (pos) {
+                    double y[M];                                   // column c of the inverse in lane c (c < m)
+#pragma unroll
+                    for (int i = 0; i < M; i++) y[i] = (i == c) ? 1.0 : 0.0;
+                    kp_ldl_solve<M>(Lm, rd, y);
+#pragma unroll
+                    for (int i = 0; i < M; i++)
+                        if (q == (i & 3)) yr[i >> 2] = (c < m) ? y[i] : 0.0;
+                    haveX = true;
+                } else if (!fail) {                                // indefinite between checks: the reference's LDLT route
+                    double *winv = sRow + 256 + 256;
+                    if (lane == 0) {
+                        for (int i = 0; i < m; i++) for (int j = 0; j < m; j++) sRow[i * 16 + j] = qel(i, j);
+                        kp_slow_ldlt_inverse(m, sRow, 16, sRow + 256, winv, sRow + 768, (int *)(sRow + 784));
+                    }
+                    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+                    __builtin_amdgcn_wave_barrier();
+                    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+#pragma unroll
+                    for (int r = 0; r < NCU; r++) {
+                        const int row = 4 * r + q;
+                        yr[r] = (row < m && c < m) ? winv[row + c * m] : 0.0;
+                    }
+                    haveX = false;
+                }
+                Xinv.x = yr[0]; Xinv.y = yr[1]; Xinv.z = yr[2]; Xinv.w = yr[3];
+            }
+            CYC(8)
+            lds_store(bufXi, lane, Xinv);
+            if (lane == 0) sFlag[0] = fail;
+            CYC(2)
+            __syncthreads();                                       // the inverse and the verdict are out
+            CYC(3)
+            if (fail) break;
+            if (check_pd) pd_counter = 0;
+            __syncthreads();
+            CYC(4)
+            __syncthreads();
+            CYC(6)
+        }
+    } else {
+        // ============================================== column wave w ==================================================
+        // sources, one step ahead: Fz(k,w), Fu(w) (consumed behind the first barrier) | Lzz(k,w), Luz(w) (joined at the end of C)
+        d4 pF[NT], pL[NT], pFu, pLuz;
+        int oF[NT][4], oL[NT][4], oFu[4], oLuz[4];
+#pragma unroll
+        for (int r = 0; r < 4; r++) {
+            const int rowu = 4 * r + q, col = 16 * w + c, rowb = 16 * w + 4 * r + q;
+#pragma unroll
+            for (int k = 0; k < NT; k++) {
+                const int row = 16 * k + 4 * r + q;
+                oF[k][r] = (row < n && col < n) ? 8 * (S.off_A + col * n + row) : OOBT;
+                oL[k][r] = (row < n && col < n) ? 8 * (S.off_lxx + row * n + col)
+                         : (col == n && row < n) ? 8 * (S.off_lx + row) : (row == n && col < n) ? 8 * (S.off_lx + col) : OOBT;
+            }
+            oFu[r] = (rowb < n && c < m) ? 8 * (S.off_B + c * n + rowb) : OOBT;
+            oLuz[r] = (rowu < m && col == n) ? 8 * (S.off_lu + rowu) : OOBT;
+        }
+        auto request = [&](__amdgpu_buffer_rsrc_t rs) {
+#pragma unroll
+            for (int k = 0; k < NT; k++) pF[k] = ld4(rs, oF[k]);
+            pFu = ld4(rs, oFu);
+        };
+        auto request_cost = [&](__amdgpu_buffer_rsrc_t rs) {
+#pragma unroll
+            for (int k = 0; k < NT; k++) pL[k] = ld4(rs, oL[k]);
+            pLuz = ld4(rs, oLuz);
+        };
+        {
+            __amdgpu_buffer_rsrc_t rs = rsrc_of(T - 1);
+            request(rs); request_cost(rs);
+        }
+        // V' <- Lzz(T-1)   (iLQR.cpp:537-539)
+#pragma unroll
+        for (int k = 0; k < NT; k++) lds_store(bufV + (k * NT + w) * TILE, lane, pL[k]);
+        char *pK = (char *)(Kout + ((size_t)b * T + (T - 1)) * m * n), *pk = (char *)(kout + ((size_t)b * T + (T - 1)) * m);
+        for (int t = T - 1; t >= 0; t--) {
+            pd_counter++;
+            const bool check_pd = pd_counter >= pd_stride;
+            __amdgpu_buffer_rsrc_t rn = t > 0 ? rsrc_of(t - 1) : __builtin_amdgcn_make_buffer_rsrc((void *)R0, 0, 0, 0x00020000);
+            CYC(0)
+            __syncthreads();                                       // V' of the step above is complete
+            CYC(1)
+            // ---- B: Tz(:,w) = V' Fz(:,w) straight from the registers the tiles were loaded into; Fz(:,w), Fu(w) -> LDS ----
+            d4 Tz[NT];
+            {
+                d4 Y[NT];
+#pragma unroll
+                for (int k = 0; k < NT; k++) {
+                    Y[k] = pF[k];
+                    if (k == tn && w == tn) Y[k] = Y[k] + nn_one;          // Fz(n,n) = 1
+                }
+                VtY(Y, Tz);
+#pragma unroll
+                for (int k = 0; k < NT; k++) lds_store(bufF + (k * NT + w) * TILE, lane, Y[k]);
+                lds_store(bufFu + w * TILE, lane, pFu);
+            }
+            __builtin_amdgcn_sched_barrier(0);
+            request(rn);
+            __builtin_amdgcn_sched_barrier(0);
+            CYC(7)
+            __syncthreads();                                       // every wave's Fz, Fu are in LDS
+            CYC(9)
+            // ---- C: Quz(w), Qzz(:,w): NT+1 chains interleaved; the cost tiles join at the end (their loads have had the step) ----
+            d4 Quzw = zero, Qzz[NT];
+#pragma unroll
+            for (int i = 0; i < NT; i++) Qzz[i] = zero;
+#pragma unroll
+            for (int k = 0; k < NT; k++) {
+                d4 Fk[NT];
+                const d4 Fuk = lds_tile(bufFu + k * TILE, lane);
+#pragma unroll
+                for (int i = 0; i < NT; i++) Fk[i] = lds_tile(bufF + (k * NT + i) * TILE, lane);
+#pragma unroll
+                for (int r = 0; r < nck(k); r++) {
+                    Quzw = MFMA(comp(Fuk, r), comp(Tz[k], r), Quzw);
+#pragma unroll
+                    for (int i = 0; i < NT; i++) Qzz[i] = MFMA(comp(Fk[i], r), comp(Tz[k], r), Qzz[i]);
+                }
+            }
+            Quzw = Quzw + pLuz;
+#pragma unroll
+            for (int i = 0; i < NT; i++) Qzz[i] = Qzz[i] + pL[i];
+            CYC(8)
+            __builtin_amdgcn_sched_barrier(0);
+            request_cost(rn);                                      // (issued while the u-wave still refreshes the inverse)
+            __builtin_amdgcn_sched_barrier(0);
+            CYC(2)
+            __syncthreads();                                       // the inverse and the verdict are out
+            CYC(3)
+            // ---- D: X(w) = Xinv Quz(w), K / k, G(w) ----------------------------------------------------------------
+            fail = sFlag[0];
+            if (fail) break;
+            if (check_pd) pd_counter = 0;
+            const d4 X = Pn(lds_tile(bufXi, lane), Quzw, zero, NCU);
+            const int col = 16 * w + c;
+            lds_store(bufX + w * TILE, lane, X);
+            __amdgpu_buffer_rsrc_t rK = __builtin_amdgcn_make_buffer_rsrc((void *)pK, 0, m * n * 8, 0x00020000);
+            __amdgpu_buffer_rsrc_t rk = __builtin_amdgcn_make_buffer_rsrc((void *)pk, 0, m * 8, 0x00020000);
+            pK -= (size_t)m * n * 8; pk -= (size_t)m * 8;
+            const double xv[4] = {X.x, X.y, X.z, X.w};
+#pragma unroll
+            for (int r = 0; r < NCU; r++) {
+                const int row = 4 * r + q;
+                const double kv = -xv[r];
+                __builtin_amdgcn_raw_buffer_store_b64(__builtin_bit_cast(u32x2t, kv), rK, (row < m && col < n) ? 8 * (row + col * m) : OOBT, 0, 0);
+                __builtin_amdgcn_raw_buffer_store_b64(__builtin_bit_cast(u32x2t, kv), rk, (row < m && col == n) ? 8 * row : OOBT, 0, 0);
+            }
+            if (col == n) {                           // delta_J -= lambda k'k: lane-local squares, reduced after the sweep
+#pragma unroll
+                for (int r = 0; r < NCU; r++) dJ -= lam * (xv[r] * xv[r]);
+            }
+            // G = (Quu + 2 lambda I) K' = -(Quz + lambda X) because (Quu + lambda I) X = Quz: no product needed
+            d4 Gw;
+            Gw.x = -__builtin_fma(lam, X.x, Quzw.x); Gw.y = -__builtin_fma(lam, X.y, Quzw.y);
+            Gw.z = -__builtin_fma(lam, X.z, Quzw.z); Gw.w = -__builtin_fma(lam, X.w, Quzw.w);
+            CYC(4)
+            __syncthreads();
+            // ---- E: acc(i,w) = Qzz(i,w) + X_i' G_w -> bufT -------------------------------------------------------
+#pragma unroll
+            for (int i = 0; i < NT; i++) {
+                Qzz[i] = Pn(lds_tile(bufX + i * TILE, lane), Gw, Qzz[i], NCU);
+                double *pw = bufT + (i * NT + w) * TPAD + q * 17 + c;
+                pw[0] = Qzz[i].x; pw[4 * 17] = Qzz[i].y; pw[8 * 17] = Qzz[i].z; pw[12 * 17] = Qzz[i].w;
+            }
+            CYC(5)
+            __syncthreads();
+            CYC(6)
+            // ---- F: V'(i,w) = (acc(i,w) + acc(w,i)')/2   (:610) -----------------------------------------------------
+#pragma unroll
+            for (int i = 0; i < NT; i++) {
+                const double *pt = bufT + (w * NT + i) * TPAD + c * 17 + q;
+                d4 at;
+                at.x = pt[0]; at.y = pt[4]; at.z = pt[8]; at.w = pt[12];
+                d4 na = 0.5 * (Qzz[i] + at);
+                if (i == tn && w == tn) na = na * nn_keep;
+                lds_store(bufV + (i * NT + w) * TILE, lane, na);
+            }
+        }
+    }
+#ifdef KP_CYC_UW
+    if (b == 0 && lane == 0) printf("wave %d: A %lld | wait1 %lld | BC %lld | wait2 %lld | D %lld | E+wait3 %lld | wait4 %lld | B %lld wait1b %lld C %lld (cycles per step; F is in A)\n", w,
+                                    cy[0] / T, cy[1] / T, cy[2] / T, cy[3] / T, cy[4] / T, cy[5] / T, cy[6] / T, cy[7] / T, cy[9] / T, cy[8] / T);
+#endif
+    dJ += __shfl_xor(dJ, 16);
+    dJ += __shfl_xor(dJ, 32);
+    if (w == tn && lane_nn) delta_J[b] = dJ;
+    if (threadIdx.x == 0) status[b] = fail;
+}
+
+template <int M, int NT, int NCL>
+static hipError_t launch_bt_uw2(Ctx *c, int pd_stride)
+{
+    const size_t ldc = backward_col_lds_bytes(NT);
+    hipError_t e = hipFuncSetAttribute((const void *)k_backward_tiled_uw<M, NT, NCL>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)ldc);
+    if (e != hipSuccess) return e;
+    hipLaunchKernelGGL((k_backward_tiled_uw<M, NT, NCL>), dim3(c->d.batch), dim3(64 * (NT + 1)), ldc, c->stream, c->L, c->d.T, c->rec,
+                       c->lambda, pd_stride, c->K, c->k, c->delta_J, c->status);
+    return hipGetLastError();
+}
+template <int M, int NT>
+static hipError_t launch_bt_uw(Ctx *c, int pd_stride)
+{
+    if constexpr (NT <= 3) {
+        const int rows = c->n + 1 - 16 * (NT - 1), ncl = rows >= 16 ? 4 : (rows + 3) / 4;
+        switch (ncl > 1 ? ncl : 1) {                 // (a state that leaves the last tile empty -- KPILQR_TILED_NT_MIN -- still runs one chunk)
+        case 1: return launch_bt_uw2<M, NT, 1>(c, pd_stride);
+        case 2: return launch_bt_uw2<M, NT, 2>(c, pd_stride);
+        case 3: return launch_bt_uw2<M, NT, 3>(c, pd_stride);
+        case 4: return launch_bt_uw2<M, NT, 4>(c, pd_stride);
+        }
+    }
+    return hipErrorInvalidValue;
+}
+
 template <int M, int NT, bool A6, bool A4>
 static hipError_t launch_bt2(Ctx *c, int pd_stride)
 {
@@ -573,6 +945,7 @@ static hipError_t launch_bt2(Ctx *c, int pd_stride)
 template <int M, int NT>
 static hipError_t launch_bt(Ctx *c, int pd_stride)
 {
+    if (NT <= 3 && !c->tiled_a4 && !c->tiled_a6 && c->tune.tiled_uw != 0) return launch_bt_uw<M, NT>(c, pd_stride);
     if (c->tiled_a4) return c->tiled_a6 ? launch_bt2<M, NT, true, true>(c, pd_stride) : launch_bt2<M, NT, false, true>(c, pd_stride);
     return c->tiled_a6 ? launch_bt2<M, NT, true, false>(c, pd_stride) : launch_bt2<M, NT, false, false>(c, pd_stride);
 }
