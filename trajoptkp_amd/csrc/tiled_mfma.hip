@@ -188,7 +188,9 @@ __device__ __forceinline__ d4 ld_Ru(__amdgpu_buffer_rsrc_t rs, int m, int nr, in
 // A4: Fz(:,w) and Fu(w) are not read from the records of every step but interpolated in registers from the key-point
 // columns (tracker.h): lane (q,c) of wave w holds rows 16k+4r+q of COLUMN 16w+c of A -- one DoF list per lane -- and rows
 // 16w+4r+q of column c of B (the list of DoF c: KeyPointGenerator.cpp:927-931), so the records are touched at key-points only.
-template <int M, int NT, bool A6, bool A4>
+// NCL > 0: the chunk count of the last row tile at compile time (see k_backward_tiled_uw) and the products of phase BC as
+// interleaved chains; NCL = 0: run-time count, one chain after the other.
+template <int M, int NT, bool A6, bool A4, int NCL = 0>
 __global__ void __launch_bounds__(64 * NT)
 k_backward_tiled_col(RecLayout L, CostSrc CS, KpSrc KP, int T, const double *__restrict__ rec, const double *__restrict__ lambda,
                      int pd_stride, double *__restrict__ Kout, double *__restrict__ kout,
@@ -380,9 +382,49 @@ k_backward_tiled_col(RecLayout L, CostSrc CS, KpSrc KP, int T, const double *__r
         __syncthreads();
         // ---- BC: Tz(:,w), Tu(w), Quu partial, Quz(w), Qzz(:,w) ------------------------------------------------
         form_cost(t == T - 1 ? W2term : W2run);        // cL, cLuz, cLuu of this step (A6: from the residual tiles)
-        d4 Fc[NT], Tz[NT];
+        d4 Fc[NT], Tz[NT], Qzz[NT];
+        d4 Quzw = cLuz;                                                     // Quz(w): also kept in registers for the fast path
 #pragma unroll
         for (int k = 0; k < NT; k++) Fc[k] = lds_tile(bufF + (k * NT + w) * TILE, lane);
+        if constexpr (NCL > 0) {
+            // independent accumulation chains issued interleaved (back-to-back MFMAs of ONE chain issue every ~80 cycles, of
+            // different chains every 64): Tz(0..NT-1,w) with Tu(w); then Quz(w) with Qzz(0..NT-1,w)
+            auto nck = [](int kt) { return kt < NT - 1 ? 4 : NCL; };
+            auto comp = [](const d4 &v, int r) { return r == 0 ? v.x : r == 1 ? v.y : r == 2 ? v.z : v.w; };
+            d4 Tu = zero;
+#pragma unroll
+            for (int i = 0; i < NT; i++) Tz[i] = zero;
+#pragma unroll
+            for (int k = 0; k < NT; k++) {
+                d4 Vk[NT];
+#pragma unroll
+                for (int i = 0; i < NT; i++) Vk[i] = lds_tile(bufV + (k * NT + i) * TILE, lane);
+                const d4 Vw = lds_tile(bufV + (k * NT + w) * TILE, lane), Fuk = lds_tile(bufFu + k * TILE, lane);
+#pragma unroll
+                for (int r = 0; r < nck(k); r++) {
+#pragma unroll
+                    for (int i = 0; i < NT; i++) Tz[i] = MFMA(comp(Vk[i], r), comp(Fc[k], r), Tz[i]);
+                    Tu = MFMA(comp(Vw, r), comp(Fuk, r), Tu);
+                }
+            }
+            lds_store(bufQp + w * TILE, lane, Pn(lds_tile(bufFu + w * TILE, lane), Tu, (A6 && w == 0) ? cLuu : zero, ncw));
+#pragma unroll
+            for (int i = 0; i < NT; i++) Qzz[i] = cL[i];
+#pragma unroll
+            for (int k = 0; k < NT; k++) {
+                d4 Fk[NT];
+#pragma unroll
+                for (int i = 0; i < NT; i++) Fk[i] = lds_tile(bufF + (k * NT + i) * TILE, lane);
+                const d4 Fuk = lds_tile(bufFu + k * TILE, lane);
+#pragma unroll
+                for (int r = 0; r < nck(k); r++) {
+                    Quzw = MFMA(comp(Fuk, r), comp(Tz[k], r), Quzw);
+#pragma unroll
+                    for (int i = 0; i < NT; i++) Qzz[i] = MFMA(comp(Fk[i], r), comp(Tz[k], r), Qzz[i]);
+                }
+            }
+            lds_store(bufQuz + w * TILE, lane, Quzw);
+        } else {
 #pragma unroll
         for (int i = 0; i < NT; i++) {
             d4 acc = zero;
@@ -397,17 +439,16 @@ k_backward_tiled_col(RecLayout L, CostSrc CS, KpSrc KP, int T, const double *__r
             // A6: l_uu rides in wave 0's partial (the other waves never form it)
             lds_store(bufQp + w * TILE, lane, Pn(lds_tile(bufFu + w * TILE, lane), Tu, (A6 && w == 0) ? cLuu : zero, ncw));
         }
-        d4 Quzw = cLuz;                                                     // Quz(w): also kept in registers for the fast path
 #pragma unroll
         for (int k = 0; k < NT; k++) Quzw = Pk<NT>(k, lds_tile(bufFu + k * TILE, lane), Tz[k], Quzw, ncl);
         lds_store(bufQuz + w * TILE, lane, Quzw);
-        d4 Qzz[NT];
 #pragma unroll
         for (int i = 0; i < NT; i++) {
             d4 acc = cL[i];
 #pragma unroll
             for (int k = 0; k < NT; k++) acc = Pk<NT>(k, lds_tile(bufF + (k * NT + i) * TILE, lane), Tz[k], acc, ncl);
             Qzz[i] = acc;
+        }
         }
         const d4 Luu_t = cLuu;
         __builtin_amdgcn_sched_barrier(0);
@@ -930,17 +971,32 @@ static hipError_t launch_bt_uw(Ctx *c, int pd_stride)
     return hipErrorInvalidValue;
 }
 
-template <int M, int NT, bool A6, bool A4>
-static hipError_t launch_bt2(Ctx *c, int pd_stride)
+template <int M, int NT, bool A6, bool A4, int NCL>
+static hipError_t launch_bt3(Ctx *c, int pd_stride)
 {
     const size_t ldc = backward_col_lds_bytes(NT);
-    hipError_t e = hipFuncSetAttribute((const void *)k_backward_tiled_col<M, NT, A6, A4>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)ldc);
+    hipError_t e = hipFuncSetAttribute((const void *)k_backward_tiled_col<M, NT, A6, A4, NCL>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)ldc);
     if (e != hipSuccess) return e;
     const CostSrc CS = {c->r, c->r_x, c->r_u, c->w_run, c->w_term, c->d.nr};
     const KpSrc KP = {c->kp_offsets, c->kp_times, c->d.dof};
-    hipLaunchKernelGGL((k_backward_tiled_col<M, NT, A6, A4>), dim3(c->d.batch), dim3(64 * NT), ldc, c->stream, c->L, CS, KP, c->d.T, c->rec,
+    hipLaunchKernelGGL((k_backward_tiled_col<M, NT, A6, A4, NCL>), dim3(c->d.batch), dim3(64 * NT), ldc, c->stream, c->L, CS, KP, c->d.T, c->rec,
                        c->lambda, pd_stride, c->K, c->k, c->delta_J, c->status);
     return hipGetLastError();
+}
+template <int M, int NT, bool A6, bool A4>
+static hipError_t launch_bt2(Ctx *c, int pd_stride)
+{
+    // four tiles, records materialised: the interleaved products, instantiated per chunk count of the last row tile
+    if constexpr (NT == 4 && !A4) {
+        const int rows = c->n + 1 - 16 * (NT - 1), ncl = rows >= 16 ? 4 : (rows + 3) / 4;
+        if (c->tune.tiled_uw != 0) switch (ncl) {
+        case 1: return launch_bt3<M, NT, A6, A4, 1>(c, pd_stride);
+        case 2: return launch_bt3<M, NT, A6, A4, 2>(c, pd_stride);
+        case 3: return launch_bt3<M, NT, A6, A4, 3>(c, pd_stride);
+        case 4: return launch_bt3<M, NT, A6, A4, 4>(c, pd_stride);
+        }
+    }
+    return launch_bt3<M, NT, A6, A4, 0>(c, pd_stride);
 }
 template <int M, int NT>
 static hipError_t launch_bt(Ctx *c, int pd_stride)
