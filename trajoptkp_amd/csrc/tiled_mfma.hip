@@ -1026,7 +1026,9 @@ hipError_t launch_backward_tiled(Ctx *c, int pd_stride)
 // back from it (tile (wi,k) was written by wave k), the B operand from the wave's own tile.  No extra barrier: the image
 // of step t+1 is complete before the barrier that ends step t.
 template <int NT> constexpr size_t forward_a4_lds_doubles() { return (size_t)(2 * NT * NT + NT) * TPAD; }
-template <int NT, bool A6, bool A4>
+// NCL > 0: chunk count of the last row tile at compile time, the two accumulation chains of a step (state cost rows Lc Z, next
+// state Ya Z) issued interleaved; NCL = 0: run-time count, one chain after the other (see k_backward_tiled_uw).
+template <int NT, bool A6, bool A4, int NCL = 0>
 __global__ void __launch_bounds__(64 * NT)
 k_forward_tiled(RecLayout L, CostSrc CS, KpSrc KP, int T, int n_alpha, const double *__restrict__ rec, const double *__restrict__ Kin,
                 const double *__restrict__ kin, const double *__restrict__ u_nom, const double *__restrict__ ctrl_lim,
@@ -1263,6 +1265,26 @@ k_forward_tiled(RecLayout L, CostSrc CS, KpSrc KP, int T, int n_alpha, const dou
         }
         // ---- state cost rows of this tile, then the linearised dynamics for this tile ------------------------------
         d4 Wz = zero, Zn = zero;
+        if constexpr (NCL > 0 && !A6 && !A4) {
+            auto nck = [](int kt) { return kt < NT - 1 ? 4 : NCL; };
+            auto comp = [](const d4 &v, int r) { return r == 0 ? v.x : r == 1 ? v.y : r == 2 ? v.z : v.w; };
+#pragma unroll
+            for (int k = 0; k < NT; k++) {
+                d4 Ya = cur.Ya[k];
+                if (k == tnz) { Ya.x += oneT[0]; Ya.y += oneT[1]; Ya.z += oneT[2]; Ya.w += oneT[3]; }
+#pragma unroll
+                for (int r = 0; r < nck(k); r++) {
+                    Zn = MFMA(comp(Ya, r), comp(Zk[k], r), Zn);
+                    Wz = MFMA(comp(cur.Lc[k], r), comp(Zk[k], r), Wz);
+                }
+            }
+            Zn = Pn(cur.Yb, dU, Zn, ncu);
+            __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+            for (int k = 0; k < NT; k++) cur.Lc[k] = ld4(rR, oLc[k]);
+            __builtin_amdgcn_sched_barrier(0);
+            partial += 0.5 * (Zi.x * Wz.x + Zi.y * Wz.y + Zi.z * Wz.z + Zi.w * Wz.w);
+        } else {
         if (!A6) {
 #pragma unroll
             for (int k = 0; k < NT; k++) Wz = Pk<NT>(k, cur.Lc[k], Zk[k], Wz, ncl);
@@ -1280,6 +1302,7 @@ k_forward_tiled(RecLayout L, CostSrc CS, KpSrc KP, int T, int n_alpha, const dou
             Zn = Pk<NT>(k, Ya, Zk[k], Zn, ncl);
         }
         Zn = Pn(cur.Yb, dU, Zn, ncu);
+        }
         __builtin_amdgcn_sched_barrier(0);
         if constexpr (A4) {
             if (t + 1 < T) {                     // A, B of step t+1 into the other half of the image (behind this step's reads of bimg)
@@ -1316,19 +1339,33 @@ bool forward_tiled_supported(int n, int m, int n_alpha, int nt_min)
     return nt >= 2 && nt <= 4 && m <= 16 && n_alpha <= 16;
 }
 
-template <int NT, bool A6, bool A4>
-static hipError_t launch_ft2(Ctx *c, double *U_alpha_dev)
+template <int NT, bool A6, bool A4, int NCL>
+static hipError_t launch_ft3(Ctx *c, double *U_alpha_dev)
 {
     const CostSrc CS = {c->r, c->r_x, c->r_u, c->w_run, c->w_term, c->d.nr};
     const KpSrc KP = {c->kp_offsets, c->kp_times, c->d.dof};
     const size_t lds = sizeof(double) * ((size_t)(3 + (A6 ? 1 : 0)) * NT * TILE + NT * 64 + (A4 ? forward_a4_lds_doubles<NT>() : 0));
     if (lds > 64 * 1024) {
-        hipError_t e = hipFuncSetAttribute((const void *)k_forward_tiled<NT, A6, A4>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        hipError_t e = hipFuncSetAttribute((const void *)k_forward_tiled<NT, A6, A4, NCL>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
         if (e != hipSuccess) return e;
     }
-    hipLaunchKernelGGL((k_forward_tiled<NT, A6, A4>), dim3(c->d.batch), dim3(64 * NT), lds, c->stream, c->L, CS, KP, c->d.T,
+    hipLaunchKernelGGL((k_forward_tiled<NT, A6, A4, NCL>), dim3(c->d.batch), dim3(64 * NT), lds, c->stream, c->L, CS, KP, c->d.T,
                        c->d.n_alpha, c->rec, c->K, c->k, c->u_nom, c->ctrl_lim, c->alphas, c->cost_pred, U_alpha_dev);
     return hipGetLastError();
+}
+template <int NT, bool A6, bool A4>
+static hipError_t launch_ft2(Ctx *c, double *U_alpha_dev)
+{
+    if constexpr (!A6 && !A4) {                      // materialised tiles: the interleaved chains, per chunk count of the last row tile
+        const int rows = c->n + 2 - 16 * (NT - 1), ncl = rows >= 16 ? 4 : (rows + 3) / 4;
+        if (c->tune.tiled_uw != 0) switch (ncl > 1 ? ncl : 1) {
+        case 1: return launch_ft3<NT, A6, A4, 1>(c, U_alpha_dev);
+        case 2: return launch_ft3<NT, A6, A4, 2>(c, U_alpha_dev);
+        case 3: return launch_ft3<NT, A6, A4, 3>(c, U_alpha_dev);
+        case 4: return launch_ft3<NT, A6, A4, 4>(c, U_alpha_dev);
+        }
+    }
+    return launch_ft3<NT, A6, A4, 0>(c, U_alpha_dev);
 }
 template <int NT>
 static hipError_t launch_ft(Ctx *c, double *U_alpha_dev)
