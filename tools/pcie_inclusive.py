@@ -87,13 +87,14 @@ def measure(B=256, steps=5, T=3000, task="panda_reaching", chunk_list=(4, 8, 16)
                     dt = timed(streamed, full, nc, sync_each)
                     assert np.array_equal(K, K0) and np.array_equal(k, k0), "streamed K differs from the staged path"
                     rows.append((label, f"chunks={nc} " + ("per-iteration sync" if sync_each else "pipelined"), dt, up))
-        # the host-differenced columns as the payload (pipelined form of the first chunk count)
+        # the host-differenced columns as the payload (pipelined form, every chunk count)
         for full in (True, False):
-            K[...] = 0
-            dt = timed(streamed, full, chunk_list[0], False, True)
-            assert np.array_equal(K, K0) and np.array_equal(k, k0), "streamed K differs from the staged path (key-point columns)"
-            rows.append(("columns + " + ("full residual payload" if full else "resident Jacobians"), f"chunks={chunk_list[0]} pipelined", dt,
-                         col_bytes + res_bytes[full]))
+            for nc in chunk_list:
+                K[...] = 0
+                dt = timed(streamed, full, nc, False, True)
+                assert np.array_equal(K, K0) and np.array_equal(k, k0), "streamed K differs from the staged path (key-point columns)"
+                rows.append(("columns + " + ("full residual payload" if full else "resident Jacobians"), f"chunks={nc} pipelined", dt,
+                             col_bytes + res_bytes[full]))
         e.iterate(lam); e.sync()
         t0 = time.perf_counter()
         for _ in range(steps):
