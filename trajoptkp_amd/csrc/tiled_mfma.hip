@@ -1200,6 +1200,12 @@ k_forward_tiled(RecLayout L, CostSrc CS, KpSrc KP, int T, int n_alpha, const dou
     }
     __syncthreads();
 
+#ifdef KP_CYC_FT
+    long long cy[8] = {0, 0, 0, 0, 0, 0, 0, 0}, c0 = __builtin_readcyclecounter(), c1;
+#define CYF(i) { c1 = __builtin_readcyclecounter(); cy[i] += c1 - c0; c0 = c1; }
+#else
+#define CYF(i)
+#endif
     for (int t = 0; t < T; t++) {
         const __amdgpu_buffer_rsrc_t rR = rs_of(rec, L.stride, t + 1, rec_bytes), rK = rs_of(Kin, (size_t)m * n, t + 1, m * n * 8);
         const __amdgpu_buffer_rsrc_t rk = rs_of(kin, m, t + 1, m * 8), ru = rs_of(u_nom, m, t + 1, m * 8);
@@ -1212,7 +1218,9 @@ k_forward_tiled(RecLayout L, CostSrc CS, KpSrc KP, int T, int n_alpha, const dou
         cur.Ykw = ld4(rK, oKw) + ld4(rk, okw);
         if (A6) cur.Lc[0] = ld4(rs_res(rxb, (size_t)nr * n, t + 1, nr * n * 8), oRxT);
         __builtin_amdgcn_sched_barrier(0);
+        CYF(0)
         __syncthreads();
+        CYF(1)
         // ---- control law + clamp (every wave; :876-890) --------------------------------------------------------
         const d4 ub = cur.ub;
         d4 U = ub;
@@ -1263,6 +1271,7 @@ k_forward_tiled(RecLayout L, CostSrc CS, KpSrc KP, int T, int n_alpha, const dou
             __builtin_amdgcn_sched_barrier(0);
             }
         }
+        CYF(2)
         // ---- state cost rows of this tile, then the linearised dynamics for this tile ------------------------------
         d4 Wz = zero, Zn = zero;
         if constexpr (NCL > 0 && !A6 && !A4) {
@@ -1317,10 +1326,17 @@ k_forward_tiled(RecLayout L, CostSrc CS, KpSrc KP, int T, int n_alpha, const dou
             cur.Yb = ld4(rR, oB);
         }
         __builtin_amdgcn_sched_barrier(0);
+        CYF(3)
         Zi = Zn;
         lds_store(zn + wi * TILE, lane, Zn);
+        CYF(4)
         __syncthreads();
+        CYF(5)
     }
+#ifdef KP_CYC_FT
+    if (b == 0 && lane == 0) printf("fwd wave %d: slice+requests %lld | wait1 %lld | law+clamp(+last wave's cost) %lld | products+requests %lld | Zn store %lld | wait2 %lld\n", wi,
+                                    cy[0] / T, cy[1] / T, cy[2] / T, cy[3] / T, cy[4] / T, cy[5] / T);
+#endif
     // column sums: over the q lane groups, then over the waves (fixed order: reproducible)
     partial += __shfl_xor(partial, 16);
     partial += __shfl_xor(partial, 32);
