@@ -1372,7 +1372,9 @@ static hipError_t launch_ft3(Ctx *c, double *U_alpha_dev)
 template <int NT, bool A6, bool A4>
 static hipError_t launch_ft2(Ctx *c, double *U_alpha_dev)
 {
-    if constexpr (!A6 && !A4) {                      // materialised tiles: the interleaved chains, per chunk count of the last row tile
+    // materialised tiles, two row tiles: the interleaved chains, per chunk count of the last row tile (pushing 3.52 -> 3.41 ms, walker
+    // 3.40 -> 3.19; with three tiles the same code is SLOWER, 4.98 -> 5.56 ms on light clutter n=38, so it stays with two)
+    if constexpr (!A6 && !A4 && NT == 2) {
         const int rows = c->n + 2 - 16 * (NT - 1), ncl = rows >= 16 ? 4 : (rows + 3) / 4;
         if (c->tune.tiled_uw != 0) switch (ncl > 1 ? ncl : 1) {
         case 1: return launch_ft3<NT, A6, A4, 1>(c, U_alpha_dev);
