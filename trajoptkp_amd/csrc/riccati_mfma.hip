@@ -157,11 +157,14 @@ __device__ __forceinline__ void backward_body(RecLayout L, int T, const double *
     constexpr int REG_NN = n >> 2;
 
     const double *R0 = rec + (size_t)b * T * L.stride;
-    StepTiles cur, nxt;
-    load_step<NCU>(R0 + (size_t)(T - 1) * L.stride, rec_bytes, o, nxt);
-    d4 V = nxt.Lzz;                         // V_x = l_x[T-1]; V_xx = l_xx[T-1]   (iLQR.cpp:537-539)
-    for (int d = 1; d <= PF_DIST; d++)
-        if (T - 1 - d >= 0) l2_prefetch_record(R0 + (size_t)(T - 1 - d) * L.stride, rec_bytes, lane, sh + LDS_PF);
+    // Two tile sets (step t works on set (T-1-t) & 1): each is re-requested for step t-2 right behind its use in step t, so a
+    // request has two steps to land (round 3; one set, copied at the top of the step, waited a trip to HBM per step AND sat out
+    // the acknowledgement of the gains stored at the end of the step before -- a wave's loads and stores return in order, fused_mfma.hip).
+    // The time loop is a body of two steps without conditions around memory operations.
+    StepTiles S[2];
+    load_step<NCU>(R0 + (size_t)(T - 1) * L.stride, rec_bytes, o, S[0]);
+    load_step<NCU>(R0 + (size_t)(T > 1 ? T - 2 : 0) * L.stride, rec_bytes, o, S[1]);
+    d4 V = S[0].Lzz;                        // V_x = l_x[T-1]; V_xx = l_xx[T-1]   (iLQR.cpp:537-539)
 
     int pd_counter = 0;
     double dJ = 0.0;
@@ -172,24 +175,46 @@ __device__ __forceinline__ void backward_body(RecLayout L, int T, const double *
     Iu.x = (q == c && c < m) ? 1.0 : 0.0; Iu.y = (4 + q == c && c < m) ? 1.0 : 0.0;
     Iu.z = (8 + q == c && c < m) ? 1.0 : 0.0; Iu.w = (12 + q == c && c < m) ? 1.0 : 0.0;
 
-    for (int t = T - 1; t >= 0; t--) {
-        // the loads issued one step ago are consumed here; then the next record is requested at once
-        cur = nxt;
-        cur.Fz.x += one[0]; cur.Fz.y += one[1]; cur.Fz.z += one[2]; cur.Fz.w += one[3];
-        if (t > 0) load_step<NCU>(R0 + (size_t)((ABL & 1) ? T - 1 : t - 1) * L.stride, rec_bytes, o, nxt);
-        if (PF_DIST > 0 && !(ABL & 1) && t - 1 - PF_DIST >= 0)
-            l2_prefetch_record(R0 + (size_t)(t - 1 - PF_DIST) * L.stride, rec_bytes, lane, sh + LDS_PF);
-        __builtin_amdgcn_sched_barrier(0);     // keep the prefetch AHEAD of this step's compute
+    // the gains of a step leave one step LATE, in front of the next requests (Kst / tst: the pending step)
+    d4 Kst = zero;
+    int tst = -1;
+    auto store_gains = [&](int t_, const d4 &Kp) {
+        const int t = __builtin_amdgcn_readfirstlane(t_);
+        if (!(ABL & 4)) {
+            // K (m x n column-major) and k out through bounds-checked buffer stores (lanes that own no
+            // element carry an out-of-range offset and are dropped): straight-line code.
+            __amdgpu_buffer_rsrc_t rK = __builtin_amdgcn_make_buffer_rsrc((void *)(Kout + ((size_t)b * T + t) * m * n), 0, m * n * 8, 0x00020000);
+            __amdgpu_buffer_rsrc_t rk = __builtin_amdgcn_make_buffer_rsrc((void *)(kout + ((size_t)b * T + t) * m), 0, m * 8, 0x00020000);
+            const double kv[4] = {Kp.x, Kp.y, Kp.z, Kp.w};
+#pragma unroll
+            for (int r = 0; r < NCU; r++) {
+                __builtin_amdgcn_raw_buffer_store_b64(__builtin_bit_cast(u32x2, kv[r]), rK, oKst[r], 0, 0);
+                __builtin_amdgcn_raw_buffer_store_b64(__builtin_bit_cast(u32x2, kv[r]), rk, okst[r], 0, 0);
+            }
+        }
+    };
+    auto step = [&](int t, StepTiles &cur) {
         pd_counter++;
         const bool check_pd = pd_counter >= pd_stride;
+        d4 Fz = cur.Fz;
+        Fz.x += one[0]; Fz.y += one[1]; Fz.z += one[2]; Fz.w += one[3];
 
         // ---- Tu = V' Fu ; Quu = l_uu + Fu' Tu --------------------------------------- :577
         d4 Tu = P<NCZ>(V, cur.Fu, zero);
         d4 Quu = P<NCZ>(cur.Fu, Tu, cur.Luu);
         // ---- Tz, Quz, Qzz --------------------------------------------------------------- :570-579
-        d4 Tz = P<NCZ>(V, cur.Fz, zero);
+        d4 Tz = P<NCZ>(V, Fz, zero);
         d4 Quz = P<NCZ>(cur.Fu, Tz, cur.Luz);
-        d4 Qzz = P<NCZ>(cur.Fz, Tz, cur.Lzz);
+        d4 Qzz = P<NCZ>(Fz, Tz, cur.Lzz);
+        // the tiles are used up: the gains of the step above go out, then this set is requested for step t-2
+        // (behind step 1 the request repeats step 0's record: never used, but no condition around the loads)
+        __builtin_amdgcn_sched_barrier(0);
+        if (tst >= 0) store_gains(tst, Kst);
+        // (readfirstlane: the step index is wave-uniform, but the compiler lost track of that in the first step of the pair and
+        // wrapped each load in a readfirstlane loop)
+        const int tn = __builtin_amdgcn_readfirstlane((ABL & 1) ? T - 1 : (t >= 2 ? t - 2 : 0));
+        load_step<NCU>(R0 + (size_t)tn * L.stride, rec_bytes, o, cur);
+        __builtin_amdgcn_sched_barrier(0);
         d4 Qr = Quu;                                  // Quu + lambda I
         Qr.x += 0.5 * lam2d[0]; Qr.y += 0.5 * lam2d[1]; Qr.z += 0.5 * lam2d[2]; Qr.w += 0.5 * lam2d[3];
 
@@ -218,9 +243,12 @@ __device__ __forceinline__ void backward_body(RecLayout L, int T, const double *
             __syncthreads();
             // ---- unpivoted LDL' of Quu + lambda I, redundantly in every lane (lower triangle) ----
             double Lm[M][M], rd[M];
-            const bool pos = kp_ldl_factor<M>([&](int i, int j) { return sh[LDS_Q + i * MS + j]; }, Lm, rd);
+            // (every lane factorises the same image; the ballot tells the compiler that the verdict -- and with it `fail` and the
+            // exit of the time loop -- is wave-uniform: with a per-lane verdict the buffer descriptors of the step became
+            // 'divergent' and every load was wrapped in a readfirstlane loop)
+            const bool pos = __builtin_amdgcn_ballot_w64(!kp_ldl_factor<M>([&](int i, int j) { return sh[LDS_Q + i * MS + j]; }, Lm, rd)) == 0;
             if (check_pd) {                       // CheckMatrixPD every pd_stride steps   :587-595
-                if (!pos) { fail = t + 1; break; }
+                if (!pos) { if (!fail) fail = t + 1; return; }
                 pd_counter = 0;
             }
             // ---- every lane solves (Quu + lambda I) x = Quz[:, c] for its own column c --------------
@@ -265,19 +293,7 @@ __device__ __forceinline__ void backward_body(RecLayout L, int T, const double *
                 if (q == (i & 3)) xr[i >> 2] = x[i];
             Xp.x = xr[0]; Xp.y = xr[1]; Xp.z = xr[2]; Xp.w = xr[3];
         }
-        const d4 Kp = -Xp;
-        if (!(ABL & 4)) {
-            // K (m x n column-major) and k out through bounds-checked buffer stores (lanes that own no
-            // element carry an out-of-range offset and are dropped): straight-line code.
-            __amdgpu_buffer_rsrc_t rK = __builtin_amdgcn_make_buffer_rsrc((void *)(Kout + ((size_t)b * T + t) * m * n), 0, m * n * 8, 0x00020000);
-            __amdgpu_buffer_rsrc_t rk = __builtin_amdgcn_make_buffer_rsrc((void *)(kout + ((size_t)b * T + t) * m), 0, m * 8, 0x00020000);
-            const double kv[4] = {Kp.x, Kp.y, Kp.z, Kp.w};
-#pragma unroll
-            for (int r = 0; r < NCU; r++) {
-                __builtin_amdgcn_raw_buffer_store_b64(__builtin_bit_cast(u32x2, kv[r]), rK, oKst[r], 0, 0);
-                __builtin_amdgcn_raw_buffer_store_b64(__builtin_bit_cast(u32x2, kv[r]), rk, okst[r], 0, 0);
-            }
-        }
+        Kst = -Xp; tst = t;
         // ---- delta_J += k'Q_u + k'Q_uu k  (:612-613).  With (Q_uu + lambda I) k = -Q_u this is
         //      k'(Q_uu k + Q_u) = -lambda k'k, evaluated in that cancellation-free form: the lanes of column n keep
         //      the squares of their rows, the four row groups are added once after the sweep.
@@ -296,7 +312,7 @@ __device__ __forceinline__ void backward_body(RecLayout L, int T, const double *
         d4 acc = P<NCU>(Xp, G, Qzz);
 
         // ---- V' = (V' + V'')/2 through an LDS transpose   (:610) -----------------------------------
-        if (ABL & 8) { V = acc; continue; }
+        if (ABL & 8) { V = acc; return; }
         sh[LDS_V + (q) * VS + c] = acc.x;
         sh[LDS_V + (4 + q) * VS + c] = acc.y;
         sh[LDS_V + (8 + q) * VS + c] = acc.z;
@@ -308,7 +324,18 @@ __device__ __forceinline__ void backward_body(RecLayout L, int T, const double *
         V.w = 0.5 * (acc.w + sh[LDS_V + c * VS + 12 + q]);
         if (lane_nn) set_reg<REG_NN>(V, 0.0);      // element (n,n) carries nothing: keep it at zero
         __syncthreads();
+    };
+    // (one exit per pair, at its end: an exit between the two steps makes the compiler carry the tile sets through copies at
+    // the back edge, and a copy of a requested register waits for the request.  A step that follows a failed one works on the
+    // stale V' -- valid numbers, results nobody reads: the status says so -- and leaves `fail` alone.)
+    int t = T - 1;
+    for (; t >= 1; t -= 2) {
+        step(t, S[0]);
+        step(t - 1, S[1]);
+        if (fail) break;
     }
+    if (t == 0 && !fail) step(0, S[0]);
+    if (tst >= 0) store_gains(tst, Kst);           // the last completed step
     // delta_J: the four row groups of column n; status is uniform
     dJ += __shfl_xor(dJ, 16);
     dJ += __shfl_xor(dJ, 32);
