@@ -81,6 +81,9 @@ __device__ __forceinline__ void l2_prefetch_record(const double *R, int rec_byte
     if (o1 < rec_bytes) glds_dword((const char *)R + o1, lds_addr);
 }
 #define PF_DIST 0
+#ifndef KP_RIC_SETS
+#define KP_RIC_SETS 2              // tile sets of the backward sweep (requests run this many steps ahead)
+#endif
 
 struct TileOffs { int fz[4], fu[4], lzz[4], luz[4], luu[4]; };
 
@@ -161,9 +164,10 @@ __device__ __forceinline__ void backward_body(RecLayout L, int T, const double *
     // request has two steps to land (round 3; one set, copied at the top of the step, waited a trip to HBM per step AND sat out
     // the acknowledgement of the gains stored at the end of the step before -- a wave's loads and stores return in order, fused_mfma.hip).
     // The time loop is a body of two steps without conditions around memory operations.
-    StepTiles S[2];
-    load_step<NCU>(R0 + (size_t)(T - 1) * L.stride, rec_bytes, o, S[0]);
-    load_step<NCU>(R0 + (size_t)(T > 1 ? T - 2 : 0) * L.stride, rec_bytes, o, S[1]);
+    constexpr int NS = KP_RIC_SETS;
+    StepTiles S[NS];
+#pragma unroll
+    for (int k = 0; k < NS; k++) load_step<NCU>(R0 + (size_t)(T - 1 - k > 0 ? T - 1 - k : 0) * L.stride, rec_bytes, o, S[k]);
     d4 V = S[0].Lzz;                        // V_x = l_x[T-1]; V_xx = l_xx[T-1]   (iLQR.cpp:537-539)
 
     int pd_counter = 0;
@@ -212,7 +216,7 @@ __device__ __forceinline__ void backward_body(RecLayout L, int T, const double *
         if (tst >= 0) store_gains(tst, Kst);
         // (readfirstlane: the step index is wave-uniform, but the compiler lost track of that in the first step of the pair and
         // wrapped each load in a readfirstlane loop)
-        const int tn = __builtin_amdgcn_readfirstlane((ABL & 1) ? T - 1 : (t >= 2 ? t - 2 : 0));
+        const int tn = __builtin_amdgcn_readfirstlane((ABL & 1) ? T - 1 : (t >= NS ? t - NS : 0));
         load_step<NCU>(R0 + (size_t)tn * L.stride, rec_bytes, o, cur);
         __builtin_amdgcn_sched_barrier(0);
         d4 Qr = Quu;                                  // Quu + lambda I
@@ -329,12 +333,14 @@ __device__ __forceinline__ void backward_body(RecLayout L, int T, const double *
     // the back edge, and a copy of a requested register waits for the request.  A step that follows a failed one works on the
     // stale V' -- valid numbers, results nobody reads: the status says so -- and leaves `fail` alone.)
     int t = T - 1;
-    for (; t >= 1; t -= 2) {
-        step(t, S[0]);
-        step(t - 1, S[1]);
+    for (; t >= NS - 1; t -= NS) {
+#pragma unroll
+        for (int k = 0; k < NS; k++) step(t - k, S[k]);
         if (fail) break;
     }
-    if (t == 0 && !fail) step(0, S[0]);
+#pragma unroll
+    for (int k = 0; k < NS - 1; k++)
+        if (t - k >= 0 && !fail) step(t - k, S[k]);
     if (tst >= 0) store_gains(tst, Kst);           // the last completed step
     // delta_J: the four row groups of column n; status is uniform
     dJ += __shfl_xor(dJ, 16);
