@@ -47,6 +47,12 @@ HBM_PEAK_GBS = 8000.0        # MI355X HBM3E spec peak (/opt/skills/guides/MI355X
 # FP64 matrix pipe: v_mfma_f64_16x16x4_f64 = 2048 flop in 64 busy cycles = 32 flop/clk/SIMD (measured,
 # profiles/r01_fp64_mfma_probe.txt) x 1024 SIMDs x 2.4 GHz; the guide has no FP64 row, this is the vector FP64 peak too
 FP64_PEAK_TFLOPS = 1024 * 32 * 2.4e9 / 1e12
+# Residual Jacobians of the ragged-key-point side workloads (configs[2], configs[4]): True = drawn independently at every step (the
+# default, and a worst case: the running inverse of Q_uu never applies, every step factorises), "smooth" = functions of the state
+# that move slowly along the trajectory and none of the control, the structure of the reference's tasks (synth.smooth_residual_jacobians)
+RESIDUAL_MODEL = "smooth" if os.environ.get("KPILQR_BENCH_RESIDUALS") == "smooth" else True
+RESIDUAL_DESC = {True: "drawn independently at every step (worst case: every step factorises)",
+                 "smooth": "smooth in time, none of the control (the structure of the reference's tasks, TwoDPushing.cpp:291-352)"}
 
 
 def algorithmic_bytes(dof, m, nr, T, Kp, n_alpha):
@@ -194,7 +200,7 @@ def slice_problem(p, B):
     return q
 
 
-def build_problem(kind, B, T, min_N, task, first_b=0, distinct=True, cache=None):
+def build_problem(kind, B, T, min_N, task, first_b=0, distinct=True, cache=None, residuals=None):
     """Returns (problem of B trajectories, the problem of its first few trajectories for the oracle check, description)."""
     from trajoptkp_amd import synth
     if kind == "set_interval":
@@ -215,8 +221,9 @@ def build_problem(kind, B, T, min_N, task, first_b=0, distinct=True, cache=None)
         rows = [host.keypoints("adaptive_jerk", dof, T, 1, 100, thresholds=thr, dt=dt,
                                X=synth.contact_trajectory(np.random.default_rng(synth.seed_for(3, b) + 17), dof, T, dt))[:2]
                 for b in range(uniq)]
-        p0 = synth.make_ragged_problem(task, T, rows, config_id=3, dense_residuals=True)
-        desc = f"{task} T={T} adaptive_jerk(min_N=1,max_N=100) ragged key-points, {uniq} distinct seeds tiled"
+        rm = residuals if residuals is not None else RESIDUAL_MODEL
+        p0 = synth.make_ragged_problem(task, T, rows, config_id=3, dense_residuals=rm)
+        desc = f"{task} T={T} adaptive_jerk(min_N=1,max_N=100) ragged key-points, {uniq} distinct seeds tiled, residual Jacobians {RESIDUAL_DESC[rm]}"
     elif kind == "iterative_error":        # BASELINE configs[4]: bisection on a dense synthetic A sequence
         from trajoptkp_amd import host
         uniq = min(2, B)
@@ -225,8 +232,9 @@ def build_problem(kind, B, T, min_N, task, first_b=0, distinct=True, cache=None)
         for b in range(uniq):
             A, Bm = synth.dynamics_dense_smooth(np.random.default_rng(synth.seed_for(5, b) + 77), dof, m, dt, T)
             rows.append(host.keypoints("iterative_error", dof, T, 1, 1, iterative_error_threshold=1e-11, dt=dt, A=A)[:2]); dyn.append((A, Bm))
-        p0 = synth.make_ragged_problem(task, T, rows, dyn=dyn, config_id=5, dense_residuals=True)
-        desc = f"{task} T={T} iterative_error(1e-11) ragged key-points (emulated on a dense synthetic A sequence), {uniq} distinct seeds tiled"
+        rm = residuals if residuals is not None else RESIDUAL_MODEL
+        p0 = synth.make_ragged_problem(task, T, rows, dyn=dyn, config_id=5, dense_residuals=rm)
+        desc = f"{task} T={T} iterative_error(1e-11) ragged key-points (emulated on a dense synthetic A sequence), {uniq} distinct seeds tiled, residual Jacobians {RESIDUAL_DESC[rm]}"
     else:
         raise ValueError(kind)
     uniq = p0["batch"]
@@ -656,15 +664,19 @@ def main():
             # ---- BASELINE configs[1], [2], [4] ----------------------------------------------------------------------
             if args.task == "panda_reaching" and args.keypoints == "set_interval" and T == 3000 and not args.generic and not args.unfused:
                 sec = {}
-                for key, (kind, task, Ts, Bs, ks) in {
-                        "configs[1] panda_reaching T=3000 batch=1": ("set_interval", "panda_reaching", 3000, 1, 10),
-                        "configs[2] panda_pushing T=3000 adaptive_jerk batch=64": ("adaptive_jerk", "panda_pushing", 3000, 64, 5),
-                        "configs[4] high_dof_push n=62 T=5000 iterative_error batch=128 (one GPU's share of 1024)": ("iterative_error", "high_dof_push", 5000, 128, 3),
+                # (configs[2] and [4] twice: with residual Jacobians drawn independently at every step -- the workload of rounds 1-3,
+                # on which the running inverse of Q_uu never applies -- and with Jacobians of the reference's structure, smooth in time)
+                for key, (kind, task, Ts, Bs, ks, rm) in {
+                        "configs[1] panda_reaching T=3000 batch=1": ("set_interval", "panda_reaching", 3000, 1, 10, None),
+                        "configs[2] panda_pushing T=3000 adaptive_jerk batch=64": ("adaptive_jerk", "panda_pushing", 3000, 64, 5, True),
+                        "configs[2] panda_pushing T=3000 adaptive_jerk batch=64, smooth residual Jacobians": ("adaptive_jerk", "panda_pushing", 3000, 64, 5, "smooth"),
+                        "configs[4] high_dof_push n=62 T=5000 iterative_error batch=128 (one GPU's share of 1024)": ("iterative_error", "high_dof_push", 5000, 128, 3, True),
+                        "configs[4] high_dof_push n=62 T=5000 iterative_error batch=128 (one GPU's share of 1024), smooth residual Jacobians": ("iterative_error", "high_dof_push", 5000, 128, 3, "smooth"),
                         # not a BASELINE config: the reference's humanoid (TaskConfigs/locomotion/humanoid.yaml, 21 actuators) on the
                         # wide-control tiled sweeps (tiled_wide.hip) instead of the VALU / LDS kernels
-                        "humanoid n=54 m=21 T=1500 set_interval batch=64": ("set_interval", "humanoid", 1500, 64, 3)}.items():
+                        "humanoid n=54 m=21 T=1500 set_interval batch=64": ("set_interval", "humanoid", 1500, 64, 3, None)}.items():
                     try:
-                        ps, ps0, ds = build_problem(kind, Bs, Ts, 5, task, distinct=False)
+                        ps, ps0, ds = build_problem(kind, Bs, Ts, 5, task, distinct=False, residuals=rm)
                         rs = time_config(torch, stream, local_rank, ps, ks, 1, True, False)
                         pc = parity_check(ps0, rs["eng"], min(ps0["batch"], 2), tiled=kind != "set_interval")
                         rs["eng"].close()

@@ -861,6 +861,31 @@ def test_fused_indefinite_quu_on_unchecked_steps(wave_form):
             assert relerr(K[b], o["K"]) < 1e-6 and relerr(k[b], o["k"]) < 1e-6, (lam, b, relerr(K[b], o["K"]))
 
 
+@pytest.mark.parametrize("task,T", [("panda_pushing", 300), ("walker", 200), ("light_clutter_push", 150), ("high_dof_push", 100)])
+@pytest.mark.parametrize("uw", ["1", "0"])
+def test_tiled_running_inverse_on_smooth_residual_jacobians(task, T, uw, monkeypatch):
+    """Residual Jacobians that move slowly along the trajectory (synth.smooth_residual_jacobians: the structure of the
+    reference's tasks): the tiled backward kernels then run on the Newton-Schulz refresh of the running inverse on nearly every
+    step -- with independently drawn Jacobians, as in the other tiled tests, every step factorises -- with the u-wave (two /
+    three tiles), with the interleaved chains (four tiles) and on the round-2 kernels, materialised and with a6 inside."""
+    monkeypatch.setenv("KPILQR_TILED_UW", uw)
+    monkeypatch.setenv("KPILQR_TILED_A6", "1")
+    p = synth.make_problem(task=task, T=T, batch=2, min_N=4, dense_residuals="smooth", one_sided_frac=0.1)
+    assert not np.any(p["r_u"])
+    ref = [pipeline.run_trajectory(p, b, want_U=True) for b in range(2)]
+    g = run_engine(p)
+    assert g["variants"][0] == "mfma_f64_tiled", g["variants"]
+    check_fused(g, p, ref)
+    with Engine(p["dof"], p["m"], p["T"], p["nr"], batch=2, fused=True) as e:      # a6 inside the sweeps
+        assert e.backward_variant == "mfma_f64_tiled_a6"
+        synth.upload(e, p)
+        e.iterate(p["lam"], 100, orc.alphas(6))
+        res = e.results()
+        g = dict(status=res["status"], delta_J=res["delta_J"], cost_pred=res["cost_pred"], U_alpha=None)
+        g["K"], g["k"] = e.gains()
+    check_fused(g, p, ref)
+
+
 @pytest.mark.parametrize("task,T", [("panda_pushing", 20), ("walker", 24), ("light_clutter_push", 20)])
 @pytest.mark.parametrize("uw", ["1", "0"])
 def test_tiled_indefinite_quu_on_unchecked_steps(task, T, uw, monkeypatch):

@@ -683,6 +683,7 @@ k_backward_tiled_uw(RecLayout L, int T, const double *__restrict__ rec, const do
     int pd_counter = 0, fail = 0;
     double dJ = 0.0;
 #ifdef KP_CYC_UW
+    int hist[6] = {0, 0, 0, 0, 0, 0};
     long long cy[12] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0}, c0 = __builtin_readcyclecounter(), c1;
 #define CYC(i) { c1 = __builtin_readcyclecounter(); cy[i] += c1 - c0; c0 = c1; }
 #else
@@ -746,6 +747,17 @@ k_backward_tiled_uw(RecLayout L, int T, const double *__restrict__ rec, const do
             Qr.x += 0.5 * lam2d[0]; Qr.y += 0.5 * lam2d[1]; Qr.z += 0.5 * lam2d[2]; Qr.w += 0.5 * lam2d[3];
             // running inverse refreshed by Newton-Schulz steps on the matrix core; LDL' on the first step, on checked
             // steps (PD verdict) and when the residual is too large to converge fast (as in k_backward_tiled_col)
+#ifdef KP_CYC_UW
+            {   // histogram of the refresh's starting residual (the bins of kp_inverse_refresh: 1, 2, 3, 4 steps, factorise)
+                const d4 R0 = Iu - kp_P<NCU>(Qr, Xinv, zero);
+                double rm = fabs(R0.x);
+                if (NCU > 1) rm = fmax(rm, fabs(R0.y));
+                const double e0 = (double)m * rm;
+                const int bin = !haveX || check_pd ? 5 : (__builtin_amdgcn_ballot_w64(!(e0 < 0.11)) != 0) ? 4 : (__builtin_amdgcn_ballot_w64(e0 >= 1.3e-2) != 0) ? 3
+                              : (__builtin_amdgcn_ballot_w64(e0 >= 1.7e-4) != 0) ? 2 : (__builtin_amdgcn_ballot_w64(e0 >= 3.0e-8) != 0) ? 1 : 0;
+                hist[bin]++;
+            }
+#endif
             if (!(haveX && !check_pd && kp_inverse_refresh<NCU>(Qr, Iu, Xinv, m))) {
                 lds_store(sQ, lane, Qr);
                 auto qel = [&](int i, int j) {
@@ -939,6 +951,8 @@ k_backward_tiled_uw(RecLayout L, int T, const double *__restrict__ rec, const do
 #ifdef KP_CYC_UW
     if (b == 0 && lane == 0) printf("wave %d: A %lld | wait1 %lld | BC %lld | wait2 %lld | D %lld | E+wait3 %lld | wait4 %lld | B %lld wait1b %lld C %lld (cycles per step; F is in A)\n", w,
                                     cy[0] / T, cy[1] / T, cy[2] / T, cy[3] / T, cy[4] / T, cy[5] / T, cy[6] / T, cy[7] / T, cy[9] / T, cy[8] / T);
+    if (b == 0 && lane == 0 && uw) printf("u-wave refresh, steps by Newton-Schulz count: 1: %d | 2: %d | 3: %d | 4: %d | residual too large, factorised: %d | first / checked steps: %d\n",
+                                          hist[0], hist[1], hist[2], hist[3], hist[4], hist[5]);
 #endif
     dJ += __shfl_xor(dJ, 16);
     dJ += __shfl_xor(dJ, 32);

@@ -145,7 +145,9 @@ def make_problem(task="panda_reaching", T=3000, batch=1, min_N=5, config_id=2, d
         # residuals: N(0, 0.5^2) decaying linearly to 0.05 at T
         scale = np.linspace(0.5, 0.05, T + 1)[:, None]
         r[b] = rng.standard_normal((T + 1, nr)) * scale
-        if dense_residuals:
+        if dense_residuals == "smooth":
+            r_x[b], r_u[b] = smooth_residual_jacobians(rng, T, nr, n, m)
+        elif dense_residuals:
             r_x[b] = rng.standard_normal((T + 1, nr, n)) * 0.3
             r_u[b] = rng.standard_normal((T + 1, nr, m)) * 0.05
         else:
@@ -246,6 +248,20 @@ def rows_from_dof_lists(dof, T, lists):
     return offs, np.asarray(cols, np.int32)
 
 
+def smooth_residual_jacobians(rng, T, nr, n, m):
+    """Residual Jacobians with the structure of the reference's manipulation tasks (TwoDPushing.cpp:291-352: distances and
+    velocities of bodies, a joint velocity, the end-effector's distance to the object -- functions of the STATE that move
+    slowly along a trajectory, none of them of the control): r_x(t) = C0 + C1 sin(w t + phi) element-wise with one to three
+    periods over the horizon, r_u = 0.  `dense_residuals=True` draws every step's Jacobians independently instead -- a worst case
+    for the backward sweeps, whose running inverse of Q_uu then never applies and every step factorises."""
+    t = np.arange(T + 1, dtype=np.float64)[:, None, None]
+    C0 = rng.standard_normal((1, nr, n)) * 0.3
+    C1 = rng.standard_normal((1, nr, n)) * 0.15
+    w = 2.0 * np.pi * rng.integers(1, 4, (1, nr, n)) / max(T, 1)
+    phi = rng.uniform(0.0, 2.0 * np.pi, (1, nr, n))
+    return C0 + C1 * np.sin(w * t + phi), np.zeros((T + 1, nr, m))
+
+
 def make_ragged_problem(task, T, kp_rows, dyn=None, config_id=3, dense_residuals=True, one_sided_frac=0.0, lam=0.1,
                         eps=1e-6, first_b=0):
     """Like make_problem, but with one key-point row list PER TRAJECTORY (adaptive_jerk / iterative_error style:
@@ -290,7 +306,9 @@ def make_ragged_problem(task, T, kp_rows, dyn=None, config_id=3, dense_residuals
         xnom.append(x0); nom_base += len(kp_t)
         scale = np.linspace(0.5, 0.05, T + 1)[:, None]
         r[b] = rng.standard_normal((T + 1, nr)) * scale
-        if dense_residuals:
+        if dense_residuals == "smooth":
+            r_x[b], r_u[b] = smooth_residual_jacobians(rng, T, nr, n, m)
+        elif dense_residuals:
             r_x[b] = rng.standard_normal((T + 1, nr, n)) * 0.3
             r_u[b] = rng.standard_normal((T + 1, nr, m)) * 0.05
         else:
