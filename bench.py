@@ -84,27 +84,36 @@ def cpu_baseline(task, T, min_N, reps_per_thread=60):
     """Times the CPU oracle (oracle/kpilqr_oracle.c = line-faithful port of the reference, built here with
     -O3 -march=native) on this host: whole trajectory-iterations (the same five stages) run by a pthread
     pool inside the C library, one independent trajectory per thread at a time -- the batch analogue of
-    the reference's hardware_concurrency() thread pools.  Thread count = the 1-GPU box's CPU share (16)."""
+    the reference's hardware_concurrency() thread pools.  Thread count = every core this process may run on (printed)."""
     import tempfile
     from oracle import oracle as orc
     from trajoptkp_amd import synth
     path = orc.build(native=True, out_dir=tempfile.mkdtemp(prefix="kpilqr_oracle_"))
     orc._LIB = orc.lib(path)
-    cores = os.cpu_count() or 1
+    online = os.cpu_count() or 1
+    avail = online
     try:
-        cores = len(os.sched_getaffinity(0))
+        avail = len(os.sched_getaffinity(0))             # the cores this process may run on (a 1-GPU box's share of the host)
     except Exception:
         pass
-    cores = min(cores, int(os.environ.get("KPILQR_CPU_THREADS", "16")))   # a 1-GPU box's CPU share is 16 cores
+    # every core the process may use, as the reference's pools do (hardware_concurrency() - 1, Optimiser.cpp:227,280);
+    # KPILQR_CPU_THREADS overrides
+    cores = max(1, int(os.environ.get("KPILQR_CPU_THREADS", str(avail))))
     p = synth.make_problem(task=task, T=T, batch=1, min_N=min_N)
     orc.iteration_batch_seconds(p, 0, 1, 1)                                # warm-up
     t_single = orc.iteration_batch_seconds(p, 0, 1, 5) / 5
-    wall = orc.iteration_batch_seconds(p, 0, cores, reps_per_thread)
-    n_traj = cores * reps_per_thread
-    return {"value": n_traj / wall, "unit": "trajectory-iterations/s", "cores": cores, "kind": "port",
-            "sample": f"{n_traj} trajectory-iterations ({task}, T={T}, key-points every {min_N}) on {cores} pthreads "
-                      f"({wall:.1f} s wall); single thread: {1.0 / t_single:.2f} it/s",
-            "single_thread_value": 1.0 / t_single}
+    reps = reps_per_thread                               # a bounded sample: ~1 s of wall clock per core whatever the core count
+    wall = orc.iteration_batch_seconds(p, 0, cores, reps)
+    n_traj = cores * reps
+    out = {"value": n_traj / wall, "unit": "trajectory-iterations/s", "cores": cores, "cores_available": avail, "cores_online": online,
+           "kind": "port",
+           "sample": f"{n_traj} trajectory-iterations ({task}, T={T}, key-points every {min_N}) on {cores} pthreads "
+                     f"({wall:.1f} s wall; the process may run on {avail} of the host's {online} cores); single thread: {1.0 / t_single:.2f} it/s",
+           "single_thread_value": 1.0 / t_single}
+    if cores > 16:         # rounds 1-3 quoted 16 threads: kept as a second figure for comparability
+        w16 = orc.iteration_batch_seconds(p, 0, 16, reps)
+        out["value_16_threads"] = 16 * reps / w16
+    return out
 
 
 # ---- problems ---------------------------------------------------------------------------------------------------------
@@ -137,7 +146,10 @@ def distinct_problem(task, T, B, min_N, first_b=0, workers=None, cache=None):
     workers = workers or max(1, min(16, len(os.sched_getaffinity(0)) // max(1, int(os.environ.get("LOCAL_WORLD_SIZE", "1")))))
     if B <= 2:
         return synth.make_problem(task=task, T=T, batch=B, min_N=min_N, first_b=first_b)
-    stem = os.path.join(cache, f"{task}_T{T}_B{B}_N{min_N}_b{first_b}_") if cache else None
+    # the generator's own text in the key: a change to synth.py (seeds, residual model, dynamics) must not be served stale arrays
+    import hashlib
+    gen = hashlib.sha256(open(synth.__file__.replace(".pyc", ".py"), "rb").read()).hexdigest()[:10]
+    stem = os.path.join(cache, f"{task}_T{T}_B{B}_N{min_N}_b{first_b}_g{gen}_") if cache else None
     if stem and all(os.path.exists(stem + k + ".npy") for k in _BIG):
         out = {k: np.load(stem + k + ".npy", mmap_mode="r") for k in _BIG}
         return _assemble(synth.make_problem(task=task, T=T, batch=1, min_N=min_N, first_b=first_b), out, B)
@@ -224,6 +236,21 @@ def build_problem(kind, B, T, min_N, task, first_b=0, distinct=True, cache=None,
         rm = residuals if residuals is not None else RESIDUAL_MODEL
         p0 = synth.make_ragged_problem(task, T, rows, config_id=3, dense_residuals=rm)
         desc = f"{task} T={T} adaptive_jerk(min_N=1,max_N=100) ragged key-points, {uniq} distinct seeds tiled, residual Jacobians {RESIDUAL_DESC[rm]}"
+    elif kind in ("reach_velocity_change", "reach_adaptive_jerk"):
+        # The reference's OWN default for reaching: keypointMethod "velocity_change", minN 1, maxN 50, magVelThresholds
+        # [2, 2, 2, 2, 0.5, 0.5, 0.5] (TaskConfigs/free_motion/reaching.yaml:6-8,18; KeyPointGenerator.cpp:642-728), and
+        # adaptive_jerk with the same interval bounds and jointJerkThresholds 10 (:17; :341-382,730-770) -- per-DoF (ragged)
+        # lists placed by the product's host KeypointGenerator on a synthetic reach (cubic spline + a small tracking wiggle).
+        from trajoptkp_amd import host
+        uniq = min(8, B)
+        dof, dt = synth.TASKS[task]["dof"], synth.TASKS[task]["dt"]
+        method = kind[len("reach_"):]
+        thr = np.array([2.0, 2.0, 2.0, 2.0, 0.5, 0.5, 0.5][:dof]) if method == "velocity_change" else np.full(dof, 10.0)
+        rows = [host.keypoints(method, dof, T, 1, 50, thresholds=thr, dt=dt,
+                               X=synth.contact_trajectory(np.random.default_rng(synth.seed_for(6, b) + 5), dof, T, dt))[:2]
+                for b in range(uniq)]
+        p0 = synth.make_ragged_problem(task, T, rows, config_id=6, dense_residuals=False)
+        desc = f"{task} T={T} {method}(min_N=1,max_N=50) per-DoF key-point lists (reaching.yaml's method), {uniq} distinct seeds tiled"
     elif kind == "iterative_error":        # BASELINE configs[4]: bisection on a dense synthetic A sequence
         from trajoptkp_amd import host
         uniq = min(2, B)
@@ -248,8 +275,10 @@ def kp_pairs(p0):
             float(np.mean([int(np.count_nonzero(np.asarray(c) < p0["m"])) for (_, c) in p0["kp_rows"]])))
 
 
-def time_config(torch, stream, dev, p, steps, warmup, fused, generic, world=1, dist=None, kp_ordered=True):
-    """Times `steps` iterations of problem p on the engine; returns timings and the live engine."""
+def time_config(torch, stream, dev, p, steps, warmup, fused, generic, world=1, dist=None, kp_ordered=True, rx_const=True):
+    """Times `steps` iterations of problem p on the engine; returns timings and the live engine.  rx_const: a task whose residual
+    Jacobian is ONE constant matrix (reaching: p["rx_const"]) uploads it once (kpilqr_upload_residual_jacobians_const) instead
+    of a copy per step -- what a host with analytic residuals does; False streams the per-step copies."""
     from trajoptkp_amd import Engine, synth
     from trajoptkp_amd import distributed as kd
     B, T = p["batch"], p["T"]
@@ -261,7 +290,8 @@ def time_config(torch, stream, dev, p, steps, warmup, fused, generic, world=1, d
     # Fused sweeps: the FD payload is resident KEY-POINT ORDERED (kpilqr_upload_fd_kp); beyond 256 trajectories the backward pass
     # differences x+ / x- itself at every segment crossing, on every timed step, and there is no differencing stage; below, and on
     # materialising / tiled contexts (job lists), kpilqr_fd_difference is a stage of every timed step.
-    synth.upload(eng, p, kp_ordered=is_fused and kp_ordered)
+    rxc = bool(rx_const and p.get("rx_const") is not None)
+    synth.upload(eng, p, kp_ordered=is_fused and kp_ordered, rx_const=rxc)
     lam = np.full(B, p["lam"])
     alphas = np.array([(i / 6.0) ** 2 for i in range(1, 7)])
     # raw: the library's own choice for a key-point ordered payload on a fused context beyond #SIMDs / 4 trajectories -- the backward
@@ -314,13 +344,14 @@ def time_config(torch, stream, dev, p, steps, warmup, fused, generic, world=1, d
         elapsed = float(tt.item())
     stage_ms = {name: float(np.mean([evs[s][i][0].elapsed_time(evs[s][i][1]) for s in range(steps)])) for i, name in enumerate(stages)}
     return dict(eng=eng, elapsed=elapsed, stage_ms=stage_ms, stages=stages, fused=is_fused, raw=raw, kp_ordered=is_fused and kp_ordered,
-                variants={"backward": eng.backward_variant, "forward": eng.forward_variant})
+                rx_const=rxc, variants={"backward": eng.backward_variant, "forward": eng.forward_variant},
+                launched={"backward": eng.last_launch("backward"), "forward": eng.last_launch("forward")})
 
 
 LAMBDAS = (1e-4, 1e-3, 1e-2, 0.1, 1.0, 10.0)        # the reference's range [min_lambda, max_lambda] (Optimiser.h:239-242)
 
 
-def lambda_sweep(torch, stream, dev, p, fused, steps=5):
+def lambda_sweep(torch, stream, dev, p, fused, steps=5, rx_const=True):
     """The two sweeps of the headline batch at every regularisation of the reference's schedule and on a MIXED batch
     (trajectory b at LAMBDAS[b % 6]): the running inverse's refresh count, the LDL' re-seeds and the pivoted slow path are
     data-dependent and a launch lasts as long as its slowest wave.  Reports stage times, the number of valid backward
@@ -328,7 +359,7 @@ def lambda_sweep(torch, stream, dev, p, fused, steps=5):
     from trajoptkp_amd import Engine, synth
     B = p["batch"]
     eng = Engine(p["dof"], p["m"], p["T"], p["nr"], batch=B, device=dev, stream=stream.cuda_stream, fused=fused)
-    synth.upload(eng, p, kp_ordered="fused" in eng.backward_variant)
+    synth.upload(eng, p, kp_ordered="fused" in eng.backward_variant, rx_const=rx_const)
     alphas = np.array([(i / 6.0) ** 2 for i in range(1, 7)])
     if "fused" not in eng.backward_variant:
         eng.fd_difference()
@@ -377,14 +408,16 @@ def roofline_of(p, p0, r, pmc=None):
     # A, B: key-point columns (the raw sweep reads x+ and x- and writes the differenced column: 3x) or every step
     kb += (3 * cols + pairs[0] if r.get("raw") else cols) if a4 else 8 * T * (n * n + n * m)
     ru0 = r["fused"] and not np.any(p0["r_u"])            # r_u never uploaded: the fused backward sweep does not read it
-    kb += 8 * T * nr * (1 + n + (0 if ru0 else m)) if a6 else 8 * T * (n * n + n + m * m + m)   # residuals + Jacobians or l_*
+    rxc = ":rxc" in r.get("launched", {}).get("backward", "")      # the constant Jacobian sits in registers: no r_x traffic
+    kb += 8 * T * nr * (1 + (0 if rxc else n) + (0 if ru0 else m)) if a6 else 8 * T * (n * n + n + m * m + m)   # residuals + Jacobians or l_*
     flops = flops_a7(n, m) * T * B
     ach_tf = flops / t_bwd / 1e12
     traffic = None
+    rxc_pmc = ":rxc" in r.get("launched", {}).get("backward", "")
     if pmc is not None:
         try:
             wl = pmc["workload"]
-            if wl["task"] == p["task"] and wl["T"] == T and wl["batch"] == B:
+            if wl["task"] == p["task"] and wl["T"] == T and wl["batch"] == B and bool(wl.get("rx_const", False)) == rxc_pmc:
                 traffic = pmc["kernels"]["backward_fused" if r["fused"] else "backward"]["traffic_bytes"]
         except Exception:
             traffic = None
@@ -396,7 +429,7 @@ def roofline_of(p, p0, r, pmc=None):
     if traffic is not None:
         hbm["traffic_GBps"] = traffic / t_bwd / 1e9
         hbm["traffic_frac_of_hbm_peak"] = traffic / t_bwd / 1e9 / HBM_PEAK_GBS
-    return {"bound": "mfma", "kernel": f"backward ({r['variants']['backward']})", "achieved": ach_tf, "peak": FP64_PEAK_TFLOPS,
+    return {"bound": "mfma", "kernel": f"backward ({r.get('launched', r['variants'])['backward']})", "achieved": ach_tf, "peak": FP64_PEAK_TFLOPS,
             "unit": "TFLOP/s", "frac": ach_tf / FP64_PEAK_TFLOPS, "traffic": traffic,
             "traffic_source": (None if traffic is None else f"profiles/{pmc.get('_file', '?')}: separate rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE "
                                "passes of this command (tools/collect_profiles.sh), NOT measured in this run"),
@@ -435,7 +468,7 @@ def pcie_inclusive(batch, steps=4):
     sys.path.insert(0, os.path.join(ROOT, "tools"))
     import pcie_inclusive as pi
     m = pi.measure(batch, steps, chunk_list=(3,), quiet=True)
-    pick = lambda payload, form: next(r for r in m["rows"] if r["payload"] == payload and r["form"].startswith(form))
+    pick = lambda payload, form: next(r for r in m["rows"] if (r["payload"] == payload or r["payload"].startswith(payload + " (")) and r["form"].startswith(form))
     out = {"batch": m["batch"], "unit": "trajectory-iterations/s", "resident_value": m["resident_traj_it_per_s"],
            "note": "H2D of the FD payload + residuals (+ Jacobians) and D2H of K,k every iteration, pinned host memory; "
                    "kpilqr_iterate_streamed over 3 trajectory chunks (SDMA uploads | kernels | kernel downloads overlapped); "
@@ -451,6 +484,15 @@ def pcie_inclusive(batch, steps=4):
         a = pick(payload, "chunks=3 pipelined")
         out[key] = {"value": a["traj_it_per_s"], "ms_per_iteration": a["ms_per_iteration"], "h2d_GB": a["h2d_GB"], "d2h_GB": a["d2h_GB"],
                     "link_GBps": a["link_GBps"]}
+    # round 4: ONE constant residual Jacobian uploaded once (kpilqr_upload_residual_jacobians_const) -- the full per-iteration
+    # payload of a task with analytic residuals is then the FD payload (or the host-differenced columns) + the residuals
+    for key, payload in (("full_payload_constant_jacobians", "constant Jacobians"), ("full_payload_constant_jacobians_host_differenced_columns", "columns + constant Jacobians")):
+        try:
+            a = pick(payload, "chunks=3 pipelined")
+            out[key] = {"value": a["traj_it_per_s"], "ms_per_iteration": a["ms_per_iteration"], "h2d_GB": a["h2d_GB"], "d2h_GB": a["d2h_GB"],
+                        "link_GBps": a["link_GBps"]}
+        except StopIteration:
+            pass
     return out
 
 
@@ -491,7 +533,7 @@ def main():
     ap.add_argument("--T", type=int, default=3000)
     ap.add_argument("--min-N", type=int, default=5)
     ap.add_argument("--task", default="panda_reaching")
-    ap.add_argument("--keypoints", default="set_interval", choices=["set_interval", "adaptive_jerk", "iterative_error"])
+    ap.add_argument("--keypoints", default="set_interval", choices=["set_interval", "adaptive_jerk", "iterative_error", "reach_velocity_change", "reach_adaptive_jerk"])
     ap.add_argument("--generic", action="store_true", help="force the generic (VALU/LDS, non-MFMA) kernels")
     ap.add_argument("--unfused", action="store_true", help="materialise A,B (interpolate) and l_* (cost_derivs) with their own kernels")
     ap.add_argument("--no-secondary", action="store_true", help="skip every side measurement (materialising pipeline, pcie_inclusive, secondary configs, weak line)")
@@ -499,6 +541,9 @@ def main():
     ap.add_argument("--pcie-batch", type=int, default=256)
     ap.add_argument("--workload-cache", default=None, help="directory for the generated workload (.npy, memory-mapped by later runs: profiler passes)")
     ap.add_argument("--tiled-seeds", action="store_true", help="8 distinct seeds tiled to the batch (round-1/2 workload) instead of one seed per trajectory")
+    ap.add_argument("--streamed-jacobians", action="store_true",
+                    help="upload the residual Jacobians per step (T+1 copies per trajectory) even when the task has ONE constant matrix "
+                         "(reaching): the round-1..3 form; default since round 4 is kpilqr_upload_residual_jacobians_const")
     args = ap.parse_args()
 
     if "WORLD_SIZE" not in os.environ and args.gpus > 1:
@@ -551,7 +596,8 @@ def main():
     torch.cuda.set_stream(stream)
     fused = not args.unfused and not args.generic
 
-    r = time_config(torch, stream, local_rank, p, args.steps, args.warmup, fused, args.generic, world, dist)
+    rx_const = not args.streamed_jacobians
+    r = time_config(torch, stream, local_rank, p, args.steps, args.warmup, fused, args.generic, world, dist, rx_const=rx_const)
     eng = r["eng"]
     res = eng.results()
     n_ok = int((res["status"] == 0).sum())
@@ -563,7 +609,7 @@ def main():
     weak_line = None
     if pw is not None:
         # the same job with 1024 trajectories PER GPU, for the weak-scaling curve beside the strong one
-        rw = time_config(torch, stream, local_rank, pw, max(3, args.steps // 2), 2, fused, args.generic, world, dist)
+        rw = time_config(torch, stream, local_rank, pw, max(3, args.steps // 2), 2, fused, args.generic, world, dist, rx_const=rx_const)
         rw["eng"].close()
         weak_line = {"batch_per_gpu": args.global_batch, "global_batch": args.global_batch * world, "steps": max(3, args.steps // 2),
                      "value": args.global_batch * world * max(3, args.steps // 2) / rw["elapsed"], "unit": "trajectory-iterations/s",
@@ -572,15 +618,22 @@ def main():
     if rank == 0:
         value = global_batch * args.steps / r["elapsed"]
         pmc = None
-        for name in ("r03_pmc_traffic.json", "r02_pmc_traffic.json", "r01_pmc_traffic.json"):
+        for name in ("r04_pmc_traffic.json", "r03_pmc_traffic.json", "r02_pmc_traffic.json", "r01_pmc_traffic.json"):
             try:
                 pmc = json.load(open(os.path.join(ROOT, "profiles", name)))
                 pmc["_file"] = name
                 break
             except Exception:
                 pmc = None
+        pmc3 = None           # the streamed-Jacobian form: PMC passes of round 3 (or a round-4 pass with --streamed-jacobians)
+        for name in ("r04_pmc_traffic_per_step_jacobians.json", "r03_pmc_traffic.json"):
+            try:
+                pmc3 = json.load(open(os.path.join(ROOT, "profiles", name))); pmc3["_file"] = name
+                break
+            except Exception:
+                pmc3 = None
         ab = algorithmic_bytes(p["dof"], p["m"], p["nr"], T, float(np.mean([np.count_nonzero(np.diff(o)) for (o, _) in p0["kp_rows"]])), 6)
-        roof = roofline_of(p, p0, r, pmc if not args.generic else None)
+        roof = roofline_of(p, p0, r, (pmc if r.get("rx_const") else pmc3) if not args.generic else None)
         out = {
             "metric": "iLQR iterations/sec (Panda 7-DoF, T=3000)" if args.task == "panda_reaching" and T == 3000
                       else f"iLQR iterations/sec ({args.task}, T={T})",
@@ -590,9 +643,12 @@ def main():
             "config": {"workload": f"{desc} per rank, global batch {global_batch} sharded over {world} GPU(s) ({B_local} on rank 0), "
                                    f"6 alphas, lambda={p['lam']}"
                                    + (", fused sweeps (a4+a6 inside a7/a8)" if r["fused"] else "")
+                                   + (", ONE constant residual Jacobian uploaded once (the task's r_x: Reaching.cpp:43-54) and kept in registers by the sweeps" if r.get("rx_const") and ":rxc" in r["launched"]["backward"]
+                                      else ", constant residual Jacobian uploaded once, read by the sweeps from its broadcast copy" if r.get("rx_const") else ", residual Jacobians streamed per step")
                                    + (", key-point ordered FD payload differenced inside the backward sweep (no fd_difference stage)" if r.get("raw") else
                                       ", key-point ordered FD payload" if r.get("kp_ordered") else ""),
-                       "batch_per_gpu": B_local, "global_batch": global_batch, "horizon": T, "kernels": r["variants"],
+                       "batch_per_gpu": B_local, "global_batch": global_batch, "horizon": T, "kernels": r["variants"], "launched": r["launched"],
+                       "residual_jacobians": "constant" if r.get("rx_const") else "per_step",
                        "valid_backward_passes_rank0": n_ok, "parallelism": f"traj-shard x{world}",
                        "workload_generation_s": t_gen},
             "rccl_ranks": (dist.get_world_size() if (world > 1 and dist.get_backend() == "nccl") else (1 if world == 1 else 0)),
@@ -613,7 +669,7 @@ def main():
         try:
             if r["fused"] and args.task == "panda_reaching" and not args.generic:
                 cnt = None
-                for name in ("r03_pmc_counters.json", "r02_pmc_counters.json", "r01_pmc_counters.json"):
+                for name in ("r04_pmc_counters.json", "r03_pmc_counters.json", "r02_pmc_counters.json", "r01_pmc_counters.json"):
                     try:
                         cnt = json.load(open(os.path.join(ROOT, "profiles", name)))["derived"]["backward_fused"]; break
                     except Exception:
@@ -637,10 +693,22 @@ def main():
                                                  "ms_per_step": 1e3 * r2["elapsed"] / k2, "kernels": r2["variants"], "stage_ms": r2["stage_ms"],
                                                  "stage_algorithmic_GBps": {k: ab[k] * B_local / (r2["stage_ms"][k] * 1e-3) / 1e9 for k in r2["stages"]},
                                                  "roofline": roofline_of(p, p0, r2)}
+            # ---- the same iteration with the residual Jacobians given per step (rounds 1-3; what a task with state-dependent
+            # residual Jacobians pays) ------------------------------------------------------------------------------------------
+            if r.get("rx_const"):
+                try:
+                    k3 = max(3, min(args.steps, 10))
+                    r3 = time_config(torch, stream, local_rank, p, k3, 2, fused, args.generic, rx_const=False)
+                    r3["eng"].close()
+                    out["per_step_residual_jacobians"] = {"value": B_local * k3 / r3["elapsed"], "unit": "trajectory-iterations/s", "steps": k3,
+                                                          "ms_per_step": 1e3 * r3["elapsed"] / k3, "stage_ms": r3["stage_ms"], "launched": r3["launched"],
+                                                          "roofline": roofline_of(p, p0, r3, pmc3)}
+                except Exception as ex:
+                    out["per_step_residual_jacobians"] = {"error": repr(ex)}
             # ---- the regularisation range and a mixed batch ------------------------------------------------------------
             if args.task == "panda_reaching" and not args.generic:
                 try:
-                    out["lambda_sweep"] = lambda_sweep(torch, stream, local_rank, p, fused)
+                    out["lambda_sweep"] = lambda_sweep(torch, stream, local_rank, p, fused, rx_const=rx_const)
                     if r.get("raw"):
                         # the kernel as launched also differences the FD payload (a2); the same sweep on a column store that
                         # is already differenced (what the lambda sweep times) is the a7 kernel proper
@@ -668,6 +736,9 @@ def main():
                 # on which the running inverse of Q_uu never applies -- and with Jacobians of the reference's structure, smooth in time)
                 for key, (kind, task, Ts, Bs, ks, rm) in {
                         "configs[1] panda_reaching T=3000 batch=1": ("set_interval", "panda_reaching", 3000, 1, 10, None),
+                        # the headline shape with the reference's OWN key-point method for reaching (reaching.yaml:6-8): per-DoF lists
+                        "panda_reaching T=3000 velocity_change(1,50) batch=1024 (reaching.yaml's key-point method)": ("reach_velocity_change", "panda_reaching", 3000, 1024, 8, None),
+                        "panda_reaching T=3000 adaptive_jerk(1,50) batch=1024": ("reach_adaptive_jerk", "panda_reaching", 3000, 1024, 8, None),
                         "configs[2] panda_pushing T=3000 adaptive_jerk batch=64": ("adaptive_jerk", "panda_pushing", 3000, 64, 5, True),
                         "configs[2] panda_pushing T=3000 adaptive_jerk batch=64, smooth residual Jacobians": ("adaptive_jerk", "panda_pushing", 3000, 64, 5, "smooth"),
                         "configs[4] high_dof_push n=62 T=5000 iterative_error batch=128 (one GPU's share of 1024)": ("iterative_error", "high_dof_push", 5000, 128, 3, True),
@@ -681,7 +752,7 @@ def main():
                         pc = parity_check(ps0, rs["eng"], min(ps0["batch"], 2), tiled=kind != "set_interval")
                         rs["eng"].close()
                         sec[key] = {"workload": ds + f", batch={Bs}", "value": Bs * ks / rs["elapsed"], "unit": "trajectory-iterations/s",
-                                    "steps": ks, "ms_per_step": 1e3 * rs["elapsed"] / ks, "kernels": rs["variants"], "stage_ms": rs["stage_ms"],
+                                    "steps": ks, "ms_per_step": 1e3 * rs["elapsed"] / ks, "kernels": rs["variants"], "launched": rs["launched"], "stage_ms": rs["stage_ms"],
                                     "keypoint_pairs_per_trajectory": kp_pairs(ps0)[0], "roofline": roofline_of(ps, ps0, rs),
                                     "parity_check": {k: pc[k] for k in ("max_rel_err_K", "max_rel_err_cost_pred", "pass")}}
                         del ps, ps0, rs

@@ -31,7 +31,7 @@
 extern "C" {
 #endif
 
-#define KPILQR_VERSION 301   /* 0.3.1 */
+#define KPILQR_VERSION 400   /* 0.4.0 */
 
 typedef struct kpilqr_ctx kpilqr_ctx;
 
@@ -101,7 +101,9 @@ int  kpilqr_get_dims(kpilqr_ctx *ctx, kpilqr_dims *out);
  * sizes do not fit; kernel families are re-selected; everything uploaded before is forgotten.  Synchronous. */
 int  kpilqr_resize(kpilqr_ctx *ctx, int new_dof, int new_num_ctrl, int new_horizon);
 
-/* Pinned host staging memory (the "one pinned hipMemcpyAsync" of the design). */
+/* Pinned host staging memory (the "one pinned hipMemcpyAsync" of the design).  kpilqr_host_free accepts ctx = NULL: an
+ * allocation may be released after the context it was made through has been destroyed (bindings whose arrays outlive the
+ * engine object); it must not be in use by a transfer still in flight. */
 int  kpilqr_host_alloc(kpilqr_ctx *ctx, size_t bytes, void **pinned);
 int  kpilqr_host_free(kpilqr_ctx *ctx, void *pinned);
 
@@ -257,6 +259,17 @@ int  kpilqr_filter_dynamics(kpilqr_ctx *ctx, const char *method, const double *c
  * products out (l_uu = l_u = 0 exactly). */
 int  kpilqr_upload_residuals(kpilqr_ctx *ctx, const double *r, const double *r_x, const double *r_u,
                              const double *w_run, const double *w_term);
+/* CONSTANT residual Jacobians: one r_x [nr][n] (and one r_u [nr][m], or NULL for r_u = 0) that holds at every step of every
+ * trajectory -- a task whose residuals are affine in the state and free of the controls, e.g. reaching: r = [q - q*, qdot],
+ * r_x = selector rows, r_u = 0 (src/ModelTranslator/Reaching.cpp:43-54; the host then skips
+ * Differentiator::ResidualDerivatives, src/Differentiator/Differentiator.cpp:464-663, altogether).  Uploaded ONCE per
+ * context instead of T+1 copies per trajectory and iteration; on a KPILQR_FLAG_FUSED context with one wavefront per
+ * trajectory (batch > #SIMDs / 4) and r_u = NULL the sweeps keep the matrix in registers and read no r_x from memory at all
+ * (Panda reaching, T = 3000: 5.0 of the 8.1 MB a trajectory's backward sweep reads, 5.0 of 9.1 MB forward).  Every other
+ * kernel family sees the same values through a broadcast copy made on demand; K, k, delta_J and the predicted costs are bit
+ * for bit those of the same matrix given per step through kpilqr_upload_residuals, which (with r_x != NULL) also ends the
+ * constant mode.  version >= 400. */
+int  kpilqr_upload_residual_jacobians_const(kpilqr_ctx *ctx, const double *r_x, const double *r_u);
 /* ModelTranslator::CostDerivativesFromResiduals (src/ModelTranslator/ModelTranslator.cpp:552-583)
  * over the loop of Optimiser::ComputeCostDerivatives (src/Optimiser/Optimiser.cpp:202-211),
  * including the terminal-weight re-write of t = T-1. */
@@ -269,7 +282,10 @@ int  kpilqr_trajectory_cost(kpilqr_ctx *ctx, double *cost /*[batch]*/);
  * iLQR::BackwardsPassQuuRegularisation + CheckMatrixPD (src/Optimiser/iLQR.cpp:535-670).
  * lambda [batch]; pd_check_stride = 100 in the reference.  status[b] = 0 ok, t+1 = first step
  * whose Q_uu + lambda I failed the Cholesky test; delta_J [batch].  status / delta_J may be NULL
- * (results stay on the device, KPILQR_BUF_STATUS / KPILQR_BUF_DELTA_J). */
+ * (results stay on the device, KPILQR_BUF_STATUS / KPILQR_BUF_DELTA_J).  A trajectory with status != 0 has stopped at that
+ * step (the reference returns false there and retries at a larger lambda, iLQR.cpp:435-442): its gains below that step, its
+ * delta_J and the outputs of a kpilqr_forward_linear that follows are UNDEFINED for that trajectory until a backward pass
+ * succeeds (on a fused context its key-point columns may be differenced only down to that step). */
 int  kpilqr_backward(kpilqr_ctx *ctx, const double *lambda, int pd_check_stride,
                      int *status, double *delta_J);
 /* Diagnostic: the backward pass of a KPILQR_FLAG_FUSED context with counters.  The explicit inverse the reference forms at
@@ -324,6 +340,19 @@ int  kpilqr_get_cost_derivs(kpilqr_ctx *ctx, double *l_x, double *l_xx, double *
  * ("mfma_f64_t1", "generic_lds", ...): for logs, tests and the bench's roofline line. */
 const char *kpilqr_backward_variant(kpilqr_ctx *ctx);
 const char *kpilqr_forward_variant(kpilqr_ctx *ctx);
+/* What the LAST backward (which = 0) / forward (which = 1) launch of this context was -- the variant above and, for the
+ * KPILQR_FLAG_FUSED sweeps, the form the library picked from the batch size, the payload and the key-point lists:
+ *     "<variant>:<waves>:<columns>:<lists>[:ru0][:rxc][:slopes]"          e.g. "mfma_f64_t1_fused:w1:raw:uni:ru0"
+ *   waves    w1 one wavefront per trajectory | w2 control / state split | pair | triple
+ *   columns  (backward only) raw: the sweep differenced the key-point ordered FD payload itself | kpc: it read the differenced
+ *            key-point column store
+ *   lists    uni: every DoF of a trajectory has the same key-point list (set_interval ...) | ragged: per-DoF lists
+ *   ru0      no control residuals (r_u never uploaded): the products with r_u are left out
+ *   rxc      constant residual Jacobians kept in registers (kpilqr_upload_residual_jacobians_const)
+ *   slopes   per-DoF lists walked on precomputed segment slopes (a crossing is loads only)
+ * The `lists` token is decided on the device; this call reads the flag back and therefore WAITS for the context's stream.
+ * For logs and tests (a test can assert which kernel form it exercised).  version >= 400. */
+const char *kpilqr_last_launch(kpilqr_ctx *ctx, int which);
 
 #ifdef __cplusplus
 }

@@ -40,7 +40,16 @@ def test_header_compiles_as_plain_c(tmp_path):
 
 
 def test_version():
-    assert trajoptkp_amd.load().kpilqr_version() == 301
+    assert trajoptkp_amd.load().kpilqr_version() == 400
+
+
+def test_null_context_calls_are_harmless():
+    """kpilqr_host_free(NULL, NULL) (bindings release pinned blocks after the context is gone) and the name queries on a NULL
+    context return without touching a device."""
+    L = trajoptkp_amd.load()
+    assert L.kpilqr_host_free(None, None) == 0
+    assert L.kpilqr_last_launch(None, 0) == b"" and L.kpilqr_backward_variant(None) == b""
+    assert L.kpilqr_upload_residual_jacobians_const(None, None, None) == _lib.ERR_ARG
 
 
 def _no_gpu():

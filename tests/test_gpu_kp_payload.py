@@ -261,3 +261,89 @@ def test_host_differenced_columns_give_the_bytes_of_the_fd_payload(fused, waves)
             e.iterate_streamed(kp_cols=cols, lam=lam, K=Kp, k=kp_, cost_pred=cp, delta_J=jp, nchunks=2)
             e.sync()
             _same(dict(K=np.array(Kp), k=np.array(kp_), delta_J=np.array(jp), cost=np.array(cp)), ref)
+
+
+# ---- constant residual Jacobians (round 4): kpilqr_upload_residual_jacobians_const ------------------------------------------
+@pytest.mark.parametrize("task,T,batch,kw", [("panda_reaching", 260, 3, dict(min_N=5)),
+                                             ("panda_reaching", 131, 2, dict(min_N=1, one_sided_frac=0.2)),
+                                             ("acrobot", 100, 2, dict(config_id=1, min_N=5)),
+                                             ("hopper", 150, 2, dict(min_N=4)), ("pentabot", 64, 3, dict(min_N=3))])
+def test_constant_residual_jacobians_give_the_bytes_of_the_streamed_form(task, T, batch, kw, waves):
+    """One r_x [nr][n] uploaded once (Reaching.cpp:43-54: r = [q - q*, qdot] -> selector rows, r_u = 0) == the same matrix given
+    at every step: K, k, delta_J, predicted costs bit for bit, in every wave organisation (the one-wave sweeps keep the matrix
+    in registers and read no r_x; the others read its broadcast copy), for either payload form -- and against the oracle."""
+    p = synth.make_problem(task=task, T=T, batch=batch, **kw)
+    assert p["rx_const"] is not None and not np.any(p["r_u"])
+    for kp_ordered in (True, False):
+        ref = _run(p, True, kp_ordered)
+        with Engine(p["dof"], p["m"], p["T"], p["nr"], batch=batch, fused=True) as e:
+            synth.upload(e, p, kp_ordered=kp_ordered, rx_const=True)
+            e.iterate(p["lam"], 100, orc.alphas(6))
+            res = e.results()
+            K, k = e.gains()
+            got = dict(K=K, k=k, status=res["status"], delta_J=res["delta_J"], cost=res["cost_pred"])
+            lb, lf = e.last_launch("backward"), e.last_launch("forward")
+            _same(got, ref)
+            if waves == "one_wave":
+                assert ":w1:" in lb and ":rxc" in lb and ":w1:" in lf and ":rxc" in lf, (lb, lf)
+                assert (":raw:" in lb) == kp_ordered
+            else:
+                assert ":rxc" not in lb, lb
+            # the materialised cost derivatives see the same Jacobians (broadcast copy on demand)
+            e.cost_derivs(); lx_c = e.get_cost_derivs()
+        with Engine(p["dof"], p["m"], p["T"], p["nr"], batch=batch, fused=True) as e:
+            synth.upload(e, p, kp_ordered=kp_ordered)
+            e.fd_difference(); e.cost_derivs(); lx_s = e.get_cost_derivs()
+        for u, v in zip(lx_c, lx_s):
+            assert np.array_equal(u, v)
+    for b in range(batch):
+        o = pipeline.run_trajectory(p, b)
+        assert relerr(ref["K"][b], o["K"]) < 1e-9 and relerr(ref["cost"][b], o["cost_pred"]) < 1e-9
+
+
+def test_constant_residual_jacobians_mode_switches():
+    """Per-step Jacobians uploaded afterwards end the constant mode; a dense constant r_u, a materialising context and the
+    chunk pipeline all see the broadcast values; kpilqr_device_ptr(R_X) hands out the broadcast copy."""
+    import torch
+    p = synth.make_problem(task="panda_reaching", T=120, batch=4, min_N=5)
+    rng = np.random.default_rng(5)
+    rxc = rng.standard_normal((p["nr"], p["n"])) * 0.3
+    ruc = rng.standard_normal((p["nr"], p["m"])) * 0.05
+    q = dict(p); q["r_x"] = np.broadcast_to(rxc, p["r_x"].shape).copy(); q["r_u"] = np.broadcast_to(ruc, p["r_u"].shape).copy()
+    for fused in (True, False):
+        ref = _run(q, fused, False)
+        with Engine(p["dof"], p["m"], p["T"], p["nr"], batch=4, fused=fused) as e:
+            synth.upload(e, p, kp_ordered=False)                     # selector rows first ...
+            e.upload_residual_jacobians_const(rxc, ruc)              # ... then the dense constants
+            e.iterate(p["lam"], 100, orc.alphas(6))
+            res = e.results(); K, k = e.gains()
+            _same(dict(K=K, k=k, delta_J=res["delta_J"], cost=res["cost_pred"]), ref)
+            assert ":rxc" not in e.last_launch("backward")           # dense r_u: the streamed instantiations on the broadcast copy
+            dev = torch.as_tensor(e.device_array(4, (4, p["T"] + 1, p["nr"], p["n"])), device="cuda").cpu().numpy()
+            assert np.array_equal(dev, q["r_x"])
+            # per-step Jacobians again: the constant mode is over
+            e.upload_residuals(None, p["r_x"], np.zeros_like(p["r_u"]), None, None)
+            e.iterate(p["lam"], 100, orc.alphas(6))
+            K2, _ = e.gains()
+        back = _run(dict(p, r_u=np.zeros_like(p["r_u"])), fused, False)
+        assert np.array_equal(K2, back["K"])
+    # chunk pipeline, constants resident (SURVEY a5: "the shim may upload constants once")
+    ref = _run(p, True, True)
+    xp, xm, mode = synth.kp_ordered_payload(p)
+    with Engine(p["dof"], p["m"], p["T"], p["nr"], batch=4, fused=True) as e:
+        e.set_keypoints_rows(p["kp_rows"])
+        e.upload_residuals(None, None, None, p["w_run"], p["w_term"])
+        e.upload_residual_jacobians_const(p["rx_const"], None)
+        e.upload_nominal(None, p["ctrl_lim"])
+        e.forward_linear(orc.alphas(6), fetch=False)
+        s = e.fd_kp_slab(xp, xm, mode)
+        pin = {}
+        for name in ("r", "u_nom"):
+            pin[name] = e.pinned(p[name].shape); pin[name][...] = p[name]
+        lam = e.pinned(4); lam[:] = p["lam"]
+        K = e.pinned(ref["K"].shape); k = e.pinned(ref["k"].shape); cp = e.pinned((4, 6)); st = e.pinned(4, np.int32)
+        e.iterate_streamed(fd_kp=s, eps=p["eps"], lam=lam, K=K, k=k, cost_pred=cp, status=st, nchunks=2, **pin)
+        e.sync()
+        assert np.array_equal(K, ref["K"]) and np.array_equal(cp, ref["cost"])
+    # the arrays above are views of pinned allocations: they outlive the engine (Engine.pinned keeps the block alive)
+    assert np.array_equal(K, ref["K"]) and int(st.sum()) == 0

@@ -196,6 +196,28 @@ def test_batched_optimiser_matches_single_trajectory_runs():
         assert res["stats"][7] >= 1.0 and np.all(np.isfinite(res["stats"]))
 
 
+@pytest.mark.gpu
+@pytest.mark.parametrize("method,min_N", [("adaptive_jerk", 2), ("velocity_change", 1), ("adaptive_accel", 3)])
+def test_batched_optimiser_partial_regeneration_with_moving_keypoint_counts(method, min_N):
+    """Fused batch context, adaptive key-point methods: every trajectory has its own per-DoF lists whose counts change with
+    every linearisation, and a trajectory whose step was rejected does NOT regenerate (iLQR.cpp:419) while the others do --
+    its entries then sit at shifted offsets of the batch CSR.  The batch must still follow, trajectory by trajectory, the
+    single-trajectory runs (round-3 advisor finding: the non-regenerating trajectories ran on stale / zero columns)."""
+    q0s = np.array([[3.1415, 0.3], [2.6, -0.4], [3.5, 0.1], [1.2, 0.8], [0.4, -1.1], [2.9, 0.9]])
+    for fused in (True, False):
+        res = host.run_acrobot_batch(q0s, T=120, min_N=min_N, max_iter=9, min_iter=2, torque_weight=1e-3, fused=fused, method=method)
+        rejected = 0
+        for b, q0 in enumerate(q0s):
+            single = host.run_acrobot(T=120, min_N=min_N, max_iter=9, min_iter=2, torque_weight=1e-3,
+                                      method=f"{method}+{'fused' if fused else 'unfused'}+q0={q0[0]},{q0[1]}")
+            assert res["iterations"][b] == single["iterations"], (method, fused, b, res["iterations"], single["iterations"])
+            assert np.allclose(res["cost_history"][b], single["cost_history"], rtol=1e-9), (method, fused, b)
+            assert np.allclose(res["U"][b], single["U"], rtol=1e-7, atol=1e-9)
+            h = res["cost_history"][b]
+            rejected += int(np.count_nonzero(np.diff(h)[:-1] == 0.0))      # a rejected step that was followed by another iteration
+        print(f"{method} fused={fused}: iterations {list(res['iterations'])}, rejected-then-continued steps {rejected}")
+
+
 # ---- a1 / a5: the host finite differences against the numpy restatement of the reference's loops ------------------------
 def _fd_states(model, rng, k):
     out = []

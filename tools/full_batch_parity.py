@@ -1,61 +1,123 @@
-"""Every trajectory of the headline workload against the CPU oracle (GPU box): python tools/full_batch_parity.py [B] [T]
+"""The headline dispatch against the CPU oracle, at the batch sizes where each kernel form is the library's DEFAULT (GPU box):
 
-bench.py's parity_check looks at the first 8 of the 1024 distinct seeds; this looks at all of them.  The oracle results are
-computed first, by forked workers, one seed at a time (synth.make_problem(first_b=b) is the same trajectory as row b of the
-batch), into shared arrays; only then is the GPU touched."""
-import os, sys, time
+    python tools/full_batch_parity.py [B] [T] [--sample N]
+
+bench.py's parity_check looks at the first 8 of the 1024 distinct seeds; this looks at all of them (or at N of them spread
+evenly over the batch).  The oracle rows are computed first, by forked workers, one seed at a time
+(synth.make_problem(first_b=b) is the same trajectory as row b of the batch), into shared arrays; only then is the GPU touched.
+
+Legs, all in the default environment except for the one switch named: the form each leg ran is read back from the library
+(kpilqr_last_launch) and ASSERTED, so two legs can never silently be the same code path.
+  B > 512         A  w1:raw:uni (one wave per trajectory, the payload differenced inside the backward sweep: the bench's kernel)
+                  B  KPILQR_FUSED_RAW=0 -> w1:kpc:uni (k_fd_kp_difference first)          bit-identical to A
+                  C  constant residual Jacobians -> w1:raw:uni:ru0:rxc                     bit-identical to A
+  256 < B <= 512  A  pair:raw:uni (the producer wave differences) | B  KPILQR_FUSED_RAW=0 -> pair:kpc:uni, bit-identical to A
+                  C  constant Jacobians (the pair streams their broadcast copy)            bit-identical to A
+  B <= 256        A  triple:kpc:uni (the triple never differences itself)
+                  B  KPILQR_FUSED_WAVES=1 + KPILQR_FUSED_FWD_WAVES=1 -> w1:raw:uni         another kernel: 1e-9 to the oracle
+Every leg: K, k, delta_J, predicted costs of the sampled trajectories within 1e-9 of the oracle, statuses equal."""
+import argparse
+import json
+import os
+import sys
+import time
 import multiprocessing as mp
+
 import numpy as np
+
 sys.path.insert(0, ".")
 import bench
 from trajoptkp_amd import synth
 
-B = int(sys.argv[1]) if len(sys.argv) > 1 else 1024
-T = int(sys.argv[2]) if len(sys.argv) > 2 else 3000
+ap = argparse.ArgumentParser()
+ap.add_argument("B", nargs="?", type=int, default=1024)
+ap.add_argument("T", nargs="?", type=int, default=3000)
+ap.add_argument("--sample", type=int, default=0, help="check this many trajectories spread over the batch (0: all)")
+args = ap.parse_args()
+B, T = args.B, args.T
 TASK, MIN_N = "panda_reaching", 5
 probe = synth.make_problem(task=TASK, T=T, batch=1, min_N=MIN_N)
 n, m = probe["n"], probe["m"]
-oK = bench._shared((B, T, n * m)); ok = bench._shared((B, T, m)); oC = bench._shared((B, 6)); oJ = bench._shared((B,))
-oS = bench._shared((B,), np.int32)
+rows = np.arange(B) if args.sample <= 0 or args.sample >= B else np.unique(np.linspace(0, B - 1, args.sample).round().astype(int))
+S = len(rows)
+oK = bench._shared((S, T, n * m)); ok = bench._shared((S, T, m)); oC = bench._shared((S, 6)); oJ = bench._shared((S,))
+oS = bench._shared((S,), np.int32)
 
 
-def work(b):
+def work(i):
     from oracle import pipeline
-    q = synth.make_problem(task=TASK, T=T, batch=1, min_N=MIN_N, first_b=b)
+    q = synth.make_problem(task=TASK, T=T, batch=1, min_N=MIN_N, first_b=int(rows[i]))
     o = pipeline.run_trajectory(q, 0)
-    oK[b] = o["K"].reshape(T, -1); ok[b] = o["k"].reshape(T, -1); oC[b] = o["cost_pred"]; oJ[b] = o["delta_J"]; oS[b] = o["status"]
-    return b
+    oK[i] = o["K"].reshape(T, -1); ok[i] = o["k"].reshape(T, -1); oC[i] = o["cost_pred"]; oJ[i] = o["delta_J"]; oS[i] = o["status"]
+    return i
 
 
 t0 = time.time()
 p = bench.distinct_problem(TASK, T, B, MIN_N, cache=os.environ.get("KPILQR_WORKLOAD_CACHE"))
 with mp.get_context("fork").Pool(max(1, min(16, len(os.sched_getaffinity(0))))) as pool:
-    for i, _ in enumerate(pool.imap_unordered(work, range(B), chunksize=4)):
+    for i, _ in enumerate(pool.imap_unordered(work, range(S), chunksize=4)):
         if i % 128 == 0:
-            print(f"oracle: {i} of {B} trajectories ({time.time() - t0:.0f} s)", flush=True)
+            print(f"oracle: {i} of {S} trajectories ({time.time() - t0:.0f} s)", flush=True)
 print(f"workload + oracle: {time.time() - t0:.1f} s", flush=True)
 
 import torch
 from trajoptkp_amd import Engine
 stream = torch.cuda.Stream(); torch.cuda.set_stream(stream)
 rel = lambda a, r: float(np.max(np.abs(a - r)) / max(float(np.max(np.abs(r))), 1e-300))
-for label, env in (("one wave per trajectory, payload differenced inside the backward sweep", {}),
-                   ("column store differenced by k_fd_kp_difference first", {"KPILQR_FUSED_RAW": "0"})):
-    os.environ.pop("KPILQR_FUSED_RAW", None)
+SWITCHES = ("KPILQR_FUSED_RAW", "KPILQR_FUSED_WAVES", "KPILQR_FUSED_FWD_WAVES", "KPILQR_FUSED_UNI")
+for k_ in SWITCHES:
+    if k_ in os.environ:
+        raise SystemExit(f"{k_} is set: this tool checks the DEFAULT dispatch and sets the switches itself")
+
+n_simd = 4 * torch.cuda.get_device_properties(0).multi_processor_count
+if 2 * B > n_simd:
+    legs = [("A", {}, False, ":w1:raw:uni:ru0", None),
+            ("B", {"KPILQR_FUSED_RAW": "0"}, False, ":w1:kpc:uni:ru0", "A"),
+            ("C", {}, True, ":w1:raw:uni:ru0:rxc", "A")]
+elif 4 * B > n_simd:
+    legs = [("A", {}, False, ":pair:raw:uni", None),
+            ("B", {"KPILQR_FUSED_RAW": "0"}, False, ":pair:kpc:uni", "A"),
+            ("C", {}, True, ":pair:raw:uni", "A")]
+else:
+    legs = [("A", {}, False, ":triple:kpc:uni", None),
+            ("B", {"KPILQR_FUSED_WAVES": "1", "KPILQR_FUSED_FWD_WAVES": "1"}, False, ":w1:raw:uni:ru0", None)]
+
+results, summary = {}, {"batch": B, "T": T, "checked": int(S), "n_simd": int(n_simd), "legs": {}}
+for name, env, rxc, want, same_as in legs:
+    for k_ in SWITCHES:
+        os.environ.pop(k_, None)
     os.environ.update(env)
     with Engine(p["dof"], p["m"], T, p["nr"], batch=B, device=0, stream=stream.cuda_stream, fused=True) as eng:
-        synth.upload(eng, p, kp_ordered=True)
+        synth.upload(eng, p, kp_ordered=True, rx_const=rxc)
         st, dJ = eng.backward(np.full(B, p["lam"]), 100)
+        lb = eng.last_launch("backward")
         K, k = eng.gains()
         cost = eng.forward_linear(np.array([(i / 6.0) ** 2 for i in range(1, 7)]))
-        var = (eng.backward_variant, eng.forward_variant)
-    eK = np.array([rel(K[b].reshape(T, -1), oK[b]) for b in range(B)])
-    ek = np.array([rel(k[b].reshape(T, -1), ok[b]) for b in range(B)])
-    eC = np.array([rel(cost[b], oC[b]) for b in range(B)])
-    eJ = np.abs(dJ - oJ) / np.abs(oJ)
-    print(f"{label}: {var[0]} / {var[1]}, B={B}, T={T}, {B} distinct seeds")
-    print(f"  worst relative error over ALL trajectories: K {eK.max():.2e} (trajectory {int(eK.argmax())}), k {ek.max():.2e}, "
-          f"predicted costs {eC.max():.2e}, delta_J {eJ.max():.2e}; median K {np.median(eK):.2e}; "
-          f"status mismatches {int(np.count_nonzero(np.asarray(st) != oS))}", flush=True)
-    assert eK.max() < 1e-9 and ek.max() < 1e-9 and eC.max() < 1e-9 and eJ.max() < 1e-9 and np.array_equal(np.asarray(st), oS)
-print("all trajectories within 1e-9 of the oracle")
+        lf = eng.last_launch("forward")
+    for k_ in env:
+        os.environ.pop(k_, None)
+    assert lb.endswith(want), f"leg {name}: the backward launch was '{lb}', expected '...{want}'"
+    eK = np.array([rel(K[b].reshape(T, -1), oK[i]) for i, b in enumerate(rows)])
+    ek = np.array([rel(k[b].reshape(T, -1), ok[i]) for i, b in enumerate(rows)])
+    eC = np.array([rel(cost[b], oC[i]) for i, b in enumerate(rows)])
+    eJ = np.abs(dJ[rows] - oJ) / np.abs(oJ)
+    bad_status = int(np.count_nonzero(np.asarray(st)[rows] != oS))
+    print(f"leg {name} ({env or 'default environment'}{', constant residual Jacobians' if rxc else ''}): backward {lb} | forward {lf}; B={B}, T={T}, {B} distinct seeds")
+    print(f"  worst relative error over {S} trajectories: K {eK.max():.2e} (trajectory {int(rows[eK.argmax()])}), k {ek.max():.2e}, "
+          f"predicted costs {eC.max():.2e}, delta_J {eJ.max():.2e}; median K {np.median(eK):.2e}; status mismatches {bad_status}", flush=True)
+    assert eK.max() < 1e-9 and ek.max() < 1e-9 and eC.max() < 1e-9 and eJ.max() < 1e-9 and bad_status == 0
+    results[name] = (K, k, dJ, cost, np.asarray(st))
+    row = {"backward": lb, "forward": lf, "max_rel_err_K": float(eK.max()), "max_rel_err_k": float(ek.max()),
+           "max_rel_err_cost_pred": float(eC.max()), "max_rel_err_delta_J": float(eJ.max())}
+    if same_as:
+        a = results[same_as]
+        row["bit_identical_to"] = same_as
+        row["bit_identical"] = bool(all(np.array_equal(u, v) for u, v in zip(results[name], a)))
+        print(f"  K, k, delta_J, predicted costs, statuses of ALL {B} trajectories bit-identical to leg {same_as}: {row['bit_identical']}", flush=True)
+        assert row["bit_identical"]
+        del results[name]
+    summary["legs"][name] = row
+forms = [summary["legs"][name]["backward"] for name, _, rxc, _, _ in legs if not rxc]
+assert len(set(forms)) == len(forms), f"two legs ran the same form: {forms}"
+print("PARITY " + json.dumps(summary))
+print(f"all {S} checked trajectories within 1e-9 of the oracle in every leg")

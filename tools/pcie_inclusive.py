@@ -101,6 +101,24 @@ def measure(B=256, steps=5, T=3000, task="panda_reaching", chunk_list=(4, 8, 16)
             e.iterate(lam)
         e.sync()
         dt_res = (time.perf_counter() - t0) / steps
+        # Reaching has ONE residual Jacobian (Reaching.cpp:43-54): a host with analytic residuals uploads it once
+        # (kpilqr_upload_residual_jacobians_const) and ships, per iteration, the FD payload + the residuals -- the FULL payload
+        # of such a task.  Same H2D bytes as "resident Jacobians"; the sweeps no longer read r_x from HBM either.
+        if p.get("rx_const") is not None:
+            e.upload_residual_jacobians_const(p["rx_const"], None)
+            for columns, label in ((False, "constant Jacobians (full payload of a task with analytic residuals)"),
+                                   (True, "columns + constant Jacobians")):
+                for nc in chunk_list:
+                    K[...] = 0
+                    dt = timed(streamed, False, nc, False, columns)
+                    assert np.array_equal(K, K0) and np.array_equal(k, k0), "streamed K differs from the staged path (constant Jacobians)"
+                    rows.append((label, f"chunks={nc} pipelined", dt, (col_bytes if columns else fd_bytes) + res_bytes[False]))
+            e.iterate(lam); e.sync()
+            t0 = time.perf_counter()
+            for _ in range(steps):
+                e.iterate(lam)
+            e.sync()
+            out["resident_constant_jacobians_traj_it_per_s"] = B / ((time.perf_counter() - t0) / steps)
     out["resident_traj_it_per_s"] = B / dt_res
     out["rows"] = [dict(payload=a, form=b, ms_per_iteration=1e3 * dt, traj_it_per_s=B / dt, h2d_GB=up / 1e9, d2h_GB=dn_bytes / 1e9,
                         link_GBps=(up + dn_bytes) / dt / 1e9) for (a, b, dt, up) in rows]

@@ -10,6 +10,10 @@ import shutil
 import sys
 
 out, tag = sys.argv[1], sys.argv[2]
+# third argument "per_step": the passes ran `bench.py --streamed-jacobians` (residual Jacobians given per step, the round-1..3 form);
+# default: the constant residual Jacobian uploaded once (round 4's bench default)
+PER_STEP = len(sys.argv) > 3 and sys.argv[3] == "per_step"
+SUFFIX = "_per_step_jacobians" if PER_STEP else ""
 root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 T, B = 3000, 1024
 
@@ -19,10 +23,10 @@ KEYS = {"k_backward_fused": "backward_fused", "k_forward_fused": "forward_fused"
 def key_of(name):
     # the one-wave forward sweep is launched in two forms (uniform key-point sets / general), one of which returns at
     # once: only the uniform form runs the bench workload (set_interval key-points)
-    if re.search(r"k_forward_fused(_excl)?<\d+, \d+, (true|false), false>", name):
+    if re.search(r"k_forward_fused(_excl)?<\d+, \d+, (true|false), false(, (true|false))?>", name):
         return None
-    # the same for the one-wave backward sweep since round 3 (<N, M, RU0, RAW, UNI>: UNI = false leaves at once here)
-    if re.search(r"k_backward_fused(_excl)?<\d+, \d+, (true|false), (true|false), false>", name):
+    # the same for the one-wave backward sweep since round 3 (<N, M, RU0, RAW, UNI[, RXC]>: UNI = false leaves at once here)
+    if re.search(r"k_backward_fused(_excl)?<\d+, \d+, (true|false), (true|false), false(, (true|false))?>", name):
         return None
     for k, v in KEYS.items():
         if k in name:
@@ -51,14 +55,14 @@ def counters(passdir):
 fetch, nl = counters("pmc_fetch")
 write, _ = counters("pmc_write")
 traffic = {"note": "rocprofv3 --pmc FETCH_SIZE and --pmc WRITE_SIZE in SEPARATE passes over `python bench.py --no-cpu-baseline "
-                   "--no-secondary --steps 3 --warmup 1` (Panda reaching, B=1024 distinct seeds, T=3000, fused sweeps, key-point ordered FD payload differenced inside the backward sweep); KB per launch, mean over launches. "
+                   "--no-secondary --steps 3 --warmup 1` (Panda reaching, B=1024 distinct seeds, T=3000, fused sweeps, key-point ordered FD payload differenced inside the backward sweep" + (", residual Jacobians per step" if PER_STEP else ", ONE constant residual Jacobian uploaded once") + "); KB per launch, mean over launches. "
                    "gfx950 correction (MI355X_MICROARCH.md, HBM): FETCH_SIZE counts 64 B per 128-B request -> x2 (calibrated in round 1 on a "
                    "kernel with exactly known reads); WRITE_SIZE is exact.",
-           "workload": {"task": "panda_reaching", "T": T, "batch": B}, "kernels": {}}
+           "workload": {"task": "panda_reaching", "T": T, "batch": B, "rx_const": not PER_STEP}, "kernels": {}}
 for k in fetch:
     fk, wk = fetch[k].get("FETCH_SIZE", 0.0), write.get(k, {}).get("WRITE_SIZE", 0.0)
     traffic["kernels"][k] = {"FETCH_SIZE_KB": fk, "WRITE_SIZE_KB": wk, "traffic_bytes": 1024.0 * (2.0 * fk + wk), "launches": nl.get(k)}
-json.dump(traffic, open(os.path.join(root, "profiles", f"{tag}_pmc_traffic.json"), "w"), indent=1)
+json.dump(traffic, open(os.path.join(root, "profiles", f"{tag}_pmc_traffic{SUFFIX}.json"), "w"), indent=1)
 
 m3, _ = counters("pmc_m3")
 m4, _ = counters("pmc_m4")
@@ -75,13 +79,13 @@ for k in m3:
                              "mfma_busy_cycles_per_instruction": d.get("SQ_VALU_MFMA_BUSY_CYCLES", 0.0) / mf,
                              "valu_instructions_per_step_per_trajectory": d.get("SQ_INSTS_VALU", 0.0) / (T * B),
                              "lds_bank_conflict_cycles": d.get("SQ_LDS_BANK_CONFLICT", 0.0)}
-json.dump(cnt, open(os.path.join(root, "profiles", f"{tag}_pmc_counters.json"), "w"), indent=1)
+json.dump(cnt, open(os.path.join(root, "profiles", f"{tag}_pmc_counters{SUFFIX}.json"), "w"), indent=1)
 
-for sub, name in (("stats", f"{tag}_kernel_stats.csv"), ("stats_generic", f"{tag}_generic_kernel_stats.csv")):
+for sub, name in (("stats", f"{tag}_kernel_stats{SUFFIX}.csv"), ("stats_generic", f"{tag}_generic_kernel_stats.csv")):
     fs = glob.glob(os.path.join(out, sub, "**", "*kernel_stats.csv"), recursive=True)
     if fs:
         shutil.copy(fs[0], os.path.join(root, "profiles", name))
-for src, name in (("bench.json", f"{tag}_bench.json"), ("generic.json", f"{tag}_generic_bench.json")):
+for src, name in (("bench.json", f"{tag}_bench{SUFFIX}.json"), ("generic.json", f"{tag}_generic_bench.json")):
     if os.path.exists(os.path.join(out, src)):
         shutil.copy(os.path.join(out, src), os.path.join(root, "profiles", name))
 print(json.dumps(cnt["derived"], indent=1))

@@ -27,7 +27,7 @@ SYMBOLS = [
     "kpilqr_comm_unique_id", "kpilqr_comm_init", "kpilqr_allreduce_linesearch",
     "kpilqr_fd_slab_layout", "kpilqr_upload_fd_slab", "kpilqr_iterate_streamed", "kpilqr_resize",
     "kpilqr_keypoint_error_test", "kpilqr_fd_kp_layout", "kpilqr_upload_fd_kp", "kpilqr_backward_stats",
-    "kpilqr_upload_kp_columns",
+    "kpilqr_upload_kp_columns", "kpilqr_upload_residual_jacobians_const", "kpilqr_last_launch",
 ]
 
 
@@ -133,6 +133,8 @@ def load():
     L.kpilqr_upload_fd_kp.argtypes = [vp, vp, C.c_int, C.c_double]
     L.kpilqr_backward_stats.argtypes = [vp, C.c_int, vp]
     L.kpilqr_upload_kp_columns.argtypes = [vp, vp, C.c_int]
+    L.kpilqr_upload_residual_jacobians_const.argtypes = [vp, vp, vp]
+    L.kpilqr_last_launch.argtypes = [vp, C.c_int]; L.kpilqr_last_launch.restype = C.c_char_p
     for s in SYMBOLS:
         getattr(L, s)          # raises AttributeError if the .so lacks a declared symbol
     _lib = L

@@ -76,6 +76,12 @@ struct Ctx {
     bool tiled_a6 = false;       // KPILQR_FLAG_FUSED on a tiled shape: the cost derivatives (a6) are formed inside the sweeps
     bool tiled_a4 = false;       // KPILQR_FLAG_FUSED on a tiled shape: A, B are interpolated (a4) inside the sweeps
     bool ru_zero = true;         // r_u was never written since create / resize (the buffer starts zeroed): r_u = 0 exactly
+    // constant residual Jacobians (kpilqr_upload_residual_jacobians_const): ONE r_x [nr][n] for every trajectory and step.
+    // rx_const_on: the fused one-wave sweeps keep it in registers and never read the r_x buffer; rx_buf_valid: the r_x buffer
+    // holds the broadcast copy (made on demand for every other kernel family, ensure_rx_buffer)
+    double *rx_const = nullptr;
+    size_t rx_const_cap = 0;
+    bool rx_const_on = false, rx_buf_valid = true;
 
     // ---- fused contexts: the key-point column store (no step records) ---------------------------------------------------
     // A fused (one-tile) context does not allocate step records: its sweeps read the differenced key-point columns from
@@ -151,6 +157,13 @@ struct Ctx {
 
     const char *bwd_variant = "";
     const char *fwd_variant = "";
+    // what the last backward / forward launch of this context actually was (kpilqr_last_launch): wave organisation
+    // (1 one wave per trajectory, 2 control / state split, 3 pair, 4 triple; 0: not a fused launch, or none yet), whether the
+    // sweep differenced the raw payload itself, which residual instantiation ran
+    int last_bwd_form = 0, last_fwd_form = 0;
+    bool last_bwd_raw = false, last_bwd_ru0 = false, last_fwd_ru0 = false, last_bwd_rxc = false, last_fwd_rxc = false;
+    bool last_bwd_slopes = false, last_fwd_slopes = false;
+    std::string launch_desc[2];
 
     // Diagnostic switches, read from the environment ONCE by kpilqr_create; the launchers only
     // look here.  0 = let the library choose.
@@ -203,6 +216,8 @@ hipError_t launch_interpolate(Ctx *c);
 hipError_t launch_filter_dynamics(Ctx *c, int method, const double *coefs_dev, int ncoef);
 hipError_t launch_dof_importance(Ctx *c, int sampling, double *sums_dev);
 hipError_t launch_cost_derivs(Ctx *c);
+hipError_t launch_broadcast_rx(Ctx *c);                  // rx_const -> r_x [batch][T+1][nr][n]
+hipError_t launch_broadcast(hipStream_t s, const double *src_dev, int len, double *dst_dev, size_t reps);   // dst [reps][len] = src [len]
 hipError_t launch_trajectory_cost(Ctx *c);
 // pack/unpack between the reference layout (column-major, separate arrays) and step records
 hipError_t launch_pack_AB(Ctx *c, const double *A, const double *B);      // device staging -> records
@@ -237,6 +252,7 @@ hipError_t launch_forward_wide(Ctx *c, double *U_alpha_dev);
 // fused_mfma.hip: a4 + a6 evaluated inside the sweeps (n+2 <= 16)
 bool fused_supported(int n, int m, int nr, int dof, int T, int stride, int n_alpha);
 int backward_fused_form(const Ctx *c);
+int forward_fused_form(const Ctx *c);
 hipError_t launch_backward_fused(Ctx *c, int pd_stride, bool raw);
 hipError_t launch_forward_fused(Ctx *c, double *U_alpha_dev);
 hipError_t launch_backward_fused_stats(Ctx *c, int pd_stride, int *hist_dev);

@@ -774,6 +774,29 @@ hipError_t launch_copy_out(hipStream_t s, double *dst_host, const double *src_de
 }
 // the same kernel the other way round (loads from pinned host memory): an upload that is a kernel on the chunk's own
 // stream never sits in a shared SDMA queue behind another chunk's copy that is still waiting for its kernels
+// One small matrix repeated along an array: dst [reps][len] = src [len].  (Constant residual Jacobians made visible to the
+// kernel families that stream r_x per step: kpilqr_upload_residual_jacobians_const.)
+__global__ void __launch_bounds__(256)
+k_broadcast(const double *__restrict__ src, int len, double *__restrict__ dst, size_t total)
+{
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (size_t)gridDim.x * blockDim.x)
+        dst[i] = src[i % (size_t)len];
+}
+
+hipError_t launch_broadcast(hipStream_t s, const double *src_dev, int len, double *dst_dev, size_t reps)
+{
+    const size_t total = reps * (size_t)len;
+    if (total == 0) return hipSuccess;
+    const size_t blocks = (total + 255) / 256;
+    hipLaunchKernelGGL(k_broadcast, dim3((unsigned)(blocks < 8192 ? blocks : 8192)), dim3(256), 0, s, src_dev, len, dst_dev, total);
+    return hipGetLastError();
+}
+
+hipError_t launch_broadcast_rx(Ctx *c)
+{
+    return launch_broadcast(c->stream, c->rx_const, c->d.nr * c->n, c->r_x, (size_t)c->d.batch * (c->d.T + 1));
+}
+
 hipError_t launch_copy_in(hipStream_t s, void *dst_dev, const void *src_host, size_t bytes)
 {
     if (bytes == 0) return hipSuccess;

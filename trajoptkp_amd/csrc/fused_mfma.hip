@@ -136,6 +136,7 @@ struct FusedArgs {
                                                    // [x+ (3n) | x- (3n) | int32 mode: bit k = kind k is one-sided | pad] = (6n + 2) * 8 bytes
     double eps2, rinv_2eps;                        // 2 eps and the host's correctly rounded 1 / (2 eps): with it fdiv IS the IEEE
                                                    // quotient (eps and 1/eps are exact halves / doubles of them)
+    const double *rx_const;                        // RXC: r_x [nr][n], the same for every trajectory and step (kpilqr_upload_residual_jacobians_const)
 };
 
 // ---- column tracker: lane (c,q) interpolates rows 4r+q of column c of A and of B ------------------------
@@ -261,7 +262,11 @@ __device__ __forceinline__ void lds_store4(double *t, int lane, const d4 &v);
 // STATS (diagnostic instantiation, kpilqr_backward_stats): counts per trajectory what every step did to obtain
 // (Quu + lambda I)^-1 -- hist[0] third-order refresh only, [1..3] plus that many second-order steps, [4] LDL' factorisation
 // (first step, checked steps, re-seeds), [5] the pivoted slow path -- into hist [batch][6].
-template <int N, int M, bool PC, bool RU0 = false, bool SIDE = false, bool RAW = false, bool UNI = false, bool STATS = false>
+// RXC (one wave per trajectory, with RU0): the residual Jacobian r_x is the same [nr][n] matrix at every step of every
+// trajectory (reaching: selector rows, src/ModelTranslator/Reaching.cpp:43-54; any task whose residuals are affine in the state):
+// the Rx tile is loaded ONCE and stays in registers, the sweep issues no r_x loads (T nr n doubles per trajectory: 5.0 of the
+// 8.1 MB a trajectory's backward sweep reads at the headline shape).  Same products in the same order: bit-identical gains.
+template <int N, int M, bool PC, bool RU0 = false, bool SIDE = false, bool RAW = false, bool UNI = false, bool STATS = false, bool RXC = false>
 __device__ __forceinline__ void backward_fused_body(double *sh, const double *pcbuf, int *sflag, RecLayout L, FusedArgs F, int T,
                 const double *__restrict__ lambda, int pd_stride, double *__restrict__ Kout, double *__restrict__ kout,
                 double *__restrict__ delta_J, int *__restrict__ status, int *__restrict__ hist = nullptr)
@@ -318,11 +323,14 @@ __device__ __forceinline__ void backward_fused_body(double *sh, const double *pc
     // instructions per step, 4.84 -> 4.77 ms).  `t` only says whether there IS a step t (the general form asks once more at the bottom).
     const double *pRx = rxb + (size_t)(T - 1) * nr * n, *pR = rb + (size_t)(T - 1) * nr, *pRu = rub + (size_t)(T - 1) * nr * m;
     auto load_res = [&](int t, ResTiles &s) {
-        __amdgpu_buffer_rsrc_t rRx = frsrc(pRx, nr * n * 8);
         __amdgpu_buffer_rsrc_t rR = frsrc(pR, nr * 8);
         __amdgpu_buffer_rsrc_t rRu = frsrc(pRu, nr * m * 8);
-        if (t > 0) { pRx -= nr * n; pR -= nr; pRu -= nr * m; }       // (behind step 0: stay on it)
-        s.Rx.x = fbld(rRx, oRx[0]); s.Rx.y = fbld(rRx, oRx[1]); s.Rx.z = fbld(rRx, oRx[2]); s.Rx.w = fbld(rRx, oRx[3]);
+        if constexpr (!RXC) {
+            __amdgpu_buffer_rsrc_t rRx = frsrc(pRx, nr * n * 8);
+            s.Rx.x = fbld(rRx, oRx[0]); s.Rx.y = fbld(rRx, oRx[1]); s.Rx.z = fbld(rRx, oRx[2]); s.Rx.w = fbld(rRx, oRx[3]);
+            if (t > 0) pRx -= nr * n;
+        }
+        if (t > 0) { pR -= nr; pRu -= nr * m; }       // (behind step 0: stay on it)
         s.R1.x = fbld(rR, oR1[0]); s.R1.y = fbld(rR, oR1[1]); s.R1.z = fbld(rR, oR1[2]); s.R1.w = fbld(rR, oR1[3]);
         if constexpr (!RU0) { s.Ru.x = fbld(rRu, oRu[0]); s.Ru.y = fbld(rRu, oRu[1]); s.Ru.z = fbld(rRu, oRu[2]); s.Ru.w = fbld(rRu, oRu[3]); }
     };
@@ -375,6 +383,10 @@ __device__ __forceinline__ void backward_fused_body(double *sh, const double *pc
     };
     (void)pm; (void)pmode; (void)bitA;
     ResTiles cur;
+    if constexpr (RXC) {                           // the one r_x of the task: in registers for the whole sweep
+        __amdgpu_buffer_rsrc_t rRx = frsrc(F.rx_const, nr * n * 8);
+        cur.Rx.x = fbld(rRx, oRx[0]); cur.Rx.y = fbld(rRx, oRx[1]); cur.Rx.z = fbld(rRx, oRx[2]); cur.Rx.w = fbld(rRx, oRx[3]);
+    }
     // UNI: lane offsets of the lane's own DoF list (kd * KpU entries into the slice), the position in the soffset operand
     const int KpU = F.kp_offsets[(size_t)bP * F.dof + 1] - E0;
     ColOffsN cu = co, cr = co;                                 // kpc / raw payload
@@ -818,7 +830,7 @@ k_backward_fused_stats(RecLayout L, FusedArgs F, int T, const double *__restrict
 // The one-wave backward sweep comes in two forms, launched back to back like the forward sweep's: UNI for key-point sets in
 // which every DoF of a trajectory has the same list, the general form otherwise; each looks at the device flag first and
 // leaves if the set is not its kind.
-template <int N, int M, bool RU0, bool RAW, bool UNI>
+template <int N, int M, bool RU0, bool RAW, bool UNI, bool RXC = false>
 __global__ void __launch_bounds__(64)
 k_backward_fused(RecLayout L, FusedArgs F, int T, const double *__restrict__ lambda,
                  int pd_stride, double *__restrict__ Kout, double *__restrict__ kout,
@@ -826,9 +838,9 @@ k_backward_fused(RecLayout L, FusedArgs F, int T, const double *__restrict__ lam
 {
     __shared__ __attribute__((aligned(16))) double sh[FLDS_TOTAL];
     if ((*kp_uniform != 0) != UNI) return;
-    backward_fused_body<N, M, false, RU0, false, RAW, UNI>(sh, nullptr, nullptr, L, F, T, lambda, pd_stride, Kout, kout, delta_J, status);
+    backward_fused_body<N, M, false, RU0, false, RAW, UNI, false, RXC>(sh, nullptr, nullptr, L, F, T, lambda, pd_stride, Kout, kout, delta_J, status);
 }
-template <int N, int M, bool RU0, bool RAW, bool UNI>
+template <int N, int M, bool RU0, bool RAW, bool UNI, bool RXC = false>
 __global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(1, 1)))
 k_backward_fused_excl(RecLayout L, FusedArgs F, int T, const double *__restrict__ lambda,
                       int pd_stride, double *__restrict__ Kout, double *__restrict__ kout,
@@ -836,7 +848,7 @@ k_backward_fused_excl(RecLayout L, FusedArgs F, int T, const double *__restrict_
 {
     __shared__ __attribute__((aligned(16))) double sh[FLDS_TOTAL];
     if ((*kp_uniform != 0) != UNI) return;
-    backward_fused_body<N, M, false, RU0, false, RAW, UNI>(sh, nullptr, nullptr, L, F, T, lambda, pd_stride, Kout, kout, delta_J, status);
+    backward_fused_body<N, M, false, RU0, false, RAW, UNI, false, RXC>(sh, nullptr, nullptr, L, F, T, lambda, pd_stride, Kout, kout, delta_J, status);
 }
 
 
@@ -1575,7 +1587,9 @@ __device__ __forceinline__ void fwd_tail(StepF &step, int t, int T)
     }
 }
 
-template <int NCZ, int NCU, bool RU0 = false, bool UNI = false>
+// RXC: one r_x [nr][n] for every trajectory and step (see backward_fused_body): its transposed tile stays in registers, the
+// sweep issues no r_x loads (4 of a step's 15) and the four tile sets shrink by a tile each.
+template <int NCZ, int NCU, bool RU0 = false, bool UNI = false, bool RXC = false>
 __device__ __forceinline__ void forward_fused_body(RecLayout L, FusedArgs F, int T, int n_alpha, const double *__restrict__ Kin, const double *__restrict__ kin,
                const double *__restrict__ u_nom, const double *__restrict__ ctrl_lim,
                const double *__restrict__ alphas, double *__restrict__ cost_pred, double *__restrict__ U_alpha)
@@ -1651,7 +1665,7 @@ __device__ __forceinline__ void forward_fused_body(RecLayout L, FusedArgs F, int
         __amdgpu_buffer_rsrc_t rR = frsrc(rb + (size_t)t * nr, nr * 8);
         s.YkK.x = fbld(rK, oK[0]); s.YkK.y = fbld(rK, oK[1]); s.YkK.z = fbld(rK, oK[2]); s.YkK.w = fbld(rK, oK[3]);
         s.kk = fbld(rk, okn);
-        s.RxT.x = fbld(rRx, oRxT[0]); s.RxT.y = fbld(rRx, oRxT[1]); s.RxT.z = fbld(rRx, oRxT[2]); s.RxT.w = fbld(rRx, oRxT[3]);
+        if constexpr (!RXC) { s.RxT.x = fbld(rRx, oRxT[0]); s.RxT.y = fbld(rRx, oRxT[1]); s.RxT.z = fbld(rRx, oRxT[2]); s.RxT.w = fbld(rRx, oRxT[3]); }
         if constexpr (!RU0) {
             s.RuT.x = fbld(rRu, oRuT[0]); s.RuT.y = NCU > 1 ? fbld(rRu, oRuT[1]) : 0.0;
             s.RuT.z = NCU > 2 ? fbld(rRu, oRuT[2]) : 0.0; s.RuT.w = NCU > 3 ? fbld(rRu, oRuT[3]) : 0.0;
@@ -1693,6 +1707,12 @@ __device__ __forceinline__ void forward_fused_body(RecLayout L, FusedArgs F, int
     // -DKP_PROBE_SAMEB), so the requests have to be two steps ahead of their use.
     constexpr int NS = KP_FWD_SETS;
     Tiles S[NS];
+    d4 RxTc = {0.0, 0.0, 0.0, 0.0};
+    if constexpr (RXC) {
+        __amdgpu_buffer_rsrc_t rRxc = frsrc(F.rx_const, nr * n * 8);
+        RxTc.x = fbld(rRxc, oRxT[0]); RxTc.y = fbld(rRxc, oRxT[1]); RxTc.z = fbld(rRxc, oRxT[2]); RxTc.w = fbld(rRxc, oRxT[3]);
+    }
+    (void)RxTc;
 #pragma unroll
     for (int k = 0; k < NS; k++) load_tiles(k < T ? k : T - 1, S[k]);
 
@@ -1798,10 +1818,10 @@ __device__ __forceinline__ void forward_fused_body(RecLayout L, FusedArgs F, int
         Zn = PS<NCU>(Yb, dU, Zn);                      // + B du: the next state
         d4 Ju = zero;                                  // RU0: r_u = 0, the control residual term vanishes
         if constexpr (!RU0) Ju = PS<NCU>(cur.RuT, dU, zero);
-                const d4 Jx = PS<ncx>(cur.RxT, Z, zero);
+        const d4 Jx = PS<ncx>(RXC ? RxTc : cur.RxT, Z, zero);
         Z = Zn;
         __builtin_amdgcn_sched_barrier(0);
-        cur.RxT.x = fblds(rRx, oRxT[0], sRx); cur.RxT.y = fblds(rRx, oRxT[1], sRx); cur.RxT.z = fblds(rRx, oRxT[2], sRx); cur.RxT.w = fblds(rRx, oRxT[3], sRx);
+        if constexpr (!RXC) { cur.RxT.x = fblds(rRx, oRxT[0], sRx); cur.RxT.y = fblds(rRx, oRxT[1], sRx); cur.RxT.z = fblds(rRx, oRxT[2], sRx); cur.RxT.w = fblds(rRx, oRxT[3], sRx); }
         if constexpr (!RU0) {
             cur.RuT.x = fblds(rRu, oRuT[0], sRu); cur.RuT.y = NCU > 1 ? fblds(rRu, oRuT[1], sRu) : 0.0;
             cur.RuT.z = NCU > 2 ? fblds(rRu, oRuT[2], sRu) : 0.0; cur.RuT.w = NCU > 3 ? fblds(rRu, oRuT[3], sRu) : 0.0;
@@ -1904,7 +1924,7 @@ __device__ __forceinline__ void forward_fused_body(RecLayout L, FusedArgs F, int
 // The one-wave forward sweep comes in two forms, launched back to back: UNI for key-point sets in which every DoF of a
 // trajectory has the same list (the device flag of k_kp_uniform says so), the general form otherwise.  Each looks at the
 // flag first and leaves if the set is not its kind, so the host never has to know.
-template <int NCZ, int NCU, bool RU0, bool UNI>
+template <int NCZ, int NCU, bool RU0, bool UNI, bool RXC = false>
 __global__ void __launch_bounds__(64)
 k_forward_fused(RecLayout L, FusedArgs F, int T, int n_alpha, const double *__restrict__ Kin,
                 const double *__restrict__ kin, const double *__restrict__ u_nom, const double *__restrict__ ctrl_lim,
@@ -1912,9 +1932,9 @@ k_forward_fused(RecLayout L, FusedArgs F, int T, int n_alpha, const double *__re
                 const int *__restrict__ kp_uniform)
 {
     if ((*kp_uniform != 0) != UNI) return;
-    forward_fused_body<NCZ, NCU, RU0, UNI>(L, F, T, n_alpha, Kin, kin, u_nom, ctrl_lim, alphas, cost_pred, U_alpha);
+    forward_fused_body<NCZ, NCU, RU0, UNI, RXC>(L, F, T, n_alpha, Kin, kin, u_nom, ctrl_lim, alphas, cost_pred, U_alpha);
 }
-template <int NCZ, int NCU, bool RU0, bool UNI>
+template <int NCZ, int NCU, bool RU0, bool UNI, bool RXC = false>
 __global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(1, 1)))
 k_forward_fused_excl(RecLayout L, FusedArgs F, int T, int n_alpha, const double *__restrict__ Kin,
                      const double *__restrict__ kin, const double *__restrict__ u_nom, const double *__restrict__ ctrl_lim,
@@ -1922,7 +1942,7 @@ k_forward_fused_excl(RecLayout L, FusedArgs F, int T, int n_alpha, const double 
                      const int *__restrict__ kp_uniform)
 {
     if ((*kp_uniform != 0) != UNI) return;
-    forward_fused_body<NCZ, NCU, RU0, UNI>(L, F, T, n_alpha, Kin, kin, u_nom, ctrl_lim, alphas, cost_pred, U_alpha);
+    forward_fused_body<NCZ, NCU, RU0, UNI, RXC>(L, F, T, n_alpha, Kin, kin, u_nom, ctrl_lim, alphas, cost_pred, U_alpha);
 }
 
 // ---------------------------------------------------------------------------------------------------------
@@ -2201,7 +2221,7 @@ bool fused_supported(int n, int m, int nr, int dof, int T, int stride, int n_alp
 static FusedArgs fused_args(const Ctx *c)
 {
     FusedArgs F = {c->kp_offsets, c->kp_times, c->r, c->r_x, c->r_u, c->w_run, c->w_term, c->d.dof, c->d.nr,
-                   c->kpc, c->fdk_dev, 2 * c->eps, 1.0 / (2 * c->eps)};
+                   c->kpc, c->fdk_dev, 2 * c->eps, 1.0 / (2 * c->eps), c->rx_const};
     return F;
 }
 
@@ -2211,6 +2231,12 @@ int backward_fused_form(const Ctx *c)
 {
     return c->tune.fused_bwd_waves ? c->tune.fused_bwd_waves
          : (4 * c->d.batch <= c->n_simd ? 4 : 2 * c->d.batch <= c->n_simd ? 3 : 1);      // a triple needs three SIMDs of ONE CU
+}
+
+// The wave organisation launch_forward_fused will pick: 1 one wave per trajectory, 2 state / cost pair, 3 the triple
+int forward_fused_form(const Ctx *c)
+{
+    return c->tune.fused_fwd_waves ? c->tune.fused_fwd_waves : (4 * c->d.batch <= c->n_simd ? 3 : 1);
 }
 
 // raw: difference the key-point ordered payload inside the sweep (one-wave form only; the caller checks backward_fused_form)
@@ -2227,6 +2253,9 @@ hipError_t launch_backward_fused(Ctx *c, int pd_stride, bool raw)
     // consumer / side / producer (while batch <= #CUs: the three waves of a workgroup share a CU).
     const int form = backward_fused_form(c);
     if (raw && form != 1 && form != 3) return hipErrorInvalidValue;
+    c->last_bwd_form = form; c->last_bwd_raw = raw; c->last_bwd_ru0 = form == 1 && c->ru_zero;       // kpilqr_last_launch
+    const bool rxc = form == 1 && c->ru_zero && c->rx_const_on;     // (the caller has materialised r_x for every other form)
+    c->last_bwd_rxc = rxc;
     const int role_shift = c->tune.role_shift;
     dim3 block2(128);
     if (form == 2) {
@@ -2270,15 +2299,17 @@ hipError_t launch_backward_fused(Ctx *c, int pd_stride, bool raw)
 #undef LAUNCHPC
         return hipErrorInvalidValue;
     }
-#define LAUNCH4(NN, MM, RU, RW, UN)                                                                           \
+#define LAUNCH5(NN, MM, RU, RW, UN, RX)                                                                       \
     do {                                                                                                     \
         if (excl)                                                                                            \
-            hipLaunchKernelGGL((k_backward_fused_excl<NN, MM, RU, RW, UN>), grid, block, 0, c->stream, c->L, F, c->d.T,  \
+            hipLaunchKernelGGL((k_backward_fused_excl<NN, MM, RU, RW, UN, RX>), grid, block, 0, c->stream, c->L, F, c->d.T,  \
                                c->lambda, pd_stride, c->K, c->k, c->delta_J, c->status, c->kp_uniform);      \
         else                                                                                                 \
-            hipLaunchKernelGGL((k_backward_fused<NN, MM, RU, RW, UN>), grid, block, 0, c->stream, c->L, F, c->d.T,   \
+            hipLaunchKernelGGL((k_backward_fused<NN, MM, RU, RW, UN, RX>), grid, block, 0, c->stream, c->L, F, c->d.T,   \
                                c->lambda, pd_stride, c->K, c->k, c->delta_J, c->status, c->kp_uniform);      \
     } while (0)
+// rxc: constant residual Jacobians (with r_u = 0 only: RU instantiations)
+#define LAUNCH4(NN, MM, RU, RW, UN) do { if (RU && rxc) LAUNCH5(NN, MM, RU, RW, UN, RU); else LAUNCH5(NN, MM, RU, RW, UN, false); } while (0)
 // both forms, back to back: the one whose kind of key-point set is not resident leaves at once.  raw: only UNIFORM sets are
 // differenced inside the sweep; for per-DoF lists a lane's crossing is a divergent branch that every lane of the wave pays for
 // (17 loads, 8 stores on most steps), and the streaming kernel + the plain general sweep are faster (iterative-error lists with
@@ -2303,6 +2334,7 @@ hipError_t launch_backward_fused(Ctx *c, int pd_stride, bool raw)
 #undef LAUNCH2
 #undef LAUNCH3
 #undef LAUNCH4
+#undef LAUNCH5
     return hipErrorInvalidValue;
 }
 
@@ -2327,7 +2359,10 @@ hipError_t launch_forward_fused(Ctx *c, double *U_alpha_dev)
     // sweep at B = 1, 1.74 ... 1.76 at B = 128 ... 256 (four tile sets per wave, a time loop without conditions) against 1.80 for
     // one wave per trajectory with its tile requests four steps ahead, which takes over beyond.
     // KPILQR_FUSED_FWD_WAVES = 1 | 2 | 3 forces a form.
-    const int form = c->tune.fused_fwd_waves ? c->tune.fused_fwd_waves : (4 * c->d.batch <= c->n_simd ? 3 : 1);
+    const int form = forward_fused_form(c);
+    c->last_fwd_form = form == 3 ? 4 : form == 2 ? 3 : 1; c->last_fwd_ru0 = form == 1 && c->ru_zero;      // kpilqr_last_launch: triple / pair / w1
+    const bool rxc = form == 1 && c->ru_zero && c->rx_const_on;
+    c->last_fwd_rxc = rxc;
     const int ncz = (n + 2 + 3) / 4, ncu = (m + 3) / 4;       // tile chunks of [dx; alpha; 1] and of the controls
     if (form == 3) {
         dim3 block3(192);
@@ -2353,17 +2388,18 @@ hipError_t launch_forward_fused(Ctx *c, double *U_alpha_dev)
 #undef LAUNCHSC
         return hipErrorInvalidValue;
     }
-#define LAUNCH3(NCZ, NCU, RU, UNI)                                                                                \
+#define LAUNCH4(NCZ, NCU, RU, UNI, RX)                                                                            \
     do {                                                                                                          \
         if (excl)                                                                                                 \
-            hipLaunchKernelGGL((k_forward_fused_excl<NCZ, NCU, RU, UNI>), grid, block, 0, c->stream, c->L, F, c->d.T, \
+            hipLaunchKernelGGL((k_forward_fused_excl<NCZ, NCU, RU, UNI, RX>), grid, block, 0, c->stream, c->L, F, c->d.T, \
                                c->d.n_alpha, c->K, c->k, c->u_nom, c->ctrl_lim, c->alphas, c->cost_pred,  \
                                U_alpha_dev, c->kp_uniform);                                                       \
         else                                                                                                      \
-            hipLaunchKernelGGL((k_forward_fused<NCZ, NCU, RU, UNI>), grid, block, 0, c->stream, c->L, F, c->d.T,  \
+            hipLaunchKernelGGL((k_forward_fused<NCZ, NCU, RU, UNI, RX>), grid, block, 0, c->stream, c->L, F, c->d.T,  \
                                c->d.n_alpha, c->K, c->k, c->u_nom, c->ctrl_lim, c->alphas, c->cost_pred,  \
                                U_alpha_dev, c->kp_uniform);                                                       \
     } while (0)
+#define LAUNCH3(NCZ, NCU, RU, UNI) do { if (RU && rxc) LAUNCH4(NCZ, NCU, RU, UNI, RU); else LAUNCH4(NCZ, NCU, RU, UNI, false); } while (0)
 // both forms, back to back: the one whose kind of key-point set is not resident leaves at once (k_forward_fused)
 #define LAUNCH2(NCZ, NCU, RU) do { LAUNCH3(NCZ, NCU, RU, true); LAUNCH3(NCZ, NCU, RU, false); } while (0)
 // r_u never uploaded (ru_zero): the instantiation without the r_u loads and the Ju product.  Round-2 history: it measured
@@ -2376,6 +2412,7 @@ hipError_t launch_forward_fused(Ctx *c, double *U_alpha_dev)
 #undef LAUNCH
 #undef LAUNCH2
 #undef LAUNCH3
+#undef LAUNCH4
     return hipErrorInvalidValue;
 }
 

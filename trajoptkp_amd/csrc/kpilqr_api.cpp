@@ -156,10 +156,20 @@ static int grow_dev(kpilqr_ctx *c, void **p, size_t *cap, size_t bytes, bool zer
     return KPILQR_OK;
 }
 
-// kpc for the current key-point capacity: 3n doubles per CSR entry
+// number of CSR entries of the current lists (known to the host since kpilqr_set_keypoints / kpilqr_generate_keypoints,
+// which reads the total back); the capacity of kp_times before any key-points exist
+static size_t kp_entries(const kpilqr_ctx *c)
+{
+    return c->kp_total_host >= 0 ? (size_t)c->kp_total_host : c->kp_cap;
+}
+
+// kpc for the current key-points: 3n doubles per CSR entry (a quarter of slack, so that lists whose counts move a little
+// from one linearisation to the next -- the adaptive methods -- do not re-allocate every time)
 static int ensure_kpc(kpilqr_ctx *c)
 {
-    const int rc = grow_dev(c, (void **)&c->kpc, &c->kpc_cap, c->kp_cap * 3 * (size_t)c->n * 8, true);
+    const size_t need = kp_entries(c) * 3 * (size_t)c->n * 8;
+    if (need <= c->kpc_cap) return KPILQR_OK;
+    const int rc = grow_dev(c, (void **)&c->kpc, &c->kpc_cap, need + need / 4 + 4096, true);
     if (rc < 0) return rc;
     if (rc > 0) c->kpc_valid = c->kpc_touched = false;
     return KPILQR_OK;
@@ -171,7 +181,10 @@ static int ensure_entry_tables(kpilqr_ctx *c)
     if (c->entry_tables_valid) return KPILQR_OK;
     int rc = grow_dev(c, (void **)&c->kp_entry, &c->kp_entry_cap, (size_t)c->d.batch * c->d.dof * c->d.T * sizeof(int), false);
     if (rc < 0) return rc;
-    rc = grow_dev(c, (void **)&c->kp_entry_list, &c->kp_entry_list_cap, (c->kp_cap ? c->kp_cap : 1) * sizeof(int), false);
+    {
+        const size_t need = (kp_entries(c) ? kp_entries(c) : 1) * sizeof(int);
+        rc = need <= c->kp_entry_list_cap ? KPILQR_OK : grow_dev(c, (void **)&c->kp_entry_list, &c->kp_entry_list_cap, need + need / 4, false);
+    }
     if (rc < 0) return rc;
     KP_HIP(c, launch_build_entry_tables(c));
     c->entry_tables_valid = true;
@@ -244,6 +257,19 @@ static void payload_changed(kpilqr_ctx *c)
     c->kpc_valid = c->kpc_touched = false;
     c->rec_synced = false;
 }
+
+// Constant residual Jacobians (kpilqr_upload_residual_jacobians_const): the one-wave fused sweeps keep r_x in registers; every
+// other kernel family streams r_x per step from the context's buffer, which then receives the broadcast copy -- once, on demand.
+static int ensure_rx_buffer(kpilqr_ctx *c)
+{
+    if (!c->rx_const_on || c->rx_buf_valid) return KPILQR_OK;
+    KP_HIP(c, launch_broadcast_rx(c));
+    c->rx_buf_valid = true;
+    return KPILQR_OK;
+}
+// whether the sweep about to be launched reads the r_x buffer (every form but the one-wave fused instantiations without r_u)
+static bool backward_reads_rx_buffer(const kpilqr_ctx *c) { return !(c->fused && backward_fused_form(c) == 1 && c->ru_zero); }
+static bool forward_reads_rx_buffer(const kpilqr_ctx *c) { return !(c->fused && forward_fused_form(c) == 1 && c->ru_zero); }
 
 // kernel families for c->d (names: kpilqr_backward_variant)
 static int select_variants(kpilqr_ctx *c)
@@ -372,7 +398,7 @@ void kpilqr_destroy(kpilqr_ctx *c)
     void *ptrs[] = {c->rec, c->K, c->k, c->r, c->r_x, c->r_u, c->w_run, c->w_term, c->u_nom, c->ctrl_lim,
                     c->lambda, c->alphas, c->cost_pred, c->delta_J, c->traj_cost, c->status, c->segmap,
                     c->kp_offsets, c->kp_times, c->X_states, c->kp_thr, c->kp_mask, c->kp_count, c->ls8, c->fd_dev,
-                    c->stage, c->err_flag, c->kp_uniform, c->kpc, c->kp_entry, c->kp_entry_list, c->fdk_dev};
+                    c->stage, c->err_flag, c->kp_uniform, c->kpc, c->kp_entry, c->kp_entry_list, c->fdk_dev, c->rx_const};
     for (void *p : ptrs) if (p) (void)hipFree(p);
     if (c->err_flag_host) (void)hipHostFree(c->err_flag_host);
     if (c->kp_traj_first_host) free(c->kp_traj_first_host);
@@ -414,6 +440,7 @@ int kpilqr_resize(kpilqr_ctx *c, int new_dof, int new_num_ctrl, int new_horizon)
     if (c->kp_traj_first_host) { free(c->kp_traj_first_host); c->kp_traj_first_host = nullptr; }
     payload_changed(c);
     c->ru_zero = true;                                   // size_buffers zeroed r_u
+    c->rx_const_on = false; c->rx_buf_valid = true;
     if (c->X_states) { KP_HIP(c, hipFree(c->X_states)); c->X_states = nullptr; }
     if (c->kp_mask) { KP_HIP(c, hipFree(c->kp_mask)); c->kp_mask = nullptr; }
     if (c->kp_count) { KP_HIP(c, hipFree(c->kp_count)); c->kp_count = nullptr; }
@@ -431,7 +458,12 @@ int kpilqr_host_alloc(kpilqr_ctx *c, size_t bytes, void **pinned)
 
 int kpilqr_host_free(kpilqr_ctx *c, void *pinned)
 {
-    if (!c) return KPILQR_ERR_ARG;
+    if (!c) {
+        // the allocation may outlive the context it was made through (a binding whose arrays are still referenced after the
+        // engine was closed): pinned host memory is not tied to a device or a stream
+        if (pinned && hipHostFree(pinned) != hipSuccess) return set_err(nullptr, KPILQR_ERR_HIP, "hipHostFree failed");
+        return KPILQR_OK;
+    }
     KP_ENTER(c);
     if (pinned) KP_HIP(c, hipHostFree(pinned));
     return KPILQR_OK;
@@ -471,7 +503,12 @@ int kpilqr_device_ptr(kpilqr_ctx *c, int which, void **dptr, size_t *bytes)
     case KPILQR_BUF_K: p = c->K; sz = B * T * n * m * 8; break;
     case KPILQR_BUF_k: p = c->k; sz = B * T * m * 8; break;
     case KPILQR_BUF_RESIDUALS: p = c->r; sz = B * (T + 1) * nr * 8; break;
-    case KPILQR_BUF_R_X: p = c->r_x; sz = B * (T + 1) * nr * n * 8; break;
+    case KPILQR_BUF_R_X:
+        // a writable pointer leaves the library: the buffer gets the constant Jacobians' broadcast copy and is what the
+        // sweeps read from here on (the constant mode is off, as for r_u below)
+        { const int rcx = ensure_rx_buffer(c); if (rcx) return rcx; }
+        c->rx_const_on = false; c->rx_buf_valid = true;
+        p = c->r_x; sz = B * (T + 1) * nr * n * 8; break;
     case KPILQR_BUF_R_U:
         // a writable pointer leaves the library: from here on r_u may be non-zero without kpilqr_upload_residuals having
         // seen it, so the r_u-free instantiations of the fused sweeps (Ctx::ru_zero) are off for this context
@@ -580,7 +617,16 @@ int kpilqr_generate_keypoints(kpilqr_ctx *c, const char *method, int min_N, int 
     KP_HIP(c, launch_build_segmap(c));
     c->have_kp = true;
     c->kp_canonical = true;      // rows 0 and T-1 are always full and the lists are strictly increasing by construction
-    c->kp_total_host = -1;       // the lists exist on the device only (kpilqr_get_keypoints brings them to the host)
+    // The lists exist on the device only (kpilqr_get_keypoints brings them to the host), but their TOTAL is read back here --
+    // one int: the column store and the entry tables are sized from it (not from the worst case batch * dof * T: 7.2 GB
+    // against 1.4 GB at the headline shape), and the `entries` of a key-point ordered upload is checked against it.
+    {
+        int total = 0;
+        KP_HIP(c, hipMemcpyAsync(&total, c->kp_offsets + nlists, sizeof(int), hipMemcpyDeviceToHost, c->stream));
+        KP_HIP(c, hipStreamSynchronize(c->stream));
+        if (total < 0 || (size_t)total > nlists * T) return set_err(c, KPILQR_ERR_HIP, "kpilqr_generate_keypoints: implausible key-point count read back");
+        c->kp_total_host = total;
+    }
     if (c->kp_traj_first_host) { free(c->kp_traj_first_host); c->kp_traj_first_host = nullptr; }
     c->entry_tables_valid = false;
     if (c->fd_kind == 2 || c->fd_kind == 3) { c->fd_kind = 0; c->fdk_entries = 0; }
@@ -754,9 +800,9 @@ int kpilqr_upload_fd_kp(kpilqr_ctx *c, const void *slab, int entries, double eps
     KP_ENTER(c);
     if (!(eps > 0.0)) return set_err(c, KPILQR_ERR_ARG, "eps must be positive");
     if (!c->have_kp) return set_err(c, KPILQR_ERR_STATE, "kpilqr_upload_fd_kp before the key-points it is ordered by (kpilqr_set_keypoints / kpilqr_generate_keypoints)");
-    if (c->kp_total_host >= 0 && entries != c->kp_total_host)
+    // (the sweeps index the slab by the device CSR, not by `entries`: a smaller slab would be read past its end)
+    if (entries != c->kp_total_host)
         return set_err(c, KPILQR_ERR_ARG, "kpilqr_upload_fd_kp: `entries` is not the number of key-point entries (kp_offsets[batch*dof])");
-    if ((size_t)entries > c->kp_cap) return set_err(c, KPILQR_ERR_ARG, "kpilqr_upload_fd_kp: more entries than key-points");
     kpilqr_fdkp_layout L;
     int rc = fdk_bind(c, entries, &L);
     if (rc) return rc;
@@ -773,9 +819,8 @@ int kpilqr_upload_kp_columns(kpilqr_ctx *c, const double *columns, int entries)
     if (!c || entries < 0 || (entries > 0 && !columns)) return KPILQR_ERR_ARG;
     KP_ENTER(c);
     if (!c->have_kp) return set_err(c, KPILQR_ERR_STATE, "kpilqr_upload_kp_columns before the key-points it is ordered by (kpilqr_set_keypoints / kpilqr_generate_keypoints)");
-    if (c->kp_total_host >= 0 && entries != c->kp_total_host)
+    if (entries != c->kp_total_host)
         return set_err(c, KPILQR_ERR_ARG, "kpilqr_upload_kp_columns: `entries` is not the number of key-point entries (kp_offsets[batch*dof])");
-    if ((size_t)entries > c->kp_cap) return set_err(c, KPILQR_ERR_ARG, "kpilqr_upload_kp_columns: more entries than key-points");
     int rc = ensure_kpc(c);
     if (rc) return rc;
     if (entries) KP_HIP(c, hipMemcpyAsync(c->kpc, columns, (size_t)entries * 3 * c->n * 8, hipMemcpyHostToDevice, c->stream));
@@ -836,10 +881,34 @@ int kpilqr_upload_residuals(kpilqr_ctx *c, const double *r, const double *r_x, c
     KP_ENTER(c);
     const size_t B = c->d.batch, T1 = c->d.T + 1, n = c->n, m = c->d.m, nr = c->d.nr;
     if (r) KP_HIP(c, hipMemcpyAsync(c->r, r, B * T1 * nr * 8, hipMemcpyHostToDevice, c->stream));
-    if (r_x) KP_HIP(c, hipMemcpyAsync(c->r_x, r_x, B * T1 * nr * n * 8, hipMemcpyHostToDevice, c->stream));
+    if (r_x) { KP_HIP(c, hipMemcpyAsync(c->r_x, r_x, B * T1 * nr * n * 8, hipMemcpyHostToDevice, c->stream)); c->rx_const_on = false; c->rx_buf_valid = true; }
     if (r_u) { KP_HIP(c, hipMemcpyAsync(c->r_u, r_u, B * T1 * nr * m * 8, hipMemcpyHostToDevice, c->stream)); c->ru_zero = false; }
     if (w_run) KP_HIP(c, hipMemcpyAsync(c->w_run, w_run, nr * 8, hipMemcpyHostToDevice, c->stream));
     if (w_term) KP_HIP(c, hipMemcpyAsync(c->w_term, w_term, nr * 8, hipMemcpyHostToDevice, c->stream));
+    return KPILQR_OK;
+}
+
+// One r_x [nr][n] (and r_u [nr][m], or none) for every trajectory and step: a task whose residuals are affine in the state
+// (reaching: r = [q - q*, qdot], Reaching.cpp:43-54).  Uploaded once; the fused one-wave sweeps then issue no r_x loads.
+int kpilqr_upload_residual_jacobians_const(kpilqr_ctx *c, const double *r_x, const double *r_u)
+{
+    if (!c || !r_x) return KPILQR_ERR_ARG;
+    KP_ENTER(c);
+    const size_t n = c->n, m = c->d.m, nr = c->d.nr, reps = (size_t)c->d.batch * (c->d.T + 1);
+    { const int rcg = grow_dev(c, (void **)&c->rx_const, &c->rx_const_cap, nr * n * 8, false); if (rcg < 0) return rcg; }
+    KP_HIP(c, hipMemcpyAsync(c->rx_const, r_x, nr * n * 8, hipMemcpyHostToDevice, c->stream));
+    c->rx_const_on = true; c->rx_buf_valid = false;
+    if (r_u) {                                   // dense control residuals: streamed from the (broadcast) buffer like r_x then
+        const int rcs = ensure_stage(c, nr * m * 8);
+        if (rcs) return rcs;
+        KP_HIP(c, hipMemcpyAsync(c->stage, r_u, nr * m * 8, hipMemcpyHostToDevice, c->stream));
+        KP_HIP(c, launch_broadcast(c->stream, c->stage, (int)(nr * m), c->r_u, reps));
+        c->ru_zero = false;
+    } else if (!c->ru_zero) {
+        KP_HIP(c, hipMemsetAsync(c->r_u, 0, reps * nr * m * 8, c->stream));
+        c->ru_zero = true;
+    }
+    if (!(is_pinned(r_x) && is_pinned(r_u))) KP_HIP(c, hipStreamSynchronize(c->stream));
     return KPILQR_OK;
 }
 
@@ -847,6 +916,7 @@ int kpilqr_cost_derivs(kpilqr_ctx *c)
 {
     if (!c) return KPILQR_ERR_ARG;
     KP_ENTER(c);
+    { const int rcx = ensure_rx_buffer(c); if (rcx) return rcx; }
     if (c->fused) { const int rc = ensure_records(c); if (rc) return rc; }
     KP_HIP(c, launch_cost_derivs(c));
     return KPILQR_OK;
@@ -872,6 +942,7 @@ static int check_fused(kpilqr_ctx *c)
 
 static int run_backward(kpilqr_ctx *c, int pd_stride)
 {
+    if (c->rx_const_on && (c->fused || c->tiled_a6) && backward_reads_rx_buffer(c)) { const int rcx = ensure_rx_buffer(c); if (rcx) return rcx; }
     if (c->tiled_a4) { int rc = check_fused(c); if (rc) return rc; }
     if (c->fused) {
         int rc = check_fused(c);
@@ -893,6 +964,7 @@ static int run_backward(kpilqr_ctx *c, int pd_stride)
         KP_HIP(c, launch_backward_fused(c, pd_stride, false));
         return KPILQR_OK;
     }
+    c->last_bwd_form = 0;
     if (strcmp(c->bwd_variant, "mfma_f64_t1") == 0) KP_HIP(c, launch_backward_mfma(c, pd_stride));
     else if (strncmp(c->bwd_variant, "mfma_f64_tiled", 14) == 0) KP_HIP(c, launch_backward_tiled(c, pd_stride));
     else if (strcmp(c->bwd_variant, "mfma_f64_wide") == 0) KP_HIP(c, launch_backward_wide(c, pd_stride));
@@ -928,6 +1000,8 @@ int kpilqr_backward_stats(kpilqr_ctx *c, int pd_check_stride, int *hist)
     rc = ensure_kpc(c);
     if (rc) return rc;
     if (!c->kpc_valid) { rc = difference_to_kpc(c); if (rc) return rc; }
+    rc = ensure_rx_buffer(c);
+    if (rc) return rc;
     const size_t bytes = (size_t)c->d.batch * 6 * sizeof(int);
     rc = ensure_stage(c, bytes);
     if (rc) return rc;
@@ -984,6 +1058,7 @@ static int ensure_stage(kpilqr_ctx *c, size_t bytes)
 
 static int run_forward(kpilqr_ctx *c, double *U_dev)
 {
+    if (c->rx_const_on && (c->fused || c->tiled_a6) && forward_reads_rx_buffer(c)) { const int rcx = ensure_rx_buffer(c); if (rcx) return rcx; }
     if (c->tiled_a4) { int rc = check_fused(c); if (rc) return rc; }
     if (c->fused) {
         int rc = check_fused(c);
@@ -995,6 +1070,7 @@ static int run_forward(kpilqr_ctx *c, double *U_dev)
         KP_HIP(c, launch_forward_fused(c, U_dev));
         return KPILQR_OK;
     }
+    c->last_fwd_form = 0;
     if (strcmp(c->fwd_variant, "mfma_f64_t1") == 0) KP_HIP(c, launch_forward_mfma(c, U_dev));
     else if (strncmp(c->fwd_variant, "mfma_f64_tiled", 14) == 0) KP_HIP(c, launch_forward_tiled(c, U_dev));
     else if (strcmp(c->fwd_variant, "mfma_f64_wide") == 0) KP_HIP(c, launch_forward_wide(c, U_dev));
@@ -1033,7 +1109,7 @@ int kpilqr_iterate(kpilqr_ctx *c, const double *lambda, int pd_check_stride, con
     if (!c->fused) {              // the fused sweeps difference (or read kpc), interpolate A, B and form l_* themselves
         { const int rcp = records_from_payload(c); if (rcp) return rcp; }
         if (!c->tiled_a4) KP_HIP(c, launch_interpolate(c));      // tiled + flag: A, B interpolated inside the sweeps
-        if (!c->tiled_a6) KP_HIP(c, launch_cost_derivs(c));      // tiled + flag: l_* are formed inside the sweeps
+        if (!c->tiled_a6) { const int rcx = ensure_rx_buffer(c); if (rcx) return rcx; KP_HIP(c, launch_cost_derivs(c)); }      // tiled + flag: l_* are formed inside the sweeps
     }
     int rc = run_backward(c, pd_check_stride);
     if (rc) return rc;
@@ -1089,6 +1165,7 @@ int kpilqr_iterate_streamed(kpilqr_ctx *c, const kpilqr_stream_io *io, int pd_ch
         if (io->entries != c->kp_total_host) return set_err(c, KPILQR_ERR_ARG, "fd_kp_slab / kp_columns: `entries` is not the number of key-point entries");
     }
     if (io->r_u) c->ru_zero = false;
+    if (io->r_x) { c->rx_const_on = false; c->rx_buf_valid = true; }
     const void *hostp[] = {io->kp_columns, io->fd_kp_slab, io->fd_slab, io->r, io->r_x, io->r_u, io->u_nom, io->lambda, io->K, io->k, io->cost_pred, io->delta_J, io->status};
     for (const void *p : hostp) if (!is_pinned(p)) return set_err(c, KPILQR_ERR_ARG, "kpilqr_iterate_streamed: host buffers must be pinned (kpilqr_host_alloc)");
     if (c->fused || c->tiled_a4) { int rc = check_fused(c); if (rc) return rc; }
@@ -1168,6 +1245,15 @@ int kpilqr_iterate_streamed(kpilqr_ctx *c, const kpilqr_stream_io *io, int pd_ch
         rc = ensure_kpc(c); if (rc) return rc;
         rc = ensure_entry_tables(c); if (rc) return rc;
     }
+    // No new payload, but the column store of the resident one is stale (key-points changed since a job-list upload): a chunk
+    // view has no jobs (its njobs is 0), so the payload is re-differenced HERE, on the context, for the whole batch -- what
+    // kpilqr_iterate would do.  (A key-point ordered payload is dropped by new key-points; the chunks handle a resident one.)
+    if (c->fused && !slab && !kslab && !kcols && !c->kpc_valid && c->fd_kind == 1) {
+        rc = difference_to_kpc(c); if (rc) return rc;
+    }
+    // constant residual Jacobians and a kernel family that streams r_x: the broadcast copy is made here, on the context (the
+    // chunks' wave organisation is the whole batch's: make_view gives a chunk its share of the SIMDs)
+    if (c->rx_const_on && (!c->fused || backward_reads_rx_buffer(c) || forward_reads_rx_buffer(c))) { rc = ensure_rx_buffer(c); if (rc) return rc; }
     // order the chunk streams behind whatever the caller enqueued on the context's stream so far (key-points, weights ...)
     KP_HIP(c, hipEventRecord(c->pipe_in, c->stream));
     // from here on chunk streams hold work: every exit path, errors included, leaves the pipeline marked for joining, so a
@@ -1238,6 +1324,9 @@ int kpilqr_iterate_streamed(kpilqr_ctx *c, const kpilqr_stream_io *io, int pd_ch
         rc = run_forward(&v, nullptr);
         if (rc) { c->err = v.err; return rc; }
         vflags_valid = v.kpc_valid; vflags_touched = v.kpc_touched;
+        c->last_bwd_form = v.last_bwd_form; c->last_fwd_form = v.last_fwd_form; c->last_bwd_raw = v.last_bwd_raw;
+        c->last_bwd_ru0 = v.last_bwd_ru0; c->last_fwd_ru0 = v.last_fwd_ru0; c->last_bwd_rxc = v.last_bwd_rxc; c->last_fwd_rxc = v.last_fwd_rxc;
+        c->last_bwd_slopes = v.last_bwd_slopes; c->last_fwd_slopes = v.last_fwd_slopes;
         // ---- D2H of the chunk ------------------------------------------------------------------------------------
         // K, k by a copy kernel: it overlaps with the SDMA uploads of the next chunks (two SDMA directions do not)
         if (k_down) {
@@ -1358,5 +1447,35 @@ int kpilqr_get_cost_derivs(kpilqr_ctx *c, double *l_x, double *l_xx, double *l_u
 
 const char *kpilqr_backward_variant(kpilqr_ctx *c) { return c ? c->bwd_variant : ""; }
 const char *kpilqr_forward_variant(kpilqr_ctx *c) { return c ? c->fwd_variant : ""; }
+
+// What the last backward (which = 0) / forward (which = 1) launch of this context WAS: "<variant>" for the materialising
+// families; for the fused sweeps "<variant>:<waves>:<columns>:<lists>[:ru0][:rxc][:slopes]" with
+//   waves    w1 one wavefront per trajectory | w2 control / state split | pair | triple
+//   columns  raw: the backward sweep differenced the key-point ordered payload itself | kpc: read from the column store
+//   lists    uni: every DoF of a trajectory has the same key-point list (the straight-line crossing forms ran) | ragged
+// The `lists` token is decided on the device (the host never needs it otherwise): this call reads the flag back, i.e. it
+// waits for the context's stream.
+const char *kpilqr_last_launch(kpilqr_ctx *c, int which)
+{
+    if (!c || which < 0 || which > 1) return "";
+    std::string &out = c->launch_desc[which];
+    const int form = which == 0 ? c->last_bwd_form : c->last_fwd_form;
+    out = which == 0 ? c->bwd_variant : c->fwd_variant;
+    if (form == 0) { if (!c->fused) return out.c_str(); out += ":none"; return out.c_str(); }
+    int uni = 0;
+    if (hipSetDevice(c->d.device) != hipSuccess || (c->pipe_dirty && join_pipeline(c) != KPILQR_OK) ||
+        hipMemcpyAsync(&uni, c->kp_uniform, sizeof(int), hipMemcpyDeviceToHost, c->stream) != hipSuccess ||
+        hipStreamSynchronize(c->stream) != hipSuccess) { out += ":?"; return out.c_str(); }
+    static const char *const wname[5] = {"", "w1", "w2", "pair", "triple"};
+    out += ":"; out += wname[form < 5 ? form : 0];
+    // (the raw launch sequence differences inside the sweep for uniform sets only: per-DoF lists take k_fd_kp_difference and
+    // the plain sweep, launched behind it -- unless KPILQR_FUSED_UNI=0 forces the general raw form, one wave per trajectory)
+    if (which == 0) out += (c->last_bwd_raw && (uni || (c->tune.fused_uni == 0 && form == 1))) ? ":raw" : ":kpc";
+    out += uni ? ":uni" : ":ragged";
+    if (which == 0 ? c->last_bwd_ru0 : c->last_fwd_ru0) out += ":ru0";
+    if (which == 0 ? c->last_bwd_rxc : c->last_fwd_rxc) out += ":rxc";
+    if (which == 0 ? c->last_bwd_slopes : c->last_fwd_slopes) out += ":slopes";
+    return out.c_str();
+}
 
 }  // extern "C"

@@ -39,6 +39,24 @@ class _DeviceArray:
         self._owner = owner
 
 
+class _PinnedBlock:
+    """One kpilqr_host_alloc allocation.  Every numpy array handed out by Engine.pinned() reaches it through its base
+    buffer, so the memory lives as long as ANY view of it does -- also after Engine.close(): a result read from a pinned
+    array behind close() is a read of live memory, not of a freed page.  The engine keeps a reference of its own until it
+    is closed (the allocation never dies under a transfer the engine still has in flight)."""
+
+    def __init__(self, lib, ptr, nbytes):
+        self._lib, self.ptr, self.nbytes = lib, ptr, nbytes
+
+    def __del__(self):
+        try:
+            if self.ptr:
+                self._lib.kpilqr_host_free(None, C.c_void_p(self.ptr))     # ctx = NULL: the context may be gone already
+                self.ptr = 0
+        except Exception:
+            pass
+
+
 class Engine:
     def __init__(self, dof, m, T, nr, batch=1, n_alpha=6, device=0, stream=None, generic=False, tiled=False, fused=False):
         self._L = _lib.load()
@@ -62,11 +80,9 @@ class Engine:
     def close(self):
         if getattr(self, "_h", None):
             self._L.kpilqr_sync(self._h)
-            for p in self._pinned:
-                self._L.kpilqr_host_free(self._h, C.c_void_p(p))
-            self._pinned = []
-            self._L.kpilqr_destroy(self._h)
+            self._L.kpilqr_destroy(self._h)      # (waits for the chunk streams too: nothing reads the pinned blocks any more)
             self._h = None
+            self._pinned = []                    # blocks without outstanding views are freed here, the others with their last view
 
     def __del__(self):
         try:
@@ -97,6 +113,11 @@ class Engine:
     @property
     def forward_variant(self):
         return self._L.kpilqr_forward_variant(self._h).decode()
+
+    def last_launch(self, which="backward"):
+        """kpilqr_last_launch: the form the last backward / forward launch actually took, e.g.
+        'mfma_f64_t1_fused:w1:raw:uni:ru0' (waits for the stream)."""
+        return self._L.kpilqr_last_launch(self._h, 0 if which == "backward" else 1).decode()
 
     def device_array(self, which, shape, typestr="<f8"):
         p, sz = C.c_void_p(), C.c_size_t()
@@ -161,13 +182,16 @@ class Engine:
 
     # -- asynchronous boundary: pinned memory, one slab, chunk pipeline -------------------------------
     def pinned(self, shape, dtype=np.float64):
-        """numpy array in pinned host memory owned by the context (kpilqr_host_alloc); freed with the engine."""
+        """numpy array in pinned host memory (kpilqr_host_alloc).  The allocation is released when the engine has been closed
+        AND no array (or view of one) refers to it any more -- whichever comes last."""
         shape = (shape,) if np.isscalar(shape) else tuple(shape)
         nbytes = max(int(np.prod(shape)) * np.dtype(dtype).itemsize, 1)
         p = C.c_void_p()
         self._ck(self._L.kpilqr_host_alloc(self._h, nbytes, C.byref(p)))
-        self._pinned.append(p.value)
+        block = _PinnedBlock(self._L, p.value, nbytes)
+        self._pinned.append(block)
         buf = (C.c_char * nbytes).from_address(p.value)
+        buf._kpilqr_block = block                # numpy keeps `buf` as the base of every view; `buf` keeps the block
         return np.frombuffer(buf, dtype=dtype, count=int(np.prod(shape))).reshape(shape)
 
     def fd_slab(self, job_b, job_t, job_col, job_mode, xplus, xminus, job_nom=None, xnom=None):
@@ -289,6 +313,14 @@ class Engine:
         w_term = None if w_term is None else _f64(w_term, (nr,))
         self._keep += [r, r_x, r_u, w_run, w_term]
         self._ck(self._L.kpilqr_upload_residuals(self._h, _ptr(r), _ptr(r_x), _ptr(r_u), _ptr(w_run), _ptr(w_term)))
+
+    def upload_residual_jacobians_const(self, r_x, r_u=None):
+        """kpilqr_upload_residual_jacobians_const: ONE r_x [nr][n] (and r_u [nr][m], or None for r_u = 0) for every trajectory
+        and step."""
+        r_x = _f64(r_x, (self.nr, self.n))
+        r_u = None if r_u is None else _f64(r_u, (self.nr, self.m))
+        self._keep += [r_x, r_u]
+        self._ck(self._L.kpilqr_upload_residual_jacobians_const(self._h, _ptr(r_x), _ptr(r_u)))
 
     def cost_derivs(self):
         self._ck(self._L.kpilqr_cost_derivs(self._h))

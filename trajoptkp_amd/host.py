@@ -39,6 +39,7 @@ def load_host():
     H.kpilqr_host_task_file.argtypes = [C.c_char_p, C.c_int, C.c_int, C.c_int, vp, vp]
     H.kpilqr_host_save_summary.argtypes = [C.c_char_p, C.c_int, C.c_int, vp, vp]
     H.kpilqr_host_run_acrobot_batch.argtypes = [C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_double, vp, C.c_int, vp, C.c_int, vp, vp, vp]
+    H.kpilqr_host_run_acrobot_batch2.argtypes = [C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_double, vp, C.c_int, C.c_char_p, vp, C.c_int, vp, vp, vp]
     H.kpilqr_host_dof_importance.argtypes = [vp, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_double, vp, vp]
     H.kpilqr_host_model_info.argtypes = [C.c_char_p, vp, vp, vp]
     H.kpilqr_host_fd_kp_check.argtypes = [C.c_char_p, C.c_int, C.c_int, C.c_int, vp, vp]
@@ -133,13 +134,15 @@ def save_summary(filename, rows, timings):
     return H.kpilqr_host_save_summary(filename.encode(), r.shape[0], t.shape[2], _p(r), _p(t))
 
 
-def run_acrobot_batch(q0s, T=100, min_N=5, max_iter=6, min_iter=2, torque_weight=-1.0, fused=False):
-    """B acrobot swing-ups from the starts q0s [B][2] through ONE batched context (iLQR_GPU_Batch)."""
+def run_acrobot_batch(q0s, T=100, min_N=5, max_iter=6, min_iter=2, torque_weight=-1.0, fused=False, method=None):
+    """B acrobot swing-ups from the starts q0s [B][2] through ONE batched context (iLQR_GPU_Batch).  method: key-point
+    method by name (None: set_interval)."""
     H = load_host()
     q = np.ascontiguousarray(q0s, np.float64); B = q.shape[0]
     cap = max_iter + 2
     hist = np.zeros((B, cap)); its = np.zeros(B, np.int32); U = np.zeros((B, T)); stats = np.zeros(8)
-    rc = H.kpilqr_host_run_acrobot_batch(B, T, min_N, max_iter, min_iter, float(torque_weight), _p(q), int(fused), _p(hist), cap, _p(its), _p(U), _p(stats))
+    rc = H.kpilqr_host_run_acrobot_batch2(B, T, min_N, max_iter, min_iter, float(torque_weight), _p(q), int(fused),
+                                          None if method is None else method.encode(), _p(hist), cap, _p(its), _p(U), _p(stats))
     if rc < 0:
         raise RuntimeError(f"kpilqr_host_run_acrobot_batch failed: {rc}")
     return dict(iterations=its, cost_history=[hist[b][hist[b] >= 0] for b in range(B)], U=U, stats=stats)

@@ -91,14 +91,25 @@ int kpilqr_host_run_acrobot(int T, int min_N, int max_iter, int min_iter, const 
 // B acrobot swing-ups from different starts q0[b] = (q0s[2b], q0s[2b+1]) optimised TOGETHER through one context
 // with dims.batch = B (iLQR_GPU_Batch).  cost_history: [B][cost_cap] (initial cost first), iterations [B],
 // U_out [B][T], stats [8] = line-search statistics of the last iteration.  Returns 0 or <0.
+int kpilqr_host_run_acrobot_batch2(int B, int T, int min_N, int max_iter, int min_iter, double torque_weight, const double *q0s,
+                                   int fused, const char *method, double *cost_history, int cost_cap, int *iterations, double *U_out, double *stats);
 int kpilqr_host_run_acrobot_batch(int B, int T, int min_N, int max_iter, int min_iter, double torque_weight, const double *q0s,
                                   int fused, double *cost_history, int cost_cap, int *iterations, double *U_out, double *stats)
+{
+    return kpilqr_host_run_acrobot_batch2(B, T, min_N, max_iter, min_iter, torque_weight, q0s, fused, nullptr, cost_history, cost_cap, iterations, U_out, stats);
+}
+
+// ... with a key-point method by name (NULL: the task's default, set_interval): the adaptive methods give every trajectory its own
+// per-DoF lists, whose counts change from one linearisation to the next
+int kpilqr_host_run_acrobot_batch2(int B, int T, int min_N, int max_iter, int min_iter, double torque_weight, const double *q0s,
+                                   int fused, const char *method, double *cost_history, int cost_cap, int *iterations, double *U_out, double *stats)
 {
     std::vector<iLQR_GPU_Batch::Problem> probs;
     for (int b = 0; b < B; b++) {
         auto sim = std::make_shared<AcrobotSimulator>(0.01, 8);
         auto mt = std::make_shared<AcrobotTranslator>(sim);
         mt->min_N = min_N;
+        if (method && *method) mt->keypoint_method = method;
         if (torque_weight >= 0) { mt->residual_list[4].weight = torque_weight; mt->residual_list[4].weight_terminal = torque_weight; }
         sim->main_data->qpos[0] = q0s[2 * b]; sim->main_data->qpos[1] = q0s[2 * b + 1];
         *sim->master_reset_data = *sim->main_data;

@@ -5,6 +5,7 @@
 #include <algorithm>
 #include <cstdio>
 #include <cstdlib>
+#include <cstring>
 
 void iLQR_GPU_Batch::fatal(const char *what, int rc)
 {
@@ -131,9 +132,27 @@ double iLQR_GPU_Batch::ConfirmRollout(int b, int tid, double alpha, std::vector<
     return cost;
 }
 
+// Moves the entry records of the trajectories NOT regenerating from where the previous batch CSR put them (old_offs) to where
+// the new one wants them (new_offs): a trajectory's records are one contiguous range, and a range that is not regenerated
+// keeps its length.  src == dst (in place): ranges that move towards the front go first in ascending order, the others in
+// descending order, so that no range is overwritten before it has been moved (the CSR keeps the trajectories' order).
+static void relocate_records(const char *src, char *dst, size_t stride, int B, int dof, const std::vector<int> &old_offs,
+                             const std::vector<int> &new_offs, const std::vector<char> &regen)
+{
+    auto move = [&](int b) {
+        const size_t o = (size_t)old_offs[(size_t)b * dof], e = (size_t)old_offs[(size_t)(b + 1) * dof], w = (size_t)new_offs[(size_t)b * dof];
+        if (e > o && (src != dst || o != w)) std::memmove(dst + w * stride, src + o * stride, (e - o) * stride);
+    };
+    if (src != dst) { for (int b = 0; b < B; b++) if (!regen[b]) move(b); return; }
+    for (int b = 0; b < B; b++) if (!regen[b] && new_offs[(size_t)b * dof] < old_offs[(size_t)b * dof]) move(b);
+    for (int b = B - 1; b >= 0; b--) if (!regen[b] && new_offs[(size_t)b * dof] > old_offs[(size_t)b * dof]) move(b);
+}
+
 // STEP 1 for the trajectories in `who` (Optimiser::GenerateDerivatives, Optimiser.cpp:80-169): key-points and FD
-// on the host (every trajectory on its own persistent pool, all into ONE pinned job list), then the GPU
-// stages for the whole batch.  Trajectories not in `who` keep their device data.
+// on the host (every trajectory on its own persistent pool, all into ONE pinned slab), then the GPU
+// stages for the whole batch.  Trajectories not in `who` keep their linearisation: on a materialising context their key-point
+// columns stay in the step records at (b, t); on a fused context -- which holds no records, only the column store indexed by CSR
+// entry -- the host slab is the authoritative copy of every trajectory's payload and the WHOLE batch goes up key-point ordered.
 void iLQR_GPU_Batch::GenerateDerivatives(const std::vector<int> &who)
 {
     const int n = 2 * dof, m = num_ctrl;
@@ -165,17 +184,28 @@ void iLQR_GPU_Batch::GenerateDerivatives(const std::vector<int> &who)
         times.insert(times.end(), s.kp_times.begin(), s.kp_times.end());
     }
     // Fused sweeps take the payload KEY-POINT ORDERED (one record per CSR entry, written in place by the FD workers, no job
-    // lists: iLQR_GPU.cpp) when every record of the batch is valid afterwards: all trajectories regenerate, or the others'
-    // records still sit where the slab of the previous call left them (the batch CSR has not moved).
-    const bool kp_ordered = fused_active && ((int)who.size() == B || (!kp_slab_offs.empty() && kp_slab_offs == offs));
+    // lists: iLQR_GPU.cpp), ALWAYS: new key-points re-index the device's column store, so the records of the trajectories
+    // that do NOT regenerate (their last step was rejected, iLQR.cpp:419) must go up again too, at their NEW entry offsets --
+    // the adaptive methods move the counts of the regenerating trajectories and with them everybody else's offsets.  The
+    // host slab of the previous call holds those records; they are moved to their new places, `who` is filled in place.
+    // (Round 3 uploaded a job list of `who` alone when the CSR had moved: the others' entries then held stale or zero columns.)
+    const bool kp_ordered = fused_active;
     kpilqr_fdkp_layout lay = {};
     if (kp_ordered) {
         if ((rc = kpilqr_fd_kp_layout(ctx, offs.back(), &lay))) fatal("kpilqr_fd_kp_layout", rc);
-        if (lay.bytes > kp_slab_bytes) {                       // (a grown slab is refilled completely: who is everybody then)
-            if ((int)who.size() != B) fatal("key-point slab grew under a partial regeneration", -1);
-            if (kp_slab) kpilqr_host_free(ctx, kp_slab);
+        const bool partial = (int)who.size() != B;
+        if (partial && kp_slab_offs.empty()) fatal("partial regeneration before any complete one", -1);
+        std::vector<char> regen(B, 0);
+        for (int b : who) regen[b] = 1;
+        if (lay.bytes > kp_slab_bytes) {
+            char *old_slab = kp_slab;
             kp_slab_bytes = lay.bytes + lay.bytes / 4 + 4096;
+            kp_slab = nullptr;
             if ((rc = kpilqr_host_alloc(ctx, kp_slab_bytes, (void **)&kp_slab))) fatal("kpilqr_host_alloc", rc);
+            if (partial) relocate_records(old_slab, kp_slab, lay.entry_stride, B, dof, kp_slab_offs, offs, regen);
+            if (old_slab) kpilqr_host_free(ctx, old_slab);
+        } else if (partial && kp_slab_offs != offs) {
+            relocate_records(kp_slab, kp_slab, lay.entry_stride, B, dof, kp_slab_offs, offs, regen);
         }
     } else {
         int tot_jobs = 0, tot_kps = 0;

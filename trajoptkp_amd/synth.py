@@ -163,6 +163,9 @@ def make_problem(task="panda_reaching", T=3000, batch=1, min_N=5, config_id=2, d
         xplus=np.concatenate(xplus), xminus=np.concatenate(xminus), xnom=np.concatenate(xnom),
         r=r, r_x=r_x, r_u=r_u, w_run=np.asarray(cfg["w_run"], np.float64), w_term=np.asarray(cfg["w_term"], np.float64),
         u_nom=u_nom, ctrl_lim=ctrl_lim, A_kp=np.stack(A_kp_all), B_kp=np.stack(B_kp_all),
+        # the ONE residual Jacobian of the task when it has one (reaching: selector rows, r_u = 0 -- Reaching.cpp:43-54): what a
+        # host with analytic residuals gives kpilqr_upload_residual_jacobians_const instead of T+1 copies per trajectory
+        rx_const=(None if dense_residuals else r_x[0, 0].copy()),
     )
 
 
@@ -322,7 +325,7 @@ def make_ragged_problem(task, T, kp_rows, dyn=None, config_id=3, dense_residuals
         job_mode=np.concatenate(job_mode), job_nom=np.concatenate(job_nom),
         xplus=np.concatenate(xplus), xminus=np.concatenate(xminus), xnom=np.concatenate(xnom),
         r=r, r_x=r_x, r_u=r_u, w_run=np.asarray(cfg["w_run"], np.float64), w_term=np.asarray(cfg["w_term"], np.float64),
-        u_nom=u_nom, ctrl_lim=ctrl_lim,
+        u_nom=u_nom, ctrl_lim=ctrl_lim, rx_const=(None if dense_residuals else r_x[0, 0].copy()),
     )
 
 
@@ -393,9 +396,11 @@ def kp_ordered_payload(p):
     return xp, xm, mode
 
 
-def upload(engine, p, keypoints=True, kp_ordered=False):
+def upload(engine, p, keypoints=True, kp_ordered=False, rx_const=False):
     """Push a problem dict into an Engine (everything the GPU path needs to run one iteration).  kp_ordered: the FD
-    payload goes up key-point ordered (kpilqr_upload_fd_kp) instead of as job lists."""
+    payload goes up key-point ordered (kpilqr_upload_fd_kp) instead of as job lists.  rx_const: a problem whose residual
+    Jacobian is one constant matrix (p["rx_const"]) uploads THAT, once (kpilqr_upload_residual_jacobians_const), instead of
+    the per-step copies."""
     if keypoints:
         engine.set_keypoints_rows(p["kp_rows"])
     if kp_ordered:
@@ -406,6 +411,10 @@ def upload(engine, p, keypoints=True, kp_ordered=False):
         engine.upload_fd(p["job_b"], p["job_t"], p["job_col"], p["job_mode"], p["xplus"], p["xminus"],
                          job_nom=p["job_nom"], xnom=p["xnom"], eps=p["eps"])
     # a task without control residuals never uploads r_u (the context's buffer starts zeroed): include/kpilqr.h
-    engine.upload_residuals(p["r"], p["r_x"], p["r_u"] if np.any(p["r_u"]) else None, p["w_run"], p["w_term"])
+    if rx_const and p.get("rx_const") is not None:
+        engine.upload_residuals(p["r"], None, None, p["w_run"], p["w_term"])
+        engine.upload_residual_jacobians_const(p["rx_const"], None)
+    else:
+        engine.upload_residuals(p["r"], p["r_x"], p["r_u"] if np.any(p["r_u"]) else None, p["w_run"], p["w_term"])
     engine.upload_nominal(p["u_nom"], p["ctrl_lim"])
     engine.sync()
