@@ -347,3 +347,58 @@ def test_constant_residual_jacobians_mode_switches():
         assert np.array_equal(K, ref["K"]) and np.array_equal(cp, ref["cost"])
     # the arrays above are views of pinned allocations: they outlive the engine (Engine.pinned keeps the block alive)
     assert np.array_equal(K, ref["K"]) and int(st.sum()) == 0
+
+
+# ---- slope store (round 4): per-DoF lists walked on precomputed segment slopes ---------------------------------------------
+@pytest.mark.parametrize("payload", ["kp_ordered", "job_lists", "columns"])
+def test_per_dof_lists_walk_the_slope_store(payload, monkeypatch):
+    """One wave per trajectory, per-DoF (ragged) key-point lists: the general forms of both sweeps take segment start AND slope
+    from memory (k_kp_slopes: (next column - column) / gap, the IEEE quotient of KeyPointGenerator.cpp:898-905) -- reported as
+    ":ragged:...:slopes" -- and give, for every payload form, the gains of the oracle and bit for bit those of the wave pair /
+    triple, which still divide at the crossing.  Also through the chunk pipeline (every chunk makes the slopes of its own entries)."""
+    T, dof, B = 280, 7, 5
+    rng = np.random.default_rng(23)
+    dens = rng.uniform(0.03, 1.0, dof); dens[2] = 0.0; dens[5] = 1.0       # one DoF only at 0 and T-1, one at every step
+    rows = [synth.bisect_keypoints(rng, dof, T, 1, np.roll(dens, b)) for b in range(B)]
+    p = synth.make_ragged_problem("panda_reaching", T, rows, config_id=4, dense_residuals=True, one_sided_frac=0.25)
+    xp, xm, mode = synth.kp_ordered_payload(p)
+
+    def run(env):
+        for k_, v_ in env.items():
+            monkeypatch.setenv(k_, v_)
+        with Engine(p["dof"], p["m"], T, p["nr"], batch=B, fused=True) as e:
+            synth.upload(e, p, kp_ordered=payload != "job_lists")
+            if payload == "columns":
+                e.upload_kp_columns(e.kp_columns(xp, xm, mode, eps=p["eps"]))
+            e.iterate(p["lam"], 100, orc.alphas(6))
+            res = e.results(); K, k = e.gains()
+            out = dict(K=K, k=k, delta_J=res["delta_J"], cost=res["cost_pred"], lb=e.last_launch("backward"), lf=e.last_launch("forward"))
+        for k_ in env:
+            monkeypatch.delenv(k_)
+        return out
+
+    one = run({"KPILQR_FUSED_WAVES": "1", "KPILQR_FUSED_FWD_WAVES": "1"})
+    assert ":w1:kpc:ragged" in one["lb"] and one["lb"].endswith(":slopes") and one["lf"].endswith(":slopes"), (one["lb"], one["lf"])
+    trip = run({})                                              # B = 5: the triples (crossings divide)
+    assert ":triple:" in trip["lb"] and "slopes" not in trip["lb"]
+    for b in range(B):
+        o = pipeline.run_trajectory(p, b)
+        assert relerr(one["K"][b], o["K"]) < 1e-9 and relerr(one["cost"][b], o["cost_pred"]) < 1e-9
+        assert relerr(trip["K"][b], one["K"][b]) < 1e-11
+    if payload == "kp_ordered":
+        # the chunk pipeline: every chunk differences and makes the slopes of its own entry range
+        monkeypatch.setenv("KPILQR_FUSED_WAVES", "1"); monkeypatch.setenv("KPILQR_FUSED_FWD_WAVES", "1")
+        with Engine(p["dof"], p["m"], T, p["nr"], batch=B, fused=True) as e:
+            e.set_keypoints_rows(p["kp_rows"])
+            e.upload_residuals(None, None, None, p["w_run"], p["w_term"]); e.upload_nominal(None, p["ctrl_lim"])
+            e.forward_linear(orc.alphas(6), fetch=False)
+            s = e.fd_kp_slab(xp, xm, mode)
+            pin = {}
+            for name in ("r", "r_x", "r_u", "u_nom"):
+                pin[name] = e.pinned(p[name].shape); pin[name][...] = p[name]
+            lam = e.pinned(B); lam[:] = p["lam"]
+            K = e.pinned(one["K"].shape); cp = e.pinned((B, 6))
+            for _ in range(2):
+                e.iterate_streamed(fd_kp=s, eps=p["eps"], lam=lam, K=K, cost_pred=cp, nchunks=3, **pin)
+            e.sync()
+            assert np.array_equal(K, one["K"]) and np.array_equal(cp, one["cost"])

@@ -93,6 +93,15 @@ struct Ctx {
     size_t kpc_cap = 0;          // bytes
     bool kpc_valid = false;      // kpc holds ALL differenced columns of the resident FD payload for the current key-points
     bool kpc_touched = false;    // a raw backward sweep has (re)written kpc from the resident payload since it was uploaded
+    // slope store beside kpc (k_kp_slopes): kps [entry][3][n] = (column of the list's next key-point - this column) / (time gap), 0 for
+    // a list's last entry.  Read by the general (per-DoF list) forms of the one-wave sweeps; allocated only when the lists may be
+    // ragged (kp_known_uniform: the host has seen that every trajectory's DoFs share one list -- then the device flag says the same
+    // and only the segment-loop forms run)
+    double *kps = nullptr;
+    size_t kps_cap = 0;
+    bool kps_valid = false;      // kps holds the slopes of the columns kpc holds (kpc_valid)
+    bool kp_known_uniform = false;
+    int kp_view_entries = -1;    // a view of a trajectory range: the CSR entries of its trajectories (first: fdk_first); -1: the context
     int *kp_entry = nullptr;     // [batch*dof][T]: CSR entry of (list, t), or -1        (built with the segment map)
     int *kp_entry_list = nullptr;// [entries]: list (= b*dof + d) of a CSR entry
     size_t kp_entry_cap = 0, kp_entry_list_cap = 0;   // ints
@@ -198,6 +207,7 @@ hipError_t launch_fd_difference(Ctx *c);                 // job lists -> step re
 hipError_t launch_fd_difference_kpc(Ctx *c);             // job lists -> key-point column store
 hipError_t launch_fd_kp_difference(Ctx *c, bool only_if_ragged = false);   // key-point ordered payload -> key-point column store (only_if_ragged: leaves at once when the device flag kp_uniform is set)
 hipError_t launch_kpc_to_records(Ctx *c);                // key-point column store -> step records
+hipError_t launch_kp_slopes(Ctx *c, bool only_if_ragged = true);   // key-point column store -> slope store (per-DoF lists only)
 hipError_t launch_build_entry_tables(Ctx *c);            // kp_entry, kp_entry_list from the CSR lists
 hipError_t launch_copy_out(hipStream_t s, double *dst_host, const double *src_dev, size_t count);   // D2H by a kernel
 hipError_t launch_copy_in(hipStream_t s, void *dst_dev, const void *src_host, size_t bytes);        // H2D by a kernel

@@ -137,6 +137,8 @@ struct FusedArgs {
     double eps2, rinv_2eps;                        // 2 eps and the host's correctly rounded 1 / (2 eps): with it fdiv IS the IEEE
                                                    // quotient (eps and 1/eps are exact halves / doubles of them)
     const double *rx_const;                        // RXC: r_x [nr][n], the same for every trajectory and step (kpilqr_upload_residual_jacobians_const)
+    const double *kps;                             // slope store [entry][3][n] beside kpc: slope of every key-point column to the next
+                                                   // key-point of its DoF list (k_kp_slopes); read by the general (per-DoF list) forms
 };
 
 // ---- column tracker: lane (c,q) interpolates rows 4r+q of column c of A and of B ------------------------
@@ -344,13 +346,19 @@ __device__ __forceinline__ void backward_fused_body(double *sh, const double *pc
     int s = has ? F.kp_times[idx] : -1;                       // == T-1 for canonical key-points
     int nb = (has && idx - 1 >= lo) ? F.kp_times[idx - 1] : -1;      // the time of the next segment start, one crossing ahead
     double sv[8], av[8], pv[8];
+    // SLP (general form on a differenced column store): the SLOPE of the next segment is prefetched with its start column (pm),
+    // from the slope store k_kp_slopes wrote -- a crossing is then two register moves per value, no division on the wave's
+    // serial chain (8 correctly rounded divisions + a reciprocal per lane before: the whole wave paid them on every step on which
+    // ANY lane crossed, which with per-DoF lists is most steps)
+    constexpr bool SLP = !PC && !UNI && !RAW;
     // RAW: the prefetched column of the next segment start waits as x+ (in pv) and x- (pm) until the crossing differences it
     double pm[8];
     int pmode = 0;
     // the raw payload: ONE descriptor over the trajectory's records; x- sits 3n doubles behind x+ and the mode word behind both,
     // so they are the same per-lane offsets plus an immediate
     constexpr int strideR = (6 * N + 2) * 8, offM = 3 * N * 8, offMode = 6 * N * 8;
-    __amdgpu_buffer_rsrc_t rP = rT;
+    __amdgpu_buffer_rsrc_t rP = rT;                               // SLP: the trajectory's slice of the slope store
+    if constexpr (SLP) rP = frsrc(F.kps + (size_t)E0 * 3 * n, NE * strideB);
     const int bitA = (c < F.dof) ? 1 : 2;                         // mode bit of this lane's A column (position / velocity job)
     auto ebase = [&](int e_rel) { return ((unsigned)e_rel < (unsigned)NE) ? e_rel * strideB : BIGOFF; };
     auto load_raw = [&](int e_rel, double *xp_, double *xm_, int &mo) {
@@ -428,6 +436,7 @@ __device__ __forceinline__ void backward_fused_body(double *sh, const double *pc
         } else {
             load_col_n<N>(rT, co, ebase(e_s), sv);
             load_col_n<N>(rT, co, ebase(e_nb), pv);
+            if constexpr (SLP) load_col_n<N>(rP, co, ebase(e_nb), pm);
         }
 #pragma unroll
         for (int i = 0; i < 8; i++) av[i] = 0.0;
@@ -517,6 +526,14 @@ __device__ __forceinline__ void backward_fused_body(double *sh, const double *pc
         if constexpr (!UNI) {
             cross = t < s;
             if (cross) {
+                if constexpr (SLP) {
+                    // the new segment [nb, s): its start column and its slope were requested a crossing ago
+#pragma unroll
+                    for (int i = 0; i < 8; i++) {
+                        asm volatile("v_mov_b64 %0, %1" : "+v"(av[i]) : "v"(pm[i]));
+                        asm volatile("v_mov_b64 %0, %1" : "+v"(sv[i]) : "v"(pv[i]));
+                    }
+                } else {
                 if constexpr (RAW) { const KArgF Fk = kernarg_fused(); eps2 = Fk->eps2; rinv2 = Fk->rinv_2eps; }
                 const double den = (double)(s - nb);
                 const double rinv = kp_rcp(den);
@@ -528,6 +545,7 @@ __device__ __forceinline__ void backward_fused_body(double *sh, const double *pc
                     // land somewhere else, and the two arrays are copied back and forth -- behind a wait for every memory
                     // operation in flight -- on EVERY step of the sweep instead of at the crossings
                     asm volatile("v_mov_b64 %0, %1" : "+v"(sv[i]) : "v"(pv[i]));
+                }
                 }
                 idx--;
                 s = nb;
@@ -567,6 +585,10 @@ __device__ __forceinline__ void backward_fused_body(double *sh, const double *pc
                 const int e_nb = (idx - 1 >= lo) ? idx - 1 - E0 : -1;
                 if constexpr (RAW) load_raw(e_nb, pv, pm, pmode);
                 else load_col_n<N>(rT, co, ebase(e_nb), pv);
+                if constexpr (SLP) {
+                    rP = frsrc(Fk->kps + (size_t)E0 * 3 * n, NE * strideB);
+                    load_col_n<N>(rP, co, ebase(e_nb), pm);
+                }
             }
         }
         if constexpr (RAW && UNI) {
@@ -1691,12 +1713,22 @@ __device__ __forceinline__ void forward_fused_body(RecLayout L, FusedArgs F, int
     // Walking up, a segment is entered at its START key-point, where the stored value is exact and the slope is
     // not needed yet: the end column is requested at the crossing and the slope formed one step later
     // (`pend`), so no second prefetch buffer is held.
-    double sv[8], ev[8], av[8];
+    // General form (!UNI): the slope store of k_kp_slopes gives every segment's slope with its start column -- requested one
+    // crossing ahead (ev, ea), so a crossing is register moves and nothing is waited for at the step behind it.
+    double sv[8], ev[8], av[8], ea[8];
+    (void)ea;
+    __amdgpu_buffer_rsrc_t rS = rT;
     load_col(rT, co, has ? idx - E0 : -1, NE, strideB, sv);
     load_col(rT, co, (has && idx + 1 < khi) ? idx + 1 - E0 : -1, NE, strideB, ev);
     bool pend = true;
 #pragma unroll
     for (int i = 0; i < 8; i++) av[i] = 0.0;
+    if constexpr (!UNI) {
+        rS = frsrc(F.kps + (size_t)E0 * 3 * L.n, NE * strideB);
+        load_col(rS, co, has ? idx - E0 : -1, NE, strideB, av);
+        load_col(rS, co, (has && idx + 1 < khi) ? idx + 1 - E0 : -1, NE, strideB, ea);
+        pend = false;
+    }
     // the identity rows of Ya (alpha and the homogeneous 1 carry over): lanes c >= n walk no list
 #pragma unroll
     for (int r = 0; r < 4; r++) if ((c == n || c == n + 1) && 4 * r + q == c) sv[r] = 1.0;
@@ -1732,6 +1764,18 @@ __device__ __forceinline__ void forward_fused_body(RecLayout L, FusedArgs F, int
         Yb.z = NCU > 2 ? shB[c * 17 + 8 + q] : 0.0; Yb.w = NCU > 3 ? shB[c * 17 + 12 + q] : 0.0;
     };
     auto advance = [&](int t) {
+        if constexpr (!UNI) {
+            if (t >= e) {                     // per lane: reached the end key-point of the segment = the start of the next one
+#pragma unroll
+                for (int i = 0; i < 8; i++) { sv[i] = ev[i]; av[i] = ea[i]; }
+                s = e; e = nb; idx++;
+                const int en = (idx + 1 < khi) ? idx + 1 - E0 : -1;
+                load_col(rT, co, en, NE, strideB, ev);
+                load_col(rS, co, en, NE, strideB, ea);
+                nb = (idx + 2 < khi) ? F.kp_times[idx + 2] : BIGT;
+            }
+            return;
+        }
         if (pend) {                           // slope of the segment entered one step ago (its end column has landed)
             const double den = (double)(e - s);
             const double rinv = kp_rcp(den);
@@ -2221,7 +2265,7 @@ bool fused_supported(int n, int m, int nr, int dof, int T, int stride, int n_alp
 static FusedArgs fused_args(const Ctx *c)
 {
     FusedArgs F = {c->kp_offsets, c->kp_times, c->r, c->r_x, c->r_u, c->w_run, c->w_term, c->d.dof, c->d.nr,
-                   c->kpc, c->fdk_dev, 2 * c->eps, 1.0 / (2 * c->eps), c->rx_const};
+                   c->kpc, c->fdk_dev, 2 * c->eps, 1.0 / (2 * c->eps), c->rx_const, c->kps};
     return F;
 }
 
@@ -2256,6 +2300,7 @@ hipError_t launch_backward_fused(Ctx *c, int pd_stride, bool raw)
     c->last_bwd_form = form; c->last_bwd_raw = raw; c->last_bwd_ru0 = form == 1 && c->ru_zero;       // kpilqr_last_launch
     const bool rxc = form == 1 && c->ru_zero && c->rx_const_on;     // (the caller has materialised r_x for every other form)
     c->last_bwd_rxc = rxc;
+    c->last_bwd_slopes = form == 1 && c->kps != nullptr && !(raw && c->tune.fused_uni == 0);      // (what the general form walks, if it runs)
     const int role_shift = c->tune.role_shift;
     dim3 block2(128);
     if (form == 2) {
@@ -2321,6 +2366,7 @@ hipError_t launch_backward_fused(Ctx *c, int pd_stride, bool raw)
         if (raw && c->tune.fused_uni != 0) {                                                                            \
             LAUNCH4(NN, MM, RU, true, true);                                                                            \
             hipError_t e_ = launch_fd_kp_difference(c, true);                                                           \
+            if (e_ == hipSuccess) e_ = launch_kp_slopes(c, true);    /* (per-DoF lists: columns, then their slopes) */  \
             if (e_ != hipSuccess) return e_;                                                                            \
             LAUNCH4(NN, MM, RU, false, false);                                                                          \
         } else if (raw) LAUNCH3(NN, MM, RU, true);                                                                      \
@@ -2363,6 +2409,7 @@ hipError_t launch_forward_fused(Ctx *c, double *U_alpha_dev)
     c->last_fwd_form = form == 3 ? 4 : form == 2 ? 3 : 1; c->last_fwd_ru0 = form == 1 && c->ru_zero;      // kpilqr_last_launch: triple / pair / w1
     const bool rxc = form == 1 && c->ru_zero && c->rx_const_on;
     c->last_fwd_rxc = rxc;
+    c->last_fwd_slopes = form == 1 && c->kps != nullptr;
     const int ncz = (n + 2 + 3) / 4, ncu = (m + 3) / 4;       // tile chunks of [dx; alpha; 1] and of the controls
     if (form == 3) {
         dim3 block3(192);

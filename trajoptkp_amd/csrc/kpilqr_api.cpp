@@ -171,7 +171,29 @@ static int ensure_kpc(kpilqr_ctx *c)
     if (need <= c->kpc_cap) return KPILQR_OK;
     const int rc = grow_dev(c, (void **)&c->kpc, &c->kpc_cap, need + need / 4 + 4096, true);
     if (rc < 0) return rc;
-    if (rc > 0) c->kpc_valid = c->kpc_touched = false;
+    if (rc > 0) c->kpc_valid = c->kpc_touched = c->kps_valid = false;
+    return KPILQR_OK;
+}
+
+// the slope store beside kpc, same size -- only when the lists may be per-DoF (ragged): uniform sets never read it
+static int ensure_kps(kpilqr_ctx *c)
+{
+    if (c->kp_known_uniform) return KPILQR_OK;
+    const size_t need = kp_entries(c) * 3 * (size_t)c->n * 8;
+    if (need <= c->kps_cap) return KPILQR_OK;
+    const int rc = grow_dev(c, (void **)&c->kps, &c->kps_cap, need + need / 4 + 4096, false);
+    if (rc < 0) return rc;
+    c->kps_valid = false;
+    return KPILQR_OK;
+}
+
+// the slopes of the columns kpc holds (per-DoF lists: the general forms of the one-wave sweeps walk them; k_kp_slopes leaves at
+// once when the device says the set is uniform)
+static int slopes_for_kpc(kpilqr_ctx *c)
+{
+    if (c->kps_valid || c->kp_known_uniform || !c->kps) return KPILQR_OK;
+    KP_HIP(c, launch_kp_slopes(c, true));
+    c->kps_valid = true;
     return KPILQR_OK;
 }
 
@@ -201,6 +223,7 @@ static int difference_to_kpc(kpilqr_ctx *c)
     }
     int rc = ensure_kpc(c);
     if (rc) return rc;
+    c->kps_valid = false;
     if (c->fd_kind == 1) {
         rc = ensure_entry_tables(c);
         if (rc) return rc;
@@ -254,7 +277,7 @@ static int ensure_records(kpilqr_ctx *c)
 // a new FD payload or new key-points: whatever was derived from the old ones is stale
 static void payload_changed(kpilqr_ctx *c)
 {
-    c->kpc_valid = c->kpc_touched = false;
+    c->kpc_valid = c->kpc_touched = c->kps_valid = false;
     c->rec_synced = false;
 }
 
@@ -398,7 +421,7 @@ void kpilqr_destroy(kpilqr_ctx *c)
     void *ptrs[] = {c->rec, c->K, c->k, c->r, c->r_x, c->r_u, c->w_run, c->w_term, c->u_nom, c->ctrl_lim,
                     c->lambda, c->alphas, c->cost_pred, c->delta_J, c->traj_cost, c->status, c->segmap,
                     c->kp_offsets, c->kp_times, c->X_states, c->kp_thr, c->kp_mask, c->kp_count, c->ls8, c->fd_dev,
-                    c->stage, c->err_flag, c->kp_uniform, c->kpc, c->kp_entry, c->kp_entry_list, c->fdk_dev, c->rx_const};
+                    c->stage, c->err_flag, c->kp_uniform, c->kpc, c->kp_entry, c->kp_entry_list, c->fdk_dev, c->rx_const, c->kps};
     for (void *p : ptrs) if (p) (void)hipFree(p);
     if (c->err_flag_host) (void)hipHostFree(c->err_flag_host);
     if (c->kp_traj_first_host) free(c->kp_traj_first_host);
@@ -434,7 +457,7 @@ int kpilqr_resize(kpilqr_ctx *c, int new_dof, int new_num_ctrl, int new_horizon)
         (void)select_variants(c); (void)size_buffers(c);
         return set_err(c, rc, msg);
     }
-    c->have_kp = c->kp_canonical = c->have_states = false;
+    c->have_kp = c->kp_canonical = c->have_states = c->kp_known_uniform = false;
     c->njobs = c->nnom = 0;
     c->fd_kind = 0; c->fdk_entries = 0; c->entry_tables_valid = false; c->kp_total_host = -1;
     if (c->kp_traj_first_host) { free(c->kp_traj_first_host); c->kp_traj_first_host = nullptr; }
@@ -545,6 +568,16 @@ int kpilqr_set_keypoints(kpilqr_ctx *c, const int *kp_offsets, const int *kp_tim
         for (int j = a + 1; j < e; j++) if (kp_times[j] <= kp_times[j - 1]) { canonical = false; break; }
     }
     c->kp_canonical = canonical;
+    // every trajectory's DoFs share one list (set_interval): the device flag of k_kp_uniform will say the same, only the
+    // segment-loop forms of the sweeps run and no slope store is needed
+    bool uniform = true;
+    for (int b = 0; b < c->d.batch && uniform; b++) {
+        const int *o = kp_offsets + (size_t)b * c->d.dof;
+        const int len0 = o[1] - o[0];
+        for (int i = 1; i < c->d.dof && uniform; i++)
+            uniform = (o[i + 1] - o[i] == len0) && memcmp(kp_times + o[i], kp_times + o[0], sizeof(int) * (size_t)len0) == 0;
+    }
+    c->kp_known_uniform = uniform;
     if ((size_t)total > c->kp_cap) {
         if (c->kp_times) { KP_HIP(c, hipStreamSynchronize(c->stream)); KP_HIP(c, hipFree(c->kp_times)); c->kp_times = nullptr; }
         c->kp_cap = (size_t)total + (size_t)total / 4 + 64;
@@ -616,6 +649,7 @@ int kpilqr_generate_keypoints(kpilqr_ctx *c, const char *method, int min_N, int 
     KP_HIP(c, launch_generate_keypoints(c, mth, min_N, max_N, dt, thresholds ? c->kp_thr : nullptr, c->X_states, c->kp_mask, c->kp_count));
     KP_HIP(c, launch_build_segmap(c));
     c->have_kp = true;
+    c->kp_known_uniform = mth == 0;          // set_interval: one list for all DoFs; the other methods place per DoF
     c->kp_canonical = true;      // rows 0 and T-1 are always full and the lists are strictly increasing by construction
     // The lists exist on the device only (kpilqr_get_keypoints brings them to the host), but their TOTAL is read back here --
     // one int: the column store and the entry tables are sized from it (not from the worst case batch * dof * T: 7.2 GB
@@ -949,6 +983,8 @@ static int run_backward(kpilqr_ctx *c, int pd_stride)
         if (rc) return rc;
         rc = ensure_kpc(c);
         if (rc) return rc;
+        rc = ensure_kps(c);
+        if (rc) return rc;
         // Key-point ordered payload, one wave per trajectory or the producer / consumer pair: the sweep (its producer wave)
         // differences the payload itself and leaves kpc
         // behind for the forward sweep -- no differencing kernel.  (It may stop at a failed PD check, so it never marks
@@ -961,6 +997,7 @@ static int run_backward(kpilqr_ctx *c, int pd_stride)
             return KPILQR_OK;
         }
         if (!c->kpc_valid) { rc = difference_to_kpc(c); if (rc) return rc; }
+        if (c->kpc_valid) { rc = slopes_for_kpc(c); if (rc) return rc; }
         KP_HIP(c, launch_backward_fused(c, pd_stride, false));
         return KPILQR_OK;
     }
@@ -1000,6 +1037,9 @@ int kpilqr_backward_stats(kpilqr_ctx *c, int pd_check_stride, int *hist)
     rc = ensure_kpc(c);
     if (rc) return rc;
     if (!c->kpc_valid) { rc = difference_to_kpc(c); if (rc) return rc; }
+    rc = ensure_kps(c);
+    if (rc == KPILQR_OK && c->kpc_valid) rc = slopes_for_kpc(c);
+    if (rc) return rc;
     rc = ensure_rx_buffer(c);
     if (rc) return rc;
     const size_t bytes = (size_t)c->d.batch * 6 * sizeof(int);
@@ -1067,6 +1107,9 @@ static int run_forward(kpilqr_ctx *c, double *U_dev)
         if (rc) return rc;
         // kpc: differenced explicitly, or left behind by the raw backward sweep of this payload
         if (!c->kpc_valid && !c->kpc_touched) { rc = difference_to_kpc(c); if (rc) return rc; }
+        rc = ensure_kps(c);
+        if (rc) return rc;
+        if (c->kpc_valid) { rc = slopes_for_kpc(c); if (rc) return rc; }       // (behind a raw backward sweep: its launch sequence made them)
         KP_HIP(c, launch_forward_fused(c, U_dev));
         return KPILQR_OK;
     }
@@ -1142,6 +1185,7 @@ static void make_view(const kpilqr_ctx *c, int b0, int nb, hipStream_t s, kpilqr
     v->r += o * (T + 1) * nr; v->r_x += o * (T + 1) * nr * n; v->r_u += o * (T + 1) * nr * m;
     v->u_nom += o * T * m; v->lambda += o; v->cost_pred += o * na; v->delta_J += o; v->traj_cost += o; v->status += o;
     v->segmap += o * dof * T; v->kp_offsets += o * dof;
+    if (c->kp_traj_first_host) { v->fdk_first = c->kp_traj_first_host[b0]; v->kp_view_entries = c->kp_traj_first_host[b0 + nb] - v->fdk_first; }
     long long share = (long long)c->n_simd * nb / c->d.batch;
     v->n_simd = share < 4 ? 4 : (int)share;
 }
@@ -1245,6 +1289,12 @@ int kpilqr_iterate_streamed(kpilqr_ctx *c, const kpilqr_stream_io *io, int pd_ch
         rc = ensure_kpc(c); if (rc) return rc;
         rc = ensure_entry_tables(c); if (rc) return rc;
     }
+    if (c->fused) {
+        // per-DoF lists: a chunk computes the slopes of ITS entries, whose range only the host copy of the lists gives
+        if (!c->kp_known_uniform && !c->kp_traj_first_host)
+            return set_err(c, KPILQR_ERR_STATE, "kpilqr_iterate_streamed with per-DoF key-point lists: the lists must be known to the host (kpilqr_set_keypoints, or kpilqr_get_keypoints after generating them)");
+        rc = ensure_kps(c); if (rc) return rc;
+    }
     // No new payload, but the column store of the resident one is stale (key-points changed since a job-list upload): a chunk
     // view has no jobs (its njobs is 0), so the payload is re-differenced HERE, on the context, for the whole batch -- what
     // kpilqr_iterate would do.  (A key-point ordered payload is dropped by new key-points; the chunks handle a resident one.)
@@ -1260,7 +1310,7 @@ int kpilqr_iterate_streamed(kpilqr_ctx *c, const kpilqr_stream_io *io, int pd_ch
     // later kpilqr_sync / kpilqr_destroy waits for the DMAs that read the caller's buffers
     c->pipe_dirty = true;
 
-    bool vflags_valid = c->kpc_valid, vflags_touched = c->kpc_touched;
+    bool vflags_valid = c->kpc_valid, vflags_touched = c->kpc_touched, vflags_slopes = c->kps_valid;
     for (int ch = 0; ch < nchunks; ch++) {
         const int b0 = (int)((long long)B * ch / nchunks), b1 = (int)((long long)B * (ch + 1) / nchunks), nb = b1 - b0;
         if (nb <= 0) continue;
@@ -1323,7 +1373,7 @@ int kpilqr_iterate_streamed(kpilqr_ctx *c, const kpilqr_stream_io *io, int pd_ch
         if (rc) { c->err = v.err; return rc; }
         rc = run_forward(&v, nullptr);
         if (rc) { c->err = v.err; return rc; }
-        vflags_valid = v.kpc_valid; vflags_touched = v.kpc_touched;
+        vflags_valid = v.kpc_valid; vflags_touched = v.kpc_touched; vflags_slopes = v.kps_valid;
         c->last_bwd_form = v.last_bwd_form; c->last_fwd_form = v.last_fwd_form; c->last_bwd_raw = v.last_bwd_raw;
         c->last_bwd_ru0 = v.last_bwd_ru0; c->last_fwd_ru0 = v.last_fwd_ru0; c->last_bwd_rxc = v.last_bwd_rxc; c->last_fwd_rxc = v.last_fwd_rxc;
         c->last_bwd_slopes = v.last_bwd_slopes; c->last_fwd_slopes = v.last_fwd_slopes;
@@ -1340,7 +1390,7 @@ int kpilqr_iterate_streamed(kpilqr_ctx *c, const kpilqr_stream_io *io, int pd_ch
         if (io->delta_J) KP_HIP(c, hipMemcpyAsync(io->delta_J + o, v.delta_J, cnt * 8, hipMemcpyDeviceToHost, s));
         if (io->status) KP_HIP(c, hipMemcpyAsync(io->status + o, v.status, cnt * 4, hipMemcpyDeviceToHost, s));
     }
-    c->kpc_valid = vflags_valid; c->kpc_touched = vflags_touched;       // what every chunk did to its slice of kpc
+    c->kpc_valid = vflags_valid; c->kpc_touched = vflags_touched; c->kps_valid = vflags_slopes;      // what every chunk did to its slice of kpc
     return KPILQR_OK;
 }
 
@@ -1474,7 +1524,7 @@ const char *kpilqr_last_launch(kpilqr_ctx *c, int which)
     out += uni ? ":uni" : ":ragged";
     if (which == 0 ? c->last_bwd_ru0 : c->last_fwd_ru0) out += ":ru0";
     if (which == 0 ? c->last_bwd_rxc : c->last_fwd_rxc) out += ":rxc";
-    if (which == 0 ? c->last_bwd_slopes : c->last_fwd_slopes) out += ":slopes";
+    if (!uni && (which == 0 ? c->last_bwd_slopes : c->last_fwd_slopes)) out += ":slopes";
     return out.c_str();
 }
 
