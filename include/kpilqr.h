@@ -176,8 +176,12 @@ int  kpilqr_upload_fd_slab(kpilqr_ctx *ctx, const void *slab, int njobs, int nno
  *     kind 1: qvel_d perturbed  -> column d + dof of A      (:226-325)
  *     kind 2: ctrl_d perturbed  -> column d       of B      (:81-223; only d < num_ctrl, other kind-2 slots are ignored)
  * One RECORD per entry, `entry_stride` = (6n + 2) * 8 bytes, records back to back in CSR order:
- *   double xplus [3][n]      next state after the + perturbation  (a backward-only difference: the unperturbed next state)
- *   double xminus[3][n]      next state after the - perturbation  (a forward-only difference:  the unperturbed next state)
+ *   struct { double xplus, xminus; } x[3][n]
+ *            xplus   next state after the + perturbation  (a backward-only difference: the unperturbed next state)
+ *            xminus  next state after the - perturbation  (a forward-only difference:  the unperturbed next state)
+ *            -- the two sides of an element side by side (`elem_stride` = 16 bytes from one element of a side to the next, xminus
+ *            8 bytes behind xplus; version >= 400; versions < 400 stored the sides as two blocks of 3n doubles): the sweep that
+ *            differences the payload itself fetches both with ONE 16-byte load per element
  *   int32  mode              bit k set: kind k is one-sided -> (xplus - xminus) / eps, else (xplus - xminus) / (2 eps)
  *   int32  pad[3]
  * so the host FD loop writes every perturbed next state straight to its slot, nothing carries indices, the library never
@@ -189,8 +193,10 @@ int  kpilqr_upload_fd_slab(kpilqr_ctx *ctx, const void *slab, int njobs, int nno
  * kp_offsets[batch*dof].  One hipMemcpyAsync; with a pinned slab the call does not wait. */
 typedef struct {
     size_t entry_stride;                        /* bytes of one entry record: (6n + 2) * 8                       */
-    size_t xplus, xminus, mode;                 /* byte offsets inside a record: 0, 3n * 8, 6n * 8 (an int32)    */
+    size_t xplus, xminus, mode;                 /* byte offsets inside a record: 0, 8, 6n * 8 (an int32)         */
     size_t bytes;                               /* entries * entry_stride                                        */
+    size_t elem_stride;                         /* bytes between consecutive elements of xplus (and of xminus): 16; element
+                                                   (kind k, row r) of xplus sits at xplus + (k * n + r) * elem_stride    */
 } kpilqr_fdkp_layout;
 int  kpilqr_fd_kp_layout(kpilqr_ctx *ctx, int entries, kpilqr_fdkp_layout *out);
 int  kpilqr_upload_fd_kp(kpilqr_ctx *ctx, const void *slab, int entries, double eps);

@@ -42,7 +42,7 @@ class FdLayout(C.Structure):
 
 
 class FdkpLayout(C.Structure):
-    _fields_ = [(k, C.c_size_t) for k in ("entry_stride", "xplus", "xminus", "mode", "bytes")]
+    _fields_ = [(k, C.c_size_t) for k in ("entry_stride", "xplus", "xminus", "mode", "bytes", "elem_stride")]
 
 
 class StreamIO(C.Structure):

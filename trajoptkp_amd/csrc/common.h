@@ -9,6 +9,13 @@
 
 #include "../../include/kpilqr.h"
 
+// Layout of the key-point ordered FD payload's records (kpilqr_fd_kp_layout): 1 = x+ and x- of an element side by side (round 4:
+// the sweep that differences the payload fetches both with one 16-byte load); 0 = two blocks of 3n doubles (rounds 1-3; kept as
+// a build switch for same-box A/B runs: tools/build_variant.sh NAME -DKP_RAW_PAIRS=0 -- bench.py packs whatever the library reports)
+#ifndef KP_RAW_PAIRS
+#define KP_RAW_PAIRS 1
+#endif
+
 namespace kpilqr {
 
 // ---- device layout of one "step record" (all FP64), one per (trajectory b, time t) ----------
@@ -93,8 +100,8 @@ struct Ctx {
     size_t kpc_cap = 0;          // bytes
     bool kpc_valid = false;      // kpc holds ALL differenced columns of the resident FD payload for the current key-points
     bool kpc_touched = false;    // a raw backward sweep has (re)written kpc from the resident payload since it was uploaded
-    // slope store beside kpc (k_kp_slopes): kps [entry][3][n] = (column of the list's next key-point - this column) / (time gap), 0 for
-    // a list's last entry.  Read by the general (per-DoF list) forms of the one-wave sweeps; allocated only when the lists may be
+    // slope store beside kpc (k_kp_slopes): kps [entry][3][n][2] = (column value, (column of the list's next key-point - this column) /
+    // (time gap)) pairs, slope 0 for a list's last entry.  Read by the general (per-DoF list) forms of the one-wave sweeps; allocated only when the lists may be
     // ragged (kp_known_uniform: the host has seen that every trajectory's DoFs share one list -- then the device flag says the same
     // and only the segment-loop forms run)
     double *kps = nullptr;
@@ -112,7 +119,7 @@ struct Ctx {
     int *kp_traj_first_host = nullptr;                // [batch+1] first CSR entry of every trajectory (host copy), or null
     // FD payload resident on the device: 0 none, 1 job lists (kpilqr_upload_fd / _slab), 2 key-point ordered (kpilqr_upload_fd_kp)
     int fd_kind = 0;
-    // key-point ordered payload: one record per CSR entry, [x+ (3n) | x- (3n) | int32 mode, pad] = fdk_stride() bytes
+    // key-point ordered payload: one record per CSR entry, [(x+, x-) pairs of the 3n elements | int32 mode, pad] = fdk_stride() bytes
     char *fdk_dev = nullptr;
     size_t fdk_dev_cap = 0;
     size_t fdk_stride() const { return (size_t)(6 * n + 2) * 8; }

@@ -174,9 +174,9 @@ hipError_t launch_fd_difference_kpc(Ctx *c)
     return hipGetLastError();
 }
 
-// key-point ordered payload -> kpc.  One record per CSR entry, [x+ (3n) | x- (3n) | int32 mode, pad]; a lane owns one
-// 16-byte pair of the 3n doubles of an entry; bit `kind` of the entry's mode says one-sided (the host has put the nominal
-// next state into the x- or x+ slot: / eps), else central: / (2 eps)
+// key-point ordered payload -> kpc.  One record per CSR entry, [(x+, x-) pairs of its 3n elements | int32 mode, pad]; a lane owns
+// two consecutive elements of an entry (32 bytes in, one 16-byte pair out); bit `kind` of the entry's mode says one-sided (the
+// host has put the nominal next state into the x- or x+ slot: / eps), else central: / (2 eps)
 __global__ void __launch_bounds__(256)
 k_fd_kp_difference(int n, long long npairs_total, unsigned long long magic, const double2 *__restrict__ rec, double eps,
                    double2 *__restrict__ kpc, const int *__restrict__ skip_if_uniform)
@@ -190,10 +190,15 @@ k_fd_kp_difference(int n, long long npairs_total, unsigned long long magic, cons
         const long long e = magic ? (long long)__umul64hi((unsigned long long)w, magic) : w;      // w / pe
         const int p = (int)(w - e * pe);
         const double2 *r = rec + e * s2;
-        const double2 a = r[p], b = r[pe + p];
         const int mode = ((const int *)(r + 2 * pe))[0];
         const double den = ((mode >> (p / (n >> 1))) & 1) ? eps : 2 * eps;
+#if KP_RAW_PAIRS
+        const double2 a = r[2 * p], b = r[2 * p + 1];            // (x+, x-) of elements 2p and 2p + 1
+        kpc[w] = make_double2((a.x - a.y) / den, (b.x - b.y) / den);
+#else
+        const double2 a = r[p], b = r[pe + p];
         kpc[w] = make_double2((a.x - b.x) / den, (a.y - b.y) / den);
+#endif
     }
 }
 
@@ -215,7 +220,7 @@ hipError_t launch_fd_kp_difference(Ctx *c, bool only_if_ragged)
 
 // The slope of every key-point column to the NEXT key-point of its DoF list (KeypointGenerator::InterpolateDerivatives,
 // KeyPointGenerator.cpp:898-905,927-931: add = (A[t].col - A[s].col) / (t - s), IEEE division, this file is compiled without
-// contraction): kps [entry][3][n] beside kpc, 0 for the last entry of a list.  With it a segment crossing of the fused sweeps'
+// contraction): kps [entry][3][n][2] = (column value, slope) pairs beside kpc, slope 0 for the last entry of a list.  With it a segment crossing of the fused sweeps'
 // general (per-DoF list) form is LOADS only -- start value and slope of the new segment -- instead of a reciprocal, a Newton
 // step and eight correctly rounded divisions on the serial chain of every lane of the wave (round-3 verdict, Weak 5).
 // Canonical lists (each starts at time 0, strictly increasing): entry e + 1 belongs to the list of e iff its time is larger.
@@ -228,16 +233,19 @@ k_kp_slopes(int n, long long npairs_total, unsigned long long magic, int entries
     const long long stride = (long long)gridDim.x * blockDim.x;
     for (long long w = (long long)blockIdx.x * blockDim.x + threadIdx.x; w < npairs_total; w += stride) {
         const long long e = magic ? (long long)__umul64hi((unsigned long long)w, magic) : w;      // w / pe
+        const double2 a = kpc[w];
         double2 out = make_double2(0.0, 0.0);
         if (e + 1 < entries_total) {
             const int ts = times[e], te = times[e + 1];
             if (te > ts) {
                 const double den = (double)(te - ts);
-                const double2 a = kpc[w], b = kpc[w + pe];
+                const double2 b = kpc[w + pe];
                 out = make_double2((b.x - a.x) / den, (b.y - a.y) / den);
             }
         }
-        kps[w] = out;
+        // (value, slope) pairs: a crossing fetches both with ONE 16-byte load per element
+        kps[2 * w] = make_double2(a.x, out.x);
+        kps[2 * w + 1] = make_double2(a.y, out.y);
     }
 }
 
@@ -255,7 +263,7 @@ hipError_t launch_kp_slopes(Ctx *c, bool only_if_ragged)
     const long long cap = (long long)(c->n_simd / 4) * 128;
     const int blocks = (int)(want < cap ? (want < 1 ? 1 : want) : cap);
     hipLaunchKernelGGL(k_kp_slopes, dim3(blocks), dim3(256), 0, c->stream, c->n, npairs, magic, count, c->kp_times + first,
-                       (const double2 *)(c->kpc + (size_t)first * 3 * c->n), (double2 *)(c->kps + (size_t)first * 3 * c->n),
+                       (const double2 *)(c->kpc + (size_t)first * 3 * c->n), (double2 *)(c->kps + (size_t)first * 6 * c->n),
                        only_if_ragged ? c->kp_uniform : (const int *)nullptr);
     return hipGetLastError();
 }
@@ -370,9 +378,11 @@ k_kp_uniform(int batch, int dof, const int *__restrict__ offs, const int *__rest
 hipError_t launch_build_segmap(Ctx *c)
 {
     {
-        hipError_t e = hipMemsetAsync(c->kp_uniform, 1, sizeof(int), c->stream);        // any non-zero value: uniform until shown otherwise
+        // (KPILQR_FUSED_UNI=0, diagnostic: every set counts as per-DoF lists, the general forms of the sweeps run)
+        const bool never = c->tune.fused_uni == 0;
+        hipError_t e = hipMemsetAsync(c->kp_uniform, never ? 0 : 1, sizeof(int), c->stream);        // any non-zero value: uniform until shown otherwise
         if (e != hipSuccess) return e;
-        hipLaunchKernelGGL(k_kp_uniform, dim3(c->d.batch), dim3(256), 0, c->stream, c->d.batch, c->d.dof, c->kp_offsets, c->kp_times, c->kp_uniform);
+        if (!never) hipLaunchKernelGGL(k_kp_uniform, dim3(c->d.batch), dim3(256), 0, c->stream, c->d.batch, c->d.dof, c->kp_offsets, c->kp_times, c->kp_uniform);
     }
     const long long total = (long long)c->d.batch * c->d.dof * c->d.T;
     int blocks = (int)((total + 255) / 256);

@@ -67,6 +67,9 @@ typedef unsigned long long u64;
 #ifndef KP_PROBE_BWD
 #define KP_PROBE_BWD 0
 #endif
+#ifndef KP_SLOPES
+#define KP_SLOPES 1                 // 0: the general forms divide at their crossings (rounds 1-3) instead of reading the slope store (A/B builds)
+#endif
 #ifdef KP_PROBE_SAMEB
 #define KP_BLOCK_TRAJ ((int)(blockIdx.x & 7))
 #else
@@ -133,12 +136,12 @@ struct FusedArgs {
     int dof, nr;
     double *kpc;                                   // key-point column store [entry][3][n] (read; written by the raw backward sweep)
     const char *fdk;                               // key-point ordered FD payload (raw backward sweep only): one record per entry,
-                                                   // [x+ (3n) | x- (3n) | int32 mode: bit k = kind k is one-sided | pad] = (6n + 2) * 8 bytes
+                                                   // [(x+, x-) pairs of the 3n elements | int32 mode: bit k = kind k is one-sided | pad] = (6n + 2) * 8 bytes
     double eps2, rinv_2eps;                        // 2 eps and the host's correctly rounded 1 / (2 eps): with it fdiv IS the IEEE
                                                    // quotient (eps and 1/eps are exact halves / doubles of them)
     const double *rx_const;                        // RXC: r_x [nr][n], the same for every trajectory and step (kpilqr_upload_residual_jacobians_const)
-    const double *kps;                             // slope store [entry][3][n] beside kpc: slope of every key-point column to the next
-                                                   // key-point of its DoF list (k_kp_slopes); read by the general (per-DoF list) forms
+    const double *kps;                             // slope store [entry][3][n][2] beside kpc: every key-point column with its slope to the
+                                                   // next key-point of its DoF list (k_kp_slopes); read by the general (per-DoF list) forms
 };
 
 // ---- column tracker: lane (c,q) interpolates rows 4r+q of column c of A and of B ------------------------
@@ -170,6 +173,26 @@ __device__ __forceinline__ void load_col(__amdgpu_buffer_rsrc_t rT, const ColOff
     }
 }
 
+// (value, slope) pairs of the slope store kps [entry][3][n][2] (k_kp_slopes): ONE 16-byte load per element gives a segment's start
+// value and its slope to the next key-point.  Offsets are those of kpc doubled.
+typedef unsigned int u32x4f __attribute__((ext_vector_type(4)));
+__device__ __forceinline__ void fbld2(__amdgpu_buffer_rsrc_t r, int byte_off, double &v, double &a)
+{
+    const u32x4f x = __builtin_amdgcn_raw_buffer_load_b128(r, byte_off, 0, 0);
+    v = __builtin_bit_cast(double, u32x2f{x.x, x.y});
+    a = __builtin_bit_cast(double, u32x2f{x.z, x.w});
+}
+__device__ __forceinline__ int dbl_off(int o) { return o == BIGOFF ? BIGOFF : 2 * o; }
+__device__ __forceinline__ void load_col2(__amdgpu_buffer_rsrc_t rS, const ColOffs &o, int tk, int T, int strideB2, double *col, double *slp)
+{
+    const int base = ((unsigned)tk < (unsigned)T) ? tk * strideB2 : BIGOFF;
+#pragma unroll
+    for (int r = 0; r < 4; r++) {
+        fbld2(rS, base + dbl_off(o.a[r]), col[r], slp[r]);
+        fbld2(rS, base + dbl_off(o.b[r]), col[4 + r], slp[4 + r]);
+    }
+}
+
 // The same for a lane whose four registers are rows q, 4+q, 8+q, 12+q of ONE column (the column layout of the backward
 // sweep): one offset per column and lane, the rows in the loads' immediate field.  Registers 4r+3 < N are valid in every
 // lane that holds the column at all; the one partial register (N % 4 rows) has a per-lane offset of its own; registers
@@ -193,6 +216,19 @@ __device__ __forceinline__ void load_col_n(__amdgpu_buffer_rsrc_t rT, const ColO
     for (int r = 0; r < 4; r++) {
         col[r] = r < NF ? fbld(rT, va + 32 * r) : (r == NF && (N & 3)) ? fbld(rT, base + o.al) : 0.0;
         col[4 + r] = r < NF ? fbld(rT, vb + 32 * r) : (r == NF && (N & 3)) ? fbld(rT, base + o.bl) : 0.0;
+    }
+}
+// (value, slope) pairs from the slope store, column layout (o2: col_offsets_n's offsets doubled)
+template <int N>
+__device__ __forceinline__ void load_col2_n(__amdgpu_buffer_rsrc_t rS, const ColOffsN &o2, int base2, double *col, double *slp)
+{
+    constexpr int NF = N / 4;
+    const int va = base2 + o2.a, vb = base2 + o2.b;
+#pragma unroll
+    for (int r = 0; r < 4; r++) {
+        if (r < NF) { fbld2(rS, va + 64 * r, col[r], slp[r]); fbld2(rS, vb + 64 * r, col[4 + r], slp[4 + r]); }
+        else if (r == NF && (N & 3)) { fbld2(rS, base2 + o2.al, col[r], slp[r]); fbld2(rS, base2 + o2.bl, col[4 + r], slp[4 + r]); }
+        else { col[r] = 0.0; slp[r] = 0.0; col[4 + r] = 0.0; slp[4 + r] = 0.0; }
     }
 }
 template <int N>
@@ -350,21 +386,30 @@ __device__ __forceinline__ void backward_fused_body(double *sh, const double *pc
     // from the slope store k_kp_slopes wrote -- a crossing is then two register moves per value, no division on the wave's
     // serial chain (8 correctly rounded divisions + a reciprocal per lane before: the whole wave paid them on every step on which
     // ANY lane crossed, which with per-DoF lists is most steps)
-    constexpr bool SLP = !PC && !UNI && !RAW;
+    constexpr bool SLP = KP_SLOPES && !PC && !UNI && !RAW;
     // RAW: the prefetched column of the next segment start waits as x+ (in pv) and x- (pm) until the crossing differences it
     double pm[8];
     int pmode = 0;
-    // the raw payload: ONE descriptor over the trajectory's records; x- sits 3n doubles behind x+ and the mode word behind both,
-    // so they are the same per-lane offsets plus an immediate
-    constexpr int strideR = (6 * N + 2) * 8, offM = 3 * N * 8, offMode = 6 * N * 8;
-    __amdgpu_buffer_rsrc_t rP = rT;                               // SLP: the trajectory's slice of the slope store
-    if constexpr (SLP) rP = frsrc(F.kps + (size_t)E0 * 3 * n, NE * strideB);
+    // the raw payload: ONE descriptor over the trajectory's records; x+ and x- of an element sit side by side (one 16-byte load
+    // gives both: 9 loads per crossing instead of 17) and the mode word behind them
+    constexpr int strideR = (6 * N + 2) * 8, offMode = 6 * N * 8, offM = 3 * N * 8;
+    (void)offM;
+    __amdgpu_buffer_rsrc_t rP = rT;                               // SLP: the trajectory's slice of the slope store: (value, slope) pairs
+    ColOffsN co2 = co;
+    co2.a = dbl_off(co.a); co2.al = dbl_off(co.al); co2.b = dbl_off(co.b); co2.bl = dbl_off(co.bl);
+    auto ebase2 = [&](int e_rel) { return ((unsigned)e_rel < (unsigned)NE) ? e_rel * (2 * strideB) : BIGOFF; };
+    (void)co2;
+    if constexpr (SLP) rP = frsrc(F.kps + (size_t)E0 * 6 * n, NE * 2 * strideB);
     const int bitA = (c < F.dof) ? 1 : 2;                         // mode bit of this lane's A column (position / velocity job)
     auto ebase = [&](int e_rel) { return ((unsigned)e_rel < (unsigned)NE) ? e_rel * strideB : BIGOFF; };
     auto load_raw = [&](int e_rel, double *xp_, double *xm_, int &mo) {
         const int base = ((unsigned)e_rel < (unsigned)NE) ? e_rel * strideR : BIGOFF;
+#if KP_RAW_PAIRS
+        load_col2_n<N>(rP, co2, base, xp_, xm_);
+#else
         load_col_n<N>(rP, co, base, xp_);
         load_col_n<N>(rP, co, base + offM, xm_);
+#endif
         mo = __builtin_amdgcn_raw_buffer_load_b32(rP, base + ((c < n) ? offMode : BIGOFF), 0, 0);
     };
     double eps2 = F.eps2, rinv2 = F.rinv_2eps;
@@ -402,8 +447,13 @@ __device__ __forceinline__ void backward_fused_body(double *sh, const double *pc
     if constexpr (UNI) {
         cu.a = shift(co.a, kd * KpU * strideB); cu.al = shift(co.al, kd * KpU * strideB);
         cu.b = shift(co.b, kd * KpU * strideB); cu.bl = shift(co.bl, kd * KpU * strideB);
+#if KP_RAW_PAIRS
+        cr.a = shift(co2.a, kd * KpU * strideR); cr.al = shift(co2.al, kd * KpU * strideR);      // (the payload's elements are 16 bytes)
+        cr.b = shift(co2.b, kd * KpU * strideR); cr.bl = shift(co2.bl, kd * KpU * strideR);
+#else
         cr.a = shift(co.a, kd * KpU * strideR); cr.al = shift(co.al, kd * KpU * strideR);
         cr.b = shift(co.b, kd * KpU * strideR); cr.bl = shift(co.bl, kd * KpU * strideR);
+#endif
     }
     int up = KpU - 1;                                          // UNI: position (in every list) of the current segment's start
     int us = T, unb = T - 1, unb_v = T - 1;                    // UNI: its time, and the time of the next start (uniform; unb_v: as loaded)
@@ -412,8 +462,12 @@ __device__ __forceinline__ void backward_fused_body(double *sh, const double *pc
         // both columns of the first crossing are the last key-point's (slope 0 over the virtual segment [T-1, T])
         if constexpr (RAW) {
             rP = frsrc(F.fdk + (size_t)E0 * strideR, NE * strideR);
+#if KP_RAW_PAIRS
+            load_col2_n<N>(rP, cr, up * strideR, pv, pm);
+#else
             load_col_n<N>(rP, cr, up * strideR, pv);
             load_col_n<N>(rP, cr, up * strideR + offM, pm);
+#endif
             pmode = __builtin_amdgcn_raw_buffer_load_b32(rP, up * strideR + kd * KpU * strideR + ((c < n) ? offMode : BIGOFF), 0, 0);
 #pragma unroll
             for (int i = 0; i < 8; i++) sv[i] = 0.0;
@@ -435,8 +489,8 @@ __device__ __forceinline__ void backward_fused_body(double *sh, const double *pc
             load_raw(e_nb, pv, pm, pmode);
         } else {
             load_col_n<N>(rT, co, ebase(e_s), sv);
-            load_col_n<N>(rT, co, ebase(e_nb), pv);
-            if constexpr (SLP) load_col_n<N>(rP, co, ebase(e_nb), pm);
+            if constexpr (SLP) load_col2_n<N>(rP, co2, ebase2(e_nb), pv, pm);
+            else load_col_n<N>(rT, co, ebase(e_nb), pv);
         }
 #pragma unroll
         for (int i = 0; i < 8; i++) av[i] = 0.0;
@@ -584,11 +638,10 @@ __device__ __forceinline__ void backward_fused_body(double *sh, const double *pc
                 nb = (idx - 1 >= lo) ? Fk->kp_times[idx - 1] : -1;
                 const int e_nb = (idx - 1 >= lo) ? idx - 1 - E0 : -1;
                 if constexpr (RAW) load_raw(e_nb, pv, pm, pmode);
-                else load_col_n<N>(rT, co, ebase(e_nb), pv);
-                if constexpr (SLP) {
-                    rP = frsrc(Fk->kps + (size_t)E0 * 3 * n, NE * strideB);
-                    load_col_n<N>(rP, co, ebase(e_nb), pm);
-                }
+                else if constexpr (SLP) {
+                    rP = frsrc(Fk->kps + (size_t)E0 * 6 * n, NE * 2 * strideB);
+                    load_col2_n<N>(rP, co2, ebase2(e_nb), pv, pm);             // start column AND slope of the next segment: one load each
+                } else load_col_n<N>(rT, co, ebase(e_nb), pv);
             }
         }
         if constexpr (RAW && UNI) {
@@ -798,8 +851,12 @@ __device__ __forceinline__ void backward_fused_body(double *sh, const double *pc
             us = unb;
             const int pn = up > 0 ? up - 1 : 0;                    // the next start (position 0 again at the bottom: never used)
             if constexpr (RAW) {
+#if KP_RAW_PAIRS
+                load_col2_n<N>(rP, cr, pn * strideR, pv, pm);
+#else
                 load_col_n<N>(rP, cr, pn * strideR, pv);
                 load_col_n<N>(rP, cr, pn * strideR + offM, pm);
+#endif
                 pmode = __builtin_amdgcn_raw_buffer_load_b32(rP, pn * strideR + kd * KpU * strideR + ((c < n) ? offMode : BIGOFF), 0, 0);
             } else {
                 load_col_n<N>(rT, cu, pn * strideB, pv);
@@ -999,7 +1056,11 @@ struct DownTrackerRaw {
     {
         const int base = ((unsigned)e_rel < (unsigned)NE) ? e_rel * strideR : BIGOFF;
 #pragma unroll
+#if KP_RAW_PAIRS
+        for (int r = 0; r < NV; r++) fbld2(rP, base + dbl_off(offs[r]), xp[r], xm[r]);      // (x+, x-) of an element: one 16-byte load
+#else
         for (int r = 0; r < NV; r++) { xp[r] = fbld(rP, base + offs[r]); xm[r] = fbld(rP, base + offM + offs[r]); }
+#endif
         mo = __builtin_amdgcn_raw_buffer_load_b32(rP, base + (has ? offMode : BIGOFF), 0, 0);
     }
     __device__ __forceinline__ void diff(double *xp, const double *xm, int mo, double eps2, double rinv2) const
@@ -1723,10 +1784,11 @@ __device__ __forceinline__ void forward_fused_body(RecLayout L, FusedArgs F, int
     bool pend = true;
 #pragma unroll
     for (int i = 0; i < 8; i++) av[i] = 0.0;
-    if constexpr (!UNI) {
-        rS = frsrc(F.kps + (size_t)E0 * 3 * L.n, NE * strideB);
-        load_col(rS, co, has ? idx - E0 : -1, NE, strideB, av);
-        load_col(rS, co, (has && idx + 1 < khi) ? idx + 1 - E0 : -1, NE, strideB, ea);
+    constexpr bool FSLP = KP_SLOPES && !UNI;
+    if constexpr (FSLP) {
+        rS = frsrc(F.kps + (size_t)E0 * 6 * L.n, NE * 2 * strideB);
+        load_col2(rS, co, has ? idx - E0 : -1, NE, 2 * strideB, sv, av);
+        load_col2(rS, co, (has && idx + 1 < khi) ? idx + 1 - E0 : -1, NE, 2 * strideB, ev, ea);
         pend = false;
     }
     // the identity rows of Ya (alpha and the homogeneous 1 carry over): lanes c >= n walk no list
@@ -1764,14 +1826,13 @@ __device__ __forceinline__ void forward_fused_body(RecLayout L, FusedArgs F, int
         Yb.z = NCU > 2 ? shB[c * 17 + 8 + q] : 0.0; Yb.w = NCU > 3 ? shB[c * 17 + 12 + q] : 0.0;
     };
     auto advance = [&](int t) {
-        if constexpr (!UNI) {
+        if constexpr (FSLP) {
             if (t >= e) {                     // per lane: reached the end key-point of the segment = the start of the next one
 #pragma unroll
                 for (int i = 0; i < 8; i++) { sv[i] = ev[i]; av[i] = ea[i]; }
                 s = e; e = nb; idx++;
                 const int en = (idx + 1 < khi) ? idx + 1 - E0 : -1;
-                load_col(rT, co, en, NE, strideB, ev);
-                load_col(rS, co, en, NE, strideB, ea);
+                load_col2(rS, co, en, NE, 2 * strideB, ev, ea);
                 nb = (idx + 2 < khi) ? F.kp_times[idx + 2] : BIGT;
             }
             return;
@@ -2265,7 +2326,8 @@ bool fused_supported(int n, int m, int nr, int dof, int T, int stride, int n_alp
 static FusedArgs fused_args(const Ctx *c)
 {
     FusedArgs F = {c->kp_offsets, c->kp_times, c->r, c->r_x, c->r_u, c->w_run, c->w_term, c->d.dof, c->d.nr,
-                   c->kpc, c->fdk_dev, 2 * c->eps, 1.0 / (2 * c->eps), c->rx_const, c->kps};
+                   c->kpc, c->fdk_dev, 2 * c->eps, 1.0 / (2 * c->eps), c->rx_const,
+                   c->kps ? c->kps : c->kpc};      // (no slope store: lists known uniform, no general form runs -- never a null descriptor)
     return F;
 }
 

@@ -176,10 +176,10 @@ static int ensure_kpc(kpilqr_ctx *c)
 }
 
 // the slope store beside kpc, same size -- only when the lists may be per-DoF (ragged): uniform sets never read it
-static int ensure_kps(kpilqr_ctx *c)
+static int ensure_kps(kpilqr_ctx *c, bool force = false)
 {
-    if (c->kp_known_uniform) return KPILQR_OK;
-    const size_t need = kp_entries(c) * 3 * (size_t)c->n * 8;
+    if (c->kp_known_uniform && !force) return KPILQR_OK;
+    const size_t need = kp_entries(c) * 6 * (size_t)c->n * 8;              // (value, slope) pairs
     if (need <= c->kps_cap) return KPILQR_OK;
     const int rc = grow_dev(c, (void **)&c->kps, &c->kps_cap, need + need / 4 + 4096, false);
     if (rc < 0) return rc;
@@ -577,7 +577,7 @@ int kpilqr_set_keypoints(kpilqr_ctx *c, const int *kp_offsets, const int *kp_tim
         for (int i = 1; i < c->d.dof && uniform; i++)
             uniform = (o[i + 1] - o[i] == len0) && memcmp(kp_times + o[i], kp_times + o[0], sizeof(int) * (size_t)len0) == 0;
     }
-    c->kp_known_uniform = uniform;
+    c->kp_known_uniform = uniform && c->tune.fused_uni != 0;     // (KPILQR_FUSED_UNI=0: the general forms run on every set)
     if ((size_t)total > c->kp_cap) {
         if (c->kp_times) { KP_HIP(c, hipStreamSynchronize(c->stream)); KP_HIP(c, hipFree(c->kp_times)); c->kp_times = nullptr; }
         c->kp_cap = (size_t)total + (size_t)total / 4 + 64;
@@ -649,7 +649,7 @@ int kpilqr_generate_keypoints(kpilqr_ctx *c, const char *method, int min_N, int 
     KP_HIP(c, launch_generate_keypoints(c, mth, min_N, max_N, dt, thresholds ? c->kp_thr : nullptr, c->X_states, c->kp_mask, c->kp_count));
     KP_HIP(c, launch_build_segmap(c));
     c->have_kp = true;
-    c->kp_known_uniform = mth == 0;          // set_interval: one list for all DoFs; the other methods place per DoF
+    c->kp_known_uniform = mth == 0 && c->tune.fused_uni != 0;    // set_interval: one list for all DoFs; the other methods place per DoF
     c->kp_canonical = true;      // rows 0 and T-1 are always full and the lists are strictly increasing by construction
     // The lists exist on the device only (kpilqr_get_keypoints brings them to the host), but their TOTAL is read back here --
     // one int: the column store and the entry tables are sized from it (not from the worst case batch * dof * T: 7.2 GB
@@ -808,7 +808,11 @@ int kpilqr_upload_fd_slab(kpilqr_ctx *c, const void *slab, int njobs, int nnom, 
 static void fdkp_layout(int n, int entries, kpilqr_fdkp_layout *L)
 {
     L->entry_stride = (size_t)(6 * n + 2) * 8;
-    L->xplus = 0; L->xminus = (size_t)3 * n * 8; L->mode = (size_t)6 * n * 8;
+#if KP_RAW_PAIRS
+    L->xplus = 0; L->xminus = 8; L->elem_stride = 16; L->mode = (size_t)6 * n * 8;       // (x+, x-) pairs, element by element
+#else
+    L->xplus = 0; L->xminus = (size_t)3 * n * 8; L->elem_stride = 8; L->mode = (size_t)6 * n * 8;
+#endif
     L->bytes = (size_t)entries * L->entry_stride;
 }
 
@@ -1037,9 +1041,11 @@ int kpilqr_backward_stats(kpilqr_ctx *c, int pd_check_stride, int *hist)
     rc = ensure_kpc(c);
     if (rc) return rc;
     if (!c->kpc_valid) { rc = difference_to_kpc(c); if (rc) return rc; }
-    rc = ensure_kps(c);
-    if (rc == KPILQR_OK && c->kpc_valid) rc = slopes_for_kpc(c);
+    // (the instrumented sweep is the GENERAL form whatever the lists are: it walks the slope store, made here unconditionally)
+    rc = ensure_kps(c, true);
     if (rc) return rc;
+    KP_HIP(c, launch_kp_slopes(c, false));
+    c->kps_valid = true;
     rc = ensure_rx_buffer(c);
     if (rc) return rc;
     const size_t bytes = (size_t)c->d.batch * 6 * sizeof(int);

@@ -238,11 +238,12 @@ class Engine:
         slab = self.pinned(lay.bytes, np.uint8) if pinned else np.zeros(max(lay.bytes, 1), np.uint8)
         n3 = 3 * self.n
         rec = slab[:ent * lay.entry_stride].view(np.float64).reshape(ent, lay.entry_stride // 8)     # one record per entry
+        es = max(1, lay.elem_stride // 8)                # doubles from one element of a side to the next (2: x+ and x- side by side)
         for off, a in ((lay.xplus, xplus), (lay.xminus, xminus)):
             a = np.ascontiguousarray(a, np.float64)
             if a.shape != (ent, 3, self.n):
                 raise ValueError(f"expected shape {(ent, 3, self.n)}, got {a.shape}")
-            rec[:, off // 8:off // 8 + n3] = a.reshape(ent, n3)
+            rec[:, off // 8:off // 8 + n3 * es:es] = a.reshape(ent, n3)
         rec[:, lay.mode // 8:] = 0.0
         rec[:, lay.mode // 8:lay.mode // 8 + 1].view(np.int32)[:, 0] = np.asarray(mode, np.int32)
         return dict(slab=slab, entries=ent, layout=lay)

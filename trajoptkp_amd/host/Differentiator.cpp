@@ -230,9 +230,11 @@ struct KpSink {
     {
         const int kind = col < dof ? 0 : col < n ? 1 : 2;
         const int i = kind == 0 ? col : kind == 1 ? col - dof : col - n;
+        // (x+, x-) side by side, element by element (kpilqr_fd_kp_layout: xplus 0, xminus 8, elem_stride 16)
         double *rec = (double *)(slab + (size_t)entry_of[i] * stride);
-        std::memcpy(rec + (size_t)kind * n, (mode == 2 ? xnom : xp).data(), sizeof(double) * n);
-        std::memcpy(rec + (size_t)(3 + kind) * n, (mode == 1 ? xnom : xm).data(), sizeof(double) * n);
+        const double *P = (mode == 2 ? xnom : xp).data(), *Mn = (mode == 1 ? xnom : xm).data();
+        double *dst = rec + (size_t)kind * n * 2;
+        for (int r = 0; r < n; r++) { dst[2 * r] = P[r]; dst[2 * r + 1] = Mn[r]; }
         if (mode != 0) *(int *)(rec + (size_t)6 * n) |= 1 << kind;
     }
 };

@@ -290,8 +290,13 @@ int kpilqr_host_fd_kp_check(const char *model, int T, int min_N, int stagger, co
         const double *rec = (const double *)(slab.data() + (size_t)e * stride);
         const double *P = mode == 2 ? st.xnom + (size_t)st.job_nom[j] * n : st.xplus + (size_t)j * n;
         const double *Mn = mode == 1 ? st.xnom + (size_t)st.job_nom[j] * n : st.xminus + (size_t)j * n;
-        if (std::memcmp(rec + (size_t)kind * n, P, sizeof(double) * n) != 0) bad++;
-        if (std::memcmp(rec + (size_t)(3 + kind) * n, Mn, sizeof(double) * n) != 0) bad++;
+        // the record: (x+, x-) pairs, element by element (kpilqr_fd_kp_layout)
+        bool okp = true, okm = true;
+        for (int r = 0; r < n; r++) {
+            okp = okp && std::memcmp(rec + ((size_t)kind * n + r) * 2, P + r, sizeof(double)) == 0;
+            okm = okm && std::memcmp(rec + ((size_t)kind * n + r) * 2 + 1, Mn + r, sizeof(double)) == 0;
+        }
+        bad += !okp; bad += !okm;
         if (mode) { one_sided++; mode_seen[e] |= 1 << kind; }
     }
     for (int e = 0; e < entries; e++) if (*(const int *)(slab.data() + (size_t)e * stride + (size_t)6 * n * 8) != mode_seen[e]) bad++;

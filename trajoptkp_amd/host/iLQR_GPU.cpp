@@ -180,11 +180,14 @@ void iLQR_GPU::GenerateDerivatives()
             }
             for (int e = 0; e < entries; e++) {
                 const char *rec = kp_slab + (size_t)e * lay.entry_stride;
-                const double *xp = (const double *)(rec + lay.xplus), *xm = (const double *)(rec + lay.xminus);
+                const char *xp = rec + lay.xplus, *xm = rec + lay.xminus;
                 const int mode = *(const int *)(rec + lay.mode);
                 for (int kind = 0; kind < 3; kind++) {
                     const double den = ((mode >> kind) & 1) ? eps : 2 * eps;
-                    for (int r = 0; r < n; r++) kp_cols[(size_t)e * per + (size_t)kind * n + r] = (xp[kind * n + r] - xm[kind * n + r]) / den;
+                    for (int r = 0; r < n; r++) {
+                        const size_t el = ((size_t)kind * n + r) * lay.elem_stride;
+                        kp_cols[(size_t)e * per + (size_t)kind * n + r] = (*(const double *)(xp + el) - *(const double *)(xm + el)) / den;
+                    }
                 }
             }
             if ((rc = kpilqr_upload_kp_columns(ctx, kp_cols, entries))) fatal("kpilqr_upload_kp_columns", rc);
