@@ -67,6 +67,9 @@ typedef unsigned long long u64;
 #ifndef KP_PROBE_BWD
 #define KP_PROBE_BWD 0
 #endif
+#ifndef KP_KINK4
+#define KP_KINK4 1                  // 0: the step below a key-point refreshes the running inverse like every other step (round 3; A/B builds)
+#endif
 #ifndef KP_SLOPES
 #define KP_SLOPES 1                 // 0: the general forms divide at their crossings (rounds 1-3) instead of reading the slope store (A/B builds)
 #endif
@@ -692,7 +695,9 @@ __device__ __forceinline__ void backward_fused_body(double *sh, const double *pc
         bool done = false;
 #if KP_NS
         int ns_steps = 0;
-        const bool refreshed = haveX && !check_pd && kp_inverse_refresh_n<NCU>(Qr, Iu, Xinv, Xprev, m, STATS ? &ns_steps : nullptr);    // Xinv, Xprev: NEGATED inverses
+        // (segment-loop forms: the peeled step is the one right below a key-point -- known at compile time)
+        constexpr bool KINK = KP_KINK4 && UNI && !PC && decltype(may_be_first)::value;
+        const bool refreshed = haveX && !check_pd && kp_inverse_refresh_n<NCU, KINK>(Qr, Iu, Xinv, Xprev, m, STATS ? &ns_steps : nullptr);    // Xinv, Xprev: NEGATED inverses
         if constexpr (STATS) { if (refreshed) hcnt[ns_steps < 0 ? 0 : ns_steps > 3 ? 3 : ns_steps]++; }
 #else
         const bool refreshed = false;

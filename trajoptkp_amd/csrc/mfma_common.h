@@ -130,7 +130,12 @@ __device__ __forceinline__ bool kp_inverse_refresh_p(const d4 &Qr, const d4 &Iu,
 // R = I - Q X = I + Q N is the MFMA accumulator started at I -- no VALU between the products of the chain -- and the gains
 // K = -X = N Quz come out with their sign.  Everything else as kp_inverse_refresh_p (N (I + R + R^2), extrapolated start).
 // steps (optional): the number of second-order steps that followed the third-order one (0..3; -1 when it gave up).
-template <int NCU>
+// KINK (the step right below a key-point, known statically in the segment-loop forms: the peeled step): the slopes of A and B
+// change there, the extrapolated first guess is off by a FIRST difference again (residual median ~4e-5 instead of ~8e-7) and the
+// third-order step alone is not enough on most such steps (round 3: 18 % of all steps ran a second-order step behind it: 4 MFMAs,
+// a residual test and a chain transition).  One more term of the series instead -- N0 (I + R + R^2 + R^3), error e^4, two more
+// MFMAs in the same straight line -- is enough up to e < 1.7e-4 (e^4 < 1e-15).
+template <int NCU, bool KINK = false>
 __device__ __forceinline__ bool kp_inverse_refresh_n(const d4 &Qr, const d4 &Iu, d4 &Ninv, d4 &Nprev, int m, int *steps = nullptr)
 {
     if (steps) *steps = 0;
@@ -142,14 +147,17 @@ __device__ __forceinline__ bool kp_inverse_refresh_n(const d4 &Qr, const d4 &Iu,
     d4 R = kp_P<NCU>(Qr, N0, Iu);                     // I + Q N0
     d4 Y = kp_P<NCU>(N0, R, N0);
     Y = kp_P<NCU>(Y, R, N0);
+    if constexpr (KINK) Y = kp_P<NCU>(Y, R, N0);      // N0 (I + R + R^2 + R^3)
     double rmax = fabs(R.x);
     if (NCU > 1) rmax = fmax(rmax, fabs(R.y));
     if (NCU > 2) rmax = fmax(rmax, fabs(R.z));
     if (NCU > 3) rmax = fmax(rmax, fabs(R.w));
     const double e = (double)m * rmax;
-    if (__builtin_amdgcn_ballot_w64(!(e < 2.0e-5)) != 0) {
+    if (__builtin_amdgcn_ballot_w64(!(e < (KINK ? 1.7e-4 : 2.0e-5))) != 0) {
         if (__builtin_amdgcn_ballot_w64(!(e < 0.11)) != 0) { if (steps) *steps = -1; return false; }
-        const int iters = (__builtin_amdgcn_ballot_w64(e >= 1.3e-2) != 0) ? 3 : (__builtin_amdgcn_ballot_w64(e >= 1.7e-4) != 0) ? 2 : 1;
+        // second-order steps behind the series: its residual is e^3 (e^4), squared by every step, to end below 1e-15
+        const int iters = KINK ? ((__builtin_amdgcn_ballot_w64(e >= 1.3e-2) != 0) ? 2 : 1)
+                               : (__builtin_amdgcn_ballot_w64(e >= 1.3e-2) != 0) ? 3 : (__builtin_amdgcn_ballot_w64(e >= 1.7e-4) != 0) ? 2 : 1;
         if (steps) *steps = iters;
         R = kp_P<NCU>(Qr, Y, Iu); Y = kp_P<NCU>(Y, R, Y);
         if (iters > 1) {
