@@ -1,32 +1,46 @@
 #!/bin/bash
-# Profiles of the round (run on the GPU box from the repo root: `gpurun -- bash tools/collect_profiles.sh r02`):
+# Profiles of the round (run on the GPU box from the repo root: `gpurun -- bash tools/collect_profiles.sh r04 [per_step]`):
 #   gpurun_out/<tag>/bench.json            the default bench line
 #   gpurun_out/<tag>/stats/                rocprofv3 --kernel-trace --stats of the same command (no side measurements)
 #   gpurun_out/<tag>/pmc_{fetch,write,m3,m4}/  separate --pmc passes (HBM traffic, MFMA / VALU / LDS counters)
 #   gpurun_out/<tag>/generic.json          the VALU/LDS (non-MFMA) kernels at the same workload: evidence for MFMA at n = 14
 # tools/pmc_summarise.py turns the counter CSVs into profiles/<tag>_pmc_*.json.
+# Second argument "per_step": the same passes (without the generic ones) for `bench.py --streamed-jacobians` -- the residual
+# Jacobians given per step, the round-1..3 form -- into profiles/<tag>_*_per_step_jacobians.*
 set -o pipefail
-TAG=${1:-r03}
-OUT=$PWD/gpurun_out/$TAG
+TAG=${1:-r04}
+MODE=${2:-}
+EXTRA=""
+SUB=$TAG
+if [ "$MODE" = per_step ]; then EXTRA="--streamed-jacobians"; SUB=${TAG}_per_step; fi
+OUT=$PWD/gpurun_out/$SUB
 mkdir -p $OUT
 export TMPDIR=/tmp
 # the 1024-distinct-seed workload is generated once (forked workers, before HIP starts) and memory-mapped by every later pass:
 # under rocprofv3 the profiler has initialised the GPU before the script starts, so those passes must not fork
 WL="--workload-cache /tmp/kpilqr_workload"
-python bench.py $WL > $OUT/bench.json 2> $OUT/bench.err || exit 1
+if [ "$MODE" = per_step ]; then
+  python bench.py $WL $EXTRA --no-secondary --no-cpu-baseline > $OUT/bench.json 2> $OUT/bench.err || exit 1
+else
+  python bench.py $WL > $OUT/bench.json 2> $OUT/bench.err || exit 1
+fi
 echo "bench done"
-python bench.py $WL --generic --steps 3 --warmup 1 --no-secondary --no-cpu-baseline > $OUT/generic.json 2> $OUT/generic.err || exit 1
-echo "generic done"
+if [ "$MODE" != per_step ]; then
+  python bench.py $WL --generic --steps 3 --warmup 1 --no-secondary --no-cpu-baseline > $OUT/generic.json 2> $OUT/generic.err || exit 1
+  echo "generic done"
+fi
 cd /tmp
-rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/stats -- python3 $OLDPWD/bench.py $WL --no-secondary --no-cpu-baseline --steps 10 --warmup 2 > $OUT/stats.log 2>&1 || exit 1
+rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/stats -- python3 $OLDPWD/bench.py $WL $EXTRA --no-secondary --no-cpu-baseline --steps 10 --warmup 2 > $OUT/stats.log 2>&1 || exit 1
 echo "stats done"
-rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/stats_generic -- python3 $OLDPWD/bench.py $WL --generic --no-secondary --no-cpu-baseline --steps 3 --warmup 1 > $OUT/stats_generic.log 2>&1 || exit 1
-echo "generic stats done"
+if [ "$MODE" != per_step ]; then
+  rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/stats_generic -- python3 $OLDPWD/bench.py $WL --generic --no-secondary --no-cpu-baseline --steps 3 --warmup 1 > $OUT/stats_generic.log 2>&1 || exit 1
+  echo "generic stats done"
+fi
 for pass in "fetch FETCH_SIZE" "write WRITE_SIZE" "m3 SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CYCLES SQ_INSTS_VALU_MFMA_F64 SQ_INSTS_VALU" "m4 SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_ANY"; do
   set -- $pass; name=$1; shift
-  rocprofv3 --pmc "$@" --output-format csv -d $OUT/pmc_$name -- python3 $OLDPWD/bench.py $WL --no-secondary --no-cpu-baseline --steps 3 --warmup 1 > $OUT/pmc_$name.log 2>&1 || exit 1
+  rocprofv3 --pmc "$@" --output-format csv -d $OUT/pmc_$name -- python3 $OLDPWD/bench.py $WL $EXTRA --no-secondary --no-cpu-baseline --steps 3 --warmup 1 > $OUT/pmc_$name.log 2>&1 || exit 1
   echo "pmc $name done"
 done
 cd $OLDPWD
-python tools/pmc_summarise.py $OUT $TAG || exit 1
+python tools/pmc_summarise.py $OUT $TAG $MODE || exit 1
 echo "summaries written"

@@ -13,8 +13,12 @@
 // read back as an MFMA operand with conflict-free 8-byte accesses.  The waves of a workgroup meet at s_barrier
 // between the phases of a step (the barrier waits for LDS traffic only, so global loads stay in flight).
 #include <cstdlib>
+#include <type_traits>
 #include "mfma_common.h"
 #include "tracker.h"
+#ifndef KP_FT_SETS
+#define KP_FT_SETS 2                // register sets of the two-tile forward sweep on materialised tiles (1: rounds 1-3, A/B builds)
+#endif
 
 // latency probe (-DKP_PROBE_SAMEB): every workgroup works on one of two trajectories, everything hits in cache
 #ifdef KP_PROBE_SAMEB
@@ -1197,19 +1201,27 @@ k_forward_tiled(RecLayout L, CostSrc CS, KpSrc KP, int T, int n_alpha, const dou
     // Single-buffered tiles: each group is re-requested for step t+1 right behind its last use in step t.
     // Every wave forms only ITS slice of the control law, P([K' ; k'] rows of tile wi, Z_wi) (4 MFMAs instead of
     // 4*NT); the slices are summed through LDS (one extra barrier), then every wave clamps the same U.
-    Tiles cur;
-    {
-        __amdgpu_buffer_rsrc_t rR = rs_of(rec, L.stride, 0, rec_bytes), rK = rs_of(Kin, (size_t)m * n, 0, m * n * 8);
-        __amdgpu_buffer_rsrc_t rk = rs_of(kin, m, 0, m * 8), ru = rs_of(u_nom, m, 0, m * 8);
+    // Register sets (round 4, the rule of fused_mfma.hip's forward sweep): the tiles of step t sit in set t mod NS and are
+    // re-requested for step t + NS right behind their last use.  With ONE set (rounds 1-3) a tile was requested one step ahead:
+    // a step of this kernel (~1.1 us at two tiles) is about one trip to HBM, and a wave's memory operations return in order,
+    // so the step time WAS that trip.  NS = 2 where the tiles are materialised and the chunk counts compile-time (NCL > 0);
+    // every step is instantiated with its set as a compile-time constant (no copies between sets).
+    constexpr int NS = (NCL > 0 && !A6 && !A4) ? KP_FT_SETS : 1;
+    Tiles S[NS];
+#pragma unroll
+    for (int s0 = 0; s0 < NS; s0++) {
+        Tiles &cur = S[s0];
+        __amdgpu_buffer_rsrc_t rR = rs_of(rec, L.stride, s0, rec_bytes), rK = rs_of(Kin, (size_t)m * n, s0, m * n * 8);
+        __amdgpu_buffer_rsrc_t rk = rs_of(kin, m, s0, m * 8), ru = rs_of(u_nom, m, s0, m * 8);
         cur.Ykw = ld4(rK, oKw) + ld4(rk, okw);
 #pragma unroll
         for (int k = 0; k < NT; k++) { if (!A4) cur.Ya[k] = ld4(rR, oA[k]); if (!A6) cur.Lc[k] = ld4(rR, oLc[k]); }
         if (!A4) cur.Yb = ld4(rR, oB);
         cur.ub = ld4(ru, oub);
         if (A6) {
-            cur.Lc[0] = ld4(rs_res(rxb, (size_t)nr * n, 0, nr * n * 8), oRxT);
-            cur.Luu = ld4(rs_res(rub, (size_t)nr * m, 0, nr * m * 8), oRuT);
-            cur.lu = ld4(rs_res(rb, nr, 0, nr * 8), oRr);
+            cur.Lc[0] = ld4(rs_res(rxb, (size_t)nr * n, s0, nr * n * 8), oRxT);
+            cur.Luu = ld4(rs_res(rub, (size_t)nr * m, s0, nr * m * 8), oRuT);
+            cur.lu = ld4(rs_res(rb, nr, s0, nr * 8), oRr);
         } else { cur.Luu = ld4(rR, oLuu); cur.lu = ld4(rR, olu); }
     }
     __syncthreads();
@@ -1220,9 +1232,11 @@ k_forward_tiled(RecLayout L, CostSrc CS, KpSrc KP, int T, int n_alpha, const dou
 #else
 #define CYF(i)
 #endif
-    for (int t = 0; t < T; t++) {
-        const __amdgpu_buffer_rsrc_t rR = rs_of(rec, L.stride, t + 1, rec_bytes), rK = rs_of(Kin, (size_t)m * n, t + 1, m * n * 8);
-        const __amdgpu_buffer_rsrc_t rk = rs_of(kin, m, t + 1, m * 8), ru = rs_of(u_nom, m, t + 1, m * 8);
+    auto step = [&](int t, auto set_tag) __attribute__((always_inline)) {
+        Tiles &cur = S[decltype(set_tag)::value];
+        const int tq = t + NS;                               // the step this set is re-requested for (beyond the horizon: empty descriptors)
+        const __amdgpu_buffer_rsrc_t rR = rs_of(rec, L.stride, tq, rec_bytes), rK = rs_of(Kin, (size_t)m * n, tq, m * n * 8);
+        const __amdgpu_buffer_rsrc_t rk = rs_of(kin, m, tq, m * 8), ru = rs_of(u_nom, m, tq, m * 8);
         const double *zc = zbuf[t & 1];
         double *zn = zbuf[(t + 1) & 1];
         // ---- this wave's slice of K dx + alpha k -------------------------------------------------------------
@@ -1230,7 +1244,7 @@ k_forward_tiled(RecLayout L, CostSrc CS, KpSrc KP, int T, int n_alpha, const dou
         if (A6) lds_store(jpart + wi * TILE, lane, Pn(cur.Lc[0], Zi, zero, ncw));        // this wave's slice of r_x dx
         __builtin_amdgcn_sched_barrier(0);
         cur.Ykw = ld4(rK, oKw) + ld4(rk, okw);
-        if (A6) cur.Lc[0] = ld4(rs_res(rxb, (size_t)nr * n, t + 1, nr * n * 8), oRxT);
+        if (A6) cur.Lc[0] = ld4(rs_res(rxb, (size_t)nr * n, tq, nr * n * 8), oRxT);
         __builtin_amdgcn_sched_barrier(0);
         CYF(0)
         __syncthreads();
@@ -1273,8 +1287,8 @@ k_forward_tiled(RecLayout L, CostSrc CS, KpSrc KP, int T, int n_alpha, const dou
                 partial += w0 * (Jx.x * (r2.x + Jx.x) + Ju.x * (r2.x + Ju.x)) + w1 * (Jx.y * (r2.y + Jx.y) + Ju.y * (r2.y + Ju.y))
                          + w2 * (Jx.z * (r2.z + Jx.z) + Ju.z * (r2.z + Ju.z)) + w3 * (Jx.w * (r2.w + Jx.w) + Ju.w * (r2.w + Ju.w));
                 __builtin_amdgcn_sched_barrier(0);
-                cur.Luu = ld4(rs_res(rub, (size_t)nr * m, t + 1, nr * m * 8), oRuT);
-                cur.lu = ld4(rs_res(rb, nr, t + 1, nr * 8), oRr);
+                cur.Luu = ld4(rs_res(rub, (size_t)nr * m, tq, nr * m * 8), oRuT);
+                cur.lu = ld4(rs_res(rb, nr, tq, nr * 8), oRr);
                 __builtin_amdgcn_sched_barrier(0);
             } else {
             const d4 Wu = Pn(cur.Luu, dU, zero, ncu);
@@ -1346,6 +1360,14 @@ k_forward_tiled(RecLayout L, CostSrc CS, KpSrc KP, int T, int n_alpha, const dou
         CYF(4)
         __syncthreads();
         CYF(5)
+    };
+    if constexpr (NS == 1) {
+        for (int t = 0; t < T; t++) step(t, std::integral_constant<int, 0>{});
+    } else {
+        static_assert(NS == 2, "the time loop below is written for two sets");
+        int t = 0;
+        for (; t + 2 <= T; t += 2) { step(t, std::integral_constant<int, 0>{}); step(t + 1, std::integral_constant<int, 1>{}); }
+        if (t < T) step(t, std::integral_constant<int, 0>{});
     }
 #ifdef KP_CYC_FT
     if (b == 0 && lane == 0) printf("fwd wave %d: slice+requests %lld | wait1 %lld | law+clamp(+last wave's cost) %lld | products+requests %lld | Zn store %lld | wait2 %lld\n", wi,
