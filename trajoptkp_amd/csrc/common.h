@@ -191,6 +191,7 @@ struct Ctx {
         int tiled_a6 = -1;         // KPILQR_TILED_A6: -1 auto, 0 | 1
         int tiled_uw = -1;         // KPILQR_TILED_UW: 0 = no u-wave in the tiled backward sweep (NT <= 3, materialised tiles)
         int tiled_a4 = -1;         // KPILQR_TILED_A4: -1 auto, 0 | 1 (a4 inside the tiled sweeps)
+        int tiled_fsc = -1;        // KPILQR_TILED_FSC: -1 auto, 0 | 1: the state / cost wave groups of the two-tile forward sweep
         int fused_uni = -1;        // KPILQR_FUSED_UNI: 0 never take the uniform-key-point form of the one-wave backward sweep (diagnostic)
         int fused_raw = -1;        // KPILQR_FUSED_RAW: 0 never difference inside the backward sweep (diagnostic), else auto
         int pipe_copy = -1;        // KPILQR_PIPE_COPY: chunk pipeline copies by kernel: bit 0 uploads, bit 1 downloads (-1 auto)
@@ -259,6 +260,7 @@ bool backward_tiled_supported(int n, int m, int nt_min);
 hipError_t launch_backward_tiled(Ctx *c, int pd_stride);
 size_t backward_tiled_lds_bytes(int nt);
 bool forward_tiled_supported(int n, int m, int n_alpha, int nt_min);
+bool forward_tiled_sc_selected(const Ctx *c);             // the state / cost wave groups will run (two tiles, small batches)
 hipError_t launch_forward_tiled(Ctx *c, double *U_alpha_dev);
 bool tiled_a4_supported(int n, int m, int dof, int T, int stride);
 // tiled_wide.hip: the same sweeps with the control block over up to two tiles (8 < m <= 32 backward, 16 < m <= 32 forward)

@@ -85,6 +85,7 @@ Ctx::Tuning read_tuning_from_env()
     t.tiled_a6 = env_int("KPILQR_TILED_A6", -1);
     t.tiled_a4 = env_int("KPILQR_TILED_A4", -1);
     t.tiled_uw = env_int("KPILQR_TILED_UW", -1);
+    t.tiled_fsc = env_int("KPILQR_TILED_FSC", -1);
     t.pipe_copy = env_int("KPILQR_PIPE_COPY", -1);
     t.fused_raw = env_int("KPILQR_FUSED_RAW", -1);
     t.fused_uni = env_int("KPILQR_FUSED_UNI", -1);
@@ -1517,7 +1518,12 @@ const char *kpilqr_last_launch(kpilqr_ctx *c, int which)
     std::string &out = c->launch_desc[which];
     const int form = which == 0 ? c->last_bwd_form : c->last_fwd_form;
     out = which == 0 ? c->bwd_variant : c->fwd_variant;
-    if (form == 0) { if (!c->fused) return out.c_str(); out += ":none"; return out.c_str(); }
+    if (form == 0) {
+        if (c->fused) { out += ":none"; return out.c_str(); }
+        // the two-tile forward sweep on materialised tiles: one wave per row tile, or state / cost wave groups (small batches)
+        if (which == 1 && strcmp(c->fwd_variant, "mfma_f64_tiled") == 0 && forward_tiled_sc_selected(c)) out += ":state_cost_waves";
+        return out.c_str();
+    }
     int uni = 0;
     if (hipSetDevice(c->d.device) != hipSuccess || (c->pipe_dirty && join_pipeline(c) != KPILQR_OK) ||
         hipMemcpyAsync(&uni, c->kp_uniform, sizeof(int), hipMemcpyDeviceToHost, c->stream) != hipSuccess ||

@@ -1385,6 +1385,316 @@ k_forward_tiled(RecLayout L, CostSrc CS, KpSrc KP, int T, int n_alpha, const dou
     }
 }
 
+// ---------------------------------------------------------------------------------------------------------------
+// Forward pass, STATE / COST wave groups (round 4; materialised tiles, two row tiles; while the 2 NT waves of a trajectory each
+// find a SIMD: 2 NT x batch <= #SIMDs -- configs[2]: Panda pushing, 64 trajectories, 4 of a CU's SIMDs instead of 2).  Only the
+// state recursion is serial in time (as in fused_mfma.hip's k_forward_fused_sc): state wave i keeps row tile i of Z and runs
+//     slice of K dx + alpha k | barrier | sum of the slices, clamp | Z' = A dx + B du | barrier          (4 + 4 NT + 2 MFMAs)
+// and publishes Z_t (a three-slot LDS ring) and dU_t; cost wave i, ONE STEP BEHIND, scores the candidates' row tile i --
+// Wz = Lc Z (4 NT MFMAs), 0.5 Z'Wz, and on the last cost wave the control cost dU'(0.5 l_uu dU + l_u) -- from the published
+// state: the 4 NT cost products, their 4 NT tile loads and the accumulation leave the recursion's wave (the products of one wave
+// do not overlap with its own VALU work; a second SIMD does them for free).  All waves pass the same two s_barrier per tick; a
+// cost wave passes the first one AT ONCE (with its scoring in front of it the recursion waited for the scoring: 3.64 against
+// 3.34 ms) and scores under the state waves' long phase.  Role-specialised time loops (a join of the roles behind a request
+// costs register copies and a wait for every load in flight: DESIGN.md, u-wave).
+// The state role is instantiated per wave (WI) and per chunk count of the last row tile (NCL) and of the controls (NCU): a
+// register that holds structural zeros only -- rows beyond n + 2 in the last tile, rows beyond num_ctrl of a control operand -- is
+// not loaded, not stored, not clamped (an out-of-range buffer load moves no data but still costs its ~30 cycles of issue on a lone
+// wave; 24 -> 15 loads per state wave and step at n = 20, m = 7).
+template <int NC> __device__ __forceinline__ d4 Pc(const d4 &Y, const d4 &X, d4 acc)
+{
+    acc = MFMA(Y.x, X.x, acc);
+    if constexpr (NC > 1) acc = MFMA(Y.y, X.y, acc);
+    if constexpr (NC > 2) acc = MFMA(Y.z, X.z, acc);
+    if constexpr (NC > 3) acc = MFMA(Y.w, X.w, acc);
+    return acc;
+}
+template <int NC> __device__ __forceinline__ d4 lds_tile_n(const double *t, int lane)
+{
+    d4 v = {0.0, 0.0, 0.0, 0.0};
+    v.x = t[lane];
+    if constexpr (NC > 1) v.y = t[64 + lane];
+    if constexpr (NC > 2) v.z = t[128 + lane];
+    if constexpr (NC > 3) v.w = t[192 + lane];
+    return v;
+}
+template <int NC> __device__ __forceinline__ void lds_store_n(double *t, int lane, const d4 &v)
+{
+    t[lane] = v.x;
+    if constexpr (NC > 1) t[64 + lane] = v.y;
+    if constexpr (NC > 2) t[128 + lane] = v.z;
+    if constexpr (NC > 3) t[192 + lane] = v.w;
+}
+template <int NC> __device__ __forceinline__ d4 ld4n(__amdgpu_buffer_rsrc_t rs, const int *off)
+{
+    d4 v = {0.0, 0.0, 0.0, 0.0};
+    v.x = tbld(rs, off[0]);
+    if constexpr (NC > 1) v.y = tbld(rs, off[1]);
+    if constexpr (NC > 2) v.z = tbld(rs, off[2]);
+    if constexpr (NC > 3) v.w = tbld(rs, off[3]);
+    return v;
+}
+
+template <int NT, int WI, int NCL, int NCU>
+__device__ __forceinline__ void ft_state_role(double *zring, double *upart, double *dubuf, RecLayout L, int T, int n_alpha, int b,
+                                              const double *__restrict__ rec, const double *__restrict__ Kin, const double *__restrict__ kin,
+                                              const double *__restrict__ u_nom, const double *__restrict__ ctrl_lim,
+                                              const double *__restrict__ alphas, double *__restrict__ U_alpha)
+{
+    constexpr int wi = WI;
+    constexpr int NCW = WI < NT - 1 ? 4 : NCL;                              // chunks of this wave's own row tile
+    const int n = L.n, m = L.m;
+    const int lane = threadIdx.x & 63, c = lane & 15, q = lane >> 4;
+    const int tnz = n >> 4;
+    const int o = 16 * wi + c;
+    const d4 zero = {0.0, 0.0, 0.0, 0.0};
+    const int rec_bytes = L.rec * 8;
+    auto rs_of = [&](const double *base, size_t step_elems, int t, int bytes) {
+        const bool ok = t < T;
+        return __builtin_amdgcn_make_buffer_rsrc((void *)(base + ((size_t)b * T + (ok ? t : 0)) * step_elems), 0, ok ? bytes : 0, 0x00020000);
+    };
+    int oKw[4], oA[NT][4], oB[4], oub[4];
+    double oneT[4], lo[NCU], hi[NCU];
+#pragma unroll
+    for (int k = 0; k < NT; k++)
+#pragma unroll
+        for (int r = 0; r < 4; r++) {
+            const int pp = 16 * k + 4 * r + q;
+            oA[k][r] = (pp < n && o < n) ? 8 * L.a(o, pp) : OOBT;
+        }
+#pragma unroll
+    for (int r = 0; r < 4; r++) {
+        const int row = 4 * r + q;
+        const int pt = 16 * tnz + row;
+        oneT[r] = ((pt == n && o == n) || (pt == n + 1 && o == n + 1)) ? 1.0 : 0.0;
+        const int pw = 16 * wi + row;
+        oKw[r] = (pw < n && c < m) ? 8 * (pw * m + c) : OOBT;
+        oB[r] = (row < m && o < n) ? 8 * L.b(o, row) : OOBT;
+        oub[r] = (row < m) ? 8 * row : OOBT;
+        if (r < NCU) {
+            lo[r] = (row < m) ? ctrl_lim[2 * row] : -1.0e300;
+            hi[r] = (row < m) ? ctrl_lim[2 * row + 1] : 1.0e300;
+        }
+    }
+    // k rides in row n of the gain operand: ONE load (the lanes of that row), added into the register that holds the row
+    const bool k_here = tnz == wi;
+    const int rk = (n & 15) >> 2;
+    const int okn = (k_here && q == (n & 3) && c < m) ? 8 * c : OOBT;
+    double kmask[4];                                                     // 1 in the register that holds row n (no branch in the loop)
+#pragma unroll
+    for (int r = 0; r < 4; r++) kmask[r] = (r == rk) ? 1.0 : 0.0;
+    const double my_alpha = (c < n_alpha) ? alphas[c] : 0.0;
+    d4 Zi;
+    {
+        double zr[4];
+#pragma unroll
+        for (int r = 0; r < 4; r++) {
+            const int row = 16 * wi + 4 * r + q;
+            zr[r] = (row == n) ? my_alpha : (row == n + 1) ? 1.0 : 0.0;
+        }
+        Zi.x = zr[0]; Zi.y = zr[1]; Zi.z = zr[2]; Zi.w = zr[3];
+        lds_store(zring + wi * TILE, lane, Zi);
+    }
+    struct STiles { d4 Ykw, Ya[NT], Yb, ub; double kk; } cur;
+    auto request_A = [&](int t) {
+        const __amdgpu_buffer_rsrc_t rR = rs_of(rec, L.stride, t, rec_bytes);
+#pragma unroll
+        for (int k = 0; k < NT - 1; k++) cur.Ya[k] = ld4n<4>(rR, oA[k]);
+        cur.Ya[NT - 1] = ld4n<NCL>(rR, oA[NT - 1]);
+    };
+    auto request_B = [&](int t) {
+        const __amdgpu_buffer_rsrc_t rR = rs_of(rec, L.stride, t, rec_bytes);
+        cur.Yb = ld4n<NCU>(rR, oB);
+    };
+    {
+        const __amdgpu_buffer_rsrc_t rK = rs_of(Kin, (size_t)m * n, 0, m * n * 8), rk_ = rs_of(kin, m, 0, m * 8), ru = rs_of(u_nom, m, 0, m * 8);
+        cur.Ykw = ld4n<NCW>(rK, oKw); cur.kk = tbld(rk_, okn);
+        request_A(0); request_B(0);
+        cur.ub = ld4n<NCU>(ru, oub);
+    }
+    __syncthreads();                                                     // Z_0 is published
+    int slot = 0;                                                        // t mod 3
+    for (int t = 0; t < T; t++) {
+        const __amdgpu_buffer_rsrc_t rK = rs_of(Kin, (size_t)m * n, t + 1, m * n * 8), rk_ = rs_of(kin, m, t + 1, m * 8), ru = rs_of(u_nom, m, t + 1, m * 8);
+        const double *zc = zring + slot * NT * TILE;
+        const int nslot = slot == 2 ? 0 : slot + 1;
+        double *zn = zring + nslot * NT * TILE;
+        d4 Yk = cur.Ykw;
+        {
+            const double kk = cur.kk;
+            Yk.x = __builtin_fma(kmask[0], kk, Yk.x);
+            if constexpr (NCW > 1) Yk.y = __builtin_fma(kmask[1], kk, Yk.y);
+            if constexpr (NCW > 2) Yk.z = __builtin_fma(kmask[2], kk, Yk.z);
+            if constexpr (NCW > 3) Yk.w = __builtin_fma(kmask[3], kk, Yk.w);
+        }
+        // Z_t has been in its ring slot since the barrier that ended step t-1: everything that needs only Z_t -- this wave's
+        // slice of the control law AND its row tile of A dx -- is formed in front of the mid-step barrier (two independent MFMA
+        // chains back to back, the slice's LDS store under the second one); behind the barrier the chain is clamp -> B du only.
+        // (every tile through LDS, the wave's own one too: taking that one from the registers it sits in measured SLOWER, 2.99 against
+        // 2.92 ms on pushing, 2.78 against 2.67 on walker -- instruction placement, as so often in these sweeps)
+        d4 Zk[NT];
+#pragma unroll
+        for (int k = 0; k < NT - 1; k++) Zk[k] = lds_tile(zc + k * TILE, lane);
+        Zk[NT - 1] = lds_tile_n<NCL>(zc + (NT - 1) * TILE, lane);
+        lds_store_n<NCU>(upart + wi * TILE, lane, Pc<NCW>(Yk, Zi, zero));      // this wave's slice of K dx + alpha k (rows < num_ctrl)
+        d4 Zn = zero;
+#pragma unroll
+        for (int k = 0; k < NT; k++) {
+            d4 Ya = cur.Ya[k];
+            if (k == tnz) { Ya.x += oneT[0]; Ya.y += oneT[1]; Ya.z += oneT[2]; Ya.w += oneT[3]; }
+            if (k < NT - 1) Zn = Pc<4>(Ya, Zk[k], Zn); else Zn = Pc<NCL>(Ya, Zk[k], Zn);
+        }
+        __builtin_amdgcn_sched_barrier(0);
+        cur.Ykw = ld4n<NCW>(rK, oKw); cur.kk = tbld(rk_, okn);
+        request_A(t + 1);
+        __builtin_amdgcn_sched_barrier(0);
+        __syncthreads();
+        // ---- control law + clamp (every state wave; :876-890) ----------------------------------------------------------
+        const d4 ub = cur.ub;
+        d4 U = ub;
+#pragma unroll
+        for (int k = 0; k < NT; k++) U = U + lds_tile_n<NCU>(upart + k * TILE, lane);
+        __builtin_amdgcn_sched_barrier(0);
+        cur.ub = ld4n<NCU>(ru, oub);
+        __builtin_amdgcn_sched_barrier(0);
+        d4 dU = zero;
+        {
+            double u;
+            u = U.x; if (u > hi[0]) u = hi[0]; if (u < lo[0]) u = lo[0]; U.x = u; dU.x = u - ub.x;
+            if constexpr (NCU > 1) { u = U.y; if (u > hi[1]) u = hi[1]; if (u < lo[1]) u = lo[1]; U.y = u; dU.y = u - ub.y; }
+            if constexpr (NCU > 2) { u = U.z; if (u > hi[2]) u = hi[2]; if (u < lo[2]) u = lo[2]; U.z = u; dU.z = u - ub.z; }
+            if constexpr (NCU > 3) { u = U.w; if (u > hi[3]) u = hi[3]; if (u < lo[3]) u = lo[3]; U.w = u; dU.w = u - ub.w; }
+        }
+        Zn = Pc<NCU>(cur.Yb, dU, Zn);
+        __builtin_amdgcn_sched_barrier(0);
+        request_B(t + 1);
+        __builtin_amdgcn_sched_barrier(0);
+        if constexpr (WI == 0) lds_store_n<NCU>(dubuf + (t & 1) * TILE, lane, dU);        // for the control cost, one tick later
+        if constexpr (WI == NT - 1) {
+            if (U_alpha && c < n_alpha) {
+                double *Ua = U_alpha + (((size_t)b * n_alpha + c) * T + t) * m;
+                const double uv[4] = {U.x, U.y, U.z, U.w};
+#pragma unroll
+                for (int r = 0; r < NCU; r++) { const int row = 4 * r + q; if (row < m) Ua[row] = uv[r]; }
+            }
+        }
+        Zi = Zn;
+        lds_store_n<NCW>(zn + wi * TILE, lane, Zn);
+        slot = nslot;
+        __syncthreads();
+    }
+    __syncthreads(); __syncthreads();                                    // the tick in which the cost waves score step T-1
+}
+
+template <int NT, int NCL, int NCU>
+__global__ void __launch_bounds__(128 * NT)
+k_forward_tiled_sc(RecLayout L, int T, int n_alpha, const double *__restrict__ rec, const double *__restrict__ Kin,
+                   const double *__restrict__ kin, const double *__restrict__ u_nom, const double *__restrict__ ctrl_lim,
+                   const double *__restrict__ alphas, double *__restrict__ cost_pred, double *__restrict__ U_alpha)
+{
+    static_assert(NT == 2, "the role dispatch below is written for two row tiles");
+    extern __shared__ __attribute__((aligned(16))) double fsh[];
+    double *zring = fsh;                                                     // [3][NT * TILE]: Z_t in slot t mod 3
+    double *upart = zring + 3 * NT * TILE;                                   // per-wave partials of K dx + alpha k
+    double *dubuf = upart + NT * TILE;                                       // [2][TILE]: dU_t in slot t & 1
+    double *red = dubuf + 2 * TILE;                                          // [NT * 64]
+    const int n = L.n, m = L.m;
+    const int lane = threadIdx.x & 63, c = lane & 15, q = lane >> 4;
+    const int wv = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const bool is_state = wv < NT;
+    const int wi = is_state ? wv : wv - NT;                                  // this wave's row tile (wave-uniform)
+    const int b = KP_TILED_TRAJ;
+    // a tile whose every register is dead (m > 4 NCU cannot happen: the launcher picks NCU from m) keeps the LDS images clean:
+    // the slots read with fewer registers than a tile has are the ones written with as few
+    if (is_state) {
+        if (wi == 0) ft_state_role<NT, 0, NCL, NCU>(zring, upart, dubuf, L, T, n_alpha, b, rec, Kin, kin, u_nom, ctrl_lim, alphas, U_alpha);
+        else ft_state_role<NT, 1, NCL, NCU>(zring, upart, dubuf, L, T, n_alpha, b, rec, Kin, kin, u_nom, ctrl_lim, alphas, U_alpha);
+    } else {
+        // ---- scoring, one tick behind ------------------------------------------------------------------------------------------
+        const int o = 16 * wi + c;
+        const d4 zero = {0.0, 0.0, 0.0, 0.0};
+        const int rec_bytes = L.rec * 8;
+        auto ld4 = [&](__amdgpu_buffer_rsrc_t rs, const int *off) -> d4 {
+            d4 v; v.x = tbld(rs, off[0]); v.y = tbld(rs, off[1]); v.z = tbld(rs, off[2]); v.w = tbld(rs, off[3]);
+            return v;
+        };
+        auto rs_of = [&](const double *base, size_t step_elems, int t, int bytes) {
+            const bool ok = t < T;
+            return __builtin_amdgcn_make_buffer_rsrc((void *)(base + ((size_t)b * T + (ok ? t : 0)) * step_elems), 0, ok ? bytes : 0, 0x00020000);
+        };
+        int oLc[NT][4], oLuu[4], olu[4];
+#pragma unroll
+        for (int k = 0; k < NT; k++)
+#pragma unroll
+            for (int r = 0; r < 4; r++) {
+                const int pp = 16 * k + 4 * r + q;
+                oLc[k][r] = (pp < n && o < n) ? 8 * (L.off_lxx + pp * n + o)
+                          : (pp == n + 1 && o < n) ? 8 * (L.off_lx + o)
+                          : (o == n + 1 && pp < n) ? 8 * (L.off_lx + pp) : OOBT;
+            }
+#pragma unroll
+        for (int r = 0; r < 4; r++) {
+            const int row = 4 * r + q;
+            oLuu[r] = (wi == NT - 1 && row < m && c < m) ? 8 * (L.off_luu + row * m + c) : OOBT;
+            olu[r] = (wi == NT - 1 && row < m) ? 8 * (L.off_lu + row) : OOBT;
+        }
+        struct CTiles { d4 Lc[NT], Luu, lu; } cur;
+        {
+            __amdgpu_buffer_rsrc_t rR = rs_of(rec, L.stride, 0, rec_bytes);
+#pragma unroll
+            for (int k = 0; k < NT - 1; k++) cur.Lc[k] = ld4(rR, oLc[k]);
+            cur.Lc[NT - 1] = ld4n<NCL>(rR, oLc[NT - 1]);
+            cur.Luu = ld4n<NCU>(rR, oLuu); cur.lu = ld4n<NCU>(rR, olu);
+        }
+        double partial = 0.0;
+        __syncthreads();
+        __syncthreads(); __syncthreads();                                    // tick 0: the state waves run step 0
+        int slot = 0;
+        for (int t = 0; t < T; t++) {
+            // the tick's FIRST barrier at once: it is the one the state waves reach behind their slice product (4 MFMAs), and
+            // nothing of this wave's work must stand in front of it; the scoring runs under the state waves' long phase
+            __syncthreads();
+            const __amdgpu_buffer_rsrc_t rR = rs_of(rec, L.stride, t + 1, rec_bytes);
+            const double *zc = zring + slot * NT * TILE;
+            slot = slot == 2 ? 0 : slot + 1;
+            d4 Zk[NT];
+#pragma unroll
+            for (int k = 0; k < NT - 1; k++) Zk[k] = lds_tile(zc + k * TILE, lane);
+            Zk[NT - 1] = lds_tile_n<NCL>(zc + (NT - 1) * TILE, lane);
+            const d4 dU = lds_tile_n<NCU>(dubuf + (t & 1) * TILE, lane);
+            d4 Wz = zero;
+#pragma unroll
+            for (int k = 0; k < NT - 1; k++) Wz = Pc<4>(cur.Lc[k], Zk[k], Wz);
+            Wz = Pc<NCL>(cur.Lc[NT - 1], Zk[NT - 1], Wz);
+            const d4 Wu = Pc<NCU>(cur.Luu, dU, zero);                        // (l_uu, l_u: the last cost wave's; zeros elsewhere)
+            __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+            for (int k = 0; k < NT - 1; k++) cur.Lc[k] = ld4(rR, oLc[k]);
+            cur.Lc[NT - 1] = ld4n<NCL>(rR, oLc[NT - 1]);
+            const d4 lu = cur.lu;
+            cur.Luu = ld4n<NCU>(rR, oLuu); cur.lu = ld4n<NCU>(rR, olu);
+            __builtin_amdgcn_sched_barrier(0);
+            d4 Zi = Zk[0];                                                   // this wave's own row tile (wi is wave-uniform)
+#pragma unroll
+            for (int k = 1; k < NT; k++) if (wi == k) Zi = Zk[k];
+            partial += 0.5 * (Zi.x * Wz.x + Zi.y * Wz.y + Zi.z * Wz.z + Zi.w * Wz.w);
+            if (wi == NT - 1)
+                partial += dU.x * (0.5 * Wu.x + lu.x) + dU.y * (0.5 * Wu.y + lu.y) + dU.z * (0.5 * Wu.z + lu.z) + dU.w * (0.5 * Wu.w + lu.w);
+            __syncthreads();
+        }
+        // column sums: over the q lane groups, then over the cost waves (fixed order: reproducible)
+        partial += __shfl_xor(partial, 16);
+        partial += __shfl_xor(partial, 32);
+        red[wi * 64 + lane] = partial;
+    }
+    __syncthreads();
+    if (!is_state && wi == 0 && q == 0 && c < n_alpha) {
+        double sum = 0.0;
+        for (int w = 0; w < NT; w++) sum += red[w * 64 + lane];
+        cost_pred[(size_t)b * n_alpha + c] = sum;
+    }
+}
+
 bool forward_tiled_supported(int n, int m, int n_alpha, int nt_min)
 {
     const int nt = tiled_nt(n, nt_min);
@@ -1421,9 +1731,39 @@ static hipError_t launch_ft2(Ctx *c, double *U_alpha_dev)
     }
     return launch_ft3<NT, A6, A4, 0>(c, U_alpha_dev);
 }
+template <int NT, int NCL, int NCU>
+static hipError_t launch_ft_sc2(Ctx *c, double *U_alpha_dev)
+{
+    const size_t lds = sizeof(double) * ((size_t)(4 * NT + 2) * TILE + NT * 64);
+    // the LDS images are read with the register counts they are written with; what lies beyond is never read -- but start clean
+    hipLaunchKernelGGL((k_forward_tiled_sc<NT, NCL, NCU>), dim3(c->d.batch), dim3(128 * NT), lds, c->stream, c->L, c->d.T, c->d.n_alpha, c->rec, c->K, c->k,
+                       c->u_nom, c->ctrl_lim, c->alphas, c->cost_pred, U_alpha_dev);
+    return hipGetLastError();
+}
+template <int NT>
+static hipError_t launch_ft_sc(Ctx *c, double *U_alpha_dev)
+{
+    const int rows = c->n + 2 - 16 * (NT - 1), ncl = rows >= 16 ? 4 : (rows + 3) / 4, ncu = (c->d.m + 3) / 4;
+#define KP_SC(NCL_, NCU_) if (ncl == NCL_ && ncu == NCU_) return launch_ft_sc2<NT, NCL_, NCU_>(c, U_alpha_dev);
+    KP_SC(1, 1) KP_SC(2, 1) KP_SC(3, 1) KP_SC(4, 1) KP_SC(1, 2) KP_SC(2, 2) KP_SC(3, 2) KP_SC(4, 2)
+#undef KP_SC
+    return hipErrorInvalidValue;
+}
+
+// The state / cost wave groups (k_forward_tiled_sc): materialised tiles, two row tiles, while every one of the 2 NT waves of a
+// trajectory finds a SIMD of its own (configs[2]: 64 trajectories x 4 waves on 1024 SIMDs).  KPILQR_TILED_FSC = 0 | 1 overrides.
+bool forward_tiled_sc_selected(const Ctx *c)
+{
+    const int nt = tiled_nt(c->n, c->tune.tiled_nt_min);
+    if (nt != 2 || c->tiled_a4 || c->tiled_a6 || c->d.m > 8) return false;
+    if (c->tune.tiled_fsc >= 0) return c->tune.tiled_fsc != 0;
+    return 2 * nt * c->d.batch <= c->n_simd;
+}
+
 template <int NT>
 static hipError_t launch_ft(Ctx *c, double *U_alpha_dev)
 {
+    if constexpr (NT == 2) { if (forward_tiled_sc_selected(c)) return launch_ft_sc<NT>(c, U_alpha_dev); }
     if (c->tiled_a4) return c->tiled_a6 ? launch_ft2<NT, true, true>(c, U_alpha_dev) : launch_ft2<NT, false, true>(c, U_alpha_dev);
     return c->tiled_a6 ? launch_ft2<NT, true, false>(c, U_alpha_dev) : launch_ft2<NT, false, false>(c, U_alpha_dev);
 }
