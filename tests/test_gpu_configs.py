@@ -156,6 +156,42 @@ def test_ragged_lists_on_two_and_three_tiles(task, T, batch, fused):
         check_against_oracle(p, b, K, k, res)
 
 
+@pytest.mark.parametrize("task,T,batch", [("panda_pushing", 420, 4), ("walker", 333, 3), ("arm5x2", 200, 2), ("arm8", 150, 2)])
+def test_two_tile_forward_state_cost_wave_groups(task, T, batch, monkeypatch):
+    """The two-tile forward sweep on materialised tiles comes in two organisations: one wave per row tile (k_forward_tiled), and --
+    while the 2 NT waves of a trajectory each find a SIMD, the library's default then -- state / cost wave groups
+    (k_forward_tiled_sc: the recursion's waves do not score, two more waves score one step behind).  Both against the oracle
+    (control law / clamp iLQR.cpp:876-890 exact, predicted costs 1e-9) and against each other, controls included; the library
+    says which one ran (kpilqr_last_launch)."""
+    dof = synth.TASKS[task]["dof"]
+    rng = np.random.default_rng(dof + T)
+    rows = [synth.bisect_keypoints(rng, dof, T, 1, rng.uniform(0.05, 0.9, dof)) for _ in range(batch)]
+    p = synth.make_ragged_problem(task, T, rows, config_id=4, dense_residuals=True, one_sided_frac=0.1)
+    p["u_nom"] *= 3.0                                            # some candidates hit the control limits
+    out = {}
+    for fsc in ("0", "1", None):
+        if fsc is None:
+            monkeypatch.delenv("KPILQR_TILED_FSC", raising=False)
+        else:
+            monkeypatch.setenv("KPILQR_TILED_FSC", fsc)
+        # (arm5x2, n = 10, fits one tile: KPILQR_FLAG_TILED_KERNELS runs it on two -- the second tile all structural zeros)
+        with Engine(p["dof"], p["m"], T, p["nr"], batch=batch, tiled=task == "arm5x2") as e:
+            synth.upload(e, p)
+            e.fd_difference(); e.interpolate(); e.cost_derivs()
+            st, dJ = e.backward(p["lam"], 100)
+            cost, U = e.forward_linear(orc.alphas(6), want_U=True)
+            out[fsc] = (cost, U, e.last_launch("forward"))
+            assert np.all(st == 0)
+    assert out["0"][2] == "mfma_f64_tiled" and out["1"][2] == "mfma_f64_tiled:state_cost_waves" and out[None][2] == out["1"][2], [v[2] for v in out.values()]
+    for b in range(batch):
+        o = pipeline.run_trajectory(p, b, want_U=True)
+        for key in ("0", "1"):
+            assert relerr(out[key][0][b], o["cost_pred"]) < TIGHT, (key, b)
+            assert relerr(out[key][1][b], o["U_alpha"]) < TIGHT, (key, b)
+    assert relerr(out["1"][0], out["0"][0]) < 1e-12 and np.array_equal(out["1"][1], out["0"][1])
+    assert np.array_equal(out[None][0], out["1"][0])
+
+
 def _full_batch_parity(*argv):
     import json, subprocess, sys, os
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))

@@ -1743,7 +1743,8 @@ static hipError_t launch_ft_sc2(Ctx *c, double *U_alpha_dev)
 template <int NT>
 static hipError_t launch_ft_sc(Ctx *c, double *U_alpha_dev)
 {
-    const int rows = c->n + 2 - 16 * (NT - 1), ncl = rows >= 16 ? 4 : (rows + 3) / 4, ncu = (c->d.m + 3) / 4;
+    // (a state smaller than one tile run on two: the second tile is all structural zeros -- one chunk of them)
+    const int rows = c->n + 2 - 16 * (NT - 1), ncl = rows >= 16 ? 4 : rows < 1 ? 1 : (rows + 3) / 4, ncu = (c->d.m + 3) / 4;
 #define KP_SC(NCL_, NCU_) if (ncl == NCL_ && ncu == NCU_) return launch_ft_sc2<NT, NCL_, NCU_>(c, U_alpha_dev);
     KP_SC(1, 1) KP_SC(2, 1) KP_SC(3, 1) KP_SC(4, 1) KP_SC(1, 2) KP_SC(2, 2) KP_SC(3, 2) KP_SC(4, 2)
 #undef KP_SC
