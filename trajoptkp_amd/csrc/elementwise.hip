@@ -177,28 +177,50 @@ hipError_t launch_fd_difference_kpc(Ctx *c)
 // key-point ordered payload -> kpc.  One record per CSR entry, [(x+, x-) pairs of its 3n elements | int32 mode, pad]; a lane owns
 // two consecutive elements of an entry (32 bytes in, one 16-byte pair out); bit `kind` of the entry's mode says one-sided (the
 // host has put the nominal next state into the x- or x+ slot: / eps), else central: / (2 eps)
+// SLOPES: the slope store of the per-DoF list forms (k_kp_slopes) written in the same pass -- the thread differences the same two
+// elements of the list's NEXT entry as well (the neighbouring record: a cache hit, other threads read it at about the same time)
+// and forms (next - this) / (time gap): no second kernel, no second pass over the column store.
+template <bool SLOPES>
 __global__ void __launch_bounds__(256)
 k_fd_kp_difference(int n, long long npairs_total, unsigned long long magic, const double2 *__restrict__ rec, double eps,
-                   double2 *__restrict__ kpc, const int *__restrict__ skip_if_uniform)
+                   double2 *__restrict__ kpc, const int *__restrict__ skip_if_uniform, int entries_total,
+                   const int *__restrict__ times, double2 *__restrict__ kps)
 {
     // launched beside the raw backward sweep, which differences UNIFORM key-point sets itself: then this kernel leaves at once
     if (skip_if_uniform && *skip_if_uniform != 0) return;
     const int pe = 3 * (n >> 1);                     // pairs per entry
     const int s2 = 3 * n + 1;                        // record stride in double2
     const long long stride = (long long)gridDim.x * blockDim.x;
-    for (long long w = (long long)blockIdx.x * blockDim.x + threadIdx.x; w < npairs_total; w += stride) {
-        const long long e = magic ? (long long)__umul64hi((unsigned long long)w, magic) : w;      // w / pe
-        const int p = (int)(w - e * pe);
-        const double2 *r = rec + e * s2;
+    auto column = [&](const double2 *r, int p) -> double2 {       // elements 2p, 2p + 1 of an entry's differenced columns
         const int mode = ((const int *)(r + 2 * pe))[0];
         const double den = ((mode >> (p / (n >> 1))) & 1) ? eps : 2 * eps;
 #if KP_RAW_PAIRS
         const double2 a = r[2 * p], b = r[2 * p + 1];            // (x+, x-) of elements 2p and 2p + 1
-        kpc[w] = make_double2((a.x - a.y) / den, (b.x - b.y) / den);
+        return make_double2((a.x - a.y) / den, (b.x - b.y) / den);
 #else
         const double2 a = r[p], b = r[pe + p];
-        kpc[w] = make_double2((a.x - b.x) / den, (a.y - b.y) / den);
+        return make_double2((a.x - b.x) / den, (a.y - b.y) / den);
 #endif
+    };
+    for (long long w = (long long)blockIdx.x * blockDim.x + threadIdx.x; w < npairs_total; w += stride) {
+        const long long e = magic ? (long long)__umul64hi((unsigned long long)w, magic) : w;      // w / pe
+        const int p = (int)(w - e * pe);
+        const double2 *r = rec + e * s2;
+        const double2 a = column(r, p);
+        kpc[w] = a;
+        if constexpr (SLOPES) {
+            double2 sl = make_double2(0.0, 0.0);
+            if (e + 1 < entries_total) {
+                const int ts = times[e], te = times[e + 1];
+                if (te > ts) {                                     // canonical lists: the next entry belongs to the same list
+                    const double gap = (double)(te - ts);
+                    const double2 b = column(r + s2, p);
+                    sl = make_double2((b.x - a.x) / gap, (b.y - a.y) / gap);
+                }
+            }
+            kps[2 * w] = make_double2(a.x, sl.x);
+            kps[2 * w + 1] = make_double2(a.y, sl.y);
+        }
     }
 }
 
@@ -212,9 +234,15 @@ hipError_t launch_fd_kp_difference(Ctx *c, bool only_if_ragged)
     const long long want = (npairs + 256LL * 4 - 1) / (256LL * 4);
     const long long cap = (long long)(c->n_simd / 4) * 128;
     const int blocks = (int)(want < cap ? (want < 1 ? 1 : want) : cap);
-    hipLaunchKernelGGL(k_fd_kp_difference, dim3(blocks), dim3(256), 0, c->stream, c->n, npairs, magic,
-                       (const double2 *)(c->fdk_dev + (size_t)c->fdk_first * c->fdk_stride()), c->eps,
-                       (double2 *)(c->kpc + (size_t)c->fdk_first * 3 * c->n), only_if_ragged ? c->kp_uniform : (const int *)nullptr);
+    const double2 *rec = (const double2 *)(c->fdk_dev + (size_t)c->fdk_first * c->fdk_stride());
+    double2 *kpc = (double2 *)(c->kpc + (size_t)c->fdk_first * 3 * c->n);
+    const int *flag = only_if_ragged ? c->kp_uniform : (const int *)nullptr;
+    if (c->kps)         // per-DoF lists possible: their slope store in the same pass (fd_kp_difference_makes_slopes)
+        hipLaunchKernelGGL(k_fd_kp_difference<true>, dim3(blocks), dim3(256), 0, c->stream, c->n, npairs, magic, rec, c->eps, kpc, flag, c->fdk_entries,
+                           c->kp_times + c->fdk_first, (double2 *)(c->kps + (size_t)c->fdk_first * 6 * c->n));
+    else
+        hipLaunchKernelGGL(k_fd_kp_difference<false>, dim3(blocks), dim3(256), 0, c->stream, c->n, npairs, magic, rec, c->eps, kpc, flag, 0,
+                           (const int *)nullptr, (double2 *)nullptr);
     return hipGetLastError();
 }
 

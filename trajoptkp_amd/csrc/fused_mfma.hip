@@ -55,6 +55,9 @@ typedef unsigned long long u64;
 #ifndef KP_FWD_SETS
 #define KP_FWD_SETS 4              // register sets of the one-wave forward sweep (requests run this many steps ahead)
 #endif
+#ifndef KP_FWD_SETS_GEN
+#define KP_FWD_SETS_GEN 4          // ... of its general (per-DoF list) form, whose tracker holds 32 more registers than the uniform form's
+#endif
 #ifndef KP_BWD_LATE_STORE
 #define KP_BWD_LATE_STORE 1
 #endif
@@ -1804,7 +1807,7 @@ __device__ __forceinline__ void forward_fused_body(RecLayout L, FusedArgs F, int
     // t+2 right behind each tile's last use.  A wavefront's loads return in order and a step is shorter than a trip to HBM
     // (the sweep ran at one memory latency per step with a single set: 2.66 ms at B = 128 where its arithmetic needs 2.13,
     // -DKP_PROBE_SAMEB), so the requests have to be two steps ahead of their use.
-    constexpr int NS = KP_FWD_SETS;
+    constexpr int NS = UNI ? KP_FWD_SETS : KP_FWD_SETS_GEN;
     Tiles S[NS];
     d4 RxTc = {0.0, 0.0, 0.0, 0.0};
     if constexpr (RXC) {
@@ -1832,10 +1835,20 @@ __device__ __forceinline__ void forward_fused_body(RecLayout L, FusedArgs F, int
     };
     auto advance = [&](int t) {
         if constexpr (FSLP) {
-            if (t >= e) {                     // per lane: reached the end key-point of the segment = the start of the next one
+            // A lane that reaches the end key-point of its segment takes the (value, slope) pairs requested a crossing ago -- register
+            // moves -- and requests the pairs of the segment after.  The REQUESTS are issued by ALL lanes, behind a wave-uniform
+            // branch ("some lane crosses"): a lane that does not cross re-requests the entry it already holds.  With the loads inside
+            // the per-lane branch their results met the old values at the join of the branch -- copies of freshly loaded registers,
+            // i.e. `s_waitcnt vmcnt(0)` on EVERY step: the wave drained its four tile sets in flight once per step and ran at one
+            // trip to HBM per step (2.7 ms where the uniform form takes 1.8).  Now nothing waits for these loads before the
+            // lane's next crossing.
+            const bool cr = t >= e;
+            if (__builtin_amdgcn_ballot_w64(cr) != 0) {
+                if (cr) {
 #pragma unroll
-                for (int i = 0; i < 8; i++) { sv[i] = ev[i]; av[i] = ea[i]; }
-                s = e; e = nb; idx++;
+                    for (int i = 0; i < 8; i++) { sv[i] = ev[i]; av[i] = ea[i]; }
+                    s = e; e = nb; idx++;
+                }
                 const int en = (idx + 1 < khi) ? idx + 1 - E0 : -1;
                 load_col2(rS, co, en, NE, 2 * strideB, ev, ea);
                 nb = (idx + 2 < khi) ? F.kp_times[idx + 2] : BIGT;
@@ -2432,8 +2445,7 @@ hipError_t launch_backward_fused(Ctx *c, int pd_stride, bool raw)
     do {                                                                                                                \
         if (raw && c->tune.fused_uni != 0) {                                                                            \
             LAUNCH4(NN, MM, RU, true, true);                                                                            \
-            hipError_t e_ = launch_fd_kp_difference(c, true);                                                           \
-            if (e_ == hipSuccess) e_ = launch_kp_slopes(c, true);    /* (per-DoF lists: columns, then their slopes) */  \
+            hipError_t e_ = launch_fd_kp_difference(c, true);     /* (per-DoF lists: columns and their slopes) */       \
             if (e_ != hipSuccess) return e_;                                                                            \
             LAUNCH4(NN, MM, RU, false, false);                                                                          \
         } else if (raw) LAUNCH3(NN, MM, RU, true);                                                                      \

@@ -224,6 +224,7 @@ static int difference_to_kpc(kpilqr_ctx *c)
     }
     int rc = ensure_kpc(c);
     if (rc) return rc;
+    if (c->fused) { rc = ensure_kps(c); if (rc) return rc; }       // (only the fused sweeps' per-DoF list forms read the slope store)
     c->kps_valid = false;
     if (c->fd_kind == 1) {
         rc = ensure_entry_tables(c);
@@ -231,6 +232,7 @@ static int difference_to_kpc(kpilqr_ctx *c)
         KP_HIP(c, launch_fd_difference_kpc(c));
     } else {
         KP_HIP(c, launch_fd_kp_difference(c));
+        if (c->kps) c->kps_valid = true;         // (the slope store of per-DoF lists is written in the same pass)
     }
     c->kpc_valid = true;
     return KPILQR_OK;
