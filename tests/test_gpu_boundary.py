@@ -177,6 +177,54 @@ print("RESULT " + json.dumps(out), flush=True)
 """
 
 
+def test_device_generated_keypoints_size_the_column_store_and_check_the_payload():
+    """Round-3 advisor findings: after kpilqr_generate_keypoints the library knows the number of entries (one int read back), so
+    (1) a key-point ordered upload whose `entries` is not that number is refused BEFORE kpilqr_get_keypoints has ever run -- the
+    sweeps index the slab by the device lists, a smaller slab would be read past its end -- and (2) the column store is sized
+    from the real count, not from the worst case batch * dof * T (Panda, T = 3000, 64 trajectories: 1.35 GB against 90 MB)."""
+    import torch
+    T, B = 3000, 64
+    p0 = synth.make_problem(task="panda_reaching", T=T, batch=1, min_N=5)
+    p = synth.tile_problem(p0, B)
+    xp, xm, mode = synth.kp_ordered_payload(p)
+    torch.cuda.synchronize(); torch.cuda.empty_cache()
+    free0 = torch.cuda.mem_get_info()[0]
+    with Engine(p["dof"], p["m"], T, p["nr"], batch=B, fused=True) as e:
+        base = free0 - torch.cuda.mem_get_info()[0]               # gains, residuals, Jacobians ...
+        e.generate_keypoints("set_interval", 5)
+        s = e.fd_kp_slab(xp, xm, mode, pinned=False)
+        bad = dict(s); bad["entries"] = s["entries"] - 7
+        with pytest.raises(KpilqrError) as ei:
+            e.upload_fd_kp(bad)                                     # ... without kpilqr_get_keypoints in between
+        assert ei.value.code == -1
+        e.upload_fd_kp(s, eps=p["eps"])
+        e.upload_residuals(p["r"], p["r_x"], None, p["w_run"], p["w_term"]); e.upload_nominal(p["u_nom"], p["ctrl_lim"])
+        e.iterate(p["lam"], 100, orc.alphas(6)); e.sync()
+        used = free0 - torch.cuda.mem_get_info()[0] - base
+        K, _ = e.gains()
+    # key-point times (worst case kept: 5.4 MB), payload slab (~245 MB), column store (~90 MB) -- far from the worst-case 1.35 GB store
+    assert used < 600e6, used
+    o = pipeline.run_trajectory(p0, 0)
+    assert relerr(K[0], o["K"]) < 1e-9 and np.array_equal(K[0], K[B - 1])
+
+
+def test_streamed_iteration_redifferences_a_resident_job_list_after_new_keypoints():
+    """Round-3 advisor finding: kpilqr_iterate_streamed without a new payload, on a fused context whose resident payload is a JOB
+    LIST and whose key-points have been set again since (the column store is stale): the chunks have no jobs of their own, so the
+    payload is re-differenced on the context first -- the result is kpilqr_iterate's."""
+    p = synth.make_problem(task="panda_reaching", T=160, batch=6, min_N=4, dense_residuals=True, one_sided_frac=0.2)
+    with Engine(p["dof"], p["m"], p["T"], p["nr"], batch=6, fused=True) as e:
+        synth.upload(e, p)
+        e.iterate(p["lam"], 100, orc.alphas(6))
+        K0, _ = e.gains(); c0 = e.results()["cost_pred"]
+        e.set_keypoints_rows(p["kp_rows"])                          # the same lists again: the column store is invalidated
+        lam = e.pinned(6); lam[:] = p["lam"]
+        K = e.pinned(K0.shape); cp = e.pinned((6, 6))
+        e.iterate_streamed(lam=lam, K=K, cost_pred=cp, nchunks=3)
+        e.sync()
+        assert np.array_equal(K, K0) and np.array_equal(cp, c0)
+
+
 def test_c_abi_linesearch_allreduce_two_processes(tmp_path):
     """Two fresh processes, one kpilqr_ctx each, kpilqr_comm_unique_id -> kpilqr_comm_init(nranks = 2) ->
     kpilqr_allreduce_linesearch, against the sum of the two ranks' local vectors.  With two GPUs visible the ranks use

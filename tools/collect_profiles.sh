@@ -41,6 +41,13 @@ for pass in "fetch FETCH_SIZE" "write WRITE_SIZE" "m3 SQ_VALU_MFMA_BUSY_CYCLES S
   rocprofv3 --pmc "$@" --output-format csv -d $OUT/pmc_$name -- python3 $OLDPWD/bench.py $WL $EXTRA --no-secondary --no-cpu-baseline --steps 3 --warmup 1 > $OUT/pmc_$name.log 2>&1 || exit 1
   echo "pmc $name done"
 done
+if [ "$MODE" != per_step ]; then
+  # the headline shape with the reference's own key-point method for reaching (per-DoF lists: reaching.yaml:6-8) and adaptive_jerk
+  for kp in reach_velocity_change reach_adaptive_jerk; do
+    rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/stats_$kp -- python3 $OLDPWD/bench.py --keypoints $kp --no-secondary --no-cpu-baseline --steps 10 --warmup 2 > $OUT/stats_$kp.log 2>&1 || exit 1
+    echo "stats $kp done"
+  done
+fi
 cd $OLDPWD
 python tools/pmc_summarise.py $OUT $TAG $MODE || exit 1
 echo "summaries written"

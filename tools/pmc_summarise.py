@@ -81,7 +81,9 @@ for k in m3:
                              "lds_bank_conflict_cycles": d.get("SQ_LDS_BANK_CONFLICT", 0.0)}
 json.dump(cnt, open(os.path.join(root, "profiles", f"{tag}_pmc_counters{SUFFIX}.json"), "w"), indent=1)
 
-for sub, name in (("stats", f"{tag}_kernel_stats{SUFFIX}.csv"), ("stats_generic", f"{tag}_generic_kernel_stats.csv")):
+for sub, name in (("stats", f"{tag}_kernel_stats{SUFFIX}.csv"), ("stats_generic", f"{tag}_generic_kernel_stats.csv"),
+                  ("stats_reach_velocity_change", f"{tag}_kernel_stats_velocity_change_lists.csv"),
+                  ("stats_reach_adaptive_jerk", f"{tag}_kernel_stats_adaptive_jerk_lists.csv")):
     fs = glob.glob(os.path.join(out, sub, "**", "*kernel_stats.csv"), recursive=True)
     if fs:
         shutil.copy(fs[0], os.path.join(root, "profiles", name))
