@@ -13,7 +13,7 @@ from trajoptkp_amd import Engine, synth
 
 TASKS = ["panda_reaching", "acrobot", "hopper", "pentabot", "panda_pushing", "walker", "arm8", "arm5x2", "high_dof_push",
          "quadruped", "humanoid_fixed"]
-ENV_KEYS = ("KPILQR_FUSED_WAVES", "KPILQR_FUSED_FWD_WAVES", "KPILQR_TILED_A4", "KPILQR_TILED_A6")
+ENV_KEYS = ("KPILQR_FUSED_WAVES", "KPILQR_FUSED_FWD_WAVES", "KPILQR_TILED_A4", "KPILQR_TILED_A6", "KPILQR_TILED_FSC")
 TOL = 1e-8
 
 
@@ -41,6 +41,11 @@ def draw_case(rng, case):
         dof = synth.TASKS[task]["dof"]
         c["rows"] = [synth.bisect_keypoints(rng, dof, c["T"], int(rng.integers(1, 4)), rng.uniform(0.0, 1.0, dof)) for _ in range(c["batch"])]
     c["config_id"] = int(rng.integers(1, 6))
+    # round 4: payload form (job lists / key-point ordered records / host-differenced columns), differencing explicit or left to
+    # the sweeps (the raw forms), ONE constant residual Jacobian where the task has one
+    c["payload"] = str(rng.choice(["jobs", "kp_ordered", "columns"]))
+    c["explicit_fd"] = bool(rng.integers(0, 2))
+    c["rx_const"] = bool(rng.integers(0, 2))
     return c
 
 
@@ -63,8 +68,12 @@ def run_case(c, worst=None):
             p = synth.make_problem(task=c["task"], T=T, batch=batch, min_N=c["min_N"], dense_residuals=c["dense_res"],
                                    one_sided_frac=c["osf"], lam=lam, config_id=c["config_id"])
         with Engine(p["dof"], p["m"], T, p["nr"], batch=batch, fused=c["fused"]) as e:
-            synth.upload(e, p)
-            e.fd_difference()
+            payload = c.get("payload", "jobs")
+            synth.upload(e, p, kp_ordered=payload != "jobs", rx_const=c.get("rx_const", False))
+            if payload == "columns":
+                e.upload_kp_columns(e.kp_columns(*synth.kp_ordered_payload(p), eps=p["eps"]))
+            if c.get("explicit_fd", True) or "fused" not in e.backward_variant:
+                e.fd_difference()
             if "fused" not in e.backward_variant:
                 tail = e.backward_variant.rsplit("_", 1)[-1] if "tiled_" in e.backward_variant else ""
                 if "a4" not in tail: e.interpolate()
@@ -72,7 +81,7 @@ def run_case(c, worst=None):
             st, dJ = e.backward(lam, pd)
             K, k = e.gains()
             cost, U = e.forward_linear(orc.alphas(6), want_U=True)
-            var = e.backward_variant + "/" + e.forward_variant + ("/" + c["form"] if "fused" in e.backward_variant else "")
+            var = e.last_launch("backward") + " / " + e.last_launch("forward")
     finally:
         for key, val in saved.items():
             if val is None: os.environ.pop(key, None)
