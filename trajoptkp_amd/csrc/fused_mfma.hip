@@ -70,6 +70,11 @@ typedef unsigned long long u64;
 #ifndef KP_PROBE_BWD
 #define KP_PROBE_BWD 0
 #endif
+#ifndef KP_XSWAP
+#define KP_XSWAP 0                  // 1: the running inverse's two tiles alternate their roles instead of being rotated by copies; every step is then
+                                    // instantiated for both assignments -- built in round 4, parity-green, SLOWER (4.94 against 4.52 ms: twice the code,
+                                    // 166 AGPRs instead of 67), kept as a switch for the record
+#endif
 #ifndef KP_KINK4
 #define KP_KINK4 1                  // 0: the step below a key-point refreshes the running inverse like every other step (round 3; A/B builds)
 #endif
@@ -128,12 +133,23 @@ __device__ __forceinline__ double bits_and(double a, u64 mask)
 {
     return __builtin_bit_cast(double, __builtin_bit_cast(u64, a) & mask);
 }
-// start + dt*slope, never contracted (k_interpolate's operation order)
+// start + dt*slope.  KP_LERP_FMA = 0: two instructions, never contracted -- k_interpolate's operation order, the bits the
+// materialising pipeline writes (KeyPointGenerator.cpp:933-948).  1: ONE fused multiply-add (a single rounding: at least as close
+// to the exact interpolant) -- 16 VALU instructions less per forward step and 8 per backward step on a wave that pays ~9 cycles
+// for each; the sweeps' results move by ~1e-16 relative (they are held to the oracle at 1e-9, not bit for bit: the MFMA
+// accumulation order differs from the reference's loops anyway); kpilqr_interpolate / get_AB still give the reference's bits.
+#ifndef KP_LERP_FMA
+#define KP_LERP_FMA 1
+#endif
 __device__ __forceinline__ double lerp_nc(double sv, double dt, double av)
 {
+#if KP_LERP_FMA
+    return __builtin_fma(dt, av, sv);
+#else
 #pragma clang fp contract(off)
     const double p = dt * av;
     return sv + p;
+#endif
 }
 
 struct FusedArgs {
@@ -516,6 +532,10 @@ __device__ __forceinline__ void backward_fused_body(double *sh, const double *pc
     int pd_counter = 0, fail = 0;
     double dJ = 0.0;
     d4 Xinv = zero, Xprev = zero, Iu;            // running inverse of Quu + lambda I (KP_NS), the one before it, the identity of the u-block
+    // KP_XSWAP: the two tiles ALTERNATE their roles from step to step instead of being rotated by copies (kp_inverse_refresh_sw):
+    // xpar = 0: Xinv holds N_{t+1} and Xprev N_{t+2}; xpar = 1: the other way round.  Every step is instantiated for both.
+    int xpar = 0;
+    (void)xpar;
     bool haveX = false;
     Iu.x = (q == c && c < m) ? 1.0 : 0.0; Iu.y = (4 + q == c && c < m) ? 1.0 : 0.0;
     Iu.z = (8 + q == c && c < m) ? 1.0 : 0.0; Iu.w = (12 + q == c && c < m) ? 1.0 : 0.0;
@@ -549,7 +569,11 @@ __device__ __forceinline__ void backward_fused_body(double *sh, const double *pc
 #endif
     // may_be_first: whether this call site can see the terminal step t = T-1 (only the first step of a sweep can: the call
     // sites inside the loops say no, and the selects of the terminal value function and weights leave the hot path)
-    auto step = [&](int t, auto may_be_first) __attribute__((always_inline)) -> bool {
+    auto step_sw = [&](int t, auto may_be_first, auto sw_tag) __attribute__((always_inline)) -> bool {
+        constexpr bool SW = decltype(sw_tag)::value;
+        d4 &Ncur = SW ? Xprev : Xinv;                  // N_{t+1}
+        d4 &Nold = SW ? Xinv : Xprev;                  // N_{t+2} in, N_t out (KP_XSWAP)
+        (void)Ncur; (void)Nold;
 #ifdef KP_CYC
         const unsigned long long cyc_s0 = __builtin_readcyclecounter();
 #endif
@@ -700,7 +724,11 @@ __device__ __forceinline__ void backward_fused_body(double *sh, const double *pc
         int ns_steps = 0;
         // (segment-loop forms: the peeled step is the one right below a key-point -- known at compile time)
         constexpr bool KINK = KP_KINK4 && UNI && !PC && decltype(may_be_first)::value;
+#if KP_XSWAP
+        const bool refreshed = haveX && !check_pd && kp_inverse_refresh_sw<NCU, KINK>(Qr, Iu, Ncur, Nold, m, STATS ? &ns_steps : nullptr);     // NEGATED inverses
+#else
         const bool refreshed = haveX && !check_pd && kp_inverse_refresh_n<NCU, KINK>(Qr, Iu, Xinv, Xprev, m, STATS ? &ns_steps : nullptr);    // Xinv, Xprev: NEGATED inverses
+#endif
         if constexpr (STATS) { if (refreshed) hcnt[ns_steps < 0 ? 0 : ns_steps > 3 ? 3 : ns_steps]++; }
 #else
         const bool refreshed = false;
@@ -711,7 +739,7 @@ __device__ __forceinline__ void backward_fused_body(double *sh, const double *pc
         }
         d4 Kp = zero;                                 // the gains -X
         if (refreshed) {
-            Kp = PS<NCU>(Xinv, Quz, zero);                                 // -(Quu + lambda I)^-1 Quz: the gains, with their sign
+            Kp = PS<NCU>(KP_XSWAP ? Nold : Xinv, Quz, zero);               // -(Quu + lambda I)^-1 Quz: the gains, with their sign
             done = true;
         }
         if (!done) {
@@ -809,6 +837,18 @@ __device__ __forceinline__ void backward_fused_body(double *sh, const double *pc
         if (PC) __syncthreads();                       // end of step: the ring slot is free, the next one is full
         else wsync();
         return true;
+    };
+    // the step for the current roles of the two inverse tiles; the roles swap behind every step (after a factorisation both
+    // tiles hold the same inverse, so either assignment is right)
+    auto step = [&](int t, auto may_be_first) __attribute__((always_inline)) -> bool {
+#if KP_XSWAP
+        bool r;
+        if (xpar) r = step_sw(t, may_be_first, std::true_type{}); else r = step_sw(t, may_be_first, std::false_type{});
+        xpar ^= 1;
+        return r;
+#else
+        return step_sw(t, may_be_first, std::false_type{});
+#endif
     };
     if constexpr (UNI && !PC) {
         // (Tried: ONE loop over the steps with the crossing's arithmetic behind a uniform branch at the top of the step and its
