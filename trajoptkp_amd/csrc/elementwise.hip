@@ -237,7 +237,7 @@ hipError_t launch_fd_kp_difference(Ctx *c, bool only_if_ragged)
     const double2 *rec = (const double2 *)(c->fdk_dev + (size_t)c->fdk_first * c->fdk_stride());
     double2 *kpc = (double2 *)(c->kpc + (size_t)c->fdk_first * 3 * c->n);
     const int *flag = only_if_ragged ? c->kp_uniform : (const int *)nullptr;
-    if (c->kps)         // per-DoF lists possible: their slope store in the same pass (fd_kp_difference_makes_slopes)
+    if (c->kps && !c->kp_known_uniform)         // per-DoF lists possible: their slope store in the same pass
         hipLaunchKernelGGL(k_fd_kp_difference<true>, dim3(blocks), dim3(256), 0, c->stream, c->n, npairs, magic, rec, c->eps, kpc, flag, c->fdk_entries,
                            c->kp_times + c->fdk_first, (double2 *)(c->kps + (size_t)c->fdk_first * 6 * c->n));
     else

@@ -232,7 +232,7 @@ static int difference_to_kpc(kpilqr_ctx *c)
         KP_HIP(c, launch_fd_difference_kpc(c));
     } else {
         KP_HIP(c, launch_fd_kp_difference(c));
-        if (c->kps) c->kps_valid = true;         // (the slope store of per-DoF lists is written in the same pass)
+        if (c->kps && !c->kp_known_uniform) c->kps_valid = true;         // (the slope store of per-DoF lists is written in the same pass)
     }
     c->kpc_valid = true;
     return KPILQR_OK;
