@@ -37,7 +37,8 @@ def key_of(name):
 def counters(passdir):
     """-> {kernel key: {counter: mean per launch (summed over the device)}}"""
     acc = {}
-    for f in glob.glob(os.path.join(out, passdir, "**", "*counter_collection.csv"), recursive=True):
+    # (a directory that several collection runs were merged into holds one file per run: the NEWEST is the run being summarised)
+    for f in sorted(glob.glob(os.path.join(out, passdir, "**", "*counter_collection.csv"), recursive=True), key=os.path.getmtime)[-1:]:
         per_dispatch = {}
         for row in csv.DictReader(open(f)):
             k = key_of(row["Kernel_Name"])
@@ -84,9 +85,9 @@ json.dump(cnt, open(os.path.join(root, "profiles", f"{tag}_pmc_counters{SUFFIX}.
 for sub, name in (("stats", f"{tag}_kernel_stats{SUFFIX}.csv"), ("stats_generic", f"{tag}_generic_kernel_stats.csv"),
                   ("stats_reach_velocity_change", f"{tag}_kernel_stats_velocity_change_lists.csv"),
                   ("stats_reach_adaptive_jerk", f"{tag}_kernel_stats_adaptive_jerk_lists.csv")):
-    fs = glob.glob(os.path.join(out, sub, "**", "*kernel_stats.csv"), recursive=True)
+    fs = sorted(glob.glob(os.path.join(out, sub, "**", "*kernel_stats.csv"), recursive=True), key=os.path.getmtime)
     if fs:
-        shutil.copy(fs[0], os.path.join(root, "profiles", name))
+        shutil.copy(fs[-1], os.path.join(root, "profiles", name))
 for src, name in (("bench.json", f"{tag}_bench{SUFFIX}.json"), ("generic.json", f"{tag}_generic_bench.json")):
     if os.path.exists(os.path.join(out, src)):
         shutil.copy(os.path.join(out, src), os.path.join(root, "profiles", name))
