@@ -12,9 +12,10 @@
 //     interpolates column-wise with one key-point list per DoF -- so each lane walks the key-point list of
 //     its own DoF and keeps (value at segment start, slope) in registers:
 //         A_t[:,c] = A_s[:,c] + (t-s) * ((A_e[:,c] - A_s[:,c]) / (e-s))          (:898-905, :933-948)
-//     same operation order as k_interpolate (no FMA contraction, correctly rounded division), so the
-//     interpolated values are the ones the materialising kernel would have written.  Key-point columns of
-//     the next segment are fetched one segment ahead (time indices two ahead).
+//     the slope is the correctly rounded quotient k_interpolate forms; the value is ONE fused multiply-add of it
+//     (KP_LERP_FMA, round 4: a single rounding where k_interpolate has two -- the sweeps are held to the oracle at 1e-9, the
+//     materialised A, B of kpilqr_interpolate keep the reference's bits).  Key-point columns of the next segment are
+//     fetched one segment ahead (time indices two ahead).
 //   * a6 (ModelTranslator::CostDerivativesFromResiduals, src/ModelTranslator/ModelTranslator.cpp:552-583):
 //     with Rz = [r_x | r] (nr x (n+1)) and W = diag(2w):  Lzz = [l_xx l_x; l_x' *] = Rz' W Rz is ONE
 //     P(Rz, W Rz); l_uu and l_u come out of P(Ru, W [Ru | r]) (columns < m and column n).  The reference
