@@ -402,3 +402,24 @@ def test_per_dof_lists_walk_the_slope_store(payload, monkeypatch):
                 e.iterate_streamed(fd_kp=s, eps=p["eps"], lam=lam, K=K, cost_pred=cp, nchunks=3, **pin)
             e.sync()
             assert np.array_equal(K, one["K"]) and np.array_equal(cp, one["cost"])
+
+
+def test_general_forms_forced_on_uniform_lists(monkeypatch):
+    """KPILQR_FUSED_UNI=0 (diagnostic): every key-point set counts as per-DoF lists, so the GENERAL forms of the one-wave sweeps --
+    the raw backward sweep that divides at its crossings, the forward sweep on the slope store -- run on set_interval lists too;
+    same gains as the segment-loop forms (1e-12) and the oracle's (1e-9), for either payload."""
+    p = synth.make_problem(task="panda_reaching", T=230, batch=3, min_N=4, one_sided_frac=0.2)
+    monkeypatch.setenv("KPILQR_FUSED_WAVES", "1"); monkeypatch.setenv("KPILQR_FUSED_FWD_WAVES", "1")
+    ref = _run(p, True, True)
+    monkeypatch.setenv("KPILQR_FUSED_UNI", "0")
+    for kp_ordered in (True, False):
+        with Engine(p["dof"], p["m"], p["T"], p["nr"], batch=3, fused=True) as e:
+            synth.upload(e, p, kp_ordered=kp_ordered)
+            e.iterate(p["lam"], 100, orc.alphas(6))
+            res = e.results(); K, k = e.gains()
+            lb, lf = e.last_launch("backward"), e.last_launch("forward")
+        assert ":ragged" in lb and ":ragged" in lf and ((":raw:" in lb) == kp_ordered), (lb, lf)
+        assert relerr(K, ref["K"]) < 1e-12 and relerr(res["cost_pred"], ref["cost"]) < 1e-11
+    for b in range(3):
+        o = pipeline.run_trajectory(p, b)
+        assert relerr(ref["K"][b], o["K"]) < 1e-9

@@ -2401,7 +2401,12 @@ int backward_fused_form(const Ctx *c)
 // The wave organisation launch_forward_fused will pick: 1 one wave per trajectory, 2 state / cost pair, 3 the triple
 int forward_fused_form(const Ctx *c)
 {
-    return c->tune.fused_fwd_waves ? c->tune.fused_fwd_waves : (4 * c->d.batch <= c->n_simd ? 3 : 1);
+    if (c->tune.fused_fwd_waves) return c->tune.fused_fwd_waves;
+    // With the constant residual Jacobian in registers the one-wave sweep runs 1.72 ms at every batch up to 256 (four loads of
+    // its fifteen per step gone), the triple 1.58 (one trajectory) ... 1.72 (64) ... 1.77 ms (256): the triple keeps the batches
+    // below 64 (profiles/r04_forward_forms.txt)
+    if (c->rx_const_on && c->ru_zero) return 16 * c->d.batch < c->n_simd ? 3 : 1;
+    return 4 * c->d.batch <= c->n_simd ? 3 : 1;
 }
 
 // raw: difference the key-point ordered payload inside the sweep (one-wave form only; the caller checks backward_fused_form)

@@ -1001,6 +1001,9 @@ static int run_backward(kpilqr_ctx *c, int pd_stride)
         if (!c->kpc_valid && c->fd_kind == 2 && (bform == 1 || bform == 3) && c->tune.fused_raw != 0) {
             KP_HIP(c, launch_backward_fused(c, pd_stride, true));
             c->kpc_touched = true;
+            // (KPILQR_FUSED_UNI=0, diagnostic: the GENERAL raw sweep has differenced every set inside the sweep -- dividing at its
+            // crossings -- and left the columns; the forward sweep's general form walks the slope store, made from them here)
+            if (c->tune.fused_uni == 0 && bform == 1 && c->kps) KP_HIP(c, launch_kp_slopes(c, false));
             return KPILQR_OK;
         }
         if (!c->kpc_valid) { rc = difference_to_kpc(c); if (rc) return rc; }
