@@ -565,7 +565,7 @@ __device__ __forceinline__ void backward_fused_body(double *sh, const double *pc
     };
     // one step of the sweep; false: the PD check of this step failed (the sweep ends)
 #ifdef KP_CYC
-    unsigned long long cyc_cross = 0, cyc_peel = 0, cyc_inner = 0, cyc_a = 0;
+    unsigned long long cyc_cross = 0, cyc_peel = 0, cyc_inner = 0, cyc_a = 0, cyc_b = 0, cyc_c = 0, cyc_d = 0, cyc_e = 0;
     const unsigned long long cyc_all0 = __builtin_readcyclecounter();
 #endif
     // may_be_first: whether this call site can see the terminal step t = T-1 (only the first step of a sweep can: the call
@@ -711,6 +711,11 @@ __device__ __forceinline__ void backward_fused_body(double *sh, const double *pc
             Quz = PS<NCZ>(Fu, Tz, Luz);
             Qzz = PS<NCZ>(Fz, Tz, Lzz);
         }
+#ifdef KP_CYC
+        asm volatile("" :: "v"(Quu.x), "v"(Quz.x), "v"(Qzz.x));
+        const unsigned long long cyc_s1 = __builtin_readcyclecounter();
+        cyc_b += cyc_s1 - cyc_s0;
+#endif
         d4 Qr = Quu;                                  // Quu + lambda I
         Qr.x += 0.5 * lam2d[0]; Qr.y += 0.5 * lam2d[1]; Qr.z += 0.5 * lam2d[2]; Qr.w += 0.5 * lam2d[3];
 
@@ -738,6 +743,11 @@ __device__ __forceinline__ void backward_fused_body(double *sh, const double *pc
             __syncthreads();
             Quz = lds_tile4(pcbuf + FPC_SIDE_QUZ, lane); Qzz = lds_tile4(pcbuf + FPC_SIDE_QZZ, lane);
         }
+#ifdef KP_CYC
+        asm volatile("" :: "v"(Xinv.x));
+        const unsigned long long cyc_s2 = __builtin_readcyclecounter();
+        cyc_c += cyc_s2 - cyc_s1;
+#endif
         d4 Kp = zero;                                 // the gains -X
         if (refreshed) {
             Kp = PS<NCU>(KP_XSWAP ? Nold : Xinv, Quz, zero);               // -(Quu + lambda I)^-1 Quz: the gains, with their sign
@@ -821,6 +831,11 @@ __device__ __forceinline__ void backward_fused_body(double *sh, const double *pc
         G.x = __builtin_fma(-lam, Kp.x, Quz.x); G.y = __builtin_fma(-lam, Kp.y, Quz.y);
         G.z = __builtin_fma(-lam, Kp.z, Quz.z); G.w = __builtin_fma(-lam, Kp.w, Quz.w);
         d4 acc = PS<NCU>(Kp, G, Qzz);
+#ifdef KP_CYC
+        asm volatile("" :: "v"(acc.x));
+        const unsigned long long cyc_s3 = __builtin_readcyclecounter();
+        cyc_d += cyc_s3 - cyc_s2;
+#endif
         sh[FLDS_V + (q) * FVS + c] = acc.x;
         sh[FLDS_V + (4 + q) * FVS + c] = acc.y;
         sh[FLDS_V + (8 + q) * FVS + c] = acc.z;
@@ -837,6 +852,10 @@ __device__ __forceinline__ void backward_fused_body(double *sh, const double *pc
         }
         if (PC) __syncthreads();                       // end of step: the ring slot is free, the next one is full
         else wsync();
+#ifdef KP_CYC
+        asm volatile("" :: "v"(V.x));
+        cyc_e += __builtin_readcyclecounter() - cyc_s3;
+#endif
         return true;
     };
     // the step for the current roles of the two inverse tiles; the roles swap behind every step (after a factorisation both
@@ -937,7 +956,9 @@ __device__ __forceinline__ void backward_fused_body(double *sh, const double *pc
     if (lane_nn) delta_J[b] = dJ;
 #ifdef KP_CYC
     if (lane_nn) { delta_J[b] = (double)cyc_cross; Kout[(size_t)b * T * m * n] = (double)cyc_peel; Kout[(size_t)b * T * m * n + 1] = (double)cyc_inner;
-                   Kout[(size_t)b * T * m * n + 2] = (double)(__builtin_readcyclecounter() - cyc_all0); Kout[(size_t)b * T * m * n + 3] = (double)cyc_a; }
+                   Kout[(size_t)b * T * m * n + 2] = (double)(__builtin_readcyclecounter() - cyc_all0); Kout[(size_t)b * T * m * n + 3] = (double)cyc_a;
+                   Kout[(size_t)b * T * m * n + 4] = (double)cyc_b; Kout[(size_t)b * T * m * n + 5] = (double)cyc_c;
+                   Kout[(size_t)b * T * m * n + 6] = (double)cyc_d; Kout[(size_t)b * T * m * n + 7] = (double)cyc_e; }
 #endif
     if (lane == 0) status[b] = fail;
     if constexpr (STATS) {
