@@ -306,24 +306,28 @@ def time_config(torch, stream, dev, p, steps, warmup, fused, generic, world=1, d
     is_fused = "fused" in eng.backward_variant
     tail = eng.backward_variant.rsplit("_", 1)[-1] if "tiled_" in eng.backward_variant else ""
     a4, a6 = "a4" in tail, "a6" in tail          # tiled shapes: which of a4 / a6 run inside the sweeps
-    # Fused sweeps: the FD payload is resident KEY-POINT ORDERED (kpilqr_upload_fd_kp); beyond 256 trajectories the backward pass
-    # differences x+ / x- itself at every segment crossing, on every timed step, and there is no differencing stage; below, and on
-    # materialising / tiled contexts (job lists), kpilqr_fd_difference is a stage of every timed step.
+    # Fused sweeps: the FD payload is resident KEY-POINT ORDERED (kpilqr_upload_fd_kp) and the backward pass differences x+ / x-
+    # itself, on every timed step (one wave per trajectory: at its segment crossings; the pairs: in the helper / producer wave; per-DoF
+    # lists: k_fd_kp_difference inside the backward launch sequence) -- there is no differencing stage.  With the triple
+    # (KPILQR_FUSED_WAVES=4) and on materialising / tiled contexts (job lists), kpilqr_fd_difference is a stage of every timed step.
     rxc = bool(rx_const and p.get("rx_const") is not None)
     synth.upload(eng, p, kp_ordered=is_fused and kp_ordered, rx_const=rxc)
     lam = np.full(B, p["lam"])
     alphas = np.array([(i / 6.0) ** 2 for i in range(1, 7)])
-    # raw: the library's own choice for a key-point ordered payload on a fused context beyond #SIMDs / 4 trajectories -- the backward
-    # pass differences the payload itself on EVERY call (in the sweep with one wave per trajectory, in the producer wave of the
-    # pair; nothing marks the column store valid).  Otherwise (the triple, below that) the differencing is a stage of its own in
+    # raw: the library's own choice for a key-point ordered payload on a fused context -- the backward pass differences the
+    # payload itself on EVERY call (nothing marks the column store valid).  Otherwise the differencing is a stage of its own in
     # every timed step (kpilqr_fd_difference: a backward pass alone would find the column store of the unchanged payload still
-    # valid and skip it).
-    raw = is_fused and kp_ordered and (4 * B > 1024 or os.environ.get("KPILQR_FUSED_WAVES") in ("1", "3")) \
-        and os.environ.get("KPILQR_FUSED_WAVES") not in ("2", "4") and os.environ.get("KPILQR_FUSED_RAW") != "0"
+    # valid and skip it).  Asked of the library below, after the first backward pass (kpilqr_last_launch names the wave form).
+    raw = False
     stages = (() if raw else ("fd_difference",)) + (() if (is_fused or a4) else ("interpolate",)) + (() if (is_fused or a6) else ("cost_derivs",)) \
         + ("backward", "forward")
     calls = {"fd_difference": eng.fd_difference, "interpolate": eng.interpolate, "cost_derivs": eng.cost_derivs,
              "backward": lambda: eng.backward(None, 100, fetch=False), "forward": lambda: eng.forward_linear(None, fetch=False)}
+    if is_fused and kp_ordered:
+        eng.backward(lam, 100, fetch=False)
+        form = (eng.last_launch("backward").split(":") + [""])[1]
+        raw = form in ("w1", "pair", "pairh") and os.environ.get("KPILQR_FUSED_RAW") != "0"      # (the forms with a raw launch sequence)
+        if raw: stages = tuple(s for s in stages if s != "fd_difference")
     if "fd_difference" in stages: eng.fd_difference()
     if "interpolate" in stages: eng.interpolate()
     if "cost_derivs" in stages: eng.cost_derivs()

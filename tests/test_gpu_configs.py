@@ -219,20 +219,23 @@ def test_headline_dispatch_one_wave_raw_uniform_at_batch_1024():
     assert s["checked"] == 64 and max(l["max_rel_err_K"] for l in legs.values()) < 1e-9
 
 
-def test_headline_dispatch_pair_with_the_raw_producer_at_batch_320():
-    """256 < B <= 512 (a GPU's share of 1024 on two or three GPUs): the producer / consumer pair whose producer wave differences
-    the payload (":pair:raw:uni"), against the oracle and bit-identical with the differencing kernel in front of it."""
+def test_headline_dispatch_helper_pair_at_batch_320():
+    """B <= 512 (a GPU's share of 1024 on two or more GPUs): the consumer / helper pair whose helper wave differences the
+    payload (":pairh:raw:uni:ru0"), against the oracle, bit-identical with the differencing kernel in front of it and with the
+    constant residual Jacobian (":rxc")."""
     s = _full_batch_parity(320, 1000, "--sample", 64)
     legs = s["legs"]
-    assert legs["A"]["backward"].endswith(":pair:raw:uni") and legs["B"]["backward"].endswith(":pair:kpc:uni")
+    assert legs["A"]["backward"].endswith(":pairh:raw:uni:ru0") and legs["B"]["backward"].endswith(":pairh:kpc:uni:ru0")
+    assert legs["C"]["backward"].endswith(":pairh:raw:uni:ru0:rxc")
     assert legs["B"]["bit_identical"] and legs["C"]["bit_identical"]
 
 
 def test_every_trajectory_of_a_distinct_seed_batch_matches_the_oracle():
-    """B = 256 (the triple, which never differences itself: ":triple:kpc:uni") and, as a second leg that really is another
-    kernel, the one-wave raw sweep forced on the same batch: K, k, predicted costs, delta_J and status of EVERY trajectory
-    against the oracle.  (The committed 1024 x 3000 run: profiles/r04_full_batch_parity.txt.)"""
+    """B = 256 (the consumer / helper pair, ":pairh:raw:uni:ru0") and, as legs that really are other kernels, the triple behind
+    the differencing kernel and the one-wave raw sweep forced on the same batch: K, k, predicted costs, delta_J and status of
+    EVERY trajectory against the oracle.  (The committed 1024 x 3000 run: profiles/r04_full_batch_parity.txt.)"""
     s = _full_batch_parity(256, 1000)
     legs = s["legs"]
     assert s["checked"] == 256
-    assert legs["A"]["backward"].endswith(":triple:kpc:uni") and legs["B"]["backward"].endswith(":w1:raw:uni:ru0")
+    assert legs["A"]["backward"].endswith(":pairh:raw:uni:ru0") and legs["B"]["backward"].endswith(":pairh:kpc:uni:ru0")
+    assert legs["D"]["backward"].endswith(":triple:kpc:uni") and legs["E"]["backward"].endswith(":w1:raw:uni:ru0")

@@ -41,16 +41,18 @@ def _same(a, b, keys=("K", "k", "delta_J", "cost")):
         assert np.array_equal(a[key], b[key]), key
 
 
-@pytest.fixture(params=["one_wave", "auto", "pair"])
+@pytest.fixture(params=["one_wave", "auto", "pair", "triple"])
 def waves(request, monkeypatch):
-    """one_wave: the raw backward sweep; auto: small batches -> the triple behind the streaming differencing kernel; pair: the
-    producer / consumer pair, whose producer wave differences the payload (the form of 256 < batch <= 512)."""
+    """one_wave: the raw backward sweep; auto: small batches -> the consumer / helper pair, whose helper wave differences the
+    payload; pair: the producer / consumer pair (its producer wave differences); triple: behind the streaming differencing kernel."""
     if request.param == "one_wave":
         monkeypatch.setenv("KPILQR_FUSED_WAVES", "1")
         monkeypatch.setenv("KPILQR_FUSED_FWD_WAVES", "1")
     elif request.param == "pair":
         monkeypatch.setenv("KPILQR_FUSED_WAVES", "3")
         monkeypatch.setenv("KPILQR_ROLE_SHIFT", "0")
+    elif request.param == "triple":
+        monkeypatch.setenv("KPILQR_FUSED_WAVES", "4")
     return request.param
 
 
@@ -270,8 +272,8 @@ def test_host_differenced_columns_give_the_bytes_of_the_fd_payload(fused, waves)
                                              ("hopper", 150, 2, dict(min_N=4)), ("pentabot", 64, 3, dict(min_N=3))])
 def test_constant_residual_jacobians_give_the_bytes_of_the_streamed_form(task, T, batch, kw, waves):
     """One r_x [nr][n] uploaded once (Reaching.cpp:43-54: r = [q - q*, qdot] -> selector rows, r_u = 0) == the same matrix given
-    at every step: K, k, delta_J, predicted costs bit for bit, in every wave organisation (the one-wave sweeps keep the matrix
-    in registers and read no r_x; the others read its broadcast copy), for either payload form -- and against the oracle."""
+    at every step: K, k, delta_J, predicted costs bit for bit, in every wave organisation (the one-wave sweeps and the helper
+    wave of the consumer / helper pair keep the matrix in registers and read no r_x; the others read its broadcast copy), for either payload form -- and against the oracle."""
     p = synth.make_problem(task=task, T=T, batch=batch, **kw)
     assert p["rx_const"] is not None and not np.any(p["r_u"])
     for kp_ordered in (True, False):
@@ -287,6 +289,8 @@ def test_constant_residual_jacobians_give_the_bytes_of_the_streamed_form(task, T
             if waves == "one_wave":
                 assert ":w1:" in lb and ":rxc" in lb and ":w1:" in lf and ":rxc" in lf, (lb, lf)
                 assert (":raw:" in lb) == kp_ordered
+            elif waves == "auto":                          # the consumer / helper pair: the helper keeps the matrix in registers
+                assert ":pairh:" in lb and lb.endswith(":ru0:rxc") and (":raw:" in lb) == kp_ordered, lb
             else:
                 assert ":rxc" not in lb, lb
             # the materialised cost derivatives see the same Jacobians (broadcast copy on demand)
@@ -379,8 +383,11 @@ def test_per_dof_lists_walk_the_slope_store(payload, monkeypatch):
 
     one = run({"KPILQR_FUSED_WAVES": "1", "KPILQR_FUSED_FWD_WAVES": "1"})
     assert ":w1:kpc:ragged" in one["lb"] and one["lb"].endswith(":slopes") and one["lf"].endswith(":slopes"), (one["lb"], one["lf"])
-    trip = run({})                                              # B = 5: the triples (crossings divide)
-    assert ":triple:" in trip["lb"] and "slopes" not in trip["lb"]
+    trip = run({})                                              # B = 5: the consumer / helper pair (its tracker divides at the crossings)
+    assert ":pairh:" in trip["lb"] and "slopes" not in trip["lb"]
+    trip4 = run({"KPILQR_FUSED_WAVES": "4"})                    # ... and the triple
+    assert ":triple:" in trip4["lb"] and "slopes" not in trip4["lb"]
+    assert all(np.array_equal(trip[key], trip4[key]) for key in ("K", "k", "delta_J"))      # (the same products in the same order)
     for b in range(B):
         o = pipeline.run_trajectory(p, b)
         assert relerr(one["K"][b], o["K"]) < 1e-9 and relerr(one["cost"][b], o["cost_pred"]) < 1e-9

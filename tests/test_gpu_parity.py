@@ -749,17 +749,17 @@ def test_c_abi_linesearch_allreduce_single_rank():
         assert np.allclose(kd.pack_linesearch(cost, dJ, st).numpy(), v0, rtol=1e-13)
 
 
-@pytest.mark.parametrize("waves", ["1", "2", "3", "4"])
+@pytest.mark.parametrize("waves", ["1", "2", "3", "4", "5"])
 def test_fused_two_wave_backward_variant(monkeypatch, waves):
-    """The wave organisations of the fused backward pass (DESIGN.md section 4.6) compute the same gains:
+    """The wave organisations of the fused backward pass (DESIGN.md section 4.4) compute the same gains:
     KPILQR_FUSED_WAVES=1 one wave per trajectory (the default above #SIMDs/2 trajectories), =2 the control-side /
-    state-side split, =3 the producer / consumer pair (the default up to #SIMDs/2 trajectories), =4 the consumer / side /
-    producer triple (the default up to #SIMDs/3)."""
+    state-side split, =3 the producer / consumer pair, =4 the consumer / side / producer triple, =5 the consumer / helper pair
+    (the default up to #SIMDs/2 trajectories)."""
     monkeypatch.setenv("KPILQR_FUSED_WAVES", waves)
     # forward sweep: one wave per trajectory with "1", the state / cost pair with "2", the state / cost / staging triple
-    # (the default up to #SIMDs/4 trajectories) with "3" and "4"
-    monkeypatch.setenv("KPILQR_FUSED_FWD_WAVES", "3" if waves == "4" else waves)
-    if waves in ("3", "4"):
+    # (the default up to #SIMDs/4 trajectories) with "3", "4" and "5"
+    monkeypatch.setenv("KPILQR_FUSED_FWD_WAVES", "3" if waves in ("4", "5") else waves)
+    if waves in ("3", "4", "5"):
         monkeypatch.setenv("KPILQR_ROLE_SHIFT", "0")             # alternate the roles with the block index
     for kw in (PROBLEMS["panda_T64"], PROBLEMS["acrobot_T100"], dict(task="panda_reaching", T=301, batch=3, min_N=4)):
         p = synth.make_problem(**kw)
@@ -826,10 +826,11 @@ def test_fused_forward_uniform_keypoint_flag(monkeypatch, mix):
     check_fused(run_fused(p), p)
 
 
-@pytest.mark.parametrize("batch", [256, 264])
+@pytest.mark.parametrize("batch", [256, 512, 520])
 def test_fused_wave_forms_at_their_batch_limits(batch):
-    """The backward triple runs while batch <= #CUs (256), the producer / consumer pair beyond: the two batches either side
-    of the switch, a few trajectories of each against the oracle, replicas of a seed bit-identical."""
+    """The consumer / helper pair runs the backward sweep while 2 x batch <= #SIMDs (512), one wave per trajectory beyond; the
+    forward triple while 4 x batch <= #SIMDs: the batches either side of the switches, a few trajectories of each against the
+    oracle, replicas of a seed bit-identical."""
     p0 = synth.make_problem(task="panda_reaching", T=60, batch=8, min_N=4, dense_residuals=True)
     reps = (batch + 7) // 8
     p = synth.tile_problem(p0, reps)

@@ -11,10 +11,11 @@ Legs, all in the default environment except for the one switch named: the form e
   B > 512         A  w1:raw:uni (one wave per trajectory, the payload differenced inside the backward sweep: the bench's kernel)
                   B  KPILQR_FUSED_RAW=0 -> w1:kpc:uni (k_fd_kp_difference first)          bit-identical to A
                   C  constant residual Jacobians -> w1:raw:uni:ru0:rxc                     bit-identical to A
-  256 < B <= 512  A  pair:raw:uni (the producer wave differences) | B  KPILQR_FUSED_RAW=0 -> pair:kpc:uni, bit-identical to A
-                  C  constant Jacobians (the pair streams their broadcast copy)            bit-identical to A
-  B <= 256        A  triple:kpc:uni (the triple never differences itself)
-                  B  KPILQR_FUSED_WAVES=1 + KPILQR_FUSED_FWD_WAVES=1 -> w1:raw:uni         another kernel: 1e-9 to the oracle
+  B <= 512        A  pairh:raw:uni:ru0 (consumer / helper pair, the helper wave differences)
+                  B  KPILQR_FUSED_RAW=0 -> pairh:kpc:uni:ru0                               bit-identical to A
+                  C  constant residual Jacobians -> pairh:raw:uni:ru0:rxc                  bit-identical to A
+  B <= 256 also   D  KPILQR_FUSED_WAVES=4 -> triple:kpc:uni (behind k_fd_kp_difference)    another kernel: 1e-9 to the oracle
+                  E  KPILQR_FUSED_WAVES=1 + KPILQR_FUSED_FWD_WAVES=1 -> w1:raw:uni:ru0     another kernel: 1e-9 to the oracle
 Every leg: K, k, delta_J, predicted costs of the sampled trajectories within 1e-9 of the oracle, statuses equal."""
 import argparse
 import json
@@ -74,13 +75,13 @@ if 2 * B > n_simd:
     legs = [("A", {}, False, ":w1:raw:uni:ru0", None),
             ("B", {"KPILQR_FUSED_RAW": "0"}, False, ":w1:kpc:uni:ru0", "A"),
             ("C", {}, True, ":w1:raw:uni:ru0:rxc", "A")]
-elif 4 * B > n_simd:
-    legs = [("A", {}, False, ":pair:raw:uni", None),
-            ("B", {"KPILQR_FUSED_RAW": "0"}, False, ":pair:kpc:uni", "A"),
-            ("C", {}, True, ":pair:raw:uni", "A")]
 else:
-    legs = [("A", {}, False, ":triple:kpc:uni", None),
-            ("B", {"KPILQR_FUSED_WAVES": "1", "KPILQR_FUSED_FWD_WAVES": "1"}, False, ":w1:raw:uni:ru0", None)]
+    legs = [("A", {}, False, ":pairh:raw:uni:ru0", None),
+            ("B", {"KPILQR_FUSED_RAW": "0"}, False, ":pairh:kpc:uni:ru0", "A"),
+            ("C", {}, True, ":pairh:raw:uni:ru0:rxc", "A")]
+    if 4 * B <= n_simd:
+        legs += [("D", {"KPILQR_FUSED_WAVES": "4"}, False, ":triple:kpc:uni", None),
+                 ("E", {"KPILQR_FUSED_WAVES": "1", "KPILQR_FUSED_FWD_WAVES": "1"}, False, ":w1:raw:uni:ru0", None)]
 
 results, summary = {}, {"batch": B, "T": T, "checked": int(S), "n_simd": int(n_simd), "legs": {}}
 for name, env, rxc, want, same_as in legs:

@@ -584,7 +584,8 @@ __device__ __forceinline__ void backward_fused_body(double *sh, const double *pc
         (void)cross;
         if constexpr (PC) {
             const double *tb = pcbuf + (t & 1) * FPC_BUF;
-            Fu = lds_tile4(tb + 256, lane); LU = lds_tile4(tb + 768, lane);
+            Fu = lds_tile4(tb + 256, lane);
+            if constexpr (RU0) LU = zero; else LU = lds_tile4(tb + 768, lane);
             if constexpr (SIDE) {                     // Fz, Lzz are the side wave's operands; only V = Lzz of the last step is ours
                 Fz = zero; Lzz = zero;
                 if (term) Lzz = lds_tile4(tb + 512, lane);
@@ -1471,7 +1472,7 @@ __device__ __forceinline__ void fused2_role_Z(double *sh, RecLayout L, FusedArgs
         if (NCU > 3) sh[F2_Z + c * 17 + 12 + q] = Quz.w;
         const d4 Qzz = PS<NCZ>(Fz, Tz, Lzz);                                  // :570,575
         __syncthreads();
-        if (sflag[0]) break;
+        if (__builtin_amdgcn_readfirstlane(sflag[0])) break;
         // ---- phase 2 (off the critical path): next step's A,B columns and Lzz -----------------------------------
         if (t > 0) {
             tr.advance(rT, F.kp_times, t - 1, strideB);
@@ -1519,9 +1520,17 @@ k_backward_fused2(RecLayout L, FusedArgs F, int T, int role_shift, const double 
 // s_barrier per step: at the end of step t the consumer has read slot t&1 and the producer has filled slot (t-1)&1.
 // Two waves per SIMD at batch = #SIMDs: the producer's independent MFMAs and FP64 FMAs issue into the bubbles of the
 // consumer's dependent chain.
-template <int N, int M, bool TRIPLE = false, bool RAWP = false>
-__device__ __forceinline__ void fusedpc_producer(double *pcbuf, int *sflag, RecLayout L, FusedArgs F, int T)
+// HELPER (consumer / helper pair, 256 < batch <= 512: two SIMDs per trajectory): ONE wave is the triple's producer AND its side
+// wave -- at the top of step t the side products Tz = V Fz, Quz, Qzz (operands kept in registers since they were published), and,
+// between the mid-step barrier and the end of the step (while the consumer forms the gains and V'), the tiles of step t-1.
+// RU0 / RXC (helper only): r_u = 0 -- no r_u loads, no [l_uu | l_u] product, the ring's LU tiles stay zero; ONE constant r_x in
+// registers (see backward_fused_body).
+template <int N, int M, bool TRIPLE = false, bool RAWP = false, bool HELPER = false, bool RU0 = false, bool RXC = false>
+__device__ __forceinline__ void fusedpc_producer(double *pcbuf, int *sflag, RecLayout L, FusedArgs F, int T, const double *sh = nullptr)
 {
+    static_assert(!HELPER || TRIPLE, "the helper keeps the triple's two barriers per step");
+    static_assert(HELPER || (!RU0 && !RXC), "RU0 / RXC are the helper's instantiations");
+    static_assert(!RXC || RU0, "RXC comes with RU0");
     constexpr int n = N, m = M;
     const int lane = threadIdx.x & 63, c = lane & 15, q = lane >> 4;
     const int b = KP_BLOCK_TRAJ;
@@ -1553,16 +1562,29 @@ __device__ __forceinline__ void fusedpc_producer(double *pcbuf, int *sflag, RecL
     const double *rxb = F.r_x + (size_t)b * (T + 1) * nr * n;
     const double *rub = F.r_u + (size_t)b * (T + 1) * nr * m;
     d4 Rx, R1, Ru;
+    // (HELPER: the steps are asked for in order, T-1 first -- running pointers, as in backward_fused_body; with the 64-bit
+    // (step x size) products the compiler formed the descriptors on the VALU and wrapped every load in a waterfall loop)
+    const double *pRx = rxb + (size_t)(T - 1) * nr * n, *pR1 = rb + (size_t)(T - 1) * nr, *pRu = rub + (size_t)(T - 1) * nr * m;
+    (void)pRx; (void)pR1; (void)pRu;
     auto load_res = [&](int t) {
         const bool ok = t >= 0;
         const size_t tt = ok ? t : 0;
-        __amdgpu_buffer_rsrc_t rA = frsrc(rxb + tt * nr * n, ok ? nr * n * 8 : 0);
-        __amdgpu_buffer_rsrc_t rR = frsrc(rb + tt * nr, ok ? nr * 8 : 0);
-        __amdgpu_buffer_rsrc_t rU = frsrc(rub + tt * nr * m, ok ? nr * m * 8 : 0);
-        Rx.x = fbld(rA, oRx[0]); Rx.y = fbld(rA, oRx[1]); Rx.z = fbld(rA, oRx[2]); Rx.w = fbld(rA, oRx[3]);
+        __amdgpu_buffer_rsrc_t rA = frsrc(HELPER ? pRx : rxb + tt * nr * n, ok ? nr * n * 8 : 0);
+        __amdgpu_buffer_rsrc_t rR = frsrc(HELPER ? pR1 : rb + tt * nr, ok ? nr * 8 : 0);
+        __amdgpu_buffer_rsrc_t rU = frsrc(HELPER ? pRu : rub + tt * nr * m, ok ? nr * m * 8 : 0);
+        if constexpr (HELPER) { if (t > 0) { pRx -= nr * n; pR1 -= nr; pRu -= nr * m; } }
+        if constexpr (!RXC) { Rx.x = fbld(rA, oRx[0]); Rx.y = fbld(rA, oRx[1]); Rx.z = fbld(rA, oRx[2]); Rx.w = fbld(rA, oRx[3]); }
         R1.x = fbld(rR, oR1[0]); R1.y = fbld(rR, oR1[1]); R1.z = fbld(rR, oR1[2]); R1.w = fbld(rR, oR1[3]);
-        Ru.x = fbld(rU, oRu[0]); Ru.y = fbld(rU, oRu[1]); Ru.z = fbld(rU, oRu[2]); Ru.w = fbld(rU, oRu[3]);
+        if constexpr (!RU0) { Ru.x = fbld(rU, oRu[0]); Ru.y = fbld(rU, oRu[1]); Ru.z = fbld(rU, oRu[2]); Ru.w = fbld(rU, oRu[3]); }
     };
+    if constexpr (RXC) {                           // the one r_x of the task: in registers for the whole sweep
+        __amdgpu_buffer_rsrc_t rA = frsrc(F.rx_const, nr * n * 8);
+        Rx.x = fbld(rA, oRx[0]); Rx.y = fbld(rA, oRx[1]); Rx.z = fbld(rA, oRx[2]); Rx.w = fbld(rA, oRx[3]);
+    }
+    if constexpr (RU0) {                           // [l_uu | l_u] = 0: both ring slots once (the consumer does not read them either)
+        Ru = zero;
+        lds_store4(pcbuf + 768, lane, zero); lds_store4(pcbuf + FPC_BUF + 768, lane, zero);
+    }
     const int kd = (c < F.dof) ? c : c - F.dof;
     __amdgpu_buffer_rsrc_t rP = rT;
     if constexpr (RAWP) {
@@ -1574,24 +1596,74 @@ __device__ __forceinline__ void fusedpc_producer(double *pcbuf, int *sflag, RecL
     (void)rP;
 #pragma unroll
     for (int r = 0; r < 4; r++) if (c == n && 4 * r + q == n) tr.sv[r] = 1.0;       // Fz(n,n) = 1
+    d4 hFz = zero, hFu = zero, hLzz = zero, hLU = zero;            // HELPER: the tiles published last, for the side products of their step
+    (void)hFz; (void)hFu; (void)hLzz; (void)hLU;
     auto publish = [&](int t, const d4 &W2) {
         const double dt = (double)(t - tr.s);
         d4 Fz, Fu, Rz, Rur;
         Fz.x = tr.value(0, dt); Fz.y = tr.value(1, dt); Fz.z = tr.value(2, dt); Fz.w = tr.value(3, dt);
         Fu.x = tr.value(4, dt); Fu.y = tr.value(5, dt); Fu.z = tr.value(6, dt); Fu.w = tr.value(7, dt);
         Rz.x = bits_or(Rx.x, R1.x); Rz.y = bits_or(Rx.y, R1.y); Rz.z = bits_or(Rx.z, R1.z); Rz.w = bits_or(Rx.w, R1.w);
-        Rur.x = bits_or(Ru.x, R1.x); Rur.y = bits_or(Ru.y, R1.y); Rur.z = bits_or(Ru.z, R1.z); Rur.w = bits_or(Ru.w, R1.w);
         const d4 Lzz = PR(Rz, Rz * W2, zero, ncr);
-        const d4 LU = PR(Ru, Rur * W2, zero, ncr);
+        d4 LU = zero;
+        if constexpr (!RU0) {
+            Rur.x = bits_or(Ru.x, R1.x); Rur.y = bits_or(Ru.y, R1.y); Rur.z = bits_or(Ru.z, R1.z); Rur.w = bits_or(Ru.w, R1.w);
+            LU = PR(Ru, Rur * W2, zero, ncr);
+        }
         load_res(t - 1);
         double *tb = pcbuf + (t & 1) * FPC_BUF;
-        lds_store4(tb, lane, Fz); lds_store4(tb + 256, lane, Fu);
-        lds_store4(tb + 512, lane, Lzz); lds_store4(tb + 768, lane, LU);
+        if constexpr (!HELPER) lds_store4(tb, lane, Fz);  // (Fz is the side products' operand only)
+        lds_store4(tb + 256, lane, Fu);
+        lds_store4(tb + 512, lane, Lzz);
+        if constexpr (!RU0) lds_store4(tb + 768, lane, LU);
+        if constexpr (HELPER) { hFz = Fz; hFu = Fu; hLzz = Lzz; hLU = LU; }
     };
     load_res(T - 1);
     if (lane == 0) sflag[0] = 0;
     publish(T - 1, Wt);                                   // terminal weights   (iLQR.cpp:537-539)
     __syncthreads();
+    if constexpr (HELPER) {
+        constexpr int NCZ = (N + 1 + 3) / 4;
+        constexpr int REG_NN = n >> 2;
+        const bool lane_nn = (c == n) && (q == (n & 3));
+        const u64 mask_n = (c == n) ? ~0ull : 0ull;
+        // everything of step t that hangs on V but not on the gains (fusedpc_side), from the tiles this wave published for it
+        auto side = [&](int t) __attribute__((always_inline)) {
+            d4 V = hLzz;                                   // V_xx = l_xx[T-1]   (iLQR.cpp:537-539)
+            if (t < T - 1) {                               // (V' + V'')/2 from the consumer's unsymmetrised image, as the consumer forms it
+                V.x = 0.5 * (sh[FLDS_V + (q) * FVS + c] + sh[FLDS_V + c * FVS + q]);
+                V.y = 0.5 * (sh[FLDS_V + (4 + q) * FVS + c] + sh[FLDS_V + c * FVS + 4 + q]);
+                V.z = 0.5 * (sh[FLDS_V + (8 + q) * FVS + c] + sh[FLDS_V + c * FVS + 8 + q]);
+                V.w = 0.5 * (sh[FLDS_V + (12 + q) * FVS + c] + sh[FLDS_V + c * FVS + 12 + q]);
+                if (lane_nn) fset_reg<REG_NN>(V, 0.0);
+            }
+            d4 Luz;
+            Luz.x = bits_and(hLU.x, mask_n); Luz.y = bits_and(hLU.y, mask_n); Luz.z = bits_and(hLU.z, mask_n); Luz.w = bits_and(hLU.w, mask_n);
+            const d4 Tz = PS<NCZ>(V, hFz, zero);
+            const d4 Quz = PS<NCZ>(hFu, Tz, Luz);
+            const d4 Qzz = PS<NCZ>(hFz, Tz, hLzz);
+            lds_store4(pcbuf + FPC_SIDE_QUZ, lane, Quz);
+            lds_store4(pcbuf + FPC_SIDE_QZZ, lane, Qzz);
+        };
+        for (int t = T - 1; t > 0; t--) {
+            side(t);
+            __syncthreads();                               // mid-step: the consumer takes Quz, Qzz
+            // the tiles of step t-1, while the consumer forms the gains and V' of step t (slot (t-1)&1 was last read at the top of step t+1)
+            // (the crossing's arithmetic in front of the wait for the residual tiles, its requests behind it: KP_PROD_SPLIT)
+            // (the prefetched x+ / x- are differenced BEHIND the publish, whose wait for the residual tiles has let them arrive)
+            if constexpr (RAWP) tr.cross(rT, t - 1, F.eps2, F.rinv_2eps);
+            else tr.cross(t - 1);
+            publish(t - 1, Wr);
+            if constexpr (RAWP) { tr.settle(rT, F.eps2, F.rinv_2eps); tr.request(rP, F.kp_times); }
+            else tr.request(rT, F.kp_times, strideB);
+            __syncthreads();                               // end of step: V of step t-1 is there
+            if (__builtin_amdgcn_readfirstlane(sflag[0])) return;     // (wave-uniform: a divergent exit makes t a per-lane value and every request a waterfall loop)
+        }
+        side(0);
+        __syncthreads();
+        __syncthreads();
+        return;
+    }
     // (no `if (t > 0)` around the body: requests behind a condition make the waits that follow conservative; the last step,
     // t = 0, has nothing left to produce and is the two barriers behind the loop)
     bool stop = false;
@@ -1609,7 +1681,7 @@ __device__ __forceinline__ void fusedpc_producer(double *pcbuf, int *sflag, RecL
 #endif
         if constexpr (TRIPLE) __syncthreads();             // the mid-step barrier of the consumer and the side wave
         __syncthreads();
-        if (sflag[0]) { stop = true; break; }
+        if (__builtin_amdgcn_readfirstlane(sflag[0])) { stop = true; break; }      // (wave-uniform, see the helper's loop)
     }
     if (!stop) {
         if constexpr (TRIPLE) __syncthreads();
@@ -1653,7 +1725,7 @@ __device__ __forceinline__ void fusedpc_side(const double *sh, double *pcbuf, in
         lds_store4(pcbuf + FPC_SIDE_QZZ, lane, Qzz);
         __syncthreads();                               // mid-step: the consumer takes Quz, Qzz
         __syncthreads();                               // end of step: V of step t-1 is there, the next ring slot is full
-        if (sflag[0]) break;
+        if (__builtin_amdgcn_readfirstlane(sflag[0])) break;
     }
 }
 
@@ -1700,6 +1772,22 @@ k_backward_fusedpc3(RecLayout L, FusedArgs F, int T, int role_shift, const doubl
         fusedpc_side<N, M>(sh, sh + FPC_RING, (int *)(sh + FPC_FLAG), T);
     else
         fusedpc_producer<N, M, true, RAWP>(sh + FPC_RING, (int *)(sh + FPC_FLAG), L, F, T);
+}
+// Consumer / helper pair (2 x batch <= #SIMDs: a SIMD each): the triple's consumer, and ONE wave for its side and producer roles
+template <int N, int M, bool RAWP, bool RU0, bool RXC>
+__global__ void __launch_bounds__(128) __attribute__((amdgpu_waves_per_eu(1, 1)))
+k_backward_fusedph(RecLayout L, FusedArgs F, int T, int role_shift, const double *__restrict__ lambda,
+                   int pd_stride, double *__restrict__ Kout, double *__restrict__ kout,
+                   double *__restrict__ delta_J, int *__restrict__ status, const int *__restrict__ kp_uniform, int guard)
+{
+    __shared__ __attribute__((aligned(16))) double sh[FPC_TOTAL];
+    if (guard >= 0 && (*kp_uniform != 0) != (guard != 0)) return;
+    const bool consumer = ((__builtin_amdgcn_readfirstlane(threadIdx.x >> 6) ^ (blockIdx.x >> role_shift)) & 1) == 0;
+    if (consumer)
+        backward_fused_body<N, M, true, RU0, true>(sh, sh + FPC_RING, (int *)(sh + FPC_FLAG), L, F, T, lambda, pd_stride, Kout, kout,
+                                                   delta_J, status);
+    else
+        fusedpc_producer<N, M, true, RAWP, true, RU0, RXC>(sh + FPC_RING, (int *)(sh + FPC_FLAG), L, F, T, sh);
 }
 // at most one wave per SIMD: while 2 x batch <= #SIMDs every wave of every pair gets a SIMD (and its FP64 unit) to itself
 template <int N, int M, bool RAWP>
@@ -2412,11 +2500,15 @@ static FusedArgs fused_args(const Ctx *c)
 }
 
 // Which wave organisation launch_backward_fused will pick: 1 one wave per trajectory, 2 control/state split, 3 producer /
-// consumer pair, 4 consumer / side / producer triple.  Only form 1 has the RAW instantiation.
+// consumer pair, 4 consumer / side / producer triple, 5 consumer / helper pair.  Forms 1, 3 and 5 have RAW instantiations.
+// While a trajectory can have two SIMDs (2 x batch <= #SIMDs) the consumer / helper pair runs it: the consumer's chain is the
+// triple's (Tu | Quu | refresh | gains | V'), the helper is the triple's side AND producer wave -- and it differences the payload,
+// which the triple left to a kernel in front of it.  Round 4, same box: 3.01 against 3.87 ms (pair) at 512 trajectories, 2.94 /
+// 2.85 / 2.78 against 3.05 / 3.01 / 2.89 ms (triple, + 0.18 / 0.09 / 0.01 ms differencing) at 256 / 128 / 1
+// (profiles/r04_helper_pair.txt).  KPILQR_FUSED_WAVES = 3 | 4 still select the pair and the triple.
 int backward_fused_form(const Ctx *c)
 {
-    return c->tune.fused_bwd_waves ? c->tune.fused_bwd_waves
-         : (4 * c->d.batch <= c->n_simd ? 4 : 2 * c->d.batch <= c->n_simd ? 3 : 1);      // a triple needs three SIMDs of ONE CU
+    return c->tune.fused_bwd_waves ? c->tune.fused_bwd_waves : (2 * c->d.batch <= c->n_simd ? 5 : 1);
 }
 
 // The wave organisation launch_forward_fused will pick: 1 one wave per trajectory, 2 state / cost pair, 3 the triple
@@ -2443,7 +2535,7 @@ hipError_t launch_backward_fused(Ctx *c, int pd_stride, bool raw)
     // KPILQR_FUSED_WAVES forces a form: 1 = one wave, 2 = control/state split, 3 = producer/consumer, 4 = the triple
     // consumer / side / producer (while batch <= #CUs: the three waves of a workgroup share a CU).
     const int form = backward_fused_form(c);
-    if (raw && form != 1 && form != 3) return hipErrorInvalidValue;
+    if (raw && form != 1 && form != 3 && form != 5) return hipErrorInvalidValue;
     c->last_bwd_form = form; c->last_bwd_raw = raw; c->last_bwd_ru0 = form == 1 && c->ru_zero;       // kpilqr_last_launch
     const bool rxc = form == 1 && c->ru_zero && c->rx_const_on;     // (the caller has materialised r_x for every other form)
     c->last_bwd_rxc = rxc;
@@ -2469,6 +2561,28 @@ hipError_t launch_backward_fused(Ctx *c, int pd_stride, bool raw)
     // raw (pair, 256 < batch <= 512): the producer wave differences the key-point ordered payload of UNIFORM sets itself (5.73
     // against 6.03 ms per iteration at B = 512); per-DoF lists take k_fd_kp_difference and the plain producer -- all three
     // launched, the device flag decides (as for one wave per trajectory)
+    // form 5, consumer / helper pair: the raw launch sequence of the pair (the helper differences the payload of uniform sets)
+    if (form == 5) {
+        const bool hru0 = c->ru_zero, hrxc = c->ru_zero && c->rx_const_on;
+        c->last_bwd_ru0 = hru0; c->last_bwd_rxc = hrxc;
+#define LAUNCHPH2(NN, MM, RW, RU, RX, GUARD) hipLaunchKernelGGL((k_backward_fusedph<NN, MM, RW, RU, RX>), grid, block2, 0, c->stream, c->L, F, c->d.T, role_shift, c->lambda, pd_stride, c->K, c->k, c->delta_J, c->status, c->kp_uniform, GUARD)
+#define LAUNCHPH(NN, MM, RW, GUARD) do { if (hrxc) LAUNCHPH2(NN, MM, RW, true, true, GUARD); else if (hru0) LAUNCHPH2(NN, MM, RW, true, false, GUARD); else LAUNCHPH2(NN, MM, RW, false, false, GUARD); } while (0)
+#define KP_X(NN, MM)                                                                                   \
+        if (n == NN && m == MM) {                                                                      \
+            if (raw) {                                                                                 \
+                LAUNCHPH(NN, MM, true, 1);                                                             \
+                hipError_t e_ = launch_fd_kp_difference(c, true);                                      \
+                if (e_ != hipSuccess) return e_;                                                       \
+                LAUNCHPH(NN, MM, false, 0);                                                            \
+            } else LAUNCHPH(NN, MM, false, -1);                                                        \
+            return hipGetLastError();                                                                  \
+        }
+        KP_T1_SHAPES(KP_X)
+#undef KP_X
+#undef LAUNCHPH
+#undef LAUNCHPH2
+        return hipErrorInvalidValue;
+    }
     if (form == 3) {
         const bool pexcl = 2 * c->d.batch <= c->n_simd;
 #define LAUNCHPC(NN, MM, RW, GUARD)                                                                                   \

@@ -294,7 +294,11 @@ static int ensure_rx_buffer(kpilqr_ctx *c)
     return KPILQR_OK;
 }
 // whether the sweep about to be launched reads the r_x buffer (every form but the one-wave fused instantiations without r_u)
-static bool backward_reads_rx_buffer(const kpilqr_ctx *c) { return !(c->fused && backward_fused_form(c) == 1 && c->ru_zero); }
+static bool backward_reads_rx_buffer(const kpilqr_ctx *c)
+{
+    const int form = c->fused ? backward_fused_form(c) : 0;
+    return !((form == 1 || form == 5) && c->ru_zero);       // (the forms with a constant-Jacobian instantiation)
+}
 static bool forward_reads_rx_buffer(const kpilqr_ctx *c) { return !(c->fused && forward_fused_form(c) == 1 && c->ru_zero); }
 
 // kernel families for c->d (names: kpilqr_backward_variant)
@@ -998,7 +1002,7 @@ static int run_backward(kpilqr_ctx *c, int pd_stride)
         // kpc valid: another backward pass on the same payload differences again.)  Otherwise the payload is differenced
         // into kpc first, once, and the sweeps read kpc.
         const int bform = backward_fused_form(c);
-        if (!c->kpc_valid && c->fd_kind == 2 && (bform == 1 || bform == 3) && c->tune.fused_raw != 0) {
+        if (!c->kpc_valid && c->fd_kind == 2 && (bform == 1 || bform == 3 || bform == 5) && c->tune.fused_raw != 0) {
             KP_HIP(c, launch_backward_fused(c, pd_stride, true));
             c->kpc_touched = true;
             // (KPILQR_FUSED_UNI=0, diagnostic: the GENERAL raw sweep has differenced every set inside the sweep -- dividing at its
@@ -1533,8 +1537,8 @@ const char *kpilqr_last_launch(kpilqr_ctx *c, int which)
     if (hipSetDevice(c->d.device) != hipSuccess || (c->pipe_dirty && join_pipeline(c) != KPILQR_OK) ||
         hipMemcpyAsync(&uni, c->kp_uniform, sizeof(int), hipMemcpyDeviceToHost, c->stream) != hipSuccess ||
         hipStreamSynchronize(c->stream) != hipSuccess) { out += ":?"; return out.c_str(); }
-    static const char *const wname[5] = {"", "w1", "w2", "pair", "triple"};
-    out += ":"; out += wname[form < 5 ? form : 0];
+    static const char *const wname[6] = {"", "w1", "w2", "pair", "triple", "pairh"};
+    out += ":"; out += wname[form < 6 ? form : 0];
     // (the raw launch sequence differences inside the sweep for uniform sets only: per-DoF lists take k_fd_kp_difference and
     // the plain sweep, launched behind it -- unless KPILQR_FUSED_UNI=0 forces the general raw form, one wave per trajectory)
     if (which == 0) out += (c->last_bwd_raw && (uni || (c->tune.fused_uni == 0 && form == 1))) ? ":raw" : ":kpc";
