@@ -227,6 +227,8 @@ def test_headline_dispatch_helper_pair_at_batch_320():
     legs = s["legs"]
     assert legs["A"]["backward"].endswith(":pairh:raw:uni:ru0") and legs["B"]["backward"].endswith(":pairh:kpc:uni:ru0")
     assert legs["C"]["backward"].endswith(":pairh:raw:uni:ru0:rxc")
+    # forward: the state / cost wave pair of uniform key-point sets (the state wave interpolates its own operands)
+    assert legs["A"]["forward"].endswith(":pair:uni:ru0") and legs["C"]["forward"].endswith(":pair:uni:ru0:rxc"), (legs["A"], legs["C"])
     assert legs["B"]["bit_identical"] and legs["C"]["bit_identical"]
 
 

@@ -385,6 +385,7 @@ def test_per_dof_lists_walk_the_slope_store(payload, monkeypatch):
     assert ":w1:kpc:ragged" in one["lb"] and one["lb"].endswith(":slopes") and one["lf"].endswith(":slopes"), (one["lb"], one["lf"])
     trip = run({})                                              # B = 5: the consumer / helper pair (its tracker divides at the crossings)
     assert ":pairh:" in trip["lb"] and "slopes" not in trip["lb"]
+    assert ":triple:ragged" in trip["lf"], trip["lf"]          # forward: the uniform pair left at once, the triple behind it ran
     trip4 = run({"KPILQR_FUSED_WAVES": "4"})                    # ... and the triple
     assert ":triple:" in trip4["lb"] and "slopes" not in trip4["lb"]
     assert all(np.array_equal(trip[key], trip4[key]) for key in ("K", "k", "delta_J"))      # (the same products in the same order)

@@ -176,7 +176,7 @@ struct Ctx {
     // what the last backward / forward launch of this context actually was (kpilqr_last_launch): wave organisation
     // (1 one wave per trajectory, 2 control / state split, 3 pair, 4 triple; 0: not a fused launch, or none yet), whether the
     // sweep differenced the raw payload itself, which residual instantiation ran
-    int last_bwd_form = 0, last_fwd_form = 0;
+    int last_bwd_form = 0, last_fwd_form = 0, last_fwd_form_ragged = 0;      // (_ragged: the form that ran instead on per-DoF lists, if another)
     bool last_bwd_raw = false, last_bwd_ru0 = false, last_fwd_ru0 = false, last_bwd_rxc = false, last_fwd_rxc = false;
     bool last_bwd_slopes = false, last_fwd_slopes = false;
     std::string launch_desc[2];

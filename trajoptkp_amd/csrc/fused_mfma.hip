@@ -2229,21 +2229,28 @@ k_forward_fused_excl(RecLayout L, FusedArgs F, int T, int n_alpha, const double 
 #define FSC_ZS (2 * FSC_Y)                        // two (Z, dU) slots, D layout
 #define FSC_TOTAL (FSC_ZS + 2 * 512)
 
-template <int NCZ, int NCU>
+// RU0: nobody reads the control change of a step (no control residuals to score): its LDS image is not written
+// UNI: every DoF of the trajectory has the same key-point list -- the state wave interpolates its own operands Ya, Yb in the
+// operand layout, straight from the column store (the segment tracker of forward_fused_body's UNI form: positions and times are
+// wave-uniform scalars, the crossing sits behind a scalar branch at the end of a segment's last step); nobody stages columns
+// through LDS, and the group needs no third wave.
+template <int NCZ, int NCU, bool RU0 = false, bool UNI = false>
 __device__ __forceinline__ void forward_sc_state(double *sh, RecLayout L, int T, int n_alpha, const double *__restrict__ Kin,
                const double *__restrict__ kin, const double *__restrict__ u_nom, const double *__restrict__ ctrl_lim,
-               const double *__restrict__ alphas, double *__restrict__ U_alpha)
+               const double *__restrict__ alphas, double *__restrict__ U_alpha, const FusedArgs *Fp = nullptr)
 {
     const int n = L.n, m = L.m;
     const int lane = threadIdx.x & 63, c = lane & 15, q = lane >> 4;
     const int b = blockIdx.x;
-    int oK[4], ok_[4], oub[4];
-    double lo[NCU], hi[NCU];
+    int oK[4], oub[4];
+    double lo[NCU], hi[NCU], kmask[4];
+    // k rides in row n of the gain operand: ONE load (the lanes of that row), added into the register that holds the row
+    const int okn = (q == (n & 3) && c < m) ? 8 * c : OOBF;
 #pragma unroll
     for (int r = 0; r < 4; r++) {
         const int row = 4 * r + q;
         oK[r] = (row < n && c < m) ? 8 * (row * m + c) : OOBF;
-        ok_[r] = (row == n && c < m) ? 8 * c : OOBF;
+        kmask[r] = (r == (n >> 2)) ? 1.0 : 0.0;
         oub[r] = (row < m) ? 8 * row : OOBF;
         if (r < NCU) {
             lo[r] = (row < m) ? ctrl_lim[2 * row] : -1.0e300;
@@ -2265,26 +2272,105 @@ __device__ __forceinline__ void forward_sc_state(double *sh, RecLayout L, int T,
     // KP_FSC_SETS tile sets (step t works on set t mod KP_FSC_SETS): each is re-requested for step t + KP_FSC_SETS right behind
     // its use in step t.  The time loop is a body of KP_FSC_SETS steps WITHOUT conditions (the steps below a full group are
     // peeled behind it): a request inside `if (t + 1 < T)` makes every later wait conservative
-    struct STiles { d4 YkK, Ykk, ub; };
-    const __amdgpu_buffer_rsrc_t rNone = frsrc(Kin, 0);
+    struct STiles { d4 YkK, ub; double kk; };
+    // one descriptor per array for the whole trajectory, the step in the loads' scalar offset (behind the last step: step T-1
+    // again, never used) -- as in forward_fused_body
+    const __amdgpu_buffer_rsrc_t rK = frsrc(Kin + (size_t)b * T * m * n, T * m * n * 8), rk = frsrc(kin + (size_t)b * T * m, T * m * 8),
+                                 ru = frsrc(u_nom + (size_t)b * T * m, T * m * 8);
     auto request = [&](int t, STiles &s_) {
-        const bool ok = t < T;
-        __amdgpu_buffer_rsrc_t rK = ok ? frsrc(Kin + ((size_t)b * T + t) * m * n, m * n * 8) : rNone;
-        __amdgpu_buffer_rsrc_t rk = ok ? frsrc(kin + ((size_t)b * T + t) * m, m * 8) : rNone;
-        __amdgpu_buffer_rsrc_t ru = ok ? frsrc(u_nom + ((size_t)b * T + t) * m, m * 8) : rNone;
-        s_.YkK.x = fbld(rK, oK[0]); s_.YkK.y = fbld(rK, oK[1]); s_.YkK.z = fbld(rK, oK[2]); s_.YkK.w = fbld(rK, oK[3]);
-        s_.Ykk.x = fbld(rk, ok_[0]); s_.Ykk.y = fbld(rk, ok_[1]); s_.Ykk.z = fbld(rk, ok_[2]); s_.Ykk.w = fbld(rk, ok_[3]);
-        s_.ub.x = fbld(ru, oub[0]); s_.ub.y = NCU > 1 ? fbld(ru, oub[1]) : 0.0;
-        s_.ub.z = NCU > 2 ? fbld(ru, oub[2]) : 0.0; s_.ub.w = NCU > 3 ? fbld(ru, oub[3]) : 0.0;
+        const int tn = t < T ? t : T - 1;
+        const int sK = tn * m * n * 8, sk = tn * m * 8;
+        s_.YkK.x = fblds(rK, oK[0], sK); s_.YkK.y = fblds(rK, oK[1], sK); s_.YkK.z = fblds(rK, oK[2], sK); s_.YkK.w = fblds(rK, oK[3], sK);
+        s_.kk = fblds(rk, okn, sk);
+        s_.ub.x = fblds(ru, oub[0], sk); s_.ub.y = NCU > 1 ? fblds(ru, oub[1], sk) : 0.0;
+        s_.ub.z = NCU > 2 ? fblds(ru, oub[2], sk) : 0.0; s_.ub.w = NCU > 3 ? fblds(ru, oub[3], sk) : 0.0;
+    };
+    // ---- UNI: the segment tracker (forward_fused_body) ----
+    ColOffs co;
+    double sv[8], ev[8], ev2[8], av[8];
+    int up = 0, uks = 0, uke = 0, ukn_v = 0, E0 = 0, NE = 0, KpU = 1;
+    __amdgpu_buffer_rsrc_t rT = rK;
+    d4 Yua = zero, Yub = zero;                         // the operands of the NEXT step
+    (void)co; (void)sv; (void)ev; (void)ev2; (void)av; (void)up; (void)uks; (void)uke; (void)ukn_v; (void)E0; (void)NE; (void)KpU; (void)rT;
+    constexpr int strideBc = 0;
+    (void)strideBc;
+    const int strideB = 3 * n * 8;
+    if constexpr (UNI) {
+        const FusedArgs &F = *Fp;
+        E0 = F.kp_offsets[(size_t)b * F.dof]; NE = F.kp_offsets[(size_t)(b + 1) * F.dof] - E0;
+        KpU = F.kp_offsets[(size_t)b * F.dof + 1] - E0;
+        rT = frsrc(F.kpc + (size_t)E0 * 3 * n, NE * strideB);
+#pragma unroll
+        for (int r = 0; r < 4; r++) {
+            // the Y operands themselves: Ya(p = row, o = c) = A(o, p), Yb(p, o) = B(o, p) -- element c of column `row`, whose
+            // DoF list starts (row mod dof) * KpU entries into the trajectory's slice
+            const int row = 4 * r + q;
+            const int d = row < F.dof ? row : row - F.dof;
+            co.a[r] = (row < n && c < n) ? 8 * ((d * KpU * 3 + (row < F.dof ? 0 : 1)) * n + c) : BIGOFF;
+            co.b[r] = (row < m && c < n) ? 8 * ((row * KpU * 3 + 2) * n + c) : BIGOFF;
+        }
+        load_col(rT, co, 0, NE, strideB, sv);
+        load_col(rT, co, KpU > 1 ? 1 : 0, NE, strideB, ev);
+        uks = __builtin_amdgcn_readfirstlane(F.kp_times[E0]);
+        uke = __builtin_amdgcn_readfirstlane(F.kp_times[E0 + (KpU > 1 ? 1 : 0)]);
+        const int p2 = KpU > 2 ? 2 : KpU - 1;
+        load_col(rT, co, p2, NE, strideB, ev2);
+        ukn_v = F.kp_times[E0 + p2];
+        const int gap = uke - uks;
+        const double den = (double)(gap > 0 ? gap : 1), rinv = kp_rcp(den);
+#pragma unroll
+        for (int i = 0; i < 8; i++) av[i] = fdiv(ev[i] - sv[i], den, rinv);
+        // the identity rows of Ya (alpha and the homogeneous 1 carry over): lanes c >= n walk no list
+        if (c == n || c == n + 1) {
+#pragma unroll
+            for (int r = 0; r < 4; r++) if (4 * r + q == c) { sv[r] = 1.0; ev[r] = 1.0; av[r] = 0.0; }
+        }
+        Yua.x = sv[0]; Yua.y = sv[1]; Yua.z = sv[2]; Yua.w = sv[3];            // Y(0): the first key-point is step 0
+        Yub.x = sv[4]; Yub.y = NCU > 1 ? sv[5] : 0.0; Yub.z = NCU > 2 ? sv[6] : 0.0; Yub.w = NCU > 3 ? sv[7] : 0.0;
+    }
+    // the operands of step t + 1, formed behind the products of step t (UNI)
+    auto next_Y = [&](int t) __attribute__((always_inline)) {
+        const FusedArgs &F = *Fp;
+        if (t + 1 == uke) {
+            // crossing into segment up + 1: its start column (ev) and end column (ev2) were requested one and two segments ago;
+            // the column after those and its time are requested now, the time BEHIND the columns (loads return in order)
+            const int kn = __builtin_amdgcn_readfirstlane(ukn_v);
+            uks = uke; uke = kn; up++;
+            const int gap = uke - uks;
+            const double den = (double)(gap > 0 ? gap : 1), rinv = kp_rcp(den);
+#pragma unroll
+            for (int i = 0; i < 8; i++) { sv[i] = ev[i]; ev[i] = ev2[i]; av[i] = fdiv(ev[i] - sv[i], den, rinv); }
+            if (c == n || c == n + 1) {
+#pragma unroll
+                for (int r = 0; r < 4; r++) if (4 * r + q == c) { sv[r] = 1.0; ev[r] = 1.0; av[r] = 0.0; }
+            }
+            const int pn = up + 2 < KpU ? up + 2 : KpU - 1;
+            load_col(rT, co, pn, NE, strideB, ev2);
+            __builtin_amdgcn_sched_barrier(0);
+            ukn_v = F.kp_times[E0 + pn];
+            __builtin_amdgcn_sched_barrier(0);
+        }
+        const double dt = (double)(t + 1 - uks);                       // 0 behind a crossing: the next step IS the key-point
+        Yua.x = lerp_nc(sv[0], dt, av[0]); Yua.y = lerp_nc(sv[1], dt, av[1]); Yua.z = lerp_nc(sv[2], dt, av[2]); Yua.w = lerp_nc(sv[3], dt, av[3]);
+        Yub.x = lerp_nc(sv[4], dt, av[4]); Yub.y = NCU > 1 ? lerp_nc(sv[5], dt, av[5]) : 0.0;
+        Yub.z = NCU > 2 ? lerp_nc(sv[6], dt, av[6]) : 0.0; Yub.w = NCU > 3 ? lerp_nc(sv[7], dt, av[7]) : 0.0;
     };
     auto step = [&](int t, STiles &s_) {
         const double *shA = sh + FSC_YS + (t & 1) * FSC_Y, *shB = shA + 272;
         d4 Ya, Yb;                                     // Ya(p, o) = A(o, p);  Yb(p, o) = B(o, p)
+        if constexpr (UNI) { Ya = Yua; Yb = Yub; }
+        else {
         Ya.x = shA[c * 17 + q];      Ya.y = shA[c * 17 + 4 + q];
         Ya.z = shA[c * 17 + 8 + q];  Ya.w = shA[c * 17 + 12 + q];
         Yb.x = shB[c * 17 + q];                Yb.y = NCU > 1 ? shB[c * 17 + 4 + q] : 0.0;
         Yb.z = NCU > 2 ? shB[c * 17 + 8 + q] : 0.0; Yb.w = NCU > 3 ? shB[c * 17 + 12 + q] : 0.0;
-        const d4 Yk = s_.YkK + s_.Ykk;
+        }
+        d4 Yk = s_.YkK;
+        {
+            const double kk = s_.kk;                   // (a product with the 0 / 1 mask: no branch, no select on the register index)
+            Yk.x = __builtin_fma(kmask[0], kk, Yk.x); Yk.y = __builtin_fma(kmask[1], kk, Yk.y);
+            Yk.z = __builtin_fma(kmask[2], kk, Yk.z); Yk.w = __builtin_fma(kmask[3], kk, Yk.w);
+        }
         const d4 ub = s_.ub;
         d4 U = PS<NCZ>(Yk, Z, ub);                     // u_nom + K dx + alpha k   (:879)
         __builtin_amdgcn_sched_barrier(0);
@@ -2301,7 +2387,7 @@ __device__ __forceinline__ void forward_sc_state(double *sh, RecLayout L, int T,
         }
         double *zs = sh + FSC_ZS + (t & 1) * 512;
         lds_store4(zs, lane, Z);                       // the state this step started from, and its control change
-        lds_store4(zs + 256, lane, dU);
+        if constexpr (!RU0) lds_store4(zs + 256, lane, dU);
         Z = PS<NCU>(Yb, dU, Zn);                       // + B du: the next state
         if (U_alpha && c < n_alpha) {
             double *Ua = U_alpha + (((size_t)b * n_alpha + c) * T + t) * m;
@@ -2309,6 +2395,7 @@ __device__ __forceinline__ void forward_sc_state(double *sh, RecLayout L, int T,
 #pragma unroll
             for (int r = 0; r < NCU; r++) { const int row = 4 * r + q; if (row < m) Ua[row] = uv[r]; }
         }
+        if constexpr (UNI) next_Y(t);                  // a4 of step t+1 under the products above
         __syncthreads();
     };
     STiles S[KP_FSC_SETS];
@@ -2325,7 +2412,8 @@ __device__ __forceinline__ void forward_sc_state(double *sh, RecLayout L, int T,
 }
 
 // ROLE 0: score and stage (second wave of the pair); 1: score only; 2: stage the A, B columns only (third wave of the triple)
-template <int NCZ, int NCU, int ROLE = 0>
+// RU0: r_u = 0 (no r_u tiles, no Ju product); RXC (with RU0): ONE constant r_x, its transposed tile in registers (forward_fused_body)
+template <int NCZ, int NCU, int ROLE = 0, bool RU0 = false, bool RXC = false>
 __device__ __forceinline__ void forward_sc_cost(double *sh, RecLayout L, FusedArgs F, int T, int n_alpha, double *__restrict__ cost_pred)
 {
     const int n = L.n, m = L.m;
@@ -2357,14 +2445,22 @@ __device__ __forceinline__ void forward_sc_cost(double *sh, RecLayout L, FusedAr
     const double *rub = F.r_u + (size_t)b * (T + 1) * nr * m;
     struct CTiles { d4 RxT, RuT, rv; };
     const __amdgpu_buffer_rsrc_t rNone = frsrc(rb, 0);
+    d4 RxTc = {0.0, 0.0, 0.0, 0.0};
+    if constexpr (RXC) {
+        __amdgpu_buffer_rsrc_t rRxc = frsrc(F.rx_const, nr * n * 8);
+        RxTc.x = fbld(rRxc, oRxT[0]); RxTc.y = fbld(rRxc, oRxT[1]); RxTc.z = fbld(rRxc, oRxT[2]); RxTc.w = fbld(rRxc, oRxT[3]);
+    }
+    (void)RxTc;
     auto request = [&](int t, CTiles &s_) {
         const bool ok = t < T;
         __amdgpu_buffer_rsrc_t rRx = ok ? frsrc(rxb + (size_t)t * nr * n, nr * n * 8) : rNone;
         __amdgpu_buffer_rsrc_t rRu = ok ? frsrc(rub + (size_t)t * nr * m, nr * m * 8) : rNone;
         __amdgpu_buffer_rsrc_t rR = ok ? frsrc(rb + (size_t)t * nr, nr * 8) : rNone;
-        s_.RxT.x = fbld(rRx, oRxT[0]); s_.RxT.y = fbld(rRx, oRxT[1]); s_.RxT.z = fbld(rRx, oRxT[2]); s_.RxT.w = fbld(rRx, oRxT[3]);
-        s_.RuT.x = fbld(rRu, oRuT[0]); s_.RuT.y = NCU > 1 ? fbld(rRu, oRuT[1]) : 0.0;
-        s_.RuT.z = NCU > 2 ? fbld(rRu, oRuT[2]) : 0.0; s_.RuT.w = NCU > 3 ? fbld(rRu, oRuT[3]) : 0.0;
+        if constexpr (!RXC) { s_.RxT.x = fbld(rRx, oRxT[0]); s_.RxT.y = fbld(rRx, oRxT[1]); s_.RxT.z = fbld(rRx, oRxT[2]); s_.RxT.w = fbld(rRx, oRxT[3]); }
+        if constexpr (!RU0) {
+            s_.RuT.x = fbld(rRu, oRuT[0]); s_.RuT.y = NCU > 1 ? fbld(rRu, oRuT[1]) : 0.0;
+            s_.RuT.z = NCU > 2 ? fbld(rRu, oRuT[2]) : 0.0; s_.RuT.w = NCU > 3 ? fbld(rRu, oRuT[3]) : 0.0;
+        }
         s_.rv.x = fbld(rR, oR[0]); s_.rv.y = fbld(rR, oR[1]); s_.rv.z = fbld(rR, oR[2]); s_.rv.w = fbld(rR, oR[3]);
     };
     // ---- column tracker, walking UP in time (as in forward_fused_body) ----
@@ -2417,9 +2513,10 @@ __device__ __forceinline__ void forward_sc_cost(double *sh, RecLayout L, FusedAr
         if (ROLE != 2 && t >= 1) {
             const int tt = t - 1;
             const double *zs = sh + FSC_ZS + (tt & 1) * 512;
-            const d4 Zt = lds_tile4(zs, lane), dU = lds_tile4(zs + 256, lane);
-            const d4 Ju = PS<NCU>(s_.RuT, dU, zero);
-            const d4 Jx = PR(s_.RxT, Zt, zero, ncx);
+            const d4 Zt = lds_tile4(zs, lane);
+            d4 Ju = zero;                              // RU0: the control residual term vanishes (and nobody reads the dU slot)
+            if constexpr (!RU0) { const d4 dU = lds_tile4(zs + 256, lane); Ju = PS<NCU>(s_.RuT, dU, zero); }
+            const d4 Jx = PR(RXC ? RxTc : s_.RxT, Zt, zero, ncx);
             const d4 r2 = s_.rv + s_.rv;
             __builtin_amdgcn_sched_barrier(0);
             request(tt + KP_FSC_SETS, s_);
@@ -2429,6 +2526,10 @@ __device__ __forceinline__ void forward_sc_cost(double *sh, RecLayout L, FusedAr
                 for (int r = 0; r < 4; r++) wcur[r] = wterm[r];
             }
             // sum_k w_k [Jx_k (2 r_k + Jx_k) + Ju_k (2 r_k + Ju_k)]
+            if constexpr (RU0)                         // (Ju = 0 exactly: its term adds a signed zero, as in forward_fused_body)
+                partial += wcur[0] * (Jx.x * (r2.x + Jx.x)) + wcur[1] * (Jx.y * (r2.y + Jx.y))
+                         + wcur[2] * (Jx.z * (r2.z + Jx.z)) + wcur[3] * (Jx.w * (r2.w + Jx.w));
+            else
             partial += wcur[0] * (Jx.x * (r2.x + Jx.x) + Ju.x * (r2.x + Ju.x))
                      + wcur[1] * (Jx.y * (r2.y + Jx.y) + Ju.y * (r2.y + Ju.y))
                      + wcur[2] * (Jx.z * (r2.z + Jx.z) + Ju.z * (r2.z + Ju.z))
@@ -2457,7 +2558,7 @@ __device__ __forceinline__ void forward_sc_cost(double *sh, RecLayout L, FusedAr
     if (ROLE != 2 && q == 0 && c < n_alpha) cost_pred[(size_t)b * n_alpha + c] = partial;
 }
 
-template <int NCZ, int NCU>
+template <int NCZ, int NCU, bool RU0 = false, bool RXC = false>
 __global__ void __launch_bounds__(128) __attribute__((amdgpu_waves_per_eu(1, 1)))
 k_forward_fused_sc(RecLayout L, FusedArgs F, int T, int n_alpha, const double *__restrict__ Kin,
                    const double *__restrict__ kin, const double *__restrict__ u_nom, const double *__restrict__ ctrl_lim,
@@ -2465,22 +2566,40 @@ k_forward_fused_sc(RecLayout L, FusedArgs F, int T, int n_alpha, const double *_
 {
     __shared__ __attribute__((aligned(16))) double sh[FSC_TOTAL];
     const bool state = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6) == 0;
-    if (state) forward_sc_state<NCZ, NCU>(sh, L, T, n_alpha, Kin, kin, u_nom, ctrl_lim, alphas, U_alpha);
-    else       forward_sc_cost<NCZ, NCU>(sh, L, F, T, n_alpha, cost_pred);
+    if (state) forward_sc_state<NCZ, NCU, RU0>(sh, L, T, n_alpha, Kin, kin, u_nom, ctrl_lim, alphas, U_alpha);
+    else       forward_sc_cost<NCZ, NCU, 0, RU0, RXC>(sh, L, F, T, n_alpha, cost_pred);
+}
+
+// UNIFORM key-point sets: state wave (with its own a4) + scoring wave -- no staging wave, whatever the batch up to #SIMDs / 2.
+// Leaves at once if the device flag says the set is not uniform (the general forms are launched behind it and look at the same flag).
+template <int NCZ, int NCU, bool RU0 = false, bool RXC = false>
+__global__ void __launch_bounds__(128) __attribute__((amdgpu_waves_per_eu(1, 1)))
+k_forward_fused_scu(RecLayout L, FusedArgs F, int T, int n_alpha, const double *__restrict__ Kin,
+                    const double *__restrict__ kin, const double *__restrict__ u_nom, const double *__restrict__ ctrl_lim,
+                    const double *__restrict__ alphas, double *__restrict__ cost_pred, double *__restrict__ U_alpha,
+                    const int *__restrict__ kp_uniform)
+{
+    __shared__ __attribute__((aligned(16))) double sh[FSC_TOTAL];
+    if (*kp_uniform == 0) return;
+    const bool state = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6) == 0;
+    if (state) forward_sc_state<NCZ, NCU, RU0, true>(sh, L, T, n_alpha, Kin, kin, u_nom, ctrl_lim, alphas, U_alpha, &F);
+    else       forward_sc_cost<NCZ, NCU, 1, RU0, RXC>(sh, L, F, T, n_alpha, cost_pred);
 }
 
 // state + cost + staging waves (4 x batch <= #SIMDs: one 3-wave workgroup per CU): the cost wave of the pair is the longer
 // one (1 360 vs 1 130 cycles per step); its a4 half goes to a third wave
-template <int NCZ, int NCU>
+template <int NCZ, int NCU, bool RU0 = false, bool RXC = false>
 __global__ void __launch_bounds__(192) __attribute__((amdgpu_waves_per_eu(1, 1)))
 k_forward_fused_sc3(RecLayout L, FusedArgs F, int T, int n_alpha, const double *__restrict__ Kin,
                     const double *__restrict__ kin, const double *__restrict__ u_nom, const double *__restrict__ ctrl_lim,
-                    const double *__restrict__ alphas, double *__restrict__ cost_pred, double *__restrict__ U_alpha)
+                    const double *__restrict__ alphas, double *__restrict__ cost_pred, double *__restrict__ U_alpha,
+                    const int *__restrict__ kp_uniform, int only_ragged)
 {
     __shared__ __attribute__((aligned(16))) double sh[FSC_TOTAL];
+    if (only_ragged && *kp_uniform != 0) return;       // (launched behind k_forward_fused_scu, which has run the uniform set)
     const int role = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-    if (role == 0) forward_sc_state<NCZ, NCU>(sh, L, T, n_alpha, Kin, kin, u_nom, ctrl_lim, alphas, U_alpha);
-    else if (role == 1) forward_sc_cost<NCZ, NCU, 1>(sh, L, F, T, n_alpha, cost_pred);
+    if (role == 0) forward_sc_state<NCZ, NCU, RU0>(sh, L, T, n_alpha, Kin, kin, u_nom, ctrl_lim, alphas, U_alpha);
+    else if (role == 1) forward_sc_cost<NCZ, NCU, 1, RU0, RXC>(sh, L, F, T, n_alpha, cost_pred);
     else forward_sc_cost<NCZ, NCU, 2>(sh, L, F, T, n_alpha, cost_pred);
 }
 
@@ -2511,15 +2630,16 @@ int backward_fused_form(const Ctx *c)
     return c->tune.fused_bwd_waves ? c->tune.fused_bwd_waves : (2 * c->d.batch <= c->n_simd ? 5 : 1);
 }
 
-// The wave organisation launch_forward_fused will pick: 1 one wave per trajectory, 2 state / cost pair, 3 the triple
+// The wave organisation launch_forward_fused will pick: 1 one wave per trajectory, 2 state / cost + staging pair, 3 the state /
+// cost / staging triple, 4 (the default while 2 x batch <= #SIMDs) the state / cost pair for UNIFORM key-point sets -- the state
+// wave interpolates its own operands, no staging wave -- with the triple (4 x batch <= #SIMDs) or the one-wave general form
+// behind it for per-DoF lists; the device flag decides which of the two runs.  Late round 4, with r_u = 0 / constant-r_x
+// instantiations of the scoring wave and a state wave that issues 7 loads per step instead of 10 (profiles/r04_forward_forms.txt):
+// 1.31 / 1.43 / 1.47 ms at 1 / 64 / 256 trajectories (one wave per trajectory: 1.72).
 int forward_fused_form(const Ctx *c)
 {
     if (c->tune.fused_fwd_waves) return c->tune.fused_fwd_waves;
-    // With the constant residual Jacobian in registers the one-wave sweep runs 1.72 ms at every batch up to 256 (four loads of
-    // its fifteen per step gone), the triple 1.58 (one trajectory) ... 1.72 (64) ... 1.77 ms (256): the triple keeps the batches
-    // below 64 (profiles/r04_forward_forms.txt)
-    if (c->rx_const_on && c->ru_zero) return 16 * c->d.batch < c->n_simd ? 3 : 1;
-    return 4 * c->d.batch <= c->n_simd ? 3 : 1;
+    return 2 * c->d.batch <= c->n_simd ? 4 : 1;
 }
 
 // raw: difference the key-point ordered payload inside the sweep (one-wave form only; the caller checks backward_fused_form)
@@ -2665,18 +2785,49 @@ hipError_t launch_forward_fused(Ctx *c, double *U_alpha_dev)
     // sweep at B = 1, 1.74 ... 1.76 at B = 128 ... 256 (four tile sets per wave, a time loop without conditions) against 1.80 for
     // one wave per trajectory with its tile requests four steps ahead, which takes over beyond.
     // KPILQR_FUSED_FWD_WAVES = 1 | 2 | 3 forces a form.
-    const int form = forward_fused_form(c);
-    c->last_fwd_form = form == 3 ? 4 : form == 2 ? 3 : 1; c->last_fwd_ru0 = form == 1 && c->ru_zero;      // kpilqr_last_launch: triple / pair / w1
-    const bool rxc = form == 1 && c->ru_zero && c->rx_const_on;
-    c->last_fwd_rxc = rxc;
-    c->last_fwd_slopes = form == 1 && c->kps != nullptr;
+    int form = forward_fused_form(c);
+    const bool src_ru0 = c->ru_zero, src_rxc = c->ru_zero && c->rx_const_on;      // the cost wave of the state / cost groups
     const int ncz = (n + 2 + 3) / 4, ncu = (m + 3) / 4;       // tile chunks of [dx; alpha; 1] and of the controls
+    int only_ragged = 0;                                      // the general forms behind the uniform pair leave on a uniform set
+    c->last_fwd_form_ragged = 0;
+    if (form == 4) {
+        dim3 block2(128);
+        const int behind = 4 * c->d.batch <= c->n_simd ? 3 : 1;      // per-DoF lists: the triple, or one wave per trajectory
+#define LAUNCHSCU(NCZ, NCU)                                                                                             \
+        if (ncz == NCZ && ncu == NCU) {                                                                                 \
+            if (src_rxc) hipLaunchKernelGGL((k_forward_fused_scu<NCZ, NCU, true, true>), grid, block2, 0, c->stream, c->L, F, c->d.T, c->d.n_alpha, \
+                               c->K, c->k, c->u_nom, c->ctrl_lim, c->alphas, c->cost_pred, U_alpha_dev, c->kp_uniform);  \
+            else if (src_ru0) hipLaunchKernelGGL((k_forward_fused_scu<NCZ, NCU, true, false>), grid, block2, 0, c->stream, c->L, F, c->d.T, c->d.n_alpha, \
+                               c->K, c->k, c->u_nom, c->ctrl_lim, c->alphas, c->cost_pred, U_alpha_dev, c->kp_uniform);  \
+            else hipLaunchKernelGGL((k_forward_fused_scu<NCZ, NCU>), grid, block2, 0, c->stream, c->L, F, c->d.T, c->d.n_alpha, \
+                               c->K, c->k, c->u_nom, c->ctrl_lim, c->alphas, c->cost_pred, U_alpha_dev, c->kp_uniform);  \
+        }
+        LAUNCHSCU(4, 2) LAUNCHSCU(2, 1) LAUNCHSCU(4, 1) LAUNCHSCU(3, 1)
+#undef LAUNCHSCU
+        hipError_t e_ = hipGetLastError();
+        if (e_ != hipSuccess) return e_;
+        c->last_fwd_form = 3;                                 // kpilqr_last_launch: "pair" on a uniform set ...
+        c->last_fwd_form_ragged = behind == 3 ? 4 : 1;        // ... the triple / w1 otherwise
+        c->last_fwd_ru0 = c->ru_zero; c->last_fwd_rxc = src_rxc;
+        c->last_fwd_slopes = behind == 1 && c->kps != nullptr;
+        if (c->kp_known_uniform) return hipSuccess;           // (the host placed the lists and saw them equal: nothing else can run)
+        form = behind; only_ragged = 1;
+    } else {
+        c->last_fwd_form = form == 3 ? 4 : form == 2 ? 3 : 1;      // kpilqr_last_launch: triple / pair / w1
+        c->last_fwd_ru0 = c->ru_zero; c->last_fwd_rxc = src_rxc;
+        c->last_fwd_slopes = form == 1 && c->kps != nullptr;
+    }
+    const bool rxc = form == 1 && c->ru_zero && c->rx_const_on;
     if (form == 3) {
         dim3 block3(192);
 #define LAUNCHSC3(NCZ, NCU)                                                                                             \
         if (ncz == NCZ && ncu == NCU) {                                                                                 \
-            hipLaunchKernelGGL((k_forward_fused_sc3<NCZ, NCU>), grid, block3, 0, c->stream, c->L, F, c->d.T, c->d.n_alpha, \
-                               c->K, c->k, c->u_nom, c->ctrl_lim, c->alphas, c->cost_pred, U_alpha_dev);                \
+            if (src_rxc) hipLaunchKernelGGL((k_forward_fused_sc3<NCZ, NCU, true, true>), grid, block3, 0, c->stream, c->L, F, c->d.T, c->d.n_alpha, \
+                               c->K, c->k, c->u_nom, c->ctrl_lim, c->alphas, c->cost_pred, U_alpha_dev, c->kp_uniform, only_ragged); \
+            else if (src_ru0) hipLaunchKernelGGL((k_forward_fused_sc3<NCZ, NCU, true, false>), grid, block3, 0, c->stream, c->L, F, c->d.T, c->d.n_alpha, \
+                               c->K, c->k, c->u_nom, c->ctrl_lim, c->alphas, c->cost_pred, U_alpha_dev, c->kp_uniform, only_ragged); \
+            else hipLaunchKernelGGL((k_forward_fused_sc3<NCZ, NCU>), grid, block3, 0, c->stream, c->L, F, c->d.T, c->d.n_alpha, \
+                               c->K, c->k, c->u_nom, c->ctrl_lim, c->alphas, c->cost_pred, U_alpha_dev, c->kp_uniform, only_ragged); \
             return hipGetLastError();                                                                                   \
         }
         LAUNCHSC3(4, 2) LAUNCHSC3(2, 1) LAUNCHSC3(4, 1) LAUNCHSC3(3, 1)
@@ -2687,7 +2838,11 @@ hipError_t launch_forward_fused(Ctx *c, double *U_alpha_dev)
         dim3 block2(128);
 #define LAUNCHSC(NCZ, NCU)                                                                                              \
         if (ncz == NCZ && ncu == NCU) {                                                                                 \
-            hipLaunchKernelGGL((k_forward_fused_sc<NCZ, NCU>), grid, block2, 0, c->stream, c->L, F, c->d.T, c->d.n_alpha, \
+            if (src_rxc) hipLaunchKernelGGL((k_forward_fused_sc<NCZ, NCU, true, true>), grid, block2, 0, c->stream, c->L, F, c->d.T, c->d.n_alpha, \
+                               c->K, c->k, c->u_nom, c->ctrl_lim, c->alphas, c->cost_pred, U_alpha_dev);                \
+            else if (src_ru0) hipLaunchKernelGGL((k_forward_fused_sc<NCZ, NCU, true, false>), grid, block2, 0, c->stream, c->L, F, c->d.T, c->d.n_alpha, \
+                               c->K, c->k, c->u_nom, c->ctrl_lim, c->alphas, c->cost_pred, U_alpha_dev);                \
+            else hipLaunchKernelGGL((k_forward_fused_sc<NCZ, NCU>), grid, block2, 0, c->stream, c->L, F, c->d.T, c->d.n_alpha, \
                                c->K, c->k, c->u_nom, c->ctrl_lim, c->alphas, c->cost_pred, U_alpha_dev);                \
             return hipGetLastError();                                                                                   \
         }
@@ -2708,7 +2863,7 @@ hipError_t launch_forward_fused(Ctx *c, double *U_alpha_dev)
     } while (0)
 #define LAUNCH3(NCZ, NCU, RU, UNI) do { if (RU && rxc) LAUNCH4(NCZ, NCU, RU, UNI, RU); else LAUNCH4(NCZ, NCU, RU, UNI, false); } while (0)
 // both forms, back to back: the one whose kind of key-point set is not resident leaves at once (k_forward_fused)
-#define LAUNCH2(NCZ, NCU, RU) do { LAUNCH3(NCZ, NCU, RU, true); LAUNCH3(NCZ, NCU, RU, false); } while (0)
+#define LAUNCH2(NCZ, NCU, RU) do { if (!only_ragged) LAUNCH3(NCZ, NCU, RU, true); LAUNCH3(NCZ, NCU, RU, false); } while (0)
 // r_u never uploaded (ru_zero): the instantiation without the r_u loads and the Ju product.  Round-2 history: it measured
 // SLOWER at first (3.76 vs 3.22 ms at B = 1024: the compiler's wait placement left the latency shadow it sat in), and
 // faster once the uniform-key-point form and the per-trajectory descriptors had changed the loop (2.81 vs 3.03 ms).

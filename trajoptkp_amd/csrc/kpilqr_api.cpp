@@ -299,7 +299,7 @@ static bool backward_reads_rx_buffer(const kpilqr_ctx *c)
     const int form = c->fused ? backward_fused_form(c) : 0;
     return !((form == 1 || form == 5) && c->ru_zero);       // (the forms with a constant-Jacobian instantiation)
 }
-static bool forward_reads_rx_buffer(const kpilqr_ctx *c) { return !(c->fused && forward_fused_form(c) == 1 && c->ru_zero); }
+static bool forward_reads_rx_buffer(const kpilqr_ctx *c) { return !(c->fused && c->ru_zero); }      // (every fused forward form has its constant-Jacobian instantiation)
 
 // kernel families for c->d (names: kpilqr_backward_variant)
 static int select_variants(kpilqr_ctx *c)
@@ -1390,7 +1390,7 @@ int kpilqr_iterate_streamed(kpilqr_ctx *c, const kpilqr_stream_io *io, int pd_ch
         rc = run_forward(&v, nullptr);
         if (rc) { c->err = v.err; return rc; }
         vflags_valid = v.kpc_valid; vflags_touched = v.kpc_touched; vflags_slopes = v.kps_valid;
-        c->last_bwd_form = v.last_bwd_form; c->last_fwd_form = v.last_fwd_form; c->last_bwd_raw = v.last_bwd_raw;
+        c->last_bwd_form = v.last_bwd_form; c->last_fwd_form = v.last_fwd_form; c->last_bwd_raw = v.last_bwd_raw; c->last_fwd_form_ragged = v.last_fwd_form_ragged;
         c->last_bwd_ru0 = v.last_bwd_ru0; c->last_fwd_ru0 = v.last_fwd_ru0; c->last_bwd_rxc = v.last_bwd_rxc; c->last_fwd_rxc = v.last_fwd_rxc;
         c->last_bwd_slopes = v.last_bwd_slopes; c->last_fwd_slopes = v.last_fwd_slopes;
         // ---- D2H of the chunk ------------------------------------------------------------------------------------
@@ -1538,7 +1538,8 @@ const char *kpilqr_last_launch(kpilqr_ctx *c, int which)
         hipMemcpyAsync(&uni, c->kp_uniform, sizeof(int), hipMemcpyDeviceToHost, c->stream) != hipSuccess ||
         hipStreamSynchronize(c->stream) != hipSuccess) { out += ":?"; return out.c_str(); }
     static const char *const wname[6] = {"", "w1", "w2", "pair", "triple", "pairh"};
-    out += ":"; out += wname[form < 6 ? form : 0];
+    const int ran = (which == 1 && !uni && c->last_fwd_form_ragged) ? c->last_fwd_form_ragged : form;
+    out += ":"; out += wname[ran < 6 ? ran : 0];
     // (the raw launch sequence differences inside the sweep for uniform sets only: per-DoF lists take k_fd_kp_difference and
     // the plain sweep, launched behind it -- unless KPILQR_FUSED_UNI=0 forces the general raw form, one wave per trajectory)
     if (which == 0) out += (c->last_bwd_raw && (uni || (c->tune.fused_uni == 0 && form == 1))) ? ":raw" : ":kpc";
