@@ -47,6 +47,11 @@ if [ "$MODE" != per_step ]; then
     rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/stats_$kp -- python3 $OLDPWD/bench.py --keypoints $kp --no-secondary --no-cpu-baseline --steps 10 --warmup 2 > $OUT/stats_$kp.log 2>&1 || exit 1
     echo "stats $kp done"
   done
+  # a GPU's share of the 1024 trajectories on 2 / 4 GPUs: the consumer / helper pair and the state / cost pair
+  for bb in 512 256; do
+    rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/stats_b$bb -- python3 $OLDPWD/bench.py $WL --batch $bb --no-secondary --no-cpu-baseline --steps 10 --warmup 2 > $OUT/stats_b$bb.log 2>&1 || exit 1
+    echo "stats batch $bb done"
+  done
 fi
 cd $OLDPWD
 python tools/pmc_summarise.py $OUT $TAG $MODE || exit 1
