@@ -185,7 +185,7 @@ int  kpilqr_upload_fd_slab(kpilqr_ctx *ctx, const void *slab, int njobs, int nno
  *   int32  mode              bit k set: kind k is one-sided -> (xplus - xminus) / eps, else (xplus - xminus) / (2 eps)
  *   int32  pad[3]
  * so the host FD loop writes every perturbed next state straight to its slot, nothing carries indices, the library never
- * walks or sorts anything, and a trajectory's (or a chunk of trajectories') payload is one contiguous range.  On a KPILQR_FLAG_FUSED context with more than #SIMDs / 4 trajectories (one wavefront per trajectory, or the producer / consumer pair) there
+ * walks or sorts anything, and a trajectory's (or a chunk of trajectories') payload is one contiguous range.  On a KPILQR_FLAG_FUSED context (one wavefront per trajectory, or the consumer / helper wave pair up to #SIMDs / 2 trajectories) there
  * is then NO differencing kernel either: the backward sweep reads the slots of a key-point when it reaches it, forms the
  * column (the arithmetic of Differentiator.cpp:166-222,441-457, bit for bit what kpilqr_fd_difference gives) and keeps it
  * for the forward sweep.  Every other context accepts the payload too (it is differenced by a streaming kernel first).
@@ -349,7 +349,8 @@ const char *kpilqr_forward_variant(kpilqr_ctx *ctx);
 /* What the LAST backward (which = 0) / forward (which = 1) launch of this context was -- the variant above and, for the
  * KPILQR_FLAG_FUSED sweeps, the form the library picked from the batch size, the payload and the key-point lists:
  *     "<variant>:<waves>:<columns>:<lists>[:ru0][:rxc][:slopes]"          e.g. "mfma_f64_t1_fused:w1:raw:uni:ru0"
- *   waves    w1 one wavefront per trajectory | w2 control / state split | pair | triple
+ *   waves    w1 one wavefront per trajectory | w2 control / state split | pair | triple | pairh (backward: consumer / helper pair)
+ *            (forward `pair` on a uniform set: state wave with its own interpolant + scoring wave)
  *   columns  (backward only) raw: the sweep differenced the key-point ordered FD payload itself | kpc: it read the differenced
  *            key-point column store
  *   lists    uni: every DoF of a trajectory has the same key-point list (set_interval ...) | ragged: per-DoF lists
