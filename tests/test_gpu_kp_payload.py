@@ -383,12 +383,13 @@ def test_per_dof_lists_walk_the_slope_store(payload, monkeypatch):
 
     one = run({"KPILQR_FUSED_WAVES": "1", "KPILQR_FUSED_FWD_WAVES": "1"})
     assert ":w1:kpc:ragged" in one["lb"] and one["lb"].endswith(":slopes") and one["lf"].endswith(":slopes"), (one["lb"], one["lf"])
-    trip = run({})                                              # B = 5: the consumer / helper pair (its tracker divides at the crossings)
-    assert ":pairh:" in trip["lb"] and "slopes" not in trip["lb"]
+    trip = run({})                                              # B = 5: the consumer / helper pair, its helper on the slope store too
+    assert ":pairh:" in trip["lb"] and trip["lb"].endswith(":slopes"), trip["lb"]
     assert ":triple:ragged" in trip["lf"], trip["lf"]          # forward: the uniform pair left at once, the triple behind it ran
-    trip4 = run({"KPILQR_FUSED_WAVES": "4"})                    # ... and the triple
+    trip4 = run({"KPILQR_FUSED_WAVES": "4"})                    # ... and the triple, whose producer divides at the crossings
     assert ":triple:" in trip4["lb"] and "slopes" not in trip4["lb"]
-    assert all(np.array_equal(trip[key], trip4[key]) for key in ("K", "k", "delta_J"))      # (the same products in the same order)
+    # (the same products in the same order; the slopes are the same correctly rounded quotients either way)
+    assert all(np.array_equal(trip[key], trip4[key]) for key in ("K", "k", "delta_J"))
     for b in range(B):
         o = pipeline.run_trajectory(p, b)
         assert relerr(one["K"][b], o["K"]) < 1e-9 and relerr(one["cost"][b], o["cost_pred"]) < 1e-9

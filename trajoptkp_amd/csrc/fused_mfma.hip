@@ -1111,6 +1111,56 @@ struct DownTracker {
     __device__ __forceinline__ double value(int i, double dt) const { return lerp_nc(sv[i], dt, av[i]); }
 };
 
+// The same on the SLOPE STORE (kps [entry][3][n][2], (value, slope) pairs: k_kp_slopes / k_fd_kp_difference<SLOPES>) -- per-DoF lists
+// in the helper wave of the consumer / helper pair: a crossing is register moves and 16-byte loads, no division (with the lists of
+// reaching.yaml's velocity_change some lane crosses on ~40 % of the steps).  The requests are issued by ALL lanes behind a
+// wave-uniform branch (a lane that did not cross asks again for the entry it holds): loads inside a per-lane branch meet the
+// old values at its join, and the wait the compiler places there drains every request in flight.
+struct DownTrackerSlp {
+    static constexpr int NV = 8;
+    int offs[NV];                                // byte offsets inside a kpc entry (doubled for the slope store)
+    int lo, idx, s, nb, nb2;
+    double sv[NV], av[NV], pv[NV], pa[NV];
+    int E0, NE;
+    bool need = false;
+    __device__ __forceinline__ void load_pairs(__amdgpu_buffer_rsrc_t rS, int e_rel, int stride2, double *v, double *a) const
+    {
+        const int base = ((unsigned)e_rel < (unsigned)NE) ? e_rel * stride2 : BIGOFF;
+#pragma unroll
+        for (int r = 0; r < NV; r++) fbld2(rS, base + dbl_off(offs[r]), v[r], a[r]);
+    }
+    __device__ __forceinline__ void init(__amdgpu_buffer_rsrc_t rS, const int *kp_offsets, const int *kp_times, bool has, size_t list, int E0_, int NE_, int stride2)
+    {
+        E0 = E0_; NE = NE_;
+        lo = has ? kp_offsets[list] : 0;
+        const int hi = has ? kp_offsets[list + 1] : 0;
+        idx = hi - 1;
+        s = has ? kp_times[idx] : -1;
+        nb = (has && idx - 1 >= lo) ? kp_times[idx - 1] : -1;
+        nb2 = (has && idx - 2 >= lo) ? kp_times[idx - 2] : -1;
+        load_pairs(rS, has ? idx - E0 : -1, stride2, sv, av);                     // (the last key-point's slope is 0)
+        load_pairs(rS, (has && idx - 1 >= lo) ? idx - 1 - E0 : -1, stride2, pv, pa);
+    }
+    __device__ __forceinline__ void cross(int t)
+    {
+        need = t < s;                            // per lane: crossed the start of the current segment
+        if (need) {
+#pragma unroll
+            for (int i = 0; i < NV; i++) { sv[i] = pv[i]; av[i] = pa[i]; }
+            s = nb; idx--;
+            nb = nb2;
+        }
+    }
+    __device__ __forceinline__ void request(__amdgpu_buffer_rsrc_t rS, const int *kp_times, int stride2)
+    {
+        if (__builtin_amdgcn_ballot_w64(need) != 0) {
+            nb2 = (idx - 2 >= lo) ? kp_times[idx - 2] : -1;
+            load_pairs(rS, (idx - 1 >= lo) ? idx - 1 - E0 : -1, stride2, pv, pa);
+        }
+    }
+    __device__ __forceinline__ double value(int i, double dt) const { return lerp_nc(sv[i], dt, av[i]); }
+};
+
 // The same walking the KEY-POINT ORDERED FD PAYLOAD (producer wave of the pair / triple, RAWP): the prefetched x+ / x- of the
 // next segment start are differenced when the lane reaches it -- (x+ - x-) / (2 eps), / eps for a one-sided job: the arithmetic
 // and the bytes of k_fd_kp_difference -- and the column goes out to kpc for the forward sweep.  The producer is a step ahead of the
@@ -1525,10 +1575,12 @@ k_backward_fused2(RecLayout L, FusedArgs F, int T, int role_shift, const double 
 // between the mid-step barrier and the end of the step (while the consumer forms the gains and V'), the tiles of step t-1.
 // RU0 / RXC (helper only): r_u = 0 -- no r_u loads, no [l_uu | l_u] product, the ring's LU tiles stay zero; ONE constant r_x in
 // registers (see backward_fused_body).
-template <int N, int M, bool TRIPLE = false, bool RAWP = false, bool HELPER = false, bool RU0 = false, bool RXC = false>
+// SLP (helper only, differenced column store): per-DoF lists walked on the slope store (DownTrackerSlp).
+template <int N, int M, bool TRIPLE = false, bool RAWP = false, bool HELPER = false, bool RU0 = false, bool RXC = false, bool SLP = false>
 __device__ __forceinline__ void fusedpc_producer(double *pcbuf, int *sflag, RecLayout L, FusedArgs F, int T, const double *sh = nullptr)
 {
     static_assert(!HELPER || TRIPLE, "the helper keeps the triple's two barriers per step");
+    static_assert(!SLP || (HELPER && !RAWP), "the slope store serves the helper on a differenced column store");
     static_assert(HELPER || (!RU0 && !RXC), "RU0 / RXC are the helper's instantiations");
     static_assert(!RXC || RU0, "RXC comes with RU0");
     constexpr int n = N, m = M;
@@ -1536,7 +1588,7 @@ __device__ __forceinline__ void fusedpc_producer(double *pcbuf, int *sflag, RecL
     const int b = KP_BLOCK_TRAJ;
     const int nr = F.nr, ncr = (nr + 3) >> 2;
     const int strideB = 3 * L.n * 8;                               // bytes of one key-point entry of kpc: three columns
-    typename std::conditional<RAWP, DownTrackerRaw, DownTracker<8>>::type tr;       // A rows then B rows of column c
+    typename std::conditional<RAWP, DownTrackerRaw, typename std::conditional<SLP, DownTrackerSlp, DownTracker<8>>::type>::type tr;       // A rows then B rows of column c
     int oRx[4], oR1[4], oRu[4];
     d4 Wt, Wr;
     {
@@ -1590,6 +1642,9 @@ __device__ __forceinline__ void fusedpc_producer(double *pcbuf, int *sflag, RecL
     if constexpr (RAWP) {
         rP = frsrc(F.fdk + (size_t)E0 * (6 * n + 2) * 8, NE * (6 * n + 2) * 8);
         tr.init(rT, rP, F.kp_offsets, F.kp_times, c < n, (size_t)b * F.dof + kd, E0, NE, n, c < F.dof, F.eps2, F.rinv_2eps);
+    } else if constexpr (SLP) {
+        rP = frsrc(F.kps + (size_t)E0 * 6 * L.n, NE * 2 * strideB);              // the trajectory's slice of the slope store
+        tr.init(rP, F.kp_offsets, F.kp_times, c < n, (size_t)b * F.dof + kd, E0, NE, 2 * strideB);
     } else {
         tr.init(rT, F.kp_offsets, F.kp_times, c < n, (size_t)b * F.dof + kd, E0, NE, strideB);
     }
@@ -1655,6 +1710,7 @@ __device__ __forceinline__ void fusedpc_producer(double *pcbuf, int *sflag, RecL
             else tr.cross(t - 1);
             publish(t - 1, Wr);
             if constexpr (RAWP) { tr.settle(rT, F.eps2, F.rinv_2eps); tr.request(rP, F.kp_times); }
+            else if constexpr (SLP) tr.request(rP, F.kp_times, 2 * strideB);
             else tr.request(rT, F.kp_times, strideB);
             __syncthreads();                               // end of step: V of step t-1 is there
             if (__builtin_amdgcn_readfirstlane(sflag[0])) return;     // (wave-uniform: a divergent exit makes t a per-lane value and every request a waterfall loop)
@@ -1774,7 +1830,7 @@ k_backward_fusedpc3(RecLayout L, FusedArgs F, int T, int role_shift, const doubl
         fusedpc_producer<N, M, true, RAWP>(sh + FPC_RING, (int *)(sh + FPC_FLAG), L, F, T);
 }
 // Consumer / helper pair (2 x batch <= #SIMDs: a SIMD each): the triple's consumer, and ONE wave for its side and producer roles
-template <int N, int M, bool RAWP, bool RU0, bool RXC>
+template <int N, int M, bool RAWP, bool RU0, bool RXC, bool SLP = false>
 __global__ void __launch_bounds__(128) __attribute__((amdgpu_waves_per_eu(1, 1)))
 k_backward_fusedph(RecLayout L, FusedArgs F, int T, int role_shift, const double *__restrict__ lambda,
                    int pd_stride, double *__restrict__ Kout, double *__restrict__ kout,
@@ -1787,7 +1843,7 @@ k_backward_fusedph(RecLayout L, FusedArgs F, int T, int role_shift, const double
         backward_fused_body<N, M, true, RU0, true>(sh, sh + FPC_RING, (int *)(sh + FPC_FLAG), L, F, T, lambda, pd_stride, Kout, kout,
                                                    delta_J, status);
     else
-        fusedpc_producer<N, M, true, RAWP, true, RU0, RXC>(sh + FPC_RING, (int *)(sh + FPC_FLAG), L, F, T, sh);
+        fusedpc_producer<N, M, true, RAWP, true, RU0, RXC, SLP>(sh + FPC_RING, (int *)(sh + FPC_FLAG), L, F, T, sh);
 }
 // at most one wave per SIMD: while 2 x batch <= #SIMDs every wave of every pair gets a SIMD (and its FP64 unit) to itself
 template <int N, int M, bool RAWP>
@@ -2685,16 +2741,21 @@ hipError_t launch_backward_fused(Ctx *c, int pd_stride, bool raw)
     if (form == 5) {
         const bool hru0 = c->ru_zero, hrxc = c->ru_zero && c->rx_const_on;
         c->last_bwd_ru0 = hru0; c->last_bwd_rxc = hrxc;
-#define LAUNCHPH2(NN, MM, RW, RU, RX, GUARD) hipLaunchKernelGGL((k_backward_fusedph<NN, MM, RW, RU, RX>), grid, block2, 0, c->stream, c->L, F, c->d.T, role_shift, c->lambda, pd_stride, c->K, c->k, c->delta_J, c->status, c->kp_uniform, GUARD)
-#define LAUNCHPH(NN, MM, RW, GUARD) do { if (hrxc) LAUNCHPH2(NN, MM, RW, true, true, GUARD); else if (hru0) LAUNCHPH2(NN, MM, RW, true, false, GUARD); else LAUNCHPH2(NN, MM, RW, false, false, GUARD); } while (0)
+        // per-DoF lists: the helper walks the slope store (made by k_fd_kp_difference / k_kp_slopes for such sets only), uniform
+        // sets the column store with its dividing tracker: two launches, the device flag decides
+        const bool hslp = c->kps != nullptr;
+        c->last_bwd_slopes = hslp;
+#define LAUNCHPH2(NN, MM, RW, RU, RX, SL, GUARD) hipLaunchKernelGGL((k_backward_fusedph<NN, MM, RW, RU, RX, SL>), grid, block2, 0, c->stream, c->L, F, c->d.T, role_shift, c->lambda, pd_stride, c->K, c->k, c->delta_J, c->status, c->kp_uniform, GUARD)
+#define LAUNCHPH(NN, MM, RW, SL, GUARD) do { if (hrxc) LAUNCHPH2(NN, MM, RW, true, true, SL, GUARD); else if (hru0) LAUNCHPH2(NN, MM, RW, true, false, SL, GUARD); else LAUNCHPH2(NN, MM, RW, false, false, SL, GUARD); } while (0)
 #define KP_X(NN, MM)                                                                                   \
         if (n == NN && m == MM) {                                                                      \
             if (raw) {                                                                                 \
-                LAUNCHPH(NN, MM, true, 1);                                                             \
+                LAUNCHPH(NN, MM, true, false, 1);                                                      \
                 hipError_t e_ = launch_fd_kp_difference(c, true);                                      \
                 if (e_ != hipSuccess) return e_;                                                       \
-                LAUNCHPH(NN, MM, false, 0);                                                            \
-            } else LAUNCHPH(NN, MM, false, -1);                                                        \
+                if (hslp) LAUNCHPH(NN, MM, false, true, 0); else LAUNCHPH(NN, MM, false, false, 0);    \
+            } else if (hslp) { LAUNCHPH(NN, MM, false, false, 1); LAUNCHPH(NN, MM, false, true, 0); }  \
+            else LAUNCHPH(NN, MM, false, false, -1);                                                   \
             return hipGetLastError();                                                                  \
         }
         KP_T1_SHAPES(KP_X)
