@@ -2618,9 +2618,11 @@ template <int NCZ, int NCU, bool RU0 = false, bool RXC = false>
 __global__ void __launch_bounds__(128) __attribute__((amdgpu_waves_per_eu(1, 1)))
 k_forward_fused_sc(RecLayout L, FusedArgs F, int T, int n_alpha, const double *__restrict__ Kin,
                    const double *__restrict__ kin, const double *__restrict__ u_nom, const double *__restrict__ ctrl_lim,
-                   const double *__restrict__ alphas, double *__restrict__ cost_pred, double *__restrict__ U_alpha)
+                   const double *__restrict__ alphas, double *__restrict__ cost_pred, double *__restrict__ U_alpha,
+                   const int *__restrict__ kp_uniform, int only_ragged)
 {
     __shared__ __attribute__((aligned(16))) double sh[FSC_TOTAL];
+    if (only_ragged && *kp_uniform != 0) return;       // (launched behind k_forward_fused_scu, which has run the uniform set)
     const bool state = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6) == 0;
     if (state) forward_sc_state<NCZ, NCU, RU0>(sh, L, T, n_alpha, Kin, kin, u_nom, ctrl_lim, alphas, U_alpha);
     else       forward_sc_cost<NCZ, NCU, 0, RU0, RXC>(sh, L, F, T, n_alpha, cost_pred);
@@ -2853,7 +2855,8 @@ hipError_t launch_forward_fused(Ctx *c, double *U_alpha_dev)
     c->last_fwd_form_ragged = 0;
     if (form == 4) {
         dim3 block2(128);
-        const int behind = 4 * c->d.batch <= c->n_simd ? 3 : 1;      // per-DoF lists: the triple, or one wave per trajectory
+        // per-DoF lists: the triple, or (KPILQR_FWD_RAGGED_PAIR=1) the state / cost+staging pair, or one wave per trajectory
+        const int behind = 4 * c->d.batch <= c->n_simd ? 3 : c->tune.fwd_ragged_pair ? 2 : 1;
 #define LAUNCHSCU(NCZ, NCU)                                                                                             \
         if (ncz == NCZ && ncu == NCU) {                                                                                 \
             if (src_rxc) hipLaunchKernelGGL((k_forward_fused_scu<NCZ, NCU, true, true>), grid, block2, 0, c->stream, c->L, F, c->d.T, c->d.n_alpha, \
@@ -2868,7 +2871,7 @@ hipError_t launch_forward_fused(Ctx *c, double *U_alpha_dev)
         hipError_t e_ = hipGetLastError();
         if (e_ != hipSuccess) return e_;
         c->last_fwd_form = 3;                                 // kpilqr_last_launch: "pair" on a uniform set ...
-        c->last_fwd_form_ragged = behind == 3 ? 4 : 1;        // ... the triple / w1 otherwise
+        c->last_fwd_form_ragged = behind == 3 ? 4 : behind == 2 ? 3 : 1;        // ... the triple / pair / w1 otherwise
         c->last_fwd_ru0 = c->ru_zero; c->last_fwd_rxc = src_rxc;
         c->last_fwd_slopes = behind == 1 && c->kps != nullptr;
         if (c->kp_known_uniform) return hipSuccess;           // (the host placed the lists and saw them equal: nothing else can run)
@@ -2900,11 +2903,11 @@ hipError_t launch_forward_fused(Ctx *c, double *U_alpha_dev)
 #define LAUNCHSC(NCZ, NCU)                                                                                              \
         if (ncz == NCZ && ncu == NCU) {                                                                                 \
             if (src_rxc) hipLaunchKernelGGL((k_forward_fused_sc<NCZ, NCU, true, true>), grid, block2, 0, c->stream, c->L, F, c->d.T, c->d.n_alpha, \
-                               c->K, c->k, c->u_nom, c->ctrl_lim, c->alphas, c->cost_pred, U_alpha_dev);                \
+                               c->K, c->k, c->u_nom, c->ctrl_lim, c->alphas, c->cost_pred, U_alpha_dev, c->kp_uniform, only_ragged); \
             else if (src_ru0) hipLaunchKernelGGL((k_forward_fused_sc<NCZ, NCU, true, false>), grid, block2, 0, c->stream, c->L, F, c->d.T, c->d.n_alpha, \
-                               c->K, c->k, c->u_nom, c->ctrl_lim, c->alphas, c->cost_pred, U_alpha_dev);                \
+                               c->K, c->k, c->u_nom, c->ctrl_lim, c->alphas, c->cost_pred, U_alpha_dev, c->kp_uniform, only_ragged); \
             else hipLaunchKernelGGL((k_forward_fused_sc<NCZ, NCU>), grid, block2, 0, c->stream, c->L, F, c->d.T, c->d.n_alpha, \
-                               c->K, c->k, c->u_nom, c->ctrl_lim, c->alphas, c->cost_pred, U_alpha_dev);                \
+                               c->K, c->k, c->u_nom, c->ctrl_lim, c->alphas, c->cost_pred, U_alpha_dev, c->kp_uniform, only_ragged); \
             return hipGetLastError();                                                                                   \
         }
         LAUNCHSC(4, 2) LAUNCHSC(2, 1) LAUNCHSC(4, 1) LAUNCHSC(3, 1)

@@ -79,6 +79,7 @@ Ctx::Tuning read_tuning_from_env()
 {
     Ctx::Tuning t;
     t.fused_bwd_waves = env_int("KPILQR_FUSED_WAVES", 0);
+    t.fwd_ragged_pair = env_int("KPILQR_FWD_RAGGED_PAIR", 0);
     t.fused_fwd_waves = env_int("KPILQR_FUSED_FWD_WAVES", 0);
     t.role_shift = env_int("KPILQR_ROLE_SHIFT", 9);
     t.tiled_nt_min = env_int("KPILQR_TILED_NT_MIN", 0);
