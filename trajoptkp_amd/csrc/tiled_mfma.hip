@@ -227,7 +227,7 @@ k_backward_tiled_col(RecLayout L, CostSrc CS, KpSrc KP, int T, const double *__r
     TileSrc S = {n, m, L.off_A, L.off_B, L.off_lxx, L.off_lx, L.off_luu, L.off_lu};
 
     const double *R0 = rec + (size_t)b * T * L.stride;
-    const int rec_bytes = L.rec * 8;
+    const int rec_bytes = L.rec * 8; (void)rec_bytes;
     const d4 zero = {0.0, 0.0, 0.0, 0.0};
     const int tn = n >> 4, cn = n & 15;
     const bool lane_nn = (c == cn) && (q == (cn & 3));
@@ -652,7 +652,7 @@ k_backward_tiled_uw(RecLayout L, int T, const double *__restrict__ rec, const do
     auto comp = [](const d4 &v, int r) { return r == 0 ? v.x : r == 1 ? v.y : r == 2 ? v.z : v.w; };
 
     const double *R0 = rec + (size_t)b * T * L.stride;
-    const int rec_bytes = L.rec * 8;
+    const int rec_bytes = L.rec * 8; (void)rec_bytes;
     const d4 zero = {0.0, 0.0, 0.0, 0.0};
     const int tn = n >> 4, cn = n & 15;
     const bool lane_nn = (c == cn) && (q == (cn & 3));
@@ -1131,7 +1131,7 @@ k_forward_tiled(RecLayout L, CostSrc CS, KpSrc KP, int T, int n_alpha, const dou
     double partial = 0.0;
 
     struct Tiles { d4 Ykw, Ya[NT], Lc[NT], Yb, Luu, lu, ub; };        // A6: Lc[0] = RxT (own slice), Luu = RuT, lu = r
-    const int rec_bytes = L.rec * 8;
+    const int rec_bytes = L.rec * 8; (void)rec_bytes;
     auto ld4 = [&](__amdgpu_buffer_rsrc_t rs, const int *off) -> d4 {
         d4 v; v.x = tbld(rs, off[0]); v.y = tbld(rs, off[1]); v.z = tbld(rs, off[2]); v.w = tbld(rs, off[3]);
         return v;
@@ -1434,6 +1434,21 @@ template <int NC> __device__ __forceinline__ d4 ld4n(__amdgpu_buffer_rsrc_t rs, 
     if constexpr (NC > 3) v.w = tbld(rs, off[3]);
     return v;
 }
+// the same with a wave-uniform byte offset in the loads' scalar operand: ONE descriptor per array and trajectory, the step selected
+// by an SGPR, instead of a descriptor rebuilt (64-bit address arithmetic) per array and step
+__device__ __forceinline__ double tblds(__amdgpu_buffer_rsrc_t r, int byte_off, int soff)
+{
+    return __builtin_bit_cast(double, __builtin_amdgcn_raw_buffer_load_b64(r, byte_off, soff, 0));
+}
+template <int NC> __device__ __forceinline__ d4 ld4ns(__amdgpu_buffer_rsrc_t rs, const int *off, int soff)
+{
+    d4 v = {0.0, 0.0, 0.0, 0.0};
+    v.x = tblds(rs, off[0], soff);
+    if constexpr (NC > 1) v.y = tblds(rs, off[1], soff);
+    if constexpr (NC > 2) v.z = tblds(rs, off[2], soff);
+    if constexpr (NC > 3) v.w = tblds(rs, off[3], soff);
+    return v;
+}
 
 template <int NT, int WI, int NCL, int NCU>
 __device__ __forceinline__ void ft_state_role(double *zring, double *upart, double *dubuf, RecLayout L, int T, int n_alpha, int b,
@@ -1448,7 +1463,7 @@ __device__ __forceinline__ void ft_state_role(double *zring, double *upart, doub
     const int tnz = n >> 4;
     const int o = 16 * wi + c;
     const d4 zero = {0.0, 0.0, 0.0, 0.0};
-    const int rec_bytes = L.rec * 8;
+    const int rec_bytes = L.rec * 8; (void)rec_bytes;
     auto rs_of = [&](const double *base, size_t step_elems, int t, int bytes) {
         const bool ok = t < T;
         return __builtin_amdgcn_make_buffer_rsrc((void *)(base + ((size_t)b * T + (ok ? t : 0)) * step_elems), 0, ok ? bytes : 0, 0x00020000);
@@ -1496,26 +1511,34 @@ __device__ __forceinline__ void ft_state_role(double *zring, double *upart, doub
         lds_store(zring + wi * TILE, lane, Zi);
     }
     struct STiles { d4 Ykw, Ya[NT], Yb, ub; double kk; } cur;
+    // one descriptor per array for the whole trajectory; the step goes into the loads' scalar offset (behind the last step: step
+    // T-1 again, never used)
+    (void)rs_of;
+    const __amdgpu_buffer_rsrc_t rRec = __builtin_amdgcn_make_buffer_rsrc((void *)(rec + (size_t)b * T * L.stride), 0, (int)((size_t)T * L.stride * 8 < 0x7fffff00u ? (size_t)T * L.stride * 8 : 0x7fffff00u), 0x00020000);
+    const __amdgpu_buffer_rsrc_t rKt = __builtin_amdgcn_make_buffer_rsrc((void *)(Kin + (size_t)b * T * m * n), 0, T * m * n * 8, 0x00020000);
+    const __amdgpu_buffer_rsrc_t rkt = __builtin_amdgcn_make_buffer_rsrc((void *)(kin + (size_t)b * T * m), 0, T * m * 8, 0x00020000);
+    const __amdgpu_buffer_rsrc_t rut = __builtin_amdgcn_make_buffer_rsrc((void *)(u_nom + (size_t)b * T * m), 0, T * m * 8, 0x00020000);
+    const int recB = L.stride * 8;
     auto request_A = [&](int t) {
-        const __amdgpu_buffer_rsrc_t rR = rs_of(rec, L.stride, t, rec_bytes);
+        const int so = (t < T ? t : T - 1) * recB;
 #pragma unroll
-        for (int k = 0; k < NT - 1; k++) cur.Ya[k] = ld4n<4>(rR, oA[k]);
-        cur.Ya[NT - 1] = ld4n<NCL>(rR, oA[NT - 1]);
+        for (int k = 0; k < NT - 1; k++) cur.Ya[k] = ld4ns<4>(rRec, oA[k], so);
+        cur.Ya[NT - 1] = ld4ns<NCL>(rRec, oA[NT - 1], so);
     };
     auto request_B = [&](int t) {
-        const __amdgpu_buffer_rsrc_t rR = rs_of(rec, L.stride, t, rec_bytes);
-        cur.Yb = ld4n<NCU>(rR, oB);
+        const int so = (t < T ? t : T - 1) * recB;
+        cur.Yb = ld4ns<NCU>(rRec, oB, so);
     };
     {
-        const __amdgpu_buffer_rsrc_t rK = rs_of(Kin, (size_t)m * n, 0, m * n * 8), rk_ = rs_of(kin, m, 0, m * 8), ru = rs_of(u_nom, m, 0, m * 8);
-        cur.Ykw = ld4n<NCW>(rK, oKw); cur.kk = tbld(rk_, okn);
+        cur.Ykw = ld4ns<NCW>(rKt, oKw, 0); cur.kk = tblds(rkt, okn, 0);
         request_A(0); request_B(0);
-        cur.ub = ld4n<NCU>(ru, oub);
+        cur.ub = ld4ns<NCU>(rut, oub, 0);
     }
     __syncthreads();                                                     // Z_0 is published
     int slot = 0;                                                        // t mod 3
     for (int t = 0; t < T; t++) {
-        const __amdgpu_buffer_rsrc_t rK = rs_of(Kin, (size_t)m * n, t + 1, m * n * 8), rk_ = rs_of(kin, m, t + 1, m * 8), ru = rs_of(u_nom, m, t + 1, m * 8);
+        const int tn1 = t + 1 < T ? t + 1 : T - 1;
+        const int sK = tn1 * m * n * 8, sk = tn1 * m * 8;
         const double *zc = zring + slot * NT * TILE;
         const int nslot = slot == 2 ? 0 : slot + 1;
         double *zn = zring + nslot * NT * TILE;
@@ -1545,7 +1568,7 @@ __device__ __forceinline__ void ft_state_role(double *zring, double *upart, doub
             if (k < NT - 1) Zn = Pc<4>(Ya, Zk[k], Zn); else Zn = Pc<NCL>(Ya, Zk[k], Zn);
         }
         __builtin_amdgcn_sched_barrier(0);
-        cur.Ykw = ld4n<NCW>(rK, oKw); cur.kk = tbld(rk_, okn);
+        cur.Ykw = ld4ns<NCW>(rKt, oKw, sK); cur.kk = tblds(rkt, okn, sk);
         request_A(t + 1);
         __builtin_amdgcn_sched_barrier(0);
         __syncthreads();
@@ -1555,7 +1578,7 @@ __device__ __forceinline__ void ft_state_role(double *zring, double *upart, doub
 #pragma unroll
         for (int k = 0; k < NT; k++) U = U + lds_tile_n<NCU>(upart + k * TILE, lane);
         __builtin_amdgcn_sched_barrier(0);
-        cur.ub = ld4n<NCU>(ru, oub);
+        cur.ub = ld4ns<NCU>(rut, oub, sk);
         __builtin_amdgcn_sched_barrier(0);
         d4 dU = zero;
         {
@@ -1639,6 +1662,8 @@ k_forward_tiled_sc(RecLayout L, int T, int n_alpha, const double *__restrict__ r
             olu[r] = (wi == NT - 1 && row < m) ? 8 * (L.off_lu + row) : OOBT;
         }
         struct CTiles { d4 Lc[NT], Luu, lu; } cur;
+        const __amdgpu_buffer_rsrc_t rRec = __builtin_amdgcn_make_buffer_rsrc((void *)(rec + (size_t)b * T * L.stride), 0, (int)((size_t)T * L.stride * 8 < 0x7fffff00u ? (size_t)T * L.stride * 8 : 0x7fffff00u), 0x00020000);
+        const int recB = L.stride * 8;
         {
             __amdgpu_buffer_rsrc_t rR = rs_of(rec, L.stride, 0, rec_bytes);
 #pragma unroll
@@ -1654,7 +1679,7 @@ k_forward_tiled_sc(RecLayout L, int T, int n_alpha, const double *__restrict__ r
             // the tick's FIRST barrier at once: it is the one the state waves reach behind their slice product (4 MFMAs), and
             // nothing of this wave's work must stand in front of it; the scoring runs under the state waves' long phase
             __syncthreads();
-            const __amdgpu_buffer_rsrc_t rR = rs_of(rec, L.stride, t + 1, rec_bytes);
+            const int so = (t + 1 < T ? t + 1 : T - 1) * recB;
             const double *zc = zring + slot * NT * TILE;
             slot = slot == 2 ? 0 : slot + 1;
             d4 Zk[NT];
@@ -1669,10 +1694,10 @@ k_forward_tiled_sc(RecLayout L, int T, int n_alpha, const double *__restrict__ r
             const d4 Wu = Pc<NCU>(cur.Luu, dU, zero);                        // (l_uu, l_u: the last cost wave's; zeros elsewhere)
             __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
-            for (int k = 0; k < NT - 1; k++) cur.Lc[k] = ld4(rR, oLc[k]);
-            cur.Lc[NT - 1] = ld4n<NCL>(rR, oLc[NT - 1]);
+            for (int k = 0; k < NT - 1; k++) cur.Lc[k] = ld4ns<4>(rRec, oLc[k], so);
+            cur.Lc[NT - 1] = ld4ns<NCL>(rRec, oLc[NT - 1], so);
             const d4 lu = cur.lu;
-            cur.Luu = ld4n<NCU>(rR, oLuu); cur.lu = ld4n<NCU>(rR, olu);
+            cur.Luu = ld4ns<NCU>(rRec, oLuu, so); cur.lu = ld4ns<NCU>(rRec, olu, so);
             __builtin_amdgcn_sched_barrier(0);
             d4 Zi = Zk[0];                                                   // this wave's own row tile (wi is wave-uniform)
 #pragma unroll
