@@ -734,7 +734,7 @@ __device__ __forceinline__ void backward_fused_body(double *sh, const double *pc
 #if KP_XSWAP
         const bool refreshed = haveX && !check_pd && kp_inverse_refresh_sw<NCU, KINK>(Qr, Iu, Ncur, Nold, m, STATS ? &ns_steps : nullptr);     // NEGATED inverses
 #else
-        const bool refreshed = haveX && !check_pd && kp_inverse_refresh_n<NCU, KINK>(Qr, Iu, Xinv, Xprev, m, STATS ? &ns_steps : nullptr);    // Xinv, Xprev: NEGATED inverses
+        const bool refreshed = haveX && !check_pd && kp_inverse_refresh_n<NCU, KINK, PC>(Qr, Iu, Xinv, Xprev, m, STATS ? &ns_steps : nullptr);    // Xinv, Xprev: NEGATED inverses
 #endif
         if constexpr (STATS) { if (refreshed) hcnt[ns_steps < 0 ? 0 : ns_steps > 3 ? 3 : ns_steps]++; }
 #else
