@@ -432,3 +432,27 @@ def test_general_forms_forced_on_uniform_lists(monkeypatch):
     for b in range(3):
         o = pipeline.run_trajectory(p, b)
         assert relerr(ref["K"][b], o["K"]) < 1e-9
+
+
+@pytest.mark.parametrize("ragged_pair", ["0", "1"])
+def test_per_dof_lists_between_256_and_512_trajectories(monkeypatch, ragged_pair):
+    """256 < B <= 512 with per-DoF key-point lists: backward = the consumer / helper pair on the slope store, forward = one wave
+    per trajectory (general form) or, with KPILQR_FWD_RAGGED_PAIR=1, the state / cost+staging wave pair behind the uniform pair
+    (which leaves at once): the forms are asserted, a few trajectories against the oracle, the two forward forms against each other."""
+    monkeypatch.setenv("KPILQR_FWD_RAGGED_PAIR", ragged_pair)
+    T, dof = 90, 7
+    rng = np.random.default_rng(5)
+    rows = [synth.bisect_keypoints(rng, dof, T, 2, rng.uniform(0.0, 1.0, dof)) for _ in range(8)]
+    p0 = synth.make_ragged_problem("panda_reaching", T, rows, config_id=6, dense_residuals=False)
+    p = synth.tile_problem(p0, 33)                          # B = 264
+    with Engine(p["dof"], p["m"], T, p["nr"], batch=p["batch"], fused=True) as e:
+        synth.upload(e, p, kp_ordered=True)
+        e.iterate(p["lam"], 100, orc.alphas(6))
+        res = e.results(); K, k = e.gains()
+        lb, lf = e.last_launch("backward"), e.last_launch("forward")
+    assert ":pairh:kpc:ragged" in lb and lb.endswith(":slopes"), lb
+    assert (":pair:ragged" in lf) if ragged_pair == "1" else (":w1:ragged" in lf), lf
+    for b in (0, 5, 8 * 32 + 3):
+        o = pipeline.run_trajectory(p0, b % 8)
+        assert res["status"][b] == 0 and relerr(K[b], o["K"]) < 1e-9 and relerr(res["cost_pred"][b], o["cost_pred"]) < 1e-9
+    assert np.array_equal(K[3], K[8 * 32 + 3]) and np.array_equal(res["cost_pred"][3], res["cost_pred"][8 * 32 + 3])
