@@ -274,6 +274,7 @@ bool fused_supported(int n, int m, int nr, int dof, int T, int stride, int n_alp
 int backward_fused_form(const Ctx *c);
 int forward_fused_form(const Ctx *c);
 hipError_t launch_backward_fused(Ctx *c, int pd_stride, bool raw);
+hipError_t launch_backward_fused_waves(Ctx *c, int pd_stride, bool raw, int form);      // forms 2..5 (fused_mfma.hip, part 2)
 hipError_t launch_forward_fused(Ctx *c, double *U_alpha_dev);
 hipError_t launch_backward_fused_stats(Ctx *c, int pd_stride, int *hist_dev);
 

@@ -76,6 +76,13 @@ typedef unsigned long long u64;
                                     // instantiated for both assignments -- built in round 4, parity-green, SLOWER (4.94 against 4.52 ms: twice the code,
                                     // 166 AGPRs instead of 67), kept as a switch for the record
 #endif
+// The launchers (and with them the kernel instantiations) of this file compile as THREE translation units (Makefile: -DKP_FUSED_PART=1|2|3;
+// unset or 0: everything in one): 1 one wave per trajectory backward + the form choices, 2 the backward wave pairs / triple,
+// 3 the forward sweeps -- the file takes two minutes as one unit.
+#ifndef KP_FUSED_PART
+#define KP_FUSED_PART 0
+#endif
+#define KP_PART(n) (KP_FUSED_PART == 0 || KP_FUSED_PART == (n))
 #ifndef KP_KINK4
 #define KP_KINK4 1                  // 0: the step below a key-point refreshes the running inverse like every other step (round 3; A/B builds)
 #endif
@@ -2661,6 +2668,7 @@ k_forward_fused_sc3(RecLayout L, FusedArgs F, int T, int n_alpha, const double *
     else forward_sc_cost<NCZ, NCU, 2>(sh, L, F, T, n_alpha, cost_pred);
 }
 
+#if KP_PART(1)
 bool fused_supported(int n, int m, int nr, int dof, int T, int stride, int n_alpha)
 {
     (void)stride;
@@ -2668,6 +2676,7 @@ bool fused_supported(int n, int m, int nr, int dof, int T, int stride, int n_alp
     return kp_t1_shape(n, m) && nr >= 1 && nr <= 16 && m <= dof && n_alpha <= 16 && (long long)T * dof * (6 * n + 2) * 8 < (long long)BIGOFF;
 }
 
+#endif
 static FusedArgs fused_args(const Ctx *c)
 {
     FusedArgs F = {c->kp_offsets, c->kp_times, c->r, c->r_x, c->r_u, c->w_run, c->w_term, c->d.dof, c->d.nr,
@@ -2676,6 +2685,7 @@ static FusedArgs fused_args(const Ctx *c)
     return F;
 }
 
+#if KP_PART(1)
 // Which wave organisation launch_backward_fused will pick: 1 one wave per trajectory, 2 control/state split, 3 producer /
 // consumer pair, 4 consumer / side / producer triple, 5 consumer / helper pair.  Forms 1, 3 and 5 have RAW instantiations.
 // While a trajectory can have two SIMDs (2 x batch <= #SIMDs) the consumer / helper pair runs it: the consumer's chain is the
@@ -2718,6 +2728,54 @@ hipError_t launch_backward_fused(Ctx *c, int pd_stride, bool raw)
     const bool rxc = form == 1 && c->ru_zero && c->rx_const_on;     // (the caller has materialised r_x for every other form)
     c->last_bwd_rxc = rxc;
     c->last_bwd_slopes = form == 1 && c->kps != nullptr && !(raw && c->tune.fused_uni == 0);      // (what the general form walks, if it runs)
+    if (form != 1) return launch_backward_fused_waves(c, pd_stride, raw, form);
+#define LAUNCH5(NN, MM, RU, RW, UN, RX)                                                                       \
+    do {                                                                                                     \
+        if (excl)                                                                                            \
+            hipLaunchKernelGGL((k_backward_fused_excl<NN, MM, RU, RW, UN, RX>), grid, block, 0, c->stream, c->L, F, c->d.T,  \
+                               c->lambda, pd_stride, c->K, c->k, c->delta_J, c->status, c->kp_uniform);      \
+        else                                                                                                 \
+            hipLaunchKernelGGL((k_backward_fused<NN, MM, RU, RW, UN, RX>), grid, block, 0, c->stream, c->L, F, c->d.T,   \
+                               c->lambda, pd_stride, c->K, c->k, c->delta_J, c->status, c->kp_uniform);      \
+    } while (0)
+// rxc: constant residual Jacobians (with r_u = 0 only: RU instantiations)
+#define LAUNCH4(NN, MM, RU, RW, UN) do { if (RU && rxc) LAUNCH5(NN, MM, RU, RW, UN, RU); else LAUNCH5(NN, MM, RU, RW, UN, false); } while (0)
+// both forms, back to back: the one whose kind of key-point set is not resident leaves at once.  raw: only UNIFORM sets are
+// differenced inside the sweep; for per-DoF lists a lane's crossing is a divergent branch that every lane of the wave pays for
+// (17 loads, 8 stores on most steps), and the streaming kernel + the plain general sweep are faster (iterative-error lists with
+// a key-point on 99 % of the steps: 8.7 + 2.2 against 11.9 ms) -- k_fd_kp_difference is launched in between and looks at the
+// same device flag.  (KPILQR_FUSED_UNI=0, diagnostic: the general raw form for every set.)
+#define LAUNCH3(NN, MM, RU, RW) do { if (c->tune.fused_uni != 0) LAUNCH4(NN, MM, RU, RW, true); LAUNCH4(NN, MM, RU, RW, false); } while (0)
+#define LAUNCH2(NN, MM, RU)                                                                                             \
+    do {                                                                                                                \
+        if (raw && c->tune.fused_uni != 0) {                                                                            \
+            LAUNCH4(NN, MM, RU, true, true);                                                                            \
+            hipError_t e_ = launch_fd_kp_difference(c, true);     /* (per-DoF lists: columns and their slopes) */       \
+            if (e_ != hipSuccess) return e_;                                                                            \
+            LAUNCH4(NN, MM, RU, false, false);                                                                          \
+        } else if (raw) LAUNCH3(NN, MM, RU, true);                                                                      \
+        else LAUNCH3(NN, MM, RU, false);                                                                                \
+    } while (0)
+#define LAUNCH(NN, MM) do { if (c->ru_zero) LAUNCH2(NN, MM, true); else LAUNCH2(NN, MM, false); } while (0)
+#define KP_X(NN, MM) if (n == NN && m == MM) { LAUNCH(NN, MM); return hipGetLastError(); }
+    KP_T1_SHAPES(KP_X)
+#undef KP_X
+#undef LAUNCH
+#undef LAUNCH2
+#undef LAUNCH3
+#undef LAUNCH4
+#undef LAUNCH5
+    return hipErrorInvalidValue;
+}
+#endif
+
+#if KP_PART(2)
+// forms 2 ... 5 of the backward sweep (the wave pairs and the triple); launch_backward_fused has filled in kpilqr_last_launch's fields
+hipError_t launch_backward_fused_waves(Ctx *c, int pd_stride, bool raw, int form)
+{
+    const int n = c->n, m = c->d.m;
+    dim3 grid(c->d.batch);
+    const FusedArgs F = fused_args(c);
     const int role_shift = c->tune.role_shift;
     dim3 block2(128);
     if (form == 2) {
@@ -2788,45 +2846,11 @@ hipError_t launch_backward_fused(Ctx *c, int pd_stride, bool raw)
 #undef LAUNCHPC
         return hipErrorInvalidValue;
     }
-#define LAUNCH5(NN, MM, RU, RW, UN, RX)                                                                       \
-    do {                                                                                                     \
-        if (excl)                                                                                            \
-            hipLaunchKernelGGL((k_backward_fused_excl<NN, MM, RU, RW, UN, RX>), grid, block, 0, c->stream, c->L, F, c->d.T,  \
-                               c->lambda, pd_stride, c->K, c->k, c->delta_J, c->status, c->kp_uniform);      \
-        else                                                                                                 \
-            hipLaunchKernelGGL((k_backward_fused<NN, MM, RU, RW, UN, RX>), grid, block, 0, c->stream, c->L, F, c->d.T,   \
-                               c->lambda, pd_stride, c->K, c->k, c->delta_J, c->status, c->kp_uniform);      \
-    } while (0)
-// rxc: constant residual Jacobians (with r_u = 0 only: RU instantiations)
-#define LAUNCH4(NN, MM, RU, RW, UN) do { if (RU && rxc) LAUNCH5(NN, MM, RU, RW, UN, RU); else LAUNCH5(NN, MM, RU, RW, UN, false); } while (0)
-// both forms, back to back: the one whose kind of key-point set is not resident leaves at once.  raw: only UNIFORM sets are
-// differenced inside the sweep; for per-DoF lists a lane's crossing is a divergent branch that every lane of the wave pays for
-// (17 loads, 8 stores on most steps), and the streaming kernel + the plain general sweep are faster (iterative-error lists with
-// a key-point on 99 % of the steps: 8.7 + 2.2 against 11.9 ms) -- k_fd_kp_difference is launched in between and looks at the
-// same device flag.  (KPILQR_FUSED_UNI=0, diagnostic: the general raw form for every set.)
-#define LAUNCH3(NN, MM, RU, RW) do { if (c->tune.fused_uni != 0) LAUNCH4(NN, MM, RU, RW, true); LAUNCH4(NN, MM, RU, RW, false); } while (0)
-#define LAUNCH2(NN, MM, RU)                                                                                             \
-    do {                                                                                                                \
-        if (raw && c->tune.fused_uni != 0) {                                                                            \
-            LAUNCH4(NN, MM, RU, true, true);                                                                            \
-            hipError_t e_ = launch_fd_kp_difference(c, true);     /* (per-DoF lists: columns and their slopes) */       \
-            if (e_ != hipSuccess) return e_;                                                                            \
-            LAUNCH4(NN, MM, RU, false, false);                                                                          \
-        } else if (raw) LAUNCH3(NN, MM, RU, true);                                                                      \
-        else LAUNCH3(NN, MM, RU, false);                                                                                \
-    } while (0)
-#define LAUNCH(NN, MM) do { if (c->ru_zero) LAUNCH2(NN, MM, true); else LAUNCH2(NN, MM, false); } while (0)
-#define KP_X(NN, MM) if (n == NN && m == MM) { LAUNCH(NN, MM); return hipGetLastError(); }
-    KP_T1_SHAPES(KP_X)
-#undef KP_X
-#undef LAUNCH
-#undef LAUNCH2
-#undef LAUNCH3
-#undef LAUNCH4
-#undef LAUNCH5
     return hipErrorInvalidValue;
 }
+#endif
 
+#if KP_PART(1)
 // diagnostic: the one-wave sweep (general form, reads kpc) with the refresh histogram
 hipError_t launch_backward_fused_stats(Ctx *c, int pd_stride, int *hist_dev)
 {
@@ -2838,6 +2862,8 @@ hipError_t launch_backward_fused_stats(Ctx *c, int pd_stride, int *hist_dev)
     return hipErrorInvalidValue;
 }
 
+#endif
+#if KP_PART(3)
 hipError_t launch_forward_fused(Ctx *c, double *U_alpha_dev)
 {
     const int n = c->n, m = c->d.m;
@@ -2941,5 +2967,6 @@ hipError_t launch_forward_fused(Ctx *c, double *U_alpha_dev)
 #undef LAUNCH4
     return hipErrorInvalidValue;
 }
+#endif
 
 }  // namespace kpilqr
