@@ -2717,11 +2717,10 @@ hipError_t launch_backward_fused(Ctx *c, int pd_stride, bool raw)
     dim3 grid(c->d.batch), block(64);
     const bool excl = c->d.batch <= c->n_simd;
     const FusedArgs F = fused_args(c);
-    // Wave organisation of the backward sweep.  While every wave of a producer/consumer pair can have a SIMD to itself
-    // (2 x batch <= #SIMDs) the pair is the fastest form (4.2 vs 5.8 ms per sweep, tools/small_batch_variants.sh);
-    // beyond that the FP64 unit is shared and one wave per trajectory wins.
-    // KPILQR_FUSED_WAVES forces a form: 1 = one wave, 2 = control/state split, 3 = producer/consumer, 4 = the triple
-    // consumer / side / producer (while batch <= #CUs: the three waves of a workgroup share a CU).
+    // Wave organisation of the backward sweep (backward_fused_form above).  While every wave of the consumer / helper pair can have
+    // a SIMD to itself (2 x batch <= #SIMDs) the pair is the fastest form; beyond that two waves take turns on a SIMD and one wave
+    // per trajectory wins (DESIGN.md sections 4.0, 4.4).  KPILQR_FUSED_WAVES forces a form: 1 = one wave, 2 = control/state split,
+    // 3 = producer/consumer pair, 4 = the consumer / side / producer triple, 5 = the consumer / helper pair.
     const int form = backward_fused_form(c);
     if (raw && form != 1 && form != 3 && form != 5) return hipErrorInvalidValue;
     c->last_bwd_form = form; c->last_bwd_raw = raw; c->last_bwd_ru0 = form == 1 && c->ru_zero;       // kpilqr_last_launch
