@@ -18,7 +18,8 @@ bad = 0
 for f in files:
     with tempfile.TemporaryDirectory() as td:
         out = os.path.join(td, "k.s")
-        subprocess.check_call(["hipcc", "-O3", "-std=c++17", "--offload-arch=gfx950", "-Wno-unused-function", "-S", "--cuda-device-only", "-o", out, f],
+        subprocess.check_call(["hipcc", "-O3", "-std=c++17", "--offload-arch=gfx950", "-Wno-unused-function", "-mllvm", "-amdgpu-mfma-vgpr-form",   # (the Makefile's flags)
+                               "-S", "--cuda-device-only", "-o", out, f],
                               stderr=subprocess.DEVNULL)
         lines = open(out).read().split("\n")
     cur, depth2, rows = None, False, {}
@@ -31,7 +32,9 @@ for f in files:
         if l.startswith(".Lfunc_end"): depth2 = False
         if "s_cbranch_execnz" in l:
             back = "\n".join(lines[max(0, i - 14):i])
-            if "v_readfirstlane" in back and "s_and_saveexec" in back: rows[cur]["waterfall"] += 1
+            # (the loop LLVM wraps a VGPR descriptor in: readfirstlane x4, v_cmp_eq_u64, s_and_saveexec, the access, s_xor exec, branch back)
+            if "v_readfirstlane" in back and "s_and_saveexec" in back and "s_xor_b64 exec, exec" in back and "v_cmp_eq_u64" in back:
+                rows[cur]["waterfall"] += 1
         if depth2 and "s_waitcnt vmcnt(0)" in l: rows[cur]["drains"] += 1
         for key, pat in (("vgpr", r"; NumVgprs: (\d+)"), ("agpr", r"; NumAgprs: (\d+)"), ("scratch", r"; ScratchSize: (\d+)")):
             mm = re.match(pat, l)
