@@ -57,7 +57,8 @@ typedef unsigned long long u64;
 #define KP_FWD_SETS 4              // register sets of the one-wave forward sweep (requests run this many steps ahead)
 #endif
 #ifndef KP_FWD_SETS_GEN
-#define KP_FWD_SETS_GEN 4          // ... of its general (per-DoF list) form, whose tracker holds 32 more registers than the uniform form's
+#define KP_FWD_SETS_GEN 6          // ... of its general (per-DoF list) form (late round 4, same box: 3 / 4 / 5 / 6 / 8 sets = 2.37 / 2.32 / 2.30 / 2.29 / 2.46 ms
+                                   // on velocity_change lists, 2.73 / 2.70 / 2.65 / 2.64 / 2.81 on adaptive_jerk lists)
 #endif
 #ifndef KP_BWD_LATE_STORE
 #define KP_BWD_LATE_STORE 1
