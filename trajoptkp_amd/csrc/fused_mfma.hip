@@ -2021,7 +2021,8 @@ __device__ __forceinline__ void forward_fused_body(RecLayout L, FusedArgs F, int
     // t+2 right behind each tile's last use.  A wavefront's loads return in order and a step is shorter than a trip to HBM
     // (the sweep ran at one memory latency per step with a single set: 2.66 ms at B = 128 where its arithmetic needs 2.13,
     // -DKP_PROBE_SAMEB), so the requests have to be two steps ahead of their use.
-    constexpr int NS = UNI ? KP_FWD_SETS : KP_FWD_SETS_GEN;
+    // (the general form with control residuals keeps four sets: with six its largest shape spills -- 100 bytes of scratch, tools/isa_lint.py)
+    constexpr int NS = UNI ? KP_FWD_SETS : (RU0 || KP_FWD_SETS_GEN < 4) ? KP_FWD_SETS_GEN : 4;
     Tiles S[NS];
     d4 RxTc = {0.0, 0.0, 0.0, 0.0};
     if constexpr (RXC) {
