@@ -1677,7 +1677,9 @@ __device__ __forceinline__ void fusedpc_producer(double *pcbuf, int *sflag, RecL
         double *tb = pcbuf + (t & 1) * FPC_BUF;
         if constexpr (!HELPER) lds_store4(tb, lane, Fz);  // (Fz is the side products' operand only)
         lds_store4(tb + 256, lane, Fu);
-        lds_store4(tb + 512, lane, Lzz);
+        // (Lzz: the consumer of the triple / helper pair reads it at the terminal step only, V = Lzz(T-1); the side products take it
+        // from registers here)
+        if (!HELPER || t == T - 1) lds_store4(tb + 512, lane, Lzz);
         if constexpr (!RU0) lds_store4(tb + 768, lane, LU);
         if constexpr (HELPER) { hFz = Fz; hFu = Fu; hLzz = Lzz; hLU = LU; }
     };
