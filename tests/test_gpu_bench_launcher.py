@@ -32,7 +32,7 @@ def test_bench_gpus_2_starts_two_ranks_itself_and_shards_the_global_batch():
     assert out["n_gpus"] == 2 and out["scaling"] == "strong" and out["steps"] == 2 and out["warmup"] == 1
     assert out["config"]["global_batch"] == 64 and out["config"]["batch_per_gpu"] == 32          # 32 trajectories on rank 0
     assert out["config"]["valid_backward_passes_rank0"] == 32 and out["parity_check"]["pass"]
-    assert out["value"] > 0 and abs(out["value"] - 64 * 2 / (out["ms_per_step"] * 2e-3)) < 1e-6 * out["value"]
+    assert out["value"] > 0 and abs(out["value"] - 64 * 2 / (out["ms_per_step"] * 2e-3)) < 1e-4 * out["value"]    # (the line carries six digits)
     if ndev >= 2:
         assert out["rccl_ranks"] == 2 and "RCCL" in out["collective"], out["collective"]
     else:   # one GPU: the ranks share it, RCCL refuses such a communicator, the rehearsal's collective runs over gloo and says so
