@@ -36,9 +36,14 @@ def _run(p, fused, kp_ordered, explicit_fd=False, lam=None, pd=100, want_AB=Fals
     return out
 
 
-def _same(a, b, keys=("K", "k", "delta_J", "cost")):
+def _same(a, b, keys=("K", "k", "delta_J", "cost"), rtol=0.0):
+    """rtol = 0: bit for bit; else max |a - b| <= rtol * max |b| per array."""
     for key in keys:
-        assert np.array_equal(a[key], b[key]), key
+        if rtol == 0.0:
+            assert np.array_equal(a[key], b[key]), key
+        else:
+            u, v = np.asarray(a[key], float), np.asarray(b[key], float)
+            assert np.max(np.abs(u - v)) <= rtol * max(float(np.max(np.abs(v))), 1e-300), (key, float(np.max(np.abs(u - v))), float(np.max(np.abs(v))))
 
 
 @pytest.fixture(params=["one_wave", "auto", "pair", "triple"])
@@ -272,8 +277,11 @@ def test_host_differenced_columns_give_the_bytes_of_the_fd_payload(fused, waves)
                                              ("hopper", 150, 2, dict(min_N=4)), ("pentabot", 64, 3, dict(min_N=3))])
 def test_constant_residual_jacobians_give_the_bytes_of_the_streamed_form(task, T, batch, kw, waves):
     """One r_x [nr][n] uploaded once (Reaching.cpp:43-54: r = [q - q*, qdot] -> selector rows, r_u = 0) == the same matrix given
-    at every step: K, k, delta_J, predicted costs bit for bit, in every wave organisation (the one-wave sweeps and the helper
-    wave of the consumer / helper pair keep the matrix in registers and read no r_x; the others read its broadcast copy), for either payload form -- and against the oracle."""
+    at every step, in every wave organisation and for either payload form -- and against the oracle.  The wave forms that read
+    the broadcast copy run the streamed kernels: K, k, delta_J, predicted costs bit for bit.  The one-wave sweeps and the helper
+    wave of the consumer / helper pair keep the matrix in registers AND (round 5) the constant block r_x' W r_x as a resident
+    tile: Lzz = Cxx + 2 e_n (r_x' W r)' is one product instead of four, in another accumulation order -- those legs are held to
+    the streamed form at 1e-12 (and to the oracle at 1e-9 like everything else)."""
     p = synth.make_problem(task=task, T=T, batch=batch, **kw)
     assert p["rx_const"] is not None and not np.any(p["r_u"])
     for kp_ordered in (True, False):
@@ -285,7 +293,7 @@ def test_constant_residual_jacobians_give_the_bytes_of_the_streamed_form(task, T
             K, k = e.gains()
             got = dict(K=K, k=k, status=res["status"], delta_J=res["delta_J"], cost=res["cost_pred"])
             lb, lf = e.last_launch("backward"), e.last_launch("forward")
-            _same(got, ref)
+            _same(got, ref, rtol=1e-12 if ":rxc" in lb else 0.0)
             if waves == "one_wave":
                 assert ":w1:" in lb and ":rxc" in lb and ":w1:" in lf and ":rxc" in lf, (lb, lf)
                 assert (":raw:" in lb) == kp_ordered
@@ -348,7 +356,10 @@ def test_constant_residual_jacobians_mode_switches():
         K = e.pinned(ref["K"].shape); k = e.pinned(ref["k"].shape); cp = e.pinned((4, 6)); st = e.pinned(4, np.int32)
         e.iterate_streamed(fd_kp=s, eps=p["eps"], lam=lam, K=K, k=k, cost_pred=cp, status=st, nchunks=2, **pin)
         e.sync()
-        assert np.array_equal(K, ref["K"]) and np.array_equal(cp, ref["cost"])
+        # (the helper wave keeps r_x' W r_x as a resident tile, round 5: l_xx -- and with it V_xx and K -- in the same bits as the
+        # streamed form, l_x in another accumulation order: k and the predicted costs to 1e-12)
+        assert np.array_equal(K, ref["K"]) and np.max(np.abs(cp - ref["cost"])) <= 1e-12 * np.max(np.abs(ref["cost"]))
+        assert np.max(np.abs(k - ref["k"])) <= 1e-12 * np.max(np.abs(ref["k"]))
     # the arrays above are views of pinned allocations: they outlive the engine (Engine.pinned keeps the block alive)
     assert np.array_equal(K, ref["K"]) and int(st.sum()) == 0
 

@@ -125,6 +125,16 @@ def test_acrobot_fused_unfused_and_analytic_residual_jacobians_agree():
     col = host.run_acrobot(T=100, min_N=5, max_iter=6, min_iter=2, method="set_interval+fused+columns", torque_weight=1e-3)
     assert col["iterations"] == base["iterations"]
     assert np.array_equal(col["cost_history"], base["cost_history"]) and np.array_equal(col["K0"], base["K0"])
+    # a task that DECLARES its residual Jacobians constant (ModelTranslator::ConstantResidualJacobians; reaching is one:
+    # Reaching.cpp:43-54): the shim uploads the pair once per context and never runs a5 -- the same matrices as the closed-form
+    # per-step path, so the same bytes come back (kpilqr_upload_residual_jacobians_const's contract)
+    for spec in ("set_interval+fused", "set_interval+unfused"):
+        per = host.run_acrobot(T=100, min_N=5, max_iter=6, min_iter=2, method=spec + "+analytic", torque_weight=1e-3)
+        con = host.run_acrobot(T=100, min_N=5, max_iter=6, min_iter=2, method=spec + "+analytic+constjac", torque_weight=1e-3)
+        assert con["constant_jacobian_uploads"] == 1 and con["per_step_jacobian_uploads"] == 0, con
+        assert per["constant_jacobian_uploads"] == 0 and per["per_step_jacobian_uploads"] >= 1, per
+        assert con["iterations"] == per["iterations"]
+        assert np.array_equal(con["cost_history"], per["cost_history"]) and np.array_equal(con["K0"], per["K0"]) and np.array_equal(con["U"], per["U"])
     # a filtering task (Optimiser::FilterDynamicsMatrices) runs on the materialising pipeline and still optimises
     for f in ("low_pass", "FIR"):
         r = host.run_acrobot(T=100, min_N=5, max_iter=6, min_iter=2, method=f"set_interval+{f}", torque_weight=1e-3)
@@ -194,6 +204,11 @@ def test_batched_optimiser_matches_single_trajectory_runs():
             assert np.allclose(res["cost_history"][b], single["cost_history"], rtol=1e-9), (fused, b)
             assert np.allclose(res["U"][b], single["U"], rtol=1e-7, atol=1e-9)
         assert res["stats"][7] >= 1.0 and np.all(np.isfinite(res["stats"]))
+    # the task's ONE residual Jacobian pair uploaded once for the whole batch (ModelTranslator::ConstantResidualJacobians)
+    res = host.run_acrobot_batch(q0s, T=100, min_N=5, max_iter=7, min_iter=2, torque_weight=1e-3, fused=True, method="set_interval+constjac")
+    for b, q0 in enumerate(q0s):
+        single = host.run_acrobot(T=100, min_N=5, max_iter=7, min_iter=2, torque_weight=1e-3, method=f"set_interval+fused+analytic+constjac+q0={q0[0]},{q0[1]}")
+        assert res["iterations"][b] == single["iterations"] and np.allclose(res["cost_history"][b], single["cost_history"], rtol=1e-9), b
 
 
 @pytest.mark.gpu

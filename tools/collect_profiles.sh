@@ -8,7 +8,7 @@
 # Second argument "per_step": the same passes (without the generic ones) for `bench.py --streamed-jacobians` -- the residual
 # Jacobians given per step, the round-1..3 form -- into profiles/<tag>_*_per_step_jacobians.*
 set -o pipefail
-TAG=${1:-r04}
+TAG=${1:-r05}
 MODE=${2:-}
 EXTRA=""
 SUB=$TAG
@@ -20,9 +20,9 @@ export TMPDIR=/tmp
 # under rocprofv3 the profiler has initialised the GPU before the script starts, so those passes must not fork
 WL="--workload-cache /tmp/kpilqr_workload"
 if [ "$MODE" = per_step ]; then
-  python bench.py $WL $EXTRA --no-secondary --no-cpu-baseline > $OUT/bench.json 2> $OUT/bench.err || exit 1
+  python bench.py $WL $EXTRA --no-secondary --no-cpu-baseline --detail $OUT/bench_detail.json > $OUT/bench.json 2> $OUT/bench.err || exit 1
 else
-  python bench.py $WL > $OUT/bench.json 2> $OUT/bench.err || exit 1
+  python bench.py $WL --detail $OUT/bench_detail.json > $OUT/bench.json 2> $OUT/bench.err || exit 1
 fi
 echo "bench done"
 if [ "$MODE" != per_step ]; then
@@ -47,7 +47,13 @@ if [ "$MODE" != per_step ]; then
     rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/stats_$kp -- python3 $OLDPWD/bench.py --keypoints $kp --no-secondary --no-cpu-baseline --steps 10 --warmup 2 > $OUT/stats_$kp.log 2>&1 || exit 1
     echo "stats $kp done"
   done
-  # a GPU's share of the 1024 trajectories on 2 / 4 GPUs: the consumer / helper pair and the state / cost pair
+  # a GPU's share of the 1024 trajectories on 2 / 4 GPUs: the consumer / helper pair and the state / cost pair.  The workload cache
+  # is keyed by the batch: warm it with a plain run first -- under rocprofv3 the profiler has initialised the GPU before the script
+  # starts and a cache miss there would fork the generator's worker pool behind it (round-4 advisor)
+  for bb in 512 256; do
+    python bench.py $WL --batch $bb --no-secondary --no-cpu-baseline --steps 1 --warmup 0 --detail /dev/null > /dev/null 2>&1 || exit 1
+  done
+  export KPILQR_BENCH_NOFORK=1
   for bb in 512 256; do
     rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/stats_b$bb -- python3 $OLDPWD/bench.py $WL --batch $bb --no-secondary --no-cpu-baseline --steps 10 --warmup 2 > $OUT/stats_b$bb.log 2>&1 || exit 1
     echo "stats batch $bb done"

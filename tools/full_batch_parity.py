@@ -10,10 +10,10 @@ Legs, all in the default environment except for the one switch named: the form e
 (kpilqr_last_launch) and ASSERTED, so two legs can never silently be the same code path.
   B > 512         A  w1:raw:uni (one wave per trajectory, the payload differenced inside the backward sweep: the bench's kernel)
                   B  KPILQR_FUSED_RAW=0 -> w1:kpc:uni (k_fd_kp_difference first)          bit-identical to A
-                  C  constant residual Jacobians -> w1:raw:uni:ru0:rxc                     bit-identical to A
+                  C  constant residual Jacobians -> w1:raw:uni:ru0:rxc                     within 1e-12 of A (one-product Lzz)
   B <= 512        A  pairh:raw:uni:ru0 (consumer / helper pair, the helper wave differences)
                   B  KPILQR_FUSED_RAW=0 -> pairh:kpc:uni:ru0                               bit-identical to A
-                  C  constant residual Jacobians -> pairh:raw:uni:ru0:rxc                  bit-identical to A
+                  C  constant residual Jacobians -> pairh:raw:uni:ru0:rxc                  within 1e-12 of A
   B <= 256 also   D  KPILQR_FUSED_WAVES=4 -> triple:kpc:uni (behind k_fd_kp_difference)    another kernel: 1e-9 to the oracle
                   E  KPILQR_FUSED_WAVES=1 + KPILQR_FUSED_FWD_WAVES=1 -> w1:raw:uni:ru0     another kernel: 1e-9 to the oracle
 Every leg: K, k, delta_J, predicted costs of the sampled trajectories within 1e-9 of the oracle, statuses equal."""
@@ -112,10 +112,23 @@ for name, env, rxc, want, same_as in legs:
            "max_rel_err_cost_pred": float(eC.max()), "max_rel_err_delta_J": float(eJ.max())}
     if same_as:
         a = results[same_as]
-        row["bit_identical_to"] = same_as
-        row["bit_identical"] = bool(all(np.array_equal(u, v) for u, v in zip(results[name], a)))
-        print(f"  K, k, delta_J, predicted costs, statuses of ALL {B} trajectories bit-identical to leg {same_as}: {row['bit_identical']}", flush=True)
-        assert row["bit_identical"]
+        if rxc:
+            # the constant-Jacobian sweeps keep r_x' W r_x as a resident tile and form Lzz with ONE product instead of four (round 5):
+            # another accumulation order -- every trajectory within 1e-12 of leg A (relative to the array's largest entry), statuses equal
+            row["agrees_with"] = same_as
+            worst = 0.0
+            for u, v in zip(results[name][:4], a[:4]):
+                u_, v_ = np.asarray(u, float).reshape(B, -1), np.asarray(v, float).reshape(B, -1)
+                worst = max(worst, float(np.max(np.max(np.abs(u_ - v_), axis=1) / np.maximum(np.max(np.abs(v_), axis=1), 1e-300))))
+            row["max_rel_diff"] = worst
+            row["agrees_1e12"] = bool(worst <= 1e-12 and np.array_equal(results[name][4], a[4]))
+            print(f"  K, k, delta_J, predicted costs of ALL {B} trajectories within {worst:.2e} of leg {same_as} (bar 1e-12), statuses equal: {row['agrees_1e12']}", flush=True)
+            assert row["agrees_1e12"]
+        else:
+            row["bit_identical_to"] = same_as
+            row["bit_identical"] = bool(all(np.array_equal(u, v) for u, v in zip(results[name], a)))
+            print(f"  K, k, delta_J, predicted costs, statuses of ALL {B} trajectories bit-identical to leg {same_as}: {row['bit_identical']}", flush=True)
+            assert row["bit_identical"]
         del results[name]
     summary["legs"][name] = row
 forms = [summary["legs"][name]["backward"] for name, _, rxc, _, _ in legs if not rxc]

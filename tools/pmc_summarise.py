@@ -89,7 +89,7 @@ for sub, name in (("stats", f"{tag}_kernel_stats{SUFFIX}.csv"), ("stats_generic"
     fs = sorted(glob.glob(os.path.join(out, sub, "**", "*kernel_stats.csv"), recursive=True), key=os.path.getmtime)
     if fs:
         shutil.copy(fs[-1], os.path.join(root, "profiles", name))
-for src, name in (("bench.json", f"{tag}_bench{SUFFIX}.json"), ("generic.json", f"{tag}_generic_bench.json")):
+for src, name in (("bench.json", f"{tag}_bench{SUFFIX}.json"), ("bench_detail.json", f"{tag}_bench_detail{SUFFIX}.json"), ("generic.json", f"{tag}_generic_bench.json")):
     if os.path.exists(os.path.join(out, src)):
         shutil.copy(os.path.join(out, src), os.path.join(root, "profiles", name))
 print(json.dumps(cnt["derived"], indent=1))

@@ -87,6 +87,9 @@ typedef unsigned long long u64;
 #ifndef KP_KINK4
 #define KP_KINK4 1                  // 0: the step below a key-point refreshes the running inverse like every other step (round 3; A/B builds)
 #endif
+#ifndef KP_RXC_CXX
+#define KP_RXC_CXX 1                // 0: the RXC sweeps form Lzz = Rz' W Rz with four products at every step (round 4; A/B builds)
+#endif
 #ifndef KP_SLOPES
 #define KP_SLOPES 1                 // 0: the general forms divide at their crossings (rounds 1-3) instead of reading the slope store (A/B builds)
 #endif
@@ -367,7 +370,8 @@ __device__ __forceinline__ void backward_fused_body(double *sh, const double *pc
     for (int r = 0; r < 4; r++) {
         const int row = 4 * r + q;
         oRx[r] = (row < nr && c < n) ? 8 * (row * n + c) : OOBF;      // Rz(k=row, c) = r_x[k][c]
-        oR1[r] = (row < nr && c == n) ? 8 * row : OOBF;               //            ... | r[k] in column n
+        // (RXC one-wave sweeps: r[k] in EVERY column -- the lanes of column c form their part of (r_x' W r)(c) from it, see CXX below)
+        oR1[r] = (row < nr && (c == n || (KP_RXC_CXX && RXC && !PC))) ? 8 * row : OOBF;               //            ... | r[k] in column n
         oRu[r] = (row < nr && c < m) ? 8 * (row * m + c) : OOBF;      // Ru(k=row, c) = r_u[k][c]
         w2run[r] = (row < nr) ? 2.0 * F.w_run[row] : 0.0;
         w2term[r] = (row < nr) ? 2.0 * F.w_term[row] : 0.0;
@@ -467,9 +471,27 @@ __device__ __forceinline__ void backward_fused_body(double *sh, const double *pc
     };
     (void)pm; (void)pmode; (void)bitA;
     ResTiles cur;
+    // CXX (RXC, one wave per trajectory; round 5): with ONE r_x for every step, l_xx = r_x' W r_x IS THE SAME MATRIX at every step
+    // below the terminal one (running weights) -- only l_x = r_x' W r moves.  The four dependent products of Lzz = Rz' W Rz become
+    //     Lzz~ = Cxx + 2 e_n v',      v(c) = sum_k r_x[k][c] 2 w_k r[k]
+    // ONE product: lane (c, q) adds up its four rows k = 4r + q on the VALU (p, four FMAs on the resident r_x W tile and a broadcast
+    // load of r), and the sum over q IS the contraction of a 16x16x4 product whose first operand is 2 e_n in every k --
+    // D(i, j) = sum_q 2 e_n(i) p(j, q) -- accumulated onto the resident tile Cxx.  Row n then carries 2 l_x and column n nothing:
+    // Lzz~ only ever enters V' = Qzz + K'G, which the step symmetrises ((V' + V'')/2, iLQR.cpp:610), and (Lzz~ + Lzz~')/2 = Lzz
+    // (element (n, n), the constant of the value function, is dropped by the sweep anyway).  The terminal step (V = Lzz under the
+    // terminal weights, :537-539) keeps the full product.  31.4 matrix instructions per step instead of 34.4, and a chain of four at
+    // the top of the step becomes one.  The accumulation order differs from the per-step form's: results agree to ~1e-15, not bit for bit.
+    constexpr bool CXX = KP_RXC_CXX && RXC && !PC;
+    d4 Cxx = {0.0, 0.0, 0.0, 0.0}, RxW = Cxx;
+    const double en2 = (c == n) ? 2.0 : 0.0;
+    (void)Cxx; (void)RxW; (void)en2;
     if constexpr (RXC) {                           // the one r_x of the task: in registers for the whole sweep
         __amdgpu_buffer_rsrc_t rRx = frsrc(F.rx_const, nr * n * 8);
         cur.Rx.x = fbld(rRx, oRx[0]); cur.Rx.y = fbld(rRx, oRx[1]); cur.Rx.z = fbld(rRx, oRx[2]); cur.Rx.w = fbld(rRx, oRx[3]);
+        if constexpr (CXX) {
+            RxW.x = cur.Rx.x * w2run[0]; RxW.y = cur.Rx.y * w2run[1]; RxW.z = cur.Rx.z * w2run[2]; RxW.w = cur.Rx.w * w2run[3];
+            Cxx = PR(cur.Rx, RxW, Cxx, ncr);
+        }
     }
     // UNI: lane offsets of the lane's own DoF list (kd * KpU entries into the slice), the position in the soffset operand
     const int KpU = F.kp_offsets[(size_t)bP * F.dof + 1] - E0;
@@ -651,10 +673,23 @@ __device__ __forceinline__ void backward_fused_body(double *sh, const double *pc
         Fu.x = lerp_nc(sv[4], dt, av[4]); Fu.y = lerp_nc(sv[5], dt, av[5]);
         Fu.z = lerp_nc(sv[6], dt, av[6]); Fu.w = lerp_nc(sv[7], dt, av[7]);
         // ---- a6: Lzz, l_uu, l_u from the residuals --------------------------------------------------------
+        if constexpr (CXX) {
+            if (term) {                                 // (compile-time false away from a sweep's first step)
+                d4 Rz;
+                Rz.x = bits_or(cur.Rx.x, bits_and(cur.R1.x, mask_n)); Rz.y = bits_or(cur.Rx.y, bits_and(cur.R1.y, mask_n));
+                Rz.z = bits_or(cur.Rx.z, bits_and(cur.R1.z, mask_n)); Rz.w = bits_or(cur.Rx.w, bits_and(cur.R1.w, mask_n));
+                Lzz = PR(Rz, Rz * W2, zero, ncr);
+            } else {
+                double p = RxW.x * cur.R1.x;
+                p = __builtin_fma(RxW.y, cur.R1.y, p); p = __builtin_fma(RxW.z, cur.R1.z, p); p = __builtin_fma(RxW.w, cur.R1.w, p);
+                Lzz = MFMA(en2, p, Cxx);
+            }
+        } else {
         d4 Rz;
         Rz.x = bits_or(cur.Rx.x, cur.R1.x); Rz.y = bits_or(cur.Rx.y, cur.R1.y);
         Rz.z = bits_or(cur.Rx.z, cur.R1.z); Rz.w = bits_or(cur.Rx.w, cur.R1.w);
         Lzz = PR(Rz, Rz * W2, zero, ncr);
+        }
         if constexpr (RU0) {
             LU = zero;
         } else {
@@ -1607,7 +1642,7 @@ __device__ __forceinline__ void fusedpc_producer(double *pcbuf, int *sflag, RecL
             tr.offs[r] = (row < n && c < n) ? 8 * ((c < F.dof ? 0 : n) + row) : BIGOFF;
             tr.offs[4 + r] = (row < n && c < m) ? 8 * (2 * n + row) : BIGOFF;
             oRx[r] = (row < nr && c < n) ? 8 * (row * n + c) : OOBF;
-            oR1[r] = (row < nr && c == n) ? 8 * row : OOBF;
+            oR1[r] = (row < nr && (c == n || (KP_RXC_CXX && RXC))) ? 8 * row : OOBF;      // (RXC: r[k] in every column, see CXX in backward_fused_body)
             oRu[r] = (row < nr && c < m) ? 8 * (row * m + c) : OOBF;
             wr[r] = (row < nr) ? 2.0 * F.w_run[row] : 0.0;
             wt[r] = (row < nr) ? 2.0 * F.w_term[row] : 0.0;
@@ -1637,9 +1672,16 @@ __device__ __forceinline__ void fusedpc_producer(double *pcbuf, int *sflag, RecL
         R1.x = fbld(rR, oR1[0]); R1.y = fbld(rR, oR1[1]); R1.z = fbld(rR, oR1[2]); R1.w = fbld(rR, oR1[3]);
         if constexpr (!RU0) { Ru.x = fbld(rU, oRu[0]); Ru.y = fbld(rU, oRu[1]); Ru.z = fbld(rU, oRu[2]); Ru.w = fbld(rU, oRu[3]); }
     };
+    // CXX: the constant block r_x' W r_x as a resident tile, Lzz~ = Cxx + 2 e_n (r_x' W r)' by ONE product (backward_fused_body)
+    constexpr bool CXX = KP_RXC_CXX && RXC;
+    d4 Cxx = zero, RxW = zero;
+    const double en2 = (c == n) ? 2.0 : 0.0;
+    const u64 mask_r1 = (c == n) ? ~0ull : 0ull;
+    (void)Cxx; (void)RxW; (void)en2; (void)mask_r1;
     if constexpr (RXC) {                           // the one r_x of the task: in registers for the whole sweep
         __amdgpu_buffer_rsrc_t rA = frsrc(F.rx_const, nr * n * 8);
         Rx.x = fbld(rA, oRx[0]); Rx.y = fbld(rA, oRx[1]); Rx.z = fbld(rA, oRx[2]); Rx.w = fbld(rA, oRx[3]);
+        if constexpr (CXX) { RxW = Rx * Wr; Cxx = PR(Rx, RxW, zero, ncr); }
     }
     if constexpr (RU0) {                           // [l_uu | l_u] = 0: both ring slots once (the consumer does not read them either)
         Ru = zero;
@@ -1661,13 +1703,24 @@ __device__ __forceinline__ void fusedpc_producer(double *pcbuf, int *sflag, RecL
     for (int r = 0; r < 4; r++) if (c == n && 4 * r + q == n) tr.sv[r] = 1.0;       // Fz(n,n) = 1
     d4 hFz = zero, hFu = zero, hLzz = zero, hLU = zero;            // HELPER: the tiles published last, for the side products of their step
     (void)hFz; (void)hFu; (void)hLzz; (void)hLU;
-    auto publish = [&](int t, const d4 &W2) {
+    auto publish = [&](int t, const d4 &W2, auto terminal) __attribute__((always_inline)) {
         const double dt = (double)(t - tr.s);
-        d4 Fz, Fu, Rz, Rur;
+        d4 Fz, Fu, Rz, Rur, Lzz;
         Fz.x = tr.value(0, dt); Fz.y = tr.value(1, dt); Fz.z = tr.value(2, dt); Fz.w = tr.value(3, dt);
         Fu.x = tr.value(4, dt); Fu.y = tr.value(5, dt); Fu.z = tr.value(6, dt); Fu.w = tr.value(7, dt);
-        Rz.x = bits_or(Rx.x, R1.x); Rz.y = bits_or(Rx.y, R1.y); Rz.z = bits_or(Rx.z, R1.z); Rz.w = bits_or(Rx.w, R1.w);
-        const d4 Lzz = PR(Rz, Rz * W2, zero, ncr);
+        if constexpr (CXX && !decltype(terminal)::value) {
+            double p = RxW.x * R1.x;
+            p = __builtin_fma(RxW.y, R1.y, p); p = __builtin_fma(RxW.z, R1.z, p); p = __builtin_fma(RxW.w, R1.w, p);
+            Lzz = MFMA(en2, p, Cxx);
+        } else {
+            if constexpr (CXX) {
+                Rz.x = bits_or(Rx.x, bits_and(R1.x, mask_r1)); Rz.y = bits_or(Rx.y, bits_and(R1.y, mask_r1));
+                Rz.z = bits_or(Rx.z, bits_and(R1.z, mask_r1)); Rz.w = bits_or(Rx.w, bits_and(R1.w, mask_r1));
+            } else {
+                Rz.x = bits_or(Rx.x, R1.x); Rz.y = bits_or(Rx.y, R1.y); Rz.z = bits_or(Rx.z, R1.z); Rz.w = bits_or(Rx.w, R1.w);
+            }
+            Lzz = PR(Rz, Rz * W2, zero, ncr);
+        }
         d4 LU = zero;
         if constexpr (!RU0) {
             Rur.x = bits_or(Ru.x, R1.x); Rur.y = bits_or(Ru.y, R1.y); Rur.z = bits_or(Ru.z, R1.z); Rur.w = bits_or(Ru.w, R1.w);
@@ -1685,7 +1738,7 @@ __device__ __forceinline__ void fusedpc_producer(double *pcbuf, int *sflag, RecL
     };
     load_res(T - 1);
     if (lane == 0) sflag[0] = 0;
-    publish(T - 1, Wt);                                   // terminal weights   (iLQR.cpp:537-539)
+    publish(T - 1, Wt, std::true_type{});                 // terminal weights   (iLQR.cpp:537-539)
     __syncthreads();
     if constexpr (HELPER) {
         constexpr int NCZ = (N + 1 + 3) / 4;
@@ -1718,7 +1771,7 @@ __device__ __forceinline__ void fusedpc_producer(double *pcbuf, int *sflag, RecL
             // (the prefetched x+ / x- are differenced BEHIND the publish, whose wait for the residual tiles has let them arrive)
             if constexpr (RAWP) tr.cross(rT, t - 1, F.eps2, F.rinv_2eps);
             else tr.cross(t - 1);
-            publish(t - 1, Wr);
+            publish(t - 1, Wr, std::false_type{});
             if constexpr (RAWP) { tr.settle(rT, F.eps2, F.rinv_2eps); tr.request(rP, F.kp_times); }
             else if constexpr (SLP) tr.request(rP, F.kp_times, 2 * strideB);
             else tr.request(rT, F.kp_times, strideB);
@@ -1737,13 +1790,13 @@ __device__ __forceinline__ void fusedpc_producer(double *pcbuf, int *sflag, RecL
 #if KP_PROD_SPLIT
         if constexpr (RAWP) { tr.settle(rT, F.eps2, F.rinv_2eps); tr.cross(rT, t - 1, F.eps2, F.rinv_2eps); }
         else tr.cross(t - 1);
-        publish(t - 1, Wr);
+        publish(t - 1, Wr, std::false_type{});
         if constexpr (RAWP) tr.request(rP, F.kp_times);
         else tr.request(rT, F.kp_times, strideB);
 #else
         if constexpr (RAWP) { tr.settle(rT, F.eps2, F.rinv_2eps); tr.advance(rT, rP, F.kp_times, t - 1, F.eps2, F.rinv_2eps); }
         else tr.advance(rT, F.kp_times, t - 1, strideB);
-        publish(t - 1, Wr);
+        publish(t - 1, Wr, std::false_type{});
 #endif
         if constexpr (TRIPLE) __syncthreads();             // the mid-step barrier of the consumer and the side wave
         __syncthreads();

@@ -70,12 +70,13 @@ def keypoints(method, dof, T, min_N, max_N=1, thresholds=None, iterative_error_t
 
 def run_acrobot(T=100, min_N=5, max_iter=5, min_iter=2, method="set_interval", torque_weight=-1.0):
     H = load_host()
-    hist = np.zeros(max_iter + 2); U = np.zeros(T); K0 = np.zeros(4); tm = np.zeros(4)
+    hist = np.zeros(max_iter + 2); U = np.zeros(T); K0 = np.zeros(4); tm = np.zeros(8)
     it = H.kpilqr_host_run_acrobot(T, min_N, max_iter, min_iter, method.encode(), float(torque_weight), _p(hist), len(hist), _p(U), _p(K0), _p(tm))
     if it < 0:
         raise RuntimeError(f"kpilqr_host_run_acrobot failed: {it}")
     return dict(iterations=it, cost_history=hist[:it + 1].copy(), U=U, K0=K0,
-                timings_ms=dict(derivs=tm[0], backward=tm[1], forward=tm[2], total=tm[3]))
+                timings_ms=dict(derivs=tm[0], backward=tm[1], forward=tm[2], total=tm[3]),
+                constant_jacobian_uploads=int(tm[4]), per_step_jacobian_uploads=int(tm[5]), last_backward_rxc=bool(tm[6]))
 
 
 def fd_kp_check(model, T, min_N, stagger, u):

@@ -74,6 +74,16 @@ bool AcrobotTranslator::ResidualJacobians(SimData *, double *r_x, double *r_u)
     return true;
 }
 
+bool AcrobotTranslator::ConstantResidualJacobians(double *r_x, double *r_u)
+{
+    if (!constant_residual_jacobians) return false;
+    for (int j = 0; j < 5; j++) {
+        for (int i = 0; i < 4; i++) r_x[j * 4 + i] = (j == i) ? 1.0 : 0.0;
+        r_u[j] = (j == 4) ? 1.0 : 0.0;
+    }
+    return true;
+}
+
 MatrixXd AcrobotTranslator::ReturnStateVector(SimData *d, const stateVectorList &)
 {
     MatrixXd x(4, 1);

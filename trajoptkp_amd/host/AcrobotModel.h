@@ -33,6 +33,9 @@ public:
     // r = [q, qdot, u] is linear: r_x = [I4; 0], r_u = e5 (used only when analytic_residual_jacobians is set;
     // off by default so that the plumbing run differences Residuals() exactly as the reference does)
     bool ResidualJacobians(SimData *d, double *r_x, double *r_u) override;
+    // ... and the same at every state: with `constant_residual_jacobians` the shim uploads them once
+    bool ConstantResidualJacobians(double *r_x, double *r_u) override;
+    bool constant_residual_jacobians = false;
     bool analytic_residual_jacobians = false;
     double torque_limit = 100.0;
 };

@@ -27,6 +27,12 @@ public:
     // reference does (src/Differentiator/Differentiator.cpp:464-663).  Tasks like reaching
     // (src/ModelTranslator/Reaching.cpp:43-54: r = [q - q*, qdot]) have constant selector Jacobians.
     virtual bool ResidualJacobians(SimData *d, double *r_x, double *r_u) { (void)d; (void)r_x; (void)r_u; return false; }
+    // A task whose residuals are AFFINE in the state and the controls has ONE residual Jacobian for every state and step
+    // (reaching: r = [q - q*, qdot], r_x = selector rows, r_u = 0, src/ModelTranslator/Reaching.cpp:43-54): fill r_x [nr][n],
+    // r_u [nr][m] (row-major) and return true.  The optimiser shims then upload the pair ONCE per context
+    // (kpilqr_upload_residual_jacobians_const) and skip Differentiator::ResidualDerivatives
+    // (src/Differentiator/Differentiator.cpp:464-663) altogether; the default (false) keeps the per-step path.
+    virtual bool ConstantResidualJacobians(double *r_x, double *r_u) { (void)r_x; (void)r_u; return false; }
     // index of state-vector position entry `state_index` in the simulator's velocity (tangent) vector -- what the
     // reference indexes vel_diff / dpos with (src/ModelTranslator/ModelTranslator.cpp:1707-1709)
     virtual int StateIndexToQposIndex(int state_index, const stateVectorList &sv) { (void)sv; return state_index; }

@@ -56,11 +56,14 @@ int kpilqr_host_run_acrobot(int T, int min_N, int max_iter, int min_iter, const 
     const std::string keypoint_method_full = spec;
     const bool unfused = spec.find("+unfused") != std::string::npos, fused = spec.find("+fused") != std::string::npos, analytic = spec.find("+analytic") != std::string::npos;
     const bool lowpass = spec.find("+low_pass") != std::string::npos, fir = spec.find("+FIR") != std::string::npos;
+    const bool constjac = spec.find("+constjac") != std::string::npos;
     if (spec.find('+') != std::string::npos) spec = spec.substr(0, spec.find('+'));
     keypoint_method_name = spec.empty() ? nullptr : spec.c_str();
     auto sim = std::make_shared<AcrobotSimulator>(0.01, 8);
     auto mt = std::make_shared<AcrobotTranslator>(sim);
     mt->analytic_residual_jacobians = analytic;
+    // "+constjac": the task declares its residual Jacobians constant (ModelTranslator::ConstantResidualJacobians): uploaded once
+    mt->constant_residual_jacobians = constjac;
     mt->min_N = min_N;
     if (torque_weight >= 0) { mt->residual_list[4].weight = torque_weight; mt->residual_list[4].weight_terminal = torque_weight; }
     if (keypoint_method_name) mt->keypoint_method = keypoint_method_name;
@@ -84,7 +87,11 @@ int kpilqr_host_run_acrobot(int T, int min_N, int max_iter, int min_iter, const 
     for (int i = 0; i < nh && i < cost_cap; i++) cost_history[i] = opt.cost_history[i];
     if (U_out) for (int t = 0; t < T; t++) U_out[t] = U[t](0);
     if (K0_out) for (int c = 0; c < 4; c++) K0_out[c] = opt.K[0](0, c);
-    if (timings_ms) { timings_ms[0] = opt.avg_time_get_derivs_ms; timings_ms[1] = opt.avg_time_backwards_pass_ms; timings_ms[2] = opt.avg_time_forwards_pass_ms; timings_ms[3] = opt.opt_time_ms; }
+    if (timings_ms) {         // [8]: four times, then how the residual Jacobians travelled and whether the last backward sweep kept them in registers
+        timings_ms[0] = opt.avg_time_get_derivs_ms; timings_ms[1] = opt.avg_time_backwards_pass_ms; timings_ms[2] = opt.avg_time_forwards_pass_ms; timings_ms[3] = opt.opt_time_ms;
+        timings_ms[4] = opt.constant_jacobian_uploads; timings_ms[5] = opt.per_step_jacobian_uploads;
+        timings_ms[6] = opt.LastLaunch(0).find(":rxc") != std::string::npos ? 1.0 : 0.0; timings_ms[7] = 0.0;
+    }
     return opt.num_iterations;
 }
 
@@ -109,7 +116,10 @@ int kpilqr_host_run_acrobot_batch2(int B, int T, int min_N, int max_iter, int mi
         auto sim = std::make_shared<AcrobotSimulator>(0.01, 8);
         auto mt = std::make_shared<AcrobotTranslator>(sim);
         mt->min_N = min_N;
-        if (method && *method) mt->keypoint_method = method;
+        std::string mspec = method ? method : "";
+        mt->constant_residual_jacobians = mspec.find("+constjac") != std::string::npos;
+        if (mspec.find('+') != std::string::npos) mspec = mspec.substr(0, mspec.find('+'));
+        if (!mspec.empty()) mt->keypoint_method = mspec;
         if (torque_weight >= 0) { mt->residual_list[4].weight = torque_weight; mt->residual_list[4].weight_terminal = torque_weight; }
         sim->main_data->qpos[0] = q0s[2 * b]; sim->main_data->qpos[1] = q0s[2 * b + 1];
         *sim->master_reset_data = *sim->main_data;

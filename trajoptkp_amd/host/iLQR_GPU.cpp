@@ -76,6 +76,9 @@ void iLQR_GPU::Resize(int new_num_dofs, int new_num_ctrl, int new_horizon)
     for (const residual &r : activeModelTranslator->residual_list) { w_run.push_back(r.weight); w_term.push_back(r.weight_terminal); }
     const MatrixXd lim = activeModelTranslator->ReturnControlLimits(activeModelTranslator->current_state_vector);
     ctrl_lim.assign(lim.data(), lim.data() + 2 * m);
+    // a task with ONE residual Jacobian (affine residuals): host_rx / host_ru hold the pair, uploaded once per context
+    const_jacobians = activeModelTranslator->ConstantResidualJacobians(host_rx, host_ru);
+    const_jacobians_resident = false;
     keypoint_generator->Resize(dof, m, T);
     while ((int)MuJoCo_helper->saved_systems_state_list.size() <= T) MuJoCo_helper->AppendSystemStateToEnd(MuJoCo_helper->main_data);
 }
@@ -218,8 +221,22 @@ void iLQR_GPU::GenerateDerivatives()
     // residuals and their Jacobians at every step (Optimiser::ComputeResidualDerivatives, :217-236)
     for (int t = 0; t <= T; t++)
         for (int i = 0; i < nr; i++) host_r[(size_t)t * nr + i] = residuals[t](i);
-    activeDifferentiator->ResidualDerivativesAll(host_rx, host_ru, T, eps);
-    rc = kpilqr_upload_residuals(ctx, host_r, host_rx, host_ru, w_run.data(), w_term.data());
+    if (const_jacobians) {
+        // Reaching.cpp:43-54 and every other task with affine residuals: no a5 at all -- the one pair goes up once per context
+        // (r_u = 0 as NULL: the sweeps then leave the control-residual products out), the residuals every linearisation
+        if (!const_jacobians_resident) {
+            bool ru_zero = true;
+            for (int i = 0; i < nr * num_ctrl; i++) ru_zero = ru_zero && host_ru[i] == 0.0;
+            if ((rc = kpilqr_upload_residual_jacobians_const(ctx, host_rx, ru_zero ? nullptr : host_ru))) fatal("kpilqr_upload_residual_jacobians_const", rc);
+            const_jacobians_resident = true;
+            constant_jacobian_uploads++;
+        }
+        rc = kpilqr_upload_residuals(ctx, host_r, nullptr, nullptr, w_run.data(), w_term.data());
+    } else {
+        activeDifferentiator->ResidualDerivativesAll(host_rx, host_ru, T, eps);
+        rc = kpilqr_upload_residuals(ctx, host_r, host_rx, host_ru, w_run.data(), w_term.data());
+        per_step_jacobian_uploads++;
+    }
     if (rc) fatal("kpilqr_upload_residuals", rc);
     if (!fused_active && (rc = kpilqr_cost_derivs(ctx))) fatal("kpilqr_cost_derivs", rc);
     double pct = 0.0;

@@ -33,6 +33,11 @@ public:
     bool host_differencing = false;
     void SetFused(bool on) { if (on != use_fused) { use_fused = on; recreate_ctx = true; Resize(dof, num_ctrl, horizon_length); } }
     std::string BackwardVariant() const { return ctx ? kpilqr_backward_variant(ctx) : ""; }
+    // what the last kernels were (kpilqr_last_launch: "...:rxc" = the constant residual Jacobian in registers)
+    std::string LastLaunch(int which) const { return ctx ? kpilqr_last_launch(ctx, which) : ""; }
+    // how the residual Jacobians reached the device: uploads of the ONE constant pair (a task that implements
+    // ModelTranslator::ConstantResidualJacobians: once per context) / linearisations that differenced and uploaded them per step
+    int constant_jacobian_uploads = 0, per_step_jacobian_uploads = 0;
 
     // STEP 3, the line search.  LINESEARCH_REFERENCE (default): every alpha is rolled out closed-loop through the
     // simulator, concurrently on the FD pool (one fd_data slot per worker), the arg-min is taken and accepted iff it
@@ -78,4 +83,5 @@ private:
     double *host_r = nullptr, *host_rx = nullptr, *host_ru = nullptr, *host_unom = nullptr, *host_K = nullptr, *host_k = nullptr;
     void free_pinned();
     bool fused_active = false, recreate_ctx = false;
+    bool const_jacobians = false, const_jacobians_resident = false;      // the task's r_x, r_u hold at every state / are on this context
 };

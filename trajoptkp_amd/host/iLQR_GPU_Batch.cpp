@@ -37,6 +37,8 @@ iLQR_GPU_Batch::iLQR_GPU_Batch(std::vector<Problem> problems, int horizon, int d
     auto pinned = [&](size_t count) { void *p = nullptr; if (kpilqr_host_alloc(ctx, std::max<size_t>(count, 1) * sizeof(double), &p)) fatal("kpilqr_host_alloc", -4); std::fill((double *)p, (double *)p + count, 0.0); return (double *)p; };
     host_r = pinned((size_t)B * (T + 1) * nr); host_rx = pinned((size_t)B * (T + 1) * nr * n); host_ru = pinned((size_t)B * (T + 1) * nr * m);
     host_unom = pinned((size_t)B * T * m); host_K = pinned((size_t)B * T * n * m); host_k = pinned((size_t)B * T * m);
+    const_rx.assign((size_t)nr * n, 0.0); const_ru.assign((size_t)nr * m, 0.0);
+    const_jacobians = P[0].model_translator->ConstantResidualJacobians(const_rx.data(), const_ru.data());     // (one task, B initial conditions)
     S.resize(B);
     lambda.assign(B, 0.1); cost_history.assign(B, {}); num_iterations.assign(B, 0);
     K.assign(B, std::vector<MatrixXd>(T, MatrixXd(m, n))); k.assign(B, std::vector<MatrixXd>(T, MatrixXd(m, 1)));
@@ -221,7 +223,7 @@ void iLQR_GPU_Batch::GenerateDerivatives(const std::vector<int> &who)
         else diff.DynamicsDerivativesPlanned(staging, b, s.kpgen->keypoints, eps);
         for (int t = 0; t <= T; t++)
             for (int i = 0; i < nr; i++) host_r[((size_t)b * (T + 1) + t) * nr + i] = s.residuals[t](i);
-        diff.ResidualDerivativesAll(host_rx + (size_t)b * (T + 1) * nr * n, host_ru + (size_t)b * (T + 1) * nr * m, T, eps);
+        if (!const_jacobians) diff.ResidualDerivativesAll(host_rx + (size_t)b * (T + 1) * nr * n, host_ru + (size_t)b * (T + 1) * nr * m, T, eps);
     }
     if ((rc = kpilqr_set_keypoints(ctx, offs.data(), times.data()))) fatal("kpilqr_set_keypoints", rc);
     if (kp_ordered) {
@@ -236,7 +238,17 @@ void iLQR_GPU_Batch::GenerateDerivatives(const std::vector<int> &who)
     }
     if ((rc = kpilqr_fd_difference(ctx))) fatal("kpilqr_fd_difference", rc);
     if (!fused_active && (rc = kpilqr_interpolate(ctx))) fatal("kpilqr_interpolate", rc);
-    if ((rc = kpilqr_upload_residuals(ctx, host_r, host_rx, host_ru, w_run.data(), w_term.data()))) fatal("kpilqr_upload_residuals", rc);
+    if (const_jacobians) {
+        // a task with ONE residual Jacobian (ModelTranslator::ConstantResidualJacobians; Reaching.cpp:43-54): the pair went into
+        // const_rx / const_ru when the optimiser was built and goes up once; only the residuals travel per linearisation
+        if (!const_jacobians_resident) {
+            bool ru_zero = true;
+            for (double v : const_ru) ru_zero = ru_zero && v == 0.0;
+            if ((rc = kpilqr_upload_residual_jacobians_const(ctx, const_rx.data(), ru_zero ? nullptr : const_ru.data()))) fatal("kpilqr_upload_residual_jacobians_const", rc);
+            const_jacobians_resident = true;
+        }
+        if ((rc = kpilqr_upload_residuals(ctx, host_r, nullptr, nullptr, w_run.data(), w_term.data()))) fatal("kpilqr_upload_residuals", rc);
+    } else if ((rc = kpilqr_upload_residuals(ctx, host_r, host_rx, host_ru, w_run.data(), w_term.data()))) fatal("kpilqr_upload_residuals", rc);
     if (!fused_active && (rc = kpilqr_cost_derivs(ctx))) fatal("kpilqr_cost_derivs", rc);
 }
 

@@ -70,5 +70,7 @@ private:
     char *kp_slab = nullptr;
     size_t kp_slab_bytes = 0;
     std::vector<int> kp_slab_offs;          // the batch CSR the slab's records were laid out for (empty: no valid slab)
+    bool const_jacobians = false, const_jacobians_resident = false;     // the task's ONE residual Jacobian pair: uploaded once
+    std::vector<double> const_rx, const_ru;
     double *host_r = nullptr, *host_rx = nullptr, *host_ru = nullptr, *host_unom = nullptr, *host_K = nullptr, *host_k = nullptr;
 };
