@@ -27,11 +27,38 @@
 
 #include <stddef.h>
 
+/* ---- Diagnostic environment switches ------------------------------------------------------------
+ * NOT part of the ABI: a caller never needs them, the defaults are what the library has measured to be fastest, and every
+ * form gives the same results (to the tolerances of the tests).  They exist so that tests can reach a kernel form the batch
+ * size would not select, and for same-box A/B timing; kpilqr_last_launch reports what actually ran.  All are read ONCE, in
+ * kpilqr_create (changing the environment afterwards has no effect on an existing context); unset or empty = default.
+ *
+ *   KPILQR_FUSED_WAVES      backward sweep of a FUSED context: 1 one wavefront per trajectory | 5 consumer / helper pair.
+ *                           Default: 5 while 2 x batch <= #SIMDs, else 1.  (Any other value = default.)
+ *   KPILQR_FUSED_FWD_WAVES  forward sweep of a FUSED context: 1 one wave | 2 state / cost+staging pair | 3 state / cost /
+ *                           staging triple | 4 state / cost pair for uniform key-point sets with 3 or 1 behind it for
+ *                           per-DoF lists.  Default: 4 while 2 x batch <= #SIMDs, else 1.
+ *   KPILQR_FWD_RAGGED_PAIR  1: per-DoF lists at 256 < batch <= 512 take form 2 instead of one wave behind form 4.
+ *   KPILQR_FUSED_RAW        0: a key-point ordered payload is differenced by k_fd_kp_difference in front of the backward
+ *                           sweep instead of inside it (default: inside, for uniform key-point sets).
+ *   KPILQR_FUSED_UNI        0: the general (per-DoF list) forms of the one-wave sweeps also for uniform key-point sets.
+ *   KPILQR_ROLE_SHIFT       wave pairs: block-index bit from which the two roles swap wave slots (default 9; 0 = every
+ *                           other block).  Placement probe; no effect on results.
+ *   KPILQR_TILED_UW         tiled backward sweep (n + 2 > 16): 1 u-wave form | 0 column-wave form (default by tile count).
+ *   KPILQR_TILED_A4 / _A6   tiled sweeps: 1 / 0 interpolation (a4) / cost derivatives (a6) inside the sweep (default:
+ *                           a4 outside; a6 inside at four tiles from ~100 trajectories).
+ *   KPILQR_TILED_FSC        two-tile forward sweep: 1 / 0 state / cost wave groups (default: on while 2 NT B <= #SIMDs).
+ *   KPILQR_TILED_NT_MIN     run the tiled kernels with at least this many tiles (test coverage of a tile count on a
+ *                           small state).
+ *   KPILQR_PIPE_COPY        kpilqr_iterate_streamed: bit 0 uploads / bit 1 downloads by copy kernels instead of SDMA
+ *                           (default 2).
+ * The host-side thread count of the FD pool is a constructor argument of the host classes, not an environment switch. */
+
 #ifdef __cplusplus
 extern "C" {
 #endif
 
-#define KPILQR_VERSION 400   /* 0.4.0 */
+#define KPILQR_VERSION 410   /* 0.4.1: same entry points and structs as 400; callers should check kpilqr_version() / 100 == 4 */
 
 typedef struct kpilqr_ctx kpilqr_ctx;
 
@@ -272,9 +299,13 @@ int  kpilqr_upload_residuals(kpilqr_ctx *ctx, const double *r, const double *r_x
  * context instead of T+1 copies per trajectory and iteration; on a KPILQR_FLAG_FUSED context with one wavefront per
  * trajectory (batch > #SIMDs / 4) and r_u = NULL the sweeps keep the matrix in registers and read no r_x from memory at all
  * (Panda reaching, T = 3000: 5.0 of the 8.1 MB a trajectory's backward sweep reads, 5.0 of 9.1 MB forward).  Every other
- * kernel family sees the same values through a broadcast copy made on demand; K, k, delta_J and the predicted costs are bit
- * for bit those of the same matrix given per step through kpilqr_upload_residuals, which (with r_x != NULL) also ends the
- * constant mode.  version >= 400. */
+ * kernel family sees the same values through a broadcast copy made on demand, and then K, k, delta_J and the predicted costs
+ * are bit for bit those of the same matrix given per step through kpilqr_upload_residuals (which, with r_x != NULL, also ends
+ * the constant mode).  The sweeps that keep the matrix in registers (kpilqr_last_launch: "...:rxc") also keep the constant
+ * block l_xx = r_x' W r_x as a resident tile and add l_x = r_x' W r to it with ONE matrix product per step instead of four
+ * (version >= 410): the same numbers in another accumulation order -- gains identical, k / delta_J / costs within ~1e-15
+ * relative of the per-step form (tests hold 1e-12).  A call that is rejected (bad argument, unpinned buffer) leaves the mode
+ * as it was.  version >= 400. */
 int  kpilqr_upload_residual_jacobians_const(kpilqr_ctx *ctx, const double *r_x, const double *r_u);
 /* ModelTranslator::CostDerivativesFromResiduals (src/ModelTranslator/ModelTranslator.cpp:552-583)
  * over the loop of Optimiser::ComputeCostDerivatives (src/Optimiser/Optimiser.cpp:202-211),

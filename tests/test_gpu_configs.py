@@ -246,11 +246,10 @@ def test_headline_dispatch_helper_pair_at_batch_320():
 
 
 def test_every_trajectory_of_a_distinct_seed_batch_matches_the_oracle():
-    """B = 256 (the consumer / helper pair, ":pairh:raw:uni:ru0") and, as legs that really are other kernels, the triple behind
-    the differencing kernel and the one-wave raw sweep forced on the same batch: K, k, predicted costs, delta_J and status of
-    EVERY trajectory against the oracle.  (The committed 1024 x 3000 run: profiles/r04_full_batch_parity.txt.)"""
+    """B = 256 (the consumer / helper pair, ":pairh:raw:uni:ru0") and, as a leg that really is another kernel, the one-wave raw
+    sweep forced on the same batch: K, k, predicted costs, delta_J and status of EVERY trajectory against the oracle.  (The committed 1024 x 3000 run: profiles/r04_full_batch_parity.txt.)"""
     s = _full_batch_parity(256, 1000)
     legs = s["legs"]
     assert s["checked"] == 256
     assert legs["A"]["backward"].endswith(":pairh:raw:uni:ru0") and legs["B"]["backward"].endswith(":pairh:kpc:uni:ru0")
-    assert legs["D"]["backward"].endswith(":triple:kpc:uni") and legs["E"]["backward"].endswith(":w1:raw:uni:ru0")
+    assert legs["E"]["backward"].endswith(":w1:raw:uni:ru0")

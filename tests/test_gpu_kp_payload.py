@@ -46,18 +46,16 @@ def _same(a, b, keys=("K", "k", "delta_J", "cost"), rtol=0.0):
             assert np.max(np.abs(u - v)) <= rtol * max(float(np.max(np.abs(v))), 1e-300), (key, float(np.max(np.abs(u - v))), float(np.max(np.abs(v))))
 
 
-@pytest.fixture(params=["one_wave", "auto", "pair", "triple"])
+@pytest.fixture(params=["one_wave", "auto", "auto_roles"])
 def waves(request, monkeypatch):
     """one_wave: the raw backward sweep; auto: small batches -> the consumer / helper pair, whose helper wave differences the
-    payload; pair: the producer / consumer pair (its producer wave differences); triple: behind the streaming differencing kernel."""
+    payload; auto_roles: the same with the two roles alternating with the block index."""
     if request.param == "one_wave":
         monkeypatch.setenv("KPILQR_FUSED_WAVES", "1")
         monkeypatch.setenv("KPILQR_FUSED_FWD_WAVES", "1")
-    elif request.param == "pair":
-        monkeypatch.setenv("KPILQR_FUSED_WAVES", "3")
+    elif request.param == "auto_roles":
         monkeypatch.setenv("KPILQR_ROLE_SHIFT", "0")
-    elif request.param == "triple":
-        monkeypatch.setenv("KPILQR_FUSED_WAVES", "4")
+        return "auto"
     return request.param
 
 
@@ -364,6 +362,33 @@ def test_constant_residual_jacobians_mode_switches():
     assert np.array_equal(K, ref["K"]) and int(st.sum()) == 0
 
 
+def test_rejected_streamed_call_leaves_the_constant_jacobian_mode_alone():
+    """Round-4 advisor: kpilqr_iterate_streamed used to leave the constant-Jacobian mode BEFORE the checks that can still reject
+    the call; after a call refused for an unpinned r_x the next sweep read an r_x buffer that never received the broadcast copy.
+    Now a rejected call changes nothing: the iteration behind it gives the constant mode's bytes."""
+    from trajoptkp_amd.engine import KpilqrError
+    p = synth.make_problem(task="panda_reaching", T=120, batch=4, min_N=5)
+    xp, xm, mode = synth.kp_ordered_payload(p)
+    for fused in (True, False):
+        with Engine(p["dof"], p["m"], p["T"], p["nr"], batch=4, fused=fused) as e:
+            synth.upload(e, p, kp_ordered=fused, rx_const=True)
+            if not fused:
+                e.fd_difference(); e.interpolate(); e.cost_derivs()
+            e.iterate(p["lam"], 100, orc.alphas(6))
+            K0, k0 = e.gains(); c0 = e.results()["cost_pred"].copy()
+            lb0 = e.last_launch("backward")
+            bad_rx = np.array(p["r_x"], copy=True)                     # ordinary (unpinned) host memory: ERR_ARG
+            lam = e.pinned(4); lam[:] = p["lam"]
+            with pytest.raises(KpilqrError):
+                e.iterate_streamed(r_x=bad_rx, lam=lam, nchunks=2)
+            if not fused:
+                e.cost_derivs()
+            e.iterate(p["lam"], 100, orc.alphas(6))
+            K1, k1 = e.gains(); c1 = e.results()["cost_pred"]
+            assert e.last_launch("backward") == lb0
+            assert np.array_equal(K1, K0) and np.array_equal(k1, k0) and np.array_equal(c1, c0)
+
+
 # ---- slope store (round 4): per-DoF lists walked on precomputed segment slopes ---------------------------------------------
 @pytest.mark.parametrize("payload", ["kp_ordered", "job_lists", "columns"])
 def test_per_dof_lists_walk_the_slope_store(payload, monkeypatch):
@@ -397,10 +422,9 @@ def test_per_dof_lists_walk_the_slope_store(payload, monkeypatch):
     trip = run({})                                              # B = 5: the consumer / helper pair, its helper on the slope store too
     assert ":pairh:" in trip["lb"] and trip["lb"].endswith(":slopes"), trip["lb"]
     assert ":triple:ragged" in trip["lf"], trip["lf"]          # forward: the uniform pair left at once, the triple behind it ran
-    trip4 = run({"KPILQR_FUSED_WAVES": "4"})                    # ... and the triple, whose producer divides at the crossings
-    assert ":triple:" in trip4["lb"] and "slopes" not in trip4["lb"]
-    # (the same products in the same order; the slopes are the same correctly rounded quotients either way)
-    assert all(np.array_equal(trip[key], trip4[key]) for key in ("K", "k", "delta_J"))
+    # (the helper on the slope store and the one-wave general form on it: the same slopes -- the correctly rounded quotients of
+    # KeyPointGenerator.cpp:898-905 -- in other wave organisations)
+    assert all(np.max(np.abs(trip[key] - one[key])) <= 1e-11 * np.max(np.abs(one[key])) for key in ("K", "k", "delta_J"))
     for b in range(B):
         o = pipeline.run_trajectory(p, b)
         assert relerr(one["K"][b], o["K"]) < 1e-9 and relerr(one["cost"][b], o["cost_pred"]) < 1e-9

@@ -14,8 +14,7 @@ Legs, all in the default environment except for the one switch named: the form e
   B <= 512        A  pairh:raw:uni:ru0 (consumer / helper pair, the helper wave differences)
                   B  KPILQR_FUSED_RAW=0 -> pairh:kpc:uni:ru0                               bit-identical to A
                   C  constant residual Jacobians -> pairh:raw:uni:ru0:rxc                  within 1e-12 of A
-  B <= 256 also   D  KPILQR_FUSED_WAVES=4 -> triple:kpc:uni (behind k_fd_kp_difference)    another kernel: 1e-9 to the oracle
-                  E  KPILQR_FUSED_WAVES=1 + KPILQR_FUSED_FWD_WAVES=1 -> w1:raw:uni:ru0     another kernel: 1e-9 to the oracle
+  B <= 256 also   E  KPILQR_FUSED_WAVES=1 + KPILQR_FUSED_FWD_WAVES=1 -> w1:raw:uni:ru0     another kernel: 1e-9 to the oracle
 Every leg: K, k, delta_J, predicted costs of the sampled trajectories within 1e-9 of the oracle, statuses equal."""
 import argparse
 import json
@@ -80,8 +79,7 @@ else:
             ("B", {"KPILQR_FUSED_RAW": "0"}, False, ":pairh:kpc:uni:ru0", "A"),
             ("C", {}, True, ":pairh:raw:uni:ru0:rxc", "A")]
     if 4 * B <= n_simd:
-        legs += [("D", {"KPILQR_FUSED_WAVES": "4"}, False, ":triple:kpc:uni", None),
-                 ("E", {"KPILQR_FUSED_WAVES": "1", "KPILQR_FUSED_FWD_WAVES": "1"}, False, ":w1:raw:uni:ru0", None)]
+        legs += [("E", {"KPILQR_FUSED_WAVES": "1", "KPILQR_FUSED_FWD_WAVES": "1"}, False, ":w1:raw:uni:ru0", None)]
 
 results, summary = {}, {"batch": B, "T": T, "checked": int(S), "n_simd": int(n_simd), "legs": {}}
 for name, env, rxc, want, same_as in legs:

@@ -53,6 +53,7 @@ class StreamIO(C.Structure):
                 ("status", C.c_void_p), ("fd_kp_slab", C.c_void_p), ("entries", C.c_int), ("kp_columns", C.c_void_p)]
 
 
+ABI_MAJOR = 4                  # KPILQR_VERSION / 100 of the include/kpilqr.h this binding mirrors
 FLAG_GENERIC_KERNELS = 1
 FLAG_TILED_KERNELS = 2
 FLAG_FUSED = 4
@@ -137,5 +138,10 @@ def load():
     L.kpilqr_last_launch.argtypes = [vp, C.c_int]; L.kpilqr_last_launch.restype = C.c_char_p
     for s in SYMBOLS:
         getattr(L, s)          # raises AttributeError if the .so lacks a declared symbol
+    # the structs above (FdkpLayout, StreamIO ...) are those of ABI major version ABI_MAJOR: a library of another major version
+    # would write past them or read them wrongly (round-4 advisor: kpilqr_fdkp_layout grew a field between 3.x and 4.0)
+    got = L.kpilqr_version()
+    if got // 100 != ABI_MAJOR:
+        raise RuntimeError(f"{LIB_PATH}: kpilqr_version() = {got}, this binding is written for {ABI_MAJOR}xx (include/kpilqr.h)")
     _lib = L
     return L

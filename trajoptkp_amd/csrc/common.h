@@ -184,7 +184,7 @@ struct Ctx {
     // Diagnostic switches, read from the environment ONCE by kpilqr_create; the launchers only
     // look here.  0 = let the library choose.
     struct Tuning {
-        int fused_bwd_waves = 0;   // KPILQR_FUSED_WAVES: 1 one wave, 2 control/state split, 3 producer/consumer pair
+        int fused_bwd_waves = 0;   // KPILQR_FUSED_WAVES: 1 one wave, 5 consumer / helper pair (include/kpilqr.h lists every switch)
         int fused_fwd_waves = 0;   // KPILQR_FUSED_FWD_WAVES: 1 | 2 | 3 | 4
         int fwd_ragged_pair = 0;   // KPILQR_FWD_RAGGED_PAIR: per-DoF lists at 256 < batch <= 512 on the state / cost+staging pair (A/B)
         int role_shift = 9;        // KPILQR_ROLE_SHIFT (wave-pair role placement probe)

@@ -66,16 +66,8 @@ typedef unsigned long long u64;
 #ifndef KP_FSC_SETS
 #define KP_FSC_SETS 4              // tile sets of the forward state / cost wave groups
 #endif
-#ifndef KP_PROD_SPLIT
-#define KP_PROD_SPLIT 1             // 0: the producer wave requests the next key-point column in front of its publish (round-3 A/B)
-#endif
 #ifndef KP_PROBE_BWD
 #define KP_PROBE_BWD 0
-#endif
-#ifndef KP_XSWAP
-#define KP_XSWAP 0                  // 1: the running inverse's two tiles alternate their roles instead of being rotated by copies; every step is then
-                                    // instantiated for both assignments -- built in round 4, parity-green, SLOWER (4.94 against 4.52 ms: twice the code,
-                                    // 166 AGPRs instead of 67), kept as a switch for the record
 #endif
 // The launchers (and with them the kernel instantiations) of this file compile as THREE translation units (Makefile: -DKP_FUSED_PART=1|2|3;
 // unset or 0: everything in one): 1 one wave per trajectory backward + the form choices, 2 the backward wave pairs / triple,
@@ -563,10 +555,6 @@ __device__ __forceinline__ void backward_fused_body(double *sh, const double *pc
     int pd_counter = 0, fail = 0;
     double dJ = 0.0;
     d4 Xinv = zero, Xprev = zero, Iu;            // running inverse of Quu + lambda I (KP_NS), the one before it, the identity of the u-block
-    // KP_XSWAP: the two tiles ALTERNATE their roles from step to step instead of being rotated by copies (kp_inverse_refresh_sw):
-    // xpar = 0: Xinv holds N_{t+1} and Xprev N_{t+2}; xpar = 1: the other way round.  Every step is instantiated for both.
-    int xpar = 0;
-    (void)xpar;
     bool haveX = false;
     Iu.x = (q == c && c < m) ? 1.0 : 0.0; Iu.y = (4 + q == c && c < m) ? 1.0 : 0.0;
     Iu.z = (8 + q == c && c < m) ? 1.0 : 0.0; Iu.w = (12 + q == c && c < m) ? 1.0 : 0.0;
@@ -600,11 +588,7 @@ __device__ __forceinline__ void backward_fused_body(double *sh, const double *pc
 #endif
     // may_be_first: whether this call site can see the terminal step t = T-1 (only the first step of a sweep can: the call
     // sites inside the loops say no, and the selects of the terminal value function and weights leave the hot path)
-    auto step_sw = [&](int t, auto may_be_first, auto sw_tag) __attribute__((always_inline)) -> bool {
-        constexpr bool SW = decltype(sw_tag)::value;
-        d4 &Ncur = SW ? Xprev : Xinv;                  // N_{t+1}
-        d4 &Nold = SW ? Xinv : Xprev;                  // N_{t+2} in, N_t out (KP_XSWAP)
-        (void)Ncur; (void)Nold;
+    auto step = [&](int t, auto may_be_first) __attribute__((always_inline)) -> bool {
 #ifdef KP_CYC
         const unsigned long long cyc_s0 = __builtin_readcyclecounter();
 #endif
@@ -774,11 +758,7 @@ __device__ __forceinline__ void backward_fused_body(double *sh, const double *pc
         int ns_steps = 0;
         // (segment-loop forms: the peeled step is the one right below a key-point -- known at compile time)
         constexpr bool KINK = KP_KINK4 && UNI && !PC && decltype(may_be_first)::value;
-#if KP_XSWAP
-        const bool refreshed = haveX && !check_pd && kp_inverse_refresh_sw<NCU, KINK>(Qr, Iu, Ncur, Nold, m, STATS ? &ns_steps : nullptr);     // NEGATED inverses
-#else
         const bool refreshed = haveX && !check_pd && kp_inverse_refresh_n<NCU, KINK, PC>(Qr, Iu, Xinv, Xprev, m, STATS ? &ns_steps : nullptr);    // Xinv, Xprev: NEGATED inverses
-#endif
         if constexpr (STATS) { if (refreshed) hcnt[ns_steps < 0 ? 0 : ns_steps > 3 ? 3 : ns_steps]++; }
 #else
         const bool refreshed = false;
@@ -794,7 +774,7 @@ __device__ __forceinline__ void backward_fused_body(double *sh, const double *pc
 #endif
         d4 Kp = zero;                                 // the gains -X
         if (refreshed) {
-            Kp = PS<NCU>(KP_XSWAP ? Nold : Xinv, Quz, zero);               // -(Quu + lambda I)^-1 Quz: the gains, with their sign
+            Kp = PS<NCU>(Xinv, Quz, zero);               // -(Quu + lambda I)^-1 Quz: the gains, with their sign
             done = true;
         }
         if (!done) {
@@ -901,18 +881,6 @@ __device__ __forceinline__ void backward_fused_body(double *sh, const double *pc
         cyc_e += __builtin_readcyclecounter() - cyc_s3;
 #endif
         return true;
-    };
-    // the step for the current roles of the two inverse tiles; the roles swap behind every step (after a factorisation both
-    // tiles hold the same inverse, so either assignment is right)
-    auto step = [&](int t, auto may_be_first) __attribute__((always_inline)) -> bool {
-#if KP_XSWAP
-        bool r;
-        if (xpar) r = step_sw(t, may_be_first, std::true_type{}); else r = step_sw(t, may_be_first, std::false_type{});
-        xpar ^= 1;
-        return r;
-#else
-        return step_sw(t, may_be_first, std::false_type{});
-#endif
     };
     if constexpr (UNI && !PC) {
         // (Tried: ONE loop over the steps with the crossing's arithmetic behind a uniform branch at the top of the step and its
@@ -1046,16 +1014,7 @@ k_backward_fused_excl(RecLayout L, FusedArgs F, int T, const double *__restrict_
 
 
 // ---------------------------------------------------------------------------------------------------------
-// Backward pass, TWO wavefronts per trajectory.  A lone wavefront cannot use a SIMD's FP64 pipe fully (it issues
-// a v_fma_f64 every 8 cycles, two co-resident waves every 4; dependent FP64 MFMAs cost 78-94 cycles, interleaved
-// ones 70): at one trajectory per SIMD the single-wave kernel leaves ~25 % on the table (B=2048 runs 1.28x
-// faster per trajectory than B=1024).  Here a trajectory's step is split by FUNCTION across two waves, so a
-// batch of #SIMDs trajectories puts two waves on every SIMD:
-//   wave U (control side): Tu = V'Fu, Quu = l_uu + Fu'Tu, LDL', the solve, K/k stores, G = (Quu + 2 lambda I)K';
-//                          off the critical path: next step's B columns (a4) and [l_uu | l_u] = Ru'W[Ru | r] (a6)
-//   wave Z (state side):   Tz = V'Fz, Quz = [0 l_u] + Fu'Tz, Qzz = Lzz + Fz'Tz, V' = Qzz + X'G, (V+V')/2;
-//                          off the critical path: next step's A,B columns and Lzz = Rz'WRz
-// exchanging through LDS: V' (Z->U), Quz (Z->U), [0 l_u] (U->Z), X and G (U->Z); three s_barrier per step.
+// Column trackers of the helper wave (consumer / helper pair below): a4 walking DOWN in time, NV values per lane.
 template <int NV>
 __device__ __forceinline__ void load_vals(__amdgpu_buffer_rsrc_t rT, const int *offs, int tk, int T, int strideB, double *out)
 {
@@ -1064,16 +1023,6 @@ __device__ __forceinline__ void load_vals(__amdgpu_buffer_rsrc_t rT, const int *
     for (int r = 0; r < NV; r++) out[r] = fbld(rT, base + offs[r]);
 }
 
-#define F2_Q 0                                   // Quu + lambda I, row-major stride 16 (U private)
-#define F2_Z (F2_Q + 16 * 16)                    // Quz, [col][row] stride 17 (Z -> U)
-#define F2_S (F2_Z + 16 * 17)                    // transpose scratch, stride 17 (Z private)
-#define F2_V (F2_S + 16 * 17)                    // V' tile, D layout (Z -> U)
-#define F2_X (F2_V + 256)                        // X tile (U -> Z)
-#define F2_G (F2_X + 256)                        // G tile (U -> Z)
-#define F2_L (F2_G + 256)                        // [0 l_u] tile of the NEXT step (U -> Z)
-#define F2_SLOW (F2_L + 256)                     // slow-path work area (U private)
-#define F2_FLAG (F2_SLOW + 2 * 256 + 32)
-#define F2_TOTAL (F2_FLAG + 2)
 
 __device__ __forceinline__ d4 lds_tile4(const double *t, int lane)
 {
@@ -1107,24 +1056,7 @@ struct DownTracker {
 #pragma unroll
         for (int i = 0; i < NV; i++) av[i] = 0.0;
     }
-    __device__ __forceinline__ void advance(__amdgpu_buffer_rsrc_t rT, const int *kp_times, int t, int strideB)
-    {
-        if (t < s) {                                 // per lane: crossed the start of the current segment
-            const double den = (double)(s - nb);
-            const double rinv = kp_rcp(den);
-#pragma unroll
-            for (int i = 0; i < NV; i++) {
-                const double ev = sv[i];
-                sv[i] = pv[i];
-                av[i] = fdiv(ev - sv[i], den, rinv);
-            }
-            s = nb; idx--;
-            nb = nb2;
-            nb2 = (idx - 2 >= lo) ? kp_times[idx - 2] : -1;
-            load_vals<NV>(rT, offs, (idx - 1 >= lo) ? idx - 1 - E0 : -1, NE, strideB, pv);
-        }
-    }
-    // advance() in two halves (producer wave of the pair / triple): the arithmetic of a crossing, and -- behind the wave's wait for
+    // a crossing in two halves: its arithmetic, and -- behind the wave's wait for
     // its residual tiles -- the request of the next column (a wait placed behind the divergent branch is conservative and would
     // sit out requests issued in front of it)
     bool need = false;
@@ -1272,25 +1204,6 @@ struct DownTrackerRaw {
             fresh = false;
         }
     }
-    __device__ __forceinline__ void advance(__amdgpu_buffer_rsrc_t rT, __amdgpu_buffer_rsrc_t rP, const int *kp_times, int t, double eps2, double rinv2)
-    {
-        if (t < s) {                                 // per lane: crossed the start of the current segment
-            const double den = (double)(s - nb);
-            const double rinv = kp_rcp(den);
-            settle(rT, eps2, rinv2);                 // (consecutive key-points: not settled yet)
-#pragma unroll
-            for (int i = 0; i < NV; i++) {
-                const double ev = sv[i];
-                sv[i] = pv[i];
-                av[i] = fdiv(ev - sv[i], den, rinv);
-            }
-            s = nb; idx--;
-            nb = nb2;
-            nb2 = (idx - 2 >= lo) ? kp_times[idx - 2] : -1;
-            load_raw(rP, (idx - 1 >= lo) ? idx - 1 - E0 : -1, pv, pm, pmode);
-            fresh = idx - 1 >= lo;
-        }
-    }
     bool need = false;
     __device__ __forceinline__ void cross(__amdgpu_buffer_rsrc_t rT, int t, double eps2, double rinv2)
     {
@@ -1320,291 +1233,6 @@ struct DownTrackerRaw {
     __device__ __forceinline__ double value(int i, double dt) const { return lerp_nc(sv[i], dt, av[i]); }
 };
 
-// ---- wave U: control side ------------------------------------------------------------------------------------
-template <int N, int M>
-__device__ __forceinline__ void fused2_role_U(double *sh, RecLayout L, FusedArgs F, int T, double lam,
-                                              int pd_stride, double *__restrict__ Kout, double *__restrict__ kout,
-                                              double *__restrict__ delta_J, int *__restrict__ status)
-{
-    constexpr int NCZ = (N + 1 + 3) / 4;
-    constexpr int NCU = (M + 3) / 4;
-    constexpr int n = N, m = M;
-    const int lane = threadIdx.x & 63, c = lane & 15, q = lane >> 4;
-    const int b = blockIdx.x;
-    const int nr = F.nr, ncr = (nr + 3) >> 2;
-    const int strideB = 3 * L.n * 8;                               // bytes of one key-point entry of kpc: three columns
-    int *sflag = (int *)(sh + F2_FLAG);
-    DownTracker<4> tr;                           // B rows of column c (c < m), key-point list of DoF c
-    int oRu[4], oR1[4], oKst[4], okst[4];
-    double w2run[4], lam2d[4];
-    d4 Wt;
-    {
-        double wt[4];
-#pragma unroll
-        for (int r = 0; r < 4; r++) {
-            const int row = 4 * r + q;
-            tr.offs[r] = (row < n && c < m) ? 8 * (2 * n + row) : BIGOFF;
-            oRu[r] = (row < nr && c < m) ? 8 * (row * m + c) : OOBF;
-            oR1[r] = (row < nr && c == n) ? 8 * row : OOBF;
-            w2run[r] = (row < nr) ? 2.0 * F.w_run[row] : 0.0;
-            wt[r] = (row < nr) ? 2.0 * F.w_term[row] : 0.0;
-            oKst[r] = (row < m && c < n) ? 8 * (row + c * m) : OOBF;
-            okst[r] = (row < m && c == n) ? 8 * row : OOBF;
-            lam2d[r] = (row == c && row < m) ? 2.0 * lam : 0.0;
-        }
-        Wt.x = wt[0]; Wt.y = wt[1]; Wt.z = wt[2]; Wt.w = wt[3];
-    }
-    const d4 Wr = {w2run[0], w2run[1], w2run[2], w2run[3]};
-    const u64 mask_n = (c == n) ? ~0ull : 0ull, mask_u = (c < m) ? ~0ull : 0ull;
-    const bool lane_nn = (c == n) && (q == (n & 3));
-    const d4 zero = {0.0, 0.0, 0.0, 0.0};
-    const int E0 = F.kp_offsets[(size_t)b * F.dof], NE = F.kp_offsets[(size_t)(b + 1) * F.dof] - E0;      // this trajectory's key-point entries
-    __amdgpu_buffer_rsrc_t rT = frsrc(F.kpc + (size_t)E0 * 3 * L.n, NE * strideB);
-    const double *rb = F.r + (size_t)b * (T + 1) * nr;
-    const double *rub = F.r_u + (size_t)b * (T + 1) * nr * m;
-    d4 Ru, R1;
-    auto load_res = [&](int t) {
-        const bool ok = t >= 0;
-        __amdgpu_buffer_rsrc_t rA = frsrc(rub + (size_t)(ok ? t : 0) * nr * m, ok ? nr * m * 8 : 0);
-        __amdgpu_buffer_rsrc_t rR = frsrc(rb + (size_t)(ok ? t : 0) * nr, ok ? nr * 8 : 0);
-        Ru.x = fbld(rA, oRu[0]); Ru.y = fbld(rA, oRu[1]); Ru.z = fbld(rA, oRu[2]); Ru.w = fbld(rA, oRu[3]);
-        R1.x = fbld(rR, oR1[0]); R1.y = fbld(rR, oR1[1]); R1.z = fbld(rR, oR1[2]); R1.w = fbld(rR, oR1[3]);
-    };
-    auto cost_tile = [&](const d4 &W2) -> d4 {         // [l_uu | l_u] = Ru' W [Ru | r]
-        d4 Rur;
-        Rur.x = bits_or(Ru.x, R1.x); Rur.y = bits_or(Ru.y, R1.y); Rur.z = bits_or(Ru.z, R1.z); Rur.w = bits_or(Ru.w, R1.w);
-        return PR(Ru, Rur * W2, zero, ncr);
-    };
-    auto publish_luz = [&](const d4 &LU) {
-        d4 Luz;
-        Luz.x = bits_and(LU.x, mask_n); Luz.y = bits_and(LU.y, mask_n); Luz.z = bits_and(LU.z, mask_n); Luz.w = bits_and(LU.w, mask_n);
-        lds_store4(sh + F2_L, lane, Luz);
-    };
-    tr.init(rT, F.kp_offsets, F.kp_times, c < m, (size_t)b * F.dof + c, E0, NE, strideB);
-    d4 Fu;
-    auto lerp_Fu = [&](int t) {
-        const double dt = (double)(t - tr.s);
-        Fu.x = tr.value(0, dt); Fu.y = tr.value(1, dt); Fu.z = tr.value(2, dt); Fu.w = tr.value(3, dt);
-    };
-    // prologue: step T-1, terminal weights
-    load_res(T - 1);
-    lerp_Fu(T - 1);
-    d4 LU = cost_tile(Wt);
-    load_res(T - 2);
-    publish_luz(LU);
-    if (lane == 0) sflag[0] = 0;
-    __syncthreads();
-
-    int pd_counter = 0, fail = 0;
-    double dJ = 0.0;
-    for (int t = T - 1; t >= 0; t--) {
-        pd_counter++;
-        const bool check_pd = pd_counter >= pd_stride;
-        if (check_pd) pd_counter = 0;
-        // ---- phase 1: Tu, Quu, LDL' ---------------------------------------------------------------------------
-        const d4 V = lds_tile4(sh + F2_V, lane);
-        d4 Luu;
-        Luu.x = bits_and(LU.x, mask_u); Luu.y = bits_and(LU.y, mask_u); Luu.z = bits_and(LU.z, mask_u); Luu.w = bits_and(LU.w, mask_u);
-        const d4 Tu = PS<NCZ>(V, Fu, zero);
-        const d4 Quu = PS<NCZ>(Fu, Tu, Luu);                                 // :577
-        sh[F2_Q + q * 16 + c] = Quu.x + 0.5 * lam2d[0];
-        if (NCU > 1) sh[F2_Q + (4 + q) * 16 + c] = Quu.y + 0.5 * lam2d[1];
-        if (NCU > 2) sh[F2_Q + (8 + q) * 16 + c] = Quu.z + 0.5 * lam2d[2];
-        if (NCU > 3) sh[F2_Q + (12 + q) * 16 + c] = Quu.w + 0.5 * lam2d[3];
-        // (same-wave LDS accesses execute in order: no barrier between these stores and the reads below)
-        double Lm[M][M], rd[M];
-        const bool pos = kp_ldl_factor<M>([&](int i, int j) { return sh[F2_Q + i * 16 + j]; }, Lm, rd);
-        if (check_pd && !pos && lane == 0) sflag[0] = t + 1;                 // CheckMatrixPD   :587-595
-        __syncthreads();
-        if (sflag[0]) { fail = sflag[0]; break; }
-        // ---- phase 2: solve, K/k, G ---------------------------------------------------------------------------
-        double x[M];
-        if (pos) {
-#pragma unroll
-            for (int i = 0; i < M; i++) x[i] = sh[F2_Z + c * 17 + i];
-            kp_ldl_solve<M>(Lm, rd, x);
-        } else {
-            // indefinite on an unchecked step: Eigen's pivoted LDLT + explicit inverse (iLQR.cpp:597-604)
-            double *wa = sh + F2_SLOW, *wx = wa + 256, *wt = wx + 256;
-            int *trp = (int *)(wt + 16);
-            if (lane == 0) kp_slow_ldlt_inverse(L.m, sh + F2_Q, 16, wa, wx, wt, trp);
-            __builtin_amdgcn_wave_barrier();
-#pragma unroll
-            for (int i = 0; i < M; i++) {
-                double sacc = 0.0;
-#pragma unroll
-                for (int p = 0; p < M; p++) sacc += (-wx[i + p * m]) * sh[F2_Z + c * 17 + p];
-                x[i] = -sacc;
-            }
-        }
-        d4 Xp = zero;
-        {
-            double xr[4] = {0.0, 0.0, 0.0, 0.0};
-#pragma unroll
-            for (int i = 0; i < M; i++)
-                if (q == (i & 3)) xr[i >> 2] = x[i];
-            Xp.x = xr[0]; Xp.y = xr[1]; Xp.z = xr[2]; Xp.w = xr[3];
-        }
-        const d4 Kp = -Xp;
-        {
-            __amdgpu_buffer_rsrc_t rK = frsrc(Kout + ((size_t)b * T + t) * m * n, m * n * 8);
-            __amdgpu_buffer_rsrc_t rk = frsrc(kout + ((size_t)b * T + t) * m, m * 8);
-            const double kv[4] = {Kp.x, Kp.y, Kp.z, Kp.w};
-#pragma unroll
-            for (int r = 0; r < NCU; r++) {
-                __builtin_amdgcn_raw_buffer_store_b64(__builtin_bit_cast(u32x2f, kv[r]), rK, oKst[r], 0, 0);
-                __builtin_amdgcn_raw_buffer_store_b64(__builtin_bit_cast(u32x2f, kv[r]), rk, okst[r], 0, 0);
-            }
-        }
-        {
-            double kk = 0.0;
-#pragma unroll
-            for (int i = 0; i < M; i++) kk += x[i] * x[i];
-            if (lane_nn) dJ -= lam * kk;                                      // :612-613
-        }
-        d4 Quu2 = Quu;
-        Quu2.x += lam2d[0]; Quu2.y += lam2d[1]; Quu2.z += lam2d[2]; Quu2.w += lam2d[3];
-        const d4 G = PS<NCU>(Quu2, Kp, zero);
-        lds_store4(sh + F2_X, lane, Xp);
-        lds_store4(sh + F2_G, lane, G);
-        __syncthreads();
-        // ---- phase 3 (off the critical path): next step's B columns and [l_uu | l_u] -----------------------------
-        if (t > 0) {
-            tr.advance(rT, F.kp_times, t - 1, strideB);
-            lerp_Fu(t - 1);
-            LU = cost_tile(Wr);
-            load_res(t - 2);
-            publish_luz(LU);
-        }
-        __syncthreads();
-    }
-    if (lane_nn) delta_J[b] = dJ;
-    if (lane == 0) status[b] = fail;
-}
-
-// ---- wave Z: state side ---------------------------------------------------------------------------------------
-template <int N, int M>
-__device__ __forceinline__ void fused2_role_Z(double *sh, RecLayout L, FusedArgs F, int T, int pd_stride)
-{
-    constexpr int NCZ = (N + 1 + 3) / 4;
-    constexpr int NCU = (M + 3) / 4;
-    constexpr int n = N, m = M;
-    const int lane = threadIdx.x & 63, c = lane & 15, q = lane >> 4;
-    const int b = blockIdx.x;
-    const int nr = F.nr, ncr = (nr + 3) >> 2;
-    const int strideB = 3 * L.n * 8;                               // bytes of one key-point entry of kpc: three columns
-    const int *sflag = (const int *)(sh + F2_FLAG);
-    DownTracker<8> tr;                           // A rows then B rows of column c
-    int oRx[4], oR1[4];
-    double w2run[4];
-    d4 Wt;
-    {
-        double wt[4];
-#pragma unroll
-        for (int r = 0; r < 4; r++) {
-            const int row = 4 * r + q;
-            tr.offs[r] = (row < n && c < n) ? 8 * ((c < F.dof ? 0 : n) + row) : BIGOFF;
-            tr.offs[4 + r] = (row < n && c < m) ? 8 * (2 * n + row) : BIGOFF;
-            oRx[r] = (row < nr && c < n) ? 8 * (row * n + c) : OOBF;
-            oR1[r] = (row < nr && c == n) ? 8 * row : OOBF;
-            w2run[r] = (row < nr) ? 2.0 * F.w_run[row] : 0.0;
-            wt[r] = (row < nr) ? 2.0 * F.w_term[row] : 0.0;
-        }
-        Wt.x = wt[0]; Wt.y = wt[1]; Wt.z = wt[2]; Wt.w = wt[3];
-    }
-    const d4 Wr = {w2run[0], w2run[1], w2run[2], w2run[3]};
-    const bool lane_nn = (c == n) && (q == (n & 3));
-    constexpr int REG_NN = n >> 2;
-    const d4 zero = {0.0, 0.0, 0.0, 0.0};
-    const int E0 = F.kp_offsets[(size_t)b * F.dof], NE = F.kp_offsets[(size_t)(b + 1) * F.dof] - E0;      // this trajectory's key-point entries
-    __amdgpu_buffer_rsrc_t rT = frsrc(F.kpc + (size_t)E0 * 3 * L.n, NE * strideB);
-    const double *rb = F.r + (size_t)b * (T + 1) * nr;
-    const double *rxb = F.r_x + (size_t)b * (T + 1) * nr * n;
-    d4 Rx, R1;
-    auto load_res = [&](int t) {
-        const bool ok = t >= 0;
-        __amdgpu_buffer_rsrc_t rA = frsrc(rxb + (size_t)(ok ? t : 0) * nr * n, ok ? nr * n * 8 : 0);
-        __amdgpu_buffer_rsrc_t rR = frsrc(rb + (size_t)(ok ? t : 0) * nr, ok ? nr * 8 : 0);
-        Rx.x = fbld(rA, oRx[0]); Rx.y = fbld(rA, oRx[1]); Rx.z = fbld(rA, oRx[2]); Rx.w = fbld(rA, oRx[3]);
-        R1.x = fbld(rR, oR1[0]); R1.y = fbld(rR, oR1[1]); R1.z = fbld(rR, oR1[2]); R1.w = fbld(rR, oR1[3]);
-    };
-    auto cost_tile = [&](const d4 &W2) -> d4 {         // Lzz = [l_xx l_x; l_x' *] = Rz' W Rz
-        d4 Rz;
-        Rz.x = bits_or(Rx.x, R1.x); Rz.y = bits_or(Rx.y, R1.y); Rz.z = bits_or(Rx.z, R1.z); Rz.w = bits_or(Rx.w, R1.w);
-        return PR(Rz, Rz * W2, zero, ncr);
-    };
-    const int kd = (c < F.dof) ? c : c - F.dof;
-    tr.init(rT, F.kp_offsets, F.kp_times, c < n, (size_t)b * F.dof + kd, E0, NE, strideB);
-#pragma unroll
-    for (int r = 0; r < 4; r++) if (c == n && 4 * r + q == n) tr.sv[r] = 1.0;       // Fz(n,n) = 1
-    d4 Fz, Fu;
-    auto lerp_F = [&](int t) {
-        const double dt = (double)(t - tr.s);
-        Fz.x = tr.value(0, dt); Fz.y = tr.value(1, dt); Fz.z = tr.value(2, dt); Fz.w = tr.value(3, dt);
-        Fu.x = tr.value(4, dt); Fu.y = tr.value(5, dt); Fu.z = tr.value(6, dt); Fu.w = tr.value(7, dt);
-    };
-    // prologue: step T-1, terminal weights; V' <- Lzz(T-1)   (iLQR.cpp:537-539)
-    load_res(T - 1);
-    lerp_F(T - 1);
-    d4 Lzz = cost_tile(Wt);
-    load_res(T - 2);
-    d4 V = Lzz;
-    lds_store4(sh + F2_V, lane, V);
-    __syncthreads();
-
-    int pd_counter = 0;
-    (void)pd_stride; (void)pd_counter;
-    for (int t = T - 1; t >= 0; t--) {
-        // ---- phase 1: Tz, Quz, Qzz --------------------------------------------------------------------------
-        const d4 Luz = lds_tile4(sh + F2_L, lane);
-        const d4 Tz = PS<NCZ>(V, Fz, zero);
-        const d4 Quz = PS<NCZ>(Fu, Tz, Luz);                                  // :572,579
-        sh[F2_Z + c * 17 + q] = Quz.x;
-        if (NCU > 1) sh[F2_Z + c * 17 + 4 + q] = Quz.y;
-        if (NCU > 2) sh[F2_Z + c * 17 + 8 + q] = Quz.z;
-        if (NCU > 3) sh[F2_Z + c * 17 + 12 + q] = Quz.w;
-        const d4 Qzz = PS<NCZ>(Fz, Tz, Lzz);                                  // :570,575
-        __syncthreads();
-        if (__builtin_amdgcn_readfirstlane(sflag[0])) break;
-        // ---- phase 2 (off the critical path): next step's A,B columns and Lzz -----------------------------------
-        if (t > 0) {
-            tr.advance(rT, F.kp_times, t - 1, strideB);
-            lerp_F(t - 1);
-            Lzz = cost_tile(Wr);
-            load_res(t - 2);
-        }
-        __syncthreads();
-        // ---- phase 3: V' = Qzz + X'G, (V+V')/2 ------------------------------------------------------------------
-        const d4 Xp = lds_tile4(sh + F2_X, lane), G = lds_tile4(sh + F2_G, lane);
-        const d4 acc = PS<NCU>(Xp, G, Qzz);                                   // :606-607
-        sh[F2_S + (q) * 17 + c] = acc.x;
-        sh[F2_S + (4 + q) * 17 + c] = acc.y;
-        sh[F2_S + (8 + q) * 17 + c] = acc.z;
-        sh[F2_S + (12 + q) * 17 + c] = acc.w;
-        V.x = 0.5 * (acc.x + sh[F2_S + c * 17 + q]);                          // :610
-        V.y = 0.5 * (acc.y + sh[F2_S + c * 17 + 4 + q]);
-        V.z = 0.5 * (acc.z + sh[F2_S + c * 17 + 8 + q]);
-        V.w = 0.5 * (acc.w + sh[F2_S + c * 17 + 12 + q]);
-        if (lane_nn) fset_reg<REG_NN>(V, 0.0);
-        lds_store4(sh + F2_V, lane, V);
-        __syncthreads();
-    }
-}
-
-template <int N, int M>
-__global__ void __launch_bounds__(128) __attribute__((amdgpu_waves_per_eu(2, 2)))
-k_backward_fused2(RecLayout L, FusedArgs F, int T, int role_shift, const double *__restrict__ lambda,
-                  int pd_stride, double *__restrict__ Kout, double *__restrict__ kout,
-                  double *__restrict__ delta_J, int *__restrict__ status)
-{
-    __shared__ __attribute__((aligned(16))) double sh[F2_TOTAL];
-    // The role is wave-uniform and the compiler must know it (readfirstlane): scalar branches, SGPR descriptors.
-    // Which wave plays which role can alternate with the block index (role_shift) to mix U and Z waves on a SIMD.
-    const bool isU = ((__builtin_amdgcn_readfirstlane(threadIdx.x >> 6) ^ (blockIdx.x >> role_shift)) & 1) == 0;
-    if (isU) fused2_role_U<N, M>(sh, L, F, T, lambda[blockIdx.x], pd_stride, Kout, kout, delta_J, status);
-    else     fused2_role_Z<N, M>(sh, L, F, T, pd_stride);
-}
-
 // ---------------------------------------------------------------------------------------------------------
 // Backward pass, PRODUCER / CONSUMER wave pair per trajectory.  Unlike the U/Z split above the dependency runs one
 // way only: the producer wave evaluates what does not depend on V' -- this step's A, B columns (a4) and the cost
@@ -1622,7 +1250,7 @@ k_backward_fused2(RecLayout L, FusedArgs F, int T, int role_shift, const double 
 template <int N, int M, bool TRIPLE = false, bool RAWP = false, bool HELPER = false, bool RU0 = false, bool RXC = false, bool SLP = false>
 __device__ __forceinline__ void fusedpc_producer(double *pcbuf, int *sflag, RecLayout L, FusedArgs F, int T, const double *sh = nullptr)
 {
-    static_assert(!HELPER || TRIPLE, "the helper keeps the triple's two barriers per step");
+    static_assert(HELPER && TRIPLE, "only the helper wave of the consumer / helper pair is left (two barriers per step)");
     static_assert(!SLP || (HELPER && !RAWP), "the slope store serves the helper on a differenced column store");
     static_assert(HELPER || (!RU0 && !RXC), "RU0 / RXC are the helper's instantiations");
     static_assert(!RXC || RU0, "RXC comes with RU0");
@@ -1663,11 +1291,10 @@ __device__ __forceinline__ void fusedpc_producer(double *pcbuf, int *sflag, RecL
     (void)pRx; (void)pR1; (void)pRu;
     auto load_res = [&](int t) {
         const bool ok = t >= 0;
-        const size_t tt = ok ? t : 0;
-        __amdgpu_buffer_rsrc_t rA = frsrc(HELPER ? pRx : rxb + tt * nr * n, ok ? nr * n * 8 : 0);
-        __amdgpu_buffer_rsrc_t rR = frsrc(HELPER ? pR1 : rb + tt * nr, ok ? nr * 8 : 0);
-        __amdgpu_buffer_rsrc_t rU = frsrc(HELPER ? pRu : rub + tt * nr * m, ok ? nr * m * 8 : 0);
-        if constexpr (HELPER) { if (t > 0) { pRx -= nr * n; pR1 -= nr; pRu -= nr * m; } }
+        __amdgpu_buffer_rsrc_t rA = frsrc(pRx, ok ? nr * n * 8 : 0);
+        __amdgpu_buffer_rsrc_t rR = frsrc(pR1, ok ? nr * 8 : 0);
+        __amdgpu_buffer_rsrc_t rU = frsrc(pRu, ok ? nr * m * 8 : 0);
+        if (t > 0) { pRx -= nr * n; pR1 -= nr; pRu -= nr * m; }
         if constexpr (!RXC) { Rx.x = fbld(rA, oRx[0]); Rx.y = fbld(rA, oRx[1]); Rx.z = fbld(rA, oRx[2]); Rx.w = fbld(rA, oRx[3]); }
         R1.x = fbld(rR, oR1[0]); R1.y = fbld(rR, oR1[1]); R1.z = fbld(rR, oR1[2]); R1.w = fbld(rR, oR1[3]);
         if constexpr (!RU0) { Ru.x = fbld(rU, oRu[0]); Ru.y = fbld(rU, oRu[1]); Ru.z = fbld(rU, oRu[2]); Ru.w = fbld(rU, oRu[3]); }
@@ -1728,11 +1355,11 @@ __device__ __forceinline__ void fusedpc_producer(double *pcbuf, int *sflag, RecL
         }
         load_res(t - 1);
         double *tb = pcbuf + (t & 1) * FPC_BUF;
-        if constexpr (!HELPER) lds_store4(tb, lane, Fz);  // (Fz is the side products' operand only)
+        // (Fz is the side products' operand only: it stays in this wave's registers)
         lds_store4(tb + 256, lane, Fu);
         // (Lzz: the consumer of the triple / helper pair reads it at the terminal step only, V = Lzz(T-1); the side products take it
         // from registers here)
-        if (!HELPER || t == T - 1) lds_store4(tb + 512, lane, Lzz);
+        if (t == T - 1) lds_store4(tb + 512, lane, Lzz);
         if constexpr (!RU0) lds_store4(tb + 768, lane, LU);
         if constexpr (HELPER) { hFz = Fz; hFu = Fu; hLzz = Lzz; hLU = LU; }
     };
@@ -1767,7 +1394,7 @@ __device__ __forceinline__ void fusedpc_producer(double *pcbuf, int *sflag, RecL
             side(t);
             __syncthreads();                               // mid-step: the consumer takes Quz, Qzz
             // the tiles of step t-1, while the consumer forms the gains and V' of step t (slot (t-1)&1 was last read at the top of step t+1)
-            // (the crossing's arithmetic in front of the wait for the residual tiles, its requests behind it: KP_PROD_SPLIT)
+            // (the crossing's arithmetic in front of the wait for the residual tiles, its requests behind it)
             // (the prefetched x+ / x- are differenced BEHIND the publish, whose wait for the residual tiles has let them arrive)
             if constexpr (RAWP) tr.cross(rT, t - 1, F.eps2, F.rinv_2eps);
             else tr.cross(t - 1);
@@ -1783,115 +1410,13 @@ __device__ __forceinline__ void fusedpc_producer(double *pcbuf, int *sflag, RecL
         __syncthreads();
         return;
     }
-    // (no `if (t > 0)` around the body: requests behind a condition make the waits that follow conservative; the last step,
-    // t = 0, has nothing left to produce and is the two barriers behind the loop)
-    bool stop = false;
-    for (int t = T - 1; t > 0; t--) {
-#if KP_PROD_SPLIT
-        if constexpr (RAWP) { tr.settle(rT, F.eps2, F.rinv_2eps); tr.cross(rT, t - 1, F.eps2, F.rinv_2eps); }
-        else tr.cross(t - 1);
-        publish(t - 1, Wr, std::false_type{});
-        if constexpr (RAWP) tr.request(rP, F.kp_times);
-        else tr.request(rT, F.kp_times, strideB);
-#else
-        if constexpr (RAWP) { tr.settle(rT, F.eps2, F.rinv_2eps); tr.advance(rT, rP, F.kp_times, t - 1, F.eps2, F.rinv_2eps); }
-        else tr.advance(rT, F.kp_times, t - 1, strideB);
-        publish(t - 1, Wr, std::false_type{});
-#endif
-        if constexpr (TRIPLE) __syncthreads();             // the mid-step barrier of the consumer and the side wave
-        __syncthreads();
-        if (__builtin_amdgcn_readfirstlane(sflag[0])) { stop = true; break; }      // (wave-uniform, see the helper's loop)
-    }
-    if (!stop) {
-        if constexpr (TRIPLE) __syncthreads();
-        __syncthreads();
-    }
-}
-
-// Third wave of the triple: everything of the step that hangs on V but not on the gains -- Tz = V Fz, Quz = Luz + Fu'Tz,
-// Qzz = Lzz + Fz'Tz (12 of the step's MFMAs) -- while the consumer runs Tu, Quu and the refresh of the inverse.  V comes
-// from the consumer through LDS at the end of the step before; Quz and Qzz go back at the mid-step barrier.  The consumer's
-// chain per step is then Tu | Quu | refresh | X | V' (20 MFMAs) with two barriers.
-template <int N, int M>
-__device__ __forceinline__ void fusedpc_side(const double *sh, double *pcbuf, int *sflag, int T)
-{
-    constexpr int NCZ = (N + 1 + 3) / 4;
-    constexpr int n = N;
-    constexpr int REG_NN = n >> 2;
-    const int lane = threadIdx.x & 63, c = lane & 15, q = lane >> 4;
-    const bool lane_nn = (c == n) && (q == (n & 3));
-    const u64 mask_n = (c == n) ? ~0ull : 0ull;
-    const d4 zero = {0.0, 0.0, 0.0, 0.0};
-    __syncthreads();                                   // the producer has published step T-1
-    for (int t = T - 1; t >= 0; t--) {
-        const double *tb = pcbuf + (t & 1) * FPC_BUF;
-        const d4 Fz = lds_tile4(tb, lane), Fu = lds_tile4(tb + 256, lane);
-        const d4 Lzz = lds_tile4(tb + 512, lane), LU = lds_tile4(tb + 768, lane);
-        d4 V = Lzz;                                    // V_xx = l_xx[T-1]   (iLQR.cpp:537-539)
-        if (t < T - 1) {                               // (V' + V'')/2 from the consumer's unsymmetrised image, as the consumer forms it
-            V.x = 0.5 * (sh[FLDS_V + (q) * FVS + c] + sh[FLDS_V + c * FVS + q]);
-            V.y = 0.5 * (sh[FLDS_V + (4 + q) * FVS + c] + sh[FLDS_V + c * FVS + 4 + q]);
-            V.z = 0.5 * (sh[FLDS_V + (8 + q) * FVS + c] + sh[FLDS_V + c * FVS + 8 + q]);
-            V.w = 0.5 * (sh[FLDS_V + (12 + q) * FVS + c] + sh[FLDS_V + c * FVS + 12 + q]);
-            if (lane_nn) fset_reg<REG_NN>(V, 0.0);
-        }
-        d4 Luz;
-        Luz.x = bits_and(LU.x, mask_n); Luz.y = bits_and(LU.y, mask_n); Luz.z = bits_and(LU.z, mask_n); Luz.w = bits_and(LU.w, mask_n);
-        const d4 Tz = PS<NCZ>(V, Fz, zero);
-        const d4 Quz = PS<NCZ>(Fu, Tz, Luz);
-        const d4 Qzz = PS<NCZ>(Fz, Tz, Lzz);
-        lds_store4(pcbuf + FPC_SIDE_QUZ, lane, Quz);
-        lds_store4(pcbuf + FPC_SIDE_QZZ, lane, Qzz);
-        __syncthreads();                               // mid-step: the consumer takes Quz, Qzz
-        __syncthreads();                               // end of step: V of step t-1 is there, the next ring slot is full
-        if (__builtin_amdgcn_readfirstlane(sflag[0])) break;
-    }
 }
 
 #define FPC_RING FLDS_TOTAL
 #define FPC_FLAG (FPC_RING + 2 * FPC_BUF + 2 * 256)
 #define FPC_TOTAL (FPC_FLAG + 2)
-// guard: -1 run, 1 run only when the device flag says the key-point set is uniform, 0 only when it is not (the raw producer is
-// launched for uniform sets; per-DoF lists go through k_fd_kp_difference and the plain producer, launched behind it)
-template <int N, int M, bool RAWP>
-__device__ __forceinline__ void backward_fusedpc_block(RecLayout L, FusedArgs F, int T, int role_shift, const double *__restrict__ lambda, int pd_stride, double *__restrict__ Kout, double *__restrict__ kout,
-                   double *__restrict__ delta_J, int *__restrict__ status)
-{
-    __shared__ __attribute__((aligned(16))) double sh[FPC_TOTAL];
-    const bool consumer = ((__builtin_amdgcn_readfirstlane(threadIdx.x >> 6) ^ (blockIdx.x >> role_shift)) & 1) == 0;
-    if (consumer)
-        backward_fused_body<N, M, true>(sh, sh + FPC_RING, (int *)(sh + FPC_FLAG), L, F, T, lambda, pd_stride, Kout, kout,
-                                        delta_J, status);
-    else
-        fusedpc_producer<N, M, false, RAWP>(sh + FPC_RING, (int *)(sh + FPC_FLAG), L, F, T);
-}
-template <int N, int M, bool RAWP>
-__global__ void __launch_bounds__(128) __attribute__((amdgpu_waves_per_eu(2, 2)))
-k_backward_fusedpc(RecLayout L, FusedArgs F, int T, int role_shift, const double *__restrict__ lambda,
-                   int pd_stride, double *__restrict__ Kout, double *__restrict__ kout,
-                   double *__restrict__ delta_J, int *__restrict__ status, const int *__restrict__ kp_uniform, int guard)
-{
-    if (guard >= 0 && (*kp_uniform != 0) != (guard != 0)) return;
-    backward_fusedpc_block<N, M, RAWP>(L, F, T, role_shift, lambda, pd_stride, Kout, kout, delta_J, status);
-}
-// Wave TRIPLE per trajectory (batch <= #CUs): consumer | side | producer, one SIMD each of one CU.
-template <int N, int M, bool RAWP>
-__global__ void __launch_bounds__(192) __attribute__((amdgpu_waves_per_eu(1, 1)))
-k_backward_fusedpc3(RecLayout L, FusedArgs F, int T, int role_shift, const double *__restrict__ lambda,
-                    int pd_stride, double *__restrict__ Kout, double *__restrict__ kout,
-                    double *__restrict__ delta_J, int *__restrict__ status, const int *__restrict__ kp_uniform, int guard)
-{
-    __shared__ __attribute__((aligned(16))) double sh[FPC_TOTAL];
-    if (guard >= 0 && (*kp_uniform != 0) != (guard != 0)) return;
-    const int role = (int)((__builtin_amdgcn_readfirstlane(threadIdx.x >> 6) + (blockIdx.x >> role_shift)) % 3);
-    if (role == 0)
-        backward_fused_body<N, M, true, false, true>(sh, sh + FPC_RING, (int *)(sh + FPC_FLAG), L, F, T, lambda, pd_stride, Kout, kout,
-                                                     delta_J, status);
-    else if (role == 1)
-        fusedpc_side<N, M>(sh, sh + FPC_RING, (int *)(sh + FPC_FLAG), T);
-    else
-        fusedpc_producer<N, M, true, RAWP>(sh + FPC_RING, (int *)(sh + FPC_FLAG), L, F, T);
-}
+// guard: -1 run, 1 run only when the device flag says the key-point set is uniform, 0 only when it is not (the raw helper is
+// launched for uniform sets; per-DoF lists go through k_fd_kp_difference and the plain / slope-store helper, launched behind it)
 // Consumer / helper pair (2 x batch <= #SIMDs: a SIMD each): the triple's consumer, and ONE wave for its side and producer roles
 template <int N, int M, bool RAWP, bool RU0, bool RXC, bool SLP = false>
 __global__ void __launch_bounds__(128) __attribute__((amdgpu_waves_per_eu(1, 1)))
@@ -1908,17 +1433,6 @@ k_backward_fusedph(RecLayout L, FusedArgs F, int T, int role_shift, const double
     else
         fusedpc_producer<N, M, true, RAWP, true, RU0, RXC, SLP>(sh + FPC_RING, (int *)(sh + FPC_FLAG), L, F, T, sh);
 }
-// at most one wave per SIMD: while 2 x batch <= #SIMDs every wave of every pair gets a SIMD (and its FP64 unit) to itself
-template <int N, int M, bool RAWP>
-__global__ void __launch_bounds__(128) __attribute__((amdgpu_waves_per_eu(1, 1)))
-k_backward_fusedpc_excl(RecLayout L, FusedArgs F, int T, int role_shift, const double *__restrict__ lambda,
-                        int pd_stride, double *__restrict__ Kout, double *__restrict__ kout,
-                        double *__restrict__ delta_J, int *__restrict__ status, const int *__restrict__ kp_uniform, int guard)
-{
-    if (guard >= 0 && (*kp_uniform != 0) != (guard != 0)) return;
-    backward_fusedpc_block<N, M, RAWP>(L, F, T, role_shift, lambda, pd_stride, Kout, kout, delta_J, status);
-}
-
 // ---------------------------------------------------------------------------------------------------------
 // Forward pass.  The column tracker walks UP in time; its tiles (row = A row, col = A column) are turned into
 // the Y operands (row = contraction index) through a padded LDS transpose, off the Z dependency chain.
@@ -2743,16 +2257,17 @@ static FusedArgs fused_args(const Ctx *c)
 }
 
 #if KP_PART(1)
-// Which wave organisation launch_backward_fused will pick: 1 one wave per trajectory, 2 control/state split, 3 producer /
-// consumer pair, 4 consumer / side / producer triple, 5 consumer / helper pair.  Forms 1, 3 and 5 have RAW instantiations.
-// While a trajectory can have two SIMDs (2 x batch <= #SIMDs) the consumer / helper pair runs it: the consumer's chain is the
-// triple's (Tu | Quu | refresh | gains | V'), the helper is the triple's side AND producer wave -- and it differences the payload,
-// which the triple left to a kernel in front of it.  Round 4, same box: 3.01 against 3.87 ms (pair) at 512 trajectories, 2.94 /
-// 2.85 / 2.78 against 3.05 / 3.01 / 2.89 ms (triple, + 0.18 / 0.09 / 0.01 ms differencing) at 256 / 128 / 1
-// (profiles/r04_helper_pair.txt).  KPILQR_FUSED_WAVES = 3 | 4 still select the pair and the triple.
+// Which wave organisation launch_backward_fused will pick: 1 one wave per trajectory, 5 the consumer / helper pair (both have RAW
+// instantiations).  While a trajectory can have two SIMDs (2 x batch <= #SIMDs) the pair runs it: the consumer's chain is
+// Tu | Quu | refresh | gains | V', the helper forms the side products Tz, Quz, Qzz, then a4 + a6 of the next step, and differences
+// the payload of uniform sets.  Beyond that two waves take turns on a SIMD and one wave per trajectory wins.
+// KPILQR_FUSED_WAVES = 1 | 5 forces a form (diagnostic, include/kpilqr.h).  Rounds 2-4 also had a control / state split (2), a
+// producer / consumer pair (3) and a consumer / side / producer triple (4): all measured slower than the helper pair at every
+// batch size (profiles/r04_helper_pair.txt) and were removed in round 5 (DESIGN_HISTORY.md keeps their numbers).
 int backward_fused_form(const Ctx *c)
 {
-    return c->tune.fused_bwd_waves ? c->tune.fused_bwd_waves : (2 * c->d.batch <= c->n_simd ? 5 : 1);
+    const int f = c->tune.fused_bwd_waves;
+    return (f == 1 || f == 5) ? f : (2 * c->d.batch <= c->n_simd ? 5 : 1);
 }
 
 // The wave organisation launch_forward_fused will pick: 1 one wave per trajectory, 2 state / cost + staging pair, 3 the state /
@@ -2779,7 +2294,7 @@ hipError_t launch_backward_fused(Ctx *c, int pd_stride, bool raw)
     // per trajectory wins (DESIGN.md sections 4.0, 4.4).  KPILQR_FUSED_WAVES forces a form: 1 = one wave, 2 = control/state split,
     // 3 = producer/consumer pair, 4 = the consumer / side / producer triple, 5 = the consumer / helper pair.
     const int form = backward_fused_form(c);
-    if (raw && form != 1 && form != 3 && form != 5) return hipErrorInvalidValue;
+    if (raw && form != 1 && form != 5) return hipErrorInvalidValue;
     c->last_bwd_form = form; c->last_bwd_raw = raw; c->last_bwd_ru0 = form == 1 && c->ru_zero;       // kpilqr_last_launch
     const bool rxc = form == 1 && c->ru_zero && c->rx_const_on;     // (the caller has materialised r_x for every other form)
     c->last_bwd_rxc = rxc;
@@ -2826,7 +2341,7 @@ hipError_t launch_backward_fused(Ctx *c, int pd_stride, bool raw)
 #endif
 
 #if KP_PART(2)
-// forms 2 ... 5 of the backward sweep (the wave pairs and the triple); launch_backward_fused has filled in kpilqr_last_launch's fields
+// form 5 of the backward sweep, the consumer / helper pair; launch_backward_fused has filled in kpilqr_last_launch's fields
 hipError_t launch_backward_fused_waves(Ctx *c, int pd_stride, bool raw, int form)
 {
     const int n = c->n, m = c->d.m;
@@ -2834,25 +2349,6 @@ hipError_t launch_backward_fused_waves(Ctx *c, int pd_stride, bool raw, int form
     const FusedArgs F = fused_args(c);
     const int role_shift = c->tune.role_shift;
     dim3 block2(128);
-    if (form == 2) {
-        if (n == 14 && m == 7) hipLaunchKernelGGL((k_backward_fused2<14, 7>), grid, block2, 0, c->stream, c->L, F, c->d.T, role_shift, c->lambda, pd_stride, c->K, c->k, c->delta_J, c->status);
-        else if (n == 4 && m == 1) hipLaunchKernelGGL((k_backward_fused2<4, 1>), grid, block2, 0, c->stream, c->L, F, c->d.T, role_shift, c->lambda, pd_stride, c->K, c->k, c->delta_J, c->status);
-        else return hipErrorInvalidValue;
-        return hipGetLastError();
-    }
-    // (the triple keeps the streaming differencing kernel in front of it: with the payload differenced in its producer wave the
-    // consumer waits for that wave -- 5.13 against 5.05 ms per iteration at B = 128, 4.81 against 4.64 at B = 1, also with the
-    // differencing moved off the crossing step)
-    if (form == 4) {
-        dim3 block3(192);
-#define KP_X(NN, MM) if (n == NN && m == MM) { hipLaunchKernelGGL((k_backward_fusedpc3<NN, MM, false>), grid, block3, 0, c->stream, c->L, F, c->d.T, role_shift, c->lambda, pd_stride, c->K, c->k, c->delta_J, c->status, c->kp_uniform, -1); return hipGetLastError(); }
-        KP_T1_SHAPES(KP_X)
-#undef KP_X
-        return hipErrorInvalidValue;
-    }
-    // raw (pair, 256 < batch <= 512): the producer wave differences the key-point ordered payload of UNIFORM sets itself (5.73
-    // against 6.03 ms per iteration at B = 512); per-DoF lists take k_fd_kp_difference and the plain producer -- all three
-    // launched, the device flag decides (as for one wave per trajectory)
     // form 5, consumer / helper pair: the raw launch sequence of the pair (the helper differences the payload of uniform sets)
     if (form == 5) {
         const bool hru0 = c->ru_zero, hrxc = c->ru_zero && c->rx_const_on;
@@ -2878,28 +2374,6 @@ hipError_t launch_backward_fused_waves(Ctx *c, int pd_stride, bool raw, int form
 #undef KP_X
 #undef LAUNCHPH
 #undef LAUNCHPH2
-        return hipErrorInvalidValue;
-    }
-    if (form == 3) {
-        const bool pexcl = 2 * c->d.batch <= c->n_simd;
-#define LAUNCHPC(NN, MM, RW, GUARD)                                                                                   \
-        do {                                                                                                          \
-            if (pexcl) hipLaunchKernelGGL((k_backward_fusedpc_excl<NN, MM, RW>), grid, block2, 0, c->stream, c->L, F, c->d.T, role_shift, c->lambda, pd_stride, c->K, c->k, c->delta_J, c->status, c->kp_uniform, GUARD); \
-            else hipLaunchKernelGGL((k_backward_fusedpc<NN, MM, RW>), grid, block2, 0, c->stream, c->L, F, c->d.T, role_shift, c->lambda, pd_stride, c->K, c->k, c->delta_J, c->status, c->kp_uniform, GUARD); \
-        } while (0)
-#define KP_X(NN, MM)                                                                                   \
-        if (n == NN && m == MM) {                                                                      \
-            if (raw) {                                                                                 \
-                LAUNCHPC(NN, MM, true, 1);                                                             \
-                hipError_t e_ = launch_fd_kp_difference(c, true);                                      \
-                if (e_ != hipSuccess) return e_;                                                       \
-                LAUNCHPC(NN, MM, false, 0);                                                            \
-            } else LAUNCHPC(NN, MM, false, -1);                                                        \
-            return hipGetLastError();                                                                  \
-        }
-        KP_T1_SHAPES(KP_X)
-#undef KP_X
-#undef LAUNCHPC
         return hipErrorInvalidValue;
     }
     return hipErrorInvalidValue;

@@ -1225,8 +1225,6 @@ int kpilqr_iterate_streamed(kpilqr_ctx *c, const kpilqr_stream_io *io, int pd_ch
             return set_err(c, KPILQR_ERR_STATE, "streamed key-point ordered payload: the lists must be known to the host (kpilqr_set_keypoints, or kpilqr_get_keypoints after generating them)");
         if (io->entries != c->kp_total_host) return set_err(c, KPILQR_ERR_ARG, "fd_kp_slab / kp_columns: `entries` is not the number of key-point entries");
     }
-    if (io->r_u) c->ru_zero = false;
-    if (io->r_x) { c->rx_const_on = false; c->rx_buf_valid = true; }
     const void *hostp[] = {io->kp_columns, io->fd_kp_slab, io->fd_slab, io->r, io->r_x, io->r_u, io->u_nom, io->lambda, io->K, io->k, io->cost_pred, io->delta_J, io->status};
     for (const void *p : hostp) if (!is_pinned(p)) return set_err(c, KPILQR_ERR_ARG, "kpilqr_iterate_streamed: host buffers must be pinned (kpilqr_host_alloc)");
     if (c->fused || c->tiled_a4) { int rc = check_fused(c); if (rc) return rc; }
@@ -1318,6 +1316,11 @@ int kpilqr_iterate_streamed(kpilqr_ctx *c, const kpilqr_stream_io *io, int pd_ch
     if (c->fused && !slab && !kslab && !kcols && !c->kpc_valid && c->fd_kind == 1) {
         rc = difference_to_kpc(c); if (rc) return rc;
     }
+    // Per-step Jacobians in this call end the constant mode -- recorded only HERE, behind every check that can still reject the
+    // call (a rejected call must leave the context as it was: round-4 advisor; before, a call refused for an unpinned buffer had
+    // already left the constant mode and the next sweep read an r_x buffer that never received the broadcast copy)
+    if (io->r_u) c->ru_zero = false;
+    if (io->r_x) { c->rx_const_on = false; c->rx_buf_valid = true; }
     // constant residual Jacobians and a kernel family that streams r_x: the broadcast copy is made here, on the context (the
     // chunks' wave organisation is the whole batch's: make_view gives a chunk its share of the SIMDs)
     if (c->rx_const_on && (!c->fused || backward_reads_rx_buffer(c) || forward_reads_rx_buffer(c))) { rc = ensure_rx_buffer(c); if (rc) return rc; }

@@ -183,44 +183,6 @@ __device__ __forceinline__ bool kp_inverse_refresh_n(const d4 &Qr, const d4 &Iu,
     return true;
 }
 
-// The same refresh WITHOUT the rotation of the two loop-carried tiles (round 4).  kp_inverse_refresh_n ends in
-// `Nprev = Ninv; Ninv = Y` and starts by copying Ninv into the first guess: on the one-wave sweep's hot path that was 18
-// v_mov_b64 per step (ISA of round 4: N0 built in a copy of Ninv, Y moved to the join's register, the two rotations) -- a lone
-// wave pays ~9 cycles for each.  Here the first guess is formed IN the tile that holds the inverse of two steps ago (dead
-// afterwards), the series accumulates onto it, and the result stays there: the caller alternates the roles of its two tiles from
-// step to step instead of moving them.  Ncur: N_{t+1} (read only); Nold: in N_{t+2}, out N_t.  On `false` Nold is clobbered
-// (the caller factorises and re-seeds both tiles).
-template <int NCU, bool KINK = false>
-__device__ __forceinline__ bool kp_inverse_refresh_sw(const d4 &Qr, const d4 &Iu, const d4 &Ncur, d4 &Nold, int m, int *steps = nullptr)
-{
-    if (steps) *steps = 0;
-    Nold.x = __builtin_fma(2.0, Ncur.x, -Nold.x);
-    if (NCU > 1) Nold.y = __builtin_fma(2.0, Ncur.y, -Nold.y);
-    if (NCU > 2) Nold.z = __builtin_fma(2.0, Ncur.z, -Nold.z);
-    if (NCU > 3) Nold.w = __builtin_fma(2.0, Ncur.w, -Nold.w);
-    d4 R = kp_P<NCU>(Qr, Nold, Iu);                   // I + Q N0
-    d4 Y = kp_P<NCU>(Nold, R, Nold);
-    if constexpr (KINK) Y = kp_P<NCU>(Y, R, Nold);    // N0 (I + R + R^2 + R^3)
-    Nold = kp_P<NCU>(Y, R, Nold);                     // the last term of the series lands in the tile itself
-    double rmax = fabs(R.x);
-    if (NCU > 1) rmax = fmax(rmax, fabs(R.y));
-    if (NCU > 2) rmax = fmax(rmax, fabs(R.z));
-    if (NCU > 3) rmax = fmax(rmax, fabs(R.w));
-    const double e = (double)m * rmax;
-    if (__builtin_amdgcn_ballot_w64(!(e < (KINK ? 1.7e-4 : 2.0e-5))) != 0) {
-        if (__builtin_amdgcn_ballot_w64(!(e < 0.11)) != 0) { if (steps) *steps = -1; return false; }
-        const int iters = KINK ? ((__builtin_amdgcn_ballot_w64(e >= 1.3e-2) != 0) ? 2 : 1)
-                               : (__builtin_amdgcn_ballot_w64(e >= 1.3e-2) != 0) ? 3 : (__builtin_amdgcn_ballot_w64(e >= 1.7e-4) != 0) ? 2 : 1;
-        if (steps) *steps = iters;
-        R = kp_P<NCU>(Qr, Nold, Iu); Nold = kp_P<NCU>(Nold, R, Nold);
-        if (iters > 1) {
-            R = kp_P<NCU>(Qr, Nold, Iu); Nold = kp_P<NCU>(Nold, R, Nold);
-            if (iters > 2) { R = kp_P<NCU>(Qr, Nold, Iu); Nold = kp_P<NCU>(Nold, R, Nold); }
-        }
-    }
-    return true;
-}
-
 // Unpivoted LDL' of an m x m SPD matrix, done redundantly by every lane from a broadcast image (`qel(i,j)` returns
 // element (i,j)): L (unit lower, strictly lower part stored) and the reciprocals of D.  Returns false when a pivot is
 // not positive -- the callers then report the PD failure (checked steps) or take the pivoted slow path.

@@ -41,6 +41,7 @@ def load_host():
     H.kpilqr_host_run_acrobot_batch.argtypes = [C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_double, vp, C.c_int, vp, C.c_int, vp, vp, vp]
     H.kpilqr_host_run_acrobot_batch2.argtypes = [C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_double, vp, C.c_int, C.c_char_p, vp, C.c_int, vp, vp, vp]
     H.kpilqr_host_dof_importance.argtypes = [vp, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_double, vp, vp]
+    H.kpilqr_host_relocate_records.argtypes = [vp, vp, C.c_size_t, C.c_int, C.c_int, vp, vp, vp]
     H.kpilqr_host_model_info.argtypes = [C.c_char_p, vp, vp, vp]
     H.kpilqr_host_fd_kp_check.argtypes = [C.c_char_p, C.c_int, C.c_int, C.c_int, vp, vp]
     H.kpilqr_host_model_op.argtypes = [C.c_char_p, C.c_int, vp, vp, vp, vp, C.c_double, C.c_int, vp, vp]
@@ -133,6 +134,17 @@ def save_summary(filename, rows, timings):
     H = load_host()
     r = np.ascontiguousarray(rows, np.float64); t = np.ascontiguousarray(timings, np.float64)
     return H.kpilqr_host_save_summary(filename.encode(), r.shape[0], t.shape[2], _p(r), _p(t))
+
+
+def relocate_records(slab, stride, B, dof, old_offs, new_offs, regen, in_place=True):
+    """iLQR_GPU_Batch's record relocation on a byte slab (numpy uint8); returns the destination slab."""
+    H = load_host()
+    oo = np.ascontiguousarray(old_offs, np.int32); no = np.ascontiguousarray(new_offs, np.int32)
+    rg = np.ascontiguousarray(regen, np.uint8)
+    src = np.ascontiguousarray(slab, np.uint8)
+    dst = src if in_place else np.zeros(max(int(no[-1]), 1) * stride, np.uint8)
+    H.kpilqr_host_relocate_records(src.ctypes.data, None if in_place else dst.ctypes.data, stride, B, dof, _p(oo), _p(no), _p(rg))
+    return dst
 
 
 def run_acrobot_batch(q0s, T=100, min_N=5, max_iter=6, min_iter=2, torque_weight=-1.0, fused=False, method=None):

@@ -139,6 +139,15 @@ int kpilqr_host_run_acrobot_batch2(int B, int T, int min_N, int max_iter, int mi
     return 0;
 }
 
+// relocate_records of the batch shim (iLQR_GPU_Batch.cpp) on caller-made slabs: dst == NULL moves in place inside src
+int kpilqr_host_relocate_records(char *src, char *dst, size_t stride, int B, int dof, const int *old_offs, const int *new_offs, const char *regen)
+{
+    const std::vector<int> oo(old_offs, old_offs + (size_t)B * dof + 1), no(new_offs, new_offs + (size_t)B * dof + 1);
+    const std::vector<char> rg(regen, regen + B);
+    relocate_records(src, dst ? dst : src, stride, B, dof, oo, no, rg);
+    return 0;
+}
+
 // iLQR_SVR::LeastImportantDofs on gains K [T][n][m] (column-major m x n per step, the ABI's host layout): sums [dof];
 // remove [dof] receives the indices below the threshold, their number is returned.
 int kpilqr_host_dof_importance(const double *K, int dof, int m, int T, int sampling_k_interval, int eigen_vector_method,

@@ -54,6 +54,8 @@ void iLQR_GPU::Resize(int new_num_dofs, int new_num_ctrl, int new_horizon)
     if (ctx) { kpilqr_sync(ctx); free_pinned(); kpilqr_destroy(ctx); ctx = nullptr; }
     // the A filters act on the materialised sequence, so a filtering task runs the materialising pipeline
     kpilqr_dims d = {dof, m, T, nr, 1, num_parallel_rollouts, device, (use_fused && filteringMethod == "none") ? KPILQR_FLAG_FUSED : 0};
+    // the structs of include/kpilqr.h this file was compiled against are those of ONE major version of the library
+    if (kpilqr_version() / 100 != KPILQR_VERSION / 100) { std::fprintf(stderr, "iLQR_GPU: libkpilqr.so is version %d, built against %d\n", kpilqr_version(), KPILQR_VERSION); std::exit(1); }
     const int rc = kpilqr_create(&d, nullptr, &ctx);
     if (rc != KPILQR_OK) { last_error = kpilqr_strerror(nullptr); ctx = nullptr; std::fprintf(stderr, "iLQR_GPU: %s\n", last_error.c_str()); std::exit(1); }
     fused_active = std::string(kpilqr_backward_variant(ctx)).find("fused") != std::string::npos;

@@ -20,6 +20,7 @@ iLQR_GPU_Batch::iLQR_GPU_Batch(std::vector<Problem> problems, int horizon, int d
     dof = sv.dof; num_ctrl = sv.num_ctrl; nr = (int)P[0].model_translator->residual_list.size();
     const int n = 2 * dof, m = num_ctrl;
     kpilqr_dims d = {dof, m, T, nr, B, num_parallel_rollouts, device, fused ? KPILQR_FLAG_FUSED : 0};
+    if (kpilqr_version() / 100 != KPILQR_VERSION / 100) { std::fprintf(stderr, "iLQR_GPU_Batch: libkpilqr.so is version %d, built against %d\n", kpilqr_version(), KPILQR_VERSION); ctx = nullptr; return; }
     if (kpilqr_create(&d, nullptr, &ctx) != KPILQR_OK) { std::fprintf(stderr, "iLQR_GPU_Batch: %s\n", kpilqr_strerror(nullptr)); ctx = nullptr; return; }
     fused_active = std::string(kpilqr_backward_variant(ctx)).find("fused") != std::string::npos;
     for (int i = 1; i <= num_parallel_rollouts; i++) { const double l = (double)i / num_parallel_rollouts; alphas.push_back(l * l); }   // :466-470
@@ -138,8 +139,8 @@ double iLQR_GPU_Batch::ConfirmRollout(int b, int tid, double alpha, std::vector<
 // the new one wants them (new_offs): a trajectory's records are one contiguous range, and a range that is not regenerated
 // keeps its length.  src == dst (in place): ranges that move towards the front go first in ascending order, the others in
 // descending order, so that no range is overwritten before it has been moved (the CSR keeps the trajectories' order).
-static void relocate_records(const char *src, char *dst, size_t stride, int B, int dof, const std::vector<int> &old_offs,
-                             const std::vector<int> &new_offs, const std::vector<char> &regen)
+void relocate_records(const char *src, char *dst, size_t stride, int B, int dof, const std::vector<int> &old_offs,
+                      const std::vector<int> &new_offs, const std::vector<char> &regen)
 {
     auto move = [&](int b) {
         const size_t o = (size_t)old_offs[(size_t)b * dof], e = (size_t)old_offs[(size_t)(b + 1) * dof], w = (size_t)new_offs[(size_t)b * dof];

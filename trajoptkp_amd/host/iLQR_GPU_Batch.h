@@ -74,3 +74,9 @@ private:
     std::vector<double> const_rx, const_ru;
     double *host_r = nullptr, *host_rx = nullptr, *host_ru = nullptr, *host_unom = nullptr, *host_K = nullptr, *host_k = nullptr;
 };
+
+// Moves the key-point records of the trajectories that do NOT regenerate (regen[b] == 0) from their entry offsets in the old batch
+// CSR (old_offs [B*dof+1]) to those of the new one (new_offs), in place (src == dst) or into another slab; iLQR_GPU_Batch.cpp.
+// Exposed for the unit test of its move order (host_capi: kpilqr_host_relocate_records).
+void relocate_records(const char *src, char *dst, size_t stride, int B, int dof, const std::vector<int> &old_offs,
+                      const std::vector<int> &new_offs, const std::vector<char> &regen);
