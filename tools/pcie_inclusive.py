@@ -111,7 +111,8 @@ def measure(B=256, steps=5, T=3000, task="panda_reaching", chunk_list=(4, 8, 16)
                 for nc in chunk_list:
                     K[...] = 0
                     dt = timed(streamed, False, nc, False, columns)
-                    assert np.array_equal(K, K0) and np.array_equal(k, k0), "streamed K differs from the staged path (constant Jacobians)"
+                    # (the :rxc sweeps form l_x from the resident r_x' W r_x tile in another accumulation order: K in the same bits, k to 1e-12)
+                    assert np.array_equal(K, K0) and np.max(np.abs(k - k0)) <= 1e-12 * np.max(np.abs(k0)), "streamed K differs from the staged path (constant Jacobians)"
                     rows.append((label, f"chunks={nc} pipelined", dt, (col_bytes if columns else fd_bytes) + res_bytes[False]))
             e.iterate(lam); e.sync()
             t0 = time.perf_counter()
