@@ -184,10 +184,18 @@ __device__ __forceinline__ d4 ld_Ru(__amdgpu_buffer_rsrc_t rs, int m, int nr, in
 // only needs the wave's own Tz column), Quu is summed from per-wave partials Fu(w)'Tu(w), and the only tiles
 // exchanged through LDS are Fz/Fu (staged once per step), X, G and the unsymmetrised V' for the transpose:
 //   A  prefetched Fz(:,w), Fu(w): registers -> LDS                                        | barrier
-//   BC Tz(:,w), Tu(w), Quu partial, Quz(w), Qzz(:,w)          (straight-line, 4*NT^2*2+... MFMAs)  | barrier
+//   BC Tz(:,w), Tu(w), Quu partial, Quz(w), Qzz(i,w) for the OWNED tiles i     (straight-line)    | barrier
 //   D  Quu = l_uu + partials; LDL' (every wave); solve / K / k / G for column tile w       | barrier
-//   E  acc(i,w) = Qzz(i,w) + X_i' G_w -> LDS                                               | barrier
-//   F  V'(i,w) = (acc(i,w) + acc(w,i)')/2                (the barrier after the next A orders it)
+//   EF V'(i,w) = Qzz(i,w) + X_i' G_w for the owned tiles, written as tile (i,w) AND, transposed, as tile (w,i)
+//                                                          (the barrier after the next A orders it)
+// Ownership (round 5): Qzz, X'G = -X'(Quu + 2 lambda I)X and V' are symmetric, so every unordered pair {i, j} of tile indices is
+// formed ONCE -- wave w owns tiles ((w + d) mod NT, w), d = 0 .. NT/2 (for even NT the antipodal pairs d = NT/2 belong to the
+// waves w < NT/2; the others form theirs redundantly and drop it, so that all waves run the same straight-line code): 3 instead
+// of 4 tiles of Qzz / Lzz per wave at four tiles (164 -> 148 products per wave and step), and the step's symmetrisation
+// (V + V')/2 (iLQR.cpp:610) becomes: the owner's tile (i,w) as it is, its transpose as tile (w,i) -- exactly symmetric by
+// construction -- with the average of the reference formed on the diagonal tiles only.  The transposes are wave-local (a private
+// padded scratch tile), so the barrier between the old phases E and F is gone.  The off-diagonal tiles differ from the reference's
+// average by the rounding-level asymmetry of Qzz (the tests hold the kernel to the oracle at 1e-9 as before).
 // All source tiles are single-buffered: re-requested for step t-1 right behind their last use in step t.
 // A4: Fz(:,w) and Fu(w) are not read from the records of every step but interpolated in registers from the key-point
 // columns (tracker.h): lane (q,c) of wave w holds rows 16k+4r+q of COLUMN 16w+c of A -- one DoF list per lane -- and rows
@@ -220,7 +228,16 @@ k_backward_tiled_col(RecLayout L, CostSrc CS, KpSrc KP, int T, const double *__r
     double *bufG = bufX + NT * TILE;                 // NT
     double *bufQp = bufG + NT * TILE;                // NT: per-wave partials of Fu'Tu
     double *sQ = bufQp + NT * TILE + w * TILE;       // NT: this wave's image of Quu + lambda I
-    double *sRow = bufT;                             // slow-path work area (phase D: bufT is free between F and E)
+    double *sRow = bufT;                             // slow-path work area (phase D: bufT is free outside phase EF)
+    // tiles this wave owns: ((w + d) mod NT, w), d < ND (see the header); `red`: the antipodal tile of a wave w >= NT/2 is formed
+    // (same code in every wave) and dropped into a dummy area
+    constexpr int ND = NT / 2 + 1;
+    int ti[ND];
+#pragma unroll
+    for (int d = 0; d < ND; d++) ti[d] = (w + d) % NT;
+    const bool red_last = (NT % 2 == 0) && w >= NT / 2;
+    double *scr = bufT + w * TPAD;                   // private padded scratch tile for the wave-local transposes
+    double *dummy = bufT + NT * TPAD;                // two tiles nobody reads
     auto nchunk = [&](int kt) { const int rows = nz - 16 * kt; return rows >= 16 ? 4 : (rows + 3) / 4; };
     const int ncl = nchunk(NT - 1);
     const int ncw = (w < NT - 1) ? 4 : ncl;          // chunks of row tile w
@@ -235,14 +252,13 @@ k_backward_tiled_col(RecLayout L, CostSrc CS, KpSrc KP, int T, const double *__r
     d4 nn_keep;
     nn_keep.x = (lane_nn && reg_nn == 0) ? 0.0 : 1.0; nn_keep.y = (lane_nn && reg_nn == 1) ? 0.0 : 1.0;
     nn_keep.z = (lane_nn && reg_nn == 2) ? 0.0 : 1.0; nn_keep.w = (lane_nn && reg_nn == 3) ? 0.0 : 1.0;
-    const d4 nn_one = 1.0 - nn_keep;
     double lam2d[4];
 #pragma unroll
     for (int r = 0; r < 4; r++) lam2d[r] = (4 * r + q == c && c < m) ? 2.0 * lam : 0.0;
 
     // source tiles of the current step (column w): Fz(k,w), Lzz(k,w), Fu(w), Luz(w), Luu -- with A6 the cost tiles are
     // formed from residual tiles instead: pL[k] holds Rx_k (r_x rows, column tile k), pLuz the r column, pLuu Ru
-    d4 pF[NT], pL[NT], pFu, pLuz, pLuu;
+    d4 pF[NT], pL[ND], pFu, pLuz, pLuu;
     auto rsrc_of = [&](int t) { return __builtin_amdgcn_make_buffer_rsrc((void *)(R0 + (size_t)t * L.stride), 0, rec_bytes, 0x00020000); };
     // ---- a4 trackers (walking down in time) ---------------------------------------------------------------------------
     constexpr int NVA = A4 ? 4 * NT : 1;
@@ -302,36 +318,33 @@ k_backward_tiled_col(RecLayout L, CostSrc CS, KpSrc KP, int T, const double *__r
             __amdgpu_buffer_rsrc_t rR = __builtin_amdgcn_make_buffer_rsrc((void *)(rb + tt * nr), 0, ok ? nr * 8 : 0, 0x00020000);
             __amdgpu_buffer_rsrc_t rU = __builtin_amdgcn_make_buffer_rsrc((void *)(rub + tt * nr * m), 0, ok ? nr * m * 8 : 0, 0x00020000);
 #pragma unroll
-            for (int k = 0; k < NT; k++) pL[k] = ld_Rx(rX, n, nr, k, q, c);
+            for (int d = 0; d < ND; d++) pL[d] = ld_Rx(rX, n, nr, ti[d], q, c);        // r_x column tiles of the owned rows (d = 0: tile w itself)
             pLuz = ld_R1(rR, nr, cn, q, c);
             pLuu = ld_Ru(rU, m, nr, q, c);
         } else {
             __amdgpu_buffer_rsrc_t rs = ok ? rsrc_of(t) : __builtin_amdgcn_make_buffer_rsrc((void *)R0, 0, 0, 0x00020000);
 #pragma unroll
-            for (int k = 0; k < NT; k++) pL[k] = ld_Lzz(rs, S, k, w, q, c);
+            for (int d = 0; d < ND; d++) pL[d] = ld_Lzz(rs, S, ti[d], w, q, c);
             pLuz = ld_Luz(rs, S, w, q, c); pLuu = ld_Luu(rs, S, q, c);
         }
     };
-    // cost tiles of the step whose sources are in pL / pLuz / pLuu:  cL[k] = Lzz(k,w), cLuz = Luz(w), cLuu
-    d4 cL[NT], cLuz, cLuu;
+    // cost tiles of the step whose sources are in pL / pLuz / pLuu:  cL[d] = Lzz(ti[d],w), cLuz = Luz(w), cLuu
+    d4 cL[ND], cLuz, cLuu;
     auto form_cost = [&](const d4 &W2) {
         if (A6) {
-            d4 Rzw = pL[0];                            // column tile w of Rz (w is wave-uniform: selects, no indexing)
-#pragma unroll
-            for (int k = 0; k < NT; k++) if (k == w) Rzw = pL[k];
             const d4 R1w = (w == tn) ? pLuz : zero;
-            const d4 WRz = (Rzw + R1w) * W2;
+            const d4 WRz = (pL[0] + R1w) * W2;          // column tile w of W Rz
 #pragma unroll
-            for (int k = 0; k < NT; k++) {
-                d4 Rzk = pL[k];
-                if (k == tn) Rzk = Rzk + pLuz;
-                cL[k] = Pn(Rzk, WRz, zero, ncr);
+            for (int d = 0; d < ND; d++) {
+                d4 Rzk = pL[d];
+                if (ti[d] == tn) Rzk = Rzk + pLuz;
+                cL[d] = Pn(Rzk, WRz, zero, ncr);
             }
             cLuz = (w == tn) ? Pn(pLuu, pLuz * W2, zero, ncr) : zero;     // l_u in column n
             cLuu = (w == 0) ? Pn(pLuu, pLuu * W2, zero, ncr) : zero;
         } else {
 #pragma unroll
-            for (int k = 0; k < NT; k++) cL[k] = pL[k];
+            for (int d = 0; d < ND; d++) cL[d] = pL[d];
             cLuz = pLuz; cLuu = pLuu;
         }
     };
@@ -346,9 +359,27 @@ k_backward_tiled_col(RecLayout L, CostSrc CS, KpSrc KP, int T, const double *__r
         load_cost(T - 1, true);
     }
     // V' <- Lzz(T-1)   (iLQR.cpp:537-539), terminal weights (Optimiser.cpp:208-211)
+    // an owned tile of V' goes out as tile (i,w) and, transposed through the private scratch tile (same-wave LDS accesses are
+    // ordered: no barrier), as tile (w,i); the diagonal tile is averaged with its own transpose (iLQR.cpp:610)
+    auto publish_V = [&](int d, const d4 &acc, bool average) {
+        double *pw = scr + q * 17 + c;                               // element (4r+q, c) at (4r+q)*17 + c
+        pw[0] = acc.x; pw[4 * 17] = acc.y; pw[8 * 17] = acc.z; pw[12 * 17] = acc.w;
+        const double *pt = scr + c * 17 + q;                         // transposed: element (c, 4r+q); <= 2-way bank conflicts
+        d4 at;
+        at.x = pt[0]; at.y = pt[4]; at.z = pt[8]; at.w = pt[12];
+        if (d == 0) {
+            d4 na = average ? 0.5 * (acc + at) : acc;
+            if (average && w == tn) na = na * nn_keep;
+            lds_store(bufV + (w * NT + w) * TILE, lane, na);
+        } else {
+            const bool red = red_last && d == NT / 2;
+            lds_store(red ? dummy : bufV + (ti[d] * NT + w) * TILE, lane, acc);
+            lds_store(red ? dummy + TILE : bufV + (w * NT + ti[d]) * TILE, lane, at);
+        }
+    };
     form_cost(W2term);
 #pragma unroll
-    for (int k = 0; k < NT; k++) lds_store(bufV + (k * NT + w) * TILE, lane, cL[k]);
+    for (int d = 0; d < ND; d++) publish_V(d, cL[d], false);
 
     int pd_counter = 0, fail = 0;
     double dJ = 0.0;
@@ -356,6 +387,12 @@ k_backward_tiled_col(RecLayout L, CostSrc CS, KpSrc KP, int T, const double *__r
     bool haveX = false;
     Iu.x = (q == c && c < m) ? 1.0 : 0.0; Iu.y = (4 + q == c && c < m) ? 1.0 : 0.0;
     Iu.z = (8 + q == c && c < m) ? 1.0 : 0.0; Iu.w = (12 + q == c && c < m) ? 1.0 : 0.0;
+#ifdef KP_CYC_COL
+    long long cyc[12] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0}, cc0 = __builtin_readcyclecounter(), cc1;
+#define CYK(i) { cc1 = __builtin_readcyclecounter(); cyc[i] += cc1 - cc0; cc0 = cc1; }
+#else
+#define CYK(i)
+#endif
     for (int t = T - 1; t >= 0; t--) {
         pd_counter++;
         const bool check_pd = pd_counter >= pd_stride;
@@ -363,11 +400,10 @@ k_backward_tiled_col(RecLayout L, CostSrc CS, KpSrc KP, int T, const double *__r
         __amdgpu_buffer_rsrc_t rn = more ? rsrc_of(t - 1) : __builtin_amdgcn_make_buffer_rsrc((void *)R0, 0, 0, 0x00020000);
         // ---- A: stage Fz(:,w) (+ the homogeneous 1) and Fu(w) ----------------------------------------------
 #pragma unroll
-        for (int k = 0; k < NT; k++) {
-            d4 f = pF[k];
-            if (k == tn && w == tn) f = f + nn_one;                    // Fz(n,n) = 1
-            lds_store(bufF + (k * NT + w) * TILE, lane, f);
-        }
+        for (int k = 0; k < NT; k++) lds_store(bufF + (k * NT + w) * TILE, lane, pF[k]);
+        // Fz(n,n) = 1: the loaded element is a structural zero, ONE lane of the wave that owns column n overwrites it (round 5: the
+        // add-and-select over every tile of the column was 80 VALU instructions per step)
+        if (w == tn && lane_nn) bufF[(tn * NT + w) * TILE + reg_nn * 64 + lane] = 1.0;
         lds_store(bufFu + w * TILE, lane, pFu);
         __builtin_amdgcn_sched_barrier(0);
         if constexpr (A4) {
@@ -383,10 +419,12 @@ k_backward_tiled_col(RecLayout L, CostSrc CS, KpSrc KP, int T, const double *__r
             pFu = ld_Fu(rn, S, w, q, c);
         }
         __builtin_amdgcn_sched_barrier(0);
+        CYK(0)
         __syncthreads();
+        CYK(1)
         // ---- BC: Tz(:,w), Tu(w), Quu partial, Quz(w), Qzz(:,w) ------------------------------------------------
         form_cost(t == T - 1 ? W2term : W2run);        // cL, cLuz, cLuu of this step (A6: from the residual tiles)
-        d4 Fc[NT], Tz[NT], Qzz[NT];
+        d4 Fc[NT], Tz[NT], Qzz[ND];
         d4 Quzw = cLuz;                                                     // Quz(w): also kept in registers for the fast path
 #pragma unroll
         for (int k = 0; k < NT; k++) Fc[k] = lds_tile(bufF + (k * NT + w) * TILE, lane);
@@ -413,18 +451,18 @@ k_backward_tiled_col(RecLayout L, CostSrc CS, KpSrc KP, int T, const double *__r
             }
             lds_store(bufQp + w * TILE, lane, Pn(lds_tile(bufFu + w * TILE, lane), Tu, (A6 && w == 0) ? cLuu : zero, ncw));
 #pragma unroll
-            for (int i = 0; i < NT; i++) Qzz[i] = cL[i];
+            for (int d = 0; d < ND; d++) Qzz[d] = cL[d];
 #pragma unroll
             for (int k = 0; k < NT; k++) {
-                d4 Fk[NT];
+                d4 Fk[ND];
 #pragma unroll
-                for (int i = 0; i < NT; i++) Fk[i] = lds_tile(bufF + (k * NT + i) * TILE, lane);
+                for (int d = 0; d < ND; d++) Fk[d] = lds_tile(bufF + (k * NT + ti[d]) * TILE, lane);
                 const d4 Fuk = lds_tile(bufFu + k * TILE, lane);
 #pragma unroll
                 for (int r = 0; r < nck(k); r++) {
                     Quzw = MFMA(comp(Fuk, r), comp(Tz[k], r), Quzw);
 #pragma unroll
-                    for (int i = 0; i < NT; i++) Qzz[i] = MFMA(comp(Fk[i], r), comp(Tz[k], r), Qzz[i]);
+                    for (int d = 0; d < ND; d++) Qzz[d] = MFMA(comp(Fk[d], r), comp(Tz[k], r), Qzz[d]);
                 }
             }
             lds_store(bufQuz + w * TILE, lane, Quzw);
@@ -447,18 +485,20 @@ k_backward_tiled_col(RecLayout L, CostSrc CS, KpSrc KP, int T, const double *__r
         for (int k = 0; k < NT; k++) Quzw = Pk<NT>(k, lds_tile(bufFu + k * TILE, lane), Tz[k], Quzw, ncl);
         lds_store(bufQuz + w * TILE, lane, Quzw);
 #pragma unroll
-        for (int i = 0; i < NT; i++) {
-            d4 acc = cL[i];
+        for (int d = 0; d < ND; d++) {
+            d4 acc = cL[d];
 #pragma unroll
-            for (int k = 0; k < NT; k++) acc = Pk<NT>(k, lds_tile(bufF + (k * NT + i) * TILE, lane), Tz[k], acc, ncl);
-            Qzz[i] = acc;
+            for (int k = 0; k < NT; k++) acc = Pk<NT>(k, lds_tile(bufF + (k * NT + ti[d]) * TILE, lane), Tz[k], acc, ncl);
+            Qzz[d] = acc;
         }
         }
         const d4 Luu_t = cLuu;
         __builtin_amdgcn_sched_barrier(0);
         load_cost(t - 1, more);
         __builtin_amdgcn_sched_barrier(0);
+        CYK(2)
         __syncthreads();
+        CYK(3)
         // ---- D: Quu, LDL' (every wave: keeps the PD verdict block-uniform), solve / K / G for column tile w ----
         d4 Quu = A6 ? zero : Luu_t;
 #pragma unroll
@@ -553,26 +593,18 @@ k_backward_tiled_col(RecLayout L, CostSrc CS, KpSrc KP, int T, const double *__r
             Gw.x = -__builtin_fma(lam, X.x, Quzw.x); Gw.y = -__builtin_fma(lam, X.y, Quzw.y);
             Gw.z = -__builtin_fma(lam, X.z, Quzw.z); Gw.w = -__builtin_fma(lam, X.w, Quzw.w);
         }
+        CYK(4)
         __syncthreads();
-        // ---- E: acc(i,w) = Qzz(i,w) + X_i' G_w -> bufT -------------------------------------------------------
+        CYK(5)
+        // ---- EF: V'(i,w) = Qzz(i,w) + X_i' G_w for the owned tiles, out as tile (i,w) and transposed as tile (w,i) ----------------
 #pragma unroll
-        for (int i = 0; i < NT; i++) {
-            Qzz[i] = Pn(lds_tile(bufX + i * TILE, lane), Gw, Qzz[i], NCU);
-            double *pw = bufT + (i * NT + w) * TPAD + q * 17 + c;           // element (4r+q, c) at (4r+q)*17 + c
-            pw[0] = Qzz[i].x; pw[4 * 17] = Qzz[i].y; pw[8 * 17] = Qzz[i].z; pw[12 * 17] = Qzz[i].w;
-        }
-        __syncthreads();
-        // ---- F: V'(i,w) = (acc(i,w) + acc(w,i)')/2   (:610) -----------------------------------------------------
-#pragma unroll
-        for (int i = 0; i < NT; i++) {
-            const double *pt = bufT + (w * NT + i) * TPAD + c * 17 + q;     // (tile (w,i))': element (c, 4r+q); <= 2-way bank conflicts
-            d4 at;
-            at.x = pt[0]; at.y = pt[4]; at.z = pt[8]; at.w = pt[12];
-            d4 na = 0.5 * (Qzz[i] + at);
-            if (i == tn && w == tn) na = na * nn_keep;
-            lds_store(bufV + (i * NT + w) * TILE, lane, na);
-        }
+        for (int d = 0; d < ND; d++) publish_V(d, Pn(lds_tile(bufX + ti[d] * TILE, lane), Gw, Qzz[d], NCU), true);
+        CYK(8)
     }
+#ifdef KP_CYC_COL
+    if (b == 0 && lane == 0) printf("col wave %d: A %lld | wait1 %lld | BC %lld | wait2 %lld | D %lld | wait3 %lld | EF %lld  (cycles per step)\n", w,
+                                    cyc[0] / T, cyc[1] / T, cyc[2] / T, cyc[3] / T, cyc[4] / T, cyc[5] / T, cyc[8] / T);
+#endif
     dJ += __shfl_xor(dJ, 16);
     dJ += __shfl_xor(dJ, 32);
     if (w == tn && lane_nn) delta_J[b] = dJ;
