@@ -16,6 +16,9 @@
 #include <type_traits>
 #include "mfma_common.h"
 #include "tracker.h"
+#ifndef KP_NS_HOLD
+#define KP_NS_HOLD 8                // factorised steps behind a Newton-Schulz refresh that gave up before the fast path is tried again
+#endif
 #ifndef KP_FT_SETS
 #define KP_FT_SETS 2                // register sets of the two-tile forward sweep on materialised tiles (1: rounds 1-3, A/B builds)
 #endif
@@ -385,6 +388,7 @@ k_backward_tiled_col(RecLayout L, CostSrc CS, KpSrc KP, int T, const double *__r
     double dJ = 0.0;
     d4 Xinv = zero, Iu;                          // running inverse of Quu + lambda I, identity of the u-block
     bool haveX = false;
+    int ns_hold = 0;                             // factorised steps left before the fast path is seeded and tried again (phase D)
     Iu.x = (q == c && c < m) ? 1.0 : 0.0; Iu.y = (4 + q == c && c < m) ? 1.0 : 0.0;
     Iu.z = (8 + q == c && c < m) ? 1.0 : 0.0; Iu.w = (12 + q == c && c < m) ? 1.0 : 0.0;
 #ifdef KP_CYC_COL
@@ -511,11 +515,17 @@ k_backward_tiled_col(RecLayout L, CostSrc CS, KpSrc KP, int T, const double *__r
         // residual is too large to converge fast.
         d4 X = zero;
         bool done = false;
-        if (haveX && !check_pd && kp_inverse_refresh<NCU>(Qr, Iu, Xinv, m)) {
+        const bool tried = haveX && !check_pd;
+        if (tried && kp_inverse_refresh<NCU>(Qr, Iu, Xinv, m)) {
             X = Pn(Xinv, Quzw, zero, NCU);
             done = true;
         }
         if (!done) {
+            // The refresh gave up (residual beyond quadratic convergence in four steps): on data whose Quu jumps from step to step it
+            // will again -- for the next KP_NS_HOLD factorised steps the fast path is neither seeded (one LDL' solve less per lane)
+            // nor tried (round 5: ~750 of a step's 3 600 cycles in phase D on the independently drawn residual Jacobians; data on
+            // which the refresh converges never gets here).  Block-uniform like every decision of this phase.
+            if (tried) ns_hold = KP_NS_HOLD;
             lds_store(sQ, lane, Qr);                  // this wave's private image (same-wave LDS accesses are ordered)
             auto qel = [&](int i, int j) {
                 if (PAD && (i >= m || j >= m)) return (i == j) ? 1.0 : 0.0;
@@ -541,6 +551,10 @@ k_backward_tiled_col(RecLayout L, CostSrc CS, KpSrc KP, int T, const double *__r
             for (int i = 0; i < M; i++) x[i] = zt[(i >> 2) * 64 + c + 16 * (i & 3)];
             if (pos) {
                 kp_ldl_solve<M>(Lm, rd, x);
+                if (ns_hold > 0) {
+                    ns_hold--;
+                    haveX = false;
+                } else {
                 double y[M];                          // seed the fast path: column c of the inverse in lane c (c < m)
 #pragma unroll
                 for (int i = 0; i < M; i++) y[i] = (i == c) ? 1.0 : 0.0;
@@ -551,6 +565,7 @@ k_backward_tiled_col(RecLayout L, CostSrc CS, KpSrc KP, int T, const double *__r
                     if (q == (i & 3)) yr[i >> 2] = (c < m) ? y[i] : 0.0;
                 Xinv.x = yr[0]; Xinv.y = yr[1]; Xinv.z = yr[2]; Xinv.w = yr[3];
                 haveX = true;
+                }
             } else {
                 double y[M];
 #pragma unroll
@@ -647,7 +662,7 @@ bool backward_tiled_supported(int n, int m, int nt_min)
 //   B  column wave w: Tz(:,w) = V'Fz(:,w) from registers, Fz(:,w), Fu(w) -> LDS  ||  u-wave: Tu = V'Fu    | barrier
 //   C  column wave w: Quz(w), Qzz(:,w)               ||  u-wave: Quu, refresh / LDL' -> Xinv, flag       | barrier
 //   D  X(w) = Xinv Quz(w), K / k stores, G(w)                                                            | barrier
-//   E, F as above (the u-wave only keeps the barrier count)
+//   EF as above: the owned tiles of V' and their transposes, wave-local (the u-wave only keeps the barrier count)
 // The u-wave reads Fu from global memory itself (its slots of the per-step requests), so its chain -- the critical path of the
 // step -- starts at the first barrier and not behind the column waves' staging.
 // NCL = 4-row chunks of the last row tile that hold rows of z (compile-time here: a run-time count puts every chunk of the last
@@ -716,8 +731,9 @@ k_backward_tiled_uw(RecLayout L, int T, const double *__restrict__ rec, const do
                 for (int i = 0; i < NT; i++) Tq[i] = MFMA(comp(Vk[i], r), comp(Y[k], r), Tq[i]);
         }
     };
-    int pd_counter = 0, fail = 0;
+    int pd_counter = 0, fail = 0, ns_hold = 0;
     double dJ = 0.0;
+    (void)ns_hold;
 #ifdef KP_CYC_UW
     int hist[6] = {0, 0, 0, 0, 0, 0};
     long long cy[12] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0}, c0 = __builtin_readcyclecounter(), c1;
@@ -794,7 +810,12 @@ k_backward_tiled_uw(RecLayout L, int T, const double *__restrict__ rec, const do
                 hist[bin]++;
             }
 #endif
-            if (!(haveX && !check_pd && kp_inverse_refresh<NCU>(Qr, Iu, Xinv, m))) {
+            // (a refresh that gave up is not tried again for KP_NS_HOLD steps: see k_backward_tiled_col)
+            const bool tried = haveX && !check_pd && ns_hold == 0;
+            if (ns_hold > 0) ns_hold--;
+            const bool refreshed = tried && kp_inverse_refresh<NCU>(Qr, Iu, Xinv, m);
+            if (tried && !refreshed) ns_hold = KP_NS_HOLD;
+            if (!refreshed) {
                 lds_store(sQ, lane, Qr);
                 auto qel = [&](int i, int j) {
                     if (PAD && (i >= m || j >= m)) return (i == j) ? 1.0 : 0.0;
@@ -839,16 +860,22 @@ k_backward_tiled_uw(RecLayout L, int T, const double *__restrict__ rec, const do
             CYC(3)
             if (fail) break;
             if (check_pd) pd_counter = 0;
-            __syncthreads();
+            __syncthreads();                                       // (the column waves' X tiles are out)
             CYC(4)
-            __syncthreads();
-            CYC(6)
         }
     } else {
         // ============================================== column wave w ==================================================
         // sources, one step ahead: Fz(k,w), Fu(w) (consumed behind the first barrier) | Lzz(k,w), Luz(w) (joined at the end of C)
-        d4 pF[NT], pL[NT], pFu, pLuz;
-        int oF[NT][4], oL[NT][4], oFu[4], oLuz[4];
+        // tiles this wave owns (see k_backward_tiled_col): ((w + d) mod NT, w), d < ND; the antipodal tile of a wave w >= NT/2
+        // (even NT) is formed and dropped
+        constexpr int ND = NT / 2 + 1;
+        int ti[ND];
+#pragma unroll
+        for (int d = 0; d < ND; d++) ti[d] = (w + d) % NT;
+        const bool red_last = (NT % 2 == 0) && w >= NT / 2;
+        double *scr = bufT + w * TPAD, *dummy = bufT + NT * TPAD;
+        d4 pF[NT], pL[ND], pFu, pLuz;
+        int oF[NT][4], oL[ND][4], oFu[4], oLuz[4];
 #pragma unroll
         for (int r = 0; r < 4; r++) {
             const int rowu = 4 * r + q, col = 16 * w + c, rowb = 16 * w + 4 * r + q;
@@ -856,7 +883,11 @@ k_backward_tiled_uw(RecLayout L, int T, const double *__restrict__ rec, const do
             for (int k = 0; k < NT; k++) {
                 const int row = 16 * k + 4 * r + q;
                 oF[k][r] = (row < n && col < n) ? 8 * (S.off_A + col * n + row) : OOBT;
-                oL[k][r] = (row < n && col < n) ? 8 * (S.off_lxx + row * n + col)
+            }
+#pragma unroll
+            for (int d = 0; d < ND; d++) {
+                const int row = 16 * ti[d] + 4 * r + q;
+                oL[d][r] = (row < n && col < n) ? 8 * (S.off_lxx + row * n + col)
                          : (col == n && row < n) ? 8 * (S.off_lx + row) : (row == n && col < n) ? 8 * (S.off_lx + col) : OOBT;
             }
             oFu[r] = (rowb < n && c < m) ? 8 * (S.off_B + c * n + rowb) : OOBT;
@@ -869,16 +900,34 @@ k_backward_tiled_uw(RecLayout L, int T, const double *__restrict__ rec, const do
         };
         auto request_cost = [&](__amdgpu_buffer_rsrc_t rs) {
 #pragma unroll
-            for (int k = 0; k < NT; k++) pL[k] = ld4(rs, oL[k]);
+            for (int d = 0; d < ND; d++) pL[d] = ld4(rs, oL[d]);
             pLuz = ld4(rs, oLuz);
         };
         {
             __amdgpu_buffer_rsrc_t rs = rsrc_of(T - 1);
             request(rs); request_cost(rs);
         }
+        // an owned tile of V' goes out as tile (i,w) and, transposed through the private scratch tile (same-wave LDS accesses are
+        // ordered), as tile (w,i); the diagonal tile is averaged with its own transpose (iLQR.cpp:610)
+        auto publish_V = [&](int d, const d4 &acc, bool average) {
+            double *pw = scr + q * 17 + c;
+            pw[0] = acc.x; pw[4 * 17] = acc.y; pw[8 * 17] = acc.z; pw[12 * 17] = acc.w;
+            const double *pt = scr + c * 17 + q;
+            d4 at;
+            at.x = pt[0]; at.y = pt[4]; at.z = pt[8]; at.w = pt[12];
+            if (d == 0) {
+                d4 na = average ? 0.5 * (acc + at) : acc;
+                if (average && w == tn) na = na * nn_keep;
+                lds_store(bufV + (w * NT + w) * TILE, lane, na);
+            } else {
+                const bool red = red_last && d == NT / 2;
+                lds_store(red ? dummy : bufV + (ti[d] * NT + w) * TILE, lane, acc);
+                lds_store(red ? dummy + TILE : bufV + (w * NT + ti[d]) * TILE, lane, at);
+            }
+        };
         // V' <- Lzz(T-1)   (iLQR.cpp:537-539)
 #pragma unroll
-        for (int k = 0; k < NT; k++) lds_store(bufV + (k * NT + w) * TILE, lane, pL[k]);
+        for (int d = 0; d < ND; d++) publish_V(d, pL[d], false);
         char *pK = (char *)(Kout + ((size_t)b * T + (T - 1)) * m * n), *pk = (char *)(kout + ((size_t)b * T + (T - 1)) * m);
         for (int t = T - 1; t >= 0; t--) {
             pd_counter++;
@@ -908,25 +957,25 @@ k_backward_tiled_uw(RecLayout L, int T, const double *__restrict__ rec, const do
             __syncthreads();                                       // every wave's Fz, Fu are in LDS
             CYC(9)
             // ---- C: Quz(w), Qzz(:,w): NT+1 chains interleaved; the cost tiles join at the end (their loads have had the step) ----
-            d4 Quzw = zero, Qzz[NT];
+            d4 Quzw = zero, Qzz[ND];
 #pragma unroll
-            for (int i = 0; i < NT; i++) Qzz[i] = zero;
+            for (int d = 0; d < ND; d++) Qzz[d] = zero;
 #pragma unroll
             for (int k = 0; k < NT; k++) {
-                d4 Fk[NT];
+                d4 Fk[ND];
                 const d4 Fuk = lds_tile(bufFu + k * TILE, lane);
 #pragma unroll
-                for (int i = 0; i < NT; i++) Fk[i] = lds_tile(bufF + (k * NT + i) * TILE, lane);
+                for (int d = 0; d < ND; d++) Fk[d] = lds_tile(bufF + (k * NT + ti[d]) * TILE, lane);
 #pragma unroll
                 for (int r = 0; r < nck(k); r++) {
                     Quzw = MFMA(comp(Fuk, r), comp(Tz[k], r), Quzw);
 #pragma unroll
-                    for (int i = 0; i < NT; i++) Qzz[i] = MFMA(comp(Fk[i], r), comp(Tz[k], r), Qzz[i]);
+                    for (int d = 0; d < ND; d++) Qzz[d] = MFMA(comp(Fk[d], r), comp(Tz[k], r), Qzz[d]);
                 }
             }
             Quzw = Quzw + pLuz;
 #pragma unroll
-            for (int i = 0; i < NT; i++) Qzz[i] = Qzz[i] + pL[i];
+            for (int d = 0; d < ND; d++) Qzz[d] = Qzz[d] + pL[d];
             CYC(8)
             __builtin_amdgcn_sched_barrier(0);
             request_cost(rn);                                      // (issued while the u-wave still refreshes the inverse)
@@ -962,26 +1011,10 @@ k_backward_tiled_uw(RecLayout L, int T, const double *__restrict__ rec, const do
             Gw.z = -__builtin_fma(lam, X.z, Quzw.z); Gw.w = -__builtin_fma(lam, X.w, Quzw.w);
             CYC(4)
             __syncthreads();
-            // ---- E: acc(i,w) = Qzz(i,w) + X_i' G_w -> bufT -------------------------------------------------------
+            // ---- EF: V'(i,w) = Qzz(i,w) + X_i' G_w for the owned tiles, out as tile (i,w) and transposed as tile (w,i) ------------
 #pragma unroll
-            for (int i = 0; i < NT; i++) {
-                Qzz[i] = Pn(lds_tile(bufX + i * TILE, lane), Gw, Qzz[i], NCU);
-                double *pw = bufT + (i * NT + w) * TPAD + q * 17 + c;
-                pw[0] = Qzz[i].x; pw[4 * 17] = Qzz[i].y; pw[8 * 17] = Qzz[i].z; pw[12 * 17] = Qzz[i].w;
-            }
+            for (int d = 0; d < ND; d++) publish_V(d, Pn(lds_tile(bufX + ti[d] * TILE, lane), Gw, Qzz[d], NCU), true);
             CYC(5)
-            __syncthreads();
-            CYC(6)
-            // ---- F: V'(i,w) = (acc(i,w) + acc(w,i)')/2   (:610) -----------------------------------------------------
-#pragma unroll
-            for (int i = 0; i < NT; i++) {
-                const double *pt = bufT + (w * NT + i) * TPAD + c * 17 + q;
-                d4 at;
-                at.x = pt[0]; at.y = pt[4]; at.z = pt[8]; at.w = pt[12];
-                d4 na = 0.5 * (Qzz[i] + at);
-                if (i == tn && w == tn) na = na * nn_keep;
-                lds_store(bufV + (i * NT + w) * TILE, lane, na);
-            }
         }
     }
 #ifdef KP_CYC_UW
