@@ -51,7 +51,7 @@ if [ "$MODE" != per_step ]; then
   # is keyed by the batch: warm it with a plain run first -- under rocprofv3 the profiler has initialised the GPU before the script
   # starts and a cache miss there would fork the generator's worker pool behind it (round-4 advisor)
   for bb in 512 256; do
-    python bench.py $WL --batch $bb --no-secondary --no-cpu-baseline --steps 2 --warmup 1 --detail $OUT/warm_b$bb.json > $OUT/warm_b$bb.log 2>&1 || { echo "warm-up run B=$bb failed"; tail -5 $OUT/warm_b$bb.log; exit 1; }
+    python3 $OLDPWD/bench.py $WL --batch $bb --no-secondary --no-cpu-baseline --steps 2 --warmup 1 --detail $OUT/warm_b$bb.json > $OUT/warm_b$bb.log 2>&1 || { echo "warm-up run B=$bb failed"; tail -5 $OUT/warm_b$bb.log; exit 1; }
   done
   export KPILQR_BENCH_NOFORK=1
   for bb in 512 256; do
