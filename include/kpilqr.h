@@ -45,8 +45,8 @@
  *   KPILQR_ROLE_SHIFT       wave pairs: block-index bit from which the two roles swap wave slots (default 9; 0 = every
  *                           other block).  Placement probe; no effect on results.
  *   KPILQR_TILED_UW         tiled backward sweep (n + 2 > 16): 1 u-wave form | 0 column-wave form (default by tile count).
- *   KPILQR_TILED_A4 / _A6   tiled sweeps: 1 / 0 interpolation (a4) / cost derivatives (a6) inside the sweep (default:
- *                           a4 outside; a6 inside at four tiles from ~100 trajectories).
+ *   KPILQR_TILED_A6         tiled sweeps: 1 / 0 cost derivatives (a6) inside the sweep (default: inside at four tiles from
+ *                           ~100 trajectories).
  *   KPILQR_TILED_FSC        two-tile forward sweep: 1 / 0 state / cost wave groups (default: on while 2 NT B <= #SIMDs).
  *   KPILQR_TILED_NT_MIN     run the tiled kernels with at least this many tiles (test coverage of a tile count on a
  *                           small state).

@@ -1,7 +1,7 @@
 """Randomised parity cases shared by tests/test_gpu_fuzz.py (fixed seed, in the -m gpu suite) and tools/fuzz_parity.py (any
 seed / count, from the command line): random horizons, batch sizes, key-point intervals or ragged per-DoF key-point lists,
 regularisation, PD-check strides, one-sided FD fractions, residuals with and without control Jacobians, over every kernel
-family, every wave organisation of the fused sweeps and every fusion form of the tiled sweeps (a4 / a6), each compared
+family, every wave organisation of the fused sweeps and both forms of the tiled sweeps (a6 inside or not), each compared
 with the CPU oracle."""
 import os
 
@@ -13,7 +13,7 @@ from trajoptkp_amd import Engine, synth
 
 TASKS = ["panda_reaching", "acrobot", "hopper", "pentabot", "panda_pushing", "walker", "arm8", "arm5x2", "high_dof_push",
          "quadruped", "humanoid_fixed"]
-ENV_KEYS = ("KPILQR_FUSED_WAVES", "KPILQR_FUSED_FWD_WAVES", "KPILQR_TILED_A4", "KPILQR_TILED_A6", "KPILQR_TILED_FSC")
+ENV_KEYS = ("KPILQR_FUSED_WAVES", "KPILQR_FUSED_FWD_WAVES", "KPILQR_TILED_A6", "KPILQR_TILED_FSC")
 TOL = 1e-8
 
 
@@ -57,7 +57,6 @@ def run_case(c, worst=None):
             os.environ.pop(key, None)
         if c["form"] == "one":
             os.environ["KPILQR_FUSED_WAVES"] = "1"; os.environ["KPILQR_FUSED_FWD_WAVES"] = "1"
-        os.environ["KPILQR_TILED_A4"] = c["a4"]
         if c["a6"]:
             os.environ["KPILQR_TILED_A6"] = c["a6"]
         T, batch, lam, pd = c["T"], c["batch"], c["lam"], c["pd"]
@@ -76,7 +75,7 @@ def run_case(c, worst=None):
                 e.fd_difference()
             if "fused" not in e.backward_variant:
                 tail = e.backward_variant.rsplit("_", 1)[-1] if "tiled_" in e.backward_variant else ""
-                if "a4" not in tail: e.interpolate()
+                e.interpolate()
                 if "a6" not in tail: e.cost_derivs()
             st, dJ = e.backward(lam, pd)
             K, k = e.gains()

@@ -425,16 +425,14 @@ def test_one_tile_shapes_of_the_other_task_plugins(task, T, batch, wave_form):
 
 @pytest.mark.parametrize("task,T,batch", [("panda_pushing", 60, 2), ("high_dof_push", 24, 2), ("panda_pushing", 301, 3),
                                           ("walker", 150, 2), ("arm8", 120, 2), ("light_clutter_push", 77, 2)])
-@pytest.mark.parametrize("a4,a6", [("0", "1"), ("1", "0"), ("1", "1")])
-def test_tiled_a4_a6_inside_the_sweeps(task, T, batch, a4, a6, monkeypatch):
-    """KPILQR_FLAG_FUSED on a tiled shape: a4 (A, B interpolated in registers from the key-point columns: kpilqr_interpolate
-    is not run, the records are touched at key-points only) and / or a6 (cost derivatives formed inside the tiled sweeps
-    from the residuals and their Jacobians: kpilqr_cost_derivs is not run) -- against the oracle, with dense residual
-    Jacobians incl. r_u, one-sided FD columns, terminal weights, and the PD-failure step.  (KPILQR_TILED_A4 / _A6 force
-    the forms for the small cases here; by itself the library takes a6 only for four-tile states at ~100 trajectories up.)"""
+def test_tiled_a6_inside_the_sweeps(task, T, batch, monkeypatch):
+    """KPILQR_FLAG_FUSED on a tiled shape: a6 (cost derivatives formed inside the tiled sweeps from the residuals and their
+    Jacobians: kpilqr_cost_derivs is not run) -- against the oracle, with dense residual Jacobians incl. r_u, one-sided FD
+    columns, terminal weights, and the PD-failure step.  (KPILQR_TILED_A6 forces the form for the small cases here; by itself
+    the library takes it only for four-tile states at ~100 trajectories up.  The a4 form of rounds 2-4 was removed in round 5.)"""
+    a6 = "1"
     monkeypatch.setenv("KPILQR_TILED_A6", a6)
-    monkeypatch.setenv("KPILQR_TILED_A4", a4)
-    want = "mfma_f64_tiled" + {("0", "1"): "_a6", ("1", "0"): "_a4", ("1", "1"): "_a4a6"}[(a4, a6)]
+    want = "mfma_f64_tiled_a6"
     p = synth.make_problem(task=task, T=T, batch=batch, min_N=4, dense_residuals=True, one_sided_frac=0.1)
     ref = [pipeline.run_trajectory(p, b, want_U=True) for b in range(batch)]
     for use_iterate in (False, True):
@@ -448,10 +446,7 @@ def test_tiled_a4_a6_inside_the_sweeps(task, T, batch, a4, a6, monkeypatch):
                 g["K"], g["k"] = e.gains()
             else:
                 e.fd_difference()
-                if a4 == "0":
-                    e.interpolate()
-                if a6 == "0":
-                    e.cost_derivs()
+                e.interpolate()
                 st, dJ = e.backward(p["lam"], 100)
                 K, k = e.gains()
                 cost, U = e.forward_linear(orc.alphas(6), want_U=True)

@@ -81,7 +81,6 @@ struct Ctx {
     bool kp_canonical = false;   // every DoF list strictly increasing, first 0, last T-1 (what the fused sweeps walk)
     bool fused = false;          // KPILQR_FLAG_FUSED and a supported shape
     bool tiled_a6 = false;       // KPILQR_FLAG_FUSED on a tiled shape: the cost derivatives (a6) are formed inside the sweeps
-    bool tiled_a4 = false;       // KPILQR_FLAG_FUSED on a tiled shape: A, B are interpolated (a4) inside the sweeps
     bool ru_zero = true;         // r_u was never written since create / resize (the buffer starts zeroed): r_u = 0 exactly
     // constant residual Jacobians (kpilqr_upload_residual_jacobians_const): ONE r_x [nr][n] for every trajectory and step.
     // rx_const_on: the fused one-wave sweeps keep it in registers and never read the r_x buffer; rx_buf_valid: the r_x buffer
@@ -191,7 +190,6 @@ struct Ctx {
         int tiled_nt_min = 0;      // KPILQR_TILED_NT_MIN: run the tiled kernels with more tiles than needed
         int tiled_a6 = -1;         // KPILQR_TILED_A6: -1 auto, 0 | 1
         int tiled_uw = -1;         // KPILQR_TILED_UW: 0 = no u-wave in the tiled backward sweep (NT <= 3, materialised tiles)
-        int tiled_a4 = -1;         // KPILQR_TILED_A4: -1 auto, 0 | 1 (a4 inside the tiled sweeps)
         int tiled_fsc = -1;        // KPILQR_TILED_FSC: -1 auto, 0 | 1: the state / cost wave groups of the two-tile forward sweep
         int fused_uni = -1;        // KPILQR_FUSED_UNI: 0 never take the uniform-key-point form of the one-wave backward sweep (diagnostic)
         int fused_raw = -1;        // KPILQR_FUSED_RAW: 0 never difference inside the backward sweep (diagnostic), else auto
@@ -263,7 +261,6 @@ size_t backward_tiled_lds_bytes(int nt);
 bool forward_tiled_supported(int n, int m, int n_alpha, int nt_min);
 bool forward_tiled_sc_selected(const Ctx *c);             // the state / cost wave groups will run (two tiles, small batches)
 hipError_t launch_forward_tiled(Ctx *c, double *U_alpha_dev);
-bool tiled_a4_supported(int n, int m, int dof, int T, int stride);
 // tiled_wide.hip: the same sweeps with the control block over up to two tiles (8 < m <= 32 backward, 16 < m <= 32 forward)
 bool backward_wide_supported(int n, int m, int nt_min);
 hipError_t launch_backward_wide(Ctx *c, int pd_stride);

@@ -84,7 +84,6 @@ Ctx::Tuning read_tuning_from_env()
     t.role_shift = env_int("KPILQR_ROLE_SHIFT", 9);
     t.tiled_nt_min = env_int("KPILQR_TILED_NT_MIN", 0);
     t.tiled_a6 = env_int("KPILQR_TILED_A6", -1);
-    t.tiled_a4 = env_int("KPILQR_TILED_A4", -1);
     t.tiled_uw = env_int("KPILQR_TILED_UW", -1);
     t.tiled_fsc = env_int("KPILQR_TILED_FSC", -1);
     t.pipe_copy = env_int("KPILQR_PIPE_COPY", -1);
@@ -306,7 +305,7 @@ static bool forward_reads_rx_buffer(const kpilqr_ctx *c) { return !(c->fused && 
 static int select_variants(kpilqr_ctx *c)
 {
     const kpilqr_dims *dims = &c->d;
-    c->fused = c->tiled_a4 = c->tiled_a6 = false;
+    c->fused = c->tiled_a6 = false;
     const bool generic = (dims->flags & KPILQR_FLAG_GENERIC_KERNELS) != 0;
     const bool force_tiled = (dims->flags & KPILQR_FLAG_TILED_KERNELS) != 0;
     c->bwd_variant = (!generic && !force_tiled && backward_mfma_supported(c->n, dims->m)) ? "mfma_f64_t1"
@@ -320,28 +319,18 @@ static int select_variants(kpilqr_ctx *c)
         c->fused = true;
         c->bwd_variant = c->fwd_variant = "mfma_f64_t1_fused";
     }
-    // The same flag on a tiled shape (n + 2 > 16): parts of the fusion the tiled sweeps offer.
-    //  a4 (variant "..._a4"): A, B interpolated in registers from the key-point columns (tracker.h) -- k_interpolate and the
-    //     per-step reads of A, B disappear; needs canonical key-points like the one-tile fused sweeps.  Built, parity-green,
-    //     and NOT the default: a lone wave per SIMD is bound by instruction issue, and the per-lane list walk (4 NT + 4
-    //     values per lane: selects, un-contracted multiply-adds, loads, AGPR traffic for the tracker state) costs more than
-    //     the k_interpolate it removes (n = 62, T = 5000, B = 128, 26 % ragged key-points: interpolate 11.2 ms saved,
-    //     backward +8.9 ms, forward +7.9 ms; pushing n = 20, B = 64: 0.28 ms saved, +2.3 and +1.9 ms).
-    //     KPILQR_TILED_A4 = 1 turns it on.
-    //  a6 (variant "..._a6"): cost derivatives formed from the residuals inside the sweeps.  It replaces k_cost_derivs
-    //     (HBM-bound: n^2 doubles written per step) by NT*ceil(nr/4) + 6 MFMAs per wave-step of the latency-bound backward
-    //     sweep (+9 % at four tiles, whatever the batch): a gain from ~100 trajectories of a four-tile state up (n = 62,
-    //     B = 128, T = 5000: 74.4 -> 70.6 ms), a loss for two or three tiles at the batches measured.  KPILQR_TILED_A6 = 0 | 1.
+    // The same flag on a tiled shape (n + 2 > 16): a6 (variant "..._a6"), cost derivatives formed from the residuals inside the
+    // sweeps.  It replaces k_cost_derivs (HBM-bound: n^2 doubles written per step) by NT*ceil(nr/4) + 6 MFMAs per wave-step of the
+    // latency-bound backward sweep (+9 % at four tiles, whatever the batch): a gain from ~100 trajectories of a four-tile state up
+    // (n = 62, B = 128, T = 5000: 74.4 -> 70.6 ms), a loss for two or three tiles at the batches measured.  KPILQR_TILED_A6 = 0 | 1.
+    // (a4 inside the tiled sweeps existed in rounds 2-4, parity-green and slower by more than the k_interpolate it removed; removed
+    // in round 5: tiled_mfma.hip.)
     if ((dims->flags & KPILQR_FLAG_FUSED) && !c->fused &&
         strcmp(c->bwd_variant, "mfma_f64_tiled") == 0 && strcmp(c->fwd_variant, "mfma_f64_tiled") == 0) {
-        const bool can_a4 = tiled_a4_supported(c->n, dims->m, dims->dof, dims->T, c->L.stride);
-        const bool want_a4 = can_a4 && c->tune.tiled_a4 == 1;
         const bool want_a6 = dims->nr <= 16 && (c->tune.tiled_a6 >= 0 ? c->tune.tiled_a6 != 0
                                                 : (tiled_tiles(c->n, c->tune.tiled_nt_min) == 4 && dims->batch >= 96));
-        c->tiled_a4 = want_a4; c->tiled_a6 = want_a6;
-        if (want_a4 && want_a6) c->bwd_variant = c->fwd_variant = "mfma_f64_tiled_a4a6";
-        else if (want_a4) c->bwd_variant = c->fwd_variant = "mfma_f64_tiled_a4";
-        else if (want_a6) c->bwd_variant = c->fwd_variant = "mfma_f64_tiled_a6";
+        c->tiled_a6 = want_a6;
+        if (want_a6) c->bwd_variant = c->fwd_variant = "mfma_f64_tiled_a6";
     }
     if (strcmp(c->bwd_variant, "generic_lds") == 0 && backward_generic_lds_bytes(c->n, dims->m) > 160 * 1024) {
         c->err = "state dimension too large for the generic backward kernel (LDS)";
@@ -909,7 +898,7 @@ int kpilqr_filter_dynamics(kpilqr_ctx *c, const char *method, const double *coef
     int mth = strcmp(method, "low_pass") == 0 ? 0 : strcmp(method, "FIR") == 0 ? 1 : -1;
     if (mth < 0) return set_err(c, KPILQR_ERR_ARG, "Filtering method not recognised (low_pass, FIR)");
     if (ncoef < 1 || ncoef > 16) return set_err(c, KPILQR_ERR_ARG, "1..16 filter coefficients");
-    if (c->fused || c->tiled_a4)
+    if (c->fused)
         return set_err(c, KPILQR_ERR_STATE, "the A filters act on the materialised sequence: create the context without KPILQR_FLAG_FUSED");
     int rc = ensure_stage(c, 16 * sizeof(double));
     if (rc) return rc;
@@ -989,7 +978,6 @@ static int check_fused(kpilqr_ctx *c)
 static int run_backward(kpilqr_ctx *c, int pd_stride)
 {
     if (c->rx_const_on && (c->fused || c->tiled_a6) && backward_reads_rx_buffer(c)) { const int rcx = ensure_rx_buffer(c); if (rcx) return rcx; }
-    if (c->tiled_a4) { int rc = check_fused(c); if (rc) return rc; }
     if (c->fused) {
         int rc = check_fused(c);
         if (rc) return rc;
@@ -1116,7 +1104,6 @@ static int ensure_stage(kpilqr_ctx *c, size_t bytes)
 static int run_forward(kpilqr_ctx *c, double *U_dev)
 {
     if (c->rx_const_on && (c->fused || c->tiled_a6) && forward_reads_rx_buffer(c)) { const int rcx = ensure_rx_buffer(c); if (rcx) return rcx; }
-    if (c->tiled_a4) { int rc = check_fused(c); if (rc) return rc; }
     if (c->fused) {
         int rc = check_fused(c);
         if (rc) return rc;
@@ -1168,7 +1155,7 @@ int kpilqr_iterate(kpilqr_ctx *c, const double *lambda, int pd_check_stride, con
     if (alphas) KP_HIP(c, hipMemcpyAsync(c->alphas, alphas, (size_t)c->d.n_alpha * 8, hipMemcpyHostToDevice, c->stream));
     if (!c->fused) {              // the fused sweeps difference (or read kpc), interpolate A, B and form l_* themselves
         { const int rcp = records_from_payload(c); if (rcp) return rcp; }
-        if (!c->tiled_a4) KP_HIP(c, launch_interpolate(c));      // tiled + flag: A, B interpolated inside the sweeps
+        KP_HIP(c, launch_interpolate(c));
         if (!c->tiled_a6) { const int rcx = ensure_rx_buffer(c); if (rcx) return rcx; KP_HIP(c, launch_cost_derivs(c)); }      // tiled + flag: l_* are formed inside the sweeps
     }
     int rc = run_backward(c, pd_check_stride);
@@ -1227,7 +1214,7 @@ int kpilqr_iterate_streamed(kpilqr_ctx *c, const kpilqr_stream_io *io, int pd_ch
     }
     const void *hostp[] = {io->kp_columns, io->fd_kp_slab, io->fd_slab, io->r, io->r_x, io->r_u, io->u_nom, io->lambda, io->K, io->k, io->cost_pred, io->delta_J, io->status};
     for (const void *p : hostp) if (!is_pinned(p)) return set_err(c, KPILQR_ERR_ARG, "kpilqr_iterate_streamed: host buffers must be pinned (kpilqr_host_alloc)");
-    if (c->fused || c->tiled_a4) { int rc = check_fused(c); if (rc) return rc; }
+    if (c->fused) { int rc = check_fused(c); if (rc) return rc; }
     int rc = pipe_setup(c);
     if (rc) return rc;
     // the chunk -> stream map must not change while earlier chunks are still in flight (same-stream order is what
@@ -1386,7 +1373,7 @@ int kpilqr_iterate_streamed(kpilqr_ctx *c, const kpilqr_stream_io *io, int pd_ch
         // ---- kernels of the chunk --------------------------------------------------------------------------------
         if (!c->fused) {
             if (slab || kslab || kcols) { rc = records_from_payload(&v); if (rc) { c->err = v.err; return rc; } }
-            if (!c->tiled_a4) KP_HIP(c, launch_interpolate(&v));
+            KP_HIP(c, launch_interpolate(&v));
             if (!c->tiled_a6) KP_HIP(c, launch_cost_derivs(&v));
         }
         rc = run_backward(&v, pd_check_stride);

@@ -15,7 +15,6 @@
 #include <cstdlib>
 #include <type_traits>
 #include "mfma_common.h"
-#include "tracker.h"
 #ifndef KP_NS_HOLD
 #define KP_NS_HOLD 8                // factorised steps behind a Newton-Schulz refresh that gave up before the fast path is tried again
 #endif
@@ -141,8 +140,6 @@ __device__ __forceinline__ d4 ld_Luu(__amdgpu_buffer_rsrc_t rs, const TileSrc &S
 // l_uu = Ru' W Ru, l_u = Ru' W r, W = diag(2 w): ModelTranslator::CostDerivativesFromResiduals
 // (ModelTranslator.cpp:552-583) as in fused_mfma.hip, so l_xx (n^2 doubles per step) is neither written nor read.
 struct CostSrc { const double *r, *r_x, *r_u, *w_run, *w_term; int nr; };
-// a4 inside the sweeps (KPILQR_FLAG_FUSED on a tiled shape, variant "..._a4"): the per-DoF key-point lists the lanes walk
-struct KpSrc { const int *kp_offsets, *kp_times; int dof; };
 
 // element (res = 4r+q, col = 16*tj + c) of r_x [nr][n]
 __device__ __forceinline__ d4 ld_Rx(__amdgpu_buffer_rsrc_t rs, int n, int nr, int tj, int q, int c)
@@ -200,14 +197,15 @@ __device__ __forceinline__ d4 ld_Ru(__amdgpu_buffer_rsrc_t rs, int m, int nr, in
 // padded scratch tile), so the barrier between the old phases E and F is gone.  The off-diagonal tiles differ from the reference's
 // average by the rounding-level asymmetry of Qzz (the tests hold the kernel to the oracle at 1e-9 as before).
 // All source tiles are single-buffered: re-requested for step t-1 right behind their last use in step t.
-// A4: Fz(:,w) and Fu(w) are not read from the records of every step but interpolated in registers from the key-point
-// columns (tracker.h): lane (q,c) of wave w holds rows 16k+4r+q of COLUMN 16w+c of A -- one DoF list per lane -- and rows
-// 16w+4r+q of column c of B (the list of DoF c: KeyPointGenerator.cpp:927-931), so the records are touched at key-points only.
+// (Rounds 2-4 also carried an A4 form -- Fz, Fu interpolated in registers from the key-point columns of the records, per-lane
+// trackers -- parity-green and slower: with per-DoF lists some lane of a wave crosses a key-point on practically every step, so
+// every step paid a crossing's 20 loads and 20 divisions per lane; configs[4], round 5: backward 49.6 against 42.7 ms, forward 19.8
+// against 12.5 ms, for 5.0 ms of k_interpolate saved.  Removed in round 5.)
 // NCL > 0: the chunk count of the last row tile at compile time (see k_backward_tiled_uw) and the products of phase BC as
 // interleaved chains; NCL = 0: run-time count, one chain after the other.
-template <int M, int NT, bool A6, bool A4, int NCL = 0>
+template <int M, int NT, bool A6, int NCL = 0>
 __global__ void __launch_bounds__(64 * NT)
-k_backward_tiled_col(RecLayout L, CostSrc CS, KpSrc KP, int T, const double *__restrict__ rec, const double *__restrict__ lambda,
+k_backward_tiled_col(RecLayout L, CostSrc CS, int T, const double *__restrict__ rec, const double *__restrict__ lambda,
                      int pd_stride, double *__restrict__ Kout, double *__restrict__ kout,
                      double *__restrict__ delta_J, int *__restrict__ status)
 {
@@ -263,42 +261,6 @@ k_backward_tiled_col(RecLayout L, CostSrc CS, KpSrc KP, int T, const double *__r
     // formed from residual tiles instead: pL[k] holds Rx_k (r_x rows, column tile k), pLuz the r column, pLuu Ru
     d4 pF[NT], pL[ND], pFu, pLuz, pLuu;
     auto rsrc_of = [&](int t) { return __builtin_amdgcn_make_buffer_rsrc((void *)(R0 + (size_t)t * L.stride), 0, rec_bytes, 0x00020000); };
-    // ---- a4 trackers (walking down in time) ---------------------------------------------------------------------------
-    constexpr int NVA = A4 ? 4 * NT : 1;
-    KpDownTracker<NVA> trA;
-    KpDownTracker<A4 ? 4 : 1> trB;
-    const int strideB = L.stride * 8;
-    __amdgpu_buffer_rsrc_t rT = __builtin_amdgcn_make_buffer_rsrc((void *)R0, 0, A4 ? T * strideB : 0, 0x00020000);
-    auto eval_F = [&](int t) {                         // pF / pFu <- A, B columns of step t
-        if constexpr (A4) {
-            const double dtA = (double)(t - trA.s), dtB = (double)(t - trB.s);
-#pragma unroll
-            for (int k = 0; k < NT; k++) {
-                pF[k].x = trA.value(4 * k, dtA); pF[k].y = trA.value(4 * k + 1, dtA);
-                pF[k].z = trA.value(4 * k + 2, dtA); pF[k].w = trA.value(4 * k + 3, dtA);
-            }
-            pFu.x = trB.value(0, dtB); pFu.y = trB.value(1, dtB); pFu.z = trB.value(2, dtB); pFu.w = trB.value(3, dtB);
-        }
-    };
-    if constexpr (A4) {
-        const int colA = 16 * w + c, dof = KP.dof;
-        const bool hasA = colA < n, hasB = c < m;
-        const int kdA = colA < dof ? colA : colA - dof;
-#pragma unroll
-        for (int k = 0; k < NT; k++)
-#pragma unroll
-            for (int r = 0; r < 4; r++) {
-                const int row = 16 * k + 4 * r + q;
-                trA.offs[4 * k + r] = (hasA && row < n) ? 8 * L.a(row, colA) : KP_OOB;
-            }
-#pragma unroll
-        for (int r = 0; r < 4; r++) {
-            const int row = 16 * w + 4 * r + q;
-            trB.offs[r] = (hasB && row < n) ? 8 * L.b(row, c) : KP_OOB;
-        }
-        trA.init(rT, KP.kp_offsets, KP.kp_times, hasA, (size_t)b * dof + (hasA ? kdA : 0), T, strideB);
-        trB.init(rT, KP.kp_offsets, KP.kp_times, hasB, (size_t)b * dof + (hasB ? c : 0), T, strideB);
-    }
     const int nr = CS.nr, ncr = (nr + 3) >> 2;
     const double *rb = CS.r + (size_t)b * (T + 1) * nr, *rxb = CS.r_x + (size_t)b * (T + 1) * nr * n,
                  *rub = CS.r_u + (size_t)b * (T + 1) * nr * m;
@@ -351,16 +313,11 @@ k_backward_tiled_col(RecLayout L, CostSrc CS, KpSrc KP, int T, const double *__r
             cLuz = pLuz; cLuu = pLuu;
         }
     };
-    if constexpr (A4) {
-        eval_F(T - 1);
-        load_cost(T - 1, true);
-    } else {
-        __amdgpu_buffer_rsrc_t rs = rsrc_of(T - 1);
+    __amdgpu_buffer_rsrc_t rs = rsrc_of(T - 1);
 #pragma unroll
-        for (int k = 0; k < NT; k++) pF[k] = ld_Fz(rs, S, k, w, q, c);
-        pFu = ld_Fu(rs, S, w, q, c);
-        load_cost(T - 1, true);
-    }
+    for (int k = 0; k < NT; k++) pF[k] = ld_Fz(rs, S, k, w, q, c);
+    pFu = ld_Fu(rs, S, w, q, c);
+    load_cost(T - 1, true);
     // V' <- Lzz(T-1)   (iLQR.cpp:537-539), terminal weights (Optimiser.cpp:208-211)
     // an owned tile of V' goes out as tile (i,w) and, transposed through the private scratch tile (same-wave LDS accesses are
     // ordered: no barrier), as tile (w,i); the diagonal tile is averaged with its own transpose (iLQR.cpp:610)
@@ -410,18 +367,10 @@ k_backward_tiled_col(RecLayout L, CostSrc CS, KpSrc KP, int T, const double *__r
         if (w == tn && lane_nn) bufF[(tn * NT + w) * TILE + reg_nn * 64 + lane] = 1.0;
         lds_store(bufFu + w * TILE, lane, pFu);
         __builtin_amdgcn_sched_barrier(0);
-        if constexpr (A4) {
-            if (more) {
-                trA.consume(); trB.consume();
-                trA.step(t - 1); trB.step(t - 1);
-                eval_F(t - 1);
-                trA.issue(rT, T, strideB); trB.issue(rT, T, strideB);
-            }
-        } else {
 #pragma unroll
-            for (int k = 0; k < NT; k++) pF[k] = ld_Fz(rn, S, k, w, q, c);
-            pFu = ld_Fu(rn, S, w, q, c);
-        }
+        for (int k = 0; k < NT; k++) pF[k] = ld_Fz(rn, S, k, w, q, c);
+        pFu = ld_Fu(rn, S, w, q, c);
+    
         __builtin_amdgcn_sched_barrier(0);
         CYK(0)
         __syncthreads();
@@ -1054,39 +1003,37 @@ static hipError_t launch_bt_uw(Ctx *c, int pd_stride)
     return hipErrorInvalidValue;
 }
 
-template <int M, int NT, bool A6, bool A4, int NCL>
+template <int M, int NT, bool A6, int NCL>
 static hipError_t launch_bt3(Ctx *c, int pd_stride)
 {
     const size_t ldc = backward_col_lds_bytes(NT);
-    hipError_t e = hipFuncSetAttribute((const void *)k_backward_tiled_col<M, NT, A6, A4, NCL>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)ldc);
+    hipError_t e = hipFuncSetAttribute((const void *)k_backward_tiled_col<M, NT, A6, NCL>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)ldc);
     if (e != hipSuccess) return e;
     const CostSrc CS = {c->r, c->r_x, c->r_u, c->w_run, c->w_term, c->d.nr};
-    const KpSrc KP = {c->kp_offsets, c->kp_times, c->d.dof};
-    hipLaunchKernelGGL((k_backward_tiled_col<M, NT, A6, A4, NCL>), dim3(c->d.batch), dim3(64 * NT), ldc, c->stream, c->L, CS, KP, c->d.T, c->rec,
+    hipLaunchKernelGGL((k_backward_tiled_col<M, NT, A6, NCL>), dim3(c->d.batch), dim3(64 * NT), ldc, c->stream, c->L, CS, c->d.T, c->rec,
                        c->lambda, pd_stride, c->K, c->k, c->delta_J, c->status);
     return hipGetLastError();
 }
-template <int M, int NT, bool A6, bool A4>
+template <int M, int NT, bool A6>
 static hipError_t launch_bt2(Ctx *c, int pd_stride)
 {
     // four tiles, records materialised: the interleaved products, instantiated per chunk count of the last row tile
-    if constexpr (NT == 4 && !A4) {
+    if constexpr (NT == 4) {
         const int rows = c->n + 1 - 16 * (NT - 1), ncl = rows >= 16 ? 4 : (rows + 3) / 4;
         if (c->tune.tiled_uw != 0) switch (ncl) {
-        case 1: return launch_bt3<M, NT, A6, A4, 1>(c, pd_stride);
-        case 2: return launch_bt3<M, NT, A6, A4, 2>(c, pd_stride);
-        case 3: return launch_bt3<M, NT, A6, A4, 3>(c, pd_stride);
-        case 4: return launch_bt3<M, NT, A6, A4, 4>(c, pd_stride);
+        case 1: return launch_bt3<M, NT, A6, 1>(c, pd_stride);
+        case 2: return launch_bt3<M, NT, A6, 2>(c, pd_stride);
+        case 3: return launch_bt3<M, NT, A6, 3>(c, pd_stride);
+        case 4: return launch_bt3<M, NT, A6, 4>(c, pd_stride);
         }
     }
-    return launch_bt3<M, NT, A6, A4, 0>(c, pd_stride);
+    return launch_bt3<M, NT, A6, 0>(c, pd_stride);
 }
 template <int M, int NT>
 static hipError_t launch_bt(Ctx *c, int pd_stride)
 {
-    if (NT <= 3 && !c->tiled_a4 && !c->tiled_a6 && c->tune.tiled_uw != 0) return launch_bt_uw<M, NT>(c, pd_stride);
-    if (c->tiled_a4) return c->tiled_a6 ? launch_bt2<M, NT, true, true>(c, pd_stride) : launch_bt2<M, NT, false, true>(c, pd_stride);
-    return c->tiled_a6 ? launch_bt2<M, NT, true, false>(c, pd_stride) : launch_bt2<M, NT, false, false>(c, pd_stride);
+    if (NT <= 3 && !c->tiled_a6 && c->tune.tiled_uw != 0) return launch_bt_uw<M, NT>(c, pd_stride);
+    return c->tiled_a6 ? launch_bt2<M, NT, true>(c, pd_stride) : launch_bt2<M, NT, false>(c, pd_stride);
 }
 
 hipError_t launch_backward_tiled(Ctx *c, int pd_stride)
@@ -1103,17 +1050,11 @@ hipError_t launch_backward_tiled(Ctx *c, int pd_stride)
 // NT wavefronts per trajectory: wave i owns row tile i of Z+ and of Lc Z (its column of Ya / Lc tiles goes
 // global -> registers, prefetched one step ahead), every wave forms the (cheap) control law itself, and the
 // Z tiles are exchanged through a double-buffered LDS image with ONE s_barrier per time-step.
-// A4: the A, B operands are not read from the records of every step: wave wi interpolates COLUMN tile wi of A (and row tile
-// wi of B, whose lanes hold one column each) in registers (tracker.h, walking up in time), one step ahead, and parks the
-// tiles in a double-buffered, padded row-major LDS image; the MFMA operands -- ROW tile wi of A, transposed -- are read
-// back from it (tile (wi,k) was written by wave k), the B operand from the wave's own tile.  No extra barrier: the image
-// of step t+1 is complete before the barrier that ends step t.
-template <int NT> constexpr size_t forward_a4_lds_doubles() { return (size_t)(2 * NT * NT + NT) * TPAD; }
 // NCL > 0: chunk count of the last row tile at compile time, the two accumulation chains of a step (state cost rows Lc Z, next
 // state Ya Z) issued interleaved; NCL = 0: run-time count, one chain after the other (see k_backward_tiled_uw).
-template <int NT, bool A6, bool A4, int NCL = 0>
+template <int NT, bool A6, int NCL = 0>
 __global__ void __launch_bounds__(64 * NT)
-k_forward_tiled(RecLayout L, CostSrc CS, KpSrc KP, int T, int n_alpha, const double *__restrict__ rec, const double *__restrict__ Kin,
+k_forward_tiled(RecLayout L, CostSrc CS, int T, int n_alpha, const double *__restrict__ rec, const double *__restrict__ Kin,
                 const double *__restrict__ kin, const double *__restrict__ u_nom, const double *__restrict__ ctrl_lim,
                 const double *__restrict__ alphas, double *__restrict__ cost_pred, double *__restrict__ U_alpha)
 {
@@ -1122,7 +1063,6 @@ k_forward_tiled(RecLayout L, CostSrc CS, KpSrc KP, int T, int n_alpha, const dou
     double *upart = fsh + 2 * NT * TILE;                                     // per-wave partials of K dx + alpha k
     double *red = upart + NT * TILE;                                         // [NT * 64]
     double *jpart = red + NT * 64;                                           // A6: per-wave partials of r_x dx  [NT * TILE]
-    double *aimg = jpart + (A6 ? NT * TILE : 0);                             // A4: [2][NT*NT] padded A tiles, then [NT] B tiles
     const int n = L.n, m = L.m, nz2 = n + 2;
     const int lane = threadIdx.x & 63, c = lane & 15, q = lane >> 4;
     const int wi = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);   // this wave's row tile (wave-uniform)
@@ -1209,60 +1149,6 @@ k_forward_tiled(RecLayout L, CostSrc CS, KpSrc KP, int T, int n_alpha, const dou
         const bool ok = t < T;
         return __builtin_amdgcn_make_buffer_rsrc((void *)(base_b + (size_t)(ok ? t : 0) * step_elems), 0, ok ? bytes : 0, 0x00020000);
     };
-    // ---- a4 trackers (walking up in time) and the LDS image ---------------------------------------------------------------
-    constexpr int NVA = A4 ? 4 * NT : 1;
-    KpUpTracker<NVA> trA;
-    KpUpTracker<A4 ? 4 : 1> trB;
-    const int strideB = L.stride * 8;
-    __amdgpu_buffer_rsrc_t rT = __builtin_amdgcn_make_buffer_rsrc((void *)(rec + (size_t)b * T * L.stride), 0, A4 ? T * strideB : 0, 0x00020000);
-    double *bimg = aimg + 2 * NT * NT * TPAD + wi * TPAD;                     // this wave's B tile
-    auto stage_AB = [&](int t) {                       // A(:, column tile wi), B(row tile wi, :) of step t -> LDS, element (row, col) at row*17 + col
-        if constexpr (A4) {
-            const double dtA = (double)(t - trA.s), dtB = (double)(t - trB.s);
-            double *img = aimg + (t & 1) * NT * NT * TPAD;
-#pragma unroll
-            for (int k = 0; k < NT; k++) {
-                double *pw = img + (k * NT + wi) * TPAD + q * 17 + c;          // tile (k, wi): rows 16k.., columns 16wi..
-                pw[0] = trA.value(4 * k, dtA); pw[4 * 17] = trA.value(4 * k + 1, dtA);
-                pw[8 * 17] = trA.value(4 * k + 2, dtA); pw[12 * 17] = trA.value(4 * k + 3, dtA);
-            }
-            double *pb = bimg + q * 17 + c;                                    // B(16wi + 4r+q, c)
-            pb[0] = trB.value(0, dtB); pb[4 * 17] = trB.value(1, dtB); pb[8 * 17] = trB.value(2, dtB); pb[12 * 17] = trB.value(3, dtB);
-        }
-    };
-    auto fetch_Ya = [&](int t, d4 *Ya) {                // Ya[k](p = 16k+4r+q, o = 16wi+c) = A(o, p): tile (wi, k) read transposed
-        const double *img = aimg + (t & 1) * NT * NT * TPAD;
-#pragma unroll
-        for (int k = 0; k < NT; k++) {
-            const double *pr = img + (wi * NT + k) * TPAD + c * 17 + q;
-            Ya[k].x = pr[0]; Ya[k].y = pr[4]; Ya[k].z = pr[8]; Ya[k].w = pr[12];
-        }
-    };
-    auto fetch_Yb = [&]() -> d4 {                      // Yb(j = 4r+q, o = 16wi+c) = B(o, j): own tile read transposed
-        const double *pr = bimg + c * 17 + q;
-        d4 v; v.x = pr[0]; v.y = pr[4]; v.z = pr[8]; v.w = pr[12];
-        return v;
-    };
-    if constexpr (A4) {
-        const int colA = 16 * wi + c, dof = KP.dof;
-        const bool hasA = colA < n, hasB = c < m;
-        const int kdA = colA < dof ? colA : colA - dof;
-#pragma unroll
-        for (int k = 0; k < NT; k++)
-#pragma unroll
-            for (int r = 0; r < 4; r++) {
-                const int row = 16 * k + 4 * r + q;
-                trA.offs[4 * k + r] = (hasA && row < n) ? 8 * L.a(row, colA) : KP_OOB;
-            }
-#pragma unroll
-        for (int r = 0; r < 4; r++) {
-            const int row = 16 * wi + 4 * r + q;
-            trB.offs[r] = (hasB && row < n) ? 8 * L.b(row, c) : KP_OOB;
-        }
-        trA.init(rT, KP.kp_offsets, KP.kp_times, hasA, (size_t)b * dof + (hasA ? kdA : 0), T, strideB);
-        trB.init(rT, KP.kp_offsets, KP.kp_times, hasB, (size_t)b * dof + (hasB ? c : 0), T, strideB);
-        stage_AB(0);
-    }
     // Single-buffered tiles: each group is re-requested for step t+1 right behind its last use in step t.
     // Every wave forms only ITS slice of the control law, P([K' ; k'] rows of tile wi, Z_wi) (4 MFMAs instead of
     // 4*NT); the slices are summed through LDS (one extra barrier), then every wave clamps the same U.
@@ -1271,7 +1157,7 @@ k_forward_tiled(RecLayout L, CostSrc CS, KpSrc KP, int T, int n_alpha, const dou
     // a step of this kernel (~1.1 us at two tiles) is about one trip to HBM, and a wave's memory operations return in order,
     // so the step time WAS that trip.  NS = 2 where the tiles are materialised and the chunk counts compile-time (NCL > 0);
     // every step is instantiated with its set as a compile-time constant (no copies between sets).
-    constexpr int NS = (NCL > 0 && !A6 && !A4) ? KP_FT_SETS : 1;
+    constexpr int NS = (NCL > 0 && !A6) ? KP_FT_SETS : 1;
     Tiles S[NS];
 #pragma unroll
     for (int s0 = 0; s0 < NS; s0++) {
@@ -1280,8 +1166,8 @@ k_forward_tiled(RecLayout L, CostSrc CS, KpSrc KP, int T, int n_alpha, const dou
         __amdgpu_buffer_rsrc_t rk = rs_of(kin, m, s0, m * 8), ru = rs_of(u_nom, m, s0, m * 8);
         cur.Ykw = ld4(rK, oKw) + ld4(rk, okw);
 #pragma unroll
-        for (int k = 0; k < NT; k++) { if (!A4) cur.Ya[k] = ld4(rR, oA[k]); if (!A6) cur.Lc[k] = ld4(rR, oLc[k]); }
-        if (!A4) cur.Yb = ld4(rR, oB);
+        for (int k = 0; k < NT; k++) { cur.Ya[k] = ld4(rR, oA[k]); if (!A6) cur.Lc[k] = ld4(rR, oLc[k]); }
+        cur.Yb = ld4(rR, oB);
         cur.ub = ld4(ru, oub);
         if (A6) {
             cur.Lc[0] = ld4(rs_res(rxb, (size_t)nr * n, s0, nr * n * 8), oRxT);
@@ -1367,7 +1253,7 @@ k_forward_tiled(RecLayout L, CostSrc CS, KpSrc KP, int T, int n_alpha, const dou
         CYF(2)
         // ---- state cost rows of this tile, then the linearised dynamics for this tile ------------------------------
         d4 Wz = zero, Zn = zero;
-        if constexpr (NCL > 0 && !A6 && !A4) {
+        if constexpr (NCL > 0 && !A6) {
             auto nck = [](int kt) { return kt < NT - 1 ? 4 : NCL; };
             auto comp = [](const d4 &v, int r) { return r == 0 ? v.x : r == 1 ? v.y : r == 2 ? v.z : v.w; };
 #pragma unroll
@@ -1396,7 +1282,7 @@ k_forward_tiled(RecLayout L, CostSrc CS, KpSrc KP, int T, int n_alpha, const dou
             __builtin_amdgcn_sched_barrier(0);
             partial += 0.5 * (Zi.x * Wz.x + Zi.y * Wz.y + Zi.z * Wz.z + Zi.w * Wz.w);
         }
-        if constexpr (A4) { fetch_Ya(t, cur.Ya); cur.Yb = fetch_Yb(); }     // staged during step t-1 (before its closing barrier)
+     // staged during step t-1 (before its closing barrier)
 #pragma unroll
         for (int k = 0; k < NT; k++) {
             d4 Ya = cur.Ya[k];
@@ -1406,18 +1292,10 @@ k_forward_tiled(RecLayout L, CostSrc CS, KpSrc KP, int T, int n_alpha, const dou
         Zn = Pn(cur.Yb, dU, Zn, ncu);
         }
         __builtin_amdgcn_sched_barrier(0);
-        if constexpr (A4) {
-            if (t + 1 < T) {                     // A, B of step t+1 into the other half of the image (behind this step's reads of bimg)
-                trA.consume(); trB.consume();
-                trA.step(t + 1); trB.step(t + 1);
-                stage_AB(t + 1);
-                trA.issue(rT, T, strideB); trB.issue(rT, T, strideB);
-            }
-        } else {
 #pragma unroll
-            for (int k = 0; k < NT; k++) cur.Ya[k] = ld4(rR, oA[k]);
-            cur.Yb = ld4(rR, oB);
-        }
+        for (int k = 0; k < NT; k++) cur.Ya[k] = ld4(rR, oA[k]);
+        cur.Yb = ld4(rR, oB);
+    
         __builtin_amdgcn_sched_barrier(0);
         CYF(3)
         Zi = Zn;
@@ -1791,35 +1669,34 @@ bool forward_tiled_supported(int n, int m, int n_alpha, int nt_min)
     return nt >= 2 && nt <= 4 && m <= 16 && n_alpha <= 16;
 }
 
-template <int NT, bool A6, bool A4, int NCL>
+template <int NT, bool A6, int NCL>
 static hipError_t launch_ft3(Ctx *c, double *U_alpha_dev)
 {
     const CostSrc CS = {c->r, c->r_x, c->r_u, c->w_run, c->w_term, c->d.nr};
-    const KpSrc KP = {c->kp_offsets, c->kp_times, c->d.dof};
-    const size_t lds = sizeof(double) * ((size_t)(3 + (A6 ? 1 : 0)) * NT * TILE + NT * 64 + (A4 ? forward_a4_lds_doubles<NT>() : 0));
+    const size_t lds = sizeof(double) * ((size_t)(3 + (A6 ? 1 : 0)) * NT * TILE + NT * 64);
     if (lds > 64 * 1024) {
-        hipError_t e = hipFuncSetAttribute((const void *)k_forward_tiled<NT, A6, A4, NCL>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        hipError_t e = hipFuncSetAttribute((const void *)k_forward_tiled<NT, A6, NCL>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
         if (e != hipSuccess) return e;
     }
-    hipLaunchKernelGGL((k_forward_tiled<NT, A6, A4, NCL>), dim3(c->d.batch), dim3(64 * NT), lds, c->stream, c->L, CS, KP, c->d.T,
+    hipLaunchKernelGGL((k_forward_tiled<NT, A6, NCL>), dim3(c->d.batch), dim3(64 * NT), lds, c->stream, c->L, CS, c->d.T,
                        c->d.n_alpha, c->rec, c->K, c->k, c->u_nom, c->ctrl_lim, c->alphas, c->cost_pred, U_alpha_dev);
     return hipGetLastError();
 }
-template <int NT, bool A6, bool A4>
+template <int NT, bool A6>
 static hipError_t launch_ft2(Ctx *c, double *U_alpha_dev)
 {
     // materialised tiles, two row tiles: the interleaved chains, per chunk count of the last row tile (pushing 3.52 -> 3.41 ms, walker
     // 3.40 -> 3.19; with three tiles the same code is SLOWER, 4.98 -> 5.56 ms on light clutter n=38, so it stays with two)
-    if constexpr (!A6 && !A4 && NT == 2) {
+    if constexpr (!A6 && NT == 2) {
         const int rows = c->n + 2 - 16 * (NT - 1), ncl = rows >= 16 ? 4 : (rows + 3) / 4;
         if (c->tune.tiled_uw != 0) switch (ncl > 1 ? ncl : 1) {
-        case 1: return launch_ft3<NT, A6, A4, 1>(c, U_alpha_dev);
-        case 2: return launch_ft3<NT, A6, A4, 2>(c, U_alpha_dev);
-        case 3: return launch_ft3<NT, A6, A4, 3>(c, U_alpha_dev);
-        case 4: return launch_ft3<NT, A6, A4, 4>(c, U_alpha_dev);
+        case 1: return launch_ft3<NT, A6, 1>(c, U_alpha_dev);
+        case 2: return launch_ft3<NT, A6, 2>(c, U_alpha_dev);
+        case 3: return launch_ft3<NT, A6, 3>(c, U_alpha_dev);
+        case 4: return launch_ft3<NT, A6, 4>(c, U_alpha_dev);
         }
     }
-    return launch_ft3<NT, A6, A4, 0>(c, U_alpha_dev);
+    return launch_ft3<NT, A6, 0>(c, U_alpha_dev);
 }
 template <int NT, int NCL, int NCU>
 static hipError_t launch_ft_sc2(Ctx *c, double *U_alpha_dev)
@@ -1846,7 +1723,7 @@ static hipError_t launch_ft_sc(Ctx *c, double *U_alpha_dev)
 bool forward_tiled_sc_selected(const Ctx *c)
 {
     const int nt = tiled_nt(c->n, c->tune.tiled_nt_min);
-    if (nt != 2 || c->tiled_a4 || c->tiled_a6 || c->d.m > 8) return false;
+    if (nt != 2 || c->tiled_a6 || c->d.m > 8) return false;
     if (c->tune.tiled_fsc >= 0) return c->tune.tiled_fsc != 0;
     return 2 * nt * c->d.batch <= c->n_simd;
 }
@@ -1855,8 +1732,7 @@ template <int NT>
 static hipError_t launch_ft(Ctx *c, double *U_alpha_dev)
 {
     if constexpr (NT == 2) { if (forward_tiled_sc_selected(c)) return launch_ft_sc<NT>(c, U_alpha_dev); }
-    if (c->tiled_a4) return c->tiled_a6 ? launch_ft2<NT, true, true>(c, U_alpha_dev) : launch_ft2<NT, false, true>(c, U_alpha_dev);
-    return c->tiled_a6 ? launch_ft2<NT, true, false>(c, U_alpha_dev) : launch_ft2<NT, false, false>(c, U_alpha_dev);
+    return c->tiled_a6 ? launch_ft2<NT, true>(c, U_alpha_dev) : launch_ft2<NT, false>(c, U_alpha_dev);
 }
 
 hipError_t launch_forward_tiled(Ctx *c, double *U_alpha_dev)
@@ -1866,13 +1742,6 @@ hipError_t launch_forward_tiled(Ctx *c, double *U_alpha_dev)
     if (nt == 3) return launch_ft<3>(c, U_alpha_dev);
     if (nt == 4) return launch_ft<4>(c, U_alpha_dev);
     return hipErrorInvalidValue;
-}
-
-// a4 inside the tiled sweeps walks per-lane key-point lists over one buffer descriptor per trajectory
-bool tiled_a4_supported(int n, int m, int dof, int T, int stride)
-{
-    (void)n;
-    return m <= dof && (long long)T * stride * 8 < 0x7ffffff0LL;
 }
 
 }  // namespace kpilqr
