@@ -1282,7 +1282,6 @@ k_forward_tiled(RecLayout L, CostSrc CS, int T, int n_alpha, const double *__res
             __builtin_amdgcn_sched_barrier(0);
             partial += 0.5 * (Zi.x * Wz.x + Zi.y * Wz.y + Zi.z * Wz.z + Zi.w * Wz.w);
         }
-     // staged during step t-1 (before its closing barrier)
 #pragma unroll
         for (int k = 0; k < NT; k++) {
             d4 Ya = cur.Ya[k];
@@ -1295,7 +1294,6 @@ k_forward_tiled(RecLayout L, CostSrc CS, int T, int n_alpha, const double *__res
 #pragma unroll
         for (int k = 0; k < NT; k++) cur.Ya[k] = ld4(rR, oA[k]);
         cur.Yb = ld4(rR, oB);
-    
         __builtin_amdgcn_sched_barrier(0);
         CYF(3)
         Zi = Zn;
