@@ -371,6 +371,7 @@ __device__ __forceinline__ void backward_fused_body(double *sh, const double *pc
         okst[r] = (row < m && c == n) ? 8 * row : OOBF;
         lam2d[r] = (row == c && row < m) ? 2.0 * lam : 0.0;
     }
+    const d4 LamI = {0.5 * lam2d[0], 0.5 * lam2d[1], 0.5 * lam2d[2], 0.5 * lam2d[3]};     // lambda on the diagonal of the u-block
     const u64 mask_n = (c == n) ? ~0ull : 0ull, mask_u = (c < m) ? ~0ull : 0ull;
     const bool lane_nn = (c == n) && (q == (n & 3));
     constexpr int REG_NN = n >> 2;
@@ -728,8 +729,12 @@ __device__ __forceinline__ void backward_fused_body(double *sh, const double *pc
         const bool check_pd = pd_counter >= pd_stride;
 
         // ---- Tu = V' Fu ; Quu = l_uu + Fu' Tu --------------------------------------- :577
+        // (one wave per trajectory: the regularisation rides in the accumulator's initial value, Qr = (l_uu + lambda I) + Fu'Tu -- nothing
+        // downstream wants the un-regularised Quu: V' and delta_J are written on Qr, G and lambda below -- so the adds leave the chain
+        // behind the product: 4.15 -> 4.10 ms at B=1024.  The consumer wave of the pair measured 1 % SLOWER with it and keeps the adds.)
         d4 Tu = PS<NCZ>(V, Fu, zero);
-        d4 Quu = PS<NCZ>(Fu, Tu, Luu);
+        d4 Qr = PS<NCZ>(Fu, Tu, PC ? Luu : Luu + LamI);          // Quu (+ lambda I)
+        if constexpr (PC) { Qr.x += LamI.x; Qr.y += LamI.y; Qr.z += LamI.z; Qr.w += LamI.w; }
         // ---- Tz, Quz, Qzz --------------------------------------------------------------- :570-579
         d4 Quz, Qzz;
         if constexpr (SIDE) {
@@ -740,12 +745,10 @@ __device__ __forceinline__ void backward_fused_body(double *sh, const double *pc
             Qzz = PS<NCZ>(Fz, Tz, Lzz);
         }
 #ifdef KP_CYC
-        asm volatile("" :: "v"(Quu.x), "v"(Quz.x), "v"(Qzz.x));
+        asm volatile("" :: "v"(Qr.x), "v"(Quz.x), "v"(Qzz.x));
         const unsigned long long cyc_s1 = __builtin_readcyclecounter();
         cyc_b += cyc_s1 - cyc_s0;
 #endif
-        d4 Qr = Quu;                                  // Quu + lambda I
-        Qr.x += 0.5 * lam2d[0]; Qr.y += 0.5 * lam2d[1]; Qr.z += 0.5 * lam2d[2]; Qr.w += 0.5 * lam2d[3];
 
         // ---- X = (Quu + lambda I)^-1 Quz.  Fast path (KP_NS): the inverse changes little from one step to the next,
         //      so it is refreshed by Newton-Schulz steps Xinv <- Xinv + Xinv (I - Q Xinv) on the matrix core (4 MFMAs
@@ -845,10 +848,11 @@ __device__ __forceinline__ void backward_fused_body(double *sh, const double *pc
         // delta_J += k'Q_u + k'Q_uu k = -lambda k'k (:612-613): lanes of column n keep the squares of their rows,
         // the four row groups are added once after the sweep
         // (every lane accumulates; only the lanes of column n are read behind the sweep)
-        dJ -= lam * (Kp.x * Kp.x);
-        if (NCU > 1) dJ -= lam * (Kp.y * Kp.y);
-        if (NCU > 2) dJ -= lam * (Kp.z * Kp.z);
-        if (NCU > 3) dJ -= lam * (Kp.w * Kp.w);
+        // (the squares are summed, -lambda joins behind the sweep: one FMA per register and step)
+        dJ = __builtin_fma(Kp.x, Kp.x, dJ);
+        if (NCU > 1) dJ = __builtin_fma(Kp.y, Kp.y, dJ);
+        if (NCU > 2) dJ = __builtin_fma(Kp.z, Kp.z, dJ);
+        if (NCU > 3) dJ = __builtin_fma(Kp.w, Kp.w, dJ);
         // V' = Qzz + K'Quu K + K'Quz + Quz'K (:606-607) with K = -X, (Quu + lambda I) X = Quz:
         //    = Qzz - X'(Quz + lambda X) = Qzz + K'(Quz - lambda K)   -- one product; G = (Quu + 2 lambda I)K' is never formed
         d4 G;
@@ -963,6 +967,7 @@ __device__ __forceinline__ void backward_fused_body(double *sh, const double *pc
             for (int t = T - 2; t >= 0; t--) if (!step(t, std::false_type{})) break;
     }
     if constexpr (KP_BWD_LATE_STORE && !PC) { if (tst >= 0) store_gains(tst, Kst); }      // the last completed step
+    dJ *= -lam;
     dJ += __shfl_xor(dJ, 16);
     dJ += __shfl_xor(dJ, 32);
     if (lane_nn) delta_J[b] = dJ;
