@@ -79,6 +79,9 @@ typedef unsigned long long u64;
 #ifndef KP_KINK4
 #define KP_KINK4 1                  // 0: the step below a key-point refreshes the running inverse like every other step (round 3; A/B builds)
 #endif
+#ifndef KP_FWD_SQW
+#define KP_FWD_SQW 1                // 0: the headline's forward sweep scores on the unscaled r_x dx (round 4; A/B builds)
+#endif
 #ifndef KP_RXC_CXX
 #define KP_RXC_CXX 1                // 0: the RXC sweeps form Lzz = Rz' W Rz with four products at every step (round 4; A/B builds)
 #endif
@@ -1598,10 +1601,29 @@ __device__ __forceinline__ void forward_fused_body(RecLayout L, FusedArgs F, int
     // (the general form with control residuals keeps four sets: with six its largest shape spills -- 100 bytes of scratch, tools/isa_lint.py)
     constexpr int NS = UNI ? KP_FWD_SETS : (RU0 || KP_FWD_SETS_GEN < 4) ? KP_FWD_SETS_GEN : 4;
     Tiles S[NS];
-    d4 RxTc = {0.0, 0.0, 0.0, 0.0};
+    d4 RxTc = {0.0, 0.0, 0.0, 0.0}, RxTt = RxTc;
+    // SQW (round 5; constant r_x, no control residuals, uniform key-point sets -- the headline's forward sweep): the ROWS of the
+    // resident r_x are scaled by sqrt(w_k) once (a second tile carries the terminal weights), so the product gives Js = sqrt(w) Jx and
+    //     sum_k w_k Jx_k (2 r_k + Jx_k)  =  sum_k Js_k (2 sqrt(w_k) r_k + Js_k)
+    // is two FMAs per register instead of an add, a multiply, an FMA and the doubling of r: 8 VALU instructions less of the step's
+    // 79 (a lone wave pays for each).  sqrt(w) is correctly rounded; the costs move by ~1e-16 relative (held to the oracle at 1e-9).
+    constexpr bool SQW = KP_FWD_SQW && RXC && RU0 && UNI;
+    double s2run[4] = {0.0, 0.0, 0.0, 0.0}, s2term[4] = {0.0, 0.0, 0.0, 0.0};
+    (void)s2run; (void)s2term; (void)RxTt;
     if constexpr (RXC) {
         __amdgpu_buffer_rsrc_t rRxc = frsrc(F.rx_const, nr * n * 8);
         RxTc.x = fbld(rRxc, oRxT[0]); RxTc.y = fbld(rRxc, oRxT[1]); RxTc.z = fbld(rRxc, oRxT[2]); RxTc.w = fbld(rRxc, oRxT[3]);
+        if constexpr (SQW) {
+            // lane (c, q) of the operand tile holds r_x[k = c][p = 4r + q]: column c is residual c
+            const double swr = (c < nr) ? __builtin_sqrt(F.w_run[c]) : 0.0, swt = (c < nr) ? __builtin_sqrt(F.w_term[c]) : 0.0;
+            RxTt = RxTc * swt;
+            RxTc = RxTc * swr;
+#pragma unroll
+            for (int r = 0; r < 4; r++) {           // the scoring side: residual k = 4r + q in register r
+                s2run[r] = (4 * r + q < nr) ? 2.0 * __builtin_sqrt(F.w_run[4 * r + q]) : 0.0;
+                s2term[r] = (4 * r + q < nr) ? 2.0 * __builtin_sqrt(F.w_term[4 * r + q]) : 0.0;
+            }
+        }
     }
     (void)RxTc;
 #pragma unroll
@@ -1730,7 +1752,7 @@ __device__ __forceinline__ void forward_fused_body(RecLayout L, FusedArgs F, int
         Zn = PS<NCU>(Yb, dU, Zn);                      // + B du: the next state
         d4 Ju = zero;                                  // RU0: r_u = 0, the control residual term vanishes
         if constexpr (!RU0) Ju = PS<NCU>(cur.RuT, dU, zero);
-        const d4 Jx = PS<ncx>(RXC ? RxTc : cur.RxT, Z, zero);
+        const d4 Jx = PS<ncx>(RXC ? ((SQW && MODE == 3) ? RxTt : RxTc) : cur.RxT, Z, zero);     // (SQW: sqrt(w) Jx; terminal weights at the final step)
         Z = Zn;
         __builtin_amdgcn_sched_barrier(0);
         if constexpr (!RXC) { cur.RxT.x = fblds(rRx, oRxT[0], sRx); cur.RxT.y = fblds(rRx, oRxT[1], sRx); cur.RxT.z = fblds(rRx, oRxT[2], sRx); cur.RxT.w = fblds(rRx, oRxT[3], sRx); }
@@ -1787,7 +1809,13 @@ __device__ __forceinline__ void forward_fused_body(RecLayout L, FusedArgs F, int
             for (int r = 0; r < 4; r++) wcur[r] = wterm[r];
         }
         const d4 r2 = cur.rv + cur.rv;
-        if constexpr (RU0)                             // Ju = 0 exactly: its term adds a signed zero
+        if constexpr (SQW) {
+            const double *s2 = MODE == 3 ? s2term : s2run;
+            partial = __builtin_fma(Jx.x, __builtin_fma(s2[0], cur.rv.x, Jx.x), partial);
+            partial = __builtin_fma(Jx.y, __builtin_fma(s2[1], cur.rv.y, Jx.y), partial);
+            partial = __builtin_fma(Jx.z, __builtin_fma(s2[2], cur.rv.z, Jx.z), partial);
+            partial = __builtin_fma(Jx.w, __builtin_fma(s2[3], cur.rv.w, Jx.w), partial);
+        } else if constexpr (RU0)                      // Ju = 0 exactly: its term adds a signed zero
             partial += wcur[0] * (Jx.x * (r2.x + Jx.x)) + wcur[1] * (Jx.y * (r2.y + Jx.y))
                      + wcur[2] * (Jx.z * (r2.z + Jx.z)) + wcur[3] * (Jx.w * (r2.w + Jx.w));
         else
