@@ -362,6 +362,26 @@ def test_constant_residual_jacobians_mode_switches():
     assert np.array_equal(K, ref["K"]) and int(st.sum()) == 0
 
 
+def test_negative_residual_weights_on_the_constant_jacobian_sweeps(monkeypatch):
+    """The headline's forward sweep scores on rows of r_x scaled by sqrt|w| (round 5): a NEGATIVE weight -- legal, the reference
+    just forms w r^2 (ModelTranslator.cpp:314-327, 552-583) -- must keep its sign (the sign joins outside the root), running and
+    terminal weights with signs of their own.  One-wave forms forced (the batch would pick the pairs), against the oracle."""
+    monkeypatch.setenv("KPILQR_FUSED_WAVES", "1"); monkeypatch.setenv("KPILQR_FUSED_FWD_WAVES", "1")
+    p = synth.make_problem(task="panda_reaching", T=150, batch=3, min_N=5, lam=1.0)
+    p["w_run"] = p["w_run"].copy(); p["w_term"] = p["w_term"].copy()
+    p["w_run"][[2, 9]] *= -0.05                    # small negative weights on one position and one velocity residual ...
+    p["w_term"][[4]] *= -0.01                      # ... and another sign pattern at the terminal step
+    with Engine(p["dof"], p["m"], p["T"], p["nr"], batch=3, fused=True) as e:
+        synth.upload(e, p, kp_ordered=True, rx_const=True)
+        e.iterate(p["lam"], 100, orc.alphas(6))
+        res = e.results(); K, k = e.gains()
+        assert e.last_launch("forward").endswith(":w1:uni:ru0:rxc"), e.last_launch("forward")
+    for b in range(3):
+        o = pipeline.run_trajectory(p, b)
+        assert res["status"][b] == 0 and o["status"] == 0
+        assert relerr(K[b], o["K"]) < 1e-9 and relerr(res["cost_pred"][b], o["cost_pred"]) < 1e-9, (b, relerr(res["cost_pred"][b], o["cost_pred"]))
+
+
 def test_rejected_streamed_call_leaves_the_constant_jacobian_mode_alone():
     """Round-4 advisor: kpilqr_iterate_streamed used to leave the constant-Jacobian mode BEFORE the checks that can still reject
     the call; after a call refused for an unpinned r_x the next sweep read an r_x buffer that never received the broadcast copy.

@@ -1615,21 +1615,26 @@ __device__ __forceinline__ void forward_fused_body(RecLayout L, FusedArgs F, int
     //     sum_k w_k Jx_k (2 r_k + Jx_k)  =  sum_k Js_k (2 sqrt(w_k) r_k + Js_k)
     // is two FMAs per register instead of an add, a multiply, an FMA and the doubling of r: 8 VALU instructions less of the step's
     // 79 (a lone wave pays for each).  sqrt(w) is correctly rounded; the costs move by ~1e-16 relative (held to the oracle at 1e-9).
+    // A NEGATIVE weight (legal: the reference just forms w r^2) keeps its sign outside the root: the rows are scaled by sqrt|w_k|, every
+    // register accumulates its own residual's terms (acc4: register r of lane (c, q) is residual 4r + q throughout), and the signs
+    // join once, behind the sweep (the final step, whose terminal weights have signs of their own, is added with them directly).
     constexpr bool SQW = KP_FWD_SQW && RXC && RU0 && UNI;
-    double s2run[4] = {0.0, 0.0, 0.0, 0.0}, s2term[4] = {0.0, 0.0, 0.0, 0.0};
-    (void)s2run; (void)s2term; (void)RxTt;
+    double s2run[4] = {0.0, 0.0, 0.0, 0.0}, s2term[4] = {0.0, 0.0, 0.0, 0.0}, sgrun[4] = {1.0, 1.0, 1.0, 1.0}, sgterm[4] = {1.0, 1.0, 1.0, 1.0};
+    double acc4[4] = {0.0, 0.0, 0.0, 0.0};
+    (void)s2run; (void)s2term; (void)RxTt; (void)sgrun; (void)sgterm; (void)acc4;
     if constexpr (RXC) {
         __amdgpu_buffer_rsrc_t rRxc = frsrc(F.rx_const, nr * n * 8);
         RxTc.x = fbld(rRxc, oRxT[0]); RxTc.y = fbld(rRxc, oRxT[1]); RxTc.z = fbld(rRxc, oRxT[2]); RxTc.w = fbld(rRxc, oRxT[3]);
         if constexpr (SQW) {
             // lane (c, q) of the operand tile holds r_x[k = c][p = 4r + q]: column c is residual c
-            const double swr = (c < nr) ? __builtin_sqrt(F.w_run[c]) : 0.0, swt = (c < nr) ? __builtin_sqrt(F.w_term[c]) : 0.0;
+            const double swr = (c < nr) ? __builtin_sqrt(fabs(F.w_run[c])) : 0.0, swt = (c < nr) ? __builtin_sqrt(fabs(F.w_term[c])) : 0.0;
             RxTt = RxTc * swt;
             RxTc = RxTc * swr;
 #pragma unroll
             for (int r = 0; r < 4; r++) {           // the scoring side: residual k = 4r + q in register r
-                s2run[r] = (4 * r + q < nr) ? 2.0 * __builtin_sqrt(F.w_run[4 * r + q]) : 0.0;
-                s2term[r] = (4 * r + q < nr) ? 2.0 * __builtin_sqrt(F.w_term[4 * r + q]) : 0.0;
+                const double wr_ = (4 * r + q < nr) ? F.w_run[4 * r + q] : 0.0, wt_ = (4 * r + q < nr) ? F.w_term[4 * r + q] : 0.0;
+                s2run[r] = 2.0 * __builtin_sqrt(fabs(wr_)); sgrun[r] = wr_ < 0.0 ? -1.0 : 1.0;
+                s2term[r] = 2.0 * __builtin_sqrt(fabs(wt_)); sgterm[r] = wt_ < 0.0 ? -1.0 : 1.0;
             }
         }
     }
@@ -1829,11 +1834,15 @@ __device__ __forceinline__ void forward_fused_body(RecLayout L, FusedArgs F, int
         }
         const d4 r2 = cur.rv + cur.rv;
         if constexpr (SQW) {
-            const double *s2 = MODE == 3 ? s2term : s2run;
-            partial = __builtin_fma(Jx.x, __builtin_fma(s2[0], cur.rv.x, Jx.x), partial);
-            partial = __builtin_fma(Jx.y, __builtin_fma(s2[1], cur.rv.y, Jx.y), partial);
-            partial = __builtin_fma(Jx.z, __builtin_fma(s2[2], cur.rv.z, Jx.z), partial);
-            partial = __builtin_fma(Jx.w, __builtin_fma(s2[3], cur.rv.w, Jx.w), partial);
+            if constexpr (MODE == 3) {         // the final step: terminal weights, their signs applied on the spot
+                partial += sgterm[0] * (Jx.x * __builtin_fma(s2term[0], cur.rv.x, Jx.x)) + sgterm[1] * (Jx.y * __builtin_fma(s2term[1], cur.rv.y, Jx.y))
+                         + sgterm[2] * (Jx.z * __builtin_fma(s2term[2], cur.rv.z, Jx.z)) + sgterm[3] * (Jx.w * __builtin_fma(s2term[3], cur.rv.w, Jx.w));
+            } else {
+                acc4[0] = __builtin_fma(Jx.x, __builtin_fma(s2run[0], cur.rv.x, Jx.x), acc4[0]);
+                acc4[1] = __builtin_fma(Jx.y, __builtin_fma(s2run[1], cur.rv.y, Jx.y), acc4[1]);
+                acc4[2] = __builtin_fma(Jx.z, __builtin_fma(s2run[2], cur.rv.z, Jx.z), acc4[2]);
+                acc4[3] = __builtin_fma(Jx.w, __builtin_fma(s2run[3], cur.rv.w, Jx.w), acc4[3]);
+            }
         } else if constexpr (RU0)                      // Ju = 0 exactly: its term adds a signed zero
             partial += wcur[0] * (Jx.x * (r2.x + Jx.x)) + wcur[1] * (Jx.y * (r2.y + Jx.y))
                      + wcur[2] * (Jx.z * (r2.z + Jx.z)) + wcur[3] * (Jx.w * (r2.w + Jx.w));
@@ -1875,6 +1884,7 @@ __device__ __forceinline__ void forward_fused_body(RecLayout L, FusedArgs F, int
         for (; t + NS <= T; t += NS) fwd_steps<0, NS, 0>(step, t);
         fwd_tail<0, NS, 0>(step, t, T);
     }
+    if constexpr (SQW) partial += sgrun[0] * acc4[0] + sgrun[1] * acc4[1] + sgrun[2] * acc4[2] + sgrun[3] * acc4[3];
     partial += __shfl_xor(partial, 16);
     partial += __shfl_xor(partial, 32);
     if (q == 0 && c < n_alpha) cost_pred[(size_t)b * n_alpha + c] = partial;
