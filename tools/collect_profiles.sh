@@ -59,6 +59,12 @@ if [ "$MODE" != per_step ]; then
     echo "stats batch $bb done"
   done
 fi
+if [ "$MODE" != per_step ]; then
+  # the tiled shapes of BASELINE configs[2] and configs[4] (8 / 2 seeds tiled: nothing forks)
+  rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/stats_configs2 -- python3 $OLDPWD/bench.py --task panda_pushing --keypoints adaptive_jerk --batch 64 --T 3000 --tiled-seeds --no-secondary --no-cpu-baseline --steps 8 --warmup 2 > $OUT/stats_configs2.log 2>&1 || exit 1
+  rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/stats_configs4 -- python3 $OLDPWD/bench.py --task high_dof_push --keypoints iterative_error --batch 128 --T 5000 --tiled-seeds --no-secondary --no-cpu-baseline --steps 4 --warmup 1 > $OUT/stats_configs4.log 2>&1 || exit 1
+  echo "stats configs[2], configs[4] done"
+fi
 cd $OLDPWD
 python tools/pmc_summarise.py $OUT $TAG $MODE || exit 1
 echo "summaries written"

@@ -85,7 +85,8 @@ json.dump(cnt, open(os.path.join(root, "profiles", f"{tag}_pmc_counters{SUFFIX}.
 for sub, name in (("stats", f"{tag}_kernel_stats{SUFFIX}.csv"), ("stats_generic", f"{tag}_generic_kernel_stats.csv"),
                   ("stats_reach_velocity_change", f"{tag}_kernel_stats_velocity_change_lists.csv"),
                   ("stats_reach_adaptive_jerk", f"{tag}_kernel_stats_adaptive_jerk_lists.csv"),
-                  ("stats_b512", f"{tag}_kernel_stats_b512.csv"), ("stats_b256", f"{tag}_kernel_stats_b256.csv")):
+                  ("stats_b512", f"{tag}_kernel_stats_b512.csv"), ("stats_b256", f"{tag}_kernel_stats_b256.csv"),
+                  ("stats_configs2", f"{tag}_kernel_stats_configs2_pushing_b64.csv"), ("stats_configs4", f"{tag}_kernel_stats_configs4_n62_b128.csv")):
     fs = sorted(glob.glob(os.path.join(out, sub, "**", "*kernel_stats.csv"), recursive=True), key=os.path.getmtime)
     if fs:
         shutil.copy(fs[-1], os.path.join(root, "profiles", name))
