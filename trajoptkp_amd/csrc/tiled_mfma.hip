@@ -15,6 +15,9 @@
 #include <cstdlib>
 #include <type_traits>
 #include "mfma_common.h"
+#ifndef KP_COL_SPREAD
+#define KP_COL_SPREAD 1             // 0: the column kernel's requests as blocks (top of the step, behind the products): A/B builds
+#endif
 #ifndef KP_NS_HOLD
 #define KP_NS_HOLD 8                // factorised steps behind a Newton-Schulz refresh that gave up before the fast path is tried again
 #endif
@@ -76,63 +79,64 @@ __device__ __forceinline__ d4 Pk(int k, const d4 &Y, const d4 &X, d4 acc, int nc
 // Tile loaders (bounds-checked: structural zeros come back as 0).
 struct TileSrc { int n, m; int off_A, off_B, off_lxx, off_lx, off_luu, off_lu; };
 
+// (register r of a tile in the accumulator layout: element (16 ti + 4 r + q, 16 tj + c); the *1 loaders fetch one register, so that
+// a sweep can spread its requests under its products)
+__device__ __forceinline__ double ld_Lzz1(__amdgpu_buffer_rsrc_t rs, const TileSrc &S, int ti, int tj, int r, int q, int c)
+{
+    const int row = 16 * ti + 4 * r + q, col = 16 * tj + c, n = S.n;
+    const int off = (row < n && col < n) ? 8 * (S.off_lxx + row * n + col)
+                  : (col == n && row < n) ? 8 * (S.off_lx + row)
+                  : (row == n && col < n) ? 8 * (S.off_lx + col) : OOBT;
+    return tbld(rs, off);
+}
+__device__ __forceinline__ double ld_Fz1(__amdgpu_buffer_rsrc_t rs, const TileSrc &S, int ti, int tj, int r, int q, int c)
+{
+    const int row = 16 * ti + 4 * r + q, col = 16 * tj + c, n = S.n;
+    return tbld(rs, (row < n && col < n) ? 8 * (S.off_A + col * n + row) : OOBT);
+}
+__device__ __forceinline__ double ld_Fu1(__amdgpu_buffer_rsrc_t rs, const TileSrc &S, int ti, int r, int q, int c)
+{
+    const int row = 16 * ti + 4 * r + q;
+    return tbld(rs, (row < S.n && c < S.m) ? 8 * (S.off_B + c * S.n + row) : OOBT);
+}
+__device__ __forceinline__ double ld_Luz1(__amdgpu_buffer_rsrc_t rs, const TileSrc &S, int tj, int r, int q, int c)
+{
+    const int row = 4 * r + q, col = 16 * tj + c;
+    return tbld(rs, (row < S.m && col == S.n) ? 8 * (S.off_lu + row) : OOBT);
+}
+__device__ __forceinline__ double ld_Luu1(__amdgpu_buffer_rsrc_t rs, const TileSrc &S, int r, int q, int c)
+{
+    const int row = 4 * r + q;
+    return tbld(rs, (row < S.m && c < S.m) ? 8 * (S.off_luu + row * S.m + c) : OOBT);
+}
 __device__ __forceinline__ d4 ld_Lzz(__amdgpu_buffer_rsrc_t rs, const TileSrc &S, int ti, int tj, int q, int c)
 {
-    double v[4];
-#pragma unroll
-    for (int r = 0; r < 4; r++) {
-        const int row = 16 * ti + 4 * r + q, col = 16 * tj + c, n = S.n;
-        const int off = (row < n && col < n) ? 8 * (S.off_lxx + row * n + col)
-                      : (col == n && row < n) ? 8 * (S.off_lx + row)
-                      : (row == n && col < n) ? 8 * (S.off_lx + col) : OOBT;
-        v[r] = tbld(rs, off);
-    }
-    d4 o = {v[0], v[1], v[2], v[3]};
+    d4 o = {ld_Lzz1(rs, S, ti, tj, 0, q, c), ld_Lzz1(rs, S, ti, tj, 1, q, c), ld_Lzz1(rs, S, ti, tj, 2, q, c), ld_Lzz1(rs, S, ti, tj, 3, q, c)};
     return o;
 }
 __device__ __forceinline__ d4 ld_Fz(__amdgpu_buffer_rsrc_t rs, const TileSrc &S, int ti, int tj, int q, int c)
 {
-    double v[4];
-#pragma unroll
-    for (int r = 0; r < 4; r++) {
-        const int row = 16 * ti + 4 * r + q, col = 16 * tj + c, n = S.n;
-        v[r] = tbld(rs, (row < n && col < n) ? 8 * (S.off_A + col * n + row) : OOBT);
-    }
-    d4 o = {v[0], v[1], v[2], v[3]};
+    d4 o = {ld_Fz1(rs, S, ti, tj, 0, q, c), ld_Fz1(rs, S, ti, tj, 1, q, c), ld_Fz1(rs, S, ti, tj, 2, q, c), ld_Fz1(rs, S, ti, tj, 3, q, c)};
     return o;
 }
 __device__ __forceinline__ d4 ld_Fu(__amdgpu_buffer_rsrc_t rs, const TileSrc &S, int ti, int q, int c)
 {
-    double v[4];
-#pragma unroll
-    for (int r = 0; r < 4; r++) {
-        const int row = 16 * ti + 4 * r + q;
-        v[r] = tbld(rs, (row < S.n && c < S.m) ? 8 * (S.off_B + c * S.n + row) : OOBT);
-    }
-    d4 o = {v[0], v[1], v[2], v[3]};
+    d4 o = {ld_Fu1(rs, S, ti, 0, q, c), ld_Fu1(rs, S, ti, 1, q, c), ld_Fu1(rs, S, ti, 2, q, c), ld_Fu1(rs, S, ti, 3, q, c)};
     return o;
 }
 __device__ __forceinline__ d4 ld_Luz(__amdgpu_buffer_rsrc_t rs, const TileSrc &S, int tj, int q, int c)
 {
-    double v[4];
-#pragma unroll
-    for (int r = 0; r < 4; r++) {
-        const int row = 4 * r + q, col = 16 * tj + c;
-        v[r] = tbld(rs, (row < S.m && col == S.n) ? 8 * (S.off_lu + row) : OOBT);
-    }
-    d4 o = {v[0], v[1], v[2], v[3]};
+    d4 o = {ld_Luz1(rs, S, tj, 0, q, c), ld_Luz1(rs, S, tj, 1, q, c), ld_Luz1(rs, S, tj, 2, q, c), ld_Luz1(rs, S, tj, 3, q, c)};
     return o;
 }
 __device__ __forceinline__ d4 ld_Luu(__amdgpu_buffer_rsrc_t rs, const TileSrc &S, int q, int c)
 {
-    double v[4];
-#pragma unroll
-    for (int r = 0; r < 4; r++) {
-        const int row = 4 * r + q;
-        v[r] = tbld(rs, (row < S.m && c < S.m) ? 8 * (S.off_luu + row * S.m + c) : OOBT);
-    }
-    d4 o = {v[0], v[1], v[2], v[3]};
+    d4 o = {ld_Luu1(rs, S, 0, q, c), ld_Luu1(rs, S, 1, q, c), ld_Luu1(rs, S, 2, q, c), ld_Luu1(rs, S, 3, q, c)};
     return o;
+}
+__device__ __forceinline__ void setc(d4 &v, int r, double x)
+{
+    if (r == 0) v.x = x; else if (r == 1) v.y = x; else if (r == 2) v.z = x; else v.w = x;
 }
 
 // a6 inside the sweeps (KPILQR_FLAG_FUSED on a tiled shape): the cost tiles are formed from the residuals and their
@@ -142,39 +146,36 @@ __device__ __forceinline__ d4 ld_Luu(__amdgpu_buffer_rsrc_t rs, const TileSrc &S
 struct CostSrc { const double *r, *r_x, *r_u, *w_run, *w_term; int nr; };
 
 // element (res = 4r+q, col = 16*tj + c) of r_x [nr][n]
-__device__ __forceinline__ d4 ld_Rx(__amdgpu_buffer_rsrc_t rs, int n, int nr, int tj, int q, int c)
+__device__ __forceinline__ double ld_Rx1(__amdgpu_buffer_rsrc_t rs, int n, int nr, int tj, int r, int q, int c)
 {
-    double v[4];
-#pragma unroll
-    for (int r = 0; r < 4; r++) {
-        const int res = 4 * r + q, col = 16 * tj + c;
-        v[r] = tbld(rs, (res < nr && col < n) ? 8 * (res * n + col) : OOBT);
-    }
-    d4 o = {v[0], v[1], v[2], v[3]};
-    return o;
+    const int res = 4 * r + q, col = 16 * tj + c;
+    return tbld(rs, (res < nr && col < n) ? 8 * (res * n + col) : OOBT);
 }
 // r [nr] in column `cn` of a tile (the homogeneous column n lives in tile n>>4 at column n&15)
-__device__ __forceinline__ d4 ld_R1(__amdgpu_buffer_rsrc_t rs, int nr, int cn, int q, int c)
+__device__ __forceinline__ double ld_R11(__amdgpu_buffer_rsrc_t rs, int nr, int cn, int r, int q, int c)
 {
-    double v[4];
-#pragma unroll
-    for (int r = 0; r < 4; r++) {
-        const int res = 4 * r + q;
-        v[r] = tbld(rs, (res < nr && c == cn) ? 8 * res : OOBT);
-    }
-    d4 o = {v[0], v[1], v[2], v[3]};
-    return o;
+    const int res = 4 * r + q;
+    return tbld(rs, (res < nr && c == cn) ? 8 * res : OOBT);
 }
 // element (res, c) of r_u [nr][m]
+__device__ __forceinline__ double ld_Ru1(__amdgpu_buffer_rsrc_t rs, int m, int nr, int r, int q, int c)
+{
+    const int res = 4 * r + q;
+    return tbld(rs, (res < nr && c < m) ? 8 * (res * m + c) : OOBT);
+}
+__device__ __forceinline__ d4 ld_Rx(__amdgpu_buffer_rsrc_t rs, int n, int nr, int tj, int q, int c)
+{
+    d4 o = {ld_Rx1(rs, n, nr, tj, 0, q, c), ld_Rx1(rs, n, nr, tj, 1, q, c), ld_Rx1(rs, n, nr, tj, 2, q, c), ld_Rx1(rs, n, nr, tj, 3, q, c)};
+    return o;
+}
+__device__ __forceinline__ d4 ld_R1(__amdgpu_buffer_rsrc_t rs, int nr, int cn, int q, int c)
+{
+    d4 o = {ld_R11(rs, nr, cn, 0, q, c), ld_R11(rs, nr, cn, 1, q, c), ld_R11(rs, nr, cn, 2, q, c), ld_R11(rs, nr, cn, 3, q, c)};
+    return o;
+}
 __device__ __forceinline__ d4 ld_Ru(__amdgpu_buffer_rsrc_t rs, int m, int nr, int q, int c)
 {
-    double v[4];
-#pragma unroll
-    for (int r = 0; r < 4; r++) {
-        const int res = 4 * r + q;
-        v[r] = tbld(rs, (res < nr && c < m) ? 8 * (res * m + c) : OOBT);
-    }
-    d4 o = {v[0], v[1], v[2], v[3]};
+    d4 o = {ld_Ru1(rs, m, nr, 0, q, c), ld_Ru1(rs, m, nr, 1, q, c), ld_Ru1(rs, m, nr, 2, q, c), ld_Ru1(rs, m, nr, 3, q, c)};
     return o;
 }
 
@@ -212,6 +213,11 @@ k_backward_tiled_col(RecLayout L, CostSrc CS, int T, const double *__restrict__ 
     extern __shared__ __attribute__((aligned(16))) double sh[];
     constexpr int NCU = (M + 3) / 4;
     constexpr int NZZ = NT * NT;
+    // SPREAD: the requests for the next step's tiles go out one by one under the products of phase BC (round 5, late: as blocks of
+    // twenty at the top of the step and behind the products they were 1 000 + ~700 exposed cycles of a 21 100-cycle step -- the four
+    // waves of a trajectory share one address unit)
+    constexpr bool SPREAD = KP_COL_SPREAD && NCL > 0;
+    static_assert(!SPREAD || NT == 4, "the spread requests deal Fu over the NT row tiles: four registers");
     // M = 8 is the catch-all instantiation for any num_ctrl <= 8 (walker 6, hopper / pentabot 3, ...): the m x m system is
     // padded with identity rows to 8 x 8 for the (rare) per-lane LDL' steps; everything else works on tiles anyway.
     constexpr bool PAD = (M == 8);
@@ -293,6 +299,29 @@ k_backward_tiled_col(RecLayout L, CostSrc CS, int T, const double *__restrict__ 
             pLuz = ld_Luz(rs, S, w, q, c); pLuu = ld_Luu(rs, S, q, c);
         }
     };
+    // SPREAD: the same requests one register at a time -- request (k, r) of the Qzz loop: register r of pL[k] (k < ND) and, at the
+    // last k, of pLuz and pLuu; `rc`: the descriptors of the step (cost_rsrc)
+    __amdgpu_buffer_rsrc_t rc0 = __builtin_amdgcn_make_buffer_rsrc((void *)R0, 0, 0, 0x00020000), rc1 = rc0, rc2 = rc0;
+    auto cost_rsrc = [&](int t, bool ok) {
+        if (A6) {
+            const size_t tt = ok ? t : 0;
+            rc0 = __builtin_amdgcn_make_buffer_rsrc((void *)(rxb + tt * nr * n), 0, ok ? nr * n * 8 : 0, 0x00020000);
+            rc1 = __builtin_amdgcn_make_buffer_rsrc((void *)(rb + tt * nr), 0, ok ? nr * 8 : 0, 0x00020000);
+            rc2 = __builtin_amdgcn_make_buffer_rsrc((void *)(rub + tt * nr * m), 0, ok ? nr * m * 8 : 0, 0x00020000);
+        } else {
+            rc0 = ok ? rsrc_of(t) : __builtin_amdgcn_make_buffer_rsrc((void *)R0, 0, 0, 0x00020000);
+        }
+    };
+    auto cost_req = [&](int k, int r) {
+        if (A6) {
+            if (k < ND) setc(pL[k], r, ld_Rx1(rc0, n, nr, ti[k], r, q, c));
+            if (k == NT - 1) { setc(pLuz, r, ld_R11(rc1, nr, cn, r, q, c)); setc(pLuu, r, ld_Ru1(rc2, m, nr, r, q, c)); }
+        } else {
+            if (k < ND) setc(pL[k], r, ld_Lzz1(rc0, S, ti[k], w, r, q, c));
+            if (k == NT - 1) { setc(pLuz, r, ld_Luz1(rc0, S, w, r, q, c)); setc(pLuu, r, ld_Luu1(rc0, S, r, q, c)); }
+        }
+    };
+    (void)rc1; (void)rc2;
     // cost tiles of the step whose sources are in pL / pLuz / pLuu:  cL[d] = Lzz(ti[d],w), cLuz = Luz(w), cLuu
     d4 cL[ND], cLuz, cLuu;
     auto form_cost = [&](const d4 &W2) {
@@ -360,6 +389,7 @@ k_backward_tiled_col(RecLayout L, CostSrc CS, int T, const double *__restrict__ 
         const bool more = t > 0;
         __amdgpu_buffer_rsrc_t rn = more ? rsrc_of(t - 1) : __builtin_amdgcn_make_buffer_rsrc((void *)R0, 0, 0, 0x00020000);
         // ---- A: stage Fz(:,w) (+ the homogeneous 1) and Fu(w) ----------------------------------------------
+        CYK(10)
 #pragma unroll
         for (int k = 0; k < NT; k++) lds_store(bufF + (k * NT + w) * TILE, lane, pF[k]);
         // Fz(n,n) = 1: the loaded element is a structural zero, ONE lane of the wave that owns column n overwrites it (round 5: the
@@ -367,16 +397,19 @@ k_backward_tiled_col(RecLayout L, CostSrc CS, int T, const double *__restrict__ 
         if (w == tn && lane_nn) bufF[(tn * NT + w) * TILE + reg_nn * 64 + lane] = 1.0;
         lds_store(bufFu + w * TILE, lane, pFu);
         __builtin_amdgcn_sched_barrier(0);
+        CYK(9)
+        if constexpr (!SPREAD) {
 #pragma unroll
-        for (int k = 0; k < NT; k++) pF[k] = ld_Fz(rn, S, k, w, q, c);
-        pFu = ld_Fu(rn, S, w, q, c);
-    
+            for (int k = 0; k < NT; k++) pF[k] = ld_Fz(rn, S, k, w, q, c);
+            pFu = ld_Fu(rn, S, w, q, c);
+        }
         __builtin_amdgcn_sched_barrier(0);
         CYK(0)
         __syncthreads();
         CYK(1)
         // ---- BC: Tz(:,w), Tu(w), Quu partial, Quz(w), Qzz(:,w) ------------------------------------------------
         form_cost(t == T - 1 ? W2term : W2run);        // cL, cLuz, cLuu of this step (A6: from the residual tiles)
+        if constexpr (SPREAD) cost_rsrc(t - 1, more);
         d4 Fc[NT], Tz[NT], Qzz[ND];
         d4 Quzw = cLuz;                                                     // Quz(w): also kept in registers for the fast path
 #pragma unroll
@@ -400,6 +433,17 @@ k_backward_tiled_col(RecLayout L, CostSrc CS, int T, const double *__restrict__ 
 #pragma unroll
                     for (int i = 0; i < NT; i++) Tz[i] = MFMA(comp(Vk[i], r), comp(Fc[k], r), Tz[i]);
                     Tu = MFMA(comp(Vw, r), comp(Fuk, r), Tu);
+                    if constexpr (SPREAD) {         // the next step's Fz(k,w), Fu(w): one request under every group of products
+                        setc(pF[k], r, ld_Fz1(rn, S, k, w, r, q, c));
+                        if (r == 0) setc(pFu, k, ld_Fu1(rn, S, w, k, q, c));
+                        __builtin_amdgcn_sched_group_barrier(0x008, NT + 1, 0);
+                        if (r == 0) __builtin_amdgcn_sched_group_barrier(0x020, 2, 0);
+                        else __builtin_amdgcn_sched_group_barrier(0x020, 1, 0);
+                    }
+                }
+                if constexpr (SPREAD) {
+#pragma unroll
+                    for (int r = nck(k); r < 4; r++) setc(pF[k], r, 0.0);       // (chunks of the last row tile that hold no rows of z)
                 }
             }
             lds_store(bufQp + w * TILE, lane, Pn(lds_tile(bufFu + w * TILE, lane), Tu, (A6 && w == 0) ? cLuu : zero, ncw));
@@ -416,6 +460,16 @@ k_backward_tiled_col(RecLayout L, CostSrc CS, int T, const double *__restrict__ 
                     Quzw = MFMA(comp(Fuk, r), comp(Tz[k], r), Quzw);
 #pragma unroll
                     for (int d = 0; d < ND; d++) Qzz[d] = MFMA(comp(Fk[d], r), comp(Tz[k], r), Qzz[d]);
+                    if constexpr (SPREAD) {         // the next step's cost sources (this step's were consumed by form_cost above)
+                        cost_req(k, r);
+                        __builtin_amdgcn_sched_group_barrier(0x008, ND + 1, 0);
+                        if (k == NT - 1) __builtin_amdgcn_sched_group_barrier(0x020, (NT - 1 < ND) ? 3 : 2, 0);
+                        else if (k < ND) __builtin_amdgcn_sched_group_barrier(0x020, 1, 0);
+                    }
+                }
+                if constexpr (SPREAD) {
+#pragma unroll
+                    for (int r = nck(k); r < 4; r++) cost_req(k, r);
                 }
             }
             lds_store(bufQuz + w * TILE, lane, Quzw);
@@ -447,7 +501,7 @@ k_backward_tiled_col(RecLayout L, CostSrc CS, int T, const double *__restrict__ 
         }
         const d4 Luu_t = cLuu;
         __builtin_amdgcn_sched_barrier(0);
-        load_cost(t - 1, more);
+        if constexpr (!SPREAD) load_cost(t - 1, more);
         __builtin_amdgcn_sched_barrier(0);
         CYK(2)
         __syncthreads();
@@ -566,8 +620,8 @@ k_backward_tiled_col(RecLayout L, CostSrc CS, int T, const double *__restrict__ 
         CYK(8)
     }
 #ifdef KP_CYC_COL
-    if (b == 0 && lane == 0) printf("col wave %d: A %lld | wait1 %lld | BC %lld | wait2 %lld | D %lld | wait3 %lld | EF %lld  (cycles per step)\n", w,
-                                    cyc[0] / T, cyc[1] / T, cyc[2] / T, cyc[3] / T, cyc[4] / T, cyc[5] / T, cyc[8] / T);
+    if (b == 1 && lane == 0) printf("col wave %d: top %lld stage %lld | A %lld | wait1 %lld | BC %lld | wait2 %lld | D %lld | wait3 %lld | EF %lld  (cycles per step)\n", w,
+                                    cyc[10] / T, cyc[9] / T, cyc[0] / T, cyc[1] / T, cyc[2] / T, cyc[3] / T, cyc[4] / T, cyc[5] / T, cyc[8] / T);
 #endif
     dJ += __shfl_xor(dJ, 16);
     dJ += __shfl_xor(dJ, 32);
