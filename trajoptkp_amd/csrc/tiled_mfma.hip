@@ -15,6 +15,9 @@
 #include <cstdlib>
 #include <type_traits>
 #include "mfma_common.h"
+#ifndef KP_FT_SPREAD
+#define KP_FT_SPREAD 1              // 0: the four-tile forward sweep's requests as blocks behind the products: A/B builds
+#endif
 #ifndef KP_COL_SPREAD
 #define KP_COL_SPREAD 1             // 0: the column kernel's requests as blocks (top of the step, behind the products): A/B builds
 #endif
@@ -1212,13 +1215,26 @@ k_forward_tiled(RecLayout L, CostSrc CS, int T, int n_alpha, const double *__res
     // so the step time WAS that trip.  NS = 2 where the tiles are materialised and the chunk counts compile-time (NCL > 0);
     // every step is instantiated with its set as a compile-time constant (no copies between sets).
     constexpr int NS = (NCL > 0 && !A6) ? KP_FT_SETS : 1;
+    // FSPREAD (a6 inside, compile-time chunk counts; round 5, late): the requests for the next step's tiles go out one by one under
+    // the products instead of in blocks behind them (the four waves of a trajectory share one address unit: a block of twenty
+    // requests per wave stood ~1 600 cycles in front of it), registers that hold structural zeros only are not requested, k rides in
+    // ONE request (the lanes of row n) and joins the gain operand at its use instead of behind the request
+    constexpr bool FSPREAD = KP_FT_SPREAD && NCL > 0 && A6;
+    const bool k_here = tnz == wi;
+    const int okn = (k_here && q == (n & 3) && c < m) ? 8 * c : OOBT;
+    double kmask[4];
+#pragma unroll
+    for (int r = 0; r < 4; r++) kmask[r] = (r == ((n & 15) >> 2)) ? 1.0 : 0.0;
+    double kv = 0.0;
+    (void)okn; (void)kmask; (void)kv;
     Tiles S[NS];
 #pragma unroll
     for (int s0 = 0; s0 < NS; s0++) {
         Tiles &cur = S[s0];
         __amdgpu_buffer_rsrc_t rR = rs_of(rec, L.stride, s0, rec_bytes), rK = rs_of(Kin, (size_t)m * n, s0, m * n * 8);
         __amdgpu_buffer_rsrc_t rk = rs_of(kin, m, s0, m * 8), ru = rs_of(u_nom, m, s0, m * 8);
-        cur.Ykw = ld4(rK, oKw) + ld4(rk, okw);
+        if constexpr (FSPREAD) { cur.Ykw = ld4(rK, oKw); kv = tbld(rk, okn); }
+        else cur.Ykw = ld4(rK, oKw) + ld4(rk, okw);
 #pragma unroll
         for (int k = 0; k < NT; k++) { cur.Ya[k] = ld4(rR, oA[k]); if (!A6) cur.Lc[k] = ld4(rR, oLc[k]); }
         cur.Yb = ld4(rR, oB);
@@ -1245,12 +1261,35 @@ k_forward_tiled(RecLayout L, CostSrc CS, int T, int n_alpha, const double *__res
         const double *zc = zbuf[t & 1];
         double *zn = zbuf[(t + 1) & 1];
         // ---- this wave's slice of K dx + alpha k -------------------------------------------------------------
+        if constexpr (FSPREAD) {
+            auto comp = [](const d4 &v, int r) { return r == 0 ? v.x : r == 1 ? v.y : r == 2 ? v.z : v.w; };
+            const __amdgpu_buffer_rsrc_t rX = rs_res(rxb, (size_t)nr * n, tq, nr * n * 8);
+            d4 Yk = cur.Ykw;                                  // K' rows of this wave's slice; + k' in row n
+            Yk.x = __builtin_fma(kmask[0], kv, Yk.x); Yk.y = __builtin_fma(kmask[1], kv, Yk.y);
+            Yk.z = __builtin_fma(kmask[2], kv, Yk.z); Yk.w = __builtin_fma(kmask[3], kv, Yk.w);
+            d4 Us = zero, Js = zero;
+            // (every request unconditional: a request behind a wave-uniform branch meets the register's old value at the join, and the
+            // copy that merges them waits for EVERY request in flight -- measured: the last wave's scoring phase 1 560 -> 4 480 cycles)
+#pragma unroll
+            for (int r = 0; r < 4; r++) {
+                if (r < ncw) {                                // (wave-uniform: only the last row tile is short)
+                    Us = MFMA(comp(Yk, r), comp(Zi, r), Us);
+                    Js = MFMA(comp(cur.Lc[0], r), comp(Zi, r), Js);
+                }
+                setc(cur.Ykw, r, tbld(rK, oKw[r]));
+                setc(cur.Lc[0], r, tbld(rX, oRxT[r]));
+            }
+            kv = tbld(rk, okn);
+            lds_store(upart + wi * TILE, lane, Us);
+            lds_store(jpart + wi * TILE, lane, Js);
+        } else {
         lds_store(upart + wi * TILE, lane, Pn(cur.Ykw, Zi, zero, ncw));
         if (A6) lds_store(jpart + wi * TILE, lane, Pn(cur.Lc[0], Zi, zero, ncw));        // this wave's slice of r_x dx
         __builtin_amdgcn_sched_barrier(0);
         cur.Ykw = ld4(rK, oKw) + ld4(rk, okw);
         if (A6) cur.Lc[0] = ld4(rs_res(rxb, (size_t)nr * n, tq, nr * n * 8), oRxT);
         __builtin_amdgcn_sched_barrier(0);
+        }
         CYF(0)
         __syncthreads();
         CYF(1)
@@ -1307,7 +1346,28 @@ k_forward_tiled(RecLayout L, CostSrc CS, int T, int n_alpha, const double *__res
         CYF(2)
         // ---- state cost rows of this tile, then the linearised dynamics for this tile ------------------------------
         d4 Wz = zero, Zn = zero;
-        if constexpr (NCL > 0 && !A6) {
+        if constexpr (FSPREAD) {
+            auto nck = [](int kt) { return kt < NT - 1 ? 4 : NCL; };
+            auto comp = [](const d4 &v, int r) { return r == 0 ? v.x : r == 1 ? v.y : r == 2 ? v.z : v.w; };
+#pragma unroll
+            for (int k = 0; k < NT; k++) {
+                d4 Ya = cur.Ya[k];
+                if (k == tnz) { Ya.x += oneT[0]; Ya.y += oneT[1]; Ya.z += oneT[2]; Ya.w += oneT[3]; }
+#pragma unroll
+                for (int r = 0; r < nck(k); r++) {
+                    Zn = MFMA(comp(Ya, r), comp(Zk[k], r), Zn);
+                    setc(cur.Ya[k], r, tbld(rR, oA[k][r]));
+                    __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+                    __builtin_amdgcn_sched_group_barrier(0x020, 1, 0);
+                }
+            }
+#pragma unroll
+            for (int r = 0; r < 4; r++)
+            {
+                if (r < ncu) Zn = MFMA(comp(cur.Yb, r), comp(dU, r), Zn);
+                setc(cur.Yb, r, tbld(rR, oB[r]));
+            }
+        } else if constexpr (NCL > 0 && !A6) {
             auto nck = [](int kt) { return kt < NT - 1 ? 4 : NCL; };
             auto comp = [](const d4 &v, int r) { return r == 0 ? v.x : r == 1 ? v.y : r == 2 ? v.z : v.w; };
 #pragma unroll
@@ -1345,9 +1405,11 @@ k_forward_tiled(RecLayout L, CostSrc CS, int T, int n_alpha, const double *__res
         Zn = Pn(cur.Yb, dU, Zn, ncu);
         }
         __builtin_amdgcn_sched_barrier(0);
+        if constexpr (!FSPREAD) {
 #pragma unroll
-        for (int k = 0; k < NT; k++) cur.Ya[k] = ld4(rR, oA[k]);
-        cur.Yb = ld4(rR, oB);
+            for (int k = 0; k < NT; k++) cur.Ya[k] = ld4(rR, oA[k]);
+            cur.Yb = ld4(rR, oB);
+        }
         __builtin_amdgcn_sched_barrier(0);
         CYF(3)
         Zi = Zn;
@@ -1739,7 +1801,7 @@ static hipError_t launch_ft2(Ctx *c, double *U_alpha_dev)
 {
     // materialised tiles, two row tiles: the interleaved chains, per chunk count of the last row tile (pushing 3.52 -> 3.41 ms, walker
     // 3.40 -> 3.19; with three tiles the same code is SLOWER, 4.98 -> 5.56 ms on light clutter n=38, so it stays with two)
-    if constexpr (!A6 && NT == 2) {
+    if constexpr ((!A6 && NT == 2) || (A6 && NT == 4)) {
         const int rows = c->n + 2 - 16 * (NT - 1), ncl = rows >= 16 ? 4 : (rows + 3) / 4;
         if (c->tune.tiled_uw != 0) switch (ncl > 1 ? ncl : 1) {
         case 1: return launch_ft3<NT, A6, 1>(c, U_alpha_dev);
