@@ -882,6 +882,28 @@ def test_tiled_running_inverse_on_smooth_residual_jacobians(task, T, uw, monkeyp
     check_fused(g, p, ref)
 
 
+@pytest.mark.parametrize("task", ["clutter_n48", "clutter_n52", "clutter_n56", "high_dof_push"])
+@pytest.mark.parametrize("residuals", ["smooth", True])
+def test_four_tile_sweeps_at_every_chunk_count(task, residuals, monkeypatch):
+    """The four-tile sweeps are instantiated per count of four-row chunks in the last row tile (1 .. 4: n = 48, 52, 56, 62) -- the
+    forms whose requests go out one by one under the products (round 5).  Materialised and with a6 inside, residual Jacobians
+    smooth (running inverse) and drawn per step (every step factorises), against the oracle."""
+    monkeypatch.setenv("KPILQR_TILED_A6", "1")
+    p = synth.make_problem(task=task, T=70, batch=2, min_N=4, dense_residuals=residuals, one_sided_frac=0.1)
+    ref = [pipeline.run_trajectory(p, b, want_U=True) for b in range(2)]
+    g = run_engine(p)
+    assert g["variants"][0] == "mfma_f64_tiled", g["variants"]
+    check_fused(g, p, ref)
+    with Engine(p["dof"], p["m"], p["T"], p["nr"], batch=2, fused=True) as e:      # a6 inside the sweeps
+        assert e.backward_variant == "mfma_f64_tiled_a6"
+        synth.upload(e, p)
+        e.iterate(p["lam"], 100, orc.alphas(6))
+        res = e.results()
+        g = dict(status=res["status"], delta_J=res["delta_J"], cost_pred=res["cost_pred"], U_alpha=None)
+        g["K"], g["k"] = e.gains()
+    check_fused(g, p, ref)
+
+
 @pytest.mark.parametrize("task,T", [("panda_pushing", 20), ("walker", 24), ("light_clutter_push", 20)])
 @pytest.mark.parametrize("uw", ["1", "0"])
 def test_tiled_indefinite_quu_on_unchecked_steps(task, T, uw, monkeypatch):

@@ -15,6 +15,9 @@
 #include <cstdlib>
 #include <type_traits>
 #include "mfma_common.h"
+#ifndef KP_UW_SPREAD
+#define KP_UW_SPREAD 1              // 0: the u-wave kernel's requests as blocks behind the products: A/B builds
+#endif
 #ifndef KP_FT_SPREAD
 #define KP_FT_SPREAD 1              // 0: the four-tile forward sweep's requests as blocks behind the products: A/B builds
 #endif
@@ -789,11 +792,19 @@ k_backward_tiled_uw(RecLayout L, int T, const double *__restrict__ rec, const do
 #pragma unroll
             for (int r = 0; r < 4; r++)
 #pragma unroll
-                for (int i = 0; i < NT; i++)
+                for (int i = 0; i < NT; i++) {
                     if (r < nck(i)) Qp[i] = MFMA(comp(pFu[i], r), comp(Tu[i], r), Qp[i]);
+                    if constexpr (KP_UW_SPREAD) {   // the next step's Fu, register by register behind its last use (see k_backward_tiled_col)
+                        setc(pFu[i], r, tbld(rn, oFu[i][r]));
+                        if (r < nck(i)) __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+                        __builtin_amdgcn_sched_group_barrier(0x020, 1, 0);
+                    }
+                }
             __builtin_amdgcn_sched_barrier(0);
+            if constexpr (!KP_UW_SPREAD) {
 #pragma unroll
-            for (int k = 0; k < NT; k++) pFu[k] = ld4(rn, oFu[k]);
+                for (int k = 0; k < NT; k++) pFu[k] = ld4(rn, oFu[k]);
+            }
             __builtin_amdgcn_sched_barrier(0);
             CYC(7)
             __syncthreads();                                       // (the column waves' Fz, Fu are in LDS: not used here)
@@ -951,13 +962,42 @@ k_backward_tiled_uw(RecLayout L, int T, const double *__restrict__ rec, const do
                     Y[k] = pF[k];
                     if (k == tn && w == tn) Y[k] = Y[k] + nn_one;          // Fz(n,n) = 1
                 }
+                if constexpr (KP_UW_SPREAD) {
+                    // VtY with the next step's requests one by one under the products (see k_backward_tiled_col): Fz(k,w) register r
+                    // behind the products that read it (from Y, its copy), Fu(w) under the first row tile
+                    const d4 Fuw = pFu;
+#pragma unroll
+                    for (int i = 0; i < NT; i++) Tz[i] = zero;
+#pragma unroll
+                    for (int k = 0; k < NT; k++) {
+                        d4 Vk[NT];
+#pragma unroll
+                        for (int i = 0; i < NT; i++) Vk[i] = lds_tile(bufV + (k * NT + i) * TILE, lane);
+#pragma unroll
+                        for (int r = 0; r < 4; r++) {
+                            if (r < nck(k)) {
+#pragma unroll
+                                for (int i = 0; i < NT; i++) Tz[i] = MFMA(comp(Vk[i], r), comp(Y[k], r), Tz[i]);
+                                __builtin_amdgcn_sched_group_barrier(0x008, NT, 0);
+                            }
+                            setc(pF[k], r, tbld(rn, oF[k][r]));
+                            if (k == 0) setc(pFu, r, tbld(rn, oFu[r]));
+                            if (k == 0) __builtin_amdgcn_sched_group_barrier(0x020, 2, 0);
+                            else __builtin_amdgcn_sched_group_barrier(0x020, 1, 0);
+                        }
+                    }
+#pragma unroll
+                    for (int k = 0; k < NT; k++) lds_store(bufF + (k * NT + w) * TILE, lane, Y[k]);
+                    lds_store(bufFu + w * TILE, lane, Fuw);
+                } else {
                 VtY(Y, Tz);
 #pragma unroll
                 for (int k = 0; k < NT; k++) lds_store(bufF + (k * NT + w) * TILE, lane, Y[k]);
                 lds_store(bufFu + w * TILE, lane, pFu);
+                }
             }
             __builtin_amdgcn_sched_barrier(0);
-            request(rn);
+            if constexpr (!KP_UW_SPREAD) request(rn);
             __builtin_amdgcn_sched_barrier(0);
             CYC(7)
             __syncthreads();                                       // every wave's Fz, Fu are in LDS
@@ -966,6 +1006,11 @@ k_backward_tiled_uw(RecLayout L, int T, const double *__restrict__ rec, const do
             d4 Quzw = zero, Qzz[ND];
 #pragma unroll
             for (int d = 0; d < ND; d++) Qzz[d] = zero;
+            if constexpr (KP_UW_SPREAD) {       // the cost tiles start the chains (requested a step ago), their registers are free for the next step's
+                Quzw = pLuz;
+#pragma unroll
+                for (int d = 0; d < ND; d++) Qzz[d] = pL[d];
+            }
 #pragma unroll
             for (int k = 0; k < NT; k++) {
                 d4 Fk[ND];
@@ -973,18 +1018,29 @@ k_backward_tiled_uw(RecLayout L, int T, const double *__restrict__ rec, const do
 #pragma unroll
                 for (int d = 0; d < ND; d++) Fk[d] = lds_tile(bufF + (k * NT + ti[d]) * TILE, lane);
 #pragma unroll
-                for (int r = 0; r < nck(k); r++) {
-                    Quzw = MFMA(comp(Fuk, r), comp(Tz[k], r), Quzw);
+                for (int r = 0; r < 4; r++) {
+                    if (r < nck(k)) {
+                        Quzw = MFMA(comp(Fuk, r), comp(Tz[k], r), Quzw);
 #pragma unroll
-                    for (int d = 0; d < ND; d++) Qzz[d] = MFMA(comp(Fk[d], r), comp(Tz[k], r), Qzz[d]);
+                        for (int d = 0; d < ND; d++) Qzz[d] = MFMA(comp(Fk[d], r), comp(Tz[k], r), Qzz[d]);
+                        if constexpr (KP_UW_SPREAD) __builtin_amdgcn_sched_group_barrier(0x008, ND + 1, 0);
+                    }
+                    if constexpr (KP_UW_SPREAD) {               // request (k, r): register r of pL[k] (k < ND) and, at k = NT-1, of pLuz
+                        if (k < ND) setc(pL[k], r, tbld(rn, oL[k][r]));
+                        if (k == NT - 1) setc(pLuz, r, tbld(rn, oLuz[r]));
+                        if (k < ND && k == NT - 1) __builtin_amdgcn_sched_group_barrier(0x020, 2, 0);
+                        else if (k < ND || k == NT - 1) __builtin_amdgcn_sched_group_barrier(0x020, 1, 0);
+                    }
                 }
             }
+            if constexpr (!KP_UW_SPREAD) {
             Quzw = Quzw + pLuz;
 #pragma unroll
             for (int d = 0; d < ND; d++) Qzz[d] = Qzz[d] + pL[d];
+            }
             CYC(8)
             __builtin_amdgcn_sched_barrier(0);
-            request_cost(rn);                                      // (issued while the u-wave still refreshes the inverse)
+            if constexpr (!KP_UW_SPREAD) request_cost(rn);         // (issued while the u-wave still refreshes the inverse)
             __builtin_amdgcn_sched_barrier(0);
             CYC(2)
             __syncthreads();                                       // the inverse and the verdict are out

@@ -25,6 +25,14 @@ TASKS = {
     # TaskConfigs/rigid_body_manipulation/twoD_push_light_clutter.yaml: 7 joints + 4 bodies x 3 (n = 38: three tiles)
     "light_clutter_push": dict(dof=19, m=7, nr=7, dt=0.008, lim=[87, 87, 87, 87, 12, 12, 12],
                                w_run=[1.0, 0.5] + [0.1] * 5, w_term=[100.0, 50.0] + [1.0] * 5),
+    # four state tiles with 1, 2, 3 four-row chunks in the last one (n = 48, 52, 56; high_dof_push has 4): synthetic clutter scenes that
+    # exist to instantiate the four-tile kernels' compile-time chunk counts
+    "clutter_n48": dict(dof=24, m=7, nr=7, dt=0.008, lim=[87, 87, 87, 87, 12, 12, 12],
+                        w_run=[1.0, 0.5] + [0.1] * 5, w_term=[100.0, 50.0] + [1.0] * 5),
+    "clutter_n52": dict(dof=26, m=7, nr=7, dt=0.008, lim=[87, 87, 87, 87, 12, 12, 12],
+                        w_run=[1.0, 0.5] + [0.1] * 5, w_term=[100.0, 50.0] + [1.0] * 5),
+    "clutter_n56": dict(dof=28, m=7, nr=7, dt=0.008, lim=[87, 87, 87, 87, 12, 12, 12],
+                        w_run=[1.0, 0.5] + [0.1] * 5, w_term=[100.0, 50.0] + [1.0] * 5),
     # other control dimensions among the reference's task plugins (joint / actuator counts of
     # TaskConfigs/locomotion/walk_plane.yaml, locomotion/hopper.yaml, toys/pentabot.yaml); weights synthetic
     "walker": dict(dof=9, m=6, nr=4, dt=0.005, lim=[1.0] * 6,
