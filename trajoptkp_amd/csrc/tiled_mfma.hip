@@ -1275,7 +1275,7 @@ k_forward_tiled(RecLayout L, CostSrc CS, int T, int n_alpha, const double *__res
     // the products instead of in blocks behind them (the four waves of a trajectory share one address unit: a block of twenty
     // requests per wave stood ~1 600 cycles in front of it), registers that hold structural zeros only are not requested, k rides in
     // ONE request (the lanes of row n) and joins the gain operand at its use instead of behind the request
-    constexpr bool FSPREAD = KP_FT_SPREAD && NCL > 0 && A6;
+    constexpr bool FSPREAD = KP_FT_SPREAD && NCL > 0 && (A6 || NT > 2);       // (two tiles, materialised: 3.54 against 3.37 ms on pushing -- stays with the blocks)
     const bool k_here = tnz == wi;
     const int okn = (k_here && q == (n & 3) && c < m) ? 8 * c : OOBT;
     double kmask[4];
@@ -1330,14 +1330,14 @@ k_forward_tiled(RecLayout L, CostSrc CS, int T, int n_alpha, const double *__res
             for (int r = 0; r < 4; r++) {
                 if (r < ncw) {                                // (wave-uniform: only the last row tile is short)
                     Us = MFMA(comp(Yk, r), comp(Zi, r), Us);
-                    Js = MFMA(comp(cur.Lc[0], r), comp(Zi, r), Js);
+                    if (A6) Js = MFMA(comp(cur.Lc[0], r), comp(Zi, r), Js);
                 }
                 setc(cur.Ykw, r, tbld(rK, oKw[r]));
-                setc(cur.Lc[0], r, tbld(rX, oRxT[r]));
+                if (A6) setc(cur.Lc[0], r, tbld(rX, oRxT[r]));
             }
             kv = tbld(rk, okn);
             lds_store(upart + wi * TILE, lane, Us);
-            lds_store(jpart + wi * TILE, lane, Js);
+            if (A6) lds_store(jpart + wi * TILE, lane, Js);
         } else {
         lds_store(upart + wi * TILE, lane, Pn(cur.Ykw, Zi, zero, ncw));
         if (A6) lds_store(jpart + wi * TILE, lane, Pn(cur.Lc[0], Zi, zero, ncw));        // this wave's slice of r_x dx
@@ -1412,9 +1412,16 @@ k_forward_tiled(RecLayout L, CostSrc CS, int T, int n_alpha, const double *__res
 #pragma unroll
                 for (int r = 0; r < nck(k); r++) {
                     Zn = MFMA(comp(Ya, r), comp(Zk[k], r), Zn);
+                    if (!A6) Wz = MFMA(comp(cur.Lc[k], r), comp(Zk[k], r), Wz);
                     setc(cur.Ya[k], r, tbld(rR, oA[k][r]));
-                    __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
-                    __builtin_amdgcn_sched_group_barrier(0x020, 1, 0);
+                    if (!A6) setc(cur.Lc[k], r, tbld(rR, oLc[k][r]));
+                    __builtin_amdgcn_sched_group_barrier(0x008, A6 ? 1 : 2, 0);
+                    __builtin_amdgcn_sched_group_barrier(0x020, A6 ? 1 : 2, 0);
+                }
+#pragma unroll
+                for (int r = nck(k); r < 4; r++) {            // (chunks of the last row tile that hold no rows of z: structural zeros)
+                    setc(cur.Ya[k], r, 0.0);
+                    if (!A6) setc(cur.Lc[k], r, 0.0);
                 }
             }
 #pragma unroll
@@ -1423,6 +1430,7 @@ k_forward_tiled(RecLayout L, CostSrc CS, int T, int n_alpha, const double *__res
                 if (r < ncu) Zn = MFMA(comp(cur.Yb, r), comp(dU, r), Zn);
                 setc(cur.Yb, r, tbld(rR, oB[r]));
             }
+            if (!A6) partial += 0.5 * (Zi.x * Wz.x + Zi.y * Wz.y + Zi.z * Wz.z + Zi.w * Wz.w);
         } else if constexpr (NCL > 0 && !A6) {
             auto nck = [](int kt) { return kt < NT - 1 ? 4 : NCL; };
             auto comp = [](const d4 &v, int r) { return r == 0 ? v.x : r == 1 ? v.y : r == 2 ? v.z : v.w; };
@@ -1855,9 +1863,10 @@ static hipError_t launch_ft3(Ctx *c, double *U_alpha_dev)
 template <int NT, bool A6>
 static hipError_t launch_ft2(Ctx *c, double *U_alpha_dev)
 {
-    // materialised tiles, two row tiles: the interleaved chains, per chunk count of the last row tile (pushing 3.52 -> 3.41 ms, walker
-    // 3.40 -> 3.19; with three tiles the same code is SLOWER, 4.98 -> 5.56 ms on light clutter n=38, so it stays with two)
-    if constexpr ((!A6 && NT == 2) || (A6 && NT == 4)) {
+    // compile-time chunk count of the last row tile: two row tiles materialised -- the interleaved chains with two register sets (pushing
+    // 3.52 -> 3.41 ms, walker 3.40 -> 3.19; with three tiles that code was SLOWER, 4.98 -> 5.56 ms on light clutter n=38); everything
+    // else -- the requests one by one under the products (round 5: light clutter 5.04 -> 4.61, configs[4] 12.5 -> 9.15 ms)
+    if constexpr (KP_FT_SPREAD || (!A6 && NT == 2)) {
         const int rows = c->n + 2 - 16 * (NT - 1), ncl = rows >= 16 ? 4 : (rows + 3) / 4;
         if (c->tune.tiled_uw != 0) switch (ncl > 1 ? ncl : 1) {
         case 1: return launch_ft3<NT, A6, 1>(c, U_alpha_dev);
