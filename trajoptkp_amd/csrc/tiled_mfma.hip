@@ -15,6 +15,9 @@
 #include <cstdlib>
 #include <type_traits>
 #include "mfma_common.h"
+#ifndef KP_SC_SPREAD
+#define KP_SC_SPREAD 1              // 0: the state / cost forward sweep's requests as blocks behind the products: A/B builds
+#endif
 #ifndef KP_UW_SPREAD
 #define KP_UW_SPREAD 1              // 0: the u-wave kernel's requests as blocks behind the products: A/B builds
 #endif
@@ -1680,8 +1683,36 @@ __device__ __forceinline__ void ft_state_role(double *zring, double *upart, doub
 #pragma unroll
         for (int k = 0; k < NT - 1; k++) Zk[k] = lds_tile(zc + k * TILE, lane);
         Zk[NT - 1] = lds_tile_n<NCL>(zc + (NT - 1) * TILE, lane);
-        lds_store_n<NCU>(upart + wi * TILE, lane, Pc<NCW>(Yk, Zi, zero));      // this wave's slice of K dx + alpha k (rows < num_ctrl)
         d4 Zn = zero;
+        if constexpr (KP_SC_SPREAD) {
+            // the next step's gain rows and A tiles, register by register behind the product that read the register (round 5, late:
+            // the waves of a trajectory share one address unit, and a block of thirteen requests stood in front of the barrier)
+            auto comp = [](const d4 &v, int r) { return r == 0 ? v.x : r == 1 ? v.y : r == 2 ? v.z : v.w; };
+            const int soA = tn1 * recB;
+            d4 Us = zero;
+#pragma unroll
+            for (int r = 0; r < NCW; r++) {
+                Us = MFMA(comp(Yk, r), comp(Zi, r), Us);
+                setc(cur.Ykw, r, tblds(rKt, oKw[r], sK));
+                __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+                __builtin_amdgcn_sched_group_barrier(0x020, 1, 0);
+            }
+            cur.kk = tblds(rkt, okn, sk);
+            lds_store_n<NCU>(upart + wi * TILE, lane, Us);
+#pragma unroll
+            for (int k = 0; k < NT; k++) {
+                d4 Ya = cur.Ya[k];
+                if (k == tnz) { Ya.x += oneT[0]; Ya.y += oneT[1]; Ya.z += oneT[2]; Ya.w += oneT[3]; }
+#pragma unroll
+                for (int r = 0; r < (k < NT - 1 ? 4 : NCL); r++) {
+                    Zn = MFMA(comp(Ya, r), comp(Zk[k], r), Zn);
+                    setc(cur.Ya[k], r, tblds(rRec, oA[k][r], soA));
+                    __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+                    __builtin_amdgcn_sched_group_barrier(0x020, 1, 0);
+                }
+            }
+        } else {
+        lds_store_n<NCU>(upart + wi * TILE, lane, Pc<NCW>(Yk, Zi, zero));      // this wave's slice of K dx + alpha k (rows < num_ctrl)
 #pragma unroll
         for (int k = 0; k < NT; k++) {
             d4 Ya = cur.Ya[k];
@@ -1692,6 +1723,7 @@ __device__ __forceinline__ void ft_state_role(double *zring, double *upart, doub
         cur.Ykw = ld4ns<NCW>(rKt, oKw, sK); cur.kk = tblds(rkt, okn, sk);
         request_A(t + 1);
         __builtin_amdgcn_sched_barrier(0);
+        }
         __syncthreads();
         // ---- control law + clamp (every state wave; :876-890) ----------------------------------------------------------
         const d4 ub = cur.ub;
@@ -1809,17 +1841,39 @@ k_forward_tiled_sc(RecLayout L, int T, int n_alpha, const double *__restrict__ r
             Zk[NT - 1] = lds_tile_n<NCL>(zc + (NT - 1) * TILE, lane);
             const d4 dU = lds_tile_n<NCU>(dubuf + (t & 1) * TILE, lane);
             d4 Wz = zero;
+            d4 Wu = zero;
+            const d4 lu = cur.lu;
+            if constexpr (KP_SC_SPREAD) {
+                auto comp = [](const d4 &v, int r) { return r == 0 ? v.x : r == 1 ? v.y : r == 2 ? v.z : v.w; };
+#pragma unroll
+                for (int k = 0; k < NT; k++)
+#pragma unroll
+                    for (int r = 0; r < (k < NT - 1 ? 4 : NCL); r++) {
+                        Wz = MFMA(comp(cur.Lc[k], r), comp(Zk[k], r), Wz);
+                        setc(cur.Lc[k], r, tblds(rRec, oLc[k][r], so));
+                        __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+                        __builtin_amdgcn_sched_group_barrier(0x020, 1, 0);
+                    }
+#pragma unroll
+                for (int r = 0; r < NCU; r++) {
+                    Wu = MFMA(comp(cur.Luu, r), comp(dU, r), Wu);
+                    setc(cur.Luu, r, tblds(rRec, oLuu[r], so));
+                    setc(cur.lu, r, tblds(rRec, olu[r], so));
+                    __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+                    __builtin_amdgcn_sched_group_barrier(0x020, 2, 0);
+                }
+            } else {
 #pragma unroll
             for (int k = 0; k < NT - 1; k++) Wz = Pc<4>(cur.Lc[k], Zk[k], Wz);
             Wz = Pc<NCL>(cur.Lc[NT - 1], Zk[NT - 1], Wz);
-            const d4 Wu = Pc<NCU>(cur.Luu, dU, zero);                        // (l_uu, l_u: the last cost wave's; zeros elsewhere)
+            Wu = Pc<NCU>(cur.Luu, dU, zero);                                 // (l_uu, l_u: the last cost wave's; zeros elsewhere)
             __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
             for (int k = 0; k < NT - 1; k++) cur.Lc[k] = ld4ns<4>(rRec, oLc[k], so);
             cur.Lc[NT - 1] = ld4ns<NCL>(rRec, oLc[NT - 1], so);
-            const d4 lu = cur.lu;
             cur.Luu = ld4ns<NCU>(rRec, oLuu, so); cur.lu = ld4ns<NCU>(rRec, olu, so);
             __builtin_amdgcn_sched_barrier(0);
+            }
             d4 Zi = Zk[0];                                                   // this wave's own row tile (wi is wave-uniform)
 #pragma unroll
             for (int k = 1; k < NT; k++) if (wi == k) Zi = Zk[k];
