@@ -22,6 +22,10 @@
 #include <cstdlib>
 #include "mfma_common.h"
 
+#ifndef KP_WIDE_SPREAD
+#define KP_WIDE_SPREAD 1            // 0: the wide-control sweeps' requests as one block per step: A/B builds
+#endif
+
 namespace kpilqr {
 
 typedef unsigned int u32x2w __attribute__((ext_vector_type(2)));
@@ -281,7 +285,10 @@ k_backward_tiled_wide(RecLayout L, int T, const double *__restrict__ rec, const 
 #pragma unroll
         for (int s_ = 0; s_ < (MT * MT + NT - 1) / NT; s_++) cLuu[s_] = pLuu[s_];
         __builtin_amdgcn_sched_barrier(0);
-        load_src(more ? rsrc_of(t - 1) : rnone);                       // single-buffered: requested right behind their last use
+        // (round 5, late: the ~50 requests of a step go out in groups behind the product groups of phase BC instead of as one block
+        // in front of this barrier -- the waves of a trajectory share one address unit)
+        const __amdgpu_buffer_rsrc_t rn = more ? rsrc_of(t - 1) : rnone;
+        if constexpr (!KP_WIDE_SPREAD) load_src(rn);                   // single-buffered: requested right behind their last use
         __builtin_amdgcn_sched_barrier(0);
         __syncthreads();
         // ---- BC: Tz(:,w), Tu(w,:), Quz(:,w), Qzz(:,w) ---------------------------------------------------------------------
@@ -294,6 +301,7 @@ k_backward_tiled_wide(RecLayout L, int T, const double *__restrict__ rec, const 
 #pragma unroll
             for (int k = 0; k < NT; k++) acc = WPn(wlds(bufV + (k * NT + i) * WTILE, lane), Fc[k], acc, k < NT - 1 ? 4 : ncl);
             Tz[i] = acc;
+            if constexpr (KP_WIDE_SPREAD) { pF[i] = wld_Fz(rn, S, i, w, q, c); pL[i] = wld_Lzz(rn, S, i, w, q, c); }
         }
 #pragma unroll
         for (int j = 0; j < MT; j++) {
@@ -301,6 +309,7 @@ k_backward_tiled_wide(RecLayout L, int T, const double *__restrict__ rec, const 
 #pragma unroll
             for (int k = 0; k < NT; k++) Tu = WPn(wlds(bufV + (k * NT + w) * WTILE, lane), wlds(bufFu + (k * MT + j) * WTILE, lane), Tu, k < NT - 1 ? 4 : ncl);
             wsts(bufTu + (w * MT + j) * WTILE, lane, Tu);
+            if constexpr (KP_WIDE_SPREAD) { pFu[j] = wld_Fu(rn, S, w, j, q, c); pLuz[j] = wld_Luz(rn, S, j, w, q, c); }
         }
         d4 Quzw[MT];
 #pragma unroll
@@ -309,6 +318,13 @@ k_backward_tiled_wide(RecLayout L, int T, const double *__restrict__ rec, const 
 #pragma unroll
             for (int k = 0; k < NT; k++) acc = WPn(wlds(bufFu + (k * MT + j) * WTILE, lane), Tz[k], acc, k < NT - 1 ? 4 : ncl);
             Quzw[j] = acc;
+        }
+        if constexpr (KP_WIDE_SPREAD) {
+#pragma unroll
+            for (int s_ = 0; s_ < (MT * MT + NT - 1) / NT; s_++) {
+                const int tq = w + s_ * NT;
+                pLuu[s_] = (tq < MT * MT) ? wld_Luu(rn, S, tq / MT, tq % MT, q, c) : zero;
+            }
         }
         d4 Qzz[NT];
 #pragma unroll
@@ -593,12 +609,24 @@ k_forward_tiled_wide(RecLayout L, int T, int n_alpha, const double *__restrict__
         return __builtin_amdgcn_make_buffer_rsrc((void *)(base + ((size_t)b * T + (ok ? t : 0)) * step_elems), 0, ok ? bytes : 0, 0x00020000);
     };
     Tiles cur;
+    // Requests (round 5, late; as in tiled_mfma.hip's k_forward_tiled): every group of tiles is re-requested for step t+1 right behind
+    // the products that read it instead of in one block of ~90 requests at the end of the step (the waves of a trajectory share one
+    // address unit), k rides in ONE request per control tile (the lanes of row n) and joins the gain operand at its use -- summed
+    // behind the request it made every step wait for the request -- and l_uu, l_u are requested by the wave that scores the controls.
+    const bool k_here = tnz == wi;
+    int okn[MT];
+    double kmask[4], kv[MT];
+#pragma unroll
+    for (int j = 0; j < MT; j++) { okn[j] = (k_here && q == (n & 3) && 16 * j + c < m) ? 8 * (16 * j + c) : OOBW; kv[j] = 0.0; }
+#pragma unroll
+    for (int r = 0; r < 4; r++) kmask[r] = (r == ((n & 15) >> 2)) ? 1.0 : 0.0;
     auto load_all = [&](int t) {
         const __amdgpu_buffer_rsrc_t rR = rs_of(rec, L.stride, t, rec_bytes), rK = rs_of(Kin, (size_t)m * n, t, m * n * 8);
         const __amdgpu_buffer_rsrc_t rk = rs_of(kin, m, t, m * 8), ru = rs_of(u_nom, m, t, m * 8);
 #pragma unroll
         for (int j = 0; j < MT; j++) {
-            cur.Ykw[j] = ld4(rK, oKw[j]) + ld4(rk, okw[j]);
+            if constexpr (KP_WIDE_SPREAD) { cur.Ykw[j] = ld4(rK, oKw[j]); kv[j] = wbld(rk, okn[j]); }
+            else cur.Ykw[j] = ld4(rK, oKw[j]) + ld4(rk, okw[j]);
             cur.Yb[j] = ld4(rR, oB[j]); cur.lu[j] = ld4(rR, olu[j]); cur.ub[j] = ld4(ru, oub[j]);
 #pragma unroll
             for (int j2 = 0; j2 < MT; j2++) cur.Luu[j][j2] = ld4(rR, oLuu[j][j2]);
@@ -612,9 +640,20 @@ k_forward_tiled_wide(RecLayout L, int T, int n_alpha, const double *__restrict__
     for (int t = 0; t < T; t++) {
         const double *zc = zbuf[t & 1];
         double *zn = zbuf[(t + 1) & 1];
+        const __amdgpu_buffer_rsrc_t rRn = rs_of(rec, L.stride, t + 1, rec_bytes), rKn = rs_of(Kin, (size_t)m * n, t + 1, m * n * 8);
+        const __amdgpu_buffer_rsrc_t rkn = rs_of(kin, m, t + 1, m * 8), run = rs_of(u_nom, m, t + 1, m * 8);
         // ---- this wave's slice of K dx + alpha k, both control tiles ---------------------------------------------------------
 #pragma unroll
-        for (int j = 0; j < MT; j++) wsts(upart + (wi * MT + j) * WTILE, lane, WPn(cur.Ykw[j], Zi, zero, ncw));
+        for (int j = 0; j < MT; j++) {
+            if constexpr (KP_WIDE_SPREAD) {
+                d4 Yk = cur.Ykw[j];
+                Yk.x = __builtin_fma(kmask[0], kv[j], Yk.x); Yk.y = __builtin_fma(kmask[1], kv[j], Yk.y);
+                Yk.z = __builtin_fma(kmask[2], kv[j], Yk.z); Yk.w = __builtin_fma(kmask[3], kv[j], Yk.w);
+                wsts(upart + (wi * MT + j) * WTILE, lane, WPn(Yk, Zi, zero, ncw));
+                cur.Ykw[j] = ld4(rKn, oKw[j]); kv[j] = wbld(rkn, okn[j]);
+            } else
+            wsts(upart + (wi * MT + j) * WTILE, lane, WPn(cur.Ykw[j], Zi, zero, ncw));
+        }
         __syncthreads();
         // ---- control law + clamp (every wave; :876-890) ----------------------------------------------------------------------
         d4 U[MT], dU[MT];
@@ -632,6 +671,7 @@ k_forward_tiled_wide(RecLayout L, int T, int n_alpha, const double *__restrict__
             v = u.z; if (v > hi[j][2]) v = hi[j][2]; if (v < lo[j][2]) v = lo[j][2]; u.z = v;
             v = u.w; if (v > hi[j][3]) v = hi[j][3]; if (v < lo[j][3]) v = lo[j][3]; u.w = v;
             U[j] = u; dU[j] = u - cur.ub[j];
+            if constexpr (KP_WIDE_SPREAD) cur.ub[j] = ld4(run, oub[j]);
         }
         if (wi == NT - 1) {                        // control cost and U_alpha by the LAST wave (its row tile is the shortest)
             if (U_alpha && c < n_alpha) {
@@ -651,23 +691,40 @@ k_forward_tiled_wide(RecLayout L, int T, int n_alpha, const double *__restrict__
                 partial += dU[j].x * (0.5 * Wu.x + cur.lu[j].x) + dU[j].y * (0.5 * Wu.y + cur.lu[j].y)
                          + dU[j].z * (0.5 * Wu.z + cur.lu[j].z) + dU[j].w * (0.5 * Wu.w + cur.lu[j].w);
             }
+            if constexpr (KP_WIDE_SPREAD) {
+#pragma unroll
+                for (int j = 0; j < MT; j++) {
+                    cur.lu[j] = ld4(rRn, olu[j]);
+#pragma unroll
+                    for (int j2 = 0; j2 < MT; j2++) cur.Luu[j][j2] = ld4(rRn, oLuu[j][j2]);
+                }
+            }
         }
         // ---- state cost rows of this tile, then the linearised dynamics for this tile ----------------------------------------------
         d4 Wz = zero, Zn = zero;
 #pragma unroll
-        for (int k = 0; k < NT; k++) Wz = WPn(cur.Lc[k], Zk[k], Wz, k < NT - 1 ? 4 : ncl);
+        for (int k = 0; k < NT; k++) {
+            Wz = WPn(cur.Lc[k], Zk[k], Wz, k < NT - 1 ? 4 : ncl);
+            if constexpr (KP_WIDE_SPREAD) cur.Lc[k] = ld4(rRn, oLc[k]);
+        }
         partial += 0.5 * (Zi.x * Wz.x + Zi.y * Wz.y + Zi.z * Wz.z + Zi.w * Wz.w);
 #pragma unroll
         for (int k = 0; k < NT; k++) {
             d4 Ya = cur.Ya[k];
             if (k == tnz) { Ya.x += oneT[0]; Ya.y += oneT[1]; Ya.z += oneT[2]; Ya.w += oneT[3]; }
             Zn = WPn(Ya, Zk[k], Zn, k < NT - 1 ? 4 : ncl);
+            if constexpr (KP_WIDE_SPREAD) cur.Ya[k] = ld4(rRn, oA[k]);
         }
 #pragma unroll
-        for (int j = 0; j < MT; j++) Zn = WPn(cur.Yb[j], dU[j], Zn, mch(j));
+        for (int j = 0; j < MT; j++) {
+            Zn = WPn(cur.Yb[j], dU[j], Zn, mch(j));
+            if constexpr (KP_WIDE_SPREAD) cur.Yb[j] = ld4(rRn, oB[j]);
+        }
+        if constexpr (!KP_WIDE_SPREAD) {
         __builtin_amdgcn_sched_barrier(0);
         load_all(t + 1);                           // single-buffered: everything of step t has been consumed
         __builtin_amdgcn_sched_barrier(0);
+        }
         Zi = Zn;
         wsts(zn + wi * WTILE, lane, Zn);
         __syncthreads();
