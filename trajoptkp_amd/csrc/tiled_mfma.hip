@@ -1251,7 +1251,7 @@ k_forward_tiled(RecLayout L, CostSrc CS, int T, int n_alpha, const double *__res
     const d4 zero = {0.0, 0.0, 0.0, 0.0};
     double partial = 0.0;
 
-    struct Tiles { d4 Ykw, Ya[NT], Lc[NT], Yb, Luu, lu, ub; };        // A6: Lc[0] = RxT (own slice), Luu = RuT, lu = r
+    struct Tiles { d4 Ykw, Ya[NT], Lc[NT], Yb, Luu, lu, ub; double kv; };        // A6: Lc[0] = RxT (own slice), Luu = RuT, lu = r; kv: k' (FSPREAD)
     const int rec_bytes = L.rec * 8; (void)rec_bytes;
     auto ld4 = [&](__amdgpu_buffer_rsrc_t rs, const int *off) -> d4 {
         d4 v; v.x = tbld(rs, off[0]); v.y = tbld(rs, off[1]); v.z = tbld(rs, off[2]); v.w = tbld(rs, off[3]);
@@ -1284,15 +1284,15 @@ k_forward_tiled(RecLayout L, CostSrc CS, int T, int n_alpha, const double *__res
     double kmask[4];
 #pragma unroll
     for (int r = 0; r < 4; r++) kmask[r] = (r == ((n & 15) >> 2)) ? 1.0 : 0.0;
-    double kv = 0.0;
-    (void)okn; (void)kmask; (void)kv;
+    (void)okn; (void)kmask;
     Tiles S[NS];
 #pragma unroll
     for (int s0 = 0; s0 < NS; s0++) {
         Tiles &cur = S[s0];
         __amdgpu_buffer_rsrc_t rR = rs_of(rec, L.stride, s0, rec_bytes), rK = rs_of(Kin, (size_t)m * n, s0, m * n * 8);
         __amdgpu_buffer_rsrc_t rk = rs_of(kin, m, s0, m * 8), ru = rs_of(u_nom, m, s0, m * 8);
-        if constexpr (FSPREAD) { cur.Ykw = ld4(rK, oKw); kv = tbld(rk, okn); }
+        cur.kv = 0.0;
+        if constexpr (FSPREAD) { cur.Ykw = ld4(rK, oKw); cur.kv = tbld(rk, okn); }
         else cur.Ykw = ld4(rK, oKw) + ld4(rk, okw);
 #pragma unroll
         for (int k = 0; k < NT; k++) { cur.Ya[k] = ld4(rR, oA[k]); if (!A6) cur.Lc[k] = ld4(rR, oLc[k]); }
@@ -1324,6 +1324,7 @@ k_forward_tiled(RecLayout L, CostSrc CS, int T, int n_alpha, const double *__res
             auto comp = [](const d4 &v, int r) { return r == 0 ? v.x : r == 1 ? v.y : r == 2 ? v.z : v.w; };
             const __amdgpu_buffer_rsrc_t rX = rs_res(rxb, (size_t)nr * n, tq, nr * n * 8);
             d4 Yk = cur.Ykw;                                  // K' rows of this wave's slice; + k' in row n
+            const double kv = cur.kv;
             Yk.x = __builtin_fma(kmask[0], kv, Yk.x); Yk.y = __builtin_fma(kmask[1], kv, Yk.y);
             Yk.z = __builtin_fma(kmask[2], kv, Yk.z); Yk.w = __builtin_fma(kmask[3], kv, Yk.w);
             d4 Us = zero, Js = zero;
@@ -1338,7 +1339,7 @@ k_forward_tiled(RecLayout L, CostSrc CS, int T, int n_alpha, const double *__res
                 setc(cur.Ykw, r, tbld(rK, oKw[r]));
                 if (A6) setc(cur.Lc[0], r, tbld(rX, oRxT[r]));
             }
-            kv = tbld(rk, okn);
+            cur.kv = tbld(rk, okn);
             lds_store(upart + wi * TILE, lane, Us);
             if (A6) lds_store(jpart + wi * TILE, lane, Js);
         } else {
