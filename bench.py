@@ -643,7 +643,8 @@ def parity_check(p0, eng, n_check, tiled=False):
     if reps > 1:        # every replica of a seed must carry its seed's bytes
         Kr = K.reshape(reps, uniq, -1)
         out["replicas_bit_identical"] = bool(np.array_equal(Kr, np.broadcast_to(Kr[0], Kr.shape)))
-    out["pass"] = bool(out["max_rel_err_K"] < 1e-6 and out["max_rel_err_k"] < 1e-6 and not out.get("status_mismatch", False)
+    out["pass"] = bool(out["max_rel_err_K"] < 1e-6 and out["max_rel_err_k"] < 1e-6 and out["max_rel_err_cost_pred"] < 1e-6
+                       and out["max_rel_err_delta_J"] < 1e-6 and not out.get("status_mismatch", False)
                        and out.get("replicas_bit_identical", True))
     return out
 
