@@ -15,6 +15,9 @@
 #include <cstdlib>
 #include <type_traits>
 #include "mfma_common.h"
+#ifndef KP_COL_STAGE_D
+#define KP_COL_STAGE_D 1            // 0: the column kernel stages Fz, Fu at the top of the step: A/B builds
+#endif
 #ifndef KP_SC_SPREAD
 #define KP_SC_SPREAD 1              // 0: the state / cost forward sweep's requests as blocks behind the products: A/B builds
 #endif
@@ -227,6 +230,7 @@ k_backward_tiled_col(RecLayout L, CostSrc CS, int T, const double *__restrict__ 
     // waves of a trajectory share one address unit)
     constexpr bool SPREAD = KP_COL_SPREAD && NCL > 0;
     static_assert(!SPREAD || NT == 4, "the spread requests deal Fu over the NT row tiles: four registers");
+    constexpr bool STAGE_D = SPREAD && KP_COL_STAGE_D;
     // M = 8 is the catch-all instantiation for any num_ctrl <= 8 (walker 6, hopper / pentabot 3, ...): the m x m system is
     // padded with identity rows to 8 x 8 for the (rare) per-lane LDL' steps; everything else works on tiles anyway.
     constexpr bool PAD = (M == 8);
@@ -392,6 +396,19 @@ k_backward_tiled_col(RecLayout L, CostSrc CS, int T, const double *__restrict__ 
 #else
 #define CYK(i)
 #endif
+    // the step's tiles into LDS.  STAGE_D (with the spread requests): Fz(:,w), Fu(w) of step t-1 are staged in phase D of step t -- bufF
+    // and bufFu are free behind the barrier that ends BC, the tiles were requested under BC's first half, and the writes drain
+    // under phase D's per-lane factorisation instead of standing (540 cycles) in front of the step's first barrier (drawn residual
+    // Jacobians 36.5 -> 35.9 ms on configs[4]; nothing where the refresh applies)
+    auto stage = [&]() {
+#pragma unroll
+        for (int k = 0; k < NT; k++) lds_store(bufF + (k * NT + w) * TILE, lane, pF[k]);
+        // Fz(n,n) = 1: the loaded element is a structural zero, ONE lane of the wave that owns column n overwrites it (round 5: the
+        // add-and-select over every tile of the column was 80 VALU instructions per step)
+        if (w == tn && lane_nn) bufF[(tn * NT + w) * TILE + reg_nn * 64 + lane] = 1.0;
+        lds_store(bufFu + w * TILE, lane, pFu);
+    };
+    if constexpr (STAGE_D) stage();
     for (int t = T - 1; t >= 0; t--) {
         pd_counter++;
         const bool check_pd = pd_counter >= pd_stride;
@@ -399,12 +416,7 @@ k_backward_tiled_col(RecLayout L, CostSrc CS, int T, const double *__restrict__ 
         __amdgpu_buffer_rsrc_t rn = more ? rsrc_of(t - 1) : __builtin_amdgcn_make_buffer_rsrc((void *)R0, 0, 0, 0x00020000);
         // ---- A: stage Fz(:,w) (+ the homogeneous 1) and Fu(w) ----------------------------------------------
         CYK(10)
-#pragma unroll
-        for (int k = 0; k < NT; k++) lds_store(bufF + (k * NT + w) * TILE, lane, pF[k]);
-        // Fz(n,n) = 1: the loaded element is a structural zero, ONE lane of the wave that owns column n overwrites it (round 5: the
-        // add-and-select over every tile of the column was 80 VALU instructions per step)
-        if (w == tn && lane_nn) bufF[(tn * NT + w) * TILE + reg_nn * 64 + lane] = 1.0;
-        lds_store(bufFu + w * TILE, lane, pFu);
+        if constexpr (!STAGE_D) stage();
         __builtin_amdgcn_sched_barrier(0);
         CYK(9)
         if constexpr (!SPREAD) {
@@ -517,8 +529,12 @@ k_backward_tiled_col(RecLayout L, CostSrc CS, int T, const double *__restrict__ 
         CYK(3)
         // ---- D: Quu, LDL' (every wave: keeps the PD verdict block-uniform), solve / K / G for column tile w ----
         d4 Quu = A6 ? zero : Luu_t;
+        d4 Qp_[NT];
 #pragma unroll
-        for (int k = 0; k < NT; k++) Quu = Quu + lds_tile(bufQp + k * TILE, lane);
+        for (int k = 0; k < NT; k++) Qp_[k] = lds_tile(bufQp + k * TILE, lane);
+        if constexpr (STAGE_D) stage();
+#pragma unroll
+        for (int k = 0; k < NT; k++) Quu = Quu + Qp_[k];
         d4 Qr = Quu;
         Qr.x += 0.5 * lam2d[0]; Qr.y += 0.5 * lam2d[1]; Qr.z += 0.5 * lam2d[2]; Qr.w += 0.5 * lam2d[3];
         // X(w) = (Quu + lambda I)^-1 Quz(w).  Fast path as in riccati_mfma.hip: every wave keeps the running inverse
