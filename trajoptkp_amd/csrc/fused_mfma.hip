@@ -85,6 +85,9 @@ typedef unsigned long long u64;
 #ifndef KP_FWD_SQW
 #define KP_FWD_SQW 1                // 0: the headline's forward sweep scores on the unscaled r_x dx (round 4; A/B builds)
 #endif
+#ifndef KP_FWD_RV2
+#define KP_FWD_RV2 1                // 0: the headline forward sweep fetches r_t with four 8-byte requests (rows in their natural order): A/B builds
+#endif
 #ifndef KP_RXC_CXX
 #define KP_RXC_CXX 1                // 0: the RXC sweeps form Lzz = Rz' W Rz with four products at every step (round 4; A/B builds)
 #endif
@@ -122,6 +125,14 @@ __device__ __forceinline__ double fbld(__amdgpu_buffer_rsrc_t r, int byte_off)
 __device__ __forceinline__ double fblds(__amdgpu_buffer_rsrc_t r, int byte_off, int soff)
 {
     return __builtin_bit_cast(double, __builtin_amdgcn_raw_buffer_load_b64(r, byte_off, soff, 0));
+}
+// two consecutive doubles with one request (16-byte aligned)
+typedef unsigned int u32x4f __attribute__((ext_vector_type(4)));
+__device__ __forceinline__ void fbld2s(__amdgpu_buffer_rsrc_t r, int byte_off, int soff, double &a, double &b)
+{
+    const u32x4f v = __builtin_amdgcn_raw_buffer_load_b128(r, byte_off, soff, 0);
+    const u32x2f lo = {v.x, v.y}, hi = {v.z, v.w};
+    a = __builtin_bit_cast(double, lo); b = __builtin_bit_cast(double, hi);
 }
 __device__ __forceinline__ __amdgpu_buffer_rsrc_t frsrc(const void *p, int bytes)
 {
@@ -1503,6 +1514,16 @@ __device__ __forceinline__ void forward_fused_body(RecLayout L, FusedArgs F, int
     if (!UNI) col_offsets(co, n, m, F.dof, c, q);
     int oK[4], oRxT[4], oRuT[4], oR[4], oub[4];
     double lo[NCU], hi[NCU], wcur[4];
+    // RV2 (with SQW: constant r_x, no control residuals, uniform key-point sets): the residuals sit in the rows of Jx in the order
+    //     row 4r + q  <->  residual sig(4r + q) = 8 (r >> 1) + 2 q + (r & 1)
+    // so that registers (0, 1) and (2, 3) of a lane are CONSECUTIVE residuals and r_t arrives with two 16-byte requests instead of four
+    // 8-byte ones (a request costs this sweep ~24 cycles of its 1 330-cycle step whatever it carries: timing probe in
+    // profiles/r05_headline_ab.txt).  The order is a relabelling of the rows of the resident r_x tile and of the per-row constants.
+    constexpr bool RV2 = KP_FWD_RV2 && KP_FWD_SQW && RXC && RU0 && UNI;
+    auto sig = [](int i) { return RV2 ? 8 * (i >> 3) + 2 * (i & 3) + ((i >> 2) & 1) : i; };
+    const int cs = sig(c);                                                  // the residual in column c of the RxT operand
+    const int oR2[2] = {(2 * q < nr) ? 16 * q : OOBF, (8 + 2 * q < nr) ? 64 + 16 * q : OOBF};
+    (void)oR2;
 #pragma unroll
     for (int r = 0; r < 4; r++) {
         const int row = 4 * r + q;
@@ -1514,7 +1535,7 @@ __device__ __forceinline__ void forward_fused_body(RecLayout L, FusedArgs F, int
             co.b[r] = (row < m && c < n) ? 8 * ((row * KpU * 3 + 2) * n + c) : BIGOFF;
         }
         oK[r] = (row < n && c < m) ? 8 * (row * m + c) : OOBF;
-        oRxT[r] = (row < n && c < nr) ? 8 * (c * n + row) : OOBF;     // RxT(p=row, k=c) = r_x[k][p]
+        oRxT[r] = (row < n && cs < nr) ? 8 * (cs * n + row) : OOBF;   // RxT(p=row, k=c) = r_x[k][p]   (RV2: residual sig(c) in column c)
         oRuT[r] = (row < m && c < nr) ? 8 * (c * m + row) : OOBF;     // RuT(p=row, k=c) = r_u[k][p]
         oR[r] = (row < nr) ? 8 * row : OOBF;                          // r[k=row] (rows of Jx / Ju)
         oub[r] = (row < m) ? 8 * row : OOBF;
@@ -1560,7 +1581,16 @@ __device__ __forceinline__ void forward_fused_body(RecLayout L, FusedArgs F, int
             s.RuT.x = fbld(rRu, oRuT[0]); s.RuT.y = NCU > 1 ? fbld(rRu, oRuT[1]) : 0.0;
             s.RuT.z = NCU > 2 ? fbld(rRu, oRuT[2]) : 0.0; s.RuT.w = NCU > 3 ? fbld(rRu, oRuT[3]) : 0.0;
         }
+        if constexpr (RV2) {
+            // (descriptor one element longer: the last pair of an odd residual count reaches into the next step's row -- the array has
+            // T + 1 rows, the weights beyond nr are zero)
+            __amdgpu_buffer_rsrc_t rR2 = frsrc(rb + (size_t)t * nr, nr * 8 + 8);
+            double r0, r1, r2, r3;
+            fbld2s(rR2, oR2[0], 0, r0, r1); fbld2s(rR2, oR2[1], 0, r2, r3);
+            s.rv.x = r0; s.rv.y = r1; s.rv.z = r2; s.rv.w = r3;
+        } else {
         s.rv.x = fbld(rR, oR[0]); s.rv.y = fbld(rR, oR[1]); s.rv.z = fbld(rR, oR[2]); s.rv.w = fbld(rR, oR[3]);
+        }
         s.ub.x = fbld(ru, oub[0]); s.ub.y = NCU > 1 ? fbld(ru, oub[1]) : 0.0;
         s.ub.z = NCU > 2 ? fbld(ru, oub[2]) : 0.0; s.ub.w = NCU > 3 ? fbld(ru, oub[3]) : 0.0;
     };
@@ -1627,12 +1657,13 @@ __device__ __forceinline__ void forward_fused_body(RecLayout L, FusedArgs F, int
         RxTc.x = fbld(rRxc, oRxT[0]); RxTc.y = fbld(rRxc, oRxT[1]); RxTc.z = fbld(rRxc, oRxT[2]); RxTc.w = fbld(rRxc, oRxT[3]);
         if constexpr (SQW) {
             // lane (c, q) of the operand tile holds r_x[k = c][p = 4r + q]: column c is residual c
-            const double swr = (c < nr) ? __builtin_sqrt(fabs(F.w_run[c])) : 0.0, swt = (c < nr) ? __builtin_sqrt(fabs(F.w_term[c])) : 0.0;
+            const double swr = (cs < nr) ? __builtin_sqrt(fabs(F.w_run[cs])) : 0.0, swt = (cs < nr) ? __builtin_sqrt(fabs(F.w_term[cs])) : 0.0;
             RxTt = RxTc * swt;
             RxTc = RxTc * swr;
 #pragma unroll
             for (int r = 0; r < 4; r++) {           // the scoring side: residual k = 4r + q in register r
-                const double wr_ = (4 * r + q < nr) ? F.w_run[4 * r + q] : 0.0, wt_ = (4 * r + q < nr) ? F.w_term[4 * r + q] : 0.0;
+                const int kr = sig(4 * r + q);
+                const double wr_ = (kr < nr) ? F.w_run[kr] : 0.0, wt_ = (kr < nr) ? F.w_term[kr] : 0.0;
                 s2run[r] = 2.0 * __builtin_sqrt(fabs(wr_)); sgrun[r] = wr_ < 0.0 ? -1.0 : 1.0;
                 s2term[r] = 2.0 * __builtin_sqrt(fabs(wt_)); sgterm[r] = wt_ < 0.0 ? -1.0 : 1.0;
             }
@@ -1852,7 +1883,13 @@ __device__ __forceinline__ void forward_fused_body(RecLayout L, FusedArgs F, int
                      + wcur[2] * (Jx.z * (r2.z + Jx.z) + Ju.z * (r2.z + Ju.z))
                      + wcur[3] * (Jx.w * (r2.w + Jx.w) + Ju.w * (r2.w + Ju.w));
         __builtin_amdgcn_sched_barrier(0);
+        if constexpr (RV2) {
+            double r0, r1, r2, r3;
+            fbld2s(rR, oR2[0], sR, r0, r1); fbld2s(rR, oR2[1], sR, r2, r3);
+            cur.rv.x = r0; cur.rv.y = r1; cur.rv.z = r2; cur.rv.w = r3;
+        } else {
         cur.rv.x = fblds(rR, oR[0], sR); cur.rv.y = fblds(rR, oR[1], sR); cur.rv.z = fblds(rR, oR[2], sR); cur.rv.w = fblds(rR, oR[3], sR);
+        }
         __builtin_amdgcn_sched_barrier(0);
     };
     if constexpr (UNI) {
