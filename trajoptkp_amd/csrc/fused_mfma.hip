@@ -85,6 +85,9 @@ typedef unsigned long long u64;
 #ifndef KP_FWD_SQW
 #define KP_FWD_SQW 1                // 0: the headline's forward sweep scores on the unscaled r_x dx (round 4; A/B builds)
 #endif
+#ifndef KP_BWD_RV2
+#define KP_BWD_RV2 1                // 0: the headline backward sweep fetches r_t with four 8-byte requests: A/B builds
+#endif
 #ifndef KP_FWD_RV2
 #define KP_FWD_RV2 1                // 0: the headline forward sweep fetches r_t with four 8-byte requests (rows in their natural order): A/B builds
 #endif
@@ -373,22 +376,35 @@ __device__ __forceinline__ void backward_fused_body(double *sh, const double *pc
     const double lam = lambda[b];
     // (probe builds, -DKP_PROBE_BWD=bits: 1 residual loads, 2 key-point stores, 4 gain stores go to one of eight trajectories)
     const int bR = (KP_PROBE_BWD & 1) ? (int)(blockIdx.x & 7) : b, bP = (KP_PROBE_BWD & 2) ? (int)(blockIdx.x & 7) : b, bS = (KP_PROBE_BWD & 4) ? (int)(blockIdx.x & 7) : b;
-    const int nr = F.nr, ncr = (nr + 3) >> 2;
+    constexpr bool RV2B = KP_BWD_RV2 && KP_RXC_CXX && RXC && RU0 && !PC;     // (see below)
+    // 4-row chunks of the residual index that hold residuals (RV2B: registers 0, 1 hold residuals 0 .. 7, registers 2, 3 residuals 8 .. 15)
+    const int nr = F.nr, ncr = RV2B ? (nr > 9 ? 4 : nr > 8 ? 3 : nr > 1 ? 2 : 1) : (nr + 3) >> 2;
     constexpr int strideB = 3 * N * 8;                            // bytes of one key-point entry: three columns
 
     ColOffsN co;
     col_offsets_n<N>(co, m, F.dof, c, q);
     double w2run[4], w2term[4], lam2d[4];
     int oRx[4], oR1[4], oRu[4], oKst[4], okst[4];
+    // RV2B (the headline's one-wave sweep: constant r_x, no control residuals): the residuals sit in the rows of the Rz tiles in the order
+    //     row 4r + q  <->  residual 8 (r >> 1) + 2 q + (r & 1)
+    // -- registers (0, 1) and (2, 3) of a lane are consecutive residuals, so r_t arrives with two 16-byte requests instead of four
+    // 8-byte ones (see RV2 in forward_fused_body).  The rows are the contraction index of every product they enter (Cxx, r_x' W r, the
+    // terminal step's Rz' W Rz): a relabelling, with the weights relabelled alike.
+    const int oR12[2] = {(2 * q < nr) ? 16 * q : OOBF, (8 + 2 * q < nr) ? 64 + 16 * q : OOBF};
+    (void)oR12;
+#pragma unroll
+    for (int r = 0; r < 4; r++) {
+        const int kr = RV2B ? 8 * (r >> 1) + 2 * q + (r & 1) : 4 * r + q;     // the residual in row 4r + q
+        oRx[r] = (kr < nr && c < n) ? 8 * (kr * n + c) : OOBF;        // Rz(k, c) = r_x[k][c]
+        w2run[r] = (kr < nr) ? 2.0 * F.w_run[kr] : 0.0;
+        w2term[r] = (kr < nr) ? 2.0 * F.w_term[kr] : 0.0;
+    }
 #pragma unroll
     for (int r = 0; r < 4; r++) {
         const int row = 4 * r + q;
-        oRx[r] = (row < nr && c < n) ? 8 * (row * n + c) : OOBF;      // Rz(k=row, c) = r_x[k][c]
         // (RXC one-wave sweeps: r[k] in EVERY column -- the lanes of column c form their part of (r_x' W r)(c) from it, see CXX below)
         oR1[r] = (row < nr && (c == n || (KP_RXC_CXX && RXC && !PC))) ? 8 * row : OOBF;               //            ... | r[k] in column n
         oRu[r] = (row < nr && c < m) ? 8 * (row * m + c) : OOBF;      // Ru(k=row, c) = r_u[k][c]
-        w2run[r] = (row < nr) ? 2.0 * F.w_run[row] : 0.0;
-        w2term[r] = (row < nr) ? 2.0 * F.w_term[row] : 0.0;
         oKst[r] = (row < m && c < n) ? 8 * (row + c * m) : OOBF;
         okst[r] = (row < m && c == n) ? 8 * row : OOBF;
         lam2d[r] = (row == c && row < m) ? 2.0 * lam : 0.0;
@@ -412,6 +428,8 @@ __device__ __forceinline__ void backward_fused_body(double *sh, const double *pc
     const double *pRx = rxb + (size_t)(T - 1) * nr * n, *pR = rb + (size_t)(T - 1) * nr, *pRu = rub + (size_t)(T - 1) * nr * m;
     auto load_res = [&](int t, ResTiles &s) {
         __amdgpu_buffer_rsrc_t rR = frsrc(pR, nr * 8);
+        __amdgpu_buffer_rsrc_t rR2 = frsrc(pR, nr * 8 + 8);
+        (void)rR2;
         __amdgpu_buffer_rsrc_t rRu = frsrc(pRu, nr * m * 8);
         if constexpr (!RXC) {
             __amdgpu_buffer_rsrc_t rRx = frsrc(pRx, nr * n * 8);
@@ -419,7 +437,14 @@ __device__ __forceinline__ void backward_fused_body(double *sh, const double *pc
             if (t > 0) pRx -= nr * n;
         }
         if (t > 0) { pR -= nr; pRu -= nr * m; }       // (behind step 0: stay on it)
+        if constexpr (RV2B) {
+            // (descriptor one element longer: the last pair of an odd residual count reaches into the next row -- the array has T + 1)
+            double r0, r1, r2, r3;
+            fbld2s(rR2, oR12[0], 0, r0, r1); fbld2s(rR2, oR12[1], 0, r2, r3);
+            s.R1.x = r0; s.R1.y = r1; s.R1.z = r2; s.R1.w = r3;
+        } else {
         s.R1.x = fbld(rR, oR1[0]); s.R1.y = fbld(rR, oR1[1]); s.R1.z = fbld(rR, oR1[2]); s.R1.w = fbld(rR, oR1[3]);
+        }
         if constexpr (!RU0) { s.Ru.x = fbld(rRu, oRu[0]); s.Ru.y = fbld(rRu, oRu[1]); s.Ru.z = fbld(rRu, oRu[2]); s.Ru.w = fbld(rRu, oRu[3]); }
     };
 
