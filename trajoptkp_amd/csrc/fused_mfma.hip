@@ -1539,12 +1539,12 @@ __device__ __forceinline__ void forward_fused_body(RecLayout L, FusedArgs F, int
     if (!UNI) col_offsets(co, n, m, F.dof, c, q);
     int oK[4], oRxT[4], oRuT[4], oR[4], oub[4];
     double lo[NCU], hi[NCU], wcur[4];
-    // RV2 (with SQW: constant r_x, no control residuals, uniform key-point sets): the residuals sit in the rows of Jx in the order
+    // RV2 (uniform key-point sets): the residuals sit in the rows of Jx, Ju in the order
     //     row 4r + q  <->  residual sig(4r + q) = 8 (r >> 1) + 2 q + (r & 1)
     // so that registers (0, 1) and (2, 3) of a lane are CONSECUTIVE residuals and r_t arrives with two 16-byte requests instead of four
     // 8-byte ones (a request costs this sweep ~24 cycles of its 1 330-cycle step whatever it carries: timing probe in
     // profiles/r05_headline_ab.txt).  The order is a relabelling of the rows of the resident r_x tile and of the per-row constants.
-    constexpr bool RV2 = KP_FWD_RV2 && KP_FWD_SQW && RXC && RU0 && UNI;
+    constexpr bool RV2 = KP_FWD_RV2 && UNI;        // (the per-DoF list form measured 1.3 % SLOWER with it: 2.31 against 2.28 ms)
     auto sig = [](int i) { return RV2 ? 8 * (i >> 3) + 2 * (i & 3) + ((i >> 2) & 1) : i; };
     const int cs = sig(c);                                                  // the residual in column c of the RxT operand
     const int oR2[2] = {(2 * q < nr) ? 16 * q : OOBF, (8 + 2 * q < nr) ? 64 + 16 * q : OOBF};
@@ -1561,14 +1561,14 @@ __device__ __forceinline__ void forward_fused_body(RecLayout L, FusedArgs F, int
         }
         oK[r] = (row < n && c < m) ? 8 * (row * m + c) : OOBF;
         oRxT[r] = (row < n && cs < nr) ? 8 * (cs * n + row) : OOBF;   // RxT(p=row, k=c) = r_x[k][p]   (RV2: residual sig(c) in column c)
-        oRuT[r] = (row < m && c < nr) ? 8 * (c * m + row) : OOBF;     // RuT(p=row, k=c) = r_u[k][p]
-        oR[r] = (row < nr) ? 8 * row : OOBF;                          // r[k=row] (rows of Jx / Ju)
+        oRuT[r] = (row < m && cs < nr) ? 8 * (cs * m + row) : OOBF;   // RuT(p=row, k=c) = r_u[k][p]
+        oR[r] = (row < nr) ? 8 * row : OOBF;                          // r[k=row] (rows of Jx / Ju; RV2: oR2)
         oub[r] = (row < m) ? 8 * row : OOBF;
         if (r < NCU) {
             lo[r] = (row < m) ? ctrl_lim[2 * row] : -1.0e300;
             hi[r] = (row < m) ? ctrl_lim[2 * row + 1] : 1.0e300;
         }
-        wcur[r] = (row < nr) ? F.w_run[row] : 0.0;
+        wcur[r] = (sig(row) < nr) ? F.w_run[sig(row)] : 0.0;
     }
     constexpr int rn = n >> 2;                                              // the register of row n (k)
     const int okn = (q == (n & 3) && c < m) ? 8 * c : OOBF;
@@ -1882,7 +1882,7 @@ __device__ __forceinline__ void forward_fused_body(RecLayout L, FusedArgs F, int
         if constexpr (MODE == 0) {
             if (t == T - 1) {                     // terminal weights at the last step (Optimiser.cpp:209-211)
 #pragma unroll
-                for (int r = 0; r < 4; r++) wcur[r] = (4 * r + q < nr) ? F.w_term[4 * r + q] : 0.0;   // (hoisting these loads out of the loop measured 0.9 ms slower)
+                for (int r = 0; r < 4; r++) wcur[r] = (sig(4 * r + q) < nr) ? F.w_term[sig(4 * r + q)] : 0.0;   // (hoisting these loads out of the loop measured 0.9 ms slower)
             }
         } else if constexpr (MODE == 3) {
 #pragma unroll
@@ -1922,7 +1922,7 @@ __device__ __forceinline__ void forward_fused_body(RecLayout L, FusedArgs F, int
         // final step).  On entry of the loop: sv = column(k_0), ev = column(k_1), ev2 = column(k_2) in flight, av = slope of
         // segment 0, Y(0) = sv.  (The per-lane tracker above did the loads of sv and ev; it is not used any further.)
 #pragma unroll
-        for (int r = 0; r < 4; r++) wterm[r] = (4 * r + q < nr) ? F.w_term[4 * r + q] : 0.0;
+        for (int r = 0; r < 4; r++) wterm[r] = (sig(4 * r + q) < nr) ? F.w_term[sig(4 * r + q)] : 0.0;
         uks = __builtin_amdgcn_readfirstlane(F.kp_times[E0]);
         uke = __builtin_amdgcn_readfirstlane(F.kp_times[E0 + (KpU > 1 ? 1 : 0)]);
         {
