@@ -25,7 +25,7 @@
 #define KP_UW_SPREAD 1              // 0: the u-wave kernel's requests as blocks behind the products: A/B builds
 #endif
 #ifndef KP_FT_SPREAD
-#define KP_FT_SPREAD 1              // 0: the four-tile forward sweep's requests as blocks behind the products: A/B builds
+#define KP_FT_SPREAD 1              // 0: the one-group forward sweeps' requests as blocks behind the products (three / four tiles, every a6-inside form): A/B builds
 #endif
 #ifndef KP_COL_SPREAD
 #define KP_COL_SPREAD 1             // 0: the column kernel's requests as blocks (top of the step, behind the products): A/B builds
