@@ -289,7 +289,11 @@ int  kpilqr_filter_dynamics(kpilqr_ctx *ctx, const char *method, const double *c
  * w_run / w_term [nr] (struct residual, include/StdInclude.h:82-88).  Any pointer may be NULL to
  * keep what is already resident.  The buffers start zeroed: a task whose residuals do not depend on the controls
  * (r_u = 0: reaching, the pushing tasks) never passes r_u, and the fused sweeps then leave the control-residual
- * products out (l_uu = l_u = 0 exactly). */
+ * products out (l_uu = l_u = 0 exactly).
+ * All T+1 rows of r must hold finite numbers, the last one (t = T) included, as the reference's do (it evaluates the residuals
+ * at every t = 0..T, src/Optimiser/Optimiser.cpp:217-236): with an ODD residual count the one-tile sweeps fetch a row of r in
+ * 16-byte pairs, and the last pair of row t reaches one element into row t+1 -- under a zero weight, which keeps a finite
+ * number out of every result and would not keep a NaN out. */
 int  kpilqr_upload_residuals(kpilqr_ctx *ctx, const double *r, const double *r_x, const double *r_u,
                              const double *w_run, const double *w_term);
 /* CONSTANT residual Jacobians: one r_x [nr][n] (and one r_u [nr][m], or NULL for r_u = 0) that holds at every step of every

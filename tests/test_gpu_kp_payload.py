@@ -311,6 +311,28 @@ def test_constant_residual_jacobians_give_the_bytes_of_the_streamed_form(task, T
         assert relerr(ref["K"][b], o["K"]) < 1e-9 and relerr(ref["cost"][b], o["cost_pred"]) < 1e-9
 
 
+@pytest.mark.parametrize("task,T", [("acrobot", 100), ("pentabot", 64), ("panda_reaching", 131)])
+def test_residual_row_fetched_in_pairs_ignores_what_lies_behind_it(task, T, waves):
+    """Round 5: the one-wave sweeps on uniform key-point sets fetch r_t with two 16-byte requests (residual rows relabelled so that
+    a lane's registers hold consecutive residuals).  With an odd residual count (acrobot 5, pentabot 3) the last pair of row t
+    reaches one element into row t+1 -- under a zero weight: whatever finite number sits there (here 1e300 in the whole row t = T,
+    which no stage uses) changes no bit of any result."""
+    p = synth.make_problem(task=task, T=T, batch=3, min_N=4, config_id=1 if task == "acrobot" else 2)
+    assert p["rx_const"] is not None
+    q = dict(p); q["r"] = p["r"].copy(); q["r"][:, T, :] = 1.0e300
+    outs = []
+    for prob in (p, q):
+        with Engine(p["dof"], p["m"], T, p["nr"], batch=3, fused=True) as e:
+            synth.upload(e, prob, kp_ordered=True, rx_const=True)
+            e.iterate(p["lam"], 100, orc.alphas(6))
+            res = e.results(); K, k = e.gains()
+            outs.append(dict(K=K, k=k, delta_J=res["delta_J"], cost=res["cost_pred"]))
+    _same(outs[1], outs[0])
+    for b in range(3):
+        o = pipeline.run_trajectory(p, b)
+        assert relerr(outs[0]["K"][b], o["K"]) < 1e-9 and relerr(outs[0]["cost"][b], o["cost_pred"]) < 1e-9
+
+
 def test_constant_residual_jacobians_mode_switches():
     """Per-step Jacobians uploaded afterwards end the constant mode; a dense constant r_u, a materialising context and the
     chunk pipeline all see the broadcast values; kpilqr_device_ptr(R_X) hands out the broadcast copy."""
